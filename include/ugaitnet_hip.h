@@ -1,0 +1,122 @@
+/*
+ * ugaitnet_hip.h -- C ABI of libugaitnet_hip.so (gfx950 / MI355X).
+ *
+ * The reference (avagait/ugaitnet) has no FFI/plugin layer: every op below is an *implicit* TensorFlow
+ * primitive reached through the Keras graph that nets/mj_uwyhNets_ba.py builds.  Each entry point cites
+ * the reference call site (path relative to the reference root) whose arithmetic it replaces.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (HBM) unless the name ends in _host; no ownership transfer;
+ *   - tensors are dense, channels-last (NHWC), fp32; index maps are uint8;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); calls only enqueue work;
+ *   - return 0 on success, a positive hipError_t on a HIP failure, UGN_EINVAL on a shape the kernels do
+ *     not implement.  ugn_last_error() returns a static description of the last failure of the thread;
+ *   - thread-compatible: no global mutable state besides that message.
+ */
+#ifndef UGAITNET_HIP_H
+#define UGAITNET_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define UGN_EINVAL (-22)
+#define UGN_ABI_VERSION 1
+
+/* fusion modes of fMerge (nets/mj_uwyhNets_ba.py:814,1189) */
+#define UGN_FUSE_SIGN_MAX 0 /* mains/mj_trainUWYHGaitNet_DataGen_CasiaB.py:169-178 */
+#define UGN_FUSE_MAX 1      /* keras Maximum */
+#define UGN_FUSE_AVG 2      /* keras Average */
+
+int ugn_abi_version(void);
+const char* ugn_last_error(void);
+
+/* ---- first layer: ZeroPadding2D(2) + Conv2D(32, 5x5, same, no bias) + LeakyReLU(0.3) ---------------
+ * nets/mj_uwyhNets_ba.py:428-430.  x [n,60,60,cin] (cin 1 or 2), w HWIO [5,5,cin,32], a1 [n,64,64,32]. */
+int ugn_conv5x5_in_fwd(const float* x, const float* w, float* a1, int n, int cin, void* stream);
+/* dw [5,5,cin,32] = sum over frames/pixels of x (padded) * dz1 [n,64,64,32].  ws: >= ugn_conv5x5_in_wgrad_ws(). */
+size_t ugn_conv5x5_in_wgrad_ws(int n, int cin);
+int ugn_conv5x5_in_wgrad(const float* x, const float* dz1, float* dw, int n, int cin, void* ws, size_t ws_bytes,
+                         void* stream);
+
+/* ---- 3x3 convolutions (TimeDistributed Conv2D / Conv2D, same, no bias), nets/mj_uwyhNets_ba.py:431-462 --
+ * Forward weights are consumed in packed [9][cout][cin] order produced by ugn_pack3x3 from HWIO. */
+int ugn_pack3x3(const float* w_hwio, float* w_packed, int cin, int cout, void* stream);
+/* out = LeakyReLU(conv(in)).  pool != 0: additionally MaxPooling2D(2,2): out is [n,hw/2,hw/2,cout] and
+ * out_idx (uint8, same shape) holds the first maximum of each window in row-major order (0..3). */
+int ugn_conv3x3_fwd(const float* in, const float* w_packed, float* out, uint8_t* out_idx, int n, int hw, int cin,
+                    int cout, int pool, void* stream);
+/* Data gradient.  Forward layer: cin -> cout at hw x hw.  dz is the gradient w.r.t. the layer's pre-activation
+ * [n,hw,hw,cout]; if dz_idx != NULL, dz is given at pooled resolution [n,hw/2,hw/2,cout] (already multiplied by
+ * LeakyReLU') and is scattered through dz_idx on the fly (MaxPool backward).  w is the HWIO weight.
+ *   t   = conv_transpose(dz, w) (+ addend if addend != NULL)
+ *   raw_out = t                           (if raw_out != NULL)
+ *   out = t * (act > 0 ? 1 : 0.3)         (if act != NULL, else out = t); all [n,hw,hw,cin]. */
+int ugn_conv3x3_dgrad(const float* dz, const uint8_t* dz_idx, const float* w_hwio, const float* act,
+                      const float* addend, float* out, float* raw_out, int n, int hw, int cin, int cout,
+                      void* stream);
+/* Weight gradient dw HWIO [3,3,cin,cout] = sum in (x) dz; dz/dz_idx as in dgrad. */
+size_t ugn_conv3x3_wgrad_ws(int n, int hw, int cin, int cout);
+int ugn_conv3x3_wgrad(const float* in, const float* dz, const uint8_t* dz_idx, float* dw, int n, int hw, int cin,
+                      int cout, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- set pooling over the L frames: tf.math.reduce_max(x, axis=1), nets/mj_uwyhNets_ba.py:435,451,463 ----
+ * p [b,l,s] -> m [b,s]; if addend != NULL also sum_out = m + addend (the Add layers :452,:465). */
+int ugn_setmax_fwd(const float* p, const float* addend, float* m, float* sum_out, int b, int l, size_t s,
+                   void* stream);
+/* out[b,l,s] = (p == max_l p) ? dm / (#maxima) : 0, times LeakyReLU'(p) when apply_lrelu != 0. */
+int ugn_setmax_bwd(const float* p, const float* dm, float* out, int b, int l, size_t s, int apply_lrelu,
+                   void* stream);
+
+/* ---- horizontal pyramid pooling, nets/mj_uwyhNets_ba.py:468-481.  a, s3 [b,16,16,128] -> feat [62,b,128] */
+int ugn_hpp_fwd(const float* a, const float* s3, float* feat, int b, void* stream);
+/* dfeat [62,b,128] -> dm3 = dL/da + dL/ds3 (a also feeds s3 = b4 + a), dzb4 = dL/ds3 * LeakyReLU'(b4). */
+int ugn_hpp_bwd(const float* a, const float* s3, const float* b4, const float* dfeat, float* dm3, float* dzb4,
+                int b, void* stream);
+
+/* ---- MatMul layer (62 per-bin FCs), nets/mj_uwyhNets_ba.py:23-40: feat [62,b,128] x w [62,128,256] ------- */
+int ugn_binfc_fwd(const float* feat, const float* w, float* out, int b, void* stream);
+int ugn_binfc_bwd(const float* feat, const float* w, const float* dout, float* dw, float* dfeat, int b,
+                  void* stream);
+
+/* ---- gate (:51-54) + fMerge (:814,:1189).  outs/uses: HOST arrays of nmod device pointers; x_m [62,b,256],
+ * use_m [b].  fused [62,b,256]; sel uint8 (selected modality). */
+int ugn_gate_fuse_fwd(const float* const* outs_host, const float* const* uses_host, int nmod, int mode,
+                      float* fused, uint8_t* sel, int b, void* stream);
+int ugn_gate_fuse_bwd(const float* dfused, const uint8_t* sel, const float* const* uses_host,
+                      float* const* douts_host, int nmod, int mode, int b, void* stream);
+/* ---- tf.math.l2_normalize(x, axis=1) on [62,b,256] (axis 1 = batch), :817,:1191 ----------------------- */
+int ugn_l2norm_batch_fwd(const float* f, float* sig, int b, void* stream);
+int ugn_l2norm_batch_bwd(const float* f, const float* sig, const float* dsig, float* df, int b, void* stream);
+
+/* ---- classification head: transpose+Flatten+Dense(softmax) + categorical cross-entropy, :848-850,:865 ---
+ * sig [62,b,256], wc [15872,ncls], bc [ncls].  part: workspace [62,b,ncls] floats.
+ * probs [b,ncls]; row_loss [b] (= -sum t log p); dlogits [b,ncls] = (p - t) * grad_scale; hit [b] (argmax match). */
+int ugn_head_fwd(const float* sig, const float* wc, const float* bc, const float* onehot, float* part,
+                 float* probs, float* row_loss, float* dlogits, float* hit, float grad_scale, int b, int ncls,
+                 void* stream);
+/* dwc, dbc written; dsig (+)= dlogits x wc^T in [62,b,256] layout (accumulate != 0 adds to dsig). */
+int ugn_head_bwd(const float* sig, const float* wc, const float* dlogits, float* dwc, float* dbc, float* dsig,
+                 int accumulate, int b, int ncls, void* stream);
+
+/* ---- batch-all triplet loss, nets/triplet_loss_all.py:8-77 --------------------------------------------
+ * Host helper: hp/hn pair-index lists (row-major boolean_mask order).  Returns 0, or UGN_EINVAL when the
+ * pair counts are not divisible by m (the reference's tf.reshape([n,m,-1,1]) would raise). */
+int ugn_triplet_indices_host(const int32_t* labels_host, int m, int32_t* hp_host, int32_t* hn_host, int* kp,
+                             int* kn);
+/* sig [62,m,256]; hp [m*kp], hn [m*kn] device int32.  bin_loss [62] (sum/num, 0 if num==0), bin_num [62].
+ * dsig = grad_scale/(62*num_k) * d(sum_k)/dsig (written, not accumulated).  m <= 128. */
+int ugn_triplet_fwd_bwd(const float* sig, const int32_t* hp, const int32_t* hn, int kp, int kn, float margin,
+                        float* bin_loss, float* bin_num, float* dsig, float grad_scale, int m, void* stream);
+
+/* ---- keras Adam (mains/mj_trainUWYHGaitNet_DataGen_CasiaB.py:227): p -= lr_t * m / (sqrt(v) + eps) -------- */
+int ugn_adam_step(float* p, const float* g, float* m, float* v, size_t n, float lr_t, float b1, float b2,
+                  float eps, float grad_scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UGAITNET_HIP_H */

@@ -1,0 +1,308 @@
+"""Per-kernel parity: every C-ABI entry point against the numpy oracle on identical seeded inputs (GPU only)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ugaitnet_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+CONV_CFGS = [  # (hw, cin, cout, pool)  == the five 3x3 shapes of the encoder
+    (64, 32, 32, True), (32, 32, 64, False), (32, 64, 64, True), (16, 64, 128, False), (16, 128, 128, False)]
+
+
+def T(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def close(got, ref, rtol, name=""):
+    got = got.detach().cpu().numpy() if isinstance(got, torch.Tensor) else np.asarray(got)
+    scale = float(np.abs(ref).max()) + 1e-30
+    err = float(np.abs(got.astype(np.float64) - ref.astype(np.float64)).max())
+    assert err <= rtol * scale, "%s: max abs err %.3e vs scale %.3e (rtol %.1e)" % (name, err, scale, rtol)
+
+
+@pytest.mark.parametrize("cin", [1, 2])
+def test_conv5x5_in_fwd_and_wgrad(dev, cin):
+    from ugaitnet_amd import ops
+    rng = np.random.default_rng(10 + cin)
+    n = 5
+    x = rng.uniform(-0.5, 0.5, (n, 60, 60, cin)).astype(np.float32)
+    w = rng.uniform(-0.3, 0.3, (5, 5, cin, 32)).astype(np.float32)
+    xf = np.pad(x, ((0, 0), (2, 2), (2, 2), (0, 0)))
+    ref = O.leaky(O.conv2d_same(xf.astype(np.float64), w.astype(np.float64)))
+    got = ops.conv5x5_in_fwd(T(x, dev), T(w, dev))
+    close(got, ref, 2e-6, "conv5x5 fwd")
+    dz = rng.normal(size=(n, 64, 64, 32)).astype(np.float32)
+    dw_ref, _ = O.conv2d_same_bwd(xf.astype(np.float64), w.astype(np.float64), dz.astype(np.float64), need_dx=False)
+    dw = ops.conv5x5_in_wgrad(T(x, dev), T(dz, dev))
+    close(dw, dw_ref, 5e-6, "conv5x5 wgrad")
+
+
+@pytest.mark.parametrize("hw,cin,cout,pool", CONV_CFGS)
+def test_conv3x3_fwd(dev, hw, cin, cout, pool):
+    from ugaitnet_amd import ops
+    rng = np.random.default_rng(hw + cin + cout)
+    n = 3
+    x = rng.uniform(-1, 1, (n, hw, hw, cin)).astype(np.float32)
+    w = rng.uniform(-0.2, 0.2, (3, 3, cin, cout)).astype(np.float32)
+    act = O.leaky(O.conv2d_same(x.astype(np.float64), w.astype(np.float64)))
+    wp = ops.pack3x3(T(w, dev))
+    assert np.array_equal(wp.cpu().numpy(), w.reshape(9, cin, cout).transpose(0, 2, 1))
+    if not pool:
+        close(ops.conv3x3_fwd(T(x, dev), wp, False), act, 2e-6, "conv3x3 fwd")
+        return
+    out, idx = ops.conv3x3_fwd(T(x, dev), wp, True)
+    pref, iref = O.maxpool2x2(act)
+    close(out, pref, 2e-6, "conv3x3+pool fwd")
+    # the index must point at a (near-)maximum of the oracle's window; it must equal the oracle's where the max is clear
+    idx = idx.cpu().numpy()
+    assert idx.max() <= 3
+    win = act.reshape(n, hw // 2, 2, hw // 2, 2, cout).transpose(0, 1, 3, 2, 4, 5).reshape(n, hw // 2, hw // 2, 4, cout)
+    picked = np.take_along_axis(win, idx[:, :, :, None, :].astype(np.int64), axis=3)[:, :, :, 0, :]
+    assert np.abs(picked - pref).max() <= 1e-5
+    srt = np.sort(win, axis=3)
+    clear = (srt[:, :, :, 3, :] - srt[:, :, :, 2, :]) > 1e-4
+    assert np.array_equal(idx[clear], iref[clear])
+
+
+def test_conv3x3_pool_first_max_on_ties(dev):
+    """Constant input -> every window is a 4-way tie in the interior: the FIRST element (index 0) must win."""
+    from ugaitnet_amd import ops
+    x = np.full((1, 64, 64, 32), 0.25, np.float32)
+    w = np.full((3, 3, 32, 32), 0.01, np.float32)
+    out, idx = ops.conv3x3_fwd(T(x, dev), ops.pack3x3(T(w, dev)), True)
+    idx = idx.cpu().numpy()
+    act = O.leaky(O.conv2d_same(x, w))
+    _, iref = O.maxpool2x2(act)
+    assert np.array_equal(idx[:, 1:-1, 1:-1], iref[:, 1:-1, 1:-1])
+    assert (idx[:, 1:-1, 1:-1] == 0).all()
+
+
+@pytest.mark.parametrize("hw,cin,cout,pool", CONV_CFGS)
+def test_conv3x3_dgrad_and_wgrad(dev, hw, cin, cout, pool):
+    from ugaitnet_amd import ops
+    rng = np.random.default_rng(1000 + hw + cin + cout)
+    n = 3
+    x = rng.uniform(-1, 1, (n, hw, hw, cin)).astype(np.float32)
+    w = rng.uniform(-0.2, 0.2, (3, 3, cin, cout)).astype(np.float32)
+    act_prev = rng.normal(size=(n, hw, hw, cin)).astype(np.float32)
+    addend = rng.normal(size=(n, hw, hw, cin)).astype(np.float32)
+    if pool:
+        dp = rng.normal(size=(n, hw // 2, hw // 2, cout)).astype(np.float32)
+        idx = rng.integers(0, 4, size=dp.shape).astype(np.uint8)
+        dz = O.maxpool2x2_bwd(idx, dp)
+        dz_t, idx_t = T(dp, dev), T(idx, dev)
+    else:
+        dz = rng.normal(size=(n, hw, hw, cout)).astype(np.float32)
+        dz_t, idx_t = T(dz, dev), None
+    dw_ref, dx_ref = O.conv2d_same_bwd(x.astype(np.float64), w.astype(np.float64), dz.astype(np.float64))
+    # plain data gradient
+    got = ops.conv3x3_dgrad(dz_t, T(w, dev), hw, dz_idx=idx_t)
+    close(got, dx_ref, 3e-6, "dgrad plain")
+    # fused epilogue: (t + addend) * lrelu'(act), raw copy
+    raw = torch.empty_like(got)
+    got2 = ops.conv3x3_dgrad(dz_t, T(w, dev), hw, dz_idx=idx_t, act=T(act_prev, dev), addend=T(addend, dev), raw_out=raw)
+    t = dx_ref + addend
+    close(raw, t, 3e-6, "dgrad raw")
+    close(got2, np.where(act_prev > 0, t, 0.3 * t), 3e-6, "dgrad fused")
+    dw = ops.conv3x3_wgrad(T(x, dev), dz_t, cout, dz_idx=idx_t)
+    close(dw, dw_ref, 5e-6, "wgrad")
+
+
+def test_conv3x3_wgrad_many_frames(dev):
+    """More tiles than persistent workgroups: exercises the tile loop and the two-level slab reduction."""
+    from ugaitnet_amd import ops
+    rng = np.random.default_rng(5)
+    n, hw, cin, cout = 40, 64, 32, 32
+    x = rng.uniform(-1, 1, (n, hw, hw, cin)).astype(np.float32)
+    dz = rng.normal(size=(n, hw, hw, cout)).astype(np.float32)
+    dp, idx = O.maxpool2x2(dz)
+    dzu = O.maxpool2x2_bwd(idx, dp)
+    dw_ref, _ = O.conv2d_same_bwd(x.astype(np.float64), np.zeros((3, 3, cin, cout)), dzu.astype(np.float64), need_dx=False)
+    dw = ops.conv3x3_wgrad(T(x, dev), T(dp, dev), cout, dz_idx=T(idx, dev))
+    close(dw, dw_ref, 1e-5, "wgrad many frames")
+
+
+def test_unsupported_shape_raises(dev):
+    from ugaitnet_amd import ops
+    x = torch.zeros((1, 8, 8, 16), device=dev)
+    wp = torch.zeros((9, 16, 16), device=dev)
+    with pytest.raises(ValueError):
+        ops.conv3x3_fwd(x, wp, False)
+
+
+@pytest.mark.parametrize("with_add", [False, True])
+def test_setmax(dev, with_add):
+    from ugaitnet_amd import ops
+    rng = np.random.default_rng(3)
+    b, l, shape = 3, 25, (16, 16, 64)
+    p = rng.normal(size=(b * l,) + shape).astype(np.float32)
+    p5 = p.reshape((b, l) + shape)
+    p5[:, 3] = p5[:, 7]          # exact ties between frames 3 and 7
+    p5[0, :, 0, 0, :] = 0.5      # a 25-way tie
+    p = p5.reshape(p.shape)
+    add = rng.normal(size=(b,) + shape).astype(np.float32)
+    m_ref = O.setmax(p5)
+    if with_add:
+        m, s = ops.setmax_fwd(T(p, dev), b, l, addend=T(add, dev))
+        assert np.array_equal(s.cpu().numpy(), m_ref + add)
+    else:
+        m = ops.setmax_fwd(T(p, dev), b, l)
+    assert np.array_equal(m.cpu().numpy(), m_ref)
+    dm = rng.normal(size=(b,) + shape).astype(np.float32)
+    ref = O.setmax_bwd(p5, m_ref, dm).reshape(p.shape)
+    got = ops.setmax_bwd(T(p, dev), T(dm, dev), b, l, False)
+    close(got, ref, 1e-6, "setmax bwd")
+    got = ops.setmax_bwd(T(p, dev), T(dm, dev), b, l, True)
+    close(got, O.leaky_bwd_from_out(p, ref), 1e-6, "setmax bwd + lrelu'")
+
+
+def test_hpp(dev):
+    from ugaitnet_amd import ops
+    rng = np.random.default_rng(4)
+    b = 5
+    a = rng.normal(size=(b, 16, 16, 128)).astype(np.float32)
+    s3 = rng.normal(size=(b, 16, 16, 128)).astype(np.float32)
+    a[0, 0, :, :] = a[0, 0, 0:1, :]   # ties inside a strip
+    s3[1] = 0.125                      # a fully constant map: 256-way ties at every level
+    b4 = rng.normal(size=a.shape).astype(np.float32)
+    feat = ops.hpp_fwd(T(a, dev), T(s3, dev))
+    close(feat, O.hpp(a.astype(np.float64), s3.astype(np.float64)), 2e-6, "hpp fwd")
+    dfeat = rng.normal(size=(62, b, 128)).astype(np.float32)
+    da, ds = O.hpp_bwd(a.astype(np.float64), s3.astype(np.float64), dfeat.astype(np.float64))
+    dm3, dzb4 = ops.hpp_bwd(T(a, dev), T(s3, dev), T(b4, dev), T(dfeat, dev))
+    close(dm3, da + ds, 2e-6, "hpp bwd dm3")
+    close(dzb4, np.where(b4 > 0, ds, 0.3 * ds), 2e-6, "hpp bwd dzb4")
+
+
+@pytest.mark.parametrize("b", [5, 24, 40])
+def test_binfc(dev, b):
+    from ugaitnet_amd import ops
+    rng = np.random.default_rng(6)
+    feat = rng.normal(size=(62, b, 128)).astype(np.float32)
+    w = rng.uniform(-0.1, 0.1, (62, 128, 256)).astype(np.float32)
+    out = ops.binfc_fwd(T(feat, dev), T(w, dev))
+    close(out, O.binfc(feat.astype(np.float64), w.astype(np.float64)), 2e-6, "binfc fwd")
+    dout = rng.normal(size=(62, b, 256)).astype(np.float32)
+    dw_ref, df_ref = O.binfc_bwd(feat.astype(np.float64), w.astype(np.float64), dout.astype(np.float64))
+    dw, df = ops.binfc_bwd(T(feat, dev), T(w, dev), T(dout, dev))
+    close(dw, dw_ref, 3e-6, "binfc dW")
+    close(df, df_ref, 3e-6, "binfc dfeat")
+
+
+@pytest.mark.parametrize("mode", ["sign_max", "max", "avg"])
+@pytest.mark.parametrize("nmod", [2, 3])
+def test_gate_fuse(dev, mode, nmod):
+    from ugaitnet_amd import ops
+    rng = np.random.default_rng(7)
+    b = 7
+    outs = [rng.normal(size=(62, b, 256)).astype(np.float32) for _ in range(nmod)]
+    outs[1][:, :, :64] = -outs[0][:, :, :64]          # |.| ties with opposite sign: first index must win
+    uses = [(rng.uniform(size=(b, 1)) > 0.4).astype(np.float32) for _ in range(nmod)]
+    uses[0][0] = 0; uses[1][0] = 0                     # all-masked row (2-mod) -> zeros, index 0
+    gs = [O.gate(o, u) for o, u in zip(outs, uses)]
+    f_ref, sel_ref = O.fuse(gs, mode)
+    ut = [T(u.reshape(-1), dev) for u in uses]
+    fused, sel = ops.gate_fuse_fwd([T(o, dev) for o in outs], ut, mode)
+    assert np.array_equal(fused.cpu().numpy(), f_ref) if mode != "avg" else True
+    close(fused, f_ref, 1e-6, "fuse fwd")
+    if mode != "avg":
+        assert np.array_equal(sel.cpu().numpy().astype(np.int64), sel_ref)
+    df = rng.normal(size=f_ref.shape).astype(np.float32)
+    ref = [O.gate(d, u) for d, u in zip(O.fuse_bwd(sel_ref, df, nmod, mode), uses)]
+    got = ops.gate_fuse_bwd(T(df, dev), sel, ut, mode)
+    for g, r in zip(got, ref):
+        close(g, r, 1e-6, "fuse bwd")
+
+
+def test_l2norm_batch(dev):
+    from ugaitnet_amd import ops
+    rng = np.random.default_rng(8)
+    b = 24
+    f = rng.normal(size=(62, b, 256)).astype(np.float32)
+    f[:, :, 5] = 0.0          # an all-zero column: hits the 1e-12 clamp
+    sig = ops.l2norm_batch_fwd(T(f, dev))
+    y_ref, inv = O.l2norm_batch(f.astype(np.float64))
+    close(sig, y_ref, 2e-6, "l2norm fwd")
+    dy = rng.normal(size=f.shape).astype(np.float32)
+    ref = O.l2norm_batch_bwd(f.astype(np.float64), y_ref, inv, dy.astype(np.float64))
+    got = ops.l2norm_batch_bwd(T(f, dev), sig, T(dy, dev))
+    # the clamped column has gradient dy * 1e6: compare per column relative
+    close(got[:, :, :5], ref[:, :, :5], 3e-6, "l2norm bwd")
+    close(got[:, :, 5], ref[:, :, 5], 3e-6, "l2norm bwd clamped column")
+
+
+@pytest.mark.parametrize("b,ncls", [(24, 150), (40, 74)])
+def test_head(dev, b, ncls):
+    from ugaitnet_amd import ops
+    rng = np.random.default_rng(9)
+    sig = rng.normal(size=(62, b, 256)).astype(np.float32) * 0.2
+    wc = rng.uniform(-0.02, 0.02, (62 * 256, ncls)).astype(np.float32)
+    bc = rng.normal(size=(ncls,)).astype(np.float32) * 0.1
+    lab = rng.integers(0, ncls, size=b)
+    onehot = np.eye(ncls, dtype=np.float32)[lab]
+    scale = 0.1 / b
+    r = ops.head_fwd(T(sig, dev), T(wc, dev), T(bc, dev), T(onehot, dev), scale)
+    logits, flat = O.head_logits(sig.astype(np.float64), wc.astype(np.float64), bc.astype(np.float64))
+    loss, probs = O.softmax_xent(logits, onehot.astype(np.float64))
+    close(r["probs"], probs, 5e-6, "probs")
+    assert abs(float(r["row_loss"].mean()) - loss) < 1e-5 * max(1.0, abs(loss))
+    dlog = (probs - onehot) * scale
+    close(r["dlogits"], dlog, 5e-6, "dlogits")
+    hit_ref = (probs.argmax(1) == lab).astype(np.float32)
+    assert np.array_equal(r["hit"].cpu().numpy(), hit_ref)
+    dsig0 = rng.normal(size=sig.shape).astype(np.float32)
+    dsig = T(dsig0, dev)
+    dwc, dbc = ops.head_bwd(T(sig, dev), T(wc, dev), r["dlogits"], dsig, True)
+    close(dwc, flat.T @ dlog, 5e-6, "dwc")
+    close(dbc, dlog.sum(0), 5e-6, "dbc")
+    dflat = dlog @ wc.astype(np.float64).T
+    close(dsig, dsig0 + dflat.reshape(b, 62, 256).transpose(1, 0, 2), 5e-6, "dsig accumulate")
+    dsig2 = torch.empty_like(dsig)
+    ops.head_bwd(T(sig, dev), T(wc, dev), r["dlogits"], dsig2, False)
+    close(dsig2, dflat.reshape(b, 62, 256).transpose(1, 0, 2), 5e-6, "dsig write")
+
+
+@pytest.mark.parametrize("labels", [np.repeat(np.arange(12), 2), np.repeat(np.arange(4), 10),
+                                    np.array([0] * 10 + [1] * 10 + [2] * 4), np.repeat(np.arange(8), 16)])
+def test_triplet(dev, labels):
+    from ugaitnet_amd import ops
+    rng = np.random.default_rng(11)
+    m = labels.shape[0]
+    f = rng.normal(size=(62, m, 256)).astype(np.float32)
+    sig, _ = O.l2norm_batch(f)
+    sig = (sig * 0.6).astype(np.float32)   # distances around the 0.2 margin: a mix of active and inactive triplets
+    hp, hn, kp, kn = ops.triplet_indices(labels)
+    hp_ref, hn_ref, kp_ref, kn_ref = O.triplet_index_lists(labels)
+    assert np.array_equal(hp, hp_ref) and np.array_equal(hn, hn_ref) and (kp, kn) == (kp_ref, kn_ref)  # bit-exact indices
+    loss_ref, aux = O.triplet_all(labels, sig.astype(np.float64), 0.2)
+    bl, bn, dsig = ops.triplet_fwd_bwd(T(sig, dev), T(hp, dev), T(hn, dev), kp, kn, 0.2, 1.0)
+    # active-triplet counts: exact unless a hinge sits within rounding of 0
+    h = aux["h"]
+    margin_raw = 0.2 + (aux["dist"].reshape(62, -1)[:, hp].reshape(62, m, kp, 1) - aux["dist"].reshape(62, -1)[:, hn].reshape(62, m, 1, kn))
+    fragile = (np.abs(margin_raw) < 1e-5).reshape(62, -1).sum(axis=1)
+    assert np.all(np.abs(bn.cpu().numpy() - aux["num"]) <= fragile)
+    assert abs(float(bl.mean()) - loss_ref) <= 2e-5 * max(1.0, abs(loss_ref))
+    close(dsig, O.triplet_all_bwd(sig.astype(np.float64), aux), 2e-4, "triplet dsig")
+
+
+def test_triplet_rejects_indivisible_labels(dev):
+    from ugaitnet_amd import ops
+    with pytest.raises(ValueError):
+        ops.triplet_indices(np.array([0, 0, 0, 1, 1]))
+
+
+def test_adam(dev):
+    from ugaitnet_amd import ops
+    rng = np.random.default_rng(12)
+    n = 100003
+    p = rng.normal(size=n).astype(np.float32); g = rng.normal(size=n).astype(np.float32)
+    m = rng.normal(size=n).astype(np.float32) * 0.1; v = rng.uniform(0, 1, n).astype(np.float32) * 0.01
+    pt, mt, vt = T(p, dev), T(m, dev), T(v, dev)
+    t = 7
+    lr_t = 1e-4 * np.sqrt(1 - 0.999 ** t) / (1 - 0.9 ** t)
+    ops.adam_step(pt, T(g, dev), mt, vt, lr_t)
+    p64, m64, v64 = p.astype(np.float64), m.astype(np.float64), v.astype(np.float64)
+    O.adam_step(p64, g.astype(np.float64), m64, v64, t)
+    close(pt, p64, 1e-6, "adam p"); close(mt, m64, 1e-6, "adam m"); close(vt, v64, 1e-6, "adam v")

@@ -1,0 +1,97 @@
+"""ctypes binding of libugaitnet_hip.so (the C ABI declared in include/ugaitnet_hip.h).
+
+The product path has NO CPU fallback: if the library is missing or a call fails, an exception is raised.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libugaitnet_hip.so")
+
+FUSE_MODES = {"sign_max": 0, "max": 1, "avg": 2}
+
+_p = C.c_void_p
+_i = C.c_int
+_f = C.c_float
+_sz = C.c_size_t
+
+# name -> (restype, argtypes); mirrors include/ugaitnet_hip.h one to one
+PROTOTYPES = {
+    "ugn_abi_version": (_i, []),
+    "ugn_last_error": (C.c_char_p, []),
+    "ugn_conv5x5_in_fwd": (_i, [_p, _p, _p, _i, _i, _p]),
+    "ugn_conv5x5_in_wgrad_ws": (_sz, [_i, _i]),
+    "ugn_conv5x5_in_wgrad": (_i, [_p, _p, _p, _i, _i, _p, _sz, _p]),
+    "ugn_pack3x3": (_i, [_p, _p, _i, _i, _p]),
+    "ugn_conv3x3_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "ugn_conv3x3_dgrad": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
+    "ugn_conv3x3_wgrad_ws": (_sz, [_i, _i, _i, _i]),
+    "ugn_conv3x3_wgrad": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p, _sz, _p]),
+    "ugn_setmax_fwd": (_i, [_p, _p, _p, _p, _i, _i, _sz, _p]),
+    "ugn_setmax_bwd": (_i, [_p, _p, _p, _i, _i, _sz, _i, _p]),
+    "ugn_hpp_fwd": (_i, [_p, _p, _p, _i, _p]),
+    "ugn_hpp_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _p]),
+    "ugn_binfc_fwd": (_i, [_p, _p, _p, _i, _p]),
+    "ugn_binfc_bwd": (_i, [_p, _p, _p, _p, _p, _i, _p]),
+    "ugn_gate_fuse_fwd": (_i, [C.POINTER(_p), C.POINTER(_p), _i, _i, _p, _p, _i, _p]),
+    "ugn_gate_fuse_bwd": (_i, [_p, _p, C.POINTER(_p), C.POINTER(_p), _i, _i, _i, _p]),
+    "ugn_l2norm_batch_fwd": (_i, [_p, _p, _i, _p]),
+    "ugn_l2norm_batch_bwd": (_i, [_p, _p, _p, _p, _i, _p]),
+    "ugn_head_fwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _f, _i, _i, _p]),
+    "ugn_head_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
+    "ugn_triplet_indices_host": (_i, [_p, _i, _p, _p, C.POINTER(_i), C.POINTER(_i)]),
+    "ugn_triplet_fwd_bwd": (_i, [_p, _p, _p, _i, _i, _f, _p, _p, _p, _f, _i, _p]),
+    "ugn_adam_step": (_i, [_p, _p, _p, _p, _sz, _f, _f, _f, _f, _f, _p]),
+}
+
+_lib = None
+
+
+class UgnError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the shared library (once).  Raises if it has not been built: there is no fallback path."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise UgnError(
+            "libugaitnet_hip.so is missing (%s). Build it with `python -m ugaitnet_amd.build`; "
+            "ugaitnet_amd has no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    if lib.ugn_abi_version() != 1:
+        raise UgnError("libugaitnet_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().ugn_last_error().decode("utf-8", "replace")
+        if rc == -22:
+            raise ValueError("%s: %s" % (what, msg))
+        raise UgnError("%s failed (code %d): %s" % (what, rc, msg))
+
+
+def call(name, *args):
+    check(getattr(load(), name)(*args), name)
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (None -> NULL)."""
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def ptr_array(tensors):
+    arr = (C.c_void_p * len(tensors))()
+    for i, t in enumerate(tensors):
+        arr[i] = t.data_ptr()
+    return arr

@@ -1,0 +1,522 @@
+// 3x3 SAME convolutions of the GaitSet-style encoder as fp32 implicit GEMMs on v_mfma_f32_32x32x2_f32.
+//
+// Replaces the implicit TF Conv2D / Conv2DBackpropInput / Conv2DBackpropFilter + LeakyRelu(Grad) +
+// MaxPool(Grad) ops behind reference nets/mj_uwyhNets_ba.py:431-462 (forward) and Keras autodiff (backward).
+//
+// Forward / data-gradient kernel (one template, `conv3x3_kernel`)
+//   GEMM view: M = output pixels, N = output channels, K = 9 taps x K-channels.
+//   A workgroup (256 threads = 4 waves) owns a TH x 16 pixel tile and all N channels.  K is walked as
+//   (32-channel chunk) x (tap): the input halo tile [(TH+2) x 18 pixels][32 ch] of the chunk sits in LDS with a
+//   36-float pixel stride (ds_read_b128 conflict-free), the [N][32] weight slice of the tap is double-buffered
+//   in LDS and prefetched through registers one tap ahead, so there is ONE barrier per tap.
+//   M-blocks are 2 rows x 16 columns in "pool order" (lane bit0 = x&1, bit1 = y&1, bits2-4 = 2x2 window), so the
+//   four pixels of a pooling window land in registers 4q..4q+3 of ONE lane of the 32x32 accumulator and the
+//   MaxPool(+argmax) epilogue needs no cross-lane traffic.
+//   K order inside an 8-channel group is permuted (lane half h takes channels 4h..4h+3) so both operands are
+//   fetched with one ds_read_b128 per 4 MFMAs; A and B use the same permutation, so the sum is unchanged.
+//   The data gradient is the same kernel with the HWIO weights read as [tap'][n=cin][k=cout], tap' = 8 - tap.
+//
+// Weight-gradient kernel (`wgrad3x3_kernel`)
+//   GEMM view: M = 32 input channels (one chunk), N = 32/64 output channels, K = pixels; 9 accumulators (one per
+//   tap) per wave.  Persistent workgroups walk 8x16 pixel tiles and keep the 9x32x32 partial sums in registers;
+//   partial slabs are summed by `reduce_slabs_kernel` (deterministic, no atomics).
+#include "common.h"
+
+namespace {
+
+constexpr int TW = 16;       // tile width (pixels)
+constexpr int PW = TW + 2;   // halo tile width
+constexpr int CS = 36;       // LDS pixel stride of a 32-channel chunk (floats): 144 B, b128 conflict-free
+
+enum { EPI_LRELU = 0, EPI_LRELU_POOL = 1, EPI_DGRAD = 2 };
+
+template <int KC, int NC, int HW, int TH, int IN_UNPOOL, int EPI>
+struct ConvCfg {
+  static constexpr int PH = TH + 2, NPIX = PH * PW;
+  static constexpr int MB = TH / 2, NB = NC / 32, WB = MB * NB / 4;
+  static constexpr int WN = (NB >= 2 && WB >= 2) ? 2 : 1, WM = WB / WN;
+  static constexpr int WAVES_N = NB / WN, WAVES_M = MB / WM;
+  static constexpr int NCHUNK = KC / 32;
+  static constexpr int SIN = NPIX * CS, SW = NC * CS;
+  static constexpr int LDS_BYTES = (SIN + 2 * SW) * 4;
+  static constexpr int IN_ITERS = (NPIX * 8 + 255) / 256;
+  static_assert(WAVES_N * WAVES_M == 4, "4 waves per workgroup");
+  static_assert(WB >= 1 && WM >= 1, "tile too small");
+  static_assert(HW % TH == 0 && HW % TW == 0, "tile must divide the image");
+};
+
+template <int KC, int NC, int HW, int TH, int IN_UNPOOL, int EPI>
+__global__ __launch_bounds__(256, 2) void conv3x3_kernel(const float* __restrict__ in,
+                                                          const uint8_t* __restrict__ in_idx,
+                                                          const float* __restrict__ w, int flip,
+                                                          float* __restrict__ out, uint8_t* __restrict__ out_idx,
+                                                          const float* __restrict__ act,
+                                                          const float* __restrict__ addend,
+                                                          float* __restrict__ raw_out) {
+  using C = ConvCfg<KC, NC, HW, TH, IN_UNPOOL, EPI>;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* sIn = smem;
+  float* sW0 = smem + C::SIN;
+  float* sW1 = sW0 + C::SW;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / C::WAVES_N, wn = wave % C::WAVES_N;
+  const int li = lane & 31, lh = lane >> 5;
+
+  constexpr int TPX = HW / TW, TPY = HW / TH, TPI = TPX * TPY;
+  const int bid = blockIdx.x;
+  const int img = bid / TPI, trem = bid % TPI;
+  const int ty0 = (trem / TPX) * TH, tx0 = (trem % TPX) * TW;
+
+  // lane's pixel inside an M-block (pool order)
+  const int py = (li >> 1) & 1, px = 2 * (li >> 2) + (li & 1);
+  int aoff[C::WM], boff[C::WN];
+#pragma unroll
+  for (int m = 0; m < C::WM; ++m) aoff[m] = ((2 * (wm * C::WM + m) + py) * PW + px) * CS + 4 * lh;
+#pragma unroll
+  for (int n = 0; n < C::WN; ++n) boff[n] = ((wn * C::WN + n) * 32 + li) * CS + 4 * lh;
+
+  f32x16 acc[C::WM][C::WN];
+#pragma unroll
+  for (int m = 0; m < C::WM; ++m)
+#pragma unroll
+    for (int n = 0; n < C::WN; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+
+  const int wrow = tid >> 3, wc4 = tid & 7;
+  float4 wreg[C::NB];
+
+  for (int chunk = 0; chunk < C::NCHUNK; ++chunk) {
+    __syncthreads();  // everyone is done with sIn / sW of the previous chunk
+    // ---- stage the input halo tile of this chunk (zero outside the image) ----
+    {
+      float4 v[C::IN_ITERS];
+#pragma unroll
+      for (int it = 0; it < C::IN_ITERS; ++it) {
+        const int e = tid + it * 256;
+        const int p = e >> 3, c4 = e & 7;
+        const int yy = p / PW, xx = p - yy * PW;
+        const int gy = ty0 - 1 + yy, gx = tx0 - 1 + xx;
+        v[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (e < C::NPIX * 8 && gy >= 0 && gy < HW && gx >= 0 && gx < HW) {
+          if constexpr (IN_UNPOOL) {
+            constexpr int HP = HW / 2;
+            const size_t o = (((size_t)img * HP + (gy >> 1)) * HP + (gx >> 1)) * KC + chunk * 32 + c4 * 4;
+            const float4 d = *reinterpret_cast<const float4*>(in + o);
+            const uchar4 id = *reinterpret_cast<const uchar4*>(in_idx + o);
+            const int pos = ((gy & 1) << 1) | (gx & 1);
+            v[it].x = id.x == pos ? d.x : 0.f;
+            v[it].y = id.y == pos ? d.y : 0.f;
+            v[it].z = id.z == pos ? d.z : 0.f;
+            v[it].w = id.w == pos ? d.w : 0.f;
+          } else {
+            const size_t o = (((size_t)img * HW + gy) * HW + gx) * KC + chunk * 32 + c4 * 4;
+            v[it] = *reinterpret_cast<const float4*>(in + o);
+          }
+        }
+      }
+#pragma unroll
+      for (int it = 0; it < C::IN_ITERS; ++it) {
+        const int e = tid + it * 256;
+        if (e < C::NPIX * 8) *reinterpret_cast<float4*>(sIn + (e >> 3) * CS + (e & 7) * 4) = v[it];
+      }
+    }
+    // ---- first weight slice of the chunk ----
+    {
+      const int t = flip ? 8 : 0;
+#pragma unroll
+      for (int q = 0; q < C::NB; ++q)
+        wreg[q] = *reinterpret_cast<const float4*>(w + ((size_t)(t * NC + q * 32 + wrow)) * KC + chunk * 32 + wc4 * 4);
+#pragma unroll
+      for (int q = 0; q < C::NB; ++q) *reinterpret_cast<float4*>(sW0 + (q * 32 + wrow) * CS + wc4 * 4) = wreg[q];
+    }
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      if (tap < 8) {
+        const int t = flip ? 7 - tap : tap + 1;
+#pragma unroll
+        for (int q = 0; q < C::NB; ++q)
+          wreg[q] =
+              *reinterpret_cast<const float4*>(w + ((size_t)(t * NC + q * 32 + wrow)) * KC + chunk * 32 + wc4 * 4);
+      }
+      __syncthreads();
+      const float* sW = (tap & 1) ? sW1 : sW0;
+      const int toff = ((tap / 3) * PW + (tap % 3)) * CS;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float4 a[C::WM], b[C::WN];
+#pragma unroll
+        for (int m = 0; m < C::WM; ++m) a[m] = *reinterpret_cast<const float4*>(sIn + aoff[m] + toff + 8 * g);
+#pragma unroll
+        for (int n = 0; n < C::WN; ++n) b[n] = *reinterpret_cast<const float4*>(sW + boff[n] + 8 * g);
+#pragma unroll
+        for (int m = 0; m < C::WM; ++m)
+#pragma unroll
+          for (int n = 0; n < C::WN; ++n) {
+            acc[m][n] = ugn_mfma(a[m].x, b[n].x, acc[m][n]);
+            acc[m][n] = ugn_mfma(a[m].y, b[n].y, acc[m][n]);
+            acc[m][n] = ugn_mfma(a[m].z, b[n].z, acc[m][n]);
+            acc[m][n] = ugn_mfma(a[m].w, b[n].w, acc[m][n]);
+          }
+      }
+      if (tap < 8) {
+        float* sWn = ((tap + 1) & 1) ? sW1 : sW0;
+#pragma unroll
+        for (int q = 0; q < C::NB; ++q) *reinterpret_cast<float4*>(sWn + (q * 32 + wrow) * CS + wc4 * 4) = wreg[q];
+      }
+    }
+  }
+
+  // ---- epilogue ----
+#pragma unroll
+  for (int m = 0; m < C::WM; ++m) {
+    const int mbi = wm * C::WM + m;
+#pragma unroll
+    for (int n = 0; n < C::WN; ++n) {
+      const int co = (wn * C::WN + n) * 32 + li;
+      if constexpr (EPI == EPI_LRELU_POOL) {
+        constexpr int HP = HW / 2;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float best = ugn_lrelu(acc[m][n][4 * q]);
+          int bi = 0;
+#pragma unroll
+          for (int r = 1; r < 4; ++r) {
+            const float v = ugn_lrelu(acc[m][n][4 * q + r]);
+            if (v > best) { best = v; bi = r; }
+          }
+          const int oy = ty0 / 2 + mbi, ox = tx0 / 2 + lh + 2 * q;
+          const size_t o = (((size_t)img * HP + oy) * HP + ox) * NC + co;
+          out[o] = best;
+          out_idx[o] = (uint8_t)bi;
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int y = ty0 + 2 * mbi + ((r >> 1) & 1);
+          const int x = tx0 + 2 * (lh + 2 * (r >> 2)) + (r & 1);
+          const size_t o = (((size_t)img * HW + y) * HW + x) * NC + co;
+          float v = acc[m][n][r];
+          if constexpr (EPI == EPI_LRELU) {
+            out[o] = ugn_lrelu(v);
+          } else {
+            if (addend) v += addend[o];
+            if (raw_out) raw_out[o] = v;
+            if (act) v *= ugn_lrelu_slope(act[o]);
+            out[o] = v;
+          }
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// weight gradient
+// ------------------------------------------------------------------------------------------------------
+constexpr int WG_TH = 8;                       // wgrad pixel tile: 8 rows x 16 columns
+constexpr int WG_NPIX = (WG_TH + 2) * PW;      // halo tile pixels
+constexpr int WG_TPIX = WG_TH * TW;            // 128 pixels = GEMM K per tile
+
+template <int CI, int CO, int HW, int COC, int DZ_UNPOOL>
+struct WgradCfg {
+  static constexpr int DS = COC + 4;           // dz pixel stride in LDS
+  static constexpr int SIN = WG_NPIX * CS, SDZ = WG_TPIX * DS;
+  static constexpr int NBW = COC / 32, PS = 4 / NBW, PPW = WG_TPIX / PS;
+  static constexpr int STAGE_BYTES = (SIN + SDZ) * 4;
+  static constexpr int RED_BYTES = 9 * 16 * 64 * 4;  // one wave's accumulators
+  static constexpr int LDS_BYTES = STAGE_BYTES > RED_BYTES ? STAGE_BYTES : RED_BYTES;
+  static constexpr int IN_ITERS = (WG_NPIX * 8 + 255) / 256;
+  static constexpr int DZ_ITERS = WG_TPIX * (COC / 4) / 256;
+  static constexpr int NCOMBO = (CI / 32) * (CO / COC);
+};
+
+template <int CI, int CO, int HW, int COC, int DZ_UNPOOL>
+__global__ __launch_bounds__(256, 2) void wgrad3x3_kernel(const float* __restrict__ in,
+                                                           const float* __restrict__ dz,
+                                                           const uint8_t* __restrict__ dz_idx,
+                                                           float* __restrict__ slab, int tiles_total, int groups) {
+  using C = WgradCfg<CI, CO, HW, COC, DZ_UNPOOL>;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* sIn = smem;
+  float* sDz = smem + C::SIN;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int cb = wave % C::NBW, ps = wave / C::NBW;
+  const int combo = blockIdx.x / groups, grp = blockIdx.x % groups;
+  constexpr int NCO = CO / COC;
+  const int cic = combo / NCO, coc = combo % NCO;
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  constexpr int TPX = HW / TW, TPY = HW / WG_TH, TPI = TPX * TPY;
+  // lane bases: pixel k = ps*PPW + 2*kp + lh
+  const int k0 = ps * C::PPW + lh;
+  const int abase = ((k0 / TW) * PW + (k0 % TW)) * CS + li;
+  const int bbase = k0 * C::DS + cb * 32 + li;
+
+  for (int tile = grp; tile < tiles_total; tile += groups) {
+    const int img = tile / TPI, trem = tile % TPI;
+    const int ty0 = (trem / TPX) * WG_TH, tx0 = (trem % TPX) * TW;
+    __syncthreads();
+    {
+      float4 v[C::IN_ITERS];
+#pragma unroll
+      for (int it = 0; it < C::IN_ITERS; ++it) {
+        const int e = tid + it * 256;
+        const int p = e >> 3, c4 = e & 7;
+        const int yy = p / PW, xx = p - yy * PW;
+        const int gy = ty0 - 1 + yy, gx = tx0 - 1 + xx;
+        v[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (e < WG_NPIX * 8 && gy >= 0 && gy < HW && gx >= 0 && gx < HW)
+          v[it] = *reinterpret_cast<const float4*>(in + (((size_t)img * HW + gy) * HW + gx) * CI + cic * 32 + c4 * 4);
+      }
+      float4 d[C::DZ_ITERS];
+#pragma unroll
+      for (int it = 0; it < C::DZ_ITERS; ++it) {
+        const int e = tid + it * 256;
+        constexpr int Q = COC / 4;
+        const int p = e / Q, c4 = e % Q;
+        const int gy = ty0 + p / TW, gx = tx0 + p % TW;
+        if constexpr (DZ_UNPOOL) {
+          constexpr int HP = HW / 2;
+          const size_t o = (((size_t)img * HP + (gy >> 1)) * HP + (gx >> 1)) * CO + coc * COC + c4 * 4;
+          const float4 g = *reinterpret_cast<const float4*>(dz + o);
+          const uchar4 id = *reinterpret_cast<const uchar4*>(dz_idx + o);
+          const int pos = ((gy & 1) << 1) | (gx & 1);
+          d[it].x = id.x == pos ? g.x : 0.f;
+          d[it].y = id.y == pos ? g.y : 0.f;
+          d[it].z = id.z == pos ? g.z : 0.f;
+          d[it].w = id.w == pos ? g.w : 0.f;
+        } else {
+          d[it] = *reinterpret_cast<const float4*>(dz + (((size_t)img * HW + gy) * HW + gx) * CO + coc * COC + c4 * 4);
+        }
+      }
+#pragma unroll
+      for (int it = 0; it < C::IN_ITERS; ++it) {
+        const int e = tid + it * 256;
+        if (e < WG_NPIX * 8) *reinterpret_cast<float4*>(sIn + (e >> 3) * CS + (e & 7) * 4) = v[it];
+      }
+#pragma unroll
+      for (int it = 0; it < C::DZ_ITERS; ++it) {
+        const int e = tid + it * 256;
+        constexpr int Q = COC / 4;
+        *reinterpret_cast<float4*>(sDz + (e / Q) * C::DS + (e % Q) * 4) = d[it];
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kp = 0; kp < C::PPW / 2; ++kp) {
+      // pixel k = ps*PPW + 2*kp + lh ; rows of 16 pixels
+      const int ko = ((2 * kp) / TW) * PW + ((2 * kp) % TW);  // compile-time after unrolling
+      const float b = sDz[bbase + 2 * kp * C::DS];
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const float a = sIn[abase + (ko + (t / 3) * PW + (t % 3)) * CS];
+        acc[t] = ugn_mfma(a, b, acc[t]);
+      }
+    }
+  }
+
+  // ---- reduce the PS pixel-split waves that share an output block, then write the slab ----
+  float* sRed = smem;
+#pragma unroll 1
+  for (int src = C::NBW; src < 4; ++src) {
+    __syncthreads();
+    if (wave == src) {
+#pragma unroll
+      for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sRed[(t * 16 + r) * 64 + lane] = acc[t][r];
+    }
+    __syncthreads();
+    if (wave == src % C::NBW) {
+#pragma unroll
+      for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] += sRed[(t * 16 + r) * 64 + lane];
+    }
+  }
+  if (wave < C::NBW) {
+    float* dst = slab + (size_t)grp * 9 * CI * CO;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ci = cic * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const int co = coc * COC + cb * 32 + li;
+        dst[((size_t)t * CI + ci) * CO + co] = acc[t][r];
+      }
+  }
+}
+
+// dst[o][e] = sum over g == o (mod nout) of src[g][e];  e in float4 units
+__global__ void reduce_slabs_kernel(const float4* __restrict__ src, float4* __restrict__ dst, int nelem4, int nin,
+                                    int nout) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  const int o = blockIdx.y;
+  if (e >= nelem4) return;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int g = o; g < nin; g += nout) {
+    const float4 v = src[(size_t)g * nelem4 + e];
+    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  }
+  dst[(size_t)o * nelem4 + e] = s;
+}
+
+__global__ void pack3x3_kernel(const float* __restrict__ w, float* __restrict__ wp, int cin, int cout) {
+  // w [9][cin][cout] -> wp [9][cout][cin]
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  const int total = 9 * cin * cout;
+  if (e >= total) return;
+  const int ci = e % cin, co = (e / cin) % cout, t = e / (cin * cout);
+  wp[e] = w[((size_t)t * cin + ci) * cout + co];
+}
+
+template <int KC, int NC, int HW, int TH, int IN_UNPOOL, int EPI>
+int launch_conv(const float* in, const uint8_t* in_idx, const float* w, int flip, float* out, uint8_t* out_idx,
+                const float* act, const float* addend, float* raw_out, int n, hipStream_t st) {
+  using C = ConvCfg<KC, NC, HW, TH, IN_UNPOOL, EPI>;
+  auto kern = conv3x3_kernel<KC, NC, HW, TH, IN_UNPOOL, EPI>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+    if (e != hipSuccess) { ugn_set_error("conv3x3: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
+    attr_done = true;
+  }
+  const int grid = n * (HW / TH) * (HW / TW);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), C::LDS_BYTES, st, in, in_idx, w, flip, out, out_idx, act, addend,
+                     raw_out);
+  UGN_CHECK_LAUNCH("conv3x3");
+  return 0;
+}
+
+constexpr int WGRAD_WGS = 512;  // persistent workgroups (2 per CU)
+
+template <int CI, int CO, int HW, int COC, int DZ_UNPOOL>
+int launch_wgrad(const float* in, const float* dz, const uint8_t* dz_idx, float* dw, int n, float* ws,
+                 size_t ws_floats, hipStream_t st) {
+  using C = WgradCfg<CI, CO, HW, COC, DZ_UNPOOL>;
+  auto kern = wgrad3x3_kernel<CI, CO, HW, COC, DZ_UNPOOL>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+    if (e != hipSuccess) { ugn_set_error("wgrad3x3: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
+    attr_done = true;
+  }
+  const int tiles = n * (HW / WG_TH) * (HW / TW);
+  int groups = WGRAD_WGS / C::NCOMBO;
+  if (groups > tiles) groups = tiles;
+  const size_t nelem = (size_t)9 * CI * CO;
+  constexpr int NOUT = 16;
+  const int mid = groups > NOUT ? NOUT : 0;
+  if (ws_floats < nelem * (size_t)(groups + mid)) {
+    ugn_set_error("wgrad3x3: workspace too small (%zu < %zu floats)", ws_floats, nelem * (size_t)(groups + mid));
+    return UGN_EINVAL;
+  }
+  hipLaunchKernelGGL(kern, dim3(groups * C::NCOMBO), dim3(256), C::LDS_BYTES, st, in, dz, dz_idx, ws, tiles, groups);
+  UGN_CHECK_LAUNCH("wgrad3x3");
+  const int nelem4 = (int)(nelem / 4);
+  const dim3 rb(256), rg((nelem4 + 255) / 256, 1);
+  if (mid) {
+    float* ws2 = ws + nelem * groups;
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(rg.x, NOUT), rb, 0, st, (const float4*)ws, (float4*)ws2, nelem4,
+                       groups, NOUT);
+    hipLaunchKernelGGL(reduce_slabs_kernel, rg, rb, 0, st, (const float4*)ws2, (float4*)dw, nelem4, NOUT, 1);
+  } else {
+    hipLaunchKernelGGL(reduce_slabs_kernel, rg, rb, 0, st, (const float4*)ws, (float4*)dw, nelem4, groups, 1);
+  }
+  UGN_CHECK_LAUNCH("wgrad3x3 reduce");
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int ugn_pack3x3(const float* w_hwio, float* w_packed, int cin, int cout, void* stream) {
+  UGN_REQUIRE(w_hwio && w_packed && cin > 0 && cout > 0, "ugn_pack3x3: bad arguments");
+  const int total = 9 * cin * cout;
+  hipLaunchKernelGGL(pack3x3_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, w_hwio, w_packed,
+                     cin, cout);
+  UGN_CHECK_LAUNCH("pack3x3");
+  return 0;
+}
+
+extern "C" int ugn_conv3x3_fwd(const float* in, const float* wp, float* out, uint8_t* out_idx, int n, int hw, int cin,
+                               int cout, int pool, void* stream) {
+  UGN_REQUIRE(in && wp && out && n > 0, "ugn_conv3x3_fwd: null pointer or n <= 0");
+  UGN_REQUIRE(!pool || out_idx, "ugn_conv3x3_fwd: pool needs out_idx");
+  hipStream_t st = (hipStream_t)stream;
+#define FWD(KC_, NC_, HW_, TH_, P_)                                                                                \
+  if (cin == KC_ && cout == NC_ && hw == HW_ && (pool != 0) == (P_ != 0))                                          \
+    return launch_conv<KC_, NC_, HW_, TH_, 0, P_ ? EPI_LRELU_POOL : EPI_LRELU>(in, nullptr, wp, 0, out, out_idx,   \
+                                                                               nullptr, nullptr, nullptr, n, st);
+  FWD(32, 32, 64, 16, 1)   // a2
+  FWD(32, 64, 32, 16, 0)   // a3, b1
+  FWD(64, 64, 32, 16, 1)   // a4, b2
+  FWD(64, 128, 16, 8, 0)   // a5, b3
+  FWD(128, 128, 16, 8, 0)  // a6, b4
+#undef FWD
+  UGN_REQUIRE(false, "ugn_conv3x3_fwd: unsupported shape cin=%d cout=%d hw=%d pool=%d", cin, cout, hw, pool);
+}
+
+extern "C" int ugn_conv3x3_dgrad(const float* dz, const uint8_t* dz_idx, const float* w, const float* act,
+                                 const float* addend, float* out, float* raw_out, int n, int hw, int cin, int cout,
+                                 void* stream) {
+  UGN_REQUIRE(dz && w && out && n > 0, "ugn_conv3x3_dgrad: null pointer or n <= 0");
+  hipStream_t st = (hipStream_t)stream;
+  const int unpool = dz_idx != nullptr;
+  // kernel K channels = forward cout, kernel N channels = forward cin
+#define DGR(CI_, CO_, HW_, TH_, U_)                                                                               \
+  if (cin == CI_ && cout == CO_ && hw == HW_ && unpool == U_)                                                      \
+    return launch_conv<CO_, CI_, HW_, TH_, U_, EPI_DGRAD>(dz, dz_idx, w, 1, out, nullptr, act, addend, raw_out, n, st);
+  DGR(32, 32, 64, 16, 1)    // a2
+  DGR(32, 64, 32, 16, 0)    // a3, b1
+  DGR(64, 64, 32, 16, 1)    // a4, b2
+  DGR(64, 128, 16, 16, 0)   // a5, b3
+  DGR(128, 128, 16, 8, 0)   // a6, b4
+#undef DGR
+  UGN_REQUIRE(false, "ugn_conv3x3_dgrad: unsupported shape cin=%d cout=%d hw=%d unpool=%d", cin, cout, hw, unpool);
+}
+
+static bool wgrad_cfg(int hw, int cin, int cout, int* coc) {
+  if ((hw == 64 && cin == 32 && cout == 32) || (hw == 32 && cin == 32 && cout == 64) ||
+      (hw == 32 && cin == 64 && cout == 64) || (hw == 16 && cin == 64 && cout == 128) ||
+      (hw == 16 && cin == 128 && cout == 128)) {
+    *coc = cout >= 64 ? 64 : 32;
+    return true;
+  }
+  return false;
+}
+
+extern "C" size_t ugn_conv3x3_wgrad_ws(int n, int hw, int cin, int cout) {
+  int coc;
+  if (!wgrad_cfg(hw, cin, cout, &coc) || n <= 0) return 0;
+  const int ncombo = (cin / 32) * (cout / coc);
+  const long tiles = (long)n * (hw / WG_TH) * (hw / TW);
+  long groups = WGRAD_WGS / ncombo;
+  if (groups > tiles) groups = tiles;
+  return (size_t)9 * cin * cout * (size_t)(groups + 16) * sizeof(float);
+}
+
+extern "C" int ugn_conv3x3_wgrad(const float* in, const float* dz, const uint8_t* dz_idx, float* dw, int n, int hw,
+                                 int cin, int cout, void* ws, size_t ws_bytes, void* stream) {
+  UGN_REQUIRE(in && dz && dw && ws && n > 0, "ugn_conv3x3_wgrad: null pointer or n <= 0");
+  hipStream_t st = (hipStream_t)stream;
+  const int unpool = dz_idx != nullptr;
+#define WGR(CI_, CO_, HW_, COC_, U_)                                  \
+  if (cin == CI_ && cout == CO_ && hw == HW_ && unpool == U_)          \
+    return launch_wgrad<CI_, CO_, HW_, COC_, U_>(in, dz, dz_idx, dw, n, (float*)ws, ws_bytes / sizeof(float), st);
+  WGR(32, 32, 64, 32, 1)    // a2
+  WGR(32, 64, 32, 64, 0)    // a3, b1
+  WGR(64, 64, 32, 64, 1)    // a4, b2
+  WGR(64, 128, 16, 64, 0)   // a5, b3
+  WGR(128, 128, 16, 64, 0)  // a6, b4
+#undef WGR
+  UGN_REQUIRE(false, "ugn_conv3x3_wgrad: unsupported shape cin=%d cout=%d hw=%d unpool=%d", cin, cout, hw, unpool);
+}

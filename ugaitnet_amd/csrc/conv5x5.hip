@@ -1,0 +1,205 @@
+// First encoder layer: ZeroPadding2D(2) + Conv2D(32, 5x5, SAME, no bias) + LeakyReLU(0.3) on the raw 60x60 frames
+// (reference nets/mj_uwyhNets_ba.py:428-430) and its weight gradient.  The input has 1 or 2 channels, so the
+// GEMM K is only 25 or 50: the kernel is bound by writing a1 (13.1 MB per clip), not by arithmetic.  It still runs
+// on v_mfma_f32_32x32x2_f32 so that the accumulator layout (32 consecutive output channels per half wave) gives
+// 128-byte coalesced NHWC stores with no LDS transpose.
+//
+// Domain: the explicit 2-pixel zero ring makes the conv domain 64x64; input pixel (u,v) of that domain is raw pixel
+// (u-2,v-2) or 0.  The 5x5 SAME conv then reads (y+dy-2, x+dx-2), dy,dx in 0..4.
+#include "common.h"
+
+namespace {
+
+constexpr int T5 = 16;          // 16x16 output tile
+constexpr int P5 = T5 + 4;      // 20x20 input patch
+constexpr int RAW = 60, DOM = 64;
+
+template <int CIN>
+__device__ __forceinline__ void stage_patch(float* sP, const float* __restrict__ x, int img, int ty0, int tx0, int tid) {
+  // patch pixel (yy,xx) = domain (ty0-2+yy, tx0-2+xx) = raw (ty0-4+yy, tx0-4+xx)
+  for (int e = tid; e < P5 * P5; e += 256) {
+    const int yy = e / P5, xx = e % P5;
+    const int ry = ty0 - 4 + yy, rx = tx0 - 4 + xx;
+    const bool ok = ry >= 0 && ry < RAW && rx >= 0 && rx < RAW;
+    const size_t o = (((size_t)img * RAW + ry) * RAW + rx) * CIN;
+    if constexpr (CIN == 1) {
+      sP[e] = ok ? x[o] : 0.f;
+    } else {
+      float2 v = make_float2(0.f, 0.f);
+      if (ok) v = *reinterpret_cast<const float2*>(x + o);
+      *reinterpret_cast<float2*>(sP + 2 * e) = v;
+    }
+  }
+}
+
+template <int CIN>
+__global__ __launch_bounds__(256) void conv5x5_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                          float* __restrict__ a1) {
+  constexpr int K = 25 * CIN, KP = (K + 1) / 2;  // k-pairs
+  __shared__ __attribute__((aligned(16))) float sP[P5 * P5 * CIN];
+  __shared__ __attribute__((aligned(16))) float sW[2 * KP * 32];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int img = blockIdx.x >> 4, trem = blockIdx.x & 15;
+  const int ty0 = (trem >> 2) * T5, tx0 = (trem & 3) * T5;
+
+  stage_patch<CIN>(sP, x, img, ty0, tx0, tid);
+  for (int e = tid; e < 2 * KP * 32; e += 256) sW[e] = e < K * 32 ? w[e] : 0.f;
+  __syncthreads();
+
+  const int py = (li >> 1) & 1, px = 2 * (li >> 2) + (li & 1);
+  f32x16 acc[2];
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+  int pb[2];
+#pragma unroll
+  for (int m = 0; m < 2; ++m) pb[m] = ((2 * (wave * 2 + m) + py) * P5 + px) * CIN + (CIN == 2 ? lh : 0);
+
+#pragma unroll
+  for (int s = 0; s < KP; ++s) {
+    int off;
+    if constexpr (CIN == 2) {
+      off = ((s / 5) * P5 + (s % 5)) * 2;  // tap s, channel = lane half
+    } else {
+      const int k0 = 2 * s, k1 = (2 * s + 1 < K) ? 2 * s + 1 : K - 1;
+      const int o0 = (k0 / 5) * P5 + (k0 % 5), o1 = (k1 / 5) * P5 + (k1 % 5);
+      off = lh ? o1 : o0;
+    }
+    const float b = sW[(2 * s + lh) * 32 + li];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) acc[m] = ugn_mfma(sP[pb[m] + off], b, acc[m]);
+  }
+#pragma unroll
+  for (int m = 0; m < 2; ++m) {
+    const int mbi = wave * 2 + m;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int y = ty0 + 2 * mbi + ((r >> 1) & 1);
+      const int xx = tx0 + 2 * (lh + 2 * (r >> 2)) + (r & 1);
+      a1[(((size_t)img * DOM + y) * DOM + xx) * 32 + li] = ugn_lrelu(acc[m][r]);
+    }
+  }
+}
+
+// dw[k][co] = sum_pixels patch[pixel + tap_k][c_k] * dz1[pixel][co]; persistent workgroups, slabs [groups][25*CIN][32].
+template <int CIN>
+__global__ __launch_bounds__(256) void conv5x5_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dz1,
+                                                            float* __restrict__ slab, int tiles_total) {
+  constexpr int K = 25 * CIN, MBK = (K + 31) / 32;
+  constexpr int DS = 36;
+  __shared__ __attribute__((aligned(16))) float sP[P5 * P5 * CIN];
+  __shared__ __attribute__((aligned(16))) float sD[T5 * T5 * DS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+
+  f32x16 acc[MBK];
+  int abase[MBK];
+#pragma unroll
+  for (int mb = 0; mb < MBK; ++mb) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[mb][r] = 0.f;
+    int k = mb * 32 + li;
+    if (k >= K) k = 0;  // padded rows: any valid address, result discarded
+    const int tap = k / CIN, c = k % CIN;
+    abase[mb] = ((tap / 5) * P5 + (tap % 5)) * CIN + c + ((wave * 4) * P5 + lh) * CIN;  // wave owns tile rows 4w..4w+3
+  }
+  const int bbase = (wave * 64 + lh) * DS + li;
+
+  for (int tile = blockIdx.x; tile < tiles_total; tile += gridDim.x) {
+    const int img = tile >> 4, trem = tile & 15;
+    const int ty0 = (trem >> 2) * T5, tx0 = (trem & 3) * T5;
+    __syncthreads();
+    stage_patch<CIN>(sP, x, img, ty0, tx0, tid);
+    {
+      float4 d[8];
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const int e = tid + it * 256;
+        const int p = e >> 3, c4 = e & 7;
+        d[it] = *reinterpret_cast<const float4*>(dz1 + (((size_t)img * DOM + ty0 + (p >> 4)) * DOM + tx0 + (p & 15)) * 32 +
+                                                 c4 * 4);
+      }
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const int e = tid + it * 256;
+        *reinterpret_cast<float4*>(sD + (e >> 3) * DS + (e & 7) * 4) = d[it];
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kp = 0; kp < 32; ++kp) {  // wave's 64 pixels: p = 2*kp + lh, row = p/16, col = p%16
+      const int po = ((2 * kp) / 16) * P5 + ((2 * kp) % 16);
+      const float b = sD[bbase + 2 * kp * DS];
+#pragma unroll
+      for (int mb = 0; mb < MBK; ++mb) acc[mb] = ugn_mfma(sP[abase[mb] + po * CIN], b, acc[mb]);
+    }
+  }
+  // cross-wave reduction through LDS (reuse sD: 4 waves x MBK x 16 x 64 floats <= 8192 floats < 9216)
+  __syncthreads();
+#pragma unroll
+  for (int mb = 0; mb < MBK; ++mb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sD[((wave * MBK + mb) * 16 + r) * 64 + lane] = acc[mb][r];
+  __syncthreads();
+  float* dst = slab + (size_t)blockIdx.x * K * 32;
+  for (int e = tid; e < MBK * 16 * 64; e += 256) {
+    const int l = e & 63, r = (e >> 6) & 15, mb = e >> 10;
+    float s = 0.f;
+#pragma unroll
+    for (int wv = 0; wv < 4; ++wv) s += sD[((wv * MBK + mb) * 16 + r) * 64 + l];
+    const int k = mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+    if (k < K) dst[k * 32 + (l & 31)] = s;
+  }
+}
+
+__global__ void reduce5_kernel(const float* __restrict__ src, float* __restrict__ dst, int nelem, int nin) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= nelem) return;
+  float s = 0.f;
+  for (int g = 0; g < nin; ++g) s += src[(size_t)g * nelem + e];
+  dst[e] = s;
+}
+
+constexpr int WG5_GROUPS = 512;
+
+}  // namespace
+
+extern "C" int ugn_conv5x5_in_fwd(const float* x, const float* w, float* a1, int n, int cin, void* stream) {
+  UGN_REQUIRE(x && w && a1 && n > 0, "ugn_conv5x5_in_fwd: null pointer or n <= 0");
+  UGN_REQUIRE(cin == 1 || cin == 2, "ugn_conv5x5_in_fwd: cin must be 1 or 2 (got %d)", cin);
+  hipStream_t st = (hipStream_t)stream;
+  if (cin == 1)
+    hipLaunchKernelGGL(conv5x5_fwd_kernel<1>, dim3(n * 16), dim3(256), 0, st, x, w, a1);
+  else
+    hipLaunchKernelGGL(conv5x5_fwd_kernel<2>, dim3(n * 16), dim3(256), 0, st, x, w, a1);
+  UGN_CHECK_LAUNCH("conv5x5_fwd");
+  return 0;
+}
+
+extern "C" size_t ugn_conv5x5_in_wgrad_ws(int n, int cin) {
+  if (n <= 0 || (cin != 1 && cin != 2)) return 0;
+  const long tiles = (long)n * 16;
+  const long groups = tiles < WG5_GROUPS ? tiles : WG5_GROUPS;
+  return (size_t)groups * 25 * cin * 32 * sizeof(float);
+}
+
+extern "C" int ugn_conv5x5_in_wgrad(const float* x, const float* dz1, float* dw, int n, int cin, void* ws, size_t ws_bytes,
+                                    void* stream) {
+  UGN_REQUIRE(x && dz1 && dw && ws && n > 0, "ugn_conv5x5_in_wgrad: null pointer or n <= 0");
+  UGN_REQUIRE(cin == 1 || cin == 2, "ugn_conv5x5_in_wgrad: cin must be 1 or 2 (got %d)", cin);
+  UGN_REQUIRE(ws_bytes >= ugn_conv5x5_in_wgrad_ws(n, cin), "ugn_conv5x5_in_wgrad: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  const int tiles = n * 16;
+  const int groups = tiles < WG5_GROUPS ? tiles : WG5_GROUPS;
+  if (cin == 1)
+    hipLaunchKernelGGL(conv5x5_wgrad_kernel<1>, dim3(groups), dim3(256), 0, st, x, dz1, (float*)ws, tiles);
+  else
+    hipLaunchKernelGGL(conv5x5_wgrad_kernel<2>, dim3(groups), dim3(256), 0, st, x, dz1, (float*)ws, tiles);
+  UGN_CHECK_LAUNCH("conv5x5_wgrad");
+  const int nelem = 25 * cin * 32;
+  hipLaunchKernelGGL(reduce5_kernel, dim3((nelem + 255) / 256), dim3(256), 0, st, (const float*)ws, dw, nelem, groups);
+  UGN_CHECK_LAUNCH("conv5x5_wgrad reduce");
+  return 0;
+}

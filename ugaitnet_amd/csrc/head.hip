@@ -1,0 +1,575 @@
+// Everything after the conv stacks: per-bin FC (MatMul layer), modality gate + fMerge, batch-axis L2 normalisation,
+// classification head with softmax cross-entropy, batch-all triplet loss, Adam.  Reference call sites:
+//   nets/mj_uwyhNets_ba.py:23-54 (MatMul, gate), :814-818 / :1189-1192 (fusion, signature), :847-851 / :1211-1214 (head),
+//   nets/triplet_loss_all.py:8-77, mains/mj_trainUWYHGaitNet_DataGen_CasiaB.py:169-178 (sign_max), :227 (Adam).
+// These tensors are tiny ([62,B,256]); the kernels are latency/HBM-bound and kept simple: coalesced global access,
+// operands shared through LDS, one workgroup per bin.
+#include "common.h"
+
+namespace {
+
+constexpr int NBINS = 62, FEAT = 128, HID = 256;
+
+// ------------------------------------------------------------------------------------------------------
+// per-bin FC
+// ------------------------------------------------------------------------------------------------------
+constexpr int FC_BT = 8;
+
+__global__ __launch_bounds__(256) void binfc_fwd_kernel(const float* __restrict__ feat, const float* __restrict__ w,
+                                                        float* __restrict__ out, int bsz) {
+  __shared__ float sF[FC_BT][FEAT];
+  const int k = blockIdx.x, o = threadIdx.x;
+  const float* wk = w + (size_t)k * FEAT * HID;
+  for (int b0 = 0; b0 < bsz; b0 += FC_BT) {
+    __syncthreads();
+    for (int e = threadIdx.x; e < FC_BT * FEAT; e += 256) {
+      const int bb = e / FEAT, i = e % FEAT;
+      sF[bb][i] = b0 + bb < bsz ? feat[((size_t)k * bsz + b0 + bb) * FEAT + i] : 0.f;
+    }
+    __syncthreads();
+    float acc[FC_BT];
+#pragma unroll
+    for (int bb = 0; bb < FC_BT; ++bb) acc[bb] = 0.f;
+    for (int i = 0; i < FEAT; ++i) {
+      const float wv = wk[(size_t)i * HID + o];
+#pragma unroll
+      for (int bb = 0; bb < FC_BT; ++bb) acc[bb] = fmaf(sF[bb][i], wv, acc[bb]);
+    }
+#pragma unroll
+    for (int bb = 0; bb < FC_BT; ++bb)
+      if (b0 + bb < bsz) out[((size_t)k * bsz + b0 + bb) * HID + o] = acc[bb];
+  }
+}
+
+constexpr int FCB_BT = 16;
+
+__global__ __launch_bounds__(256) void binfc_bwd_kernel(const float* __restrict__ feat, const float* __restrict__ w,
+                                                        const float* __restrict__ dout, float* __restrict__ dw,
+                                                        float* __restrict__ dfeat, int bsz) {
+  __shared__ float sF[FCB_BT][FEAT];        // 8 KB
+  __shared__ float sD[FCB_BT][HID];         // 16 KB
+  __shared__ float sWt[FEAT][33];           // 16.5 KB : W[k][i][o0..o0+31]
+  const int k = blockIdx.x, tid = threadIdx.x;
+  const float* wk = w + (size_t)k * FEAT * HID;
+  float* dwk = dw + (size_t)k * FEAT * HID;
+  for (int b0 = 0; b0 < bsz; b0 += FCB_BT) {
+    const int nb = min(FCB_BT, bsz - b0);
+    __syncthreads();
+    for (int e = tid; e < FCB_BT * FEAT; e += 256) {
+      const int bb = e / FEAT, i = e % FEAT;
+      sF[bb][i] = bb < nb ? feat[((size_t)k * bsz + b0 + bb) * FEAT + i] : 0.f;
+    }
+    for (int e = tid; e < FCB_BT * HID; e += 256) {
+      const int bb = e / HID, o = e % HID;
+      sD[bb][o] = bb < nb ? dout[((size_t)k * bsz + b0 + bb) * HID + o] : 0.f;
+    }
+    __syncthreads();
+    // dW[i][o] (+)= sum_b feat[b][i] * dout[b][o]; thread = o
+    {
+      float dreg[FCB_BT];
+#pragma unroll
+      for (int bb = 0; bb < FCB_BT; ++bb) dreg[bb] = sD[bb][tid];
+      for (int i = 0; i < FEAT; ++i) {
+        float acc = 0.f;
+#pragma unroll
+        for (int bb = 0; bb < FCB_BT; ++bb) acc = fmaf(sF[bb][i], dreg[bb], acc);
+        if (b0 == 0) dwk[(size_t)i * HID + tid] = acc;
+        else dwk[(size_t)i * HID + tid] += acc;
+      }
+    }
+    // dfeat[b][i] = sum_o dout[b][o] * W[i][o]; thread = (half, i), half owns FCB_BT/2 samples
+    {
+      const int i = tid & 127, half = tid >> 7;
+      constexpr int HB = FCB_BT / 2;
+      float acc[HB];
+#pragma unroll
+      for (int q = 0; q < HB; ++q) acc[q] = 0.f;
+      for (int o0 = 0; o0 < HID; o0 += 32) {
+        __syncthreads();
+        for (int e = tid; e < FEAT * 32; e += 256) sWt[e >> 5][e & 31] = wk[(size_t)(e >> 5) * HID + o0 + (e & 31)];
+        __syncthreads();
+        for (int oo = 0; oo < 32; ++oo) {
+          const float wv = sWt[i][oo];
+#pragma unroll
+          for (int q = 0; q < HB; ++q) acc[q] = fmaf(sD[half * HB + q][o0 + oo], wv, acc[q]);
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < HB; ++q) {
+        const int bb = half * HB + q;
+        if (bb < nb) dfeat[((size_t)k * bsz + b0 + bb) * FEAT + i] = acc[q];
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// gate + fMerge
+// ------------------------------------------------------------------------------------------------------
+struct ModPtrs {
+  const float* x[4];
+  const float* use[4];
+  float* dx[4];
+};
+
+__global__ void gate_fuse_fwd_kernel(ModPtrs mp, int nmod, int mode, float* __restrict__ fused, uint8_t* __restrict__ sel,
+                                     int bsz, size_t total) {
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= total) return;
+  const int b = (int)((e / HID) % bsz);
+  float g[4];
+  for (int m = 0; m < nmod; ++m) g[m] = mp.x[m][e] * mp.use[m][b];
+  float out;
+  int s = 0;
+  if (mode == UGN_FUSE_SIGN_MAX) {
+    float best = fabsf(g[0]);
+    for (int m = 1; m < nmod; ++m)
+      if (fabsf(g[m]) > best) { best = fabsf(g[m]); s = m; }   // first index wins ties (tf.argmax)
+    out = g[s];
+  } else if (mode == UGN_FUSE_MAX) {
+    out = g[0];
+    for (int m = 1; m < nmod; ++m)
+      if (g[m] > out) { out = g[m]; s = m; }                   // tf.maximum gradient: ties to the first argument
+  } else {
+    out = 0.f;
+    for (int m = 0; m < nmod; ++m) out += g[m];
+    out /= (float)nmod;
+    s = 255;
+  }
+  fused[e] = out;
+  sel[e] = (uint8_t)s;
+}
+
+__global__ void gate_fuse_bwd_kernel(ModPtrs mp, int nmod, int mode, const float* __restrict__ df,
+                                     const uint8_t* __restrict__ sel, int bsz, size_t total) {
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= total) return;
+  const int b = (int)((e / HID) % bsz);
+  const float g = df[e];
+  const int s = sel[e];
+  for (int m = 0; m < nmod; ++m) {
+    const float part = mode == UGN_FUSE_AVG ? g / (float)nmod : (s == m ? g : 0.f);
+    mp.dx[m][e] = part * mp.use[m][b];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// batch-axis L2 normalisation: one thread per (bin, feature) column of length B
+// ------------------------------------------------------------------------------------------------------
+__global__ void l2norm_fwd_kernel(const float* __restrict__ f, float* __restrict__ sig, int bsz) {
+  const int col = blockIdx.x * blockDim.x + threadIdx.x;
+  if (col >= NBINS * HID) return;
+  const int k = col / HID, d = col % HID;
+  const float* src = f + (size_t)k * bsz * HID + d;
+  float ss = 0.f;
+  for (int b = 0; b < bsz; ++b) { const float v = src[(size_t)b * HID]; ss = fmaf(v, v, ss); }
+  const float inv = 1.f / sqrtf(fmaxf(ss, 1e-12f));
+  float* dst = sig + (size_t)k * bsz * HID + d;
+  for (int b = 0; b < bsz; ++b) dst[(size_t)b * HID] = src[(size_t)b * HID] * inv;
+}
+
+__global__ void l2norm_bwd_kernel(const float* __restrict__ f, const float* __restrict__ sig, const float* __restrict__ dsig,
+                                  float* __restrict__ df, int bsz) {
+  const int col = blockIdx.x * blockDim.x + threadIdx.x;
+  if (col >= NBINS * HID) return;
+  const int k = col / HID, d = col % HID;
+  const size_t base = (size_t)k * bsz * HID + d;
+  float ss = 0.f, dot = 0.f;
+  for (int b = 0; b < bsz; ++b) {
+    const float v = f[base + (size_t)b * HID];
+    ss = fmaf(v, v, ss);
+    dot = fmaf(sig[base + (size_t)b * HID], dsig[base + (size_t)b * HID], dot);
+  }
+  const bool active = ss > 1e-12f;  // below the clamp the norm is a constant
+  const float inv = 1.f / sqrtf(fmaxf(ss, 1e-12f));
+  for (int b = 0; b < bsz; ++b) {
+    const size_t o = base + (size_t)b * HID;
+    const float g = dsig[o];
+    df[o] = active ? (g - sig[o] * dot) * inv : g * inv;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// classification head
+// ------------------------------------------------------------------------------------------------------
+constexpr int HD_BT = 8;
+
+// part[k][b][c] = sum_d sig[k][b][d] * wc[(k*256+d)*ncls + c]
+__global__ __launch_bounds__(256) void head_partial_kernel(const float* __restrict__ sig, const float* __restrict__ wc,
+                                                           float* __restrict__ part, int bsz, int ncls) {
+  __shared__ float sS[HD_BT][HID];
+  const int k = blockIdx.x, c = threadIdx.x;
+  for (int b0 = 0; b0 < bsz; b0 += HD_BT) {
+    __syncthreads();
+    for (int e = threadIdx.x; e < HD_BT * HID; e += 256) {
+      const int bb = e / HID, d = e % HID;
+      sS[bb][d] = b0 + bb < bsz ? sig[((size_t)k * bsz + b0 + bb) * HID + d] : 0.f;
+    }
+    __syncthreads();
+    if (c < ncls) {
+      float acc[HD_BT];
+#pragma unroll
+      for (int bb = 0; bb < HD_BT; ++bb) acc[bb] = 0.f;
+      for (int d = 0; d < HID; ++d) {
+        const float wv = wc[((size_t)k * HID + d) * ncls + c];
+#pragma unroll
+        for (int bb = 0; bb < HD_BT; ++bb) acc[bb] = fmaf(sS[bb][d], wv, acc[bb]);
+      }
+#pragma unroll
+      for (int bb = 0; bb < HD_BT; ++bb)
+        if (b0 + bb < bsz) part[((size_t)k * bsz + b0 + bb) * ncls + c] = acc[bb];
+    }
+  }
+}
+
+__device__ __forceinline__ float block_reduce(float v, float* sRed, bool is_max) {
+  // 256 threads
+  for (int off = 32; off > 0; off >>= 1) {
+    const float o = __shfl_down(v, off, 64);
+    v = is_max ? fmaxf(v, o) : v + o;
+  }
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sRed[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float r = sRed[0];
+  for (int i = 1; i < 4; ++i) r = is_max ? fmaxf(r, sRed[i]) : r + sRed[i];
+  return r;
+}
+
+// one workgroup per sample: logits = bc + sum_k part; softmax; loss; dlogits; top-1 hit
+__global__ __launch_bounds__(256) void head_softmax_kernel(const float* __restrict__ part, const float* __restrict__ bc,
+                                                           const float* __restrict__ onehot, float* __restrict__ probs,
+                                                           float* __restrict__ row_loss, float* __restrict__ dlogits,
+                                                           float* __restrict__ hit, float grad_scale, int bsz, int ncls) {
+  __shared__ float sRed[4];
+  __shared__ int sArg[2];
+  const int b = blockIdx.x, c = threadIdx.x;
+  float z = -INFINITY, t = 0.f;
+  if (c < ncls) {
+    z = bc[c];
+    for (int k = 0; k < NBINS; ++k) z += part[((size_t)k * bsz + b) * ncls + c];
+    t = onehot[(size_t)b * ncls + c];
+  }
+  const float zmax = block_reduce(z, sRed, true);
+  const float ex = c < ncls ? expf(z - zmax) : 0.f;
+  const float esum = block_reduce(ex, sRed, false);
+  const float lse = logf(esum);
+  const float logp = (z - zmax) - lse;
+  const float lsum = block_reduce(c < ncls ? -t * logp : 0.f, sRed, false);
+  const float tmax = block_reduce(c < ncls ? t : -INFINITY, sRed, true);
+  if (c == 0) { sArg[0] = ncls; sArg[1] = ncls; }
+  __syncthreads();
+  if (c < ncls && z == zmax) atomicMin(&sArg[0], c);   // first maximum, as np/tf argmax
+  if (c < ncls && t == tmax) atomicMin(&sArg[1], c);
+  __syncthreads();
+  if (c < ncls) {
+    const float p = ex / esum;
+    probs[(size_t)b * ncls + c] = p;
+    dlogits[(size_t)b * ncls + c] = (p - t) * grad_scale;
+  }
+  if (c == 0) {
+    row_loss[b] = lsum;
+    hit[b] = sArg[0] == sArg[1] ? 1.f : 0.f;
+  }
+}
+
+constexpr int HB_BT = 16;
+
+__global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__ sig, const float* __restrict__ wc,
+                                                       const float* __restrict__ dlogits, float* __restrict__ dwc,
+                                                       float* __restrict__ dbc, float* __restrict__ dsig, int accumulate,
+                                                       int bsz, int ncls) {
+  __shared__ float sS[HB_BT][HID];    // 16 KB
+  __shared__ float sL[HB_BT][HID];    // dlogits rows (ncls <= 256), 16 KB
+  const int k = blockIdx.x, tid = threadIdx.x;
+  float bsum = 0.f;
+  for (int b0 = 0; b0 < bsz; b0 += HB_BT) {
+    const int nb = min(HB_BT, bsz - b0);
+    __syncthreads();
+    for (int e = tid; e < HB_BT * HID; e += 256) {
+      const int bb = e / HID, d = e % HID;
+      sS[bb][d] = bb < nb ? sig[((size_t)k * bsz + b0 + bb) * HID + d] : 0.f;
+      sL[bb][d] = (bb < nb && d < ncls) ? dlogits[(size_t)(b0 + bb) * ncls + d] : 0.f;
+    }
+    __syncthreads();
+    // dwc rows of this bin: thread = class c
+    if (tid < ncls) {
+      float lreg[HB_BT];
+#pragma unroll
+      for (int bb = 0; bb < HB_BT; ++bb) { lreg[bb] = sL[bb][tid]; bsum += lreg[bb]; }
+      for (int d = 0; d < HID; ++d) {
+        float acc = 0.f;
+#pragma unroll
+        for (int bb = 0; bb < HB_BT; ++bb) acc = fmaf(sS[bb][d], lreg[bb], acc);
+        const size_t o = ((size_t)k * HID + d) * ncls + tid;
+        if (b0 == 0) dwc[o] = acc; else dwc[o] += acc;
+      }
+    }
+    // dsig[k][b][d] (+)= sum_c dlogits[b][c] * wc[(k*256+d)][c]; thread = d
+    {
+      float acc[HB_BT];
+#pragma unroll
+      for (int bb = 0; bb < HB_BT; ++bb) acc[bb] = 0.f;
+      const float* wrow = wc + ((size_t)k * HID + tid) * ncls;
+      for (int c = 0; c < ncls; ++c) {
+        const float wv = wrow[c];
+#pragma unroll
+        for (int bb = 0; bb < HB_BT; ++bb) acc[bb] = fmaf(sL[bb][c], wv, acc[bb]);
+      }
+#pragma unroll
+      for (int bb = 0; bb < HB_BT; ++bb)
+        if (bb < nb) {
+          const size_t o = ((size_t)k * bsz + b0 + bb) * HID + tid;
+          dsig[o] = accumulate ? dsig[o] + acc[bb] : acc[bb];
+        }
+    }
+  }
+  if (k == 0 && tid < ncls) dbc[tid] = bsum;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// batch-all triplet loss: one workgroup per bin, Gram/distance matrix in LDS (m <= 128)
+// ------------------------------------------------------------------------------------------------------
+constexpr int TR_DC = 32;  // feature chunk staged in LDS
+
+__global__ __launch_bounds__(256) void triplet_kernel(const float* __restrict__ sig, const int32_t* __restrict__ hp,
+                                                      const int32_t* __restrict__ hn, int kp, int kn, float margin,
+                                                      float* __restrict__ bin_loss, float* __restrict__ bin_num,
+                                                      float* __restrict__ dsig, float grad_scale, int m) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* sD = smem;                 // [m*m] Gram -> distance -> S
+  float* sG = smem + m * m;         // [m*m] dL/d(dist) -> dL/d(sqdist)
+  float* sY = sG + m * m;           // [m][TR_DC+1]
+  __shared__ float sRed[4];
+  const int k = blockIdx.x, tid = threadIdx.x;
+  const float* Y = sig + (size_t)k * m * HID;
+  const int mm = m * m;
+
+  for (int p = tid; p < mm; p += 256) { sD[p] = 0.f; sG[p] = 0.f; }
+  for (int d0 = 0; d0 < HID; d0 += TR_DC) {
+    __syncthreads();
+    for (int e = tid; e < m * TR_DC; e += 256) sY[(e / TR_DC) * (TR_DC + 1) + (e % TR_DC)] = Y[(size_t)(e / TR_DC) * HID + d0 + (e % TR_DC)];
+    __syncthreads();
+    for (int p = tid; p < mm; p += 256) {
+      const int i = p / m, j = p % m;
+      if (j < i) continue;  // symmetric: compute the upper triangle, mirror below
+      float acc = 0.f;
+#pragma unroll
+      for (int dd = 0; dd < TR_DC; ++dd) acc = fmaf(sY[i * (TR_DC + 1) + dd], sY[j * (TR_DC + 1) + dd], acc);
+      sD[p] += acc;
+    }
+  }
+  __syncthreads();
+  for (int p = tid; p < mm; p += 256) {
+    const int i = p / m, j = p % m;
+    if (j < i) sD[p] = sD[j * m + i];
+  }
+  __syncthreads();
+  // squared norms = diagonal of the Gram matrix (same summation order -> d_ii is exactly 0)
+  float* sN = sY;  // reuse: m floats
+  for (int i = tid; i < m; i += 256) sN[i] = sD[i * m + i];
+  __syncthreads();
+  for (int p = tid; p < mm; p += 256) {
+    const int i = p / m, j = p % m;
+    const float q = fmaxf(sN[i] + sN[j] - 2.f * sD[p], 0.f);
+    // reference: sqrt(q + [q<=0]*1e-16) * [q>0]  ==  q > 0 ? sqrt(q) : 0
+    sD[p] = q > 0.f ? sqrtf(q) : 0.f;
+  }
+  __syncthreads();
+  // pass A: items (row r, positive a): hinge sum, active count, gradient of the positive distance
+  float lsum = 0.f, lnum = 0.f;
+  for (int it = tid; it < m * kp; it += 256) {
+    const int r = it / kp;
+    const int pi = hp[it];
+    const float dpv = sD[pi] + margin;
+    float cnt = 0.f;
+    for (int b = 0; b < kn; ++b) {
+      const float h = dpv - sD[hn[r * kn + b]];
+      if (h > 0.f) { lsum += h; cnt += 1.f; }
+    }
+    lnum += cnt;
+    sG[pi] = cnt;
+  }
+  // pass B: items (row r, negative b): gradient of the negative distance
+  for (int it = tid; it < m * kn; it += 256) {
+    const int r = it / kn;
+    const int ni = hn[it];
+    const float dnv = sD[ni];
+    float cnt = 0.f;
+    for (int a = 0; a < kp; ++a) {
+      const float h = sD[hp[r * kp + a]] + margin - dnv;
+      if (h > 0.f) cnt += 1.f;
+    }
+    sG[ni] = -cnt;
+  }
+  const float tsum = block_reduce(lsum, sRed, false);
+  const float tnum = block_reduce(lnum, sRed, false);
+  if (tid == 0) {
+    bin_loss[k] = tnum != 0.f ? tsum / tnum : 0.f;
+    bin_num[k] = tnum;
+  }
+  const float scale = tnum != 0.f ? grad_scale / (tnum * (float)NBINS) : 0.f;
+  __syncthreads();
+  // dL/d(sqdist) = dL/d(dist) / (2 dist), 0 where dist == 0
+  for (int p = tid; p < mm; p += 256) {
+    const float d = sD[p];
+    sG[p] = d > 0.f ? sG[p] * scale / (2.f * d) : 0.f;
+  }
+  __syncthreads();
+  // S = dq + dq^T into sD; row sums into sN
+  for (int p = tid; p < mm; p += 256) {
+    const int i = p / m, j = p % m;
+    sD[p] = sG[p] + sG[j * m + i];
+  }
+  __syncthreads();
+  for (int i = tid; i < m; i += 256) {
+    float s = 0.f;
+    for (int j = 0; j < m; ++j) s += sD[i * m + j];
+    sN[i] = s;
+  }
+  __syncthreads();
+  // dY_i = 2 * (rows_i * Y_i - sum_j S_ij Y_j); thread = feature d
+  for (int i = 0; i < m; ++i) {
+    float acc = sN[i] * Y[(size_t)i * HID + tid];
+    for (int j = 0; j < m; ++j) acc = fmaf(-sD[i * m + j], Y[(size_t)j * HID + tid], acc);
+    dsig[((size_t)k * m + i) * HID + tid] = 2.f * acc;
+  }
+}
+
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                            size_t n, float lr_t, float b1, float b2, float eps, float gscale) {
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n) return;
+  const float gv = g[e] * gscale;
+  const float mv = b1 * m[e] + (1.f - b1) * gv;
+  const float vv = b2 * v[e] + (1.f - b2) * gv * gv;
+  m[e] = mv;
+  v[e] = vv;
+  p[e] = p[e] - lr_t * mv / (sqrtf(vv) + eps);
+}
+
+}  // namespace
+
+extern "C" int ugn_binfc_fwd(const float* feat, const float* w, float* out, int b, void* stream) {
+  UGN_REQUIRE(feat && w && out && b > 0, "ugn_binfc_fwd: bad arguments");
+  hipLaunchKernelGGL(binfc_fwd_kernel, dim3(NBINS), dim3(256), 0, (hipStream_t)stream, feat, w, out, b);
+  UGN_CHECK_LAUNCH("binfc_fwd");
+  return 0;
+}
+
+extern "C" int ugn_binfc_bwd(const float* feat, const float* w, const float* dout, float* dw, float* dfeat, int b,
+                             void* stream) {
+  UGN_REQUIRE(feat && w && dout && dw && dfeat && b > 0, "ugn_binfc_bwd: bad arguments");
+  hipLaunchKernelGGL(binfc_bwd_kernel, dim3(NBINS), dim3(256), 0, (hipStream_t)stream, feat, w, dout, dw, dfeat, b);
+  UGN_CHECK_LAUNCH("binfc_bwd");
+  return 0;
+}
+
+extern "C" int ugn_gate_fuse_fwd(const float* const* outs_host, const float* const* uses_host, int nmod, int mode,
+                                 float* fused, uint8_t* sel, int b, void* stream) {
+  UGN_REQUIRE(outs_host && uses_host && fused && sel && b > 0, "ugn_gate_fuse_fwd: bad arguments");
+  UGN_REQUIRE(nmod >= 1 && nmod <= 4, "ugn_gate_fuse_fwd: nmod must be 1..4 (got %d)", nmod);
+  UGN_REQUIRE(mode >= 0 && mode <= 2, "ugn_gate_fuse_fwd: unknown mode %d", mode);
+  ModPtrs mp = {};
+  for (int m = 0; m < nmod; ++m) { mp.x[m] = outs_host[m]; mp.use[m] = uses_host[m]; }
+  const size_t total = (size_t)NBINS * b * HID;
+  hipLaunchKernelGGL(gate_fuse_fwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, mp,
+                     nmod, mode, fused, sel, b, total);
+  UGN_CHECK_LAUNCH("gate_fuse_fwd");
+  return 0;
+}
+
+extern "C" int ugn_gate_fuse_bwd(const float* dfused, const uint8_t* sel, const float* const* uses_host,
+                                 float* const* douts_host, int nmod, int mode, int b, void* stream) {
+  UGN_REQUIRE(dfused && sel && uses_host && douts_host && b > 0, "ugn_gate_fuse_bwd: bad arguments");
+  UGN_REQUIRE(nmod >= 1 && nmod <= 4, "ugn_gate_fuse_bwd: nmod must be 1..4 (got %d)", nmod);
+  ModPtrs mp = {};
+  for (int m = 0; m < nmod; ++m) { mp.dx[m] = douts_host[m]; mp.use[m] = uses_host[m]; }
+  const size_t total = (size_t)NBINS * b * HID;
+  hipLaunchKernelGGL(gate_fuse_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, mp,
+                     nmod, mode, dfused, sel, b, total);
+  UGN_CHECK_LAUNCH("gate_fuse_bwd");
+  return 0;
+}
+
+extern "C" int ugn_l2norm_batch_fwd(const float* f, float* sig, int b, void* stream) {
+  UGN_REQUIRE(f && sig && b > 0, "ugn_l2norm_batch_fwd: bad arguments");
+  hipLaunchKernelGGL(l2norm_fwd_kernel, dim3(NBINS * HID / 64), dim3(64), 0, (hipStream_t)stream, f, sig, b);
+  UGN_CHECK_LAUNCH("l2norm_fwd");
+  return 0;
+}
+
+extern "C" int ugn_l2norm_batch_bwd(const float* f, const float* sig, const float* dsig, float* df, int b, void* stream) {
+  UGN_REQUIRE(f && sig && dsig && df && b > 0, "ugn_l2norm_batch_bwd: bad arguments");
+  hipLaunchKernelGGL(l2norm_bwd_kernel, dim3(NBINS * HID / 64), dim3(64), 0, (hipStream_t)stream, f, sig, dsig, df, b);
+  UGN_CHECK_LAUNCH("l2norm_bwd");
+  return 0;
+}
+
+extern "C" int ugn_head_fwd(const float* sig, const float* wc, const float* bc, const float* onehot, float* part,
+                            float* probs, float* row_loss, float* dlogits, float* hit, float grad_scale, int b, int ncls,
+                            void* stream) {
+  UGN_REQUIRE(sig && wc && bc && onehot && part && probs && row_loss && dlogits && hit && b > 0,
+              "ugn_head_fwd: bad arguments");
+  UGN_REQUIRE(ncls >= 1 && ncls <= 256, "ugn_head_fwd: ncls must be 1..256 (got %d)", ncls);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(head_partial_kernel, dim3(NBINS), dim3(256), 0, st, sig, wc, part, b, ncls);
+  hipLaunchKernelGGL(head_softmax_kernel, dim3(b), dim3(256), 0, st, part, bc, onehot, probs, row_loss, dlogits, hit,
+                     grad_scale, b, ncls);
+  UGN_CHECK_LAUNCH("head_fwd");
+  return 0;
+}
+
+extern "C" int ugn_head_bwd(const float* sig, const float* wc, const float* dlogits, float* dwc, float* dbc, float* dsig,
+                            int accumulate, int b, int ncls, void* stream) {
+  UGN_REQUIRE(sig && wc && dlogits && dwc && dbc && dsig && b > 0, "ugn_head_bwd: bad arguments");
+  UGN_REQUIRE(ncls >= 1 && ncls <= 256, "ugn_head_bwd: ncls must be 1..256 (got %d)", ncls);
+  hipLaunchKernelGGL(head_bwd_kernel, dim3(NBINS), dim3(256), 0, (hipStream_t)stream, sig, wc, dlogits, dwc, dbc, dsig,
+                     accumulate, b, ncls);
+  UGN_CHECK_LAUNCH("head_bwd");
+  return 0;
+}
+
+extern "C" int ugn_triplet_indices_host(const int32_t* labels, int m, int32_t* hp, int32_t* hn, int* kp, int* kn) {
+  UGN_REQUIRE(labels && hp && hn && kp && kn && m > 0, "ugn_triplet_indices_host: bad arguments");
+  int np = 0, nn = 0;
+  for (int i = 0; i < m; ++i)
+    for (int j = 0; j < m; ++j) {
+      if (labels[i] == labels[j]) hp[np++] = i * m + j;
+      else hn[nn++] = i * m + j;
+    }
+  UGN_REQUIRE(np % m == 0 && nn % m == 0,
+              "triplet_loss: reshape([n,m,-1,1]) needs pair counts divisible by the batch size (m=%d, positives=%d, "
+              "negatives=%d)", m, np, nn);
+  *kp = np / m;
+  *kn = nn / m;
+  return 0;
+}
+
+extern "C" int ugn_triplet_fwd_bwd(const float* sig, const int32_t* hp, const int32_t* hn, int kp, int kn, float margin,
+                                   float* bin_loss, float* bin_num, float* dsig, float grad_scale, int m, void* stream) {
+  UGN_REQUIRE(sig && hp && hn && bin_loss && bin_num && dsig, "ugn_triplet_fwd_bwd: null pointer");
+  UGN_REQUIRE(m >= 1 && m <= 128, "ugn_triplet_fwd_bwd: batch size must be 1..128 (got %d)", m);
+  UGN_REQUIRE(kp >= 0 && kn >= 0 && kp + kn == m, "ugn_triplet_fwd_bwd: kp + kn must equal m (kp=%d kn=%d m=%d)", kp, kn, m);
+  const int lds = (2 * m * m + m * (TR_DC + 1)) * (int)sizeof(float);
+  static int lds_set = 0;
+  if (lds > lds_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)triplet_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) { ugn_set_error("triplet: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
+    lds_set = lds;
+  }
+  hipLaunchKernelGGL(triplet_kernel, dim3(NBINS), dim3(256), lds, (hipStream_t)stream, sig, hp, hn, kp, kn, margin,
+                     bin_loss, bin_num, dsig, grad_scale, m);
+  UGN_CHECK_LAUNCH("triplet");
+  return 0;
+}
+
+extern "C" int ugn_adam_step(float* p, const float* g, float* m, float* v, size_t n, float lr_t, float b1, float b2,
+                             float eps, float grad_scale, void* stream) {
+  UGN_REQUIRE(p && g && m && v, "ugn_adam_step: null pointer");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr_t,
+                     b1, b2, eps, grad_scale);
+  UGN_CHECK_LAUNCH("adam");
+  return 0;
+}

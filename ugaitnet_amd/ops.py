@@ -1,0 +1,233 @@
+"""Thin host wrappers over the C ABI: torch tensors are used as HBM buffers only (allocation + pointers).
+
+Every function enqueues HIP kernels on torch's current stream and returns device tensors.  No arithmetic
+happens in torch here.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import call, ptr, ptr_array
+
+F32 = torch.float32
+U8 = torch.uint8
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _chk(t, dtype=F32):
+    assert t.is_cuda and t.is_contiguous() and t.dtype == dtype, (t.device, t.is_contiguous(), t.dtype)
+    return t
+
+
+class Workspace:
+    """Grow-only scratch buffer for the weight-gradient partial slabs."""
+
+    def __init__(self):
+        self.buf = None
+
+    def get(self, nbytes, device):
+        if self.buf is None or self.buf.numel() < nbytes or self.buf.device != device:
+            self.buf = torch.empty(max(int(nbytes), 1), dtype=U8, device=device)
+        return self.buf
+
+
+_WS = Workspace()
+
+
+def conv5x5_in_fwd(x, w, out=None):
+    n, cin = x.shape[0], x.shape[3]
+    _chk(x), _chk(w)
+    out = torch.empty((n, 64, 64, 32), dtype=F32, device=x.device) if out is None else out
+    call("ugn_conv5x5_in_fwd", ptr(x), ptr(w), ptr(out), n, cin, _stream())
+    return out
+
+
+def conv5x5_in_wgrad(x, dz1, dw=None):
+    n, cin = x.shape[0], x.shape[3]
+    _chk(x), _chk(dz1)
+    dw = torch.empty((5, 5, cin, 32), dtype=F32, device=x.device) if dw is None else dw
+    nbytes = _lib.load().ugn_conv5x5_in_wgrad_ws(n, cin)
+    ws = _WS.get(nbytes, x.device)
+    call("ugn_conv5x5_in_wgrad", ptr(x), ptr(dz1), ptr(dw), n, cin, ptr(ws), ws.numel(), _stream())
+    return dw
+
+
+def pack3x3(w, out=None):
+    _chk(w)
+    cin, cout = w.shape[2], w.shape[3]
+    out = torch.empty((9, cout, cin), dtype=F32, device=w.device) if out is None else out
+    call("ugn_pack3x3", ptr(w), ptr(out), cin, cout, _stream())
+    return out
+
+
+def conv3x3_fwd(x, wp, pool, out=None, idx=None):
+    """x [n,hw,hw,cin], wp packed [9,cout,cin] -> LeakyReLU(conv) ([n,hw,hw,cout]) or pooled + argmax index."""
+    _chk(x), _chk(wp)
+    n, hw, cin = x.shape[0], x.shape[1], x.shape[3]
+    cout = wp.shape[1]
+    ho = hw // 2 if pool else hw
+    out = torch.empty((n, ho, ho, cout), dtype=F32, device=x.device) if out is None else out
+    if pool and idx is None:
+        idx = torch.empty((n, ho, ho, cout), dtype=U8, device=x.device)
+    call("ugn_conv3x3_fwd", ptr(x), ptr(wp), ptr(out), ptr(idx) if pool else None, n, hw, cin, cout, int(bool(pool)),
+         _stream())
+    return (out, idx) if pool else out
+
+
+def conv3x3_dgrad(dz, w, hw, dz_idx=None, act=None, addend=None, out=None, raw_out=None):
+    """w HWIO [3,3,cin,cout]; dz [n,hw,hw,cout] or pooled [n,hw/2,hw/2,cout] with dz_idx."""
+    _chk(dz), _chk(w)
+    n, cin, cout = dz.shape[0], w.shape[2], w.shape[3]
+    out = torch.empty((n, hw, hw, cin), dtype=F32, device=dz.device) if out is None else out
+    call("ugn_conv3x3_dgrad", ptr(dz), ptr(dz_idx), ptr(w), ptr(act), ptr(addend), ptr(out), ptr(raw_out), n, hw, cin,
+         cout, _stream())
+    return out
+
+
+def conv3x3_wgrad(x, dz, cout, dz_idx=None, dw=None):
+    _chk(x), _chk(dz)
+    n, hw, cin = x.shape[0], x.shape[1], x.shape[3]
+    dw = torch.empty((3, 3, cin, cout), dtype=F32, device=x.device) if dw is None else dw
+    nbytes = _lib.load().ugn_conv3x3_wgrad_ws(n, hw, cin, cout)
+    if nbytes == 0:
+        raise ValueError("conv3x3_wgrad: unsupported shape hw=%d cin=%d cout=%d" % (hw, cin, cout))
+    ws = _WS.get(nbytes, x.device)
+    call("ugn_conv3x3_wgrad", ptr(x), ptr(dz), ptr(dz_idx), ptr(dw), n, hw, cin, cout, ptr(ws), ws.numel(), _stream())
+    return dw
+
+
+def setmax_fwd(p, b, l, addend=None, m=None, sum_out=None):
+    _chk(p)
+    s = p.numel() // (b * l)
+    shape = tuple(p.shape[1:])
+    m = torch.empty((b,) + shape, dtype=F32, device=p.device) if m is None else m
+    if addend is not None and sum_out is None:
+        sum_out = torch.empty_like(m)
+    call("ugn_setmax_fwd", ptr(p), ptr(addend), ptr(m), ptr(sum_out), b, l, s, _stream())
+    return (m, sum_out) if addend is not None else m
+
+
+def setmax_bwd(p, dm, b, l, apply_lrelu, out=None):
+    _chk(p), _chk(dm)
+    s = p.numel() // (b * l)
+    out = torch.empty_like(p) if out is None else out
+    call("ugn_setmax_bwd", ptr(p), ptr(dm), ptr(out), b, l, s, int(bool(apply_lrelu)), _stream())
+    return out
+
+
+def hpp_fwd(a, s3, feat=None):
+    b = a.shape[0]
+    feat = torch.empty((62, b, 128), dtype=F32, device=a.device) if feat is None else feat
+    call("ugn_hpp_fwd", ptr(_chk(a)), ptr(_chk(s3)), ptr(feat), b, _stream())
+    return feat
+
+
+def hpp_bwd(a, s3, b4, dfeat, dm3=None, dzb4=None):
+    b = a.shape[0]
+    dm3 = torch.empty_like(a) if dm3 is None else dm3
+    dzb4 = torch.empty_like(a) if dzb4 is None else dzb4
+    call("ugn_hpp_bwd", ptr(_chk(a)), ptr(_chk(s3)), ptr(_chk(b4)), ptr(_chk(dfeat)), ptr(dm3), ptr(dzb4), b, _stream())
+    return dm3, dzb4
+
+
+def binfc_fwd(feat, w, out=None):
+    b = feat.shape[1]
+    out = torch.empty((62, b, 256), dtype=F32, device=feat.device) if out is None else out
+    call("ugn_binfc_fwd", ptr(_chk(feat)), ptr(_chk(w)), ptr(out), b, _stream())
+    return out
+
+
+def binfc_bwd(feat, w, dout, dw=None, dfeat=None):
+    b = feat.shape[1]
+    dw = torch.empty_like(w) if dw is None else dw
+    dfeat = torch.empty_like(feat) if dfeat is None else dfeat
+    call("ugn_binfc_bwd", ptr(_chk(feat)), ptr(_chk(w)), ptr(_chk(dout)), ptr(dw), ptr(dfeat), b, _stream())
+    return dw, dfeat
+
+
+def gate_fuse_fwd(outs, uses, mode, fused=None, sel=None):
+    b = outs[0].shape[1]
+    fused = torch.empty_like(outs[0]) if fused is None else fused
+    sel = torch.empty(outs[0].shape, dtype=U8, device=outs[0].device) if sel is None else sel
+    call("ugn_gate_fuse_fwd", ptr_array(outs), ptr_array(uses), len(outs), _lib.FUSE_MODES[mode], ptr(fused), ptr(sel), b,
+         _stream())
+    return fused, sel
+
+
+def gate_fuse_bwd(dfused, sel, uses, mode, douts=None):
+    b = dfused.shape[1]
+    douts = [torch.empty_like(dfused) for _ in uses] if douts is None else douts
+    call("ugn_gate_fuse_bwd", ptr(_chk(dfused)), ptr(sel), ptr_array(uses), ptr_array(douts), len(uses),
+         _lib.FUSE_MODES[mode], b, _stream())
+    return douts
+
+
+def l2norm_batch_fwd(f, sig=None):
+    sig = torch.empty_like(f) if sig is None else sig
+    call("ugn_l2norm_batch_fwd", ptr(_chk(f)), ptr(sig), f.shape[1], _stream())
+    return sig
+
+
+def l2norm_batch_bwd(f, sig, dsig, df=None):
+    df = torch.empty_like(f) if df is None else df
+    call("ugn_l2norm_batch_bwd", ptr(_chk(f)), ptr(_chk(sig)), ptr(_chk(dsig)), ptr(df), f.shape[1], _stream())
+    return df
+
+
+def head_fwd(sig, wc, bc, onehot, grad_scale, bufs=None):
+    b, ncls = sig.shape[1], wc.shape[1]
+    dev = sig.device
+    if bufs is None:
+        bufs = dict(part=torch.empty((62, b, ncls), dtype=F32, device=dev),
+                    probs=torch.empty((b, ncls), dtype=F32, device=dev),
+                    row_loss=torch.empty((b,), dtype=F32, device=dev),
+                    dlogits=torch.empty((b, ncls), dtype=F32, device=dev),
+                    hit=torch.empty((b,), dtype=F32, device=dev))
+    call("ugn_head_fwd", ptr(_chk(sig)), ptr(_chk(wc)), ptr(_chk(bc)), ptr(_chk(onehot)), ptr(bufs["part"]),
+         ptr(bufs["probs"]), ptr(bufs["row_loss"]), ptr(bufs["dlogits"]), ptr(bufs["hit"]), float(grad_scale), b, ncls,
+         _stream())
+    return bufs
+
+
+def head_bwd(sig, wc, dlogits, dsig, accumulate, dwc=None, dbc=None):
+    b, ncls = sig.shape[1], wc.shape[1]
+    dwc = torch.empty_like(wc) if dwc is None else dwc
+    dbc = torch.empty((ncls,), dtype=F32, device=sig.device) if dbc is None else dbc
+    call("ugn_head_bwd", ptr(_chk(sig)), ptr(_chk(wc)), ptr(_chk(dlogits)), ptr(dwc), ptr(dbc), ptr(dsig),
+         int(bool(accumulate)), b, ncls, _stream())
+    return dwc, dbc
+
+
+def triplet_indices(labels):
+    """labels: 1-D integer array (host).  Returns (hp, hn, kp, kn) with hp/hn int32 numpy arrays."""
+    lab = np.ascontiguousarray(np.asarray(labels).reshape(-1), dtype=np.int32)
+    m = lab.shape[0]
+    hp = np.empty(m * m, dtype=np.int32)
+    hn = np.empty(m * m, dtype=np.int32)
+    kp, kn = C.c_int(0), C.c_int(0)
+    call("ugn_triplet_indices_host", lab.ctypes.data_as(C.c_void_p), m, hp.ctypes.data_as(C.c_void_p),
+         hn.ctypes.data_as(C.c_void_p), C.byref(kp), C.byref(kn))
+    return hp[:m * kp.value].copy(), hn[:m * kn.value].copy(), kp.value, kn.value
+
+
+def triplet_fwd_bwd(sig, hp, hn, kp, kn, margin, grad_scale, bin_loss=None, bin_num=None, dsig=None):
+    m = sig.shape[1]
+    dev = sig.device
+    bin_loss = torch.empty((62,), dtype=F32, device=dev) if bin_loss is None else bin_loss
+    bin_num = torch.empty((62,), dtype=F32, device=dev) if bin_num is None else bin_num
+    dsig = torch.empty_like(sig) if dsig is None else dsig
+    call("ugn_triplet_fwd_bwd", ptr(_chk(sig)), ptr(hp), ptr(hn), kp, kn, float(margin), ptr(bin_loss), ptr(bin_num),
+         ptr(dsig), float(grad_scale), m, _stream())
+    return bin_loss, bin_num, dsig
+
+
+def adam_step(p, g, m, v, lr_t, b1=0.9, b2=0.999, eps=1e-7, grad_scale=1.0):
+    call("ugn_adam_step", ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), float(lr_t), float(b1), float(b2), float(eps),
+         float(grad_scale), _stream())
