@@ -272,11 +272,15 @@ def triplet_all_bwd(emb, aux, dloss=1.0):
 
 
 def adam_step(p, g, m, v, t, lr=1e-4, b1=0.9, b2=0.999, eps=1e-7):
-    """keras Adam (mains/mj_trainUWYHGaitNet_DataGen_CasiaB.py:227), t = 1-based step."""
-    m[...] = b1 * m + (1 - b1) * g
-    v[...] = b2 * v + (1 - b2) * g * g
-    lr_t = lr * np.sqrt(1 - b2 ** t) / (1 - b1 ** t)
-    p[...] = p - (lr_t * m / (np.sqrt(v) + eps)).astype(p.dtype)
+    """keras Adam (mains/mj_trainUWYHGaitNet_DataGen_CasiaB.py:227), t = 1-based step.
+    As in TF's resource-apply kernel the hyper-parameters are cast to the variable dtype first, so
+    (1 - beta) is formed in that dtype; lr_t = lr * sqrt(1 - b2^t) / (1 - b1^t) is a host scalar."""
+    dt = p.dtype.type
+    b1v, b2v, one = dt(b1), dt(b2), dt(1)
+    m[...] = b1v * m + (one - b1v) * g
+    v[...] = b2v * v + (one - b2v) * g * g
+    lr_t = dt(lr * np.sqrt(1 - b2 ** t) / (1 - b1 ** t))
+    p[...] = p - lr_t * m / (np.sqrt(v) + dt(eps))
 
 
 # --------------------------------------------------------------------------------------

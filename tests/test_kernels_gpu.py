@@ -303,6 +303,6 @@ def test_adam(dev):
     t = 7
     lr_t = 1e-4 * np.sqrt(1 - 0.999 ** t) / (1 - 0.9 ** t)
     ops.adam_step(pt, T(g, dev), mt, vt, lr_t)
-    p64, m64, v64 = p.astype(np.float64), m.astype(np.float64), v.astype(np.float64)
-    O.adam_step(p64, g.astype(np.float64), m64, v64, t)
-    close(pt, p64, 1e-6, "adam p"); close(mt, m64, 1e-6, "adam m"); close(vt, v64, 1e-6, "adam v")
+    pr, mr, vr = p.copy(), m.copy(), v.copy()
+    O.adam_step(pr, g, mr, vr, t)       # fp32 oracle: hyper-parameters rounded to fp32 as TF does
+    close(pt, pr, 1e-6, "adam p"); close(mt, mr, 1e-6, "adam m"); close(vt, vr, 1e-6, "adam v")

@@ -1,0 +1,362 @@
+"""Device-side execution of the UGaitNet gaitset hot path: kernel sequencing and HBM buffer ownership.
+
+This is the host half of the path SURVEY.md section 8(a) rows A1-A16: it owns the parameters (one flat fp32 buffer,
+so Adam and the RCCL gradient all-reduce are one launch / one collective per bucket), the saved activations, and
+the order in which the HIP kernels of libugaitnet_hip.so run.  torch is used for allocation, streams and
+torch.distributed only; every arithmetic op is a C-ABI call (ugaitnet_amd.ops).
+
+Reference call sites mirrored: nets/mj_uwyhNets_ba.py:419-484 (encoder), :668-935 and :1031-1299 (assembly),
+nets/triplet_loss_all.py:8-77 (loss), mains/mj_trainUWYHGaitNet_DataGen_CasiaB.py:342-349 (data parallel).
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+import torch
+
+from . import ops
+
+F32 = torch.float32
+
+# name, kernel, cin (None = modality channels), cout, spatial size, pooled -- creation order of the reference's Conv2D
+# layers (nets/mj_uwyhNets_ba.py:428-462), which is also the Keras weight order.
+CONV_SPECS = (
+    ("a1", 5, None, 32, 64, False), ("a2", 3, 32, 32, 64, True),
+    ("b1", 3, 32, 64, 32, False), ("b2", 3, 64, 64, 32, True),
+    ("a3", 3, 32, 64, 32, False), ("a4", 3, 64, 64, 32, True),
+    ("b3", 3, 64, 128, 16, False), ("b4", 3, 128, 128, 16, False),
+    ("a5", 3, 64, 128, 16, False), ("a6", 3, 128, 128, 16, False),
+)
+NBINS, FEAT, HIDDEN = 62, 128, 256
+
+
+def glorot_uniform(gen, shape):
+    """keras GlorotUniform (receptive field = prod(shape[:-2]) for rank > 2), host-side numpy."""
+    rf = int(np.prod(shape[:-2])) if len(shape) > 2 else 1
+    lim = math.sqrt(6.0 / ((shape[-2] + shape[-1]) * rf))
+    return gen.uniform(-lim, lim, size=shape).astype(np.float32)
+
+
+def branch_param_shapes(cin):
+    shapes = [(name, (k, k, cin if ci is None else ci, co)) for name, k, ci, co, _, _ in CONV_SPECS]
+    shapes.append(("fc", (NBINS, FEAT, HIDDEN)))
+    return shapes
+
+
+class ParamStore:
+    """All trainable parameters in ONE flat HBM buffer (+ flat grad / Adam m / Adam v), with named views."""
+
+    def __init__(self, named_shapes, device):
+        self.device = device
+        self.names = [n for n, _ in named_shapes]
+        self.shapes = dict(named_shapes)
+        self.offsets = {}
+        off = 0
+        for n, s in named_shapes:
+            self.offsets[n] = off
+            off += int(np.prod(s))
+            off = (off + 3) // 4 * 4  # keep every view 16-byte aligned
+        self.numel = off
+        self.flat = torch.zeros(off, dtype=F32, device=device)
+        self.grad = torch.zeros(off, dtype=F32, device=device)
+        self.m = torch.zeros(off, dtype=F32, device=device)
+        self.v = torch.zeros(off, dtype=F32, device=device)
+        self.p = {n: self._view(self.flat, n) for n in self.names}
+        self.g = {n: self._view(self.grad, n) for n in self.names}
+
+    def _view(self, buf, n):
+        k = int(np.prod(self.shapes[n]))
+        return buf[self.offsets[n]:self.offsets[n] + k].view(self.shapes[n])
+
+    def set(self, name, array):
+        self.p[name].copy_(torch.as_tensor(np.ascontiguousarray(array), dtype=F32))
+
+    def get(self, name):
+        return self.p[name].detach().cpu().numpy()
+
+
+class Encoder:
+    """One modality branch: build_gaitset_branch (nets/mj_uwyhNets_ba.py:419-484), forward and backward."""
+
+    def __init__(self, store, prefix, cin):
+        self.store, self.prefix, self.cin = store, prefix, cin
+        self.wp = {}       # packed forward weights of the 3x3 layers
+        self.act = None    # saved activations of the last forward
+        self.shape = None
+        self.scratch = {}
+
+    def W(self, name):
+        return self.store.p[self.prefix + name]
+
+    def G(self, name):
+        return self.store.g[self.prefix + name]
+
+    def repack(self):
+        for name, k, _, _, _, _ in CONV_SPECS:
+            if k == 3:
+                self.wp[name] = ops.pack3x3(self.W(name), self.wp.get(name))
+
+    def _buf(self, pool, key, shape, dtype=F32):
+        t = pool.get(key)
+        if t is None or tuple(t.shape) != tuple(shape) or t.dtype != dtype:
+            t = torch.empty(shape, dtype=dtype, device=self.store.device)
+            pool[key] = t
+        return t
+
+    def forward(self, x):
+        """x [B,L,60,60,C] (device, fp32) -> [62,B,256]."""
+        b, l = x.shape[0], x.shape[1]
+        n = b * l
+        if self.act is None or self.shape != (b, l):
+            self.act, self.shape = {}, (b, l)
+        A = self.act
+        U8 = torch.uint8
+        if not self.wp:
+            self.repack()
+        xf = x.reshape(n, 60, 60, self.cin)
+        A["x"] = xf
+        a1 = ops.conv5x5_in_fwd(xf, self.W("a1"), self._buf(A, "a1", (n, 64, 64, 32)))
+        p2, i2 = ops.conv3x3_fwd(a1, self.wp["a2"], True, self._buf(A, "p2", (n, 32, 32, 32)),
+                                 self._buf(A, "i2", (n, 32, 32, 32), U8))
+        m1 = ops.setmax_fwd(p2, b, l, m=self._buf(A, "m1", (b, 32, 32, 32)))
+        b1 = ops.conv3x3_fwd(m1, self.wp["b1"], False, self._buf(A, "b1", (b, 32, 32, 64)))
+        q2, j2 = ops.conv3x3_fwd(b1, self.wp["b2"], True, self._buf(A, "q2", (b, 16, 16, 64)),
+                                 self._buf(A, "j2", (b, 16, 16, 64), U8))
+        a3 = ops.conv3x3_fwd(p2, self.wp["a3"], False, self._buf(A, "a3", (n, 32, 32, 64)))
+        p4, i4 = ops.conv3x3_fwd(a3, self.wp["a4"], True, self._buf(A, "p4", (n, 16, 16, 64)),
+                                 self._buf(A, "i4", (n, 16, 16, 64), U8))
+        _, s2 = ops.setmax_fwd(p4, b, l, addend=q2, m=self._buf(A, "m2", (b, 16, 16, 64)),
+                               sum_out=self._buf(A, "s2", (b, 16, 16, 64)))
+        b3 = ops.conv3x3_fwd(s2, self.wp["b3"], False, self._buf(A, "b3", (b, 16, 16, 128)))
+        b4 = ops.conv3x3_fwd(b3, self.wp["b4"], False, self._buf(A, "b4", (b, 16, 16, 128)))
+        a5 = ops.conv3x3_fwd(p4, self.wp["a5"], False, self._buf(A, "a5", (n, 16, 16, 128)))
+        a6 = ops.conv3x3_fwd(a5, self.wp["a6"], False, self._buf(A, "a6", (n, 16, 16, 128)))
+        m3, s3 = ops.setmax_fwd(a6, b, l, addend=b4, m=self._buf(A, "m3", (b, 16, 16, 128)),
+                                sum_out=self._buf(A, "s3", (b, 16, 16, 128)))
+        feat = ops.hpp_fwd(m3, s3, self._buf(A, "feat", (NBINS, b, FEAT)))
+        return ops.binfc_fwd(feat, self.W("fc"), self._buf(A, "out", (NBINS, b, HIDDEN)))
+
+    def backward(self, dout, scratch):
+        """dout [62,B,256] -> parameter gradients written into the store's grad views.
+        `scratch` is a dict of frame-sized gradient buffers that may be shared by all branches."""
+        A = self.act
+        b, l = self.shape
+        n = b * l
+        S = scratch
+        buf = lambda key, shape: self._buf(S, key, shape)
+        ops.binfc_bwd(A["feat"], self.W("fc"), dout, self.G("fc"), buf("dfeat", (NBINS, b, FEAT)))
+        dm3, dzb4 = ops.hpp_bwd(A["m3"], A["s3"], A["b4"], S["dfeat"], buf("dm3", (b, 16, 16, 128)),
+                                buf("dzb4", (b, 16, 16, 128)))
+        # global branch, block 2 (b3, b4)
+        ops.conv3x3_wgrad(A["b3"], dzb4, 128, dw=self.G("b4"))
+        dzb3 = ops.conv3x3_dgrad(dzb4, self.W("b4"), 16, act=A["b3"], out=buf("dzb3", (b, 16, 16, 128)))
+        ops.conv3x3_wgrad(A["s2"], dzb3, 128, dw=self.G("b3"))
+        ds2 = buf("ds2", (b, 16, 16, 64))
+        dq2 = ops.conv3x3_dgrad(dzb3, self.W("b3"), 16, act=A["q2"], out=buf("dq2", (b, 16, 16, 64)), raw_out=ds2)
+        # global branch, block 1 (b1, b2); b2 is pooled: dq2 is its gradient at pooled resolution, routed through j2
+        ops.conv3x3_wgrad(A["b1"], dq2, 64, dz_idx=A["j2"], dw=self.G("b2"))
+        dzb1 = ops.conv3x3_dgrad(dq2, self.W("b2"), 32, dz_idx=A["j2"], act=A["b1"], out=buf("dzb1", (b, 32, 32, 64)))
+        ops.conv3x3_wgrad(A["m1"], dzb1, 64, dw=self.G("b1"))
+        dm1 = ops.conv3x3_dgrad(dzb1, self.W("b1"), 32, out=buf("dm1", (b, 32, 32, 32)))
+        # frame stack, block 3 (a5, a6)
+        dz6 = ops.setmax_bwd(A["a6"], dm3, b, l, True, buf("dz6", (n, 16, 16, 128)))
+        ops.conv3x3_wgrad(A["a5"], dz6, 128, dw=self.G("a6"))
+        dz5 = ops.conv3x3_dgrad(dz6, self.W("a6"), 16, act=A["a5"], out=buf("dz5", (n, 16, 16, 128)))
+        ops.conv3x3_wgrad(A["p4"], dz5, 128, dw=self.G("a5"))
+        g4 = ops.setmax_bwd(A["p4"], ds2, b, l, False, buf("g4", (n, 16, 16, 64)))
+        dp4 = ops.conv3x3_dgrad(dz5, self.W("a5"), 16, act=A["p4"], addend=g4, out=g4)  # in place over the addend
+        # block 2 (a3, a4)
+        ops.conv3x3_wgrad(A["a3"], dp4, 64, dz_idx=A["i4"], dw=self.G("a4"))
+        dz3 = ops.conv3x3_dgrad(dp4, self.W("a4"), 32, dz_idx=A["i4"], act=A["a3"], out=buf("dz3", (n, 32, 32, 64)))
+        ops.conv3x3_wgrad(A["p2"], dz3, 64, dw=self.G("a3"))
+        g2 = ops.setmax_bwd(A["p2"], dm1, b, l, False, buf("g2", (n, 32, 32, 32)))
+        dp2 = ops.conv3x3_dgrad(dz3, self.W("a3"), 32, act=A["p2"], addend=g2, out=g2)
+        # block 1 (a1, a2)
+        ops.conv3x3_wgrad(A["a1"], dp2, 32, dz_idx=A["i2"], dw=self.G("a2"))
+        dz1 = ops.conv3x3_dgrad(dp2, self.W("a2"), 64, dz_idx=A["i2"], act=A["a1"], out=buf("dz1", (n, 64, 64, 32)))
+        ops.conv5x5_in_wgrad(A["x"], dz1, self.G("a1"))
+
+
+class GaitCore:
+    """Encoders + gate/fusion/normalisation + heads + losses + Adam, for 1, 2 or 3 modalities."""
+
+    def __init__(self, in_channels, nclasses=0, multimodal=None, fuse_mode="sign_max", margin=0.2,
+                 loss_weights=(1.0, 1.0), device=None, seed=None, lr=1e-4, beta_1=0.9, beta_2=0.999, epsilon=1e-7,
+                 process_group=None, world_size=1):
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        self.in_channels = tuple(int(c) for c in in_channels)
+        self.nmod = len(self.in_channels)
+        self.multimodal = (self.nmod > 1) if multimodal is None else bool(multimodal)
+        if not self.multimodal and self.nmod != 1:
+            raise ValueError("the single-modality graph takes exactly one input")
+        self.nclasses = int(nclasses)
+        self.fuse_mode = fuse_mode
+        self.margin = float(margin)
+        lw = list(loss_weights) if isinstance(loss_weights, (list, tuple)) else [float(loss_weights)]
+        self.loss_weights = (float(lw[0]), float(lw[1]) if len(lw) > 1 else float(lw[0]))
+        self.lr, self.beta_1, self.beta_2, self.epsilon = float(lr), float(beta_1), float(beta_2), float(epsilon)
+        self.iterations = 0
+        self.pg, self.world = process_group, int(world_size)
+
+        named = []
+        for mi, cin in enumerate(self.in_channels):
+            named += [("m%d." % mi + n, s) for n, s in branch_param_shapes(cin)]
+        if self.nclasses > 0:
+            named += [("head.wc", (NBINS * HIDDEN, self.nclasses)), ("head.bc", (self.nclasses,))]
+        self.store = ParamStore(named, self.device)
+        self.encoders = [Encoder(self.store, "m%d." % mi, cin) for mi, cin in enumerate(self.in_channels)]
+        self.scratch = {}
+        self.bufs = {}
+        self._tri_cache = {}
+        self.init_weights(seed)
+
+    # ---- parameters -------------------------------------------------------------------------------------
+    def init_weights(self, seed=None):
+        gen = np.random.default_rng(seed)
+        for name in self.store.names:
+            shape = self.store.shapes[name]
+            self.store.set(name, np.zeros(shape, np.float32) if name.endswith(".bc") else glorot_uniform(gen, shape))
+        self.weights_changed()
+
+    def weights_changed(self):
+        for e in self.encoders:
+            e.repack()
+
+    def set_params_numpy(self, params):
+        """params in the oracle's layout: dict(branches=[{a1..fc}], head={wc,bc})."""
+        for mi, bp in enumerate(params["branches"]):
+            for k, v in bp.items():
+                self.store.set("m%d.%s" % (mi, k), v)
+        if "head" in params and self.nclasses > 0:
+            self.store.set("head.wc", params["head"]["wc"])
+            self.store.set("head.bc", params["head"]["bc"])
+        self.weights_changed()
+
+    def get_params_numpy(self):
+        out = dict(branches=[{n: self.store.get("m%d.%s" % (mi, n)) for n, _ in branch_param_shapes(c)}
+                             for mi, c in enumerate(self.in_channels)])
+        if self.nclasses > 0:
+            out["head"] = dict(wc=self.store.get("head.wc"), bc=self.store.get("head.bc"))
+        return out
+
+    def get_grads_numpy(self):
+        g = lambda n: self.store.g[n].detach().cpu().numpy()
+        out = dict(branches=[{n: g("m%d.%s" % (mi, n)) for n, _ in branch_param_shapes(c)}
+                             for mi, c in enumerate(self.in_channels)])
+        if self.nclasses > 0:
+            out["head"] = dict(wc=g("head.wc"), bc=g("head.bc"))
+        return out
+
+    # ---- helpers ----------------------------------------------------------------------------------------
+    def _dev(self, a, shape=None):
+        t = a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(a))
+        t = t.to(device=self.device, dtype=F32, non_blocking=True).contiguous()
+        return t if shape is None else t.reshape(shape)
+
+    def _buf(self, key, shape, dtype=F32):
+        t = self.bufs.get(key)
+        if t is None or tuple(t.shape) != tuple(shape) or t.dtype != dtype:
+            t = torch.empty(shape, dtype=dtype, device=self.device)
+            self.bufs[key] = t
+        return t
+
+    def _triplet_lists(self, labels):
+        lab = np.asarray(labels).reshape(-1).astype(np.int32)
+        key = lab.tobytes()
+        hit = self._tri_cache.get(key)
+        if hit is None:
+            hp, hn, kp, kn = ops.triplet_indices(lab)
+            hit = (torch.from_numpy(hp).to(self.device), torch.from_numpy(hn).to(self.device), kp, kn)
+            if len(self._tri_cache) > 64:
+                self._tri_cache.clear()
+            self._tri_cache[key] = hit
+        return hit
+
+    # ---- forward ----------------------------------------------------------------------------------------
+    def forward(self, xs, uses=None):
+        """xs: list of [B,L,60,60,C_m]; uses: list of [B,1] / [B] (multimodal only).  Returns the signature [62,B,256]."""
+        xs = [self._dev(x) for x in xs]
+        b = xs[0].shape[0]
+        outs = [enc.forward(x) for enc, x in zip(self.encoders, xs)]
+        self.last_b = b
+        if not self.multimodal:
+            self.sig = outs[0]           # single-modality graph: no gate, no normalisation (:893-903)
+            return self.sig
+        self.uses = [self._dev(u, (b,)) for u in uses]
+        self.fused, self.sel = ops.gate_fuse_fwd(outs, self.uses, self.fuse_mode, self._buf("fused", (NBINS, b, HIDDEN)),
+                                                 self._buf("sel", (NBINS, b, HIDDEN), torch.uint8))
+        self.sig = ops.l2norm_batch_fwd(self.fused, self._buf("sig", (NBINS, b, HIDDEN)))
+        return self.sig
+
+    def predict(self, xs, uses=None):
+        """Forward only: (signature [62,B,256], flatten [B,15872], classprob [B,ncls] or None)."""
+        sig = self.forward(xs, uses)
+        b = sig.shape[1]
+        probs = None
+        if self.nclasses > 0:
+            zeros = self._buf("onehot0", (b, self.nclasses))
+            zeros.zero_()
+            self.head = ops.head_fwd(sig, self.store.p["head.wc"], self.store.p["head.bc"], zeros, 0.0,
+                                     self._head_bufs(b))
+            probs = self.head["probs"]
+        flat = sig.permute(1, 0, 2).reshape(b, NBINS * HIDDEN)   # transpose [1,0,2] + Flatten (layer 'flatten')
+        return sig, flat, probs
+
+    def _head_bufs(self, b):
+        n = self.nclasses
+        return dict(part=self._buf("part", (NBINS, b, n)), probs=self._buf("probs", (b, n)),
+                    row_loss=self._buf("row_loss", (b,)), dlogits=self._buf("dlogits", (b, n)), hit=self._buf("hit", (b,)))
+
+    # ---- training step ----------------------------------------------------------------------------------
+    def forward_backward(self, xs, uses, labels, onehot):
+        """Forward + loss + full backward; gradients land in store.grad.  Returns device scalars (no sync)."""
+        sig = self.forward(xs, uses)
+        b = sig.shape[1]
+        hp, hn, kp, kn = self._triplet_lists(labels)
+        w_tri, w_id = self.loss_weights
+        self.bin_loss, self.bin_num, dsig = ops.triplet_fwd_bwd(
+            sig, hp, hn, kp, kn, self.margin, w_tri, self._buf("bin_loss", (NBINS,)), self._buf("bin_num", (NBINS,)),
+            self._buf("dsig", (NBINS, b, HIDDEN)))
+        if self.nclasses > 0:
+            oh = self._dev(onehot, (b, self.nclasses))
+            self.head = ops.head_fwd(sig, self.store.p["head.wc"], self.store.p["head.bc"], oh, w_id / b,
+                                     self._head_bufs(b))
+            ops.head_bwd(sig, self.store.p["head.wc"], self.head["dlogits"], dsig, True, self.store.g["head.wc"],
+                         self.store.g["head.bc"])
+        if self.multimodal:
+            df = ops.l2norm_batch_bwd(self.fused, sig, dsig, self._buf("df", (NBINS, b, HIDDEN)))
+            douts = ops.gate_fuse_bwd(df, self.sel, self.uses, self.fuse_mode,
+                                      [self._buf("dout%d" % m, (NBINS, b, HIDDEN)) for m in range(self.nmod)])
+        else:
+            douts = [dsig]
+        for enc, d in zip(self.encoders, douts):
+            enc.backward(d, self.scratch)
+
+    def apply_gradients(self):
+        """Gradient all-reduce over RCCL (data parallel) + keras Adam, one launch over the flat buffer."""
+        scale = 1.0
+        if self.world > 1:
+            torch.distributed.all_reduce(self.store.grad, group=self.pg)
+            scale = 1.0 / self.world
+        self.iterations += 1
+        t = self.iterations
+        lr_t = self.lr * math.sqrt(1.0 - self.beta_2 ** t) / (1.0 - self.beta_1 ** t)
+        ops.adam_step(self.store.flat, self.store.grad, self.store.m, self.store.v, lr_t, self.beta_1, self.beta_2,
+                      self.epsilon, scale)
+        self.weights_changed()
+
+    def train_step(self, xs, uses, labels, onehot):
+        self.forward_backward(xs, uses, labels, onehot)
+        self.apply_gradients()
+
+    def losses(self):
+        """Host copies of the last step's losses/metrics (synchronises)."""
+        w_tri, w_id = self.loss_weights
+        tri = float(self.bin_loss.cpu().numpy().mean())
+        out = dict(triplet=tri, loss=w_tri * tri)
+        if self.nclasses > 0:
+            xent = float(self.head["row_loss"].cpu().numpy().mean())
+            acc = float(self.head["hit"].cpu().numpy().mean())
+            out.update(xent=xent, acc=acc, loss=w_tri * tri + w_id * xent)
+        return out

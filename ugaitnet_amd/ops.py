@@ -40,6 +40,29 @@ class Workspace:
 
 _WS = Workspace()
 
+# bench.py's roofline leg: HIP-event pairs recorded around the launches of ONE named kernel, on the stream the kernel
+# is launched on (torch's current stream).  Disabled outside the timed region of the benchmark.
+TIMING_ENABLED = False
+TIMING = {}
+ROOFLINE_OP = "conv3x3_fwd[a2: 32->32 @64x64 +LeakyReLU +MaxPool]"
+ROOFLINE_FLOPS_PER_FRAME = 2.0 * 9 * 32 * 32 * 64 * 64   # algorithmic FLOPs of that layer per frame (a.c2)
+
+
+class _Timed:
+    def __init__(self, name, active):
+        self.name, self.active = name, active and TIMING_ENABLED
+
+    def __enter__(self):
+        if self.active:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e1 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+
+    def __exit__(self, *exc):
+        if self.active:
+            self.e1.record()
+            TIMING.setdefault(self.name, []).append((self.e0, self.e1))
+
 
 def conv5x5_in_fwd(x, w, out=None):
     n, cin = x.shape[0], x.shape[3]
@@ -76,8 +99,9 @@ def conv3x3_fwd(x, wp, pool, out=None, idx=None):
     out = torch.empty((n, ho, ho, cout), dtype=F32, device=x.device) if out is None else out
     if pool and idx is None:
         idx = torch.empty((n, ho, ho, cout), dtype=U8, device=x.device)
-    call("ugn_conv3x3_fwd", ptr(x), ptr(wp), ptr(out), ptr(idx) if pool else None, n, hw, cin, cout, int(bool(pool)),
-         _stream())
+    with _Timed(ROOFLINE_OP, hw == 64 and cin == 32 and cout == 32):
+        call("ugn_conv3x3_fwd", ptr(x), ptr(wp), ptr(out), ptr(idx) if pool else None, n, hw, cin, cout,
+             int(bool(pool)), _stream())
     return (out, idx) if pool else out
 
 
