@@ -1,0 +1,102 @@
+"""The drop-in boundary: the reference's class API (nets/mj_uwyhNets_ba.py) and the Keras subset its mains use."""
+import os
+
+import numpy as np
+import pytest
+
+from tests.synth import make_batch
+
+pytestmark = pytest.mark.gpu
+
+
+class ToyGenerator:
+    """keras.utils.Sequence-shaped generator with the reference's batch contract:
+    X = [of, use_of, gray, use_gray, depth, use_depth], y = [labels [B,1], onehot]."""
+
+    def __init__(self, kinds, b, l, ncls, n_batches=3, multimodal=True):
+        self.batches = []
+        for i in range(n_batches):
+            xs, uses, labels, onehot = make_batch(kinds, b, l, ncls, ids=b // 2, seed=100 + i)
+            X = [a for pair in zip(xs, uses) for a in pair] if multimodal else xs[0]
+            self.batches.append((X, [labels.reshape(-1, 1).astype(np.float32), onehot]))
+        self.epochs_ended = 0
+
+    def __len__(self):
+        return len(self.batches)
+
+    def __getitem__(self, i):
+        return self.batches[i]
+
+    def on_epoch_end(self):
+        self.epochs_ended += 1
+
+
+def test_three_mod_build_fit_predict_save_load(dev, tmp_path):
+    from ugaitnet_amd.nets.mj_uwyhNets_ba import Model, UWYHSemiNet, UWYHSemiNet3Mods, optimizers, sign_max
+    shapes = [(3, 60, 60, 2), (3, 60, 60, 1), (3, 60, 60, 1)]
+    model = UWYHSemiNet3Mods.build_or_load(shapes, 4, [7, 5, 3, 2], [96, 192, 512, 4096], ndense_units=0,
+                                           optimizer=optimizers.Adam(lr=1e-3), margin=0.2, nclasses=6,
+                                           loss_weights=[1.0, 0.1], fMerge=sign_max, gaitset=True, seed=1)
+    assert [t.name for t in model.input] == ["ofinput1", "ofuse1", "grayinput1", "grayuse1", "depthinput1", "depthuse1"]
+    assert model.get_layer("classprob").units == 6 and model.get_layer("fusion") is not None
+    gen = ToyGenerator(("of", "gray", "depth"), 4, 3, 6)
+    seen = []
+
+    class CB:
+        def on_epoch_end(self, epoch, logs):
+            seen.append((epoch, sorted(logs)))
+
+    model, hist = UWYHSemiNet.fit_generator(model, 3, [CB()], gen, gen, 1, 2, 1, new_lr=5e-4)
+    assert hist.epoch == [1, 2] and gen.epochs_ended == 2            # initial_epoch=1 .. epochs=3
+    assert model.optimizer.lr == 5e-4 and hist.history["lr"] == [5e-4, 5e-4]
+    for k in ("loss", "signature_loss", "classprob_loss", "classprob_acc", "val_loss", "val_classprob_acc"):
+        assert k in hist.history and len(hist.history[k]) == 2
+    assert seen[0][0] == 1
+    X, y = gen[0]
+    sig, probs = model.predict(X)
+    assert sig.shape == (62, 4, 256) and probs.shape == (4, 6) and np.allclose(probs.sum(1), 1, atol=1e-5)
+    flat = Model(model.input, model.get_layer("flatten").output).predict(X)
+    assert flat.shape == (4, 62 * 256) and np.array_equal(flat[1, 256:512], sig[1, 1])   # index k*256+d
+    # masked modality rows contribute exactly nothing: zeroing their (already ignored) pixels changes no output
+    X2 = [a.copy() for a in X]
+    use_of = X[1].reshape(-1)
+    X2[0][use_of == 0] = 123.0
+    sig2, _ = model.predict(X2)
+    assert np.array_equal(sig, sig2)
+    # save / load round trip (full model and weights-only), classprob surgery by name with skip_mismatch
+    path = os.path.join(tmp_path, "model-state-0002.hdf5")
+    model.save(path)
+    model.save_weights(UWYHSemiNet.get_weights_filename(path))
+    again = UWYHSemiNet3Mods.loadnet(path)
+    assert np.array_equal(again.predict(X)[0], sig)
+    other = UWYHSemiNet3Mods.build_or_load(shapes, 4, [7, 5, 3, 2], [96, 192, 512, 4096], optimizer=optimizers.Adam(lr=1e-3),
+                                           nclasses=9, loss_weights=[1.0, 0.1], initnet=path, fMerge=sign_max, gaitset=True)
+    assert other.get_layer("classprob").units == 9
+    assert np.array_equal(other.predict(X)[0], sig)                   # encoders were loaded, head re-initialised
+    w = model.get_layer("ofBranch_a1").get_weights()[0]
+    assert w.shape == (5, 5, 2, 32)
+
+
+def test_single_and_two_modality_models_and_encode(dev):
+    from ugaitnet_amd.nets.mj_uwyhNets_ba import Maximum, UWYHSemiNet, optimizers
+    one = UWYHSemiNet.build_or_load((3, 60, 60, 1), 4, [7, 5, 3, 2], [96, 192, 512, 4096], optimizer=optimizers.Adam(lr=1e-4),
+                                    nclasses=4, loss_weights=[1.0, 0.1], gaitset=True, seed=2)
+    gen = ToyGenerator(("gray",), 4, 3, 4, multimodal=False)
+    hist = one.fit(gen, epochs=1, steps_per_epoch=2, verbose=0)
+    assert "mat_mul_loss" in hist.history
+    two = UWYHSemiNet.build_or_load([(3, 60, 60, 2), (3, 60, 60, 1)], 4, [7, 5, 3, 2], [96, 192, 512, 4096],
+                                    optimizer=optimizers.Adam(lr=1e-4), nclasses=0, fMerge=Maximum, gaitset=True, seed=3)
+    xs, uses, labels, _ = make_batch(("of", "gray"), 4, 3, 4, ids=2, seed=5)
+    logs = two.train_on_batch([xs[0], uses[0], xs[1], uses[1]], labels.reshape(-1, 1))
+    assert set(logs) == {"loss"} and np.isfinite(logs["loss"])
+    codes = UWYHSemiNet.encode(two, [xs[0], xs[1]], uses, gaitset=True)
+    assert codes.shape == (62, 4, 256)
+    assert np.allclose((codes ** 2).sum(axis=1), 1.0, atol=1e-4)      # l2_normalize over the batch axis
+
+
+def test_unsupported_configurations_fail_loudly(dev):
+    from ugaitnet_amd.nets.mj_uwyhNets_ba import UWYHSemiNet, optimizers
+    with pytest.raises(NotImplementedError):
+        UWYHSemiNet.build((3, 60, 60, 1), 4, [7], [96], optimizer=optimizers.SGD(0.001, 0.9), gaitset=True)
+    with pytest.raises(ValueError):
+        UWYHSemiNet.build((3, 50, 60, 1), 4, [7], [96], optimizer=optimizers.Adam(), gaitset=True)

@@ -1,0 +1,68 @@
+"""Golden fixtures: (CPU) the oracle still reproduces them; (GPU) the HIP path matches them through the C ABI."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from oracle import ugaitnet_oracle as O
+from tests.golden.make_golden import digest, params_for
+
+FILES = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
+
+
+def load(path):
+    z = np.load(path)
+    kinds = tuple(str(k) for k in z['kinds'])
+    n = len(kinds)
+    xs = [z['x%d' % i] for i in range(n)]
+    uses = [z['use%d' % i] for i in range(n)]
+    p = params_for(kinds, int(z['ncls']), int(z['param_seed']))
+    assert digest(p) == str(z['param_sha256']), "parameter generator drifted from the fixture"
+    return z, kinds, xs, uses, p
+
+
+def test_fixtures_present():
+    assert len(FILES) >= 3
+
+
+@pytest.mark.parametrize("path", FILES, ids=[os.path.basename(f) for f in FILES])
+def test_oracle_reproduces_fixture(path):
+    z, kinds, xs, uses, p = load(path)
+    mm = bool(z['multimodal'])
+    r, g = O.model_loss_and_grads([x.astype(np.float64) for x in xs], [u.astype(np.float64) for u in uses] if mm else None,
+                                  z['labels'], z['onehot'].astype(np.float64), p, margin=0.2, loss_weights=(1.0, 0.1),
+                                  mode=str(z['mode']), multimodal=mm)
+    assert np.abs(r['signature'] - z['signature']).max() < 1e-6
+    assert abs(float(r['loss']) - float(z['loss'])) < 1e-10
+    assert np.array_equal(r['tri_aux']['hp'], z['hp']) and np.array_equal(r['tri_aux']['hn'], z['hn'])
+    assert np.array_equal(r['tri_aux']['num'], z['active_triplets'])
+    assert np.abs(g['branches'][0]['a1'] - z['grad_m0_a1']).max() < 1e-10
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("path", FILES, ids=[os.path.basename(f) for f in FILES])
+def test_hip_path_matches_fixture(dev, path):
+    from ugaitnet_amd import ops
+    from ugaitnet_amd.engine import GaitCore
+    z, kinds, xs, uses, p = load(path)
+    mm = bool(z['multimodal'])
+    core = GaitCore([x.shape[-1] for x in xs], nclasses=int(z['ncls']), multimodal=mm, fuse_mode=str(z['mode']),
+                    margin=0.2, loss_weights=(1.0, 0.1))
+    core.set_params_numpy(O.cast_params(p, np.float32))
+    core.forward_backward(xs, uses if mm else None, z['labels'], z['onehot'])
+    # north_star: signatures / logits within 1e-3 in fp32, triplet indices bit-exact
+    assert np.abs(core.sig.cpu().numpy() - z['signature']).max() <= 1e-3
+    assert np.abs(core.head['probs'].cpu().numpy() - z['probs']).max() <= 1e-3
+    hp, hn, kp, kn = ops.triplet_indices(z['labels'])
+    assert np.array_equal(hp, z['hp']) and np.array_equal(hn, z['hn']) and (kp, kn) == (int(z['kp']), int(z['kn']))
+    assert np.array_equal(core.bin_num.cpu().numpy(), z['active_triplets'])
+    ls = core.losses()
+    assert abs(ls['loss'] - float(z['loss'])) <= 1e-4 and abs(ls['triplet'] - float(z['triplet'])) <= 1e-4
+    got = core.get_grads_numpy()
+    for i in range(len(kinds)):
+        ref = z['grad_m%d_a1' % i]
+        assert np.linalg.norm(got['branches'][i]['a1'] - ref) <= 2e-3 * np.linalg.norm(ref) + 1e-12
+        assert abs(np.linalg.norm(got['branches'][i]['fc']) - float(z['grad_m%d_fc_l2' % i])) <= 1e-3 * float(z['grad_m%d_fc_l2' % i]) + 1e-12
+    if 'sel' in z.files:
+        assert (core.sel.cpu().numpy() != z['sel']).mean() < 1e-3

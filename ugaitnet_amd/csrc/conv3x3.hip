@@ -20,9 +20,23 @@
 //   GEMM view: M = 32 input channels (one chunk), N = 32/64 output channels, K = pixels; 9 accumulators (one per
 //   tap) per wave.  Persistent workgroups walk 8x16 pixel tiles and keep the 9x32x32 partial sums in registers;
 //   partial slabs are summed by `reduce_slabs_kernel` (deterministic, no atomics).
+#include <stdlib.h>
 #include "common.h"
 
 namespace {
+
+// Two workgroups share a CU (one wave of each per SIMD) and every workgroup does identical work, so left alone they run
+// in lockstep: both stage (matrix pipe idle), both compute (pipe shared), both store.  Delaying the workgroups of the
+// first resident round that sit in an odd wave slot by about one compute phase puts the partners out of phase for the
+// whole launch: one computes while the other stages/stores.  Placement only affects speed, never results.
+constexpr int kResidentWgs = 512;
+__device__ __forceinline__ void ugn_stagger_first_round(int sleeps) {
+  if (sleeps > 0 && blockIdx.x < kResidentWgs) {
+    const unsigned wave_slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4);  // HW_REG_HW_ID.WAVE_ID
+    if (wave_slot & 1u)
+      for (int i = 0; i < sleeps; ++i) __builtin_amdgcn_s_sleep(127);
+  }
+}
 
 constexpr int TW = 16;       // tile width (pixels)
 constexpr int PW = TW + 2;   // halo tile width
@@ -30,30 +44,38 @@ constexpr int CS = 36;       // LDS pixel stride of a 32-channel chunk (floats):
 
 enum { EPI_LRELU = 0, EPI_LRELU_POOL = 1, EPI_DGRAD = 2 };
 
-template <int KC, int NC, int HW, int TH, int IN_UNPOOL, int EPI>
+// NCF = output channels of the layer, NC = output channels owned by one workgroup (NCF / NC workgroups share a tile)
+template <int KC, int NCF, int NC, int HW, int TH>
 struct ConvCfg {
   static constexpr int PH = TH + 2, NPIX = PH * PW;
+  static constexpr int NSPLIT = NCF / NC;
   static constexpr int MB = TH / 2, NB = NC / 32, WB = MB * NB / 4;
   static constexpr int WN = (NB >= 2 && WB >= 2) ? 2 : 1, WM = WB / WN;
   static constexpr int WAVES_N = NB / WN, WAVES_M = MB / WM;
   static constexpr int NCHUNK = KC / 32;
   static constexpr int SIN = NPIX * CS, SW = NC * CS;
-  static constexpr int LDS_BYTES = (SIN + 2 * SW) * 4;
+  static constexpr int LDS_USED = (SIN + 2 * SW) * 4;
+  // request at least 56 KB so that exactly two workgroups share a CU: with 2400..9600 equal work items the
+  // 512 resident workgroups then finish in ~4.7..18.75 rounds (>= 94 % full) instead of quantising at 3 per CU
+  static constexpr int LDS_BYTES = LDS_USED < 57344 ? 57344 : LDS_USED;
   static constexpr int IN_ITERS = (NPIX * 8 + 255) / 256;
   static_assert(WAVES_N * WAVES_M == 4, "4 waves per workgroup");
   static_assert(WB >= 1 && WM >= 1, "tile too small");
   static_assert(HW % TH == 0 && HW % TW == 0, "tile must divide the image");
 };
 
-template <int KC, int NC, int HW, int TH, int IN_UNPOOL, int EPI>
+// EFLAGS (data-gradient epilogue, compile time so that the loads are batched, not branched around):
+//   bit 0 = multiply by LeakyReLU'(act), bit 1 = add `addend`, bit 2 = also store the un-multiplied sum to raw_out
+template <int KC, int NCF, int NC, int HW, int TH, int IN_UNPOOL, int EPI, int EFLAGS>
 __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const float* __restrict__ in,
                                                           const uint8_t* __restrict__ in_idx,
                                                           const float* __restrict__ w, int flip,
                                                           float* __restrict__ out, uint8_t* __restrict__ out_idx,
                                                           const float* __restrict__ act,
                                                           const float* __restrict__ addend,
-                                                          float* __restrict__ raw_out) {
-  using C = ConvCfg<KC, NC, HW, TH, IN_UNPOOL, EPI>;
+                                                          float* __restrict__ raw_out, int stagger) {
+  using C = ConvCfg<KC, NCF, NC, HW, TH>;
+  ugn_stagger_first_round(stagger);
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* sIn = smem;
   float* sW0 = smem + C::SIN;
@@ -64,7 +86,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const float* __restrict
   const int li = lane & 31, lh = lane >> 5;
 
   constexpr int TPX = HW / TW, TPY = HW / TH, TPI = TPX * TPY;
-  const int bid = blockIdx.x;
+  const int bid = blockIdx.x / C::NSPLIT, nsp = blockIdx.x % C::NSPLIT;
   const int img = bid / TPI, trem = bid % TPI;
   const int ty0 = (trem / TPX) * TH, tx0 = (trem % TPX) * TW;
 
@@ -127,7 +149,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const float* __restrict
       const int t = flip ? 8 : 0;
 #pragma unroll
       for (int q = 0; q < C::NB; ++q)
-        wreg[q] = *reinterpret_cast<const float4*>(w + ((size_t)(t * NC + q * 32 + wrow)) * KC + chunk * 32 + wc4 * 4);
+        wreg[q] = *reinterpret_cast<const float4*>(w + ((size_t)(t * NCF + nsp * NC + q * 32 + wrow)) * KC + chunk * 32 + wc4 * 4);
 #pragma unroll
       for (int q = 0; q < C::NB; ++q) *reinterpret_cast<float4*>(sW0 + (q * 32 + wrow) * CS + wc4 * 4) = wreg[q];
     }
@@ -138,27 +160,39 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const float* __restrict
 #pragma unroll
         for (int q = 0; q < C::NB; ++q)
           wreg[q] =
-              *reinterpret_cast<const float4*>(w + ((size_t)(t * NC + q * 32 + wrow)) * KC + chunk * 32 + wc4 * 4);
+              *reinterpret_cast<const float4*>(w + ((size_t)(t * NCF + nsp * NC + q * 32 + wrow)) * KC + chunk * 32 + wc4 * 4);
       }
       __syncthreads();
       const float* sW = (tap & 1) ? sW1 : sW0;
       const int toff = ((tap / 3) * PW + (tap % 3)) * CS;
+      // register double-buffered operand fragments: the ds_read_b128 of group g+1 are in flight under the MFMAs of
+      // group g (left to itself hipcc reuses one register set and exposes the LDS latency after every 4 MFMAs)
+      float4 a[2][C::WM], b[2][C::WN];
+#pragma unroll
+      for (int m = 0; m < C::WM; ++m) a[0][m] = *reinterpret_cast<const float4*>(sIn + aoff[m] + toff);
+#pragma unroll
+      for (int n = 0; n < C::WN; ++n) b[0][n] = *reinterpret_cast<const float4*>(sW + boff[n]);
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        float4 a[C::WM], b[C::WN];
+        const int cur = g & 1, nxt = cur ^ 1;
+        if (g < 3) {
 #pragma unroll
-        for (int m = 0; m < C::WM; ++m) a[m] = *reinterpret_cast<const float4*>(sIn + aoff[m] + toff + 8 * g);
+          for (int m = 0; m < C::WM; ++m)
+            a[nxt][m] = *reinterpret_cast<const float4*>(sIn + aoff[m] + toff + 8 * (g + 1));
 #pragma unroll
-        for (int n = 0; n < C::WN; ++n) b[n] = *reinterpret_cast<const float4*>(sW + boff[n] + 8 * g);
+          for (int n = 0; n < C::WN; ++n) b[nxt][n] = *reinterpret_cast<const float4*>(sW + boff[n] + 8 * (g + 1));
+          __builtin_amdgcn_sched_group_barrier(0x100, C::WM + C::WN, 0);  // the next group's DS reads first ...
+        }
 #pragma unroll
         for (int m = 0; m < C::WM; ++m)
 #pragma unroll
           for (int n = 0; n < C::WN; ++n) {
-            acc[m][n] = ugn_mfma(a[m].x, b[n].x, acc[m][n]);
-            acc[m][n] = ugn_mfma(a[m].y, b[n].y, acc[m][n]);
-            acc[m][n] = ugn_mfma(a[m].z, b[n].z, acc[m][n]);
-            acc[m][n] = ugn_mfma(a[m].w, b[n].w, acc[m][n]);
+            acc[m][n] = ugn_mfma(a[cur][m].x, b[cur][n].x, acc[m][n]);
+            acc[m][n] = ugn_mfma(a[cur][m].y, b[cur][n].y, acc[m][n]);
+            acc[m][n] = ugn_mfma(a[cur][m].z, b[cur][n].z, acc[m][n]);
+            acc[m][n] = ugn_mfma(a[cur][m].w, b[cur][n].w, acc[m][n]);
           }
+        __builtin_amdgcn_sched_group_barrier(0x8, 4 * C::WM * C::WN, 0);   // ... then this group's MFMAs
       }
       if (tap < 8) {
         float* sWn = ((tap + 1) & 1) ? sW1 : sW0;
@@ -174,7 +208,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const float* __restrict
     const int mbi = wm * C::WM + m;
 #pragma unroll
     for (int n = 0; n < C::WN; ++n) {
-      const int co = (wn * C::WN + n) * 32 + li;
+      const int co = nsp * NC + (wn * C::WN + n) * 32 + li;
       if constexpr (EPI == EPI_LRELU_POOL) {
         constexpr int HP = HW / 2;
 #pragma unroll
@@ -187,24 +221,38 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const float* __restrict
             if (v > best) { best = v; bi = r; }
           }
           const int oy = ty0 / 2 + mbi, ox = tx0 / 2 + lh + 2 * q;
-          const size_t o = (((size_t)img * HP + oy) * HP + ox) * NC + co;
+          const size_t o = (((size_t)img * HP + oy) * HP + ox) * NCF + co;
           out[o] = best;
           out_idx[o] = (uint8_t)bi;
         }
       } else {
+        size_t o[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int y = ty0 + 2 * mbi + ((r >> 1) & 1);
           const int x = tx0 + 2 * (lh + 2 * (r >> 2)) + (r & 1);
-          const size_t o = (((size_t)img * HW + y) * HW + x) * NC + co;
-          float v = acc[m][n][r];
-          if constexpr (EPI == EPI_LRELU) {
-            out[o] = ugn_lrelu(v);
-          } else {
-            if (addend) v += addend[o];
-            if (raw_out) raw_out[o] = v;
-            if (act) v *= ugn_lrelu_slope(act[o]);
-            out[o] = v;
+          o[r] = (((size_t)img * HW + y) * HW + x) * NCF + co;
+        }
+        if constexpr (EPI == EPI_LRELU) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) out[o[r]] = ugn_lrelu(acc[m][n][r]);
+        } else {
+          float av[16], dv[16];
+          if constexpr (EFLAGS & 1) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) av[r] = act[o[r]];
+          }
+          if constexpr (EFLAGS & 2) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dv[r] = addend[o[r]];
+          }
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            float v = acc[m][n][r];
+            if constexpr (EFLAGS & 2) v += dv[r];
+            if constexpr (EFLAGS & 4) raw_out[o[r]] = v;
+            if constexpr (EFLAGS & 1) v *= ugn_lrelu_slope(av[r]);
+            out[o[r]] = v;
           }
         }
       }
@@ -311,16 +359,25 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_kernel(const float* __restric
       }
     }
     __syncthreads();
+    // operands of pixel pair kp+1 are fetched (into a second register set) under the 9 MFMAs of pixel pair kp
+    float av[2][9], bv[2];
+    bv[0] = sDz[bbase];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) av[0][t] = sIn[abase + ((t / 3) * PW + (t % 3)) * CS];
 #pragma unroll
     for (int kp = 0; kp < C::PPW / 2; ++kp) {
       // pixel k = ps*PPW + 2*kp + lh ; rows of 16 pixels
-      const int ko = ((2 * kp) / TW) * PW + ((2 * kp) % TW);  // compile-time after unrolling
-      const float b = sDz[bbase + 2 * kp * C::DS];
+      const int cur = kp & 1, nxt = cur ^ 1;
+      if (kp + 1 < C::PPW / 2) {
+        const int ko = ((2 * (kp + 1)) / TW) * PW + ((2 * (kp + 1)) % TW);  // compile-time after unrolling
+        bv[nxt] = sDz[bbase + 2 * (kp + 1) * C::DS];
 #pragma unroll
-      for (int t = 0; t < 9; ++t) {
-        const float a = sIn[abase + (ko + (t / 3) * PW + (t % 3)) * CS];
-        acc[t] = ugn_mfma(a, b, acc[t]);
+        for (int t = 0; t < 9; ++t) av[nxt][t] = sIn[abase + (ko + (t / 3) * PW + (t % 3)) * CS];
+        __builtin_amdgcn_sched_group_barrier(0x100, 10, 0);
       }
+#pragma unroll
+      for (int t = 0; t < 9; ++t) acc[t] = ugn_mfma(av[cur][t], bv[cur], acc[t]);
+      __builtin_amdgcn_sched_group_barrier(0x8, 9, 0);
     }
   }
 
@@ -379,22 +436,49 @@ __global__ void pack3x3_kernel(const float* __restrict__ w, float* __restrict__ 
   wp[e] = w[((size_t)t * cin + ci) * cout + co];
 }
 
-template <int KC, int NC, int HW, int TH, int IN_UNPOOL, int EPI>
+inline bool ugn_stagger_enabled() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("UGN_STAGGER");
+    v = (e && e[0] == '0') ? 0 : 1;
+  }
+  return v != 0;
+}
+
+template <int KC, int NCF, int NC, int HW, int TH, int IN_UNPOOL, int EPI, int EFLAGS>
 int launch_conv(const float* in, const uint8_t* in_idx, const float* w, int flip, float* out, uint8_t* out_idx,
                 const float* act, const float* addend, float* raw_out, int n, hipStream_t st) {
-  using C = ConvCfg<KC, NC, HW, TH, IN_UNPOOL, EPI>;
-  auto kern = conv3x3_kernel<KC, NC, HW, TH, IN_UNPOOL, EPI>;
+  using C = ConvCfg<KC, NCF, NC, HW, TH>;
+  auto kern = conv3x3_kernel<KC, NCF, NC, HW, TH, IN_UNPOOL, EPI, EFLAGS>;
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
     if (e != hipSuccess) { ugn_set_error("conv3x3: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
     attr_done = true;
   }
-  const int grid = n * (HW / TH) * (HW / TW);
+  const int grid = n * (HW / TH) * (HW / TW) * C::NSPLIT;
+  // one workgroup's matrix work: NCHUNK * 9 taps * 16 k-pairs * WB blocks, 64 cycles each; s_sleep(127) = 8128 cycles
+  int stagger = 0;
+  if (ugn_stagger_enabled() && grid > kResidentWgs) stagger = (C::NCHUNK * 9 * 16 * C::WB * 64 + 4064) / 8128;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256), C::LDS_BYTES, st, in, in_idx, w, flip, out, out_idx, act, addend,
-                     raw_out);
+                     raw_out, stagger);
   UGN_CHECK_LAUNCH("conv3x3");
   return 0;
+}
+
+template <int KC, int NCF, int NC, int HW, int TH, int IN_UNPOOL>
+int launch_dgrad(const float* in, const uint8_t* in_idx, const float* w, float* out, const float* act,
+                 const float* addend, float* raw_out, int n, hipStream_t st) {
+  const int flags = (act ? 1 : 0) | (addend ? 2 : 0) | (raw_out ? 4 : 0);
+#define UGN_DG(F_)                                                                                              \
+  case F_:                                                                                                      \
+    return launch_conv<KC, NCF, NC, HW, TH, IN_UNPOOL, EPI_DGRAD, F_>(in, in_idx, w, 1, out, nullptr, act, addend, \
+                                                                      raw_out, n, st);
+  switch (flags) {
+    UGN_DG(0) UGN_DG(1) UGN_DG(2) UGN_DG(3) UGN_DG(4) UGN_DG(5) UGN_DG(6) UGN_DG(7)
+  }
+#undef UGN_DG
+  return UGN_EINVAL;
 }
 
 constexpr int WGRAD_WGS = 512;  // persistent workgroups (2 per CU)
@@ -452,15 +536,15 @@ extern "C" int ugn_conv3x3_fwd(const float* in, const float* wp, float* out, uin
   UGN_REQUIRE(in && wp && out && n > 0, "ugn_conv3x3_fwd: null pointer or n <= 0");
   UGN_REQUIRE(!pool || out_idx, "ugn_conv3x3_fwd: pool needs out_idx");
   hipStream_t st = (hipStream_t)stream;
-#define FWD(KC_, NC_, HW_, TH_, P_)                                                                                \
-  if (cin == KC_ && cout == NC_ && hw == HW_ && (pool != 0) == (P_ != 0))                                          \
-    return launch_conv<KC_, NC_, HW_, TH_, 0, P_ ? EPI_LRELU_POOL : EPI_LRELU>(in, nullptr, wp, 0, out, out_idx,   \
-                                                                               nullptr, nullptr, nullptr, n, st);
-  FWD(32, 32, 64, 16, 1)   // a2
-  FWD(32, 64, 32, 16, 0)   // a3, b1
-  FWD(64, 64, 32, 16, 1)   // a4, b2
-  FWD(64, 128, 16, 8, 0)   // a5, b3
-  FWD(128, 128, 16, 8, 0)  // a6, b4
+#define FWD(KC_, NCF_, NC_, HW_, TH_, P_)                                                                       \
+  if (cin == KC_ && cout == NCF_ && hw == HW_ && (pool != 0) == (P_ != 0))                                        \
+    return launch_conv<KC_, NCF_, NC_, HW_, TH_, 0, P_ ? EPI_LRELU_POOL : EPI_LRELU, 0>(                          \
+        in, nullptr, wp, 0, out, out_idx, nullptr, nullptr, nullptr, n, st);
+  FWD(32, 32, 32, 64, 16, 1)    // a2
+  FWD(32, 64, 64, 32, 16, 0)    // a3, b1
+  FWD(64, 64, 64, 32, 16, 1)    // a4, b2
+  FWD(64, 128, 64, 16, 8, 0)    // a5, b3 : 2 workgroups per 8x16 tile (64 channels each) -> 2400 items / 600 frames
+  FWD(128, 128, 64, 16, 8, 0)   // a6, b4
 #undef FWD
   UGN_REQUIRE(false, "ugn_conv3x3_fwd: unsupported shape cin=%d cout=%d hw=%d pool=%d", cin, cout, hw, pool);
 }
@@ -472,14 +556,14 @@ extern "C" int ugn_conv3x3_dgrad(const float* dz, const uint8_t* dz_idx, const f
   hipStream_t st = (hipStream_t)stream;
   const int unpool = dz_idx != nullptr;
   // kernel K channels = forward cout, kernel N channels = forward cin
-#define DGR(CI_, CO_, HW_, TH_, U_)                                                                               \
-  if (cin == CI_ && cout == CO_ && hw == HW_ && unpool == U_)                                                      \
-    return launch_conv<CO_, CI_, HW_, TH_, U_, EPI_DGRAD>(dz, dz_idx, w, 1, out, nullptr, act, addend, raw_out, n, st);
-  DGR(32, 32, 64, 16, 1)    // a2
-  DGR(32, 64, 32, 16, 0)    // a3, b1
-  DGR(64, 64, 32, 16, 1)    // a4, b2
-  DGR(64, 128, 16, 16, 0)   // a5, b3
-  DGR(128, 128, 16, 8, 0)   // a6, b4
+#define DGR(CI_, NCW_, CO_, HW_, TH_, U_)                                                                 \
+  if (cin == CI_ && cout == CO_ && hw == HW_ && unpool == U_)                                                \
+    return launch_dgrad<CO_, CI_, NCW_, HW_, TH_, U_>(dz, dz_idx, w, out, act, addend, raw_out, n, st);
+  DGR(32, 32, 32, 64, 16, 1)    // a2
+  DGR(32, 32, 64, 32, 16, 0)    // a3, b1
+  DGR(64, 64, 64, 32, 16, 1)    // a4, b2
+  DGR(64, 32, 128, 16, 8, 0)    // a5, b3 : 8x16 tiles x 2 channel halves -> 2400 items / 600 frames
+  DGR(128, 64, 128, 16, 8, 0)   // a6, b4
 #undef DGR
   UGN_REQUIRE(false, "ugn_conv3x3_dgrad: unsupported shape cin=%d cout=%d hw=%d unpool=%d", cin, cout, hw, unpool);
 }

@@ -103,93 +103,70 @@ __global__ void hpp_fwd_kernel(const float* __restrict__ a, const float* __restr
   }
 }
 
-// per tensor: strip maxima, incoming strip gradients and tie counts of the 31 strips (5 levels).
-__device__ __forceinline__ void hpp_bwd_one(const float* __restrict__ src, const float* __restrict__ dfeat, int t, int b,
-                                            int bsz, int c, float* mxl /*31*/, float* gl /*31*/, float* cl /*31*/) {
-  // level maxima: index base per level: lev 4 -> 0..15, lev 3 -> 16..23, lev 2 -> 24..27, lev 1 -> 28..29, lev 0 -> 30
-#pragma unroll
-  for (int st = 0; st < 16; ++st) {
-    float m = -INFINITY;
-#pragma unroll 1
-    for (int q = 0; q < 16; ++q) m = fmaxf(m, src[(size_t)(st * 16 + q) * 128]);
-    mxl[st] = m;
-  }
-#pragma unroll
-  for (int i = 0; i < 8; ++i) mxl[16 + i] = fmaxf(mxl[2 * i], mxl[2 * i + 1]);
-#pragma unroll
-  for (int i = 0; i < 4; ++i) mxl[24 + i] = fmaxf(mxl[16 + 2 * i], mxl[16 + 2 * i + 1]);
-#pragma unroll
-  for (int i = 0; i < 2; ++i) mxl[28 + i] = fmaxf(mxl[24 + 2 * i], mxl[24 + 2 * i + 1]);
-  mxl[30] = fmaxf(mxl[28], mxl[29]);
-  // incoming gradients per strip per level
-#pragma unroll
-  for (int lev = 0; lev < 5; ++lev) {
-    const int nb = 1 << lev;
-    const int base = lev == 4 ? 0 : lev == 3 ? 16 : lev == 2 ? 24 : lev == 1 ? 28 : 30;
-#pragma unroll
-    for (int st = 0; st < 16; ++st)
-      if (st < nb) gl[base + st] = dfeat[((size_t)(kHppOff[lev] + t * nb + st) * bsz + b) * 128 + c];
-  }
-  // tie counts per strip per level
-#pragma unroll
-  for (int i = 0; i < 31; ++i) cl[i] = 0.f;
-#pragma unroll
-  for (int st = 0; st < 16; ++st) {
-#pragma unroll 1
-    for (int q = 0; q < 16; ++q) {
-      const float v = src[(size_t)(st * 16 + q) * 128];
-      cl[st] += v == mxl[st] ? 1.f : 0.f;
-      cl[16 + st / 2] += v == mxl[16 + st / 2] ? 1.f : 0.f;
-      cl[24 + st / 4] += v == mxl[24 + st / 4] ? 1.f : 0.f;
-      cl[28 + st / 8] += v == mxl[28 + st / 8] ? 1.f : 0.f;
-      cl[30] += v == mxl[30] ? 1.f : 0.f;
-    }
-  }
-}
-
-__device__ __forceinline__ float hpp_grad_at(float v, int st, const float* mxl, const float* gl, const float* cl) {
-  float g = gl[st] * (1.f / 16.f) + gl[16 + st / 2] * (1.f / 32.f) + gl[24 + st / 4] * (1.f / 64.f) +
-            gl[28 + st / 8] * (1.f / 128.f) + gl[30] * (1.f / 256.f);
-  if (v == mxl[st]) g += gl[st] / cl[st];
-  if (v == mxl[16 + st / 2]) g += gl[16 + st / 2] / cl[16 + st / 2];
-  if (v == mxl[24 + st / 4]) g += gl[24 + st / 4] / cl[24 + st / 4];
-  if (v == mxl[28 + st / 8]) g += gl[28 + st / 8] / cl[28 + st / 8];
-  if (v == mxl[30]) g += gl[30] / cl[30];
-  return g;
-}
-
-// 256 threads: thread (t, c) owns tensor t (0 = a, 1 = s3) and channel c of sample b.
-// dm3 = dL/da + dL/ds3 (a also feeds s3 = b4 + a); dzb4 = dL/ds3 * LeakyReLU'(b4).
-__global__ __launch_bounds__(256) void hpp_bwd_kernel(const float* __restrict__ a, const float* __restrict__ s3,
+// HPP backward.  Workgroup = (sample b, 32-channel chunk), 512 threads = 16 finest strips x 32 channels; each thread
+// owns the 16 positions of one finest strip for BOTH tensors (a and s3), so dm3 = dL/da + dL/ds3 needs no exchange.
+// Level l (0..4) has 2^l strips of 256 / 2^l positions; strip maxima and tie counts of the coarser levels are combined
+// through LDS.  mean: g / n ; max: g / (#maxima) to every maximum (TF reduce_max gradient).
+__global__ __launch_bounds__(512) void hpp_bwd_kernel(const float* __restrict__ a, const float* __restrict__ s3,
                                                       const float* __restrict__ b4, const float* __restrict__ dfeat,
                                                       float* __restrict__ dm3, float* __restrict__ dzb4, int bsz) {
-  const int c = threadIdx.x & 127, t = threadIdx.x >> 7, b = blockIdx.x;
-  const size_t base = (size_t)b * 256 * 128 + c;
-  const float* src = t ? s3 : a;
-  float mxl[31], gl[31], cl[31];
-  hpp_bwd_one(src + base, dfeat, t, b, bsz, c, mxl, gl, cl);
-  if (t == 1) {
+  __shared__ float sMx[2][16][32];
+  __shared__ float sCnt[2][5][16][32];
+  const int b = blockIdx.x >> 2, cc = blockIdx.x & 3;
+  const int st = threadIdx.x >> 5, lc = threadIdx.x & 31, c = cc * 32 + lc;
+  const size_t base = ((size_t)b * 256 + st * 16) * 128 + c;
+  float v[2][16];
 #pragma unroll
-    for (int st = 0; st < 16; ++st) {
-#pragma unroll 1
-      for (int q = 0; q < 16; ++q) {
-        const size_t o = base + (size_t)(st * 16 + q) * 128;
-        const float ds = hpp_grad_at(src[o], st, mxl, gl, cl);
-        dm3[o] = ds;
-        dzb4[o] = ds * ugn_lrelu_slope(b4[o]);
-      }
+  for (int q = 0; q < 16; ++q) {
+    v[0][q] = a[base + (size_t)q * 128];
+    v[1][q] = s3[base + (size_t)q * 128];
+  }
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    float m = v[t][0];
+#pragma unroll
+    for (int q = 1; q < 16; ++q) m = fmaxf(m, v[t][q]);
+    sMx[t][st][lc] = m;
+  }
+  __syncthreads();
+  float mx[2][5];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+#pragma unroll
+    for (int l = 0; l < 5; ++l) {
+      const int span = 16 >> l, s0 = st & ~(span - 1);   // finest strips covered by my level-l strip
+      float m = sMx[t][s0][lc];
+      for (int k = 1; k < span; ++k) m = fmaxf(m, sMx[t][s0 + k][lc]);
+      mx[t][l] = m;
+      float cnt = 0.f;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) cnt += v[t][q] == m ? 1.f : 0.f;
+      sCnt[t][l][st][lc] = cnt;
     }
   }
-  __syncthreads();  // the s3-half of the workgroup has written ds into dm3 (same addresses, same CU)
-  if (t == 0) {
+  __syncthreads();
+  float g[2][16];
 #pragma unroll
-    for (int st = 0; st < 16; ++st) {
-#pragma unroll 1
-      for (int q = 0; q < 16; ++q) {
-        const size_t o = base + (size_t)(st * 16 + q) * 128;
-        dm3[o] += hpp_grad_at(src[o], st, mxl, gl, cl);
-      }
+  for (int t = 0; t < 2; ++t) {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) g[t][q] = 0.f;
+#pragma unroll
+    for (int l = 0; l < 5; ++l) {
+      const int span = 16 >> l, s0 = st & ~(span - 1);
+      float cnt = 0.f;
+      for (int k = 0; k < span; ++k) cnt += sCnt[t][l][s0 + k][lc];
+      const int nb = 1 << l;
+      const float gl = dfeat[((size_t)(kHppOff[l] + t * nb + (st >> (4 - l))) * bsz + b) * 128 + c];
+      const float gmean = gl * (1.f / (float)(256 >> l)), gmax = gl / cnt;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) g[t][q] += gmean + (v[t][q] == mx[t][l] ? gmax : 0.f);
     }
+  }
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const size_t o = base + (size_t)q * 128;
+    dm3[o] = g[0][q] + g[1][q];
+    dzb4[o] = g[1][q] * ugn_lrelu_slope(b4[o]);
   }
 }
 
@@ -227,7 +204,7 @@ extern "C" int ugn_hpp_fwd(const float* a, const float* s3, float* feat, int b, 
 extern "C" int ugn_hpp_bwd(const float* a, const float* s3, const float* b4, const float* dfeat, float* dm3, float* dzb4,
                            int b, void* stream) {
   UGN_REQUIRE(a && s3 && b4 && dfeat && dm3 && dzb4 && b > 0, "ugn_hpp_bwd: bad arguments");
-  hipLaunchKernelGGL(hpp_bwd_kernel, dim3(b), dim3(256), 0, (hipStream_t)stream, a, s3, b4, dfeat, dm3, dzb4, b);
+  hipLaunchKernelGGL(hpp_bwd_kernel, dim3(b * 4), dim3(512), 0, (hipStream_t)stream, a, s3, b4, dfeat, dm3, dzb4, b);
   UGN_CHECK_LAUNCH("hpp_bwd");
   return 0;
 }

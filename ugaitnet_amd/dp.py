@@ -1,0 +1,61 @@
+"""Data-parallel plumbing: one process per GPU, RCCL over xGMI via torch.distributed (backend "nccl" IS RCCL on ROCm).
+
+Replaces the reference's `tf.distribute.MirroredStrategy()` scope (mains/mj_trainUWYHGaitNet_DataGen_CasiaB.py:342-349,
+458-461): every replica owns a contiguous slice of the batch, evaluates the loss on ITS slice (Keras per-replica loss,
+scaled by 1/replicas) and the parameter gradients are summed across replicas.  The only exchange on the path is that
+gradient all-reduce: one collective over the flat fp32 gradient buffer (35.8-40.7 MB); the 1/world
+factor is folded into the Adam kernel.  These helpers are backend-agnostic so that the logic is testable with gloo on CPU.
+"""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+
+
+def env_rank_world():
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
+
+
+def init_from_env(backend="nccl"):
+    """Initialise torch.distributed from torchrun's environment (no-op for a single process)."""
+    import torch
+    import torch.distributed as dist
+    rank, world, local = env_rank_world()
+    if world > 1 and not dist.is_initialized():
+        kw = {}
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+            kw["device_id"] = torch.device("cuda", local)
+        dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+    return rank, world, local
+
+
+def shard_bounds(n, rank, world):
+    """Contiguous slice [lo, hi) of a batch of n rows owned by `rank` (remainder rows go to the first ranks)."""
+    base, rem = divmod(n, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def shard_batch(X, y, rank, world):
+    """Slice every array of the generator's batch (X list, y list) along axis 0."""
+    n = np.asarray(X[0] if isinstance(X, (list, tuple)) else X).shape[0]
+    lo, hi = shard_bounds(n, rank, world)
+    cut = lambda a: a[lo:hi]
+    Xs = [cut(a) for a in X] if isinstance(X, (list, tuple)) else cut(X)
+    ys = [cut(a) for a in y] if isinstance(y, (list, tuple)) else cut(y)
+    return Xs, ys
+
+
+def allreduce_sum_(flat, group=None):
+    """In-place SUM all-reduce of the flat gradient buffer; returns the factor that turns the sum into the
+    replica mean (applied inside ugn_adam_step)."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return 1.0
+    world = dist.get_world_size(group)
+    if world == 1:
+        return 1.0
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    return 1.0 / world

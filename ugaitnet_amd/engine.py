@@ -15,7 +15,7 @@ import math
 import numpy as np
 import torch
 
-from . import ops
+from . import dp, ops
 
 F32 = torch.float32
 
@@ -333,12 +333,21 @@ class GaitCore:
         for enc, d in zip(self.encoders, douts):
             enc.backward(d, self.scratch)
 
+    def forward_loss_only(self, xs, uses, labels, onehot):
+        """Validation step: forward + both losses/metrics, no parameter gradients."""
+        sig = self.forward(xs, uses)
+        b = sig.shape[1]
+        hp, hn, kp, kn = self._triplet_lists(labels)
+        self.bin_loss, self.bin_num, _ = ops.triplet_fwd_bwd(
+            sig, hp, hn, kp, kn, self.margin, 0.0, self._buf("bin_loss", (NBINS,)), self._buf("bin_num", (NBINS,)),
+            self._buf("dsig", (NBINS, b, HIDDEN)))
+        if self.nclasses > 0:
+            oh = self._dev(onehot, (b, self.nclasses))
+            self.head = ops.head_fwd(sig, self.store.p["head.wc"], self.store.p["head.bc"], oh, 0.0, self._head_bufs(b))
+
     def apply_gradients(self):
         """Gradient all-reduce over RCCL (data parallel) + keras Adam, one launch over the flat buffer."""
-        scale = 1.0
-        if self.world > 1:
-            torch.distributed.all_reduce(self.store.grad, group=self.pg)
-            scale = 1.0 / self.world
+        scale = dp.allreduce_sum_(self.store.grad, self.pg) if self.world > 1 else 1.0
         self.iterations += 1
         t = self.iterations
         lr_t = self.lr * math.sqrt(1.0 - self.beta_2 ** t) / (1.0 - self.beta_1 ** t)

@@ -1,0 +1,414 @@
+"""The subset of the Keras surface that the reference's mains touch, backed by the HIP engine (GaitCore).
+
+Nothing here computes on the hot path: these classes carry configuration, drive the training loop on the host and
+move numpy batches to HBM.  Surfaces mirrored:
+  * `optimizers.Adam(lr=...)`                          mains/mj_trainUWYHGaitNet_DataGen_CasiaB.py:227
+  * `Maximum`, `Average`, `sign_max(**kwargs)`          nets/mj_uwyhNets_ba.py:814,1189; mains/...CasiaB.py:169-178
+  * `Model.fit / predict / save / save_weights / load_weights / get_layer / summary / optimizer.lr / loss / input`
+    as used by nets/mj_uwyhNets_ba.py:937-999 and the mains (grep counts in SURVEY.md section 8b)
+  * `History.epoch`, `History.history[...]`             mains/mj_trainUWYHGaitNet_DataGen_1mod.py:544,551,614-637
+"""
+from __future__ import annotations
+
+import json
+import os
+
+import numpy as np
+
+
+# ---------------------------------------------------------------------------------------------------------
+# optimizers
+# ---------------------------------------------------------------------------------------------------------
+class _Optimizer:
+    def get_config(self):
+        return dict(self.__dict__, name=type(self).__name__)
+
+
+class Adam(_Optimizer):
+    """keras.optimizers.Adam defaults (epsilon 1e-7).  The update itself is the ugn_adam_step HIP kernel."""
+
+    def __init__(self, lr=0.001, beta_1=0.9, beta_2=0.999, epsilon=1e-7, amsgrad=False, learning_rate=None, **kwargs):
+        if amsgrad:
+            raise NotImplementedError("AMSGrad is not part of the MI355X hot path (SURVEY.md section 8: out of scope)")
+        self.lr = float(lr if learning_rate is None else learning_rate)
+        self.beta_1, self.beta_2, self.epsilon = float(beta_1), float(beta_2), float(epsilon)
+
+    @property
+    def learning_rate(self):
+        return self.lr
+
+    @learning_rate.setter
+    def learning_rate(self, v):
+        self.lr = float(v)
+
+
+class SGD(_Optimizer):
+    def __init__(self, lr=0.01, momentum=0.0, decay=0.0, nesterov=False, learning_rate=None, **kwargs):
+        self.lr = float(lr if learning_rate is None else learning_rate)
+        self.momentum, self.decay, self.nesterov = float(momentum), float(decay), bool(nesterov)
+
+
+class optimizers:  # namespace, so that `optimizers.Adam(lr=lr)` reads like the reference
+    Adam = Adam
+    SGD = SGD
+
+
+# ---------------------------------------------------------------------------------------------------------
+# fMerge factories
+# ---------------------------------------------------------------------------------------------------------
+class _Fusion:
+    mode = None
+
+    def __init__(self, name="fusion", **kwargs):
+        self.name = name
+
+    def __call__(self, tensors):
+        raise TypeError("fusion layers are descriptors here: the merge runs inside ugn_gate_fuse_fwd on the GPU")
+
+
+class Maximum(_Fusion):
+    """keras.layers.Maximum stand-in (fMerge default, nets/mj_uwyhNets_ba.py:585)."""
+    mode = "max"
+
+
+class Average(_Fusion):
+    """keras.layers.Average stand-in."""
+    mode = "avg"
+
+
+class _SignMax(_Fusion):
+    mode = "sign_max"
+
+
+def sign_max(**kwargs):
+    """Factory with the reference's signature (mains/mj_trainUWYHGaitNet_DataGen_CasiaB.py:169-178):
+    elementwise pick of the modality with the largest |value|, sign kept, first index on ties."""
+    return _SignMax(**kwargs)
+
+
+def fusion_mode(fmerge):
+    """Accepts the class/factory (as `eval(mergefun)` yields in the reference) or an instance."""
+    obj = fmerge(name="fusion") if callable(fmerge) and not isinstance(fmerge, _Fusion) else fmerge
+    mode = getattr(obj, "mode", None)
+    if mode not in ("sign_max", "max", "avg"):
+        raise ValueError("unsupported fMerge %r: expected Maximum, Average or sign_max" % (fmerge,))
+    return mode
+
+
+# ---------------------------------------------------------------------------------------------------------
+# model object
+# ---------------------------------------------------------------------------------------------------------
+class History:
+    def __init__(self):
+        self.epoch = []
+        self.history = {}
+
+    def _append(self, epoch, logs):
+        self.epoch.append(epoch)
+        for k, v in logs.items():
+            self.history.setdefault(k, []).append(v)
+
+
+class _Tensor:
+    """Symbolic handle of a layer output (only what `Model(model.input, model.get_layer(n).output)` needs)."""
+
+    def __init__(self, model, name):
+        self.model, self.name = model, name
+
+
+class LayerHandle:
+    def __init__(self, model, name, units=None, weight_names=()):
+        self._model, self.name, self.units, self._weight_names = model, name, units, tuple(weight_names)
+        self.trainable = True
+        self.output = _Tensor(model, name)
+
+    def get_weights(self):
+        return [self._model.core.store.get(n) for n in self._weight_names]
+
+    def set_weights(self, arrays):
+        for n, a in zip(self._weight_names, arrays):
+            self._model.core.store.set(n, a)
+        self._model.core.weights_changed()
+
+
+_MOD_NAMES = ("of", "gray", "depth")
+
+
+class GaitSetModel:
+    """What `UWYHSemiNet.build(..., gaitset=True)` returns: a compiled model driving the HIP engine."""
+
+    dtype = "float32"
+
+    def __init__(self, input_shapes, nclasses, loss_weights, margin, optimizer, fmerge, multimodal, seed=None,
+                 name="ugaitnet"):
+        from .engine import GaitCore
+        self.name = name
+        self.input_shapes = [tuple(s) for s in input_shapes]
+        for s in self.input_shapes:
+            if len(s) != 4 or tuple(s[1:3]) != (60, 60) or s[3] not in (1, 2):
+                raise ValueError("gaitset branch expects inputs of shape (L, 60, 60, 1|2), got %r" % (s,))
+        self.nclasses = int(nclasses)
+        self.multimodal = bool(multimodal)
+        self.margin = float(margin)
+        self.fmerge_mode = fusion_mode(fmerge) if multimodal else "max"
+        if not isinstance(optimizer, Adam):
+            raise NotImplementedError("only optimizers.Adam is implemented on the MI355X path (the reference's "
+                                      "published configurations all use --optimizer=Adam); got %r" % (optimizer,))
+        self.optimizer = optimizer
+        lw = list(loss_weights) if isinstance(loss_weights, (list, tuple, np.ndarray)) else [1.0]
+        if self.nclasses == 0:
+            lw = [1.0]
+        self.loss_weights = [float(v) for v in lw]
+        self.loss = ["triplet_loss(margin=%g)" % self.margin] + (["categorical_crossentropy"] if self.nclasses else [])
+        self.sig_name = "signature" if self.multimodal else "mat_mul"
+        import torch
+        world = torch.distributed.get_world_size() if torch.distributed.is_available() and torch.distributed.is_initialized() else 1
+        self.core = GaitCore([s[3] for s in self.input_shapes], nclasses=self.nclasses, multimodal=self.multimodal,
+                             fuse_mode=self.fmerge_mode, margin=self.margin,
+                             loss_weights=(self.loss_weights[0], self.loss_weights[1] if len(self.loss_weights) > 1 else 0.0),
+                             seed=seed, lr=optimizer.lr, beta_1=optimizer.beta_1, beta_2=optimizer.beta_2,
+                             epsilon=optimizer.epsilon, world_size=world)
+        if world > 1:  # replicas start from identical weights (MirroredStrategy semantics)
+            torch.distributed.broadcast(self.core.store.flat, src=0)
+            self.core.weights_changed()
+        self.input_names = []
+        mods = _MOD_NAMES[:len(self.input_shapes)]
+        for m in mods:
+            self.input_names.append(m + "input1")
+            if self.multimodal:
+                self.input_names.append(m + "use1")
+        self.input = [_Tensor(self, n) for n in self.input_names]
+        self.inputs = self.input
+        self.layers = []
+        for mi, m in enumerate(mods):
+            for n in ("a1", "a2", "b1", "b2", "a3", "a4", "b3", "b4", "a5", "a6"):
+                self.layers.append(LayerHandle(self, "%sBranch_%s" % (m, n), weight_names=["m%d.%s" % (mi, n)]))
+            self.layers.append(LayerHandle(self, "%sBranch_mat_mul" % m, weight_names=["m%d.fc" % mi]))
+            if self.multimodal:
+                self.layers.append(LayerHandle(self, "gate_%s1" % m))
+        if self.multimodal:
+            self.layers += [LayerHandle(self, "fusion"), LayerHandle(self, "signature")]
+        if self.nclasses:
+            self.layers += [LayerHandle(self, "flatten"),
+                            LayerHandle(self, "classprob", units=self.nclasses, weight_names=["head.wc", "head.bc"])]
+        self.stop_training = False
+
+    # ---- Keras-like surface ------------------------------------------------------------------------------
+    def get_layer(self, name):
+        for l in self.layers:
+            if l.name == name:
+                return l
+        raise ValueError("No such layer: %s" % name)
+
+    def compile(self, optimizer=None, loss=None, loss_weights=None, metrics=None):
+        if optimizer is not None:
+            if not isinstance(optimizer, Adam):
+                raise NotImplementedError("only optimizers.Adam is implemented")
+            self.optimizer = optimizer
+        if loss_weights is not None:
+            lw = [float(v) for v in (loss_weights if isinstance(loss_weights, (list, tuple)) else [loss_weights])]
+            self.loss_weights = lw
+            self.core.loss_weights = (lw[0], lw[1] if len(lw) > 1 else 0.0)
+
+    def count_params(self):
+        return int(sum(int(np.prod(s)) for s in self.core.store.shapes.values()))
+
+    def summary(self, print_fn=print):
+        print_fn('Model: "%s" (MI355X HIP engine; %d modality branch(es), fusion=%s)' %
+                 (self.name, len(self.input_shapes), self.fmerge_mode if self.multimodal else "none"))
+        for n in self.core.store.names:
+            print_fn("  %-12s %s" % (n, self.core.store.shapes[n]))
+        print_fn("Total params: %d" % self.count_params())
+
+    def _split_x(self, X):
+        nm = len(self.input_shapes)
+        if not self.multimodal:
+            x = X[0] if isinstance(X, (list, tuple)) else X
+            return [x], None
+        if len(X) != 2 * nm:
+            raise ValueError("expected %d inputs %s, got %d" % (2 * nm, self.input_names, len(X)))
+        return [X[2 * i] for i in range(nm)], [X[2 * i + 1] for i in range(nm)]
+
+    def _split_y(self, y):
+        if self.nclasses:
+            labels, onehot = y
+            return np.asarray(labels).reshape(-1), onehot
+        labels = y[0] if isinstance(y, (list, tuple)) else y
+        return np.asarray(labels).reshape(-1), None
+
+    def _sync_lr(self):
+        c, o = self.core, self.optimizer
+        c.lr, c.beta_1, c.beta_2, c.epsilon = float(o.lr), o.beta_1, o.beta_2, o.epsilon
+
+    def train_on_batch(self, X, y):
+        xs, uses = self._split_x(X)
+        labels, onehot = self._split_y(y)
+        self._sync_lr()
+        self.core.train_step(xs, uses, labels, onehot)
+        return self._logs(self.core.losses())
+
+    def test_on_batch(self, X, y):
+        xs, uses = self._split_x(X)
+        labels, onehot = self._split_y(y)
+        self.core.forward_loss_only(xs, uses, labels, onehot)
+        return self._logs(self.core.losses())
+
+    def _logs(self, ls):
+        out = {"loss": ls["loss"]}
+        if self.nclasses:
+            out[self.sig_name + "_loss"] = ls["triplet"]
+            out["classprob_loss"] = ls["xent"]
+            out["classprob_acc"] = ls["acc"]
+        return out
+
+    def predict(self, X, batch_size=None, verbose=0):
+        """Outputs of the compiled graph: [signature [62,B,256], classprob [B,ncls]] (or the signature alone)."""
+        xs, uses = self._split_x(X)
+        sig, _, probs = self.core.predict(xs, uses)
+        sig = sig.cpu().numpy()
+        return [sig, probs.cpu().numpy()] if self.nclasses else sig
+
+    def predict_layer(self, name, X):
+        xs, uses = self._split_x(X)
+        sig, flat, probs = self.core.predict(xs, uses)
+        if name == "flatten":
+            return flat.cpu().numpy()
+        if name in ("signature", "mat_mul", self.sig_name):
+            return sig.cpu().numpy()
+        if name == "classprob":
+            return probs.cpu().numpy()
+        if name == "fusion" and self.multimodal:
+            return self.core.fused.cpu().numpy()
+        raise ValueError("no output tap for layer %r" % name)
+
+    def evaluate(self, generator, steps=None, verbose=0):
+        n = len(generator) if steps is None else steps
+        acc = {}
+        for i in range(n):
+            X, y = generator[i]
+            for k, v in self.test_on_batch(X, y).items():
+                acc[k] = acc.get(k, 0.0) + v / n
+        return acc
+
+    def fit(self, x=None, y=None, validation_data=None, epochs=1, steps_per_epoch=None, callbacks=None,
+            validation_steps=None, initial_epoch=0, verbose=2, **kwargs):
+        """The loop `model.fit(training_generator, ...)` runs in nets/mj_uwyhNets_ba.py:963: per epoch
+        steps_per_epoch batches from the keras.utils.Sequence-like generator, Keras callbacks, History."""
+        gen = x
+        hist = History()
+        callbacks = list(callbacks or [])
+        for cb in callbacks:
+            if hasattr(cb, "set_model"):
+                cb.set_model(self)
+        _call(callbacks, "on_train_begin", {})
+        self.stop_training = False
+        for epoch in range(initial_epoch, epochs):
+            _call(callbacks, "on_epoch_begin", epoch, {})
+            n = steps_per_epoch if steps_per_epoch else len(gen)
+            sums = {}
+            for step in range(n):
+                X, Y = gen[step % len(gen)] if hasattr(gen, "__len__") else next(gen)
+                logs = self.train_on_batch(X, Y)
+                for k, v in logs.items():
+                    sums[k] = sums.get(k, 0.0) + v
+                _call(callbacks, "on_batch_end", step, logs)
+            logs = {k: v / n for k, v in sums.items()}
+            if validation_data is not None:
+                vn = validation_steps if validation_steps else len(validation_data)
+                for k, v in self.evaluate(validation_data, vn).items():
+                    logs["val_" + k] = v
+            logs["lr"] = float(self.optimizer.lr)
+            hist._append(epoch, logs)
+            if verbose:
+                print("Epoch %d/%d - " % (epoch + 1, epochs) + " - ".join("%s: %.4f" % kv for kv in logs.items()), flush=True)
+            if hasattr(gen, "on_epoch_end"):
+                gen.on_epoch_end()
+            _call(callbacks, "on_epoch_end", epoch, logs)
+            if self.stop_training:
+                break
+        _call(callbacks, "on_train_end", {})
+        return hist
+
+    # ---- persistence (npz container; h5py/deepdish are not available on the target image) --------------------
+    def get_config(self):
+        return dict(input_shapes=[list(s) for s in self.input_shapes], nclasses=self.nclasses,
+                    loss_weights=self.loss_weights, margin=self.margin, fmerge=self.fmerge_mode,
+                    multimodal=self.multimodal, optimizer=self.optimizer.get_config())
+
+    def _weights_dict(self):
+        return {"w/" + n: self.core.store.get(n) for n in self.core.store.names}
+
+    def save_weights(self, path):
+        _savez(path, self._weights_dict())
+
+    def save(self, path):
+        d = self._weights_dict()
+        d["config_json"] = np.frombuffer(json.dumps(self.get_config()).encode(), dtype=np.uint8)
+        d["opt/m"] = self.core.store.m.cpu().numpy()
+        d["opt/v"] = self.core.store.v.cpu().numpy()
+        d["opt/iterations"] = np.array([self.core.iterations], dtype=np.int64)
+        _savez(path, d)
+
+    def load_weights(self, path, by_name=False, skip_mismatch=False):
+        with np.load(path, allow_pickle=False) as z:
+            for n in self.core.store.names:
+                key = "w/" + n
+                if key not in z.files:
+                    if by_name:
+                        continue
+                    raise ValueError("weight %s missing in %s" % (n, path))
+                a = z[key]
+                if tuple(a.shape) != tuple(self.core.store.shapes[n]):
+                    if skip_mismatch:
+                        continue
+                    raise ValueError("shape mismatch for %s: %r vs %r" % (n, a.shape, self.core.store.shapes[n]))
+                self.core.store.set(n, a)
+            if "opt/m" in z.files and z["opt/m"].shape[0] == self.core.store.numel:
+                import torch
+                self.core.store.m.copy_(torch.from_numpy(z["opt/m"]))
+                self.core.store.v.copy_(torch.from_numpy(z["opt/v"]))
+                self.core.iterations = int(z["opt/iterations"][0])
+        self.core.weights_changed()
+
+
+def _savez(path, arrays):
+    """npz container written to EXACTLY `path` (the mains name their files *.hdf5; np.load does not mind)."""
+    with open(os.fspath(path), "wb") as f:
+        np.savez(f, **arrays)
+
+
+def _call(callbacks, method, *args):
+    for cb in callbacks:
+        fn = getattr(cb, method, None)
+        if fn is not None:
+            fn(*args)
+
+
+class SubModel:
+    """`Model(model.input, model.get_layer('flatten').output)`: a forward-only tap (test mains, :139-148)."""
+
+    def __init__(self, model, layer_name):
+        self.model, self.layer_name = model, layer_name
+
+    def predict(self, X, batch_size=None, verbose=0):
+        return self.model.predict_layer(self.layer_name, X)
+
+    __call__ = predict
+
+
+def Model(inputs=None, outputs=None):
+    if isinstance(outputs, _Tensor):
+        return SubModel(outputs.model, outputs.name)
+    raise TypeError("Model(inputs, outputs): outputs must be `model.get_layer(name).output` of a GaitSetModel")
+
+
+def load_model(path, custom_objects=None, compile=False):
+    """Counterpart of keras load_model for files written by GaitSetModel.save()."""
+    with np.load(path, allow_pickle=False) as z:
+        cfg = json.loads(bytes(z["config_json"]).decode())
+    fm = {"sign_max": sign_max, "max": Maximum, "avg": Average}[cfg["fmerge"]]
+    oc = cfg["optimizer"]
+    opt = Adam(lr=oc["lr"], beta_1=oc["beta_1"], beta_2=oc["beta_2"], epsilon=oc["epsilon"])
+    m = GaitSetModel(cfg["input_shapes"], cfg["nclasses"], cfg["loss_weights"], cfg["margin"], opt, fm, cfg["multimodal"])
+    m.load_weights(path)
+    return m
