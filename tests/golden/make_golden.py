@@ -38,8 +38,8 @@ def digest(params):
     return h.hexdigest()
 
 
-def case(name, kinds, b, l, ncls, ids, mode, multimodal, seed):
-    xs, uses, labels, onehot = make_batch(kinds, b, l, max(ncls, 1), ids=ids, seed=seed)
+def case(name, kinds, b, l, ncls, ids, mode, multimodal, seed, masks=True):
+    xs, uses, labels, onehot = make_batch(kinds, b, l, max(ncls, 1), ids=ids, seed=seed, masks=masks)
     p = params_for(kinds, ncls, seed + 1)
     r, g = O.model_loss_and_grads([x.astype(np.float64) for x in xs], [u.astype(np.float64) for u in uses] if multimodal else None,
                                   labels, onehot.astype(np.float64), p, margin=0.2, loss_weights=(1.0, 0.1), mode=mode,
@@ -68,4 +68,7 @@ def case(name, kinds, b, l, ncls, ids, mode, multimodal, seed):
 if __name__ == '__main__':
     case('c3_3mod_signmax', ('of', 'gray', 'depth'), 4, 2, 6, 2, 'sign_max', True, 11)
     case('c1_1mod_gray', ('gray',), 4, 2, 6, 2, 'sign_max', False, 12)
-    case('c4_3mod_sil_max', ('of', 'gray', 'sil'), 4, 2, 5, 2, 'max', True, 13)
+    case('c4_3mod_sil_signmax', ('of', 'gray', 'sil'), 4, 2, 5, 2, 'sign_max', True, 13)
+    # keras Maximum fusion, no missing modality (with masked rows the batch-axis norm of a column can be ~0, which
+    # amplifies fp32 rounding beyond the 1e-3 band at this tiny batch size)
+    case('c2mod_of_gray_max', ('of', 'gray'), 4, 2, 5, 2, 'max', True, 14, masks=False)

@@ -1,0 +1,77 @@
+"""BASELINE.json's full sizes (C3: 3 modalities, B=24, L=25, 150 classes) checked through size-independent properties
+plus an oracle spot check on two of the 24 clips (encoders are per-clip independent before the batch-axis norm)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ugaitnet_oracle as O
+from tests.synth import make_batch
+
+pytestmark = pytest.mark.gpu
+
+KINDS, B, L, NCLS = ("of", "gray", "depth"), 24, 25, 150
+
+
+@pytest.fixture(scope="module")
+def setup(dev):
+    from ugaitnet_amd.engine import GaitCore
+    xs, uses, labels, onehot = make_batch(KINDS, B, L, NCLS, seed=232323)
+    core = GaitCore([2, 1, 1], nclasses=NCLS, fuse_mode="sign_max", margin=0.2, loss_weights=(1.0, 0.1), seed=232323)
+    return core, xs, uses, labels, onehot
+
+
+def test_encoder_outputs_of_two_clips_match_oracle(setup):
+    core, xs, uses, labels, onehot = setup
+    core.forward(xs, uses)
+    p = core.get_params_numpy()
+    for mi in (0, 1):
+        rows = [0, 5] if mi == 0 else [1, 17]            # unmasked rows of that modality in the 7-pattern cycle
+        assert all(uses[mi][r, 0] == 1 for r in rows)
+        ref, _ = O.branch_forward(xs[mi][rows].astype(np.float64), {k: v.astype(np.float64) for k, v in p['branches'][mi].items()})
+        got = core.encoders[mi].act['out'].cpu().numpy()[:, rows, :]
+        assert np.abs(got - ref).max() <= 1e-5 * max(1.0, np.abs(ref).max())
+
+
+def test_frame_order_does_not_matter_bit_exact(setup):
+    """Set pooling is a max over the L frames: shuffling the frames of every clip leaves the signature bit-identical."""
+    core, xs, uses, labels, onehot = setup
+    sig = core.forward(xs, uses).cpu().numpy().copy()
+    perm = np.random.default_rng(0).permutation(L)
+    sig2 = core.forward([x[:, perm] for x in xs], uses).cpu().numpy()
+    assert np.array_equal(sig, sig2)
+
+
+def test_masked_modalities_contribute_nothing_bit_exact(setup):
+    core, xs, uses, labels, onehot = setup
+    sig = core.forward(xs, uses).cpu().numpy().copy()
+    xs2 = [x.copy() for x in xs]
+    for m in range(3):
+        xs2[m][uses[m][:, 0] == 0] = 0.77
+    assert np.array_equal(sig, core.forward(xs2, uses).cpu().numpy())
+
+
+def test_signature_columns_have_unit_batch_norm_and_step_is_deterministic(setup):
+    core, xs, uses, labels, onehot = setup
+    core.forward_backward(xs, uses, labels, onehot)
+    sig = core.sig.cpu().numpy()
+    assert np.allclose((sig.astype(np.float64) ** 2).sum(axis=1), 1.0, atol=1e-5)
+    g1 = core.store.grad.clone()
+    l1 = core.losses()
+    core.forward_backward(xs, uses, labels, onehot)
+    assert torch.equal(g1, core.store.grad) and l1 == core.losses()      # no atomics anywhere: bitwise repeatable
+    assert np.isfinite(l1['loss']) and 0 < core.bin_num.cpu().numpy().max() <= 24 * 2 * 22
+
+
+def test_gradient_is_linear_in_the_loss_weights(setup):
+    core, xs, uses, labels, onehot = setup
+    core.loss_weights = (1.0, 0.0)
+    core.forward_backward(xs, uses, labels, onehot)
+    g_tri = core.store.grad.clone()
+    core.loss_weights = (0.0, 1.0)
+    core.forward_backward(xs, uses, labels, onehot)
+    g_id = core.store.grad.clone()
+    core.loss_weights = (1.0, 0.1)
+    core.forward_backward(xs, uses, labels, onehot)
+    ref = g_tri + 0.1 * g_id
+    err = (core.store.grad - ref).norm() / ref.norm()
+    assert float(err) < 1e-5
