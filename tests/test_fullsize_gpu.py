@@ -25,8 +25,7 @@ def test_encoder_outputs_of_two_clips_match_oracle(setup):
     core.forward(xs, uses)
     p = core.get_params_numpy()
     for mi in (0, 1):
-        rows = [0, 5] if mi == 0 else [1, 17]            # unmasked rows of that modality in the 7-pattern cycle
-        assert all(uses[mi][r, 0] == 1 for r in rows)
+        rows = [int(r) for r in np.nonzero(uses[mi][:, 0] == 1)[0][[0, -1]]]   # first and last unmasked clip
         ref, _ = O.branch_forward(xs[mi][rows].astype(np.float64), {k: v.astype(np.float64) for k, v in p['branches'][mi].items()})
         got = core.encoders[mi].act['out'].cpu().numpy()[:, rows, :]
         assert np.abs(got - ref).max() <= 1e-5 * max(1.0, np.abs(ref).max())
