@@ -63,6 +63,17 @@ size_t ugn_conv3x3_wgrad_ws(int n, int hw, int cin, int cout);
 int ugn_conv3x3_wgrad(const float* in, const float* dz, const uint8_t* dz_idx, float* dw, int n, int hw, int cin,
                       int cout, void* ws, size_t ws_bytes, void* stream);
 
+/* Winograd F(2x2,3x3) variants of the forward / data-gradient convolutions (same results up to fp32 rounding, 2.25x
+ * fewer matrix FLOPs).  u_packed: 16*cin*cout floats produced by ugn_wino_pack from the HWIO weight
+ * (dgrad = 0 for ugn_conv3x3_fwd_wino, 1 for ugn_conv3x3_dgrad_wino).  Arguments otherwise as the direct versions;
+ * in the data gradient `addend` and `raw_out` require `act`. */
+int ugn_wino_pack(const float* w_hwio, float* u_packed, int cin, int cout, int dgrad, void* stream);
+int ugn_conv3x3_fwd_wino(const float* in, const float* u_packed, float* out, uint8_t* out_idx, int n, int hw, int cin,
+                         int cout, int pool, void* stream);
+int ugn_conv3x3_dgrad_wino(const float* dz, const uint8_t* dz_idx, const float* u_packed, const float* act,
+                           const float* addend, float* out, float* raw_out, int n, int hw, int cin, int cout,
+                           void* stream);
+
 /* ---- set pooling over the L frames: tf.math.reduce_max(x, axis=1), nets/mj_uwyhNets_ba.py:435,451,463 ----
  * p [b,l,s] -> m [b,s]; if addend != NULL also sum_out = m + addend (the Add layers :452,:465). */
 int ugn_setmax_fwd(const float* p, const float* addend, float* m, float* sum_out, int b, int l, size_t s,

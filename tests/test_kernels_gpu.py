@@ -66,6 +66,43 @@ def test_conv3x3_fwd(dev, hw, cin, cout, pool):
     assert np.array_equal(idx[clear], iref[clear])
 
 
+@pytest.mark.parametrize("hw,cin,cout,pool", CONV_CFGS)
+def test_conv3x3_winograd_fwd_and_dgrad(dev, hw, cin, cout, pool):
+    """Winograd F(2x2,3x3) path: same operator contract, fp32 rounding-level agreement with the fp64 oracle."""
+    from ugaitnet_amd import ops
+    rng = np.random.default_rng(7000 + hw + cin + cout)
+    n = 9 if hw <= 32 else 5   # more items than one workgroup round for the small images: exercises the item pipeline
+    x = rng.uniform(-1, 1, (n, hw, hw, cin)).astype(np.float32)
+    w = rng.uniform(-0.2, 0.2, (3, 3, cin, cout)).astype(np.float32)
+    act = O.leaky(O.conv2d_same(x.astype(np.float64), w.astype(np.float64)))
+    uf = ops.wino_pack(T(w, dev), False)
+    if pool:
+        out, idx = ops.conv3x3_fwd_wino(T(x, dev), uf, cout, True)
+        pref, iref = O.maxpool2x2(act)
+        close(out, pref, 4e-6, "wino fwd+pool")
+        idx = idx.cpu().numpy()
+        win = act.reshape(n, hw // 2, 2, hw // 2, 2, cout).transpose(0, 1, 3, 2, 4, 5).reshape(n, hw // 2, hw // 2, 4, cout)
+        srt = np.sort(win, axis=3)
+        clear = (srt[:, :, :, 3, :] - srt[:, :, :, 2, :]) > 1e-4
+        assert idx.max() <= 3 and np.array_equal(idx[clear], iref[clear])
+    else:
+        close(ops.conv3x3_fwd_wino(T(x, dev), uf, cout, False), act, 4e-6, "wino fwd")
+    # data gradient (with and without the fused epilogue); pooled-resolution gradients stay on the direct kernel
+    act_prev = rng.normal(size=(n, hw, hw, cin)).astype(np.float32)
+    addend = rng.normal(size=(n, hw, hw, cin)).astype(np.float32)
+    dz = rng.normal(size=(n, hw, hw, cout)).astype(np.float32)
+    _, dx_ref = O.conv2d_same_bwd(x.astype(np.float64), w.astype(np.float64), dz.astype(np.float64))
+    ud = ops.wino_pack(T(w, dev), True)
+    close(ops.conv3x3_dgrad_wino(T(dz, dev), ud, hw, cin, cout), dx_ref, 5e-6, "wino dgrad plain")
+    raw = torch.empty((n, hw, hw, cin), device=dev)
+    got = ops.conv3x3_dgrad_wino(T(dz, dev), ud, hw, cin, cout, act=T(act_prev, dev), addend=T(addend, dev), raw_out=raw)
+    t = dx_ref + addend
+    close(raw, t, 5e-6, "wino dgrad raw")
+    close(got, np.where(act_prev > 0, t, 0.3 * t), 5e-6, "wino dgrad fused")
+    with pytest.raises(ValueError):
+        ops.conv3x3_dgrad_wino(T(dz[:, ::2, ::2], dev).contiguous(), ud, hw, cin, cout, dz_idx=torch.zeros((n, hw // 2, hw // 2, cout), dtype=torch.uint8, device=dev))
+
+
 def test_conv3x3_pool_first_max_on_ties(dev):
     """Constant input -> every window is a 4-way tie in the interior: the FIRST element (index 0) must win."""
     from ugaitnet_amd import ops

@@ -29,6 +29,9 @@ PROTOTYPES = {
     "ugn_conv3x3_dgrad": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "ugn_conv3x3_wgrad_ws": (_sz, [_i, _i, _i, _i]),
     "ugn_conv3x3_wgrad": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p, _sz, _p]),
+    "ugn_wino_pack": (_i, [_p, _p, _i, _i, _i, _p]),
+    "ugn_conv3x3_fwd_wino": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "ugn_conv3x3_dgrad_wino": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "ugn_setmax_fwd": (_i, [_p, _p, _p, _p, _i, _i, _sz, _p]),
     "ugn_setmax_bwd": (_i, [_p, _p, _p, _i, _i, _sz, _i, _p]),
     "ugn_hpp_fwd": (_i, [_p, _p, _p, _i, _p]),

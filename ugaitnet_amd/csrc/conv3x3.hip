@@ -261,6 +261,207 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const float* __restrict
 }
 
 // ------------------------------------------------------------------------------------------------------
+// Weights-resident persistent variant for the layers whose GEMM K is one 32-channel chunk (a2 fwd/dgrad, a3/b1 fwd).
+// All nine [N][32] weight slices stay in LDS for the whole launch; the halo tile is double-buffered and the NEXT tile's
+// halo is fetched into registers while the current tile computes, so a tile costs ONE barrier and no exposed global
+// latency.  One workgroup per CU (LDS 93..135 KB), 256 persistent workgroups striding over the tiles.
+// ------------------------------------------------------------------------------------------------------
+template <int NC, int HW, int TH>
+struct ResCfg {
+  static constexpr int PH = TH + 2, NPIX = PH * PW;
+  static constexpr int MB = TH / 2, NB = NC / 32, WB = MB * NB / 4;
+  static constexpr int WN = (NB >= 2 && WB >= 2) ? 2 : 1, WM = WB / WN;
+  static constexpr int WAVES_N = NB / WN, WAVES_M = MB / WM;
+  static constexpr int SIN = NPIX * CS, SW = 9 * NC * CS;
+  static constexpr int LDS_BYTES = (2 * SIN + SW) * 4;
+  static constexpr int IN_ITERS = (NPIX * 8 + 255) / 256;
+  static_assert(WAVES_N * WAVES_M == 4, "4 waves per workgroup");
+};
+
+template <int HW, int TH, int KCT, int IN_UNPOOL, int ITERS>
+__device__ __forceinline__ void res_load_halo(float4 (&v)[ITERS], const float* __restrict__ in,
+                                              const uint8_t* __restrict__ in_idx, int item, int tid) {
+  constexpr int TPX = HW / TW, TPI = TPX * (HW / TH), NPIX = (TH + 2) * PW;
+  const int img = item / TPI, trem = item % TPI;
+  const int ty0 = (trem / TPX) * TH, tx0 = (trem % TPX) * TW;
+#pragma unroll
+  for (int it = 0; it < ITERS; ++it) {
+    const int e = tid + it * 256;
+    const int p = e >> 3, c4 = e & 7;
+    const int yy = p / PW, xx = p - yy * PW;
+    const int gy = ty0 - 1 + yy, gx = tx0 - 1 + xx;
+    v[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (e < NPIX * 8 && gy >= 0 && gy < HW && gx >= 0 && gx < HW) {
+      if constexpr (IN_UNPOOL) {
+        constexpr int HP = HW / 2;
+        const size_t o = (((size_t)img * HP + (gy >> 1)) * HP + (gx >> 1)) * KCT + c4 * 4;
+        const float4 d = *reinterpret_cast<const float4*>(in + o);
+        const uchar4 id = *reinterpret_cast<const uchar4*>(in_idx + o);
+        const int pos = ((gy & 1) << 1) | (gx & 1);
+        v[it].x = id.x == pos ? d.x : 0.f;
+        v[it].y = id.y == pos ? d.y : 0.f;
+        v[it].z = id.z == pos ? d.z : 0.f;
+        v[it].w = id.w == pos ? d.w : 0.f;
+      } else {
+        v[it] = *reinterpret_cast<const float4*>(in + (((size_t)img * HW + gy) * HW + gx) * KCT + c4 * 4);
+      }
+    }
+  }
+}
+
+template <int NC, int HW, int TH, int IN_UNPOOL, int EPI, int EFLAGS>
+__global__ __launch_bounds__(256, 1) void conv3x3_resident_kernel(const float* __restrict__ in,
+                                                                   const uint8_t* __restrict__ in_idx,
+                                                                   const float* __restrict__ w, int flip,
+                                                                   float* __restrict__ out, uint8_t* __restrict__ out_idx,
+                                                                   const float* __restrict__ act,
+                                                                   const float* __restrict__ addend,
+                                                                   float* __restrict__ raw_out, int nitems) {
+  using C = ResCfg<NC, HW, TH>;
+  constexpr int KC = 32;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* sW = smem;                 // [9][NC][36]
+  float* sIn0 = smem + C::SW;       // two halo buffers
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / C::WAVES_N, wn = wave % C::WAVES_N;
+  const int li = lane & 31, lh = lane >> 5;
+  constexpr int TPX = HW / TW, TPI = TPX * (HW / TH);
+
+  // ---- all weights, once ----
+  for (int e = tid; e < 9 * NC * 8; e += 256) {
+    const int row = e >> 3, c4 = e & 7;          // row = tap*NC + n
+    const int tap = row / NC, n = row % NC;
+    const int t = flip ? 8 - tap : tap;
+    *reinterpret_cast<float4*>(sW + row * CS + c4 * 4) =
+        *reinterpret_cast<const float4*>(w + ((size_t)(t * NC + n)) * KC + c4 * 4);
+  }
+  const int py = (li >> 1) & 1, px = 2 * (li >> 2) + (li & 1);
+  int aoff[C::WM], boff[C::WN];
+#pragma unroll
+  for (int m = 0; m < C::WM; ++m) aoff[m] = ((2 * (wm * C::WM + m) + py) * PW + px) * CS + 4 * lh;
+#pragma unroll
+  for (int n = 0; n < C::WN; ++n) boff[n] = ((wn * C::WN + n) * 32 + li) * CS + 4 * lh;
+
+  int item = blockIdx.x;
+  float4 vin[C::IN_ITERS];
+  if (item < nitems) {
+    res_load_halo<HW, TH, KC, IN_UNPOOL>(vin, in, in_idx, item, tid);
+#pragma unroll
+    for (int it = 0; it < C::IN_ITERS; ++it) {
+      const int e = tid + it * 256;
+      if (e < C::NPIX * 8) *reinterpret_cast<float4*>(sIn0 + (e >> 3) * CS + (e & 7) * 4) = vin[it];
+    }
+  }
+  int buf = 0;
+  for (; item < nitems; item += gridDim.x, buf ^= 1) {
+    const int next = item + gridDim.x;
+    if (next < nitems) res_load_halo<HW, TH, KC, IN_UNPOOL>(vin, in, in_idx, next, tid);
+    const int img = item / TPI, trem = item % TPI;
+    const int ty0 = (trem / TPX) * TH, tx0 = (trem % TPX) * TW;
+    // output offsets (+ early loads of the epilogue operands: they land while the tile computes)
+    size_t oo[C::WM][C::WN][EPI == EPI_LRELU_POOL ? 4 : 16];
+    float av[C::WM][C::WN][16], dv[C::WM][C::WN][16];
+#pragma unroll
+    for (int m = 0; m < C::WM; ++m)
+#pragma unroll
+      for (int n = 0; n < C::WN; ++n) {
+        const int mbi = wm * C::WM + m, co = (wn * C::WN + n) * 32 + li;
+        if constexpr (EPI == EPI_LRELU_POOL) {
+          constexpr int HP = HW / 2;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) oo[m][n][q] = (((size_t)img * HP + ty0 / 2 + mbi) * HP + tx0 / 2 + lh + 2 * q) * NC + co;
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int y = ty0 + 2 * mbi + ((r >> 1) & 1), x = tx0 + 2 * (lh + 2 * (r >> 2)) + (r & 1);
+            oo[m][n][r] = (((size_t)img * HW + y) * HW + x) * NC + co;
+            if constexpr (EPI == EPI_DGRAD && (EFLAGS & 1)) av[m][n][r] = act[oo[m][n][r]];
+            if constexpr (EPI == EPI_DGRAD && (EFLAGS & 2)) dv[m][n][r] = addend[oo[m][n][r]];
+          }
+        }
+      }
+    __syncthreads();   // sIn[buf] (and, first time, sW) visible; everyone finished reading sIn[buf^1]
+    const float* sIn = sIn0 + buf * C::SIN;
+    f32x16 acc[C::WM][C::WN];
+#pragma unroll
+    for (int m = 0; m < C::WM; ++m)
+#pragma unroll
+      for (int n = 0; n < C::WN; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+    float4 a[2][C::WM], b[2][C::WN];
+#pragma unroll
+    for (int m = 0; m < C::WM; ++m) a[0][m] = *reinterpret_cast<const float4*>(sIn + aoff[m]);
+#pragma unroll
+    for (int n = 0; n < C::WN; ++n) b[0][n] = *reinterpret_cast<const float4*>(sW + boff[n]);
+#pragma unroll
+    for (int s = 0; s < 36; ++s) {     // s = tap*4 + group
+      const int cur = s & 1, nxt = cur ^ 1;
+      if (s < 35) {
+        const int tap = (s + 1) >> 2, g = (s + 1) & 3;
+        const int toff = ((tap / 3) * PW + (tap % 3)) * CS + 8 * g;
+#pragma unroll
+        for (int m = 0; m < C::WM; ++m) a[nxt][m] = *reinterpret_cast<const float4*>(sIn + aoff[m] + toff);
+#pragma unroll
+        for (int n = 0; n < C::WN; ++n) b[nxt][n] = *reinterpret_cast<const float4*>(sW + boff[n] + tap * NC * CS + 8 * g);
+        __builtin_amdgcn_sched_group_barrier(0x100, C::WM + C::WN, 0);
+      }
+#pragma unroll
+      for (int m = 0; m < C::WM; ++m)
+#pragma unroll
+        for (int n = 0; n < C::WN; ++n) {
+          acc[m][n] = ugn_mfma(a[cur][m].x, b[cur][n].x, acc[m][n]);
+          acc[m][n] = ugn_mfma(a[cur][m].y, b[cur][n].y, acc[m][n]);
+          acc[m][n] = ugn_mfma(a[cur][m].z, b[cur][n].z, acc[m][n]);
+          acc[m][n] = ugn_mfma(a[cur][m].w, b[cur][n].w, acc[m][n]);
+        }
+      __builtin_amdgcn_sched_group_barrier(0x8, 4 * C::WM * C::WN, 0);
+    }
+    // next tile's halo into the other buffer (its last readers passed this iteration's barrier)
+    if (next < nitems) {
+      float* sNext = sIn0 + (buf ^ 1) * C::SIN;
+#pragma unroll
+      for (int it = 0; it < C::IN_ITERS; ++it) {
+        const int e = tid + it * 256;
+        if (e < C::NPIX * 8) *reinterpret_cast<float4*>(sNext + (e >> 3) * CS + (e & 7) * 4) = vin[it];
+      }
+    }
+    // ---- epilogue ----
+#pragma unroll
+    for (int m = 0; m < C::WM; ++m)
+#pragma unroll
+      for (int n = 0; n < C::WN; ++n) {
+        if constexpr (EPI == EPI_LRELU_POOL) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            float best = ugn_lrelu(acc[m][n][4 * q]);
+            int bi = 0;
+#pragma unroll
+            for (int r = 1; r < 4; ++r) {
+              const float v = ugn_lrelu(acc[m][n][4 * q + r]);
+              if (v > best) { best = v; bi = r; }
+            }
+            out[oo[m][n][q]] = best;
+            out_idx[oo[m][n][q]] = (uint8_t)bi;
+          }
+        } else if constexpr (EPI == EPI_LRELU) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) out[oo[m][n][r]] = ugn_lrelu(acc[m][n][r]);
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            float v = acc[m][n][r];
+            if constexpr (EFLAGS & 2) v += dv[m][n][r];
+            if constexpr (EFLAGS & 4) raw_out[oo[m][n][r]] = v;
+            if constexpr (EFLAGS & 1) v *= ugn_lrelu_slope(av[m][n][r]);
+            out[oo[m][n][r]] = v;
+          }
+        }
+      }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------
 // weight gradient
 // ------------------------------------------------------------------------------------------------------
 constexpr int WG_TH = 8;                       // wgrad pixel tile: 8 rows x 16 columns
@@ -466,6 +667,51 @@ int launch_conv(const float* in, const uint8_t* in_idx, const float* w, int flip
   return 0;
 }
 
+inline bool ugn_resident_enabled() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("UGN_RESIDENT");
+    v = (e && e[0] == '0') ? 0 : 1;
+  }
+  return v != 0;
+}
+
+constexpr int kResidentGrid = 256;   // one persistent workgroup per CU
+
+template <int NC, int HW, int TH, int IN_UNPOOL, int EPI, int EFLAGS>
+int launch_resident(const float* in, const uint8_t* in_idx, const float* w, int flip, float* out, uint8_t* out_idx,
+                    const float* act, const float* addend, float* raw_out, int n, hipStream_t st) {
+  using C = ResCfg<NC, HW, TH>;
+  auto kern = conv3x3_resident_kernel<NC, HW, TH, IN_UNPOOL, EPI, EFLAGS>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+    if (e != hipSuccess) { ugn_set_error("conv3x3 resident: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
+    attr_done = true;
+  }
+  const int nitems = n * (HW / TH) * (HW / TW);
+  const int grid = nitems < kResidentGrid ? nitems : kResidentGrid;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), C::LDS_BYTES, st, in, in_idx, w, flip, out, out_idx, act, addend,
+                     raw_out, nitems);
+  UGN_CHECK_LAUNCH("conv3x3 resident");
+  return 0;
+}
+
+template <int NC, int HW, int TH, int IN_UNPOOL>
+int launch_resident_dgrad(const float* in, const uint8_t* in_idx, const float* w, float* out, const float* act,
+                          const float* addend, float* raw_out, int n, hipStream_t st) {
+  const int flags = (act ? 1 : 0) | (addend ? 2 : 0) | (raw_out ? 4 : 0);
+#define UGN_RDG(F_)                                                                                            \
+  case F_:                                                                                                     \
+    return launch_resident<NC, HW, TH, IN_UNPOOL, EPI_DGRAD, F_>(in, in_idx, w, 1, out, nullptr, act, addend,  \
+                                                                 raw_out, n, st);
+  switch (flags) {
+    UGN_RDG(0) UGN_RDG(1) UGN_RDG(2) UGN_RDG(3) UGN_RDG(4) UGN_RDG(5) UGN_RDG(6) UGN_RDG(7)
+  }
+#undef UGN_RDG
+  return UGN_EINVAL;
+}
+
 template <int KC, int NCF, int NC, int HW, int TH, int IN_UNPOOL>
 int launch_dgrad(const float* in, const uint8_t* in_idx, const float* w, float* out, const float* act,
                  const float* addend, float* raw_out, int n, hipStream_t st) {
@@ -536,6 +782,12 @@ extern "C" int ugn_conv3x3_fwd(const float* in, const float* wp, float* out, uin
   UGN_REQUIRE(in && wp && out && n > 0, "ugn_conv3x3_fwd: null pointer or n <= 0");
   UGN_REQUIRE(!pool || out_idx, "ugn_conv3x3_fwd: pool needs out_idx");
   hipStream_t st = (hipStream_t)stream;
+  if (ugn_resident_enabled()) {
+    if (cin == 32 && cout == 32 && hw == 64 && pool)
+      return launch_resident<32, 64, 16, 0, EPI_LRELU_POOL, 0>(in, nullptr, wp, 0, out, out_idx, nullptr, nullptr, nullptr, n, st);
+    if (cin == 32 && cout == 64 && hw == 32 && !pool)
+      return launch_resident<64, 32, 8, 0, EPI_LRELU, 0>(in, nullptr, wp, 0, out, nullptr, nullptr, nullptr, nullptr, n, st);
+  }
 #define FWD(KC_, NCF_, NC_, HW_, TH_, P_)                                                                       \
   if (cin == KC_ && cout == NCF_ && hw == HW_ && (pool != 0) == (P_ != 0))                                        \
     return launch_conv<KC_, NCF_, NC_, HW_, TH_, 0, P_ ? EPI_LRELU_POOL : EPI_LRELU, 0>(                          \
@@ -555,6 +807,8 @@ extern "C" int ugn_conv3x3_dgrad(const float* dz, const uint8_t* dz_idx, const f
   UGN_REQUIRE(dz && w && out && n > 0, "ugn_conv3x3_dgrad: null pointer or n <= 0");
   hipStream_t st = (hipStream_t)stream;
   const int unpool = dz_idx != nullptr;
+  if (ugn_resident_enabled() && cin == 32 && cout == 32 && hw == 64 && unpool)
+    return launch_resident_dgrad<32, 64, 16, 1>(dz, dz_idx, w, out, act, addend, raw_out, n, st);
   // kernel K channels = forward cout, kernel N channels = forward cin
 #define DGR(CI_, NCW_, CO_, HW_, TH_, U_)                                                                 \
   if (cin == CI_ && cout == CO_ && hw == HW_ && unpool == U_)                                                \

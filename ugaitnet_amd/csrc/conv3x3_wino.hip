@@ -1,0 +1,421 @@
+// Winograd F(2x2,3x3) forward / data-gradient convolution on v_mfma_f32_16x16x4_f32 (exact fp32, 2.25x fewer matrix
+// FLOPs than the direct implicit GEMM in conv3x3.hip).  Same operator contract as conv3x3_kernel: replaces the implicit
+// TF Conv2D / Conv2DBackpropInput + LeakyRelu(Grad) + MaxPool(Grad) of reference nets/mj_uwyhNets_ba.py:431-462.
+//
+//   Y = A^T [ sum_cin (G g G^T) .* (B^T d B) ] A      per 2x2 output tile, 4x4 input patch d, 3x3 filter g
+//
+// Mapping.  A workgroup (4 waves, one per SIMD, persistent: 256 workgroups stride over the items) owns a 16x16 output
+// region (64 Winograd tiles) and 32 output channels; wave w owns the 16 tiles of region rows 4w..4w+3.  The GEMM of each
+// of the 16 Winograd points is [16 tiles] x [32 channels] x [K channels] on 16x16x4 MFMAs: 16 points x 2 channel blocks
+// = 32 independent accumulators (128 registers) per wave.
+//   * The transformed filters U = G g G^T are precomputed once per step (wino_pack_kernel) in the order the kernel
+//     consumes them: [32-channel chunk][8-channel group][point][32 out][8 in]; one 16 KB group slice is double-buffered
+//     in LDS, prefetched through registers -> one barrier per 8-channel group (64 MFMAs per wave).
+//   * The input transform B^T d B is computed IN REGISTERS by the lane that feeds it to the MFMA (lane = tile x
+//     channel pair), straight from the fp32 halo tile in LDS: transformed activations never touch LDS or HBM.
+//   * The halo tile of the next chunk / next item is fetched into registers while the current chunk computes and
+//     written to the other LDS buffer, so global latency is never exposed.
+//   * The output transform A^T M A is lane-local (a lane holds all 16 points of its 4 tiles x 2 channels), and a 2x2
+//     Winograd tile IS a pooling window, so LeakyReLU + MaxPool + argmax need no cross-lane traffic either.
+#include <stdlib.h>
+#include "common.h"
+
+namespace {
+
+constexpr int TW = 16, PW = TW + 2, PH = 18, NPIX = PH * PW;   // 16x16 output region, 18x18 halo
+constexpr int CS = 36;                                         // halo pixel stride (floats) per 32-channel chunk
+constexpr int HSLOTS = NPIX * 9;                                // 16-byte slots of a halo tile (8 data + 1 pad per pixel)
+constexpr int HPIECES = 46;                                     // 1 KB LDS-DMA pieces per halo tile (46 * 64 >= HSLOTS)
+constexpr int SIN = HPIECES * 256;                              // one halo buffer (floats) = 47,104 B
+constexpr int SU = 16 * 4 * 32 * 4;                             // one filter slice: [16 pts][4 kq][32 out][4 ch] = 32 KB
+constexpr int LDS_BYTES = (2 * SIN + 2 * SU) * 4;               // 159,744 B (of 163,840)
+constexpr int IN_ITERS = (NPIX * 8 + 255) / 256;                // 11
+
+enum { EPI_LRELU = 0, EPI_LRELU_POOL = 1, EPI_DGRAD = 2 };
+
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+  // lane l: A[i = l&15][k = l>>4], B[k = l>>4][j = l&15]; D reg r of lane l = D[i = 4*(l>>4) + r][j = l&15]
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// U[pt][n][k] = (G g G^T)[pt] for filter g(k -> n).  Layout [nsp][chunk][G][pt][kq][32 n][4 s] with k = 32*chunk + 16*G +
+// 4*kq + s: a 32 KB slice per 16-channel group, and the lane (n, kq) of an MFMA reads its 4 steps with one ds_read_b128
+// at consecutive 16-byte slots (conflict-free).
+// fwd : g[dy][dx] = w[dy][dx][k = cin][n = cout]            (kc = cin, nc = cout)
+// dgrad: g[dy][dx] = w[2-dy][2-dx][n = cin][k = cout]        (kc = cout, nc = cin)
+__global__ void wino_pack_kernel(const float* __restrict__ w, float* __restrict__ u, int cin, int cout, int dgrad) {
+  const int kc = dgrad ? cout : cin, nc = dgrad ? cin : cout;
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= kc * nc) return;
+  const int k = e % kc, n = e / kc;
+  float g[3][3];
+  for (int dy = 0; dy < 3; ++dy)
+    for (int dx = 0; dx < 3; ++dx)
+      g[dy][dx] = dgrad ? w[(((2 - dy) * 3 + (2 - dx)) * cin + n) * cout + k] : w[((dy * 3 + dx) * cin + k) * cout + n];
+  float t[4][3];   // G g
+  for (int c = 0; c < 3; ++c) {
+    t[0][c] = g[0][c];
+    t[1][c] = 0.5f * (g[0][c] + g[1][c] + g[2][c]);
+    t[2][c] = 0.5f * (g[0][c] - g[1][c] + g[2][c]);
+    t[3][c] = g[2][c];
+  }
+  const int nsp = n >> 5, nl = n & 31, chunk = k >> 5, G = (k >> 4) & 1, kq = (k >> 2) & 3, st = k & 3;
+  const int nchunk = kc >> 5;
+  float* dst = u + (((size_t)nsp * nchunk + chunk) * 2 + G) * SU + (kq * 32 + nl) * 4 + st;
+  for (int r = 0; r < 4; ++r) {
+    const float u0 = t[r][0], u1 = 0.5f * (t[r][0] + t[r][1] + t[r][2]), u2 = 0.5f * (t[r][0] - t[r][1] + t[r][2]),
+                u3 = t[r][2];
+    dst[(r * 4 + 0) * 512] = u0;
+    dst[(r * 4 + 1) * 512] = u1;
+    dst[(r * 4 + 2) * 512] = u2;
+    dst[(r * 4 + 3) * 512] = u3;
+  }
+}
+
+// global -> LDS, 16 B per lane, no VGPR destination (LDS address = M0 + lane * 16).  Inline asm: with the builtin hipcc
+// waits vmcnt(0) before the next ds_read (it cannot tell the DMA target from the buffers being read), which exposes the
+// whole global latency.  Completion is awaited by the caller (s_waitcnt vmcnt) before the barrier that publishes the data.
+__device__ __forceinline__ void dma16(const void* gsrc, unsigned lds_dst_uniform) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(gsrc), "s"(lds_dst_uniform)
+               : "memory");
+}
+
+// One 1 KB piece of the halo tile of (image, region origin, chunk): lane l fills 16-byte slot inst*64 + l; slot s =
+// pixel s/9, quarter-row s%9 (the 9th is the pad of the 36-float pixel stride and receives don't-care bytes).
+template <int KC, int HW>
+__device__ __forceinline__ void dma_halo_piece(const float* __restrict__ in, const float* __restrict__ zeros, int img, int ry0,
+                                               int rx0, int chunk, int inst, int lane, unsigned lds_byte_base) {
+  inst = inst < HPIECES ? inst : HPIECES - 1;      // 8 waves x 6 pieces = 48 >= 46: the surplus repeats the last piece
+  int slot = inst * 64 + lane;
+  slot = slot < HSLOTS ? slot : HSLOTS - 1;
+  const int p = slot / 9, c4 = slot - p * 9;
+  const int yy = p / PW, xx = p - yy * PW;
+  const int gy = ry0 - 1 + yy, gx = rx0 - 1 + xx;
+  const bool ok = c4 < 8 && gy >= 0 && gy < HW && gx >= 0 && gx < HW;
+  const float* src = ok ? in + (((size_t)img * HW + gy) * HW + gx) * KC + chunk * 32 + c4 * 4 : zeros;
+  dma16(src, lds_byte_base + (unsigned)inst * 1024u);   // all-scalar: base, inst are wave-uniform SGPR values
+}
+
+// 32 KB filter slice: linear in both spaces, 4 pieces of 1 KB per wave (8 waves)
+__device__ __forceinline__ void dma_u_slice(const float* __restrict__ us, unsigned lds_byte_base, int tid, int wave) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) dma16(us + (q * 512 + tid) * 4, lds_byte_base + (unsigned)(q * 512 + wave * 64) * 16u);
+}
+
+// KC: GEMM K channels, NCF: output channels of the layer (a workgroup owns 32 of them), HW: image size
+template <int KC, int NCF, int HW, int EPI, int EFLAGS>
+__global__ __launch_bounds__(512, 2) void wino_kernel(const float* __restrict__ in, const float* __restrict__ upk,
+                                                      float* __restrict__ out, uint8_t* __restrict__ out_idx,
+                                                      const float* __restrict__ act, const float* __restrict__ addend,
+                                                      float* __restrict__ raw_out, const float* __restrict__ zeros,
+                                                      int nitems) {
+  constexpr int NCHUNK = KC / 32, NSPLIT = NCF / 32;
+  constexpr int RPX = HW / 16, RPI = RPX * RPX;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* sIn0 = smem;
+  float* sU0 = smem + 2 * SIN;
+  const unsigned sin_bytes = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)smem);
+  const unsigned su_bytes = sin_bytes + 2u * SIN * 4u;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform: DMA targets stay in SGPRs
+  const int tg = wave & 3, ch = wave >> 2;                     // tile group (region rows 4tg..4tg+3), 16-channel half
+  const int lj = lane & 15, kq = lane >> 4;
+  // A-side role of the lane: tile (tr, tc) of the wave's 2 x 8 tiles; B-side: output channel lj (+16), both: channels 4*kq..
+  const int a_tr = lj >> 3, a_tc = lj & 7;
+  const int pbase = ((4 * tg + 2 * a_tr) * PW + 2 * a_tc) * CS + 4 * kq;   // patch origin in the halo tile
+  const int ubase = (kq * 32 + ch * 16 + lj) * 4;
+
+  int item = blockIdx.x;
+  if (item >= nitems) return;
+  auto u_slice = [&](int it, int chunk, int G) {
+    return upk + (((size_t)(it % NSPLIT) * NCHUNK + chunk) * 2 + G) * SU;
+  };
+  // ---- prologue: halo(item, chunk 0) -> sIn[0]; U(item, 0, 0) -> sU[0]
+  {
+    const int region = item / NSPLIT, img = region / RPI, rrem = region % RPI;
+#pragma unroll
+    for (int j = 0; j < 6; ++j)
+      dma_halo_piece<KC, HW>(in, zeros, img, (rrem / RPX) * 16, (rrem % RPX) * 16, 0, wave * 6 + j, lane, sin_bytes);
+    dma_u_slice(u_slice(item, 0, 0), su_bytes, tid, wave);
+  }
+  int ibuf = 0, ubuf = 0;
+  float V[16][4];      // transformed patch (4 channels) of the group about to be multiplied
+  bool first = true;   // only the very first group of the workgroup transforms its patch un-pipelined
+
+  for (; item < nitems; item += gridDim.x) {
+    const int next_item = item + gridDim.x;
+    f32x4 acc[16];
+#pragma unroll
+    for (int pt = 0; pt < 16; ++pt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[pt][r] = 0.f;
+
+#pragma unroll
+    for (int chunk = 0; chunk < NCHUNK; ++chunk) {
+      const bool last_chunk = chunk + 1 == NCHUNK;
+      const bool has_next = !last_chunk || next_item < nitems;
+      // no next stage (last chunk of the last item): the prefetches re-fetch the current stage into the free buffers
+      // instead of branching around the DMA (keeps the MFMA stream one basic block)
+      const int n_item = last_chunk ? (has_next ? next_item : item) : item, n_chunk = last_chunk ? (has_next ? 0 : chunk) : chunk + 1;
+      const int n_region = n_item / NSPLIT;
+      const int n_img = n_region / RPI, n_rrem = n_region % RPI;
+      const int n_ry0 = (n_rrem / RPX) * 16, n_rx0 = (n_rrem % RPX) * 16;
+      const float* sIn = sIn0 + ibuf * SIN;
+      const float* sInNext = sIn0 + (ibuf ^ 1) * SIN;
+#pragma unroll
+      for (int G = 0; G < 2; ++G) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every DMA issued so far has landed (all are >= 1 group old)
+        __syncthreads();                                    // ... and is visible; the other buffers have no readers left
+        const float* sU = sU0 + ubuf * SU;
+        // filter slice of the next group -> the other buffer, while this group computes
+        dma_u_slice(G == 0 ? u_slice(item, chunk, 1) : u_slice(n_item, n_chunk, 0), su_bytes + (unsigned)(ubuf ^ 1) * SU * 4u, tid, wave);
+        if (first) {
+          first = false;
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            float2 d[16], t[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+              d[e] = *reinterpret_cast<const float2*>(sIn + pbase + ((e >> 2) * PW + (e & 3)) * CS + 2 * h);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              t[0 + c] = make_float2(d[0 + c].x - d[8 + c].x, d[0 + c].y - d[8 + c].y);
+              t[4 + c] = make_float2(d[4 + c].x + d[8 + c].x, d[4 + c].y + d[8 + c].y);
+              t[8 + c] = make_float2(d[8 + c].x - d[4 + c].x, d[8 + c].y - d[4 + c].y);
+              t[12 + c] = make_float2(d[4 + c].x - d[12 + c].x, d[4 + c].y - d[12 + c].y);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              V[r * 4 + 0][2 * h] = t[r * 4 + 0].x - t[r * 4 + 2].x; V[r * 4 + 0][2 * h + 1] = t[r * 4 + 0].y - t[r * 4 + 2].y;
+              V[r * 4 + 1][2 * h] = t[r * 4 + 1].x + t[r * 4 + 2].x; V[r * 4 + 1][2 * h + 1] = t[r * 4 + 1].y + t[r * 4 + 2].y;
+              V[r * 4 + 2][2 * h] = t[r * 4 + 2].x - t[r * 4 + 1].x; V[r * 4 + 2][2 * h + 1] = t[r * 4 + 2].y - t[r * 4 + 1].y;
+              V[r * 4 + 3][2 * h] = t[r * 4 + 1].x - t[r * 4 + 3].x; V[r * 4 + 3][2 * h + 1] = t[r * 4 + 1].y - t[r * 4 + 3].y;
+            }
+          }
+        }
+        // the NEXT group's patch comes from this chunk (G == 0) or from the next chunk's halo, which landed a group ago
+        constexpr bool tnext = true;   // (at the very end this transforms a re-fetched tile that nobody consumes)
+        const float* sNx = (G == 0 ? sIn + 16 : sInNext) + pbase;
+        // The next group's transformed patch is built in the shadow of this group's MFMAs and written straight into the
+        // V registers of points that have already been multiplied (V[4r..4r+3] are dead once point 4r+3 is done), so only
+        // one V set plus the row-pass temporaries are live: the kernel must fit 256 arch VGPRs beside 128 accumulators.
+        float2 dn[16], tn0[16], tn1[16];
+        float4 u[2];
+        u[0] = *reinterpret_cast<const float4*>(sU + ubase);
+        auto rowpass = [&](float2 (&tn)[16], int c) {
+          tn[0 + c] = make_float2(dn[0 + c].x - dn[8 + c].x, dn[0 + c].y - dn[8 + c].y);
+          tn[4 + c] = make_float2(dn[4 + c].x + dn[8 + c].x, dn[4 + c].y + dn[8 + c].y);
+          tn[8 + c] = make_float2(dn[8 + c].x - dn[4 + c].x, dn[8 + c].y - dn[4 + c].y);
+          tn[12 + c] = make_float2(dn[4 + c].x - dn[12 + c].x, dn[4 + c].y - dn[12 + c].y);
+        };
+        auto colpass = [&](int r) {
+          V[r * 4 + 0][0] = tn0[r * 4 + 0].x - tn0[r * 4 + 2].x; V[r * 4 + 0][1] = tn0[r * 4 + 0].y - tn0[r * 4 + 2].y;
+          V[r * 4 + 1][0] = tn0[r * 4 + 1].x + tn0[r * 4 + 2].x; V[r * 4 + 1][1] = tn0[r * 4 + 1].y + tn0[r * 4 + 2].y;
+          V[r * 4 + 2][0] = tn0[r * 4 + 2].x - tn0[r * 4 + 1].x; V[r * 4 + 2][1] = tn0[r * 4 + 2].y - tn0[r * 4 + 1].y;
+          V[r * 4 + 3][0] = tn0[r * 4 + 1].x - tn0[r * 4 + 3].x; V[r * 4 + 3][1] = tn0[r * 4 + 1].y - tn0[r * 4 + 3].y;
+          V[r * 4 + 0][2] = tn1[r * 4 + 0].x - tn1[r * 4 + 2].x; V[r * 4 + 0][3] = tn1[r * 4 + 0].y - tn1[r * 4 + 2].y;
+          V[r * 4 + 1][2] = tn1[r * 4 + 1].x + tn1[r * 4 + 2].x; V[r * 4 + 1][3] = tn1[r * 4 + 1].y + tn1[r * 4 + 2].y;
+          V[r * 4 + 2][2] = tn1[r * 4 + 2].x - tn1[r * 4 + 1].x; V[r * 4 + 2][3] = tn1[r * 4 + 2].y - tn1[r * 4 + 1].y;
+          V[r * 4 + 3][2] = tn1[r * 4 + 1].x - tn1[r * 4 + 3].x; V[r * 4 + 3][3] = tn1[r * 4 + 1].y - tn1[r * 4 + 3].y;
+        };
+#pragma unroll
+        for (int pt = 0; pt < 16; ++pt) {
+          const int cu = pt & 1, nu = cu ^ 1;
+          if (tnext && (pt == 0 || pt == 3)) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+              dn[e] = *reinterpret_cast<const float2*>(sNx + ((e >> 2) * PW + (e & 3)) * CS + (pt == 0 ? 0 : 2));   // channels +0,1 / +2,3
+          }
+          if (pt < 15) u[nu] = *reinterpret_cast<const float4*>(sU + ubase + (pt + 1) * 512);
+#pragma unroll
+          for (int st = 0; st < 4; ++st) acc[pt] = mfma16(V[pt][st], u[cu][st], acc[pt]);
+          // halo of the next stage: all 12 pieces of this wave during the FIRST group of the chunk, so that they are
+          // a full group old at the next barrier and the next chunk's first transform can be pipelined as well
+          if (G == 0 && pt >= 2 && pt < 14 && (pt & 1) == 0)
+            dma_halo_piece<KC, HW>(in, zeros, n_img, n_ry0, n_rx0, n_chunk, wave * 6 + ((pt - 2) >> 1), lane,
+                                   sin_bytes + (unsigned)(ibuf ^ 1) * SIN * 4u);
+          if (tnext) {
+            if (pt == 1) { rowpass(tn0, 0); rowpass(tn0, 1); }
+            if (pt == 2) { rowpass(tn0, 2); rowpass(tn0, 3); }   // pair 0 done before pair 1 is loaded at point 3
+            if (pt == 4) { rowpass(tn1, 0); rowpass(tn1, 1); }
+            if (pt == 5) { rowpass(tn1, 2); rowpass(tn1, 3); }
+            if (pt == 6) colpass(0);
+            if (pt == 8) colpass(1);
+            if (pt == 12) colpass(2);
+            if (pt == 15) colpass(3);
+          }
+        }
+        ubuf ^= 1;
+      }
+      ibuf ^= 1;
+    }
+
+    // ---- output transform + epilogue: lane holds tiles 4*kq + r (r = 0..3) x channels {lj, 16 + lj}, all 16 points
+    const int region = item / NSPLIT, nsp = item % NSPLIT;
+    const int img = region / RPI, rrem = region % RPI;
+    const int ry0 = (rrem / RPX) * 16, rx0 = (rrem % RPX) * 16;
+    {
+      const int co = nsp * 32 + ch * 16 + lj;
+      float y[4][4];     // [tile r][output (a,b) row-major]
+      size_t o[4][4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int ti = 4 * kq + r, tr = ti >> 3, tc = ti & 7;
+        float sm[2][4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          sm[0][c] = acc[0 * 4 + c][r] + acc[1 * 4 + c][r] + acc[2 * 4 + c][r];
+          sm[1][c] = acc[1 * 4 + c][r] - acc[2 * 4 + c][r] - acc[3 * 4 + c][r];
+        }
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+          y[r][a * 2 + 0] = sm[a][0] + sm[a][1] + sm[a][2];
+          y[r][a * 2 + 1] = sm[a][1] - sm[a][2] - sm[a][3];
+        }
+        const int oy = ry0 + 4 * tg + 2 * tr, ox = rx0 + 2 * tc;
+        if constexpr (EPI == EPI_LRELU_POOL) {
+          constexpr int HP = HW / 2;
+          o[r][0] = (((size_t)img * HP + oy / 2) * HP + ox / 2) * NCF + co;
+        } else {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) o[r][q] = (((size_t)img * HW + oy + (q >> 1)) * HW + ox + (q & 1)) * NCF + co;
+        }
+      }
+      if constexpr (EPI == EPI_LRELU_POOL) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float best = ugn_lrelu(y[r][0]);
+          int bi = 0;
+#pragma unroll
+          for (int q = 1; q < 4; ++q) {
+            const float v = ugn_lrelu(y[r][q]);
+            if (v > best) { best = v; bi = q; }
+          }
+          out[o[r][0]] = best;
+          out_idx[o[r][0]] = (uint8_t)bi;
+        }
+      } else if constexpr (EPI == EPI_LRELU) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) out[o[r][q]] = ugn_lrelu(y[r][q]);
+      } else {
+        float av[4][4], dv[4][4];
+        if constexpr (EFLAGS & 1) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) av[r][q] = act[o[r][q]];
+        }
+        if constexpr (EFLAGS & 2) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) dv[r][q] = addend[o[r][q]];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            float v = y[r][q];
+            if constexpr (EFLAGS & 2) v += dv[r][q];
+            if constexpr (EFLAGS & 4) raw_out[o[r][q]] = v;
+            if constexpr (EFLAGS & 1) v *= ugn_lrelu_slope(av[r][q]);
+            out[o[r][q]] = v;
+          }
+      }
+    }
+  }
+}
+
+constexpr int kGrid = 256;
+
+// 64 B of zeros in HBM: the LDS-DMA source for halo lanes outside the image.  Allocated once per process, never written.
+inline const float* zero_block() {
+  static float* z = nullptr;
+  if (!z) {
+    float* p = nullptr;
+    if (hipMalloc((void**)&p, 256) != hipSuccess || hipMemset(p, 0, 256) != hipSuccess) return nullptr;
+    z = p;
+  }
+  return z;
+}
+
+template <int KC, int NCF, int HW, int EPI, int EFLAGS>
+int launch_wino(const float* in, const float* upk, float* out, uint8_t* out_idx, const float* act, const float* addend,
+                float* raw_out, int n, hipStream_t st) {
+  auto kern = wino_kernel<KC, NCF, HW, EPI, EFLAGS>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    if (e != hipSuccess) { ugn_set_error("wino: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
+    attr_done = true;
+  }
+  const float* zeros = zero_block();
+  if (!zeros) { ugn_set_error("wino: cannot allocate the zero block"); return UGN_EINVAL; }
+  const int nitems = n * (HW / 16) * (HW / 16) * (NCF / 32);
+  const int grid = nitems < kGrid ? nitems : kGrid;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), LDS_BYTES, st, in, upk, out, out_idx, act, addend, raw_out, zeros, nitems);
+  UGN_CHECK_LAUNCH("wino");
+  return 0;
+}
+
+template <int KC, int NCF, int HW>
+int launch_wino_dgrad(const float* in, const float* upk, float* out, const float* act, const float* addend, float* raw_out,
+                      int n, hipStream_t st) {
+  const int flags = (act ? 1 : 0) | (addend ? 2 : 0) | (raw_out ? 4 : 0);
+#define UGN_WDG(F_)                                                                                                  \
+  case F_:                                                                                                           \
+    return launch_wino<KC, NCF, HW, EPI_DGRAD, F_>(in, upk, out, nullptr, act, addend, raw_out, n, st);
+  switch (flags) {
+    UGN_WDG(0) UGN_WDG(1) UGN_WDG(3) UGN_WDG(5) UGN_WDG(7)
+    default: break;
+  }
+#undef UGN_WDG
+  ugn_set_error("ugn_conv3x3_dgrad_wino: unsupported epilogue combination %d (addend/raw_out need act)", flags);
+  return UGN_EINVAL;
+}
+
+}  // namespace
+
+extern "C" int ugn_wino_pack(const float* w_hwio, float* u_packed, int cin, int cout, int dgrad, void* stream) {
+  UGN_REQUIRE(w_hwio && u_packed, "ugn_wino_pack: null pointer");
+  UGN_REQUIRE(cin % 32 == 0 && cout % 32 == 0 && cin > 0 && cout > 0, "ugn_wino_pack: channels must be multiples of 32");
+  const int total = cin * cout;
+  hipLaunchKernelGGL(wino_pack_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, w_hwio, u_packed, cin,
+                     cout, dgrad);
+  UGN_CHECK_LAUNCH("wino_pack");
+  return 0;
+}
+
+extern "C" int ugn_conv3x3_fwd_wino(const float* in, const float* u_packed, float* out, uint8_t* out_idx, int n, int hw,
+                                    int cin, int cout, int pool, void* stream) {
+  UGN_REQUIRE(in && u_packed && out && n > 0, "ugn_conv3x3_fwd_wino: null pointer or n <= 0");
+  UGN_REQUIRE(!pool || out_idx, "ugn_conv3x3_fwd_wino: pool needs out_idx");
+  hipStream_t st = (hipStream_t)stream;
+#define WF(KC_, NC_, HW_, P_)                                                                                     \
+  if (cin == KC_ && cout == NC_ && hw == HW_ && (pool != 0) == (P_ != 0))                                          \
+    return launch_wino<KC_, NC_, HW_, P_ ? EPI_LRELU_POOL : EPI_LRELU, 0>(in, u_packed, out, out_idx, nullptr, nullptr, \
+                                                                          nullptr, n, st);
+  WF(32, 32, 64, 1) WF(32, 64, 32, 0) WF(64, 64, 32, 1) WF(64, 128, 16, 0) WF(128, 128, 16, 0)
+#undef WF
+  UGN_REQUIRE(false, "ugn_conv3x3_fwd_wino: unsupported shape cin=%d cout=%d hw=%d pool=%d", cin, cout, hw, pool);
+}
+
+extern "C" int ugn_conv3x3_dgrad_wino(const float* dz, const uint8_t* dz_idx, const float* u_packed, const float* act,
+                                      const float* addend, float* out, float* raw_out, int n, int hw, int cin, int cout,
+                                      void* stream) {
+  UGN_REQUIRE(dz && u_packed && out && n > 0, "ugn_conv3x3_dgrad_wino: null pointer or n <= 0");
+  hipStream_t st = (hipStream_t)stream;
+  UGN_REQUIRE(dz_idx == nullptr, "ugn_conv3x3_dgrad_wino: pooled-resolution gradients (dz_idx) are not implemented in the "
+                                 "Winograd path; use ugn_conv3x3_dgrad");
+#define WD(CI_, CO_, HW_)                        \
+  if (cin == CI_ && cout == CO_ && hw == HW_)    \
+    return launch_wino_dgrad<CO_, CI_, HW_>(dz, u_packed, out, act, addend, raw_out, n, st);
+  WD(32, 32, 64) WD(32, 64, 32) WD(64, 64, 32) WD(64, 128, 16) WD(128, 128, 16)
+#undef WD
+  UGN_REQUIRE(false, "ugn_conv3x3_dgrad_wino: unsupported shape cin=%d cout=%d hw=%d", cin, cout, hw);
+}

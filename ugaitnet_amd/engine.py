@@ -15,6 +15,8 @@ import math
 import numpy as np
 import torch
 
+import os
+
 from . import dp, ops
 
 F32 = torch.float32
@@ -29,6 +31,11 @@ CONV_SPECS = (
     ("a5", 3, 64, 128, 16, False), ("a6", 3, 128, 128, 16, False),
 )
 NBINS, FEAT, HIDDEN = 62, 128, 256
+
+# Winograd F(2x2,3x3) kernels for the 3x3 forward convolutions and for the data gradients whose incoming gradient is at
+# full resolution (a3, a5, a6, b1, b3, b4); the pooled layers' data gradients (a2, a4, b2) use the direct kernel.
+USE_WINOGRAD = os.environ.get("UGN_WINO", "1") != "0"
+WINO_DGRAD = ("a3", "a5", "a6", "b1", "b3", "b4")
 
 
 def glorot_uniform(gen, shape):
@@ -81,7 +88,9 @@ class Encoder:
 
     def __init__(self, store, prefix, cin):
         self.store, self.prefix, self.cin = store, prefix, cin
-        self.wp = {}       # packed forward weights of the 3x3 layers
+        self.wp = {}       # packed forward weights of the 3x3 layers (direct kernels)
+        self.uf = {}       # Winograd-transformed filters, forward
+        self.ud = {}       # Winograd-transformed filters, data gradient
         self.act = None    # saved activations of the last forward
         self.shape = None
         self.scratch = {}
@@ -94,8 +103,28 @@ class Encoder:
 
     def repack(self):
         for name, k, _, _, _, _ in CONV_SPECS:
-            if k == 3:
+            if k != 3:
+                continue
+            if USE_WINOGRAD:
+                self.uf[name] = ops.wino_pack(self.W(name), False, self.uf.get(name))
+                if name in WINO_DGRAD:
+                    self.ud[name] = ops.wino_pack(self.W(name), True, self.ud.get(name))
+            else:
                 self.wp[name] = ops.pack3x3(self.W(name), self.wp.get(name))
+
+    def conv(self, name, x, pool, out, idx=None):
+        """3x3 conv + LeakyReLU (+ MaxPool) of layer `name`."""
+        if USE_WINOGRAD:
+            return ops.conv3x3_fwd_wino(x, self.uf[name], self.W(name).shape[3], pool, out, idx)
+        return ops.conv3x3_fwd(x, self.wp[name], pool, out, idx)
+
+    def dgrad(self, name, dz, hw, **kw):
+        """Data gradient of layer `name` (fused epilogue options as in ops.conv3x3_dgrad)."""
+        if USE_WINOGRAD and name in WINO_DGRAD and kw.get("dz_idx") is None:
+            w = self.W(name)
+            kw.pop("dz_idx", None)
+            return ops.conv3x3_dgrad_wino(dz, self.ud[name], hw, w.shape[2], w.shape[3], **kw)
+        return ops.conv3x3_dgrad(dz, self.W(name), hw, **kw)
 
     def _buf(self, pool, key, shape, dtype=F32):
         t = pool.get(key)
@@ -112,26 +141,26 @@ class Encoder:
             self.act, self.shape = {}, (b, l)
         A = self.act
         U8 = torch.uint8
-        if not self.wp:
+        if not (self.uf if USE_WINOGRAD else self.wp):
             self.repack()
         xf = x.reshape(n, 60, 60, self.cin)
         A["x"] = xf
         a1 = ops.conv5x5_in_fwd(xf, self.W("a1"), self._buf(A, "a1", (n, 64, 64, 32)))
-        p2, i2 = ops.conv3x3_fwd(a1, self.wp["a2"], True, self._buf(A, "p2", (n, 32, 32, 32)),
+        p2, i2 = self.conv("a2", a1, True, self._buf(A, "p2", (n, 32, 32, 32)),
                                  self._buf(A, "i2", (n, 32, 32, 32), U8))
         m1 = ops.setmax_fwd(p2, b, l, m=self._buf(A, "m1", (b, 32, 32, 32)))
-        b1 = ops.conv3x3_fwd(m1, self.wp["b1"], False, self._buf(A, "b1", (b, 32, 32, 64)))
-        q2, j2 = ops.conv3x3_fwd(b1, self.wp["b2"], True, self._buf(A, "q2", (b, 16, 16, 64)),
+        b1 = self.conv("b1", m1, False, self._buf(A, "b1", (b, 32, 32, 64)))
+        q2, j2 = self.conv("b2", b1, True, self._buf(A, "q2", (b, 16, 16, 64)),
                                  self._buf(A, "j2", (b, 16, 16, 64), U8))
-        a3 = ops.conv3x3_fwd(p2, self.wp["a3"], False, self._buf(A, "a3", (n, 32, 32, 64)))
-        p4, i4 = ops.conv3x3_fwd(a3, self.wp["a4"], True, self._buf(A, "p4", (n, 16, 16, 64)),
+        a3 = self.conv("a3", p2, False, self._buf(A, "a3", (n, 32, 32, 64)))
+        p4, i4 = self.conv("a4", a3, True, self._buf(A, "p4", (n, 16, 16, 64)),
                                  self._buf(A, "i4", (n, 16, 16, 64), U8))
         _, s2 = ops.setmax_fwd(p4, b, l, addend=q2, m=self._buf(A, "m2", (b, 16, 16, 64)),
                                sum_out=self._buf(A, "s2", (b, 16, 16, 64)))
-        b3 = ops.conv3x3_fwd(s2, self.wp["b3"], False, self._buf(A, "b3", (b, 16, 16, 128)))
-        b4 = ops.conv3x3_fwd(b3, self.wp["b4"], False, self._buf(A, "b4", (b, 16, 16, 128)))
-        a5 = ops.conv3x3_fwd(p4, self.wp["a5"], False, self._buf(A, "a5", (n, 16, 16, 128)))
-        a6 = ops.conv3x3_fwd(a5, self.wp["a6"], False, self._buf(A, "a6", (n, 16, 16, 128)))
+        b3 = self.conv("b3", s2, False, self._buf(A, "b3", (b, 16, 16, 128)))
+        b4 = self.conv("b4", b3, False, self._buf(A, "b4", (b, 16, 16, 128)))
+        a5 = self.conv("a5", p4, False, self._buf(A, "a5", (n, 16, 16, 128)))
+        a6 = self.conv("a6", a5, False, self._buf(A, "a6", (n, 16, 16, 128)))
         m3, s3 = ops.setmax_fwd(a6, b, l, addend=b4, m=self._buf(A, "m3", (b, 16, 16, 128)),
                                 sum_out=self._buf(A, "s3", (b, 16, 16, 128)))
         feat = ops.hpp_fwd(m3, s3, self._buf(A, "feat", (NBINS, b, FEAT)))
@@ -150,31 +179,31 @@ class Encoder:
                                 buf("dzb4", (b, 16, 16, 128)))
         # global branch, block 2 (b3, b4)
         ops.conv3x3_wgrad(A["b3"], dzb4, 128, dw=self.G("b4"))
-        dzb3 = ops.conv3x3_dgrad(dzb4, self.W("b4"), 16, act=A["b3"], out=buf("dzb3", (b, 16, 16, 128)))
+        dzb3 = self.dgrad("b4", dzb4, 16, act=A["b3"], out=buf("dzb3", (b, 16, 16, 128)))
         ops.conv3x3_wgrad(A["s2"], dzb3, 128, dw=self.G("b3"))
         ds2 = buf("ds2", (b, 16, 16, 64))
-        dq2 = ops.conv3x3_dgrad(dzb3, self.W("b3"), 16, act=A["q2"], out=buf("dq2", (b, 16, 16, 64)), raw_out=ds2)
+        dq2 = self.dgrad("b3", dzb3, 16, act=A["q2"], out=buf("dq2", (b, 16, 16, 64)), raw_out=ds2)
         # global branch, block 1 (b1, b2); b2 is pooled: dq2 is its gradient at pooled resolution, routed through j2
         ops.conv3x3_wgrad(A["b1"], dq2, 64, dz_idx=A["j2"], dw=self.G("b2"))
-        dzb1 = ops.conv3x3_dgrad(dq2, self.W("b2"), 32, dz_idx=A["j2"], act=A["b1"], out=buf("dzb1", (b, 32, 32, 64)))
+        dzb1 = self.dgrad("b2", dq2, 32, dz_idx=A["j2"], act=A["b1"], out=buf("dzb1", (b, 32, 32, 64)))
         ops.conv3x3_wgrad(A["m1"], dzb1, 64, dw=self.G("b1"))
-        dm1 = ops.conv3x3_dgrad(dzb1, self.W("b1"), 32, out=buf("dm1", (b, 32, 32, 32)))
+        dm1 = self.dgrad("b1", dzb1, 32, out=buf("dm1", (b, 32, 32, 32)))
         # frame stack, block 3 (a5, a6)
         dz6 = ops.setmax_bwd(A["a6"], dm3, b, l, True, buf("dz6", (n, 16, 16, 128)))
         ops.conv3x3_wgrad(A["a5"], dz6, 128, dw=self.G("a6"))
-        dz5 = ops.conv3x3_dgrad(dz6, self.W("a6"), 16, act=A["a5"], out=buf("dz5", (n, 16, 16, 128)))
+        dz5 = self.dgrad("a6", dz6, 16, act=A["a5"], out=buf("dz5", (n, 16, 16, 128)))
         ops.conv3x3_wgrad(A["p4"], dz5, 128, dw=self.G("a5"))
         g4 = ops.setmax_bwd(A["p4"], ds2, b, l, False, buf("g4", (n, 16, 16, 64)))
-        dp4 = ops.conv3x3_dgrad(dz5, self.W("a5"), 16, act=A["p4"], addend=g4, out=g4)  # in place over the addend
+        dp4 = self.dgrad("a5", dz5, 16, act=A["p4"], addend=g4, out=g4)  # in place over the addend
         # block 2 (a3, a4)
         ops.conv3x3_wgrad(A["a3"], dp4, 64, dz_idx=A["i4"], dw=self.G("a4"))
-        dz3 = ops.conv3x3_dgrad(dp4, self.W("a4"), 32, dz_idx=A["i4"], act=A["a3"], out=buf("dz3", (n, 32, 32, 64)))
+        dz3 = self.dgrad("a4", dp4, 32, dz_idx=A["i4"], act=A["a3"], out=buf("dz3", (n, 32, 32, 64)))
         ops.conv3x3_wgrad(A["p2"], dz3, 64, dw=self.G("a3"))
         g2 = ops.setmax_bwd(A["p2"], dm1, b, l, False, buf("g2", (n, 32, 32, 32)))
-        dp2 = ops.conv3x3_dgrad(dz3, self.W("a3"), 32, act=A["p2"], addend=g2, out=g2)
+        dp2 = self.dgrad("a3", dz3, 32, act=A["p2"], addend=g2, out=g2)
         # block 1 (a1, a2)
         ops.conv3x3_wgrad(A["a1"], dp2, 32, dz_idx=A["i2"], dw=self.G("a2"))
-        dz1 = ops.conv3x3_dgrad(dp2, self.W("a2"), 64, dz_idx=A["i2"], act=A["a1"], out=buf("dz1", (n, 64, 64, 32)))
+        dz1 = self.dgrad("a2", dp2, 64, dz_idx=A["i2"], act=A["a1"], out=buf("dz1", (n, 64, 64, 32)))
         ops.conv5x5_in_wgrad(A["x"], dz1, self.G("a1"))
 
 

@@ -115,6 +115,37 @@ def conv3x3_dgrad(dz, w, hw, dz_idx=None, act=None, addend=None, out=None, raw_o
     return out
 
 
+def wino_pack(w, dgrad, out=None):
+    """HWIO [3,3,cin,cout] -> transformed filters G g G^T in the Winograd kernels' streaming order (16*cin*cout floats)."""
+    _chk(w)
+    cin, cout = w.shape[2], w.shape[3]
+    out = torch.empty((16 * cin * cout,), dtype=F32, device=w.device) if out is None else out
+    call("ugn_wino_pack", ptr(w), ptr(out), cin, cout, int(bool(dgrad)), _stream())
+    return out
+
+
+def conv3x3_fwd_wino(x, upk, cout, pool, out=None, idx=None):
+    _chk(x), _chk(upk)
+    n, hw, cin = x.shape[0], x.shape[1], x.shape[3]
+    ho = hw // 2 if pool else hw
+    out = torch.empty((n, ho, ho, cout), dtype=F32, device=x.device) if out is None else out
+    if pool and idx is None:
+        idx = torch.empty((n, ho, ho, cout), dtype=U8, device=x.device)
+    with _Timed(ROOFLINE_OP, hw == 64 and cin == 32 and cout == 32):
+        call("ugn_conv3x3_fwd_wino", ptr(x), ptr(upk), ptr(out), ptr(idx) if pool else None, n, hw, cin, cout,
+             int(bool(pool)), _stream())
+    return (out, idx) if pool else out
+
+
+def conv3x3_dgrad_wino(dz, upk, hw, cin, cout, dz_idx=None, act=None, addend=None, out=None, raw_out=None):
+    _chk(dz), _chk(upk)
+    n = dz.shape[0]
+    out = torch.empty((n, hw, hw, cin), dtype=F32, device=dz.device) if out is None else out
+    call("ugn_conv3x3_dgrad_wino", ptr(dz), ptr(dz_idx), ptr(upk), ptr(act), ptr(addend), ptr(out), ptr(raw_out), n, hw,
+         cin, cout, _stream())
+    return out
+
+
 def conv3x3_wgrad(x, dz, cout, dz_idx=None, dw=None):
     _chk(x), _chk(dz)
     n, hw, cin = x.shape[0], x.shape[1], x.shape[3]
