@@ -104,7 +104,7 @@ int ugn_l2norm_batch_fwd(const float* f, float* sig, int b, void* stream);
 int ugn_l2norm_batch_bwd(const float* f, const float* sig, const float* dsig, float* df, int b, void* stream);
 
 /* ---- classification head: transpose+Flatten+Dense(softmax) + categorical cross-entropy, :848-850,:865 ---
- * sig [62,b,256], wc [15872,ncls], bc [ncls].  part: workspace [62,b,ncls] floats.
+ * sig [62,b,256], wc [15872,ncls], bc [ncls].  part: workspace [248,b,ncls] floats.
  * probs [b,ncls]; row_loss [b] (= -sum t log p); dlogits [b,ncls] = (p - t) * grad_scale; hit [b] (argmax match). */
 int ugn_head_fwd(const float* sig, const float* wc, const float* bc, const float* onehot, float* part,
                  float* probs, float* row_loss, float* dlogits, float* hit, float grad_scale, int b, int ncls,

@@ -41,35 +41,39 @@ __global__ __launch_bounds__(256) void binfc_fwd_kernel(const float* __restrict_
   }
 }
 
-constexpr int FCB_BT = 16;
+constexpr int FCB_BT = 16;   // samples per pass
+constexpr int FCB_IQ = 32;   // input features per workgroup (grid.y = 128 / FCB_IQ)
 
+// dW[k][i][o] = sum_b feat[k][b][i] * dout[k][b][o];  dfeat[k][b][i] = sum_o dout[k][b][o] * W[k][i][o].
+// Workgroup (k, iq) owns input features i in [32*iq, 32*iq + 32): 248 workgroups instead of 62.
 __global__ __launch_bounds__(256) void binfc_bwd_kernel(const float* __restrict__ feat, const float* __restrict__ w,
                                                         const float* __restrict__ dout, float* __restrict__ dw,
                                                         float* __restrict__ dfeat, int bsz) {
-  __shared__ float sF[FCB_BT][FEAT];        // 8 KB
+  __shared__ float sF[FCB_BT][FCB_IQ];      // 2 KB
   __shared__ float sD[FCB_BT][HID];         // 16 KB
-  __shared__ float sWt[FEAT][33];           // 16.5 KB : W[k][i][o0..o0+31]
-  const int k = blockIdx.x, tid = threadIdx.x;
-  const float* wk = w + (size_t)k * FEAT * HID;
-  float* dwk = dw + (size_t)k * FEAT * HID;
+  __shared__ float sW[FCB_IQ][HID + 1];     // 32.9 KB: this workgroup's slice of W[k]
+  const int k = blockIdx.x, i0 = blockIdx.y * FCB_IQ, tid = threadIdx.x;
+  const float* wk = w + ((size_t)k * FEAT + i0) * HID;
+  float* dwk = dw + ((size_t)k * FEAT + i0) * HID;
+  for (int e = tid; e < FCB_IQ * HID; e += 256) sW[e / HID][e % HID] = wk[e];
   for (int b0 = 0; b0 < bsz; b0 += FCB_BT) {
     const int nb = min(FCB_BT, bsz - b0);
     __syncthreads();
-    for (int e = tid; e < FCB_BT * FEAT; e += 256) {
-      const int bb = e / FEAT, i = e % FEAT;
-      sF[bb][i] = bb < nb ? feat[((size_t)k * bsz + b0 + bb) * FEAT + i] : 0.f;
+    for (int e = tid; e < FCB_BT * FCB_IQ; e += 256) {
+      const int bb = e / FCB_IQ, i = e % FCB_IQ;
+      sF[bb][i] = bb < nb ? feat[((size_t)k * bsz + b0 + bb) * FEAT + i0 + i] : 0.f;
     }
     for (int e = tid; e < FCB_BT * HID; e += 256) {
       const int bb = e / HID, o = e % HID;
       sD[bb][o] = bb < nb ? dout[((size_t)k * bsz + b0 + bb) * HID + o] : 0.f;
     }
     __syncthreads();
-    // dW[i][o] (+)= sum_b feat[b][i] * dout[b][o]; thread = o
-    {
+    {   // dW rows of this slice; thread = output feature o
       float dreg[FCB_BT];
 #pragma unroll
       for (int bb = 0; bb < FCB_BT; ++bb) dreg[bb] = sD[bb][tid];
-      for (int i = 0; i < FEAT; ++i) {
+#pragma unroll 4
+      for (int i = 0; i < FCB_IQ; ++i) {
         float acc = 0.f;
 #pragma unroll
         for (int bb = 0; bb < FCB_BT; ++bb) acc = fmaf(sF[bb][i], dreg[bb], acc);
@@ -77,28 +81,17 @@ __global__ __launch_bounds__(256) void binfc_bwd_kernel(const float* __restrict_
         else dwk[(size_t)i * HID + tid] += acc;
       }
     }
-    // dfeat[b][i] = sum_o dout[b][o] * W[i][o]; thread = (half, i), half owns FCB_BT/2 samples
-    {
-      const int i = tid & 127, half = tid >> 7;
-      constexpr int HB = FCB_BT / 2;
-      float acc[HB];
-#pragma unroll
-      for (int q = 0; q < HB; ++q) acc[q] = 0.f;
-      for (int o0 = 0; o0 < HID; o0 += 32) {
-        __syncthreads();
-        for (int e = tid; e < FEAT * 32; e += 256) sWt[e >> 5][e & 31] = wk[(size_t)(e >> 5) * HID + o0 + (e & 31)];
-        __syncthreads();
-        for (int oo = 0; oo < 32; ++oo) {
-          const float wv = sWt[i][oo];
-#pragma unroll
-          for (int q = 0; q < HB; ++q) acc[q] = fmaf(sD[half * HB + q][o0 + oo], wv, acc[q]);
-        }
+    {   // dfeat for this slice; thread = (i, sample pair): 32 x 8 threads, 2 samples each
+      const int i = tid & 31, bq = tid >> 5;
+      float a0 = 0.f, a1 = 0.f;
+#pragma unroll 8
+      for (int o = 0; o < HID; ++o) {
+        const float wv = sW[i][o];
+        a0 = fmaf(sD[2 * bq][o], wv, a0);
+        a1 = fmaf(sD[2 * bq + 1][o], wv, a1);
       }
-#pragma unroll
-      for (int q = 0; q < HB; ++q) {
-        const int bb = half * HB + q;
-        if (bb < nb) dfeat[((size_t)k * bsz + b0 + bb) * FEAT + i] = acc[q];
-      }
+      if (2 * bq < nb) dfeat[((size_t)k * bsz + b0 + 2 * bq) * FEAT + i0 + i] = a0;
+      if (2 * bq + 1 < nb) dfeat[((size_t)k * bsz + b0 + 2 * bq + 1) * FEAT + i0 + i] = a1;
     }
   }
 }
@@ -193,31 +186,35 @@ __global__ void l2norm_bwd_kernel(const float* __restrict__ f, const float* __re
 // classification head
 // ------------------------------------------------------------------------------------------------------
 constexpr int HD_BT = 8;
+constexpr int HD_DQ = 64;                    // features per workgroup
+constexpr int HD_PARTS = NBINS * (HID / HD_DQ);   // 248 partial-logit slabs
 
-// part[k][b][c] = sum_d sig[k][b][d] * wc[(k*256+d)*ncls + c]
+// part[(k*4+q)][b][c] = sum_{d in quarter q} sig[k][b][d] * wc[(k*256+d)*ncls + c]
 __global__ __launch_bounds__(256) void head_partial_kernel(const float* __restrict__ sig, const float* __restrict__ wc,
                                                            float* __restrict__ part, int bsz, int ncls) {
-  __shared__ float sS[HD_BT][HID];
-  const int k = blockIdx.x, c = threadIdx.x;
+  __shared__ float sS[HD_BT][HD_DQ];
+  const int k = blockIdx.x, q = blockIdx.y, c = threadIdx.x;
+  const int d0 = q * HD_DQ;
   for (int b0 = 0; b0 < bsz; b0 += HD_BT) {
     __syncthreads();
-    for (int e = threadIdx.x; e < HD_BT * HID; e += 256) {
-      const int bb = e / HID, d = e % HID;
-      sS[bb][d] = b0 + bb < bsz ? sig[((size_t)k * bsz + b0 + bb) * HID + d] : 0.f;
+    for (int e = threadIdx.x; e < HD_BT * HD_DQ; e += 256) {
+      const int bb = e / HD_DQ, d = e % HD_DQ;
+      sS[bb][d] = b0 + bb < bsz ? sig[((size_t)k * bsz + b0 + bb) * HID + d0 + d] : 0.f;
     }
     __syncthreads();
     if (c < ncls) {
       float acc[HD_BT];
 #pragma unroll
       for (int bb = 0; bb < HD_BT; ++bb) acc[bb] = 0.f;
-      for (int d = 0; d < HID; ++d) {
-        const float wv = wc[((size_t)k * HID + d) * ncls + c];
+#pragma unroll 8
+      for (int d = 0; d < HD_DQ; ++d) {
+        const float wv = wc[((size_t)k * HID + d0 + d) * ncls + c];
 #pragma unroll
         for (int bb = 0; bb < HD_BT; ++bb) acc[bb] = fmaf(sS[bb][d], wv, acc[bb]);
       }
 #pragma unroll
       for (int bb = 0; bb < HD_BT; ++bb)
-        if (b0 + bb < bsz) part[((size_t)k * bsz + b0 + bb) * ncls + c] = acc[bb];
+        if (b0 + bb < bsz) part[((size_t)(k * (HID / HD_DQ) + q) * bsz + b0 + bb) * ncls + c] = acc[bb];
     }
   }
 }
@@ -247,7 +244,7 @@ __global__ __launch_bounds__(256) void head_softmax_kernel(const float* __restri
   float z = -INFINITY, t = 0.f;
   if (c < ncls) {
     z = bc[c];
-    for (int k = 0; k < NBINS; ++k) z += part[((size_t)k * bsz + b) * ncls + c];
+    for (int k = 0; k < HD_PARTS; ++k) z += part[((size_t)k * bsz + b) * ncls + c];
     t = onehot[(size_t)b * ncls + c];
   }
   const float zmax = block_reduce(z, sRed, true);
@@ -275,56 +272,59 @@ __global__ __launch_bounds__(256) void head_softmax_kernel(const float* __restri
 
 constexpr int HB_BT = 16;
 
+// Workgroup (k, q) owns features d in [64q, 64q+64) of bin k: rows (k*256 + d) of wc / dwc and columns d of dsig.
 __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__ sig, const float* __restrict__ wc,
                                                        const float* __restrict__ dlogits, float* __restrict__ dwc,
                                                        float* __restrict__ dbc, float* __restrict__ dsig, int accumulate,
                                                        int bsz, int ncls) {
-  __shared__ float sS[HB_BT][HID];    // 16 KB
-  __shared__ float sL[HB_BT][HID];    // dlogits rows (ncls <= 256), 16 KB
-  const int k = blockIdx.x, tid = threadIdx.x;
+  __shared__ float sS[HB_BT][HD_DQ];    // 4 KB
+  __shared__ float sL[HB_BT][HID];      // dlogits rows (ncls <= 256), 16 KB
+  const int k = blockIdx.x, q = blockIdx.y, tid = threadIdx.x;
+  const int d0 = q * HD_DQ;
   float bsum = 0.f;
   for (int b0 = 0; b0 < bsz; b0 += HB_BT) {
     const int nb = min(HB_BT, bsz - b0);
     __syncthreads();
+    for (int e = tid; e < HB_BT * HD_DQ; e += 256) {
+      const int bb = e / HD_DQ, d = e % HD_DQ;
+      sS[bb][d] = bb < nb ? sig[((size_t)k * bsz + b0 + bb) * HID + d0 + d] : 0.f;
+    }
     for (int e = tid; e < HB_BT * HID; e += 256) {
-      const int bb = e / HID, d = e % HID;
-      sS[bb][d] = bb < nb ? sig[((size_t)k * bsz + b0 + bb) * HID + d] : 0.f;
-      sL[bb][d] = (bb < nb && d < ncls) ? dlogits[(size_t)(b0 + bb) * ncls + d] : 0.f;
+      const int bb = e / HID, c = e % HID;
+      sL[bb][c] = (bb < nb && c < ncls) ? dlogits[(size_t)(b0 + bb) * ncls + c] : 0.f;
     }
     __syncthreads();
-    // dwc rows of this bin: thread = class c
-    if (tid < ncls) {
+    if (tid < ncls) {   // dwc rows of this slice; thread = class c
       float lreg[HB_BT];
 #pragma unroll
       for (int bb = 0; bb < HB_BT; ++bb) { lreg[bb] = sL[bb][tid]; bsum += lreg[bb]; }
-      for (int d = 0; d < HID; ++d) {
+#pragma unroll 4
+      for (int d = 0; d < HD_DQ; ++d) {
         float acc = 0.f;
 #pragma unroll
         for (int bb = 0; bb < HB_BT; ++bb) acc = fmaf(sS[bb][d], lreg[bb], acc);
-        const size_t o = ((size_t)k * HID + d) * ncls + tid;
+        const size_t o = ((size_t)k * HID + d0 + d) * ncls + tid;
         if (b0 == 0) dwc[o] = acc; else dwc[o] += acc;
       }
     }
-    // dsig[k][b][d] (+)= sum_c dlogits[b][c] * wc[(k*256+d)][c]; thread = d
-    {
-      float acc[HB_BT];
-#pragma unroll
-      for (int bb = 0; bb < HB_BT; ++bb) acc[bb] = 0.f;
-      const float* wrow = wc + ((size_t)k * HID + tid) * ncls;
+    {   // dsig[k][b][d] (+)= sum_c dlogits[b][c] * wc[k*256+d][c]; thread = (d, sample quad): 64 x 4 threads
+      const int d = tid & 63, bq = tid >> 6;
+      float acc[4] = {0.f, 0.f, 0.f, 0.f};
+      const float* wrow = wc + ((size_t)k * HID + d0 + d) * ncls;
       for (int c = 0; c < ncls; ++c) {
         const float wv = wrow[c];
 #pragma unroll
-        for (int bb = 0; bb < HB_BT; ++bb) acc[bb] = fmaf(sL[bb][c], wv, acc[bb]);
+        for (int j = 0; j < 4; ++j) acc[j] = fmaf(sL[4 * bq + j][c], wv, acc[j]);
       }
 #pragma unroll
-      for (int bb = 0; bb < HB_BT; ++bb)
-        if (bb < nb) {
-          const size_t o = ((size_t)k * bsz + b0 + bb) * HID + tid;
-          dsig[o] = accumulate ? dsig[o] + acc[bb] : acc[bb];
+      for (int j = 0; j < 4; ++j)
+        if (4 * bq + j < nb) {
+          const size_t o = ((size_t)k * bsz + b0 + 4 * bq + j) * HID + d0 + d;
+          dsig[o] = accumulate ? dsig[o] + acc[j] : acc[j];
         }
     }
   }
-  if (k == 0 && tid < ncls) dbc[tid] = bsum;
+  if (k == 0 && q == 0 && tid < ncls) dbc[tid] = bsum;
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -460,7 +460,7 @@ extern "C" int ugn_binfc_fwd(const float* feat, const float* w, float* out, int 
 extern "C" int ugn_binfc_bwd(const float* feat, const float* w, const float* dout, float* dw, float* dfeat, int b,
                              void* stream) {
   UGN_REQUIRE(feat && w && dout && dw && dfeat && b > 0, "ugn_binfc_bwd: bad arguments");
-  hipLaunchKernelGGL(binfc_bwd_kernel, dim3(NBINS), dim3(256), 0, (hipStream_t)stream, feat, w, dout, dw, dfeat, b);
+  hipLaunchKernelGGL(binfc_bwd_kernel, dim3(NBINS, FEAT / FCB_IQ), dim3(256), 0, (hipStream_t)stream, feat, w, dout, dw, dfeat, b);
   UGN_CHECK_LAUNCH("binfc_bwd");
   return 0;
 }
@@ -513,7 +513,7 @@ extern "C" int ugn_head_fwd(const float* sig, const float* wc, const float* bc, 
               "ugn_head_fwd: bad arguments");
   UGN_REQUIRE(ncls >= 1 && ncls <= 256, "ugn_head_fwd: ncls must be 1..256 (got %d)", ncls);
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(head_partial_kernel, dim3(NBINS), dim3(256), 0, st, sig, wc, part, b, ncls);
+  hipLaunchKernelGGL(head_partial_kernel, dim3(NBINS, HID / HD_DQ), dim3(256), 0, st, sig, wc, part, b, ncls);
   hipLaunchKernelGGL(head_softmax_kernel, dim3(b), dim3(256), 0, st, part, bc, onehot, probs, row_loss, dlogits, hit,
                      grad_scale, b, ncls);
   UGN_CHECK_LAUNCH("head_fwd");
@@ -524,7 +524,7 @@ extern "C" int ugn_head_bwd(const float* sig, const float* wc, const float* dlog
                             int accumulate, int b, int ncls, void* stream) {
   UGN_REQUIRE(sig && wc && dlogits && dwc && dbc && dsig && b > 0, "ugn_head_bwd: bad arguments");
   UGN_REQUIRE(ncls >= 1 && ncls <= 256, "ugn_head_bwd: ncls must be 1..256 (got %d)", ncls);
-  hipLaunchKernelGGL(head_bwd_kernel, dim3(NBINS), dim3(256), 0, (hipStream_t)stream, sig, wc, dlogits, dwc, dbc, dsig,
+  hipLaunchKernelGGL(head_bwd_kernel, dim3(NBINS, HID / HD_DQ), dim3(256), 0, (hipStream_t)stream, sig, wc, dlogits, dwc, dbc, dsig,
                      accumulate, b, ncls);
   UGN_CHECK_LAUNCH("head_bwd");
   return 0;

@@ -334,7 +334,7 @@ class GaitCore:
 
     def _head_bufs(self, b):
         n = self.nclasses
-        return dict(part=self._buf("part", (NBINS, b, n)), probs=self._buf("probs", (b, n)),
+        return dict(part=self._buf("part", (4 * NBINS, b, n)), probs=self._buf("probs", (b, n)),
                     row_loss=self._buf("row_loss", (b,)), dlogits=self._buf("dlogits", (b, n)), hit=self._buf("hit", (b,)))
 
     # ---- training step ----------------------------------------------------------------------------------

@@ -240,7 +240,7 @@ def head_fwd(sig, wc, bc, onehot, grad_scale, bufs=None):
     b, ncls = sig.shape[1], wc.shape[1]
     dev = sig.device
     if bufs is None:
-        bufs = dict(part=torch.empty((62, b, ncls), dtype=F32, device=dev),
+        bufs = dict(part=torch.empty((248, b, ncls), dtype=F32, device=dev),
                     probs=torch.empty((b, ncls), dtype=F32, device=dev),
                     row_loss=torch.empty((b,), dtype=F32, device=dev),
                     dlogits=torch.empty((b, ncls), dtype=F32, device=dev),
