@@ -87,20 +87,25 @@ def test_conv3x3_winograd_fwd_and_dgrad(dev, hw, cin, cout, pool):
         assert idx.max() <= 3 and np.array_equal(idx[clear], iref[clear])
     else:
         close(ops.conv3x3_fwd_wino(T(x, dev), uf, cout, False), act, 4e-6, "wino fwd")
-    # data gradient (with and without the fused epilogue); pooled-resolution gradients stay on the direct kernel
+    # data gradient (with and without the fused epilogue; pooled layers get their gradient at pooled resolution + argmax map)
     act_prev = rng.normal(size=(n, hw, hw, cin)).astype(np.float32)
     addend = rng.normal(size=(n, hw, hw, cin)).astype(np.float32)
-    dz = rng.normal(size=(n, hw, hw, cout)).astype(np.float32)
+    if pool:
+        dp = rng.normal(size=(n, hw // 2, hw // 2, cout)).astype(np.float32)
+        pidx = rng.integers(0, 4, size=dp.shape).astype(np.uint8)
+        dz = O.maxpool2x2_bwd(pidx, dp)
+        dz_t, idx_t = T(dp, dev), T(pidx, dev)
+    else:
+        dz = rng.normal(size=(n, hw, hw, cout)).astype(np.float32)
+        dz_t, idx_t = T(dz, dev), None
     _, dx_ref = O.conv2d_same_bwd(x.astype(np.float64), w.astype(np.float64), dz.astype(np.float64))
     ud = ops.wino_pack(T(w, dev), True)
-    close(ops.conv3x3_dgrad_wino(T(dz, dev), ud, hw, cin, cout), dx_ref, 5e-6, "wino dgrad plain")
+    close(ops.conv3x3_dgrad_wino(dz_t, ud, hw, cin, cout, dz_idx=idx_t), dx_ref, 5e-6, "wino dgrad plain")
     raw = torch.empty((n, hw, hw, cin), device=dev)
-    got = ops.conv3x3_dgrad_wino(T(dz, dev), ud, hw, cin, cout, act=T(act_prev, dev), addend=T(addend, dev), raw_out=raw)
+    got = ops.conv3x3_dgrad_wino(dz_t, ud, hw, cin, cout, dz_idx=idx_t, act=T(act_prev, dev), addend=T(addend, dev), raw_out=raw)
     t = dx_ref + addend
     close(raw, t, 5e-6, "wino dgrad raw")
     close(got, np.where(act_prev > 0, t, 0.3 * t), 5e-6, "wino dgrad fused")
-    with pytest.raises(ValueError):
-        ops.conv3x3_dgrad_wino(T(dz[:, ::2, ::2], dev).contiguous(), ud, hw, cin, cout, dz_idx=torch.zeros((n, hw // 2, hw // 2, cout), dtype=torch.uint8, device=dev))
 
 
 def test_conv3x3_pool_first_max_on_ties(dev):

@@ -29,7 +29,10 @@ constexpr int HPIECES = 46;                                     // 1 KB LDS-DMA 
 constexpr int SIN = HPIECES * 256;                              // one halo buffer (floats) = 47,104 B
 constexpr int SU = 16 * 4 * 32 * 4;                             // one filter slice: [16 pts][4 kq][32 out][4 ch] = 32 KB
 constexpr int LDS_BYTES = (2 * SIN + 2 * SU) * 4;               // 159,744 B (of 163,840)
-constexpr int IN_ITERS = (NPIX * 8 + 255) / 256;                // 11
+// pooled-resolution input (data gradient of a MaxPool'ed layer): the LDS tile holds the 10x10 POOLED pixels under the halo,
+// 40 floats per pixel = 32 gradient values + 32 argmax bytes; the scatter through the argmax happens when a lane reads
+// its 4x4 patch (3x3 pooled pixels), so the 4x larger un-pooled gradient is never materialised anywhere.
+constexpr int UPW = 10, UCS = 40, UPIX = UPW * UPW, USLOTS = UPIX * 10, UPIECES = 16;
 
 enum { EPI_LRELU = 0, EPI_LRELU_POOL = 1, EPI_DGRAD = 2 };
 
@@ -99,6 +102,55 @@ __device__ __forceinline__ void dma_halo_piece(const float* __restrict__ in, con
   dma16(src, lds_byte_base + (unsigned)inst * 1024u);   // all-scalar: base, inst are wave-uniform SGPR values
 }
 
+// One 1 KB piece of the POOLED input tile: slot s = pooled pixel s/10, part s%10 (0..7 values, 8..9 argmax bytes).
+template <int KC, int HW>
+__device__ __forceinline__ void dma_pooled_piece(const float* __restrict__ dz, const uint8_t* __restrict__ idx,
+                                                 const float* __restrict__ zeros, int img, int ry0, int rx0, int chunk,
+                                                 int inst, int lane, unsigned lds_byte_base) {
+  constexpr int HP = HW / 2;
+  int slot = inst * 64 + lane;
+  slot = slot < USLOTS ? slot : USLOTS - 1;
+  const int p = slot / 10, c = slot - p * 10;
+  const int pr = ry0 / 2 - 1 + p / UPW, pc = rx0 / 2 - 1 + p % UPW;
+  const bool ok = pr >= 0 && pr < HP && pc >= 0 && pc < HP;
+  const size_t o = (((size_t)img * HP + pr) * HP + pc) * KC + chunk * 32;
+  const void* src = !ok ? (const void*)zeros
+                        : (c < 8 ? (const void*)(dz + o + c * 4) : (const void*)(idx + o + (c - 8) * 16));
+  dma16(src, lds_byte_base + (unsigned)inst * 1024u);
+}
+
+// The 4x4 patch of one channel pair.  Plain input: 16 ds_read_b64 from the halo tile.  Pooled input: the 3x3 pooled
+// pixels under the patch; patch element (r,c) is pooled pixel ((r+1)>>1, (c+1)>>1) if its argmax byte equals the
+// element's position ((r+1)&1)*2 + ((c+1)&1) inside the 2x2 window, else 0 (MaxPool backward).
+template <int IN_UNPOOL>
+__device__ __forceinline__ void read_pair(float2 (&dn)[16], const unsigned (&iw)[9], const float* base, int h) {
+  if constexpr (!IN_UNPOOL) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) dn[e] = *reinterpret_cast<const float2*>(base + ((e >> 2) * PW + (e & 3)) * CS + 2 * h);
+  } else {
+    float2 pv[9];
+#pragma unroll
+    for (int q = 0; q < 9; ++q) pv[q] = *reinterpret_cast<const float2*>(base + ((q / 3) * UPW + (q % 3)) * UCS + 2 * h);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int r = e >> 2, c = e & 3;
+      const int q = ((r + 1) >> 1) * 3 + ((c + 1) >> 1);
+      const unsigned pos = (((r + 1) & 1) << 1) | ((c + 1) & 1);
+      const unsigned b0 = (iw[q] >> (16 * h)) & 0xffu, b1 = (iw[q] >> (16 * h + 8)) & 0xffu;
+      dn[e].x = b0 == pos ? pv[q].x : 0.f;
+      dn[e].y = b1 == pos ? pv[q].y : 0.f;
+    }
+  }
+}
+
+template <int IN_UNPOOL>
+__device__ __forceinline__ void read_idx(unsigned (&iw)[9], const float* ibase) {
+  if constexpr (IN_UNPOOL) {
+#pragma unroll
+    for (int q = 0; q < 9; ++q) iw[q] = *reinterpret_cast<const unsigned*>(ibase + ((q / 3) * UPW + (q % 3)) * UCS);
+  }
+}
+
 // 32 KB filter slice: linear in both spaces, 4 pieces of 1 KB per wave (8 waves)
 __device__ __forceinline__ void dma_u_slice(const float* __restrict__ us, unsigned lds_byte_base, int tid, int wave) {
 #pragma unroll
@@ -106,8 +158,9 @@ __device__ __forceinline__ void dma_u_slice(const float* __restrict__ us, unsign
 }
 
 // KC: GEMM K channels, NCF: output channels of the layer (a workgroup owns 32 of them), HW: image size
-template <int KC, int NCF, int HW, int EPI, int EFLAGS>
-__global__ __launch_bounds__(512, 2) void wino_kernel(const float* __restrict__ in, const float* __restrict__ upk,
+template <int KC, int NCF, int HW, int IN_UNPOOL, int EPI, int EFLAGS>
+__global__ __launch_bounds__(512, 2) void wino_kernel(const float* __restrict__ in, const uint8_t* __restrict__ in_idx,
+                                                      const float* __restrict__ upk,
                                                       float* __restrict__ out, uint8_t* __restrict__ out_idx,
                                                       const float* __restrict__ act, const float* __restrict__ addend,
                                                       float* __restrict__ raw_out, const float* __restrict__ zeros,
@@ -125,7 +178,9 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const float* __restrict__ 
   const int lj = lane & 15, kq = lane >> 4;
   // A-side role of the lane: tile (tr, tc) of the wave's 2 x 8 tiles; B-side: output channel lj (+16), both: channels 4*kq..
   const int a_tr = lj >> 3, a_tc = lj & 7;
-  const int pbase = ((4 * tg + 2 * a_tr) * PW + 2 * a_tc) * CS + 4 * kq;   // patch origin in the halo tile
+  // patch origin in the halo tile (plain) / first of the 3x3 pooled pixels in the pooled tile
+  const int pbase = IN_UNPOOL ? ((2 * tg + a_tr) * UPW + a_tc) * UCS + 4 * kq : ((4 * tg + 2 * a_tr) * PW + 2 * a_tc) * CS + 4 * kq;
+  const int ibase = ((2 * tg + a_tr) * UPW + a_tc) * UCS + 32 + kq;          // argmax dword of channels 4kq..4kq+3 (pooled)
   const int ubase = (kq * 32 + ch * 16 + lj) * 4;
 
   int item = blockIdx.x;
@@ -136,9 +191,15 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const float* __restrict__ 
   // ---- prologue: halo(item, chunk 0) -> sIn[0]; U(item, 0, 0) -> sU[0]
   {
     const int region = item / NSPLIT, img = region / RPI, rrem = region % RPI;
+    if constexpr (IN_UNPOOL) {
 #pragma unroll
-    for (int j = 0; j < 6; ++j)
-      dma_halo_piece<KC, HW>(in, zeros, img, (rrem / RPX) * 16, (rrem % RPX) * 16, 0, wave * 6 + j, lane, sin_bytes);
+      for (int j = 0; j < 2; ++j)
+        dma_pooled_piece<KC, HW>(in, in_idx, zeros, img, (rrem / RPX) * 16, (rrem % RPX) * 16, 0, wave * 2 + j, lane, sin_bytes);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 6; ++j)
+        dma_halo_piece<KC, HW>(in, zeros, img, (rrem / RPX) * 16, (rrem % RPX) * 16, 0, wave * 6 + j, lane, sin_bytes);
+    }
     dma_u_slice(u_slice(item, 0, 0), su_bytes, tid, wave);
   }
   int ibuf = 0, ubuf = 0;
@@ -174,12 +235,12 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const float* __restrict__ 
         dma_u_slice(G == 0 ? u_slice(item, chunk, 1) : u_slice(n_item, n_chunk, 0), su_bytes + (unsigned)(ubuf ^ 1) * SU * 4u, tid, wave);
         if (first) {
           first = false;
+          unsigned iw0[9];
+          read_idx<IN_UNPOOL>(iw0, sIn + ibase);
 #pragma unroll
           for (int h = 0; h < 2; ++h) {
             float2 d[16], t[16];
-#pragma unroll
-            for (int e = 0; e < 16; ++e)
-              d[e] = *reinterpret_cast<const float2*>(sIn + pbase + ((e >> 2) * PW + (e & 3)) * CS + 2 * h);
+            read_pair<IN_UNPOOL>(d, iw0, sIn + pbase, h);
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
               t[0 + c] = make_float2(d[0 + c].x - d[8 + c].x, d[0 + c].y - d[8 + c].y);
@@ -199,6 +260,8 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const float* __restrict__ 
         // the NEXT group's patch comes from this chunk (G == 0) or from the next chunk's halo, which landed a group ago
         constexpr bool tnext = true;   // (at the very end this transforms a re-fetched tile that nobody consumes)
         const float* sNx = (G == 0 ? sIn + 16 : sInNext) + pbase;
+        const float* sNi = (G == 0 ? sIn + 4 : sInNext) + ibase;
+        unsigned iw[9];
         // The next group's transformed patch is built in the shadow of this group's MFMAs and written straight into the
         // V registers of points that have already been multiplied (V[4r..4r+3] are dead once point 4r+3 is done), so only
         // one V set plus the row-pass temporaries are live: the kernel must fit 256 arch VGPRs beside 128 accumulators.
@@ -224,19 +287,22 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const float* __restrict__ 
 #pragma unroll
         for (int pt = 0; pt < 16; ++pt) {
           const int cu = pt & 1, nu = cu ^ 1;
-          if (tnext && (pt == 0 || pt == 3)) {
-#pragma unroll
-            for (int e = 0; e < 16; ++e)
-              dn[e] = *reinterpret_cast<const float2*>(sNx + ((e >> 2) * PW + (e & 3)) * CS + (pt == 0 ? 0 : 2));   // channels +0,1 / +2,3
-          }
+          if (tnext && pt == 0) read_idx<IN_UNPOOL>(iw, sNi);
+          if (tnext && (pt == 0 || pt == 3)) read_pair<IN_UNPOOL>(dn, iw, sNx, pt == 0 ? 0 : 1);   // channels +0,1 / +2,3
           if (pt < 15) u[nu] = *reinterpret_cast<const float4*>(sU + ubase + (pt + 1) * 512);
 #pragma unroll
           for (int st = 0; st < 4; ++st) acc[pt] = mfma16(V[pt][st], u[cu][st], acc[pt]);
           // halo of the next stage: all 12 pieces of this wave during the FIRST group of the chunk, so that they are
           // a full group old at the next barrier and the next chunk's first transform can be pipelined as well
-          if (G == 0 && pt >= 2 && pt < 14 && (pt & 1) == 0)
-            dma_halo_piece<KC, HW>(in, zeros, n_img, n_ry0, n_rx0, n_chunk, wave * 6 + ((pt - 2) >> 1), lane,
-                                   sin_bytes + (unsigned)(ibuf ^ 1) * SIN * 4u);
+          if constexpr (IN_UNPOOL) {
+            if (G == 0 && (pt == 4 || pt == 8))
+              dma_pooled_piece<KC, HW>(in, in_idx, zeros, n_img, n_ry0, n_rx0, n_chunk, wave * 2 + (pt >> 3), lane,
+                                       sin_bytes + (unsigned)(ibuf ^ 1) * SIN * 4u);
+          } else {
+            if (G == 0 && pt >= 2 && pt < 14 && (pt & 1) == 0)
+              dma_halo_piece<KC, HW>(in, zeros, n_img, n_ry0, n_rx0, n_chunk, wave * 6 + ((pt - 2) >> 1), lane,
+                                     sin_bytes + (unsigned)(ibuf ^ 1) * SIN * 4u);
+          }
           if (tnext) {
             if (pt == 1) { rowpass(tn0, 0); rowpass(tn0, 1); }
             if (pt == 2) { rowpass(tn0, 2); rowpass(tn0, 3); }   // pair 0 done before pair 1 is loaded at point 3
@@ -344,10 +410,10 @@ inline const float* zero_block() {
   return z;
 }
 
-template <int KC, int NCF, int HW, int EPI, int EFLAGS>
-int launch_wino(const float* in, const float* upk, float* out, uint8_t* out_idx, const float* act, const float* addend,
-                float* raw_out, int n, hipStream_t st) {
-  auto kern = wino_kernel<KC, NCF, HW, EPI, EFLAGS>;
+template <int KC, int NCF, int HW, int IN_UNPOOL, int EPI, int EFLAGS>
+int launch_wino(const float* in, const uint8_t* in_idx, const float* upk, float* out, uint8_t* out_idx, const float* act,
+                const float* addend, float* raw_out, int n, hipStream_t st) {
+  auto kern = wino_kernel<KC, NCF, HW, IN_UNPOOL, EPI, EFLAGS>;
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
@@ -358,18 +424,19 @@ int launch_wino(const float* in, const float* upk, float* out, uint8_t* out_idx,
   if (!zeros) { ugn_set_error("wino: cannot allocate the zero block"); return UGN_EINVAL; }
   const int nitems = n * (HW / 16) * (HW / 16) * (NCF / 32);
   const int grid = nitems < kGrid ? nitems : kGrid;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), LDS_BYTES, st, in, upk, out, out_idx, act, addend, raw_out, zeros, nitems);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), LDS_BYTES, st, in, in_idx, upk, out, out_idx, act, addend, raw_out, zeros,
+                     nitems);
   UGN_CHECK_LAUNCH("wino");
   return 0;
 }
 
-template <int KC, int NCF, int HW>
-int launch_wino_dgrad(const float* in, const float* upk, float* out, const float* act, const float* addend, float* raw_out,
-                      int n, hipStream_t st) {
+template <int KC, int NCF, int HW, int IN_UNPOOL>
+int launch_wino_dgrad(const float* in, const uint8_t* in_idx, const float* upk, float* out, const float* act,
+                      const float* addend, float* raw_out, int n, hipStream_t st) {
   const int flags = (act ? 1 : 0) | (addend ? 2 : 0) | (raw_out ? 4 : 0);
 #define UGN_WDG(F_)                                                                                                  \
   case F_:                                                                                                           \
-    return launch_wino<KC, NCF, HW, EPI_DGRAD, F_>(in, upk, out, nullptr, act, addend, raw_out, n, st);
+    return launch_wino<KC, NCF, HW, IN_UNPOOL, EPI_DGRAD, F_>(in, in_idx, upk, out, nullptr, act, addend, raw_out, n, st);
   switch (flags) {
     UGN_WDG(0) UGN_WDG(1) UGN_WDG(3) UGN_WDG(5) UGN_WDG(7)
     default: break;
@@ -398,8 +465,8 @@ extern "C" int ugn_conv3x3_fwd_wino(const float* in, const float* u_packed, floa
   hipStream_t st = (hipStream_t)stream;
 #define WF(KC_, NC_, HW_, P_)                                                                                     \
   if (cin == KC_ && cout == NC_ && hw == HW_ && (pool != 0) == (P_ != 0))                                          \
-    return launch_wino<KC_, NC_, HW_, P_ ? EPI_LRELU_POOL : EPI_LRELU, 0>(in, u_packed, out, out_idx, nullptr, nullptr, \
-                                                                          nullptr, n, st);
+    return launch_wino<KC_, NC_, HW_, 0, P_ ? EPI_LRELU_POOL : EPI_LRELU, 0>(in, nullptr, u_packed, out, out_idx, nullptr, \
+                                                                             nullptr, nullptr, n, st);
   WF(32, 32, 64, 1) WF(32, 64, 32, 0) WF(64, 64, 32, 1) WF(64, 128, 16, 0) WF(128, 128, 16, 0)
 #undef WF
   UGN_REQUIRE(false, "ugn_conv3x3_fwd_wino: unsupported shape cin=%d cout=%d hw=%d pool=%d", cin, cout, hw, pool);
@@ -410,12 +477,11 @@ extern "C" int ugn_conv3x3_dgrad_wino(const float* dz, const uint8_t* dz_idx, co
                                       void* stream) {
   UGN_REQUIRE(dz && u_packed && out && n > 0, "ugn_conv3x3_dgrad_wino: null pointer or n <= 0");
   hipStream_t st = (hipStream_t)stream;
-  UGN_REQUIRE(dz_idx == nullptr, "ugn_conv3x3_dgrad_wino: pooled-resolution gradients (dz_idx) are not implemented in the "
-                                 "Winograd path; use ugn_conv3x3_dgrad");
-#define WD(CI_, CO_, HW_)                        \
-  if (cin == CI_ && cout == CO_ && hw == HW_)    \
-    return launch_wino_dgrad<CO_, CI_, HW_>(dz, u_packed, out, act, addend, raw_out, n, st);
-  WD(32, 32, 64) WD(32, 64, 32) WD(64, 64, 32) WD(64, 128, 16) WD(128, 128, 16)
+  const int unpool = dz_idx != nullptr;
+#define WD(CI_, CO_, HW_, U_)                                 \
+  if (cin == CI_ && cout == CO_ && hw == HW_ && unpool == U_) \
+    return launch_wino_dgrad<CO_, CI_, HW_, U_>(dz, dz_idx, u_packed, out, act, addend, raw_out, n, st);
+  WD(32, 32, 64, 1) WD(32, 64, 32, 0) WD(64, 64, 32, 1) WD(64, 128, 16, 0) WD(128, 128, 16, 0)
 #undef WD
-  UGN_REQUIRE(false, "ugn_conv3x3_dgrad_wino: unsupported shape cin=%d cout=%d hw=%d", cin, cout, hw);
+  UGN_REQUIRE(false, "ugn_conv3x3_dgrad_wino: unsupported shape cin=%d cout=%d hw=%d unpool=%d", cin, cout, hw, unpool);
 }

@@ -32,10 +32,10 @@ CONV_SPECS = (
 )
 NBINS, FEAT, HIDDEN = 62, 128, 256
 
-# Winograd F(2x2,3x3) kernels for the 3x3 forward convolutions and for the data gradients whose incoming gradient is at
-# full resolution (a3, a5, a6, b1, b3, b4); the pooled layers' data gradients (a2, a4, b2) use the direct kernel.
+# Winograd F(2x2,3x3) kernels for the 3x3 forward convolutions and data gradients (UGN_WINO=0 selects the direct
+# implicit-GEMM kernels, whose MaxPool tie-breaking on exactly equal activations follows the reference's first-max rule).
 USE_WINOGRAD = os.environ.get("UGN_WINO", "1") != "0"
-WINO_DGRAD = ("a3", "a5", "a6", "b1", "b3", "b4")
+WINO_DGRAD = ("a2", "a3", "a4", "a5", "a6", "b1", "b2", "b3", "b4")
 
 
 def glorot_uniform(gen, shape):
@@ -120,9 +120,8 @@ class Encoder:
 
     def dgrad(self, name, dz, hw, **kw):
         """Data gradient of layer `name` (fused epilogue options as in ops.conv3x3_dgrad)."""
-        if USE_WINOGRAD and name in WINO_DGRAD and kw.get("dz_idx") is None:
+        if USE_WINOGRAD and name in WINO_DGRAD:
             w = self.W(name)
-            kw.pop("dz_idx", None)
             return ops.conv3x3_dgrad_wino(dz, self.ud[name], hw, w.shape[2], w.shape[3], **kw)
         return ops.conv3x3_dgrad(dz, self.W(name), hw, **kw)
 
