@@ -88,16 +88,24 @@ __device__ __forceinline__ void dma16(const void* gsrc, unsigned lds_dst_uniform
 
 // One 1 KB piece of the halo tile of (image, region origin, chunk): lane l fills 16-byte slot inst*64 + l; slot s =
 // pixel s/9, quarter-row s%9 (the 9th is the pad of the 36-float pixel stride and receives don't-care bytes).
-template <int KC, int HW>
-__device__ __forceinline__ void dma_halo_piece(const float* __restrict__ in, const float* __restrict__ zeros, int img, int ry0,
-                                               int rx0, int chunk, int inst, int lane, unsigned lds_byte_base) {
+// Geometry of halo slot (piece inst, lane): row, column and quarter-row, packed (yy << 16 | xx << 8 | c4).  It does not
+// depend on the item, so each lane computes its 6 values once per launch instead of dividing by 9 and 18 per piece.
+__device__ __forceinline__ int halo_slot_geometry(int inst, int lane) {
   inst = inst < HPIECES ? inst : HPIECES - 1;      // 8 waves x 6 pieces = 48 >= 46: the surplus repeats the last piece
   int slot = inst * 64 + lane;
   slot = slot < HSLOTS ? slot : HSLOTS - 1;
   const int p = slot / 9, c4 = slot - p * 9;
   const int yy = p / PW, xx = p - yy * PW;
+  return (yy << 16) | (xx << 8) | c4;
+}
+
+template <int KC, int HW>
+__device__ __forceinline__ void dma_halo_piece(const float* __restrict__ in, const float* __restrict__ zeros, int img, int ry0,
+                                               int rx0, int chunk, int inst, int geom, unsigned lds_byte_base) {
+  inst = inst < HPIECES ? inst : HPIECES - 1;
+  const int yy = geom >> 16, xx = (geom >> 8) & 0xff, c4 = geom & 0xff;
   const int gy = ry0 - 1 + yy, gx = rx0 - 1 + xx;
-  const bool ok = c4 < 8 && gy >= 0 && gy < HW && gx >= 0 && gx < HW;
+  const bool ok = c4 < 8 && (unsigned)gy < (unsigned)HW && (unsigned)gx < (unsigned)HW;
   const float* src = ok ? in + (((size_t)img * HW + gy) * HW + gx) * KC + chunk * 32 + c4 * 4 : zeros;
   dma16(src, lds_byte_base + (unsigned)inst * 1024u);   // all-scalar: base, inst are wave-uniform SGPR values
 }
@@ -185,6 +193,9 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const float* __restrict__ 
 
   int item = blockIdx.x;
   if (item >= nitems) return;
+  int hgeo[6];
+#pragma unroll
+  for (int j = 0; j < 6; ++j) hgeo[j] = halo_slot_geometry(wave * 6 + j, lane);
   auto u_slice = [&](int it, int chunk, int G) {
     return upk + (((size_t)(it % NSPLIT) * NCHUNK + chunk) * 2 + G) * SU;
   };
@@ -198,7 +209,7 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const float* __restrict__ 
     } else {
 #pragma unroll
       for (int j = 0; j < 6; ++j)
-        dma_halo_piece<KC, HW>(in, zeros, img, (rrem / RPX) * 16, (rrem % RPX) * 16, 0, wave * 6 + j, lane, sin_bytes);
+        dma_halo_piece<KC, HW>(in, zeros, img, (rrem / RPX) * 16, (rrem % RPX) * 16, 0, wave * 6 + j, hgeo[j], sin_bytes);
     }
     dma_u_slice(u_slice(item, 0, 0), su_bytes, tid, wave);
   }
@@ -266,8 +277,6 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const float* __restrict__ 
         // V registers of points that have already been multiplied (V[4r..4r+3] are dead once point 4r+3 is done), so only
         // one V set plus the row-pass temporaries are live: the kernel must fit 256 arch VGPRs beside 128 accumulators.
         float2 dn[16], tn0[16], tn1[16];
-        float4 u[2];
-        u[0] = *reinterpret_cast<const float4*>(sU + ubase);
         auto rowpass = [&](float2 (&tn)[16], int c) {
           tn[0 + c] = make_float2(dn[0 + c].x - dn[8 + c].x, dn[0 + c].y - dn[8 + c].y);
           tn[4 + c] = make_float2(dn[4 + c].x + dn[8 + c].x, dn[4 + c].y + dn[8 + c].y);
@@ -284,23 +293,37 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const float* __restrict__ 
           V[r * 4 + 2][2] = tn1[r * 4 + 2].x - tn1[r * 4 + 1].x; V[r * 4 + 2][3] = tn1[r * 4 + 2].y - tn1[r * 4 + 1].y;
           V[r * 4 + 3][2] = tn1[r * 4 + 1].x - tn1[r * 4 + 3].x; V[r * 4 + 3][3] = tn1[r * 4 + 1].y - tn1[r * 4 + 3].y;
         };
+        // points are multiplied in PAIRS with their 4 k-steps interleaved (pt0 s0, pt1 s0, pt0 s1, ...): consecutive
+        // MFMAs on one accumulator would each wait out the 40-cycle dependent latency of v_mfma_f32_16x16x4_f32
+        float4 u[2][2];
+        u[0][0] = *reinterpret_cast<const float4*>(sU + ubase);
+        u[0][1] = *reinterpret_cast<const float4*>(sU + ubase + 512);
 #pragma unroll
-        for (int pt = 0; pt < 16; ++pt) {
-          const int cu = pt & 1, nu = cu ^ 1;
+        for (int pp = 0; pp < 8; ++pp) {
+          const int cu = pp & 1, nu = cu ^ 1;
+          if (pp < 7) {
+            u[nu][0] = *reinterpret_cast<const float4*>(sU + ubase + (2 * pp + 2) * 512);
+            u[nu][1] = *reinterpret_cast<const float4*>(sU + ubase + (2 * pp + 3) * 512);
+          }
+#pragma unroll
+          for (int st = 0; st < 4; ++st) {
+            acc[2 * pp] = mfma16(V[2 * pp][st], u[cu][0][st], acc[2 * pp]);
+            acc[2 * pp + 1] = mfma16(V[2 * pp + 1][st], u[cu][1][st], acc[2 * pp + 1]);
+          }
+#pragma unroll
+          for (int half = 0; half < 2; ++half) {
+          const int pt = 2 * pp + half;
           if (tnext && pt == 0) read_idx<IN_UNPOOL>(iw, sNi);
           if (tnext && (pt == 0 || pt == 3)) read_pair<IN_UNPOOL>(dn, iw, sNx, pt == 0 ? 0 : 1);   // channels +0,1 / +2,3
-          if (pt < 15) u[nu] = *reinterpret_cast<const float4*>(sU + ubase + (pt + 1) * 512);
-#pragma unroll
-          for (int st = 0; st < 4; ++st) acc[pt] = mfma16(V[pt][st], u[cu][st], acc[pt]);
-          // halo of the next stage: all 12 pieces of this wave during the FIRST group of the chunk, so that they are
+          // halo of the next stage: all pieces of this wave during the FIRST group of the chunk, so that they are
           // a full group old at the next barrier and the next chunk's first transform can be pipelined as well
           if constexpr (IN_UNPOOL) {
-            if (G == 0 && (pt == 4 || pt == 8))
-              dma_pooled_piece<KC, HW>(in, in_idx, zeros, n_img, n_ry0, n_rx0, n_chunk, wave * 2 + (pt >> 3), lane,
+            if (G == 0 && (pt == 1 || pt == 2))
+              dma_pooled_piece<KC, HW>(in, in_idx, zeros, n_img, n_ry0, n_rx0, n_chunk, wave * 2 + (pt - 1), lane,
                                        sin_bytes + (unsigned)(ibuf ^ 1) * SIN * 4u);
           } else {
-            if (G == 0 && pt >= 2 && pt < 14 && (pt & 1) == 0)
-              dma_halo_piece<KC, HW>(in, zeros, n_img, n_ry0, n_rx0, n_chunk, wave * 6 + ((pt - 2) >> 1), lane,
+            if (G == 0 && pt >= 1 && pt < 7)   // early in the group: the pieces must have landed by the group's end
+              dma_halo_piece<KC, HW>(in, zeros, n_img, n_ry0, n_rx0, n_chunk, wave * 6 + (pt - 1), hgeo[pt - 1],
                                      sin_bytes + (unsigned)(ibuf ^ 1) * SIN * 4u);
           }
           if (tnext) {
@@ -312,6 +335,7 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const float* __restrict__ 
             if (pt == 8) colpass(1);
             if (pt == 12) colpass(2);
             if (pt == 15) colpass(3);
+          }
           }
         }
         ubuf ^= 1;
