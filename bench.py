@@ -66,7 +66,9 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--skip-masked", action="store_true", help="(reported separately) skip masked (clip, modality) pairs")
+    ap.add_argument("--skip-masked", action="store_true",
+                    help="run each encoder only on the clips whose modality flag is 1 (exactly the same results; the default "
+                         "line computes the masked pairs too)")
     args = ap.parse_args()
 
     import torch
@@ -88,9 +90,9 @@ def main():
 
     xs, uses, labels, onehot = make_batch(KINDS, B_PER_GPU, L, NCLS, seed=232323 + rank)
     core = GaitCore([2, 1, 1], nclasses=NCLS, fuse_mode="sign_max", margin=0.2, loss_weights=(1.0, 0.1), device=dev,
-                    seed=232323, lr=1e-4, world_size=world)
+                    seed=232323, lr=1e-4, world_size=world, skip_masked=args.skip_masked)
     dxs = [torch.from_numpy(x).to(dev) for x in xs]
-    dus = [torch.from_numpy(u).to(dev) for u in uses]
+    dus = uses if args.skip_masked else [torch.from_numpy(u).to(dev) for u in uses]   # flags: host copies when they steer the launch
     doh = torch.from_numpy(onehot).to(dev)
 
     def sync_all():
@@ -114,6 +116,28 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     losses = core.losses()
+
+    # secondary figure, same workload: encoders run only on the clips whose modality flag is 1 (the gate multiplies the
+    # rest by 0, so every result is unchanged; tests/test_fullsize_gpu.py).  Never reported as `value`.
+    skip_rate = None
+    if not args.skip_masked:
+        del core
+        torch.cuda.empty_cache()
+        core2 = GaitCore([2, 1, 1], nclasses=NCLS, fuse_mode="sign_max", margin=0.2, loss_weights=(1.0, 0.1), device=dev,
+                         seed=232323, lr=1e-4, world_size=world, skip_masked=True)
+        for _ in range(args.warmup):
+            core2.train_step(dxs, uses, labels, doh)
+        sync_all()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            core2.train_step(dxs, uses, labels, doh)
+        sync_all()
+        dt2 = time.perf_counter() - t1
+        if world > 1:
+            t = torch.tensor([dt2], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt2 = float(t.item())
+        skip_rate = world * B_PER_GPU * args.steps / dt2
 
     if rank == 0:
         clips = world * B_PER_GPU * args.steps
@@ -139,10 +163,12 @@ def main():
                    higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
                    config=dict(workload="C3: 3 modalities (of 2ch + gray + depth), 25x60x60, 24 clips/GPU, 12 ids x 2, "
                                         "150 classes, sign_max, 7-pattern masks, triplet(0.2)+0.1*xent, Adam 1e-4",
-                               clips_per_gpu=B_PER_GPU, parallelism="dp%d" % world, masked_pairs_skipped=False),
+                               clips_per_gpu=B_PER_GPU, parallelism="dp%d" % world, masked_pairs_skipped=bool(args.skip_masked)),
                    whole_step_tflops=round(value * FLOP_PER_CLIP / 1e12, 2),
                    whole_step_frac_of_f32_mfma_peak=round(value * FLOP_PER_CLIP / world / PEAK_F32_MFMA, 4),
                    loss=round(losses["loss"], 5), roofline=roof)
+        if skip_rate is not None:
+            out["value_skip_masked"] = round(skip_rate, 2)   # 29 of the 72 (clip, modality) pairs of this batch are masked
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

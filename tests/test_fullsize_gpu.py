@@ -74,3 +74,23 @@ def test_gradient_is_linear_in_the_loss_weights(setup):
     ref = g_tri + 0.1 * g_id
     err = (core.store.grad - ref).norm() / ref.norm()
     assert float(err) < 1e-5
+
+
+def test_skipping_masked_pairs_changes_no_result(setup):
+    """skip_masked runs each encoder only on the clips whose flag is 1: the gate multiplies the rest by 0 anyway."""
+    from ugaitnet_amd.engine import GaitCore
+    core, xs, uses, labels, onehot = setup
+    core.loss_weights = (1.0, 0.1)
+    core.forward_backward(xs, uses, labels, onehot)
+    sig = core.sig.cpu().numpy().copy()
+    g_dense = core.store.grad.clone()
+    l_dense = core.losses()
+    skip = GaitCore([2, 1, 1], nclasses=NCLS, fuse_mode="sign_max", margin=0.2, loss_weights=(1.0, 0.1), skip_masked=True)
+    skip.set_params_numpy(core.get_params_numpy())
+    skip.forward_backward(xs, uses, labels, onehot)
+    assert np.array_equal(np.abs(sig), np.abs(skip.sig.cpu().numpy()))          # bit-identical up to the sign of zeros
+    assert skip.encoders[0].shape[0] == int(uses[0].sum()) < 24                  # really ran on the active clips only
+    ls = skip.losses()
+    assert abs(ls['loss'] - l_dense['loss']) <= 1e-6 and ls['acc'] == l_dense['acc']
+    err = (skip.store.grad - g_dense).norm() / g_dense.norm()
+    assert float(err) < 1e-5      # weight-gradient partial sums are grouped differently over fewer frames

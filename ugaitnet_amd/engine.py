@@ -211,7 +211,7 @@ class GaitCore:
 
     def __init__(self, in_channels, nclasses=0, multimodal=None, fuse_mode="sign_max", margin=0.2,
                  loss_weights=(1.0, 1.0), device=None, seed=None, lr=1e-4, beta_1=0.9, beta_2=0.999, epsilon=1e-7,
-                 process_group=None, world_size=1):
+                 process_group=None, world_size=1, skip_masked=False):
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         self.in_channels = tuple(int(c) for c in in_channels)
         self.nmod = len(self.in_channels)
@@ -226,6 +226,11 @@ class GaitCore:
         self.lr, self.beta_1, self.beta_2, self.epsilon = float(lr), float(beta_1), float(beta_2), float(epsilon)
         self.iterations = 0
         self.pg, self.world = process_group, int(world_size)
+        # skip_masked: run each encoder only on the clips whose modality flag is 1.  A masked (clip, modality) pair is
+        # multiplied by 0 in the gate (nets/mj_uwyhNets_ba.py:51-54), so its branch output contributes exactly 0 forward
+        # and receives exactly 0 gradient: skipping it changes no result, only the work done.
+        self.skip_masked = bool(skip_masked)
+        self._active = None
 
         named = []
         for mi, cin in enumerate(self.in_channels):
@@ -306,7 +311,26 @@ class GaitCore:
         """xs: list of [B,L,60,60,C_m]; uses: list of [B,1] / [B] (multimodal only).  Returns the signature [62,B,256]."""
         xs = [self._dev(x) for x in xs]
         b = xs[0].shape[0]
-        outs = [enc.forward(x) for enc, x in zip(self.encoders, xs)]
+        self._active = None
+        if self.multimodal and self.skip_masked:
+            outs, self._active = [], []
+            for mi, (enc, x) in enumerate(zip(self.encoders, xs)):
+                u = uses[mi]
+                uh = (u.detach().cpu().numpy() if isinstance(u, torch.Tensor) else np.asarray(u)).reshape(-1)
+                rows = np.nonzero(uh != 0)[0]
+                full = self._buf("out_full%d" % mi, (NBINS, b, HIDDEN))
+                if len(rows) == b:
+                    self._active.append(None)
+                    outs.append(enc.forward(x))
+                    continue
+                idx = torch.from_numpy(rows).to(self.device)
+                self._active.append(idx)
+                full.zero_()
+                if len(rows):
+                    full.index_copy_(1, idx, enc.forward(x.index_select(0, idx).contiguous()))
+                outs.append(full)
+        else:
+            outs = [enc.forward(x) for enc, x in zip(self.encoders, xs)]
         self.last_b = b
         if not self.multimodal:
             self.sig = outs[0]           # single-modality graph: no gate, no normalisation (:893-903)
@@ -358,8 +382,15 @@ class GaitCore:
                                       [self._buf("dout%d" % m, (NBINS, b, HIDDEN)) for m in range(self.nmod)])
         else:
             douts = [dsig]
-        for enc, d in zip(self.encoders, douts):
-            enc.backward(d, self.scratch)
+        for mi, (enc, d) in enumerate(zip(self.encoders, douts)):
+            idx = self._active[mi] if self._active is not None else None
+            if idx is None:
+                enc.backward(d, self.scratch)
+            elif idx.numel() == 0:
+                for name, _ in branch_param_shapes(enc.cin):   # no active clip: this branch's gradient is exactly zero
+                    enc.G(name).zero_()
+            else:
+                enc.backward(d.index_select(1, idx).contiguous(), self.scratch)
 
     def forward_loss_only(self, xs, uses, labels, onehot):
         """Validation step: forward + both losses/metrics, no parameter gradients."""
