@@ -68,6 +68,9 @@ int ugn_conv3x3_wgrad(const float* in, const float* dz, const uint8_t* dz_idx, f
  * (dgrad = 0 for ugn_conv3x3_fwd_wino, 1 for ugn_conv3x3_dgrad_wino).  Arguments otherwise as the direct versions;
  * in the data gradient `addend` and `raw_out` require `act`. */
 int ugn_wino_pack(const float* w_hwio, float* u_packed, int cin, int cout, int dgrad, void* stream);
+/* Same for up to 32 (layer, direction) jobs in ONE launch; all five arrays are HOST arrays of length njobs. */
+int ugn_wino_pack_multi(const float* const* w_hwio_host, float* const* u_packed_host, const int* cin_host,
+                        const int* cout_host, const int* dgrad_host, int njobs, void* stream);
 int ugn_conv3x3_fwd_wino(const float* in, const float* u_packed, float* out, uint8_t* out_idx, int n, int hw, int cin,
                          int cout, int pool, void* stream);
 int ugn_conv3x3_dgrad_wino(const float* dz, const uint8_t* dz_idx, const float* u_packed, const float* act,

@@ -108,6 +108,20 @@ def test_conv3x3_winograd_fwd_and_dgrad(dev, hw, cin, cout, pool):
     close(got, np.where(act_prev > 0, t, 0.3 * t), 5e-6, "wino dgrad fused")
 
 
+def test_wino_pack_multi_matches_single(dev):
+    from ugaitnet_amd import ops
+    rng = np.random.default_rng(77)
+    ws = [T(rng.normal(size=(3, 3, ci, co)).astype(np.float32), dev) for ci, co in ((32, 32), (64, 128), (128, 128))]
+    jobs, refs = [], []
+    for w in ws:
+        for dg in (False, True):
+            jobs.append((w, torch.zeros(16 * w.shape[2] * w.shape[3], device=dev), dg))
+            refs.append(ops.wino_pack(w, dg))
+    ops.wino_pack_multi(jobs)
+    for (_, u, _), r in zip(jobs, refs):
+        assert torch.equal(u, r)
+
+
 def test_conv3x3_pool_first_max_on_ties(dev):
     """Constant input -> every window is a 4-way tie in the interior: the FIRST element (index 0) must win."""
     from ugaitnet_amd import ops

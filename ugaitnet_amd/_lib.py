@@ -30,6 +30,7 @@ PROTOTYPES = {
     "ugn_conv3x3_wgrad_ws": (_sz, [_i, _i, _i, _i]),
     "ugn_conv3x3_wgrad": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p, _sz, _p]),
     "ugn_wino_pack": (_i, [_p, _p, _i, _i, _i, _p]),
+    "ugn_wino_pack_multi": (_i, [C.POINTER(_p), C.POINTER(_p), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), _i, _p]),
     "ugn_conv3x3_fwd_wino": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "ugn_conv3x3_dgrad_wino": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "ugn_setmax_fwd": (_i, [_p, _p, _p, _p, _i, _i, _sz, _p]),

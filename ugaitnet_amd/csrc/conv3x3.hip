@@ -614,18 +614,29 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_kernel(const float* __restric
   }
 }
 
-// dst[o][e] = sum over g == o (mod nout) of src[g][e];  e in float4 units
-__global__ void reduce_slabs_kernel(const float4* __restrict__ src, float4* __restrict__ dst, int nelem4, int nin,
-                                    int nout) {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  const int o = blockIdx.y;
-  if (e >= nelem4) return;
+// dst[e] = sum_g src[g][e] (e in float4 units): 256 threads = 16 elements x 16 slab lanes; each lane sums every 16th slab
+// in a fixed order and the 16 partial sums are combined in a fixed order through LDS -> one launch, bitwise reproducible.
+__global__ __launch_bounds__(256) void reduce_slabs_kernel(const float4* __restrict__ src, float4* __restrict__ dst,
+                                                           int nelem4, int nin) {
+  __shared__ float4 sR[16][16];
+  const int le = threadIdx.x & 15, lg = threadIdx.x >> 4;
+  const int e = blockIdx.x * 16 + le;
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int g = o; g < nin; g += nout) {
-    const float4 v = src[(size_t)g * nelem4 + e];
-    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  if (e < nelem4)
+    for (int g = lg; g < nin; g += 16) {
+      const float4 v = src[(size_t)g * nelem4 + e];
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+  sR[lg][le] = s;
+  __syncthreads();
+  if (lg == 0 && e < nelem4) {
+#pragma unroll
+    for (int k = 1; k < 16; ++k) {
+      const float4 v = sR[k][le];
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    dst[e] = s;
   }
-  dst[(size_t)o * nelem4 + e] = s;
 }
 
 __global__ void pack3x3_kernel(const float* __restrict__ w, float* __restrict__ wp, int cin, int cout) {
@@ -744,24 +755,15 @@ int launch_wgrad(const float* in, const float* dz, const uint8_t* dz_idx, float*
   int groups = WGRAD_WGS / C::NCOMBO;
   if (groups > tiles) groups = tiles;
   const size_t nelem = (size_t)9 * CI * CO;
-  constexpr int NOUT = 16;
-  const int mid = groups > NOUT ? NOUT : 0;
-  if (ws_floats < nelem * (size_t)(groups + mid)) {
-    ugn_set_error("wgrad3x3: workspace too small (%zu < %zu floats)", ws_floats, nelem * (size_t)(groups + mid));
+  if (ws_floats < nelem * (size_t)groups) {
+    ugn_set_error("wgrad3x3: workspace too small (%zu < %zu floats)", ws_floats, nelem * (size_t)groups);
     return UGN_EINVAL;
   }
   hipLaunchKernelGGL(kern, dim3(groups * C::NCOMBO), dim3(256), C::LDS_BYTES, st, in, dz, dz_idx, ws, tiles, groups);
   UGN_CHECK_LAUNCH("wgrad3x3");
   const int nelem4 = (int)(nelem / 4);
-  const dim3 rb(256), rg((nelem4 + 255) / 256, 1);
-  if (mid) {
-    float* ws2 = ws + nelem * groups;
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(rg.x, NOUT), rb, 0, st, (const float4*)ws, (float4*)ws2, nelem4,
-                       groups, NOUT);
-    hipLaunchKernelGGL(reduce_slabs_kernel, rg, rb, 0, st, (const float4*)ws2, (float4*)dw, nelem4, NOUT, 1);
-  } else {
-    hipLaunchKernelGGL(reduce_slabs_kernel, rg, rb, 0, st, (const float4*)ws, (float4*)dw, nelem4, groups, 1);
-  }
+  hipLaunchKernelGGL(reduce_slabs_kernel, dim3((nelem4 + 15) / 16), dim3(256), 0, st, (const float4*)ws, (float4*)dw, nelem4,
+                     groups);
   UGN_CHECK_LAUNCH("wgrad3x3 reduce");
   return 0;
 }
@@ -839,7 +841,7 @@ extern "C" size_t ugn_conv3x3_wgrad_ws(int n, int hw, int cin, int cout) {
   const long tiles = (long)n * (hw / WG_TH) * (hw / TW);
   long groups = WGRAD_WGS / ncombo;
   if (groups > tiles) groups = tiles;
-  return (size_t)9 * cin * cout * (size_t)(groups + 16) * sizeof(float);
+  return (size_t)9 * cin * cout * (size_t)groups * sizeof(float);
 }
 
 extern "C" int ugn_conv3x3_wgrad(const float* in, const float* dz, const uint8_t* dz_idx, float* dw, int n, int hw,

@@ -46,9 +46,9 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
 // at consecutive 16-byte slots (conflict-free).
 // fwd : g[dy][dx] = w[dy][dx][k = cin][n = cout]            (kc = cin, nc = cout)
 // dgrad: g[dy][dx] = w[2-dy][2-dx][n = cin][k = cout]        (kc = cout, nc = cin)
-__global__ void wino_pack_kernel(const float* __restrict__ w, float* __restrict__ u, int cin, int cout, int dgrad) {
+__device__ __forceinline__ void wino_pack_one(const float* __restrict__ w, float* __restrict__ u, int cin, int cout, int dgrad,
+                                              int e) {
   const int kc = dgrad ? cout : cin, nc = dgrad ? cin : cout;
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= kc * nc) return;
   const int k = e % kc, n = e / kc;
   float g[3][3];
@@ -73,6 +73,21 @@ __global__ void wino_pack_kernel(const float* __restrict__ w, float* __restrict_
     dst[(r * 4 + 2) * 512] = u2;
     dst[(r * 4 + 3) * 512] = u3;
   }
+}
+
+__global__ void wino_pack_kernel(const float* __restrict__ w, float* __restrict__ u, int cin, int cout, int dgrad) {
+  wino_pack_one(w, u, cin, cout, dgrad, blockIdx.x * blockDim.x + threadIdx.x);
+}
+
+struct WinoPackTable {   // up to 32 (layer, direction) jobs in one launch; job = blockIdx.y
+  const float* w[32];
+  float* u[32];
+  int cin[32], cout[32], dgrad[32];
+};
+
+__global__ void wino_pack_multi_kernel(WinoPackTable t) {
+  const int j = blockIdx.y;
+  wino_pack_one(t.w[j], t.u[j], t.cin[j], t.cout[j], t.dgrad[j], blockIdx.x * blockDim.x + threadIdx.x);
 }
 
 // global -> LDS, 16 B per lane, no VGPR destination (LDS address = M0 + lane * 16).  Inline asm: with the builtin hipcc
@@ -479,6 +494,24 @@ extern "C" int ugn_wino_pack(const float* w_hwio, float* u_packed, int cin, int 
   hipLaunchKernelGGL(wino_pack_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, w_hwio, u_packed, cin,
                      cout, dgrad);
   UGN_CHECK_LAUNCH("wino_pack");
+  return 0;
+}
+
+extern "C" int ugn_wino_pack_multi(const float* const* w_hwio_host, float* const* u_packed_host, const int* cin_host,
+                                   const int* cout_host, const int* dgrad_host, int njobs, void* stream) {
+  UGN_REQUIRE(w_hwio_host && u_packed_host && cin_host && cout_host && dgrad_host, "ugn_wino_pack_multi: null pointer");
+  UGN_REQUIRE(njobs >= 1 && njobs <= 32, "ugn_wino_pack_multi: njobs must be 1..32 (got %d)", njobs);
+  WinoPackTable t = {};
+  int maxe = 0;
+  for (int j = 0; j < njobs; ++j) {
+    UGN_REQUIRE(w_hwio_host[j] && u_packed_host[j] && cin_host[j] % 32 == 0 && cout_host[j] % 32 == 0 && cin_host[j] > 0 &&
+                    cout_host[j] > 0, "ugn_wino_pack_multi: bad job %d", j);
+    t.w[j] = w_hwio_host[j]; t.u[j] = u_packed_host[j];
+    t.cin[j] = cin_host[j]; t.cout[j] = cout_host[j]; t.dgrad[j] = dgrad_host[j];
+    if (cin_host[j] * cout_host[j] > maxe) maxe = cin_host[j] * cout_host[j];
+  }
+  hipLaunchKernelGGL(wino_pack_multi_kernel, dim3((maxe + 255) / 256, njobs), dim3(256), 0, (hipStream_t)stream, t);
+  UGN_CHECK_LAUNCH("wino_pack_multi");
   return 0;
 }
 

@@ -102,15 +102,22 @@ class Encoder:
         return self.store.g[self.prefix + name]
 
     def repack(self):
-        for name, k, _, _, _, _ in CONV_SPECS:
-            if k != 3:
-                continue
-            if USE_WINOGRAD:
-                self.uf[name] = ops.wino_pack(self.W(name), False, self.uf.get(name))
-                if name in WINO_DGRAD:
-                    self.ud[name] = ops.wino_pack(self.W(name), True, self.ud.get(name))
-            else:
-                self.wp[name] = ops.pack3x3(self.W(name), self.wp.get(name))
+        """Refresh the kernel-ready copies of the 3x3 weights (after every optimizer step): one launch per branch."""
+        if USE_WINOGRAD:
+            jobs = []
+            for name, k, _, _, _, _ in CONV_SPECS:
+                if k != 3:
+                    continue
+                w = self.W(name)
+                for store, dgrad in ((self.uf, False), (self.ud, True)):
+                    if name not in store:
+                        store[name] = torch.empty((16 * w.shape[2] * w.shape[3],), dtype=F32, device=w.device)
+                    jobs.append((w, store[name], dgrad))
+            ops.wino_pack_multi(jobs)
+        else:
+            for name, k, _, _, _, _ in CONV_SPECS:
+                if k == 3:
+                    self.wp[name] = ops.pack3x3(self.W(name), self.wp.get(name))
 
     def conv(self, name, x, pool, out, idx=None):
         """3x3 conv + LeakyReLU (+ MaxPool) of layer `name`."""

@@ -124,6 +124,19 @@ def wino_pack(w, dgrad, out=None):
     return out
 
 
+def wino_pack_multi(jobs):
+    """jobs: list of (w HWIO tensor, u_packed tensor, dgrad flag); one launch for up to 32 of them."""
+    for k in range(0, len(jobs), 32):
+        part = jobs[k:k + 32]
+        n = len(part)
+        ws = ptr_array([w for w, _, _ in part])
+        us = ptr_array([u for _, u, _ in part])
+        cin = (C.c_int * n)(*[w.shape[2] for w, _, _ in part])
+        cout = (C.c_int * n)(*[w.shape[3] for w, _, _ in part])
+        dg = (C.c_int * n)(*[int(bool(d)) for _, _, d in part])
+        call("ugn_wino_pack_multi", ws, us, cin, cout, dg, n, _stream())
+
+
 def conv3x3_fwd_wino(x, upk, cout, pool, out=None, idx=None):
     _chk(x), _chk(upk)
     n, hw, cin = x.shape[0], x.shape[1], x.shape[3]
