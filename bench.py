@@ -157,7 +157,18 @@ def main():
                 traffic = json.load(open(tfile)).get("hbm_bytes_per_launch")
             roof = dict(bound="mfma", achieved=round(achieved, 2), peak=PEAK_F32_MFMA / 1e12, unit="TFLOP/s",
                         frac=round(achieved * 1e12 / PEAK_F32_MFMA, 4), traffic=traffic, kernel=name,
-                        launches=len(evs), avg_us=round(avg_s * 1e6, 1))
+                        launches=len(evs), avg_us=round(avg_s * 1e6, 1),
+                        note="achieved = direct-convolution (algorithmic) FLOPs / time; the kernel is Winograd F(2x2,3x3) and "
+                             "executes 1/2.25 of them on the fp32 MFMA, so frac can exceed 1")
+            others = []
+            for oname, oflops in ops.EXTRA_TIMED.items():
+                oev = ops.TIMING.get(oname, [])
+                if oev:
+                    oavg = float(np.mean([a.elapsed_time(b) for a, b in oev])) * 1e-3
+                    otf = oflops * frames / oavg / 1e12
+                    others.append(dict(kernel=oname, achieved=round(otf, 2), frac=round(otf * 1e12 / PEAK_F32_MFMA, 4),
+                                       avg_us=round(oavg * 1e6, 1), launches=len(oev)))
+            roof["other_kernels"] = others
         out = dict(metric="clips/sec (3-mod, L=25, 60x60) fwd+bwd+Adam", value=round(value, 2), unit="clips/s",
                    n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(dt / args.steps * 1e3, 3),
                    higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",

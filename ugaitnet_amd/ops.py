@@ -46,6 +46,11 @@ TIMING_ENABLED = False
 TIMING = {}
 ROOFLINE_OP = "conv3x3_fwd[a2: 32->32 @64x64 +LeakyReLU +MaxPool]"
 ROOFLINE_FLOPS_PER_FRAME = 2.0 * 9 * 32 * 32 * 64 * 64   # algorithmic FLOPs of that layer per frame (a.c2)
+# further kernels timed the same way (reported beside the roofline object): name -> algorithmic FLOPs per frame
+EXTRA_TIMED = {
+    "conv3x3_wgrad[a4: 64->64 @32x32, pooled dz]": 2.0 * 9 * 64 * 64 * 32 * 32,
+    "conv3x3_fwd[a6: 128->128 @16x16 +LeakyReLU]": 2.0 * 9 * 128 * 128 * 16 * 16,
+}
 
 
 class _Timed:
@@ -144,7 +149,8 @@ def conv3x3_fwd_wino(x, upk, cout, pool, out=None, idx=None):
     out = torch.empty((n, ho, ho, cout), dtype=F32, device=x.device) if out is None else out
     if pool and idx is None:
         idx = torch.empty((n, ho, ho, cout), dtype=U8, device=x.device)
-    with _Timed(ROOFLINE_OP, hw == 64 and cin == 32 and cout == 32):
+    name = ROOFLINE_OP if (hw == 64 and cin == 32 and cout == 32) else "conv3x3_fwd[a6: 128->128 @16x16 +LeakyReLU]"
+    with _Timed(name, (hw == 64 and cin == 32 and cout == 32) or (hw == 16 and cin == 128 and cout == 128 and n >= 100)):
         call("ugn_conv3x3_fwd_wino", ptr(x), ptr(upk), ptr(out), ptr(idx) if pool else None, n, hw, cin, cout,
              int(bool(pool)), _stream())
     return (out, idx) if pool else out
@@ -167,7 +173,8 @@ def conv3x3_wgrad(x, dz, cout, dz_idx=None, dw=None):
     if nbytes == 0:
         raise ValueError("conv3x3_wgrad: unsupported shape hw=%d cin=%d cout=%d" % (hw, cin, cout))
     ws = _WS.get(nbytes, x.device)
-    call("ugn_conv3x3_wgrad", ptr(x), ptr(dz), ptr(dz_idx), ptr(dw), n, hw, cin, cout, ptr(ws), ws.numel(), _stream())
+    with _Timed("conv3x3_wgrad[a4: 64->64 @32x32, pooled dz]", hw == 32 and cin == 64 and cout == 64 and n >= 100):
+        call("ugn_conv3x3_wgrad", ptr(x), ptr(dz), ptr(dz_idx), ptr(dw), n, hw, cin, cout, ptr(ws), ws.numel(), _stream())
     return dw
 
 
