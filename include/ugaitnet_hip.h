@@ -76,6 +76,11 @@ int ugn_conv3x3_fwd_wino(const float* in, const float* u_packed, float* out, uin
 int ugn_conv3x3_dgrad_wino(const float* dz, const uint8_t* dz_idx, const float* u_packed, const float* act,
                            const float* addend, float* out, float* raw_out, int n, int hw, int cin, int cout,
                            void* stream);
+/* Winograd F(2x2,3x3) weight gradient (Conv2DBackpropFilter of the same layers); arguments as ugn_conv3x3_wgrad,
+ * workspace size from ugn_conv3x3_wgrad_wino_ws (0 = unsupported shape).  Deterministic (fixed summation order). */
+size_t ugn_conv3x3_wgrad_wino_ws(int n, int hw, int cin, int cout);
+int ugn_conv3x3_wgrad_wino(const float* in, const float* dz, const uint8_t* dz_idx, float* dw, int n, int hw, int cin,
+                           int cout, void* ws, size_t ws_bytes, void* stream);
 
 /* ---- set pooling over the L frames: tf.math.reduce_max(x, axis=1), nets/mj_uwyhNets_ba.py:435,451,463 ----
  * p [b,l,s] -> m [b,s]; if addend != NULL also sum_out = m + addend (the Add layers :452,:465). */

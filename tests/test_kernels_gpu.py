@@ -164,6 +164,8 @@ def test_conv3x3_dgrad_and_wgrad(dev, hw, cin, cout, pool):
     close(got2, np.where(act_prev > 0, t, 0.3 * t), 3e-6, "dgrad fused")
     dw = ops.conv3x3_wgrad(T(x, dev), dz_t, cout, dz_idx=idx_t)
     close(dw, dw_ref, 5e-6, "wgrad")
+    dww = ops.conv3x3_wgrad_wino(T(x, dev), dz_t, cout, dz_idx=idx_t)
+    close(dww, dw_ref, 1e-5, "wgrad winograd")
 
 
 def test_conv3x3_wgrad_many_frames(dev):
@@ -178,6 +180,23 @@ def test_conv3x3_wgrad_many_frames(dev):
     dw_ref, _ = O.conv2d_same_bwd(x.astype(np.float64), np.zeros((3, 3, cin, cout)), dzu.astype(np.float64), need_dx=False)
     dw = ops.conv3x3_wgrad(T(x, dev), T(dp, dev), cout, dz_idx=T(idx, dev))
     close(dw, dw_ref, 1e-5, "wgrad many frames")
+    dww = ops.conv3x3_wgrad_wino(T(x, dev), T(dp, dev), cout, dz_idx=T(idx, dev))
+    close(dww, dw_ref, 2e-5, "wgrad winograd many frames")
+    again = ops.conv3x3_wgrad_wino(T(x, dev), T(dp, dev), cout, dz_idx=T(idx, dev))
+    assert torch.equal(dww, again), "winograd wgrad must be bitwise reproducible"
+
+
+@pytest.mark.parametrize("n", [1, 7, 70])
+def test_conv3x3_wgrad_wino_region_loop(dev, n):
+    """Odd frame counts: fewer regions than workgroups (n=1), ragged shares of the persistent loop (n=7, 70)."""
+    from ugaitnet_amd import ops
+    rng = np.random.default_rng(50 + n)
+    hw, cin, cout = 16, 128, 128
+    x = rng.uniform(-1, 1, (n, hw, hw, cin)).astype(np.float32)
+    dz = rng.normal(size=(n, hw, hw, cout)).astype(np.float32)
+    dw_ref, _ = O.conv2d_same_bwd(x.astype(np.float64), np.zeros((3, 3, cin, cout)), dz.astype(np.float64), need_dx=False)
+    dww = ops.conv3x3_wgrad_wino(T(x, dev), T(dz, dev), cout)
+    close(dww, dw_ref, 2e-5, "wgrad winograd n=%d" % n)
 
 
 def test_unsupported_shape_raises(dev):

@@ -36,5 +36,7 @@ for hw, cin, cout, pool, name in CFGS:
     t_dd = timeit(lambda: ops.conv3x3_dgrad(dz, w, hw, dz_idx=idx, act=act))
     t_dw = timeit(lambda: ops.conv3x3_dgrad_wino(dz, ud, hw, cin, cout, dz_idx=idx, act=act))
     t_wg = timeit(lambda: ops.conv3x3_wgrad(x, dz, cout, dz_idx=idx))
+    t_ww = timeit(lambda: ops.conv3x3_wgrad_wino(x, dz, cout, dz_idx=idx))
+    print("%s wgrad wino %6.1f us (%5.1f TF)" % (name, t_ww, gf / t_ww * 1e3))
     print("%s %3dx%-3d %3d->%-3d  fwd direct %6.1f us (%5.1f TF)  wino %6.1f us (%5.1f TF) | dgrad direct %6.1f (%5.1f)  wino %6.1f (%5.1f) | wgrad %6.1f (%5.1f)" % (
         name, hw, hw, cin, cout, t_fd, gf / t_fd * 1e3, t_fw, gf / t_fw * 1e3, t_dd, gf / t_dd * 1e3, t_dw, gf / t_dw * 1e3, t_wg, gf / t_wg * 1e3), flush=True)

@@ -33,6 +33,8 @@ PROTOTYPES = {
     "ugn_wino_pack_multi": (_i, [C.POINTER(_p), C.POINTER(_p), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), _i, _p]),
     "ugn_conv3x3_fwd_wino": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "ugn_conv3x3_dgrad_wino": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
+    "ugn_conv3x3_wgrad_wino_ws": (_sz, [_i, _i, _i, _i]),
+    "ugn_conv3x3_wgrad_wino": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p, _sz, _p]),
     "ugn_setmax_fwd": (_i, [_p, _p, _p, _p, _i, _i, _sz, _p]),
     "ugn_setmax_bwd": (_i, [_p, _p, _p, _i, _i, _sz, _i, _p]),
     "ugn_hpp_fwd": (_i, [_p, _p, _p, _i, _p]),

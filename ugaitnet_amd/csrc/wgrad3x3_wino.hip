@@ -1,0 +1,375 @@
+// Winograd F(2x2,3x3) weight gradient of the 3x3 convolutions on v_mfma_f32_16x16x4_f32 (exact fp32, 16/36 of the direct
+// kernel's matrix FLOPs).  Replaces TF's Conv2DBackpropFilter behind reference nets/mj_uwyhNets_ba.py:431-462.
+//
+//   dW = G^T [ sum over tiles  (B^T d B) .* (A dY A^T) ] G        d: 4x4 input patch, dY: 2x2 output-gradient tile
+//
+// GEMM view per Winograd point: Z[pt][ci][co] += V[pt][tile][ci] * Q[pt][tile][co], K = tiles (4 per MFMA).
+// A 512-thread workgroup (8 waves, 2 per SIMD; persistent) owns a (32 input channel) x (32|64 output channel) block of
+// every point and walks 8x16-pixel regions (32 tiles).  A wave owns 16 ci x 32 co (16 points x 2 channel blocks = 128
+// accumulator registers) and a 1/KSPLIT share of each region's tiles.  Both operands are transformed IN REGISTERS by the
+// lane that feeds them to the MFMA: lane (ci, tile) reads its 4x4 patch from the fp32 halo tile and applies B^T.B;
+// lane (tile, co) reads its 2x2 gradient tile and applies A.A^T -- for a pooled layer the tile is ONE pooled pixel plus its
+// argmax, so Q is that value times a sign pattern.  Halo and gradient tiles of the next region stream in by LDS-DMA while
+// the current one computes: one barrier per region.  Partial sums leave as slabs [group][pt][32][co]; `wino_wgrad_finish`
+// sums the slabs in a fixed order and applies G^T . G (bitwise reproducible, no atomics).
+#include <stdlib.h>
+#include "common.h"
+
+namespace {
+
+constexpr int RH = 8, RW = 16;                      // region: 8 x 16 output pixels = 4 x 8 tiles
+constexpr int PW = RW + 2, PHH = RH + 2, NPIX = PHH * PW;   // 10 x 18 halo
+constexpr int CS = 36;                               // halo pixel stride (floats), 32 channels + pad
+constexpr int HSLOTS = NPIX * 9, HPIECES = (HSLOTS + 63) / 64;     // 1620 slots -> 26 pieces of 1 KB
+constexpr int SIN = HPIECES * 256;                   // floats per halo buffer
+
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ void dma16(const void* gsrc, unsigned lds_dst_uniform) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(gsrc), "s"(lds_dst_uniform)
+               : "memory");
+}
+
+template <int COC, int DZ_UNPOOL>
+struct DzCfg {
+  // plain : [128 px][COC + 4] floats                       -> (COC/4 + 1) 16-byte slots per pixel
+  // pooled: [32 pooled px][COC values + COC argmax bytes]  -> (COC/4 + COC/16) slots per pooled pixel
+  static constexpr int PX = DZ_UNPOOL ? 32 : 128;
+  static constexpr int SPP = DZ_UNPOOL ? (COC / 4 + COC / 16) : (COC / 4 + 1);
+  static constexpr int STRIDE = SPP * 4;              // floats per (pooled) pixel
+  static constexpr int SLOTS = PX * SPP, PIECES = (SLOTS + 63) / 64;
+  static constexpr int SDZ = PIECES * 256;            // floats per buffer
+};
+
+template <int CI, int CO, int HW, int COC, int DZ_UNPOOL>
+__global__ __launch_bounds__(512, 2) void wgrad_wino_kernel(const float* __restrict__ in, const float* __restrict__ dz,
+                                                            const uint8_t* __restrict__ dz_idx, float* __restrict__ slab,
+                                                            const float* __restrict__ zeros, int nregions, int groups) {
+  using D = DzCfg<COC, DZ_UNPOOL>;
+  constexpr int COP = COC / 32;                       // 32-channel output pairs per workgroup (1 or 2)
+  constexpr int KSPLIT = 8 / (2 * COP);               // waves sharing one output block (4 or 2)
+  constexpr int TPW = 32 / KSPLIT, STEPS = TPW / 4;   // tiles per wave per region, MFMA k-steps
+  constexpr int RPX = HW / RW, RPY = HW / RH, RPI = RPX * RPY;
+  constexpr int NCO = CO / COC;
+  constexpr int HPW = (HPIECES + 7) / 8, DPW = (D::PIECES + 7) / 8;   // DMA pieces per wave
+
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* sIn0 = smem;
+  float* sDz0 = smem + 2 * SIN;
+  const unsigned sin_bytes = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)smem);
+  const unsigned sdz_bytes = sin_bytes + 2u * SIN * 4u;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lj = lane & 15, kq = lane >> 4;
+  const int cop = wave % COP, cib = (wave / COP) & 1, ks = wave / (2 * COP);
+  const int combo = blockIdx.x / groups, grp = blockIdx.x % groups;
+  const int cic = combo / NCO, coc = combo % NCO;
+
+  // per-lane geometry of this wave's DMA pieces (region independent)
+  int hgeo[HPW], dgeo[DPW];
+#pragma unroll
+  for (int j = 0; j < HPW; ++j) {
+    int inst = wave * HPW + j;
+    inst = inst < HPIECES ? inst : HPIECES - 1;
+    int slot = inst * 64 + lane;
+    slot = slot < HSLOTS ? slot : HSLOTS - 1;
+    const int p = slot / 9, c4 = slot - p * 9;
+    hgeo[j] = ((p / PW) << 16) | ((p % PW) << 8) | c4;
+  }
+#pragma unroll
+  for (int j = 0; j < DPW; ++j) {
+    int inst = wave * DPW + j;
+    inst = inst < D::PIECES ? inst : D::PIECES - 1;
+    int slot = inst * 64 + lane;
+    slot = slot < D::SLOTS ? slot : D::SLOTS - 1;
+    dgeo[j] = ((slot / D::SPP) << 8) | (slot % D::SPP);
+  }
+  auto issue_dma = [&](int region, int buf) {
+    const int img = region / RPI, rrem = region % RPI;
+    const int ry0 = (rrem / RPX) * RH, rx0 = (rrem % RPX) * RW;
+#pragma unroll
+    for (int j = 0; j < HPW; ++j) {
+      int inst = wave * HPW + j;
+      inst = inst < HPIECES ? inst : HPIECES - 1;
+      const int yy = hgeo[j] >> 16, xx = (hgeo[j] >> 8) & 0xff, c4 = hgeo[j] & 0xff;
+      const int gy = ry0 - 1 + yy, gx = rx0 - 1 + xx;
+      const bool ok = c4 < 8 && (unsigned)gy < (unsigned)HW && (unsigned)gx < (unsigned)HW;
+      const float* src = ok ? in + (((size_t)img * HW + gy) * HW + gx) * CI + cic * 32 + c4 * 4 : zeros;
+      dma16(src, sin_bytes + (unsigned)buf * SIN * 4u + (unsigned)inst * 1024u);
+    }
+#pragma unroll
+    for (int j = 0; j < DPW; ++j) {
+      int inst = wave * DPW + j;
+      inst = inst < D::PIECES ? inst : D::PIECES - 1;
+      const int p = dgeo[j] >> 8, q = dgeo[j] & 0xff;
+      const void* src;
+      if constexpr (DZ_UNPOOL) {
+        constexpr int HP = HW / 2;
+        const size_t o = (((size_t)img * HP + ry0 / 2 + (p >> 3)) * HP + rx0 / 2 + (p & 7)) * CO + coc * COC;
+        src = q < COC / 4 ? (const void*)(dz + o + q * 4) : (const void*)(dz_idx + o + (q - COC / 4) * 16);
+      } else {
+        const size_t o = (((size_t)img * HW + ry0 + (p >> 4)) * HW + rx0 + (p & 15)) * CO + coc * COC;
+        src = q < COC / 4 ? (const void*)(dz + o + q * 4) : (const void*)zeros;
+      }
+      dma16(src, sdz_bytes + (unsigned)buf * D::SDZ * 4u + (unsigned)inst * 1024u);
+    }
+  };
+
+  f32x4 acc[16][2];
+#pragma unroll
+  for (int pt = 0; pt < 16; ++pt)
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[pt][cb][r] = 0.f;
+
+  int region = grp;
+  if (region < nregions) issue_dma(region, 0);
+  int buf = 0;
+  for (; region < nregions; region += groups, buf ^= 1) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of the current buffers have landed
+    __syncthreads();                                    // everyone's have; the other buffers have no readers left
+    const int next = region + groups;
+    issue_dma(next < nregions ? next : region, buf ^ 1);   // branch-free: at the end re-fetch the current region
+    const float* sIn = sIn0 + buf * SIN;
+    const float* sDz = sDz0 + buf * D::SDZ;
+#pragma unroll
+    for (int st = 0; st < STEPS; ++st) {
+      const int t = ks * TPW + st * 4 + kq;             // this lane's tile of the step: row t>>3 (0..3), col t&7
+      const int tr = t >> 3, tc = t & 7;
+      // ---- A operand: V = B^T d B of (tile, input channel cib*16 + lj)
+      float V[16];
+      {
+        const float* pb = sIn + ((2 * tr) * PW + 2 * tc) * CS + cib * 16 + lj;
+        float d[16], tt[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) d[e] = pb[((e >> 2) * PW + (e & 3)) * CS];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          tt[0 + c] = d[0 + c] - d[8 + c];
+          tt[4 + c] = d[4 + c] + d[8 + c];
+          tt[8 + c] = d[8 + c] - d[4 + c];
+          tt[12 + c] = d[4 + c] - d[12 + c];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          V[r * 4 + 0] = tt[r * 4 + 0] - tt[r * 4 + 2];
+          V[r * 4 + 1] = tt[r * 4 + 1] + tt[r * 4 + 2];
+          V[r * 4 + 2] = tt[r * 4 + 2] - tt[r * 4 + 1];
+          V[r * 4 + 3] = tt[r * 4 + 1] - tt[r * 4 + 3];
+        }
+      }
+      // ---- B operand: Q = A dY A^T of (tile, output channel cop*32 + cb*16 + lj)
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb) {
+        const int co = cop * 32 + cb * 16 + lj;
+        float Q[16];
+        if constexpr (DZ_UNPOOL) {
+          const float* pp = sDz + (tr * 8 + tc) * D::STRIDE;
+          const float v = pp[co];
+          const unsigned pos = reinterpret_cast<const uint8_t*>(pp + COC)[co];
+          // dY has one non-zero, v at (pos>>1, pos&1): Q = v * a_y (x) a_x with a_0 = (1,1,1,0), a_1 = (0,1,-1,-1)
+          const bool ay = pos >> 1, ax = pos & 1;
+          float ty[4], sx[4];
+          ty[0] = ay ? 0.f : v; ty[1] = v; ty[2] = ay ? -v : v; ty[3] = ay ? -v : 0.f;
+          sx[0] = ax ? 0.f : 1.f; sx[1] = 1.f; sx[2] = ax ? -1.f : 1.f; sx[3] = ax ? -1.f : 0.f;
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) Q[r * 4 + c] = ty[r] * sx[c];
+        } else {
+          const float* pp = sDz + ((2 * tr) * RW + 2 * tc) * D::STRIDE + co;
+          const float y00 = pp[0], y01 = pp[D::STRIDE], y10 = pp[RW * D::STRIDE], y11 = pp[(RW + 1) * D::STRIDE];
+          float q[4][2];   // A dY : rows (y0, y0+y1, y0-y1, -y1)
+          q[0][0] = y00; q[0][1] = y01;
+          q[1][0] = y00 + y10; q[1][1] = y01 + y11;
+          q[2][0] = y00 - y10; q[2][1] = y01 - y11;
+          q[3][0] = -y10; q[3][1] = -y11;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            Q[r * 4 + 0] = q[r][0];
+            Q[r * 4 + 1] = q[r][0] + q[r][1];
+            Q[r * 4 + 2] = q[r][0] - q[r][1];
+            Q[r * 4 + 3] = -q[r][1];
+          }
+        }
+#pragma unroll
+        for (int pt = 0; pt < 16; ++pt) acc[pt][cb] = mfma16(V[pt], Q[pt], acc[pt][cb]);
+      }
+    }
+  }
+
+  // ---- combine the KSPLIT waves that share an output block (through LDS, fixed order), then write the slab
+  __syncthreads();
+  float* sRed = smem;   // 16 points x 4 registers x 64 lanes = 16 KB per (wave, channel block)
+#pragma unroll
+  for (int src = 1; src < KSPLIT; ++src) {
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+      __syncthreads();
+      if (ks == src) {
+        float* dst = sRed + (cib * COP + cop) * 4096;
+#pragma unroll
+        for (int pt = 0; pt < 16; ++pt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) dst[(pt * 4 + r) * 64 + lane] = acc[pt][cb][r];
+      }
+      __syncthreads();
+      if (ks == 0) {
+        const float* s2 = sRed + (cib * COP + cop) * 4096;
+#pragma unroll
+        for (int pt = 0; pt < 16; ++pt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[pt][cb][r] += s2[(pt * 4 + r) * 64 + lane];
+      }
+    }
+  }
+  if (ks == 0) {
+    float* dst = slab + ((size_t)combo * groups + grp) * 16 * 32 * COC;
+#pragma unroll
+    for (int pt = 0; pt < 16; ++pt)
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          dst[((size_t)pt * 32 + cib * 16 + 4 * kq + r) * COC + cop * 32 + cb * 16 + lj] = acc[pt][cb][r];
+  }
+}
+
+// dW[a][b][ci][co] = sum_g (G^T Z_g G)[a][b], G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]].
+// 256 threads = 16 (ci,co) elements x 16 slab lanes; lane gl sums groups gl, gl+16, ... then the lanes are added in order.
+template <int COC>
+__global__ __launch_bounds__(256) void wino_wgrad_finish(const float* __restrict__ slab, float* __restrict__ dw, int CI,
+                                                         int CO, int groups) {
+  __shared__ float s1[16][16][17];
+  __shared__ float s2[16][17];
+  const int tid = threadIdx.x, el = tid & 15, gl = tid >> 4;
+  const int combo = blockIdx.y, e = blockIdx.x * 16 + el;
+  const int ci = e / COC, co = e % COC;
+  const int nco = CO / COC, cic = combo / nco, coc = combo % nco;
+  float z[16];
+#pragma unroll
+  for (int pt = 0; pt < 16; ++pt) z[pt] = 0.f;
+  for (int g = gl; g < groups; g += 16) {
+    const float* s = slab + ((size_t)combo * groups + g) * 16 * 32 * COC + (size_t)ci * COC + co;
+#pragma unroll
+    for (int pt = 0; pt < 16; ++pt) z[pt] += s[(size_t)pt * 32 * COC];
+  }
+#pragma unroll
+  for (int pt = 0; pt < 16; ++pt) s1[pt][gl][el] = z[pt];
+  __syncthreads();
+  {
+    const int pt = tid >> 4;
+    float a = 0.f;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) a += s1[pt][g][el];
+    s2[pt][el] = a;
+  }
+  __syncthreads();
+  if (tid >= 16) return;
+#pragma unroll
+  for (int pt = 0; pt < 16; ++pt) z[pt] = s2[pt][el];
+  float t[3][4];   // G^T Z
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    t[0][c] = z[0 + c] + 0.5f * (z[4 + c] + z[8 + c]);
+    t[1][c] = 0.5f * (z[4 + c] - z[8 + c]);
+    t[2][c] = 0.5f * (z[4 + c] + z[8 + c]) + z[12 + c];
+  }
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const float w0 = t[a][0] + 0.5f * (t[a][1] + t[a][2]);
+    const float w1 = 0.5f * (t[a][1] - t[a][2]);
+    const float w2 = 0.5f * (t[a][1] + t[a][2]) + t[a][3];
+    const size_t o = ((size_t)(a * 3) * CI + cic * 32 + ci) * CO + coc * COC + co;
+    dw[o] = w0;
+    dw[o + (size_t)CI * CO] = w1;
+    dw[o + 2 * (size_t)CI * CO] = w2;
+  }
+}
+
+inline const float* zero_block_w() {
+  static float* z = nullptr;
+  if (!z) {
+    float* p = nullptr;
+    if (hipMalloc((void**)&p, 256) != hipSuccess || hipMemset(p, 0, 256) != hipSuccess) return nullptr;
+    z = p;
+  }
+  return z;
+}
+
+constexpr int kWgs = 256;
+
+template <int CI, int CO, int HW, int COC, int DZ_UNPOOL>
+int launch_wgrad_wino(const float* in, const float* dz, const uint8_t* dz_idx, float* dw, int n, float* ws, size_t ws_floats,
+                      hipStream_t st) {
+  using D = DzCfg<COC, DZ_UNPOOL>;
+  constexpr int LDS = (2 * SIN + 2 * D::SDZ) * 4 > 8 * 16384 ? (2 * SIN + 2 * D::SDZ) * 4 : 8 * 16384;
+  auto kern = wgrad_wino_kernel<CI, CO, HW, COC, DZ_UNPOOL>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    if (e != hipSuccess) { ugn_set_error("wgrad wino: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
+    attr_done = true;
+  }
+  const float* zeros = zero_block_w();
+  if (!zeros) { ugn_set_error("wgrad wino: cannot allocate the zero block"); return UGN_EINVAL; }
+  constexpr int NCOMBO = (CI / 32) * (CO / COC);
+  const int nregions = n * (HW / RH) * (HW / RW);
+  int groups = kWgs / NCOMBO;
+  if (groups > nregions) groups = nregions;
+  const size_t need = (size_t)NCOMBO * groups * 16 * 32 * COC;
+  if (ws_floats < need) {
+    ugn_set_error("wgrad wino: workspace too small (%zu < %zu floats)", ws_floats, need);
+    return UGN_EINVAL;
+  }
+  hipLaunchKernelGGL(kern, dim3(NCOMBO * groups), dim3(512), LDS, st, in, dz, dz_idx, ws, zeros, nregions, groups);
+  UGN_CHECK_LAUNCH("wgrad wino");
+  hipLaunchKernelGGL(wino_wgrad_finish<COC>, dim3(32 * COC / 16, NCOMBO), dim3(256), 0, st, (const float*)ws, dw, CI,
+                     CO, groups);
+  UGN_CHECK_LAUNCH("wgrad wino finish");
+  return 0;
+}
+
+bool wg_cfg(int hw, int cin, int cout, int* coc) {
+  if ((hw == 64 && cin == 32 && cout == 32) || (hw == 32 && cin == 32 && cout == 64) || (hw == 32 && cin == 64 && cout == 64) ||
+      (hw == 16 && cin == 64 && cout == 128) || (hw == 16 && cin == 128 && cout == 128)) {
+    *coc = cout >= 64 ? 64 : 32;
+    return true;
+  }
+  return false;
+}
+
+}  // namespace
+
+extern "C" size_t ugn_conv3x3_wgrad_wino_ws(int n, int hw, int cin, int cout) {
+  int coc;
+  if (!wg_cfg(hw, cin, cout, &coc) || n <= 0) return 0;
+  const int ncombo = (cin / 32) * (cout / coc);
+  const long nregions = (long)n * (hw / RH) * (hw / RW);
+  long groups = kWgs / ncombo;
+  if (groups > nregions) groups = nregions;
+  return (size_t)ncombo * groups * 16 * 32 * coc * sizeof(float);
+}
+
+extern "C" int ugn_conv3x3_wgrad_wino(const float* in, const float* dz, const uint8_t* dz_idx, float* dw, int n, int hw,
+                                      int cin, int cout, void* ws, size_t ws_bytes, void* stream) {
+  UGN_REQUIRE(in && dz && dw && ws && n > 0, "ugn_conv3x3_wgrad_wino: null pointer or n <= 0");
+  hipStream_t st = (hipStream_t)stream;
+  const int unpool = dz_idx != nullptr;
+#define WGW(CI_, CO_, HW_, COC_, U_)                          \
+  if (cin == CI_ && cout == CO_ && hw == HW_ && unpool == U_) \
+    return launch_wgrad_wino<CI_, CO_, HW_, COC_, U_>(in, dz, dz_idx, dw, n, (float*)ws, ws_bytes / sizeof(float), st);
+  WGW(32, 32, 64, 32, 1)    // a2
+  WGW(32, 64, 32, 64, 0)    // a3, b1
+  WGW(64, 64, 32, 64, 1)    // a4, b2
+  WGW(64, 128, 16, 64, 0)   // a5, b3
+  WGW(128, 128, 16, 64, 0)  // a6, b4
+#undef WGW
+  UGN_REQUIRE(false, "ugn_conv3x3_wgrad_wino: unsupported shape cin=%d cout=%d hw=%d unpool=%d", cin, cout, hw, unpool);
+}

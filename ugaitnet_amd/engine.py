@@ -36,6 +36,7 @@ NBINS, FEAT, HIDDEN = 62, 128, 256
 # implicit-GEMM kernels, whose MaxPool tie-breaking on exactly equal activations follows the reference's first-max rule).
 USE_WINOGRAD = os.environ.get("UGN_WINO", "1") != "0"
 WINO_DGRAD = ("a2", "a3", "a4", "a5", "a6", "b1", "b2", "b3", "b4")
+_wgrad3x3 = ops.conv3x3_wgrad_wino if USE_WINOGRAD else ops.conv3x3_wgrad
 
 
 def glorot_uniform(gen, shape):
@@ -184,31 +185,31 @@ class Encoder:
         dm3, dzb4 = ops.hpp_bwd(A["m3"], A["s3"], A["b4"], S["dfeat"], buf("dm3", (b, 16, 16, 128)),
                                 buf("dzb4", (b, 16, 16, 128)))
         # global branch, block 2 (b3, b4)
-        ops.conv3x3_wgrad(A["b3"], dzb4, 128, dw=self.G("b4"))
+        _wgrad3x3(A["b3"], dzb4, 128, dw=self.G("b4"))
         dzb3 = self.dgrad("b4", dzb4, 16, act=A["b3"], out=buf("dzb3", (b, 16, 16, 128)))
-        ops.conv3x3_wgrad(A["s2"], dzb3, 128, dw=self.G("b3"))
+        _wgrad3x3(A["s2"], dzb3, 128, dw=self.G("b3"))
         ds2 = buf("ds2", (b, 16, 16, 64))
         dq2 = self.dgrad("b3", dzb3, 16, act=A["q2"], out=buf("dq2", (b, 16, 16, 64)), raw_out=ds2)
         # global branch, block 1 (b1, b2); b2 is pooled: dq2 is its gradient at pooled resolution, routed through j2
-        ops.conv3x3_wgrad(A["b1"], dq2, 64, dz_idx=A["j2"], dw=self.G("b2"))
+        _wgrad3x3(A["b1"], dq2, 64, dz_idx=A["j2"], dw=self.G("b2"))
         dzb1 = self.dgrad("b2", dq2, 32, dz_idx=A["j2"], act=A["b1"], out=buf("dzb1", (b, 32, 32, 64)))
-        ops.conv3x3_wgrad(A["m1"], dzb1, 64, dw=self.G("b1"))
+        _wgrad3x3(A["m1"], dzb1, 64, dw=self.G("b1"))
         dm1 = self.dgrad("b1", dzb1, 32, out=buf("dm1", (b, 32, 32, 32)))
         # frame stack, block 3 (a5, a6)
         dz6 = ops.setmax_bwd(A["a6"], dm3, b, l, True, buf("dz6", (n, 16, 16, 128)))
-        ops.conv3x3_wgrad(A["a5"], dz6, 128, dw=self.G("a6"))
+        _wgrad3x3(A["a5"], dz6, 128, dw=self.G("a6"))
         dz5 = self.dgrad("a6", dz6, 16, act=A["a5"], out=buf("dz5", (n, 16, 16, 128)))
-        ops.conv3x3_wgrad(A["p4"], dz5, 128, dw=self.G("a5"))
+        _wgrad3x3(A["p4"], dz5, 128, dw=self.G("a5"))
         g4 = ops.setmax_bwd(A["p4"], ds2, b, l, False, buf("g4", (n, 16, 16, 64)))
         dp4 = self.dgrad("a5", dz5, 16, act=A["p4"], addend=g4, out=g4)  # in place over the addend
         # block 2 (a3, a4)
-        ops.conv3x3_wgrad(A["a3"], dp4, 64, dz_idx=A["i4"], dw=self.G("a4"))
+        _wgrad3x3(A["a3"], dp4, 64, dz_idx=A["i4"], dw=self.G("a4"))
         dz3 = self.dgrad("a4", dp4, 32, dz_idx=A["i4"], act=A["a3"], out=buf("dz3", (n, 32, 32, 64)))
-        ops.conv3x3_wgrad(A["p2"], dz3, 64, dw=self.G("a3"))
+        _wgrad3x3(A["p2"], dz3, 64, dw=self.G("a3"))
         g2 = ops.setmax_bwd(A["p2"], dm1, b, l, False, buf("g2", (n, 32, 32, 32)))
         dp2 = self.dgrad("a3", dz3, 32, act=A["p2"], addend=g2, out=g2)
         # block 1 (a1, a2)
-        ops.conv3x3_wgrad(A["a1"], dp2, 32, dz_idx=A["i2"], dw=self.G("a2"))
+        _wgrad3x3(A["a1"], dp2, 32, dz_idx=A["i2"], dw=self.G("a2"))
         dz1 = self.dgrad("a2", dp2, 64, dz_idx=A["i2"], act=A["a1"], out=buf("dz1", (n, 64, 64, 32)))
         ops.conv5x5_in_wgrad(A["x"], dz1, self.G("a1"))
 

@@ -178,6 +178,21 @@ def conv3x3_wgrad(x, dz, cout, dz_idx=None, dw=None):
     return dw
 
 
+def conv3x3_wgrad_wino(x, dz, cout, dz_idx=None, dw=None):
+    """Winograd F(2x2,3x3) weight gradient; same contract as conv3x3_wgrad."""
+    _chk(x), _chk(dz)
+    n, hw, cin = x.shape[0], x.shape[1], x.shape[3]
+    dw = torch.empty((3, 3, cin, cout), dtype=F32, device=x.device) if dw is None else dw
+    nbytes = _lib.load().ugn_conv3x3_wgrad_wino_ws(n, hw, cin, cout)
+    if nbytes == 0:
+        raise ValueError("conv3x3_wgrad_wino: unsupported shape hw=%d cin=%d cout=%d" % (hw, cin, cout))
+    ws = _WS.get(nbytes, x.device)
+    with _Timed("conv3x3_wgrad[a4: 64->64 @32x32, pooled dz]", hw == 32 and cin == 64 and cout == 64 and n >= 100):
+        call("ugn_conv3x3_wgrad_wino", ptr(x), ptr(dz), ptr(dz_idx), ptr(dw), n, hw, cin, cout, ptr(ws), ws.numel(),
+             _stream())
+    return dw
+
+
 def setmax_fwd(p, b, l, addend=None, m=None, sum_out=None):
     _chk(p)
     s = p.numel() // (b * l)
