@@ -10,8 +10,8 @@
 // lane that feeds them to the MFMA: lane (ci, tile) reads its 4x4 patch from the fp32 halo tile and applies B^T.B;
 // lane (tile, co) reads its 2x2 gradient tile and applies A.A^T -- for a pooled layer the tile is ONE pooled pixel plus its
 // argmax, so Q is that value times a sign pattern.  Halo and gradient tiles of the next region stream in by LDS-DMA while
-// the current one computes: one barrier per region.  Partial sums leave as slabs [group][pt][32][co]; `wino_wgrad_finish`
-// sums the slabs in a fixed order and applies G^T . G (bitwise reproducible, no atomics).
+// the current one computes: one barrier per region.  G^T . G is applied lane-locally at the end and the partial sums leave
+// as slabs [group][tap][32][co]; `wino_wgrad_finish` sums the slabs in a fixed order (bitwise reproducible, no atomics).
 #include <stdlib.h>
 #include "common.h"
 
@@ -19,8 +19,10 @@ namespace {
 
 constexpr int RH = 8, RW = 16;                      // region: 8 x 16 output pixels = 4 x 8 tiles
 constexpr int PW = RW + 2, PHH = RH + 2, NPIX = PHH * PW;   // 10 x 18 halo
-constexpr int CS = 36;                               // halo pixel stride (floats), 32 channels + pad
-constexpr int HSLOTS = NPIX * 9, HPIECES = (HSLOTS + 63) / 64;     // 1620 slots -> 26 pieces of 1 KB
+constexpr int CS = 40;                               // halo pixel stride (floats), 32 channels + 8 pad: the 4 tiles of an
+                                                     // MFMA step sit 2 pixels = 80 floats apart -> banks 0/16, conflict-free
+constexpr int SPX = CS / 4;                          // 16-byte slots per halo pixel
+constexpr int HSLOTS = NPIX * SPX, HPIECES = (HSLOTS + 63) / 64;   // 1800 slots -> 29 pieces of 1 KB
 constexpr int SIN = HPIECES * 256;                   // floats per halo buffer
 
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
@@ -37,10 +39,11 @@ __device__ __forceinline__ void dma16(const void* gsrc, unsigned lds_dst_uniform
 
 template <int COC, int DZ_UNPOOL>
 struct DzCfg {
-  // plain : [128 px][COC + 4] floats                       -> (COC/4 + 1) 16-byte slots per pixel
-  // pooled: [32 pooled px][COC values + COC argmax bytes]  -> (COC/4 + COC/16) slots per pooled pixel
+  // plain : [128 px][COC + 8] floats                              -> (COC/4 + 2) 16-byte slots per pixel
+  // pooled: [32 pooled px][COC values + COC argmax bytes (+ pad)]  -> 20 (COC = 64) / 12 (COC = 32) slots per pooled pixel
+  // (strides chosen so that the 4 tiles of an MFMA step fall into different bank halves)
   static constexpr int PX = DZ_UNPOOL ? 32 : 128;
-  static constexpr int SPP = DZ_UNPOOL ? (COC / 4 + COC / 16) : (COC / 4 + 1);
+  static constexpr int SPP = DZ_UNPOOL ? (COC == 64 ? 20 : 12) : (COC / 4 + 2);
   static constexpr int STRIDE = SPP * 4;              // floats per (pooled) pixel
   static constexpr int SLOTS = PX * SPP, PIECES = (SLOTS + 63) / 64;
   static constexpr int SDZ = PIECES * 256;            // floats per buffer
@@ -78,7 +81,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_wino_kernel(const float* __restr
     inst = inst < HPIECES ? inst : HPIECES - 1;
     int slot = inst * 64 + lane;
     slot = slot < HSLOTS ? slot : HSLOTS - 1;
-    const int p = slot / 9, c4 = slot - p * 9;
+    const int p = slot / SPX, c4 = slot - p * SPX;
     hgeo[j] = ((p / PW) << 16) | ((p % PW) << 8) | c4;
   }
 #pragma unroll
@@ -111,7 +114,8 @@ __global__ __launch_bounds__(512, 2) void wgrad_wino_kernel(const float* __restr
       if constexpr (DZ_UNPOOL) {
         constexpr int HP = HW / 2;
         const size_t o = (((size_t)img * HP + ry0 / 2 + (p >> 3)) * HP + rx0 / 2 + (p & 7)) * CO + coc * COC;
-        src = q < COC / 4 ? (const void*)(dz + o + q * 4) : (const void*)(dz_idx + o + (q - COC / 4) * 16);
+        src = q < COC / 4 ? (const void*)(dz + o + q * 4)
+                          : (q < COC / 4 + COC / 16 ? (const void*)(dz_idx + o + (q - COC / 4) * 16) : (const void*)zeros);
       } else {
         const size_t o = (((size_t)img * HW + ry0 + (p >> 4)) * HW + rx0 + (p & 15)) * CO + coc * COC;
         src = q < COC / 4 ? (const void*)(dz + o + q * 4) : (const void*)zeros;
@@ -138,17 +142,36 @@ __global__ __launch_bounds__(512, 2) void wgrad_wino_kernel(const float* __restr
     issue_dma(next < nregions ? next : region, buf ^ 1);   // branch-free: at the end re-fetch the current region
     const float* sIn = sIn0 + buf * SIN;
     const float* sDz = sDz0 + buf * D::SDZ;
-#pragma unroll
-    for (int st = 0; st < STEPS; ++st) {
+    // raw operands of one MFMA step: the lane's 4x4 input patch and its two 2x2 gradient tiles (or pooled pixel + argmax);
+    // the reads of step st+1 are issued before the MFMAs of step st, so their latency hides behind the matrix pipe
+    float d[16], yv[2][4];
+    unsigned ypos[2];
+    auto load_raw = [&](int st) {
       const int t = ks * TPW + st * 4 + kq;             // this lane's tile of the step: row t>>3 (0..3), col t&7
       const int tr = t >> 3, tc = t & 7;
-      // ---- A operand: V = B^T d B of (tile, input channel cib*16 + lj)
-      float V[16];
-      {
-        const float* pb = sIn + ((2 * tr) * PW + 2 * tc) * CS + cib * 16 + lj;
-        float d[16], tt[16];
+      const float* pb = sIn + ((2 * tr) * PW + 2 * tc) * CS + cib * 16 + lj;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) d[e] = pb[((e >> 2) * PW + (e & 3)) * CS];
+      for (int e = 0; e < 16; ++e) d[e] = pb[((e >> 2) * PW + (e & 3)) * CS];
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb) {
+        const int co = cop * 32 + cb * 16 + lj;
+        if constexpr (DZ_UNPOOL) {
+          const float* pp = sDz + (tr * 8 + tc) * D::STRIDE;
+          yv[cb][0] = pp[co];
+          ypos[cb] = reinterpret_cast<const uint8_t*>(pp + COC)[co];
+        } else {
+          const float* pp = sDz + ((2 * tr) * RW + 2 * tc) * D::STRIDE + co;
+          yv[cb][0] = pp[0]; yv[cb][1] = pp[D::STRIDE]; yv[cb][2] = pp[RW * D::STRIDE]; yv[cb][3] = pp[(RW + 1) * D::STRIDE];
+        }
+      }
+    };
+    load_raw(0);
+#pragma unroll
+    for (int st = 0; st < STEPS; ++st) {
+      // ---- A operand: V = B^T d B of (tile, input channel cib*16 + lj)
+      float V[16], Q[2][16];
+      {
+        float tt[16];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
           tt[0 + c] = d[0 + c] - d[8 + c];
@@ -167,24 +190,21 @@ __global__ __launch_bounds__(512, 2) void wgrad_wino_kernel(const float* __restr
       // ---- B operand: Q = A dY A^T of (tile, output channel cop*32 + cb*16 + lj)
 #pragma unroll
       for (int cb = 0; cb < 2; ++cb) {
-        const int co = cop * 32 + cb * 16 + lj;
-        float Q[16];
         if constexpr (DZ_UNPOOL) {
-          const float* pp = sDz + (tr * 8 + tc) * D::STRIDE;
-          const float v = pp[co];
-          const unsigned pos = reinterpret_cast<const uint8_t*>(pp + COC)[co];
           // dY has one non-zero, v at (pos>>1, pos&1): Q = v * a_y (x) a_x with a_0 = (1,1,1,0), a_1 = (0,1,-1,-1)
-          const bool ay = pos >> 1, ax = pos & 1;
-          float ty[4], sx[4];
+          const float v = yv[cb][0];
+          const bool ay = (ypos[cb] >> 1) != 0, ax = (ypos[cb] & 1) != 0;
+          float ty[4];
           ty[0] = ay ? 0.f : v; ty[1] = v; ty[2] = ay ? -v : v; ty[3] = ay ? -v : 0.f;
-          sx[0] = ax ? 0.f : 1.f; sx[1] = 1.f; sx[2] = ax ? -1.f : 1.f; sx[3] = ax ? -1.f : 0.f;
 #pragma unroll
-          for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int c = 0; c < 4; ++c) Q[r * 4 + c] = ty[r] * sx[c];
+          for (int r = 0; r < 4; ++r) {
+            Q[cb][r * 4 + 0] = ax ? 0.f : ty[r];
+            Q[cb][r * 4 + 1] = ty[r];
+            Q[cb][r * 4 + 2] = ax ? -ty[r] : ty[r];
+            Q[cb][r * 4 + 3] = ax ? -ty[r] : 0.f;
+          }
         } else {
-          const float* pp = sDz + ((2 * tr) * RW + 2 * tc) * D::STRIDE + co;
-          const float y00 = pp[0], y01 = pp[D::STRIDE], y10 = pp[RW * D::STRIDE], y11 = pp[(RW + 1) * D::STRIDE];
+          const float y00 = yv[cb][0], y01 = yv[cb][1], y10 = yv[cb][2], y11 = yv[cb][3];
           float q[4][2];   // A dY : rows (y0, y0+y1, y0-y1, -y1)
           q[0][0] = y00; q[0][1] = y01;
           q[1][0] = y00 + y10; q[1][1] = y01 + y11;
@@ -192,15 +212,21 @@ __global__ __launch_bounds__(512, 2) void wgrad_wino_kernel(const float* __restr
           q[3][0] = -y10; q[3][1] = -y11;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            Q[r * 4 + 0] = q[r][0];
-            Q[r * 4 + 1] = q[r][0] + q[r][1];
-            Q[r * 4 + 2] = q[r][0] - q[r][1];
-            Q[r * 4 + 3] = -q[r][1];
+            Q[cb][r * 4 + 0] = q[r][0];
+            Q[cb][r * 4 + 1] = q[r][0] + q[r][1];
+            Q[cb][r * 4 + 2] = q[r][0] - q[r][1];
+            Q[cb][r * 4 + 3] = -q[r][1];
           }
         }
-#pragma unroll
-        for (int pt = 0; pt < 16; ++pt) acc[pt][cb] = mfma16(V[pt], Q[pt], acc[pt][cb]);
       }
+      if (st + 1 < STEPS) load_raw(st + 1);
+      __builtin_amdgcn_s_setprio(1);   // keep the matrix pipe while the SIMD's other wave transforms its operands
+#pragma unroll
+      for (int pt = 0; pt < 16; ++pt) {
+        acc[pt][0] = mfma16(V[pt], Q[0][pt], acc[pt][0]);
+        acc[pt][1] = mfma16(V[pt], Q[1][pt], acc[pt][1]);
+      }
+      __builtin_amdgcn_s_setprio(0);
     }
   }
 
@@ -230,67 +256,56 @@ __global__ __launch_bounds__(512, 2) void wgrad_wino_kernel(const float* __restr
     }
   }
   if (ks == 0) {
-    float* dst = slab + ((size_t)combo * groups + grp) * 16 * 32 * COC;
+    // G^T Z G is lane-local (a lane holds all 16 points of its (ci, co) elements): the slab carries the 9 taps
+    float* dst = slab + ((size_t)combo * groups + grp) * 9 * 32 * COC;
 #pragma unroll
-    for (int pt = 0; pt < 16; ++pt)
+    for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
-      for (int cb = 0; cb < 2; ++cb)
+      for (int r = 0; r < 4; ++r) {
+        float t[3][4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-          dst[((size_t)pt * 32 + cib * 16 + 4 * kq + r) * COC + cop * 32 + cb * 16 + lj] = acc[pt][cb][r];
+        for (int c = 0; c < 4; ++c) {
+          const float z0 = acc[0 + c][cb][r], z1 = acc[4 + c][cb][r], z2 = acc[8 + c][cb][r], z3 = acc[12 + c][cb][r];
+          t[0][c] = z0 + 0.5f * (z1 + z2);
+          t[1][c] = 0.5f * (z1 - z2);
+          t[2][c] = 0.5f * (z1 + z2) + z3;
+        }
+        float* o = dst + ((size_t)cib * 16 + 4 * kq + r) * COC + cop * 32 + cb * 16 + lj;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+          o[(size_t)(a * 3 + 0) * 32 * COC] = t[a][0] + 0.5f * (t[a][1] + t[a][2]);
+          o[(size_t)(a * 3 + 1) * 32 * COC] = 0.5f * (t[a][1] - t[a][2]);
+          o[(size_t)(a * 3 + 2) * 32 * COC] = 0.5f * (t[a][1] + t[a][2]) + t[a][3];
+        }
+      }
   }
 }
 
-// dW[a][b][ci][co] = sum_g (G^T Z_g G)[a][b], G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]].
-// 256 threads = 16 (ci,co) elements x 16 slab lanes; lane gl sums groups gl, gl+16, ... then the lanes are added in order.
+// dW[tap][cic*32 + ci][coc*COC + co] = sum_g slab[combo][g][tap][ci][co], in float4 units over co.
+// 256 threads = 16 elements x 16 slab lanes; lane gl sums groups gl, gl+16, ..., then the 16 lanes are added in order.
 template <int COC>
-__global__ __launch_bounds__(256) void wino_wgrad_finish(const float* __restrict__ slab, float* __restrict__ dw, int CI,
+__global__ __launch_bounds__(256) void wino_wgrad_finish(const float4* __restrict__ slab, float* __restrict__ dw, int CI,
                                                          int CO, int groups) {
-  __shared__ float s1[16][16][17];
-  __shared__ float s2[16][17];
-  const int tid = threadIdx.x, el = tid & 15, gl = tid >> 4;
-  const int combo = blockIdx.y, e = blockIdx.x * 16 + el;
-  const int ci = e / COC, co = e % COC;
+  __shared__ float4 sR[16][16];
+  constexpr int E4 = 9 * 32 * COC / 4;
+  const int le = threadIdx.x & 15, lg = threadIdx.x >> 4;
+  const int combo = blockIdx.y, e = blockIdx.x * 16 + le;   // E4 is a multiple of 16
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int g = lg; g < groups; g += 16) {
+    const float4 v = slab[((size_t)combo * groups + g) * E4 + e];
+    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  }
+  sR[lg][le] = s;
+  __syncthreads();
+  if (lg != 0) return;
+#pragma unroll
+  for (int k = 1; k < 16; ++k) {
+    const float4 v = sR[k][le];
+    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  }
   const int nco = CO / COC, cic = combo / nco, coc = combo % nco;
-  float z[16];
-#pragma unroll
-  for (int pt = 0; pt < 16; ++pt) z[pt] = 0.f;
-  for (int g = gl; g < groups; g += 16) {
-    const float* s = slab + ((size_t)combo * groups + g) * 16 * 32 * COC + (size_t)ci * COC + co;
-#pragma unroll
-    for (int pt = 0; pt < 16; ++pt) z[pt] += s[(size_t)pt * 32 * COC];
-  }
-#pragma unroll
-  for (int pt = 0; pt < 16; ++pt) s1[pt][gl][el] = z[pt];
-  __syncthreads();
-  {
-    const int pt = tid >> 4;
-    float a = 0.f;
-#pragma unroll
-    for (int g = 0; g < 16; ++g) a += s1[pt][g][el];
-    s2[pt][el] = a;
-  }
-  __syncthreads();
-  if (tid >= 16) return;
-#pragma unroll
-  for (int pt = 0; pt < 16; ++pt) z[pt] = s2[pt][el];
-  float t[3][4];   // G^T Z
-#pragma unroll
-  for (int c = 0; c < 4; ++c) {
-    t[0][c] = z[0 + c] + 0.5f * (z[4 + c] + z[8 + c]);
-    t[1][c] = 0.5f * (z[4 + c] - z[8 + c]);
-    t[2][c] = 0.5f * (z[4 + c] + z[8 + c]) + z[12 + c];
-  }
-#pragma unroll
-  for (int a = 0; a < 3; ++a) {
-    const float w0 = t[a][0] + 0.5f * (t[a][1] + t[a][2]);
-    const float w1 = 0.5f * (t[a][1] - t[a][2]);
-    const float w2 = 0.5f * (t[a][1] + t[a][2]) + t[a][3];
-    const size_t o = ((size_t)(a * 3) * CI + cic * 32 + ci) * CO + coc * COC + co;
-    dw[o] = w0;
-    dw[o + (size_t)CI * CO] = w1;
-    dw[o + 2 * (size_t)CI * CO] = w2;
-  }
+  const int co4 = e % (COC / 4), ci = (e / (COC / 4)) % 32, tap = e / (COC / 4 * 32);
+  *reinterpret_cast<float4*>(dw + ((size_t)tap * CI + cic * 32 + ci) * CO + coc * COC + co4 * 4) = s;
 }
 
 inline const float* zero_block_w() {
@@ -323,15 +338,15 @@ int launch_wgrad_wino(const float* in, const float* dz, const uint8_t* dz_idx, f
   const int nregions = n * (HW / RH) * (HW / RW);
   int groups = kWgs / NCOMBO;
   if (groups > nregions) groups = nregions;
-  const size_t need = (size_t)NCOMBO * groups * 16 * 32 * COC;
+  const size_t need = (size_t)NCOMBO * groups * 9 * 32 * COC;
   if (ws_floats < need) {
     ugn_set_error("wgrad wino: workspace too small (%zu < %zu floats)", ws_floats, need);
     return UGN_EINVAL;
   }
   hipLaunchKernelGGL(kern, dim3(NCOMBO * groups), dim3(512), LDS, st, in, dz, dz_idx, ws, zeros, nregions, groups);
   UGN_CHECK_LAUNCH("wgrad wino");
-  hipLaunchKernelGGL(wino_wgrad_finish<COC>, dim3(32 * COC / 16, NCOMBO), dim3(256), 0, st, (const float*)ws, dw, CI,
-                     CO, groups);
+  hipLaunchKernelGGL(wino_wgrad_finish<COC>, dim3(9 * 32 * COC / 4 / 16, NCOMBO), dim3(256), 0, st, (const float4*)ws, dw,
+                     CI, CO, groups);
   UGN_CHECK_LAUNCH("wgrad wino finish");
   return 0;
 }
@@ -354,7 +369,7 @@ extern "C" size_t ugn_conv3x3_wgrad_wino_ws(int n, int hw, int cin, int cout) {
   const long nregions = (long)n * (hw / RH) * (hw / RW);
   long groups = kWgs / ncombo;
   if (groups > nregions) groups = nregions;
-  return (size_t)ncombo * groups * 16 * 32 * coc * sizeof(float);
+  return (size_t)ncombo * groups * 9 * 32 * coc * sizeof(float);
 }
 
 extern "C" int ugn_conv3x3_wgrad_wino(const float* in, const float* dz, const uint8_t* dz_idx, float* dw, int n, int hw,
