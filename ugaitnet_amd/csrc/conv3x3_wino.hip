@@ -32,7 +32,14 @@ constexpr int LDS_BYTES = (2 * SIN + 2 * SU) * 4;               // 159,744 B (of
 // pooled-resolution input (data gradient of a MaxPool'ed layer): the LDS tile holds the 10x10 POOLED pixels under the halo,
 // 40 floats per pixel = 32 gradient values + 32 argmax bytes; the scatter through the argmax happens when a lane reads
 // its 4x4 patch (3x3 pooled pixels), so the 4x larger un-pooled gradient is never materialised anywhere.
-constexpr int UPW = 10, UCS = 40, UPIX = UPW * UPW, USLOTS = UPIX * 10, UPIECES = 16;
+constexpr int UPW = 12, UCS = 44, UPIX = 10 * UPW, USLOTS = UPIX * 11, UPIECES = 21;   // 10 rows x (10 + 2 pad) positions
+// LDS bank layout.  A lane of an MFMA is (tile lj, channel slot kq) and reads its patch with ds_read_b64; the hardware
+// serves 32 lanes per pass, i.e. all 16 tiles x 2 channel slots.  Two choices make every pass touch each bank exactly twice
+// (ds_read_b64: 64 banks, 32 lanes per pass) -- the b64 optimum: (1) the halo tile stores the EVEN columns of a row first,
+// then the odd ones, so the 8 tile columns fall into 8 different bank quads (pixel stride 36 floats; pooled tile: 44);
+// (2) a wave's two tile rows are chosen 32 banks apart (see trow0 in the kernel); (3) lane kq owns channels
+// {2kq, 2kq+1, 8+2kq, 9+2kq} of a 16-channel group, so the two slots of a pass are the two halves of one quad.
+__device__ __forceinline__ constexpr int colpos(int col) { return (col & 1) ? 9 + (col >> 1) : (col >> 1); }
 
 enum { EPI_LRELU = 0, EPI_LRELU_POOL = 1, EPI_DGRAD = 2 };
 
@@ -42,8 +49,8 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
 }
 
 // U[pt][n][k] = (G g G^T)[pt] for filter g(k -> n).  Layout [nsp][chunk][G][pt][kq][32 n][4 s] with k = 32*chunk + 16*G +
-// 4*kq + s: a 32 KB slice per 16-channel group, and the lane (n, kq) of an MFMA reads its 4 steps with one ds_read_b128
-// at consecutive 16-byte slots (conflict-free).
+// 8*(s>>1) + 2*kq + (s&1): a 32 KB slice per 16-channel group, and the lane (n, kq) of an MFMA reads its 4 steps with one
+// ds_read_b128 at consecutive 16-byte slots (conflict-free).
 // fwd : g[dy][dx] = w[dy][dx][k = cin][n = cout]            (kc = cin, nc = cout)
 // dgrad: g[dy][dx] = w[2-dy][2-dx][n = cin][k = cout]        (kc = cout, nc = cin)
 __device__ __forceinline__ void wino_pack_one(const float* __restrict__ w, float* __restrict__ u, int cin, int cout, int dgrad,
@@ -62,7 +69,7 @@ __device__ __forceinline__ void wino_pack_one(const float* __restrict__ w, float
     t[2][c] = 0.5f * (g[0][c] - g[1][c] + g[2][c]);
     t[3][c] = g[2][c];
   }
-  const int nsp = n >> 5, nl = n & 31, chunk = k >> 5, G = (k >> 4) & 1, kq = (k >> 2) & 3, st = k & 3;
+  const int nsp = n >> 5, nl = n & 31, chunk = k >> 5, G = (k >> 4) & 1, kq = (k >> 1) & 3, st = ((k >> 3) & 1) * 2 + (k & 1);
   const int nchunk = kc >> 5;
   float* dst = u + (((size_t)nsp * nchunk + chunk) * 2 + G) * SU + (kq * 32 + nl) * 4 + st;
   for (int r = 0; r < 4; ++r) {
@@ -102,7 +109,7 @@ __device__ __forceinline__ void dma16(const void* gsrc, unsigned lds_dst_uniform
 }
 
 // One 1 KB piece of the halo tile of (image, region origin, chunk): lane l fills 16-byte slot inst*64 + l; slot s =
-// pixel s/9, quarter-row s%9 (the 9th is the pad of the 36-float pixel stride and receives don't-care bytes).
+// pixel position s/9 (row-major, columns in colpos order), quarter-row s%9 (the 9th is the pad of the 36-float stride).
 // Geometry of halo slot (piece inst, lane): row, column and quarter-row, packed (yy << 16 | xx << 8 | c4).  It does not
 // depend on the item, so each lane computes its 6 values once per launch instead of dividing by 9 and 18 per piece.
 __device__ __forceinline__ int halo_slot_geometry(int inst, int lane) {
@@ -110,7 +117,8 @@ __device__ __forceinline__ int halo_slot_geometry(int inst, int lane) {
   int slot = inst * 64 + lane;
   slot = slot < HSLOTS ? slot : HSLOTS - 1;
   const int p = slot / 9, c4 = slot - p * 9;
-  const int yy = p / PW, xx = p - yy * PW;
+  const int yy = p / PW, xp = p - yy * PW;
+  const int xx = xp < 9 ? 2 * xp : 2 * (xp - 9) + 1;   // even columns first (see colpos)
   return (yy << 16) | (xx << 8) | c4;
 }
 
@@ -125,52 +133,51 @@ __device__ __forceinline__ void dma_halo_piece(const float* __restrict__ in, con
   dma16(src, lds_byte_base + (unsigned)inst * 1024u);   // all-scalar: base, inst are wave-uniform SGPR values
 }
 
-// One 1 KB piece of the POOLED input tile: slot s = pooled pixel s/10, part s%10 (0..7 values, 8..9 argmax bytes).
+// One 1 KB piece of the POOLED input tile: slot s = pooled pixel s/11, part s%11 (0..7 values, 8..9 argmax bytes, 10 pad).
 template <int KC, int HW>
 __device__ __forceinline__ void dma_pooled_piece(const float* __restrict__ dz, const uint8_t* __restrict__ idx,
                                                  const float* __restrict__ zeros, int img, int ry0, int rx0, int chunk,
                                                  int inst, int lane, unsigned lds_byte_base) {
   constexpr int HP = HW / 2;
+  inst = inst < UPIECES ? inst : UPIECES - 1;     // 8 waves x 3 pieces = 24 >= 18: the surplus repeats the last piece
   int slot = inst * 64 + lane;
   slot = slot < USLOTS ? slot : USLOTS - 1;
-  const int p = slot / 10, c = slot - p * 10;
+  const int p = slot / 11, c = slot - p * 11;
   const int pr = ry0 / 2 - 1 + p / UPW, pc = rx0 / 2 - 1 + p % UPW;
-  const bool ok = pr >= 0 && pr < HP && pc >= 0 && pc < HP;
+  const bool ok = pr >= 0 && pr < HP && pc >= 0 && pc < HP && p % UPW < 10;   // positions 10, 11 of a row are padding
   const size_t o = (((size_t)img * HP + pr) * HP + pc) * KC + chunk * 32;
-  const void* src = !ok ? (const void*)zeros
-                        : (c < 8 ? (const void*)(dz + o + c * 4) : (const void*)(idx + o + (c - 8) * 16));
+  const void* src = (!ok || c >= 10) ? (const void*)zeros
+                                     : (c < 8 ? (const void*)(dz + o + c * 4) : (const void*)(idx + o + (c - 8) * 16));
   dma16(src, lds_byte_base + (unsigned)inst * 1024u);
 }
 
-// The 4x4 patch of one channel pair.  Plain input: 16 ds_read_b64 from the halo tile.  Pooled input: the 3x3 pooled
-// pixels under the patch; patch element (r,c) is pooled pixel ((r+1)>>1, (c+1)>>1) if its argmax byte equals the
-// element's position ((r+1)&1)*2 + ((c+1)&1) inside the 2x2 window, else 0 (MaxPool backward).
+// The 4x4 patch of one channel pair (h = 0: channels 2kq, 2kq+1 of the group; h = 1: 8 + those).  Plain input: 16
+// ds_read_b64 from the halo tile.  Pooled input: the 3x3 pooled pixels under the patch and their argmax byte pairs; patch
+// element (r,c) is pooled pixel ((r+1)>>1, (c+1)>>1) if its argmax byte equals the element's position
+// ((r+1)&1)*2 + ((c+1)&1) inside the 2x2 window, else 0 (MaxPool backward).  `ibytes`: the lane's argmax pair for h = 0.
+// (hipcc fuses pairs of these reads into ds_read2_b64, which banks mod 32 and is 2-way conflicted on this layout; keeping
+// them apart costs address registers that the 256-register budget of the multi-chunk variants does not have.)
 template <int IN_UNPOOL>
-__device__ __forceinline__ void read_pair(float2 (&dn)[16], const unsigned (&iw)[9], const float* base, int h) {
+__device__ __forceinline__ void read_pair(float2 (&dn)[16], const float* base, const uint8_t* ibytes, int h) {
   if constexpr (!IN_UNPOOL) {
 #pragma unroll
-    for (int e = 0; e < 16; ++e) dn[e] = *reinterpret_cast<const float2*>(base + ((e >> 2) * PW + (e & 3)) * CS + 2 * h);
+    for (int e = 0; e < 16; ++e) dn[e] = *reinterpret_cast<const float2*>(base + ((e >> 2) * PW + colpos(e & 3)) * CS + 8 * h);
   } else {
     float2 pv[9];
+    unsigned iw[9];
 #pragma unroll
-    for (int q = 0; q < 9; ++q) pv[q] = *reinterpret_cast<const float2*>(base + ((q / 3) * UPW + (q % 3)) * UCS + 2 * h);
+    for (int q = 0; q < 9; ++q) {
+      pv[q] = *reinterpret_cast<const float2*>(base + ((q / 3) * UPW + (q % 3)) * UCS + 8 * h);
+      iw[q] = *reinterpret_cast<const uint16_t*>(ibytes + ((q / 3) * UPW + (q % 3)) * UCS * 4 + 8 * h);
+    }
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       const int r = e >> 2, c = e & 3;
       const int q = ((r + 1) >> 1) * 3 + ((c + 1) >> 1);
       const unsigned pos = (((r + 1) & 1) << 1) | ((c + 1) & 1);
-      const unsigned b0 = (iw[q] >> (16 * h)) & 0xffu, b1 = (iw[q] >> (16 * h + 8)) & 0xffu;
-      dn[e].x = b0 == pos ? pv[q].x : 0.f;
-      dn[e].y = b1 == pos ? pv[q].y : 0.f;
+      dn[e].x = (iw[q] & 0xffu) == pos ? pv[q].x : 0.f;
+      dn[e].y = (iw[q] >> 8) == pos ? pv[q].y : 0.f;
     }
-  }
-}
-
-template <int IN_UNPOOL>
-__device__ __forceinline__ void read_idx(unsigned (&iw)[9], const float* ibase) {
-  if constexpr (IN_UNPOOL) {
-#pragma unroll
-    for (int q = 0; q < 9; ++q) iw[q] = *reinterpret_cast<const unsigned*>(ibase + ((q / 3) * UPW + (q % 3)) * UCS);
   }
 }
 
@@ -191,7 +198,6 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const float* __restrict__ 
   constexpr int NCHUNK = KC / 32, NSPLIT = NCF / 32;
   constexpr int RPX = HW / 16, RPI = RPX * RPX;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* sIn0 = smem;
   float* sU0 = smem + 2 * SIN;
   const unsigned sin_bytes = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)smem);
   const unsigned su_bytes = sin_bytes + 2u * SIN * 4u;
@@ -202,8 +208,13 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const float* __restrict__ 
   // A-side role of the lane: tile (tr, tc) of the wave's 2 x 8 tiles; B-side: output channel lj (+16), both: channels 4*kq..
   const int a_tr = lj >> 3, a_tc = lj & 7;
   // patch origin in the halo tile (plain) / first of the 3x3 pooled pixels in the pooled tile
-  const int pbase = IN_UNPOOL ? ((2 * tg + a_tr) * UPW + a_tc) * UCS + 4 * kq : ((4 * tg + 2 * a_tr) * PW + 2 * a_tc) * CS + 4 * kq;
-  const int ibase = ((2 * tg + a_tr) * UPW + a_tc) * UCS + 32 + kq;          // argmax dword of channels 4kq..4kq+3 (pooled)
+  // The wave's two tile rows are 2 tile rows apart: that offsets their LDS images by 32 banks (of 64),
+  // so with the 8 tile columns the 16 tile origins cover all 16 bank quads and a ds_read_b64 pass is conflict-free.
+  const int trow0 = (tg & 1) + 4 * (tg >> 1);
+  constexpr int TRSTEP = 2;
+  const int a_trow = trow0 + TRSTEP * a_tr;                                    // tile row (0..7) of the lane's A-side tile
+  const int pbase = IN_UNPOOL ? (a_trow * UPW + a_tc) * UCS + 2 * kq : (2 * a_trow * PW + a_tc) * CS + 2 * kq;
+  const int ibase = ((a_trow * UPW + a_tc) * UCS + 32) * 4 + 2 * kq;           // BYTE offset of the argmax pair (pooled tile)
   const int ubase = (kq * 32 + ch * 16 + lj) * 4;
 
   int item = blockIdx.x;
@@ -219,8 +230,8 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const float* __restrict__ 
     const int region = item / NSPLIT, img = region / RPI, rrem = region % RPI;
     if constexpr (IN_UNPOOL) {
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
-        dma_pooled_piece<KC, HW>(in, in_idx, zeros, img, (rrem / RPX) * 16, (rrem % RPX) * 16, 0, wave * 2 + j, lane, sin_bytes);
+      for (int j = 0; j < 3; ++j)
+        dma_pooled_piece<KC, HW>(in, in_idx, zeros, img, (rrem / RPX) * 16, (rrem % RPX) * 16, 0, wave * 3 + j, lane, sin_bytes);
     } else {
 #pragma unroll
       for (int j = 0; j < 6; ++j)
@@ -232,6 +243,9 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const float* __restrict__ 
   float V[16][4];      // transformed patch (4 channels) of the group about to be multiplied
   bool first = true;   // only the very first group of the workgroup transforms its patch un-pipelined
 
+  // every item of this workgroup has the same nsp (-> the same filter slices) when the grid is a multiple of NSPLIT
+  const bool u_resident = NCHUNK == 1 && gridDim.x % NSPLIT == 0;
+  bool first_item = true;
   for (; item < nitems; item += gridDim.x) {
     const int next_item = item + gridDim.x;
     f32x4 acc[16];
@@ -250,23 +264,23 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const float* __restrict__ 
       const int n_region = n_item / NSPLIT;
       const int n_img = n_region / RPI, n_rrem = n_region % RPI;
       const int n_ry0 = (n_rrem / RPX) * 16, n_rx0 = (n_rrem % RPX) * 16;
-      const float* sIn = sIn0 + ibuf * SIN;
-      const float* sInNext = sIn0 + (ibuf ^ 1) * SIN;
+      const float* sIn = smem + ibuf * SIN;
+      const float* sInNext = smem + (ibuf ^ 1) * SIN;
 #pragma unroll
       for (int G = 0; G < 2; ++G) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every DMA issued so far has landed (all are >= 1 group old)
         __syncthreads();                                    // ... and is visible; the other buffers have no readers left
         const float* sU = sU0 + ubuf * SU;
         // filter slice of the next group -> the other buffer, while this group computes
-        dma_u_slice(G == 0 ? u_slice(item, chunk, 1) : u_slice(n_item, n_chunk, 0), su_bytes + (unsigned)(ubuf ^ 1) * SU * 4u, tid, wave);
+        // (single-chunk layers: the two slices of the workgroup's 32 output channels stay resident after the first item)
+        if (NCHUNK > 1 || !u_resident || first_item)
+          dma_u_slice(G == 0 ? u_slice(item, chunk, 1) : u_slice(n_item, n_chunk, 0), su_bytes + (unsigned)(ubuf ^ 1) * SU * 4u, tid, wave);
         if (first) {
           first = false;
-          unsigned iw0[9];
-          read_idx<IN_UNPOOL>(iw0, sIn + ibase);
 #pragma unroll
           for (int h = 0; h < 2; ++h) {
             float2 d[16], t[16];
-            read_pair<IN_UNPOOL>(d, iw0, sIn + pbase, h);
+            read_pair<IN_UNPOOL>(d, sIn + pbase, reinterpret_cast<const uint8_t*>(sIn) + ibase, h);
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
               t[0 + c] = make_float2(d[0 + c].x - d[8 + c].x, d[0 + c].y - d[8 + c].y);
@@ -286,8 +300,7 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const float* __restrict__ 
         // the NEXT group's patch comes from this chunk (G == 0) or from the next chunk's halo, which landed a group ago
         constexpr bool tnext = true;   // (at the very end this transforms a re-fetched tile that nobody consumes)
         const float* sNx = (G == 0 ? sIn + 16 : sInNext) + pbase;
-        const float* sNi = (G == 0 ? sIn + 4 : sInNext) + ibase;
-        unsigned iw[9];
+        const uint8_t* sNi = reinterpret_cast<const uint8_t*>(G == 0 ? sIn + 4 : sInNext) + ibase;
         // The next group's transformed patch is built in the shadow of this group's MFMAs and written straight into the
         // V registers of points that have already been multiplied (V[4r..4r+3] are dead once point 4r+3 is done), so only
         // one V set plus the row-pass temporaries are live: the kernel must fit 256 arch VGPRs beside 128 accumulators.
@@ -328,13 +341,12 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const float* __restrict__ 
 #pragma unroll
           for (int half = 0; half < 2; ++half) {
           const int pt = 2 * pp + half;
-          if (tnext && pt == 0) read_idx<IN_UNPOOL>(iw, sNi);
-          if (tnext && (pt == 0 || pt == 3)) read_pair<IN_UNPOOL>(dn, iw, sNx, pt == 0 ? 0 : 1);   // channels +0,1 / +2,3
+          if (tnext && (pt == 0 || pt == 3)) read_pair<IN_UNPOOL>(dn, sNx, sNi, pt == 0 ? 0 : 1);   // channels 2kq.. / 8+2kq..
           // halo of the next stage: all pieces of this wave during the FIRST group of the chunk, so that they are
           // a full group old at the next barrier and the next chunk's first transform can be pipelined as well
           if constexpr (IN_UNPOOL) {
-            if (G == 0 && (pt == 1 || pt == 2))
-              dma_pooled_piece<KC, HW>(in, in_idx, zeros, n_img, n_ry0, n_rx0, n_chunk, wave * 2 + (pt - 1), lane,
+            if (G == 0 && pt >= 1 && pt <= 3)
+              dma_pooled_piece<KC, HW>(in, in_idx, zeros, n_img, n_ry0, n_rx0, n_chunk, wave * 3 + (pt - 1), lane,
                                        sin_bytes + (unsigned)(ibuf ^ 1) * SIN * 4u);
           } else {
             if (G == 0 && pt >= 1 && pt < 7)   // early in the group: the pieces must have landed by the group's end
@@ -357,6 +369,7 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const float* __restrict__ 
       }
       ibuf ^= 1;
     }
+    first_item = false;
 
     // ---- output transform + epilogue: lane holds tiles 4*kq + r (r = 0..3) x channels {lj, 16 + lj}, all 16 points
     const int region = item / NSPLIT, nsp = item % NSPLIT;
@@ -380,7 +393,7 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const float* __restrict__ 
           y[r][a * 2 + 0] = sm[a][0] + sm[a][1] + sm[a][2];
           y[r][a * 2 + 1] = sm[a][1] - sm[a][2] - sm[a][3];
         }
-        const int oy = ry0 + 4 * tg + 2 * tr, ox = rx0 + 2 * tc;
+        const int oy = ry0 + 2 * (trow0 + TRSTEP * tr), ox = rx0 + 2 * tc;
         if constexpr (EPI == EPI_LRELU_POOL) {
           constexpr int HP = HW / 2;
           o[r][0] = (((size_t)img * HP + oy / 2) * HP + ox / 2) * NCF + co;
