@@ -65,8 +65,9 @@ int ugn_conv3x3_wgrad(const float* in, const float* dz, const uint8_t* dz_idx, f
 
 /* Winograd F(2x2,3x3) variants of the forward / data-gradient convolutions (same results up to fp32 rounding, 2.25x
  * fewer matrix FLOPs).  u_packed: 16*cin*cout floats produced by ugn_wino_pack from the HWIO weight
- * (dgrad = 0 for ugn_conv3x3_fwd_wino, 1 for ugn_conv3x3_dgrad_wino).  Arguments otherwise as the direct versions;
- * in the data gradient `addend` and `raw_out` require `act`. */
+ * (dgrad = 0 for ugn_conv3x3_fwd_wino; for ugn_conv3x3_dgrad_wino 1 when dz is full-resolution and 3 when dz is the
+ * pooled gradient + argmax of a MaxPool'ed layer: the kernels for the two cases consume different filter layouts).
+ * Arguments otherwise as the direct versions; in the data gradient `addend` and `raw_out` require `act`. */
 int ugn_wino_pack(const float* w_hwio, float* u_packed, int cin, int cout, int dgrad, void* stream);
 /* Same for up to 32 (layer, direction) jobs in ONE launch; all five arrays are HOST arrays of length njobs. */
 int ugn_wino_pack_multi(const float* const* w_hwio_host, float* const* u_packed_host, const int* cin_host,

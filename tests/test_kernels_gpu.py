@@ -99,7 +99,7 @@ def test_conv3x3_winograd_fwd_and_dgrad(dev, hw, cin, cout, pool):
         dz = rng.normal(size=(n, hw, hw, cout)).astype(np.float32)
         dz_t, idx_t = T(dz, dev), None
     _, dx_ref = O.conv2d_same_bwd(x.astype(np.float64), w.astype(np.float64), dz.astype(np.float64))
-    ud = ops.wino_pack(T(w, dev), True)
+    ud = ops.wino_pack(T(w, dev), True, pooled_dz=bool(pool))
     close(ops.conv3x3_dgrad_wino(dz_t, ud, hw, cin, cout, dz_idx=idx_t), dx_ref, 5e-6, "wino dgrad plain")
     raw = torch.empty((n, hw, hw, cin), device=dev)
     got = ops.conv3x3_dgrad_wino(dz_t, ud, hw, cin, cout, dz_idx=idx_t, act=T(act_prev, dev), addend=T(addend, dev), raw_out=raw)
@@ -111,15 +111,19 @@ def test_conv3x3_winograd_fwd_and_dgrad(dev, hw, cin, cout, pool):
 def test_wino_pack_multi_matches_single(dev):
     from ugaitnet_amd import ops
     rng = np.random.default_rng(77)
-    ws = [T(rng.normal(size=(3, 3, ci, co)).astype(np.float32), dev) for ci, co in ((32, 32), (64, 128), (128, 128))]
+    ws = [T(rng.normal(size=(3, 3, ci, co)).astype(np.float32), dev) for ci, co in ((32, 32), (64, 64), (64, 128), (128, 128))]
     jobs, refs = [], []
     for w in ws:
-        for dg in (False, True):
-            jobs.append((w, torch.zeros(16 * w.shape[2] * w.shape[3], device=dev), dg))
-            refs.append(ops.wino_pack(w, dg))
+        for dg, pooled in ((False, False), (True, False), (True, True)):   # wide and narrow filter layouts
+            jobs.append((w, torch.zeros(16 * w.shape[2] * w.shape[3], device=dev), dg, pooled))
+            refs.append(ops.wino_pack(w, dg, pooled_dz=pooled))
     ops.wino_pack_multi(jobs)
-    for (_, u, _), r in zip(jobs, refs):
+    for (_, u, _, _), r in zip(jobs, refs):
         assert torch.equal(u, r)
+    # the packed tensor is a permutation of G g G^T: same multiset of values in every layout
+    a = ops.wino_pack(ws[1], True, pooled_dz=False).sort().values
+    b = ops.wino_pack(ws[1], True, pooled_dz=True).sort().values
+    assert torch.equal(a, b)
 
 
 def test_conv3x3_pool_first_max_on_ties(dev):

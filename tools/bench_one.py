@@ -11,7 +11,7 @@ N = 600
 dev = torch.device("cuda")
 x = torch.randn(N, hw, hw, cin, device=dev)
 w = torch.randn(3, 3, cin, cout, device=dev) * 0.1
-uf, ud = ops.wino_pack(w, False), ops.wino_pack(w, True)
+uf, ud = ops.wino_pack(w, False), ops.wino_pack(w, True, pooled_dz=pool)
 ho = hw // 2 if pool else hw
 dz = torch.randn(N, ho, ho, cout, device=dev)
 idx = torch.randint(0, 4, (N, ho, ho, cout), device=dev, dtype=torch.uint8) if pool else None

@@ -51,10 +51,16 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
 // U[pt][n][k] = (G g G^T)[pt] for filter g(k -> n).  Layout [nsp][chunk][G][pt][kq][32 n][4 s] with k = 32*chunk + 16*G +
 // 8*(s>>1) + 2*kq + (s&1): a 32 KB slice per 16-channel group, and the lane (n, kq) of an MFMA reads its 4 steps with one
 // ds_read_b128 at consecutive 16-byte slots (conflict-free).
+// Layers with >= 64 output channels use the WIDE kernel variant (a wave owns 16 tiles x 32 channels) and its own layout.
 // fwd : g[dy][dx] = w[dy][dx][k = cin][n = cout]            (kc = cin, nc = cout)
 // dgrad: g[dy][dx] = w[2-dy][2-dx][n = cin][k = cout]        (kc = cout, nc = cin)
-__device__ __forceinline__ void wino_pack_one(const float* __restrict__ w, float* __restrict__ u, int cin, int cout, int dgrad,
+// The WIDE variant pays off when there are at least two 32-channel chunks to stream and the input is a plain tile
+// (measured: a4/a5/a6 fwd and a5/a6 dgrad 12-17 % faster; a3 fwd and the pooled a4 dgrad slower).
+__host__ __device__ constexpr bool wino_wide(int kc, int nc, int unpool) { return nc >= 64 && kc >= 64 && !unpool; }
+
+__device__ __forceinline__ void wino_pack_one(const float* __restrict__ w, float* __restrict__ u, int cin, int cout, int mode,
                                               int e) {
+  const int dgrad = mode & 1, unpool = (mode >> 1) & 1;   // mode: 0 fwd, 1 dgrad of a full-resolution dz, 3 dgrad of a pooled dz
   const int kc = dgrad ? cout : cin, nc = dgrad ? cin : cout;
   if (e >= kc * nc) return;
   const int k = e % kc, n = e / kc;
@@ -69,9 +75,17 @@ __device__ __forceinline__ void wino_pack_one(const float* __restrict__ w, float
     t[2][c] = 0.5f * (g[0][c] - g[1][c] + g[2][c]);
     t[3][c] = g[2][c];
   }
-  const int nsp = n >> 5, nl = n & 31, chunk = k >> 5, G = (k >> 4) & 1, kq = (k >> 1) & 3, st = ((k >> 3) & 1) * 2 + (k & 1);
-  const int nchunk = kc >> 5;
-  float* dst = u + (((size_t)nsp * nchunk + chunk) * 2 + G) * SU + (kq * 32 + nl) * 4 + st;
+  const int nchunk = kc >> 5, chunk = k >> 5, kq = (k >> 1) & 3;
+  float* dst;
+  if (wino_wide(kc, nc, unpool)) {
+    // wide: a workgroup owns 64 output channels, a wave 2 blocks of 16 (cb); 8-channel groups (k = 32*chunk + 8*G + 2*kq + s):
+    // [nsp64][chunk][G 0..3][pt][kq][32 = 16*cp + lj][cb][s]
+    const int nsp = n >> 6, nl = ((n >> 5) & 1) * 16 + (n & 15), cb = (n >> 4) & 1, G = (k >> 3) & 3;
+    dst = u + (((size_t)nsp * nchunk + chunk) * 4 + G) * SU + (kq * 32 + nl) * 4 + cb * 2 + (k & 1);
+  } else {
+    const int nsp = n >> 5, nl = n & 31, G = (k >> 4) & 1, st = ((k >> 3) & 1) * 2 + (k & 1);
+    dst = u + (((size_t)nsp * nchunk + chunk) * 2 + G) * SU + (kq * 32 + nl) * 4 + st;
+  }
   for (int r = 0; r < 4; ++r) {
     const float u0 = t[r][0], u1 = 0.5f * (t[r][0] + t[r][1] + t[r][2]), u2 = 0.5f * (t[r][0] - t[r][1] + t[r][2]),
                 u3 = t[r][2];
@@ -195,7 +209,14 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const float* __restrict__ 
                                                       const float* __restrict__ act, const float* __restrict__ addend,
                                                       float* __restrict__ raw_out, const float* __restrict__ zeros,
                                                       int nitems) {
-  constexpr int NCHUNK = KC / 32, NSPLIT = NCF / 32;
+  // WIDE (NCF >= 64): the workgroup owns 64 output channels, a wave 16 tiles x 2 channel blocks, and a group is 8 input
+  // channels (2 k-steps): per MFMA half the transform work, patch reads and halo traffic of the narrow variant.
+  constexpr bool WIDE = wino_wide(KC, NCF, IN_UNPOOL);
+  constexpr int NB = WIDE ? 2 : 1;          // 16-channel output blocks per wave
+  constexpr int NG = WIDE ? 4 : 2;          // channel groups per 32-channel chunk
+  constexpr int GW = 32 / NG;               // input channels per group
+  constexpr int NH = GW / 8;                // channel pairs per lane and group
+  constexpr int NCHUNK = KC / 32, NSPLIT = NCF / (32 * NB);
   constexpr int RPX = HW / 16, RPI = RPX * RPX;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* sU0 = smem + 2 * SIN;
@@ -223,7 +244,7 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const float* __restrict__ 
 #pragma unroll
   for (int j = 0; j < 6; ++j) hgeo[j] = halo_slot_geometry(wave * 6 + j, lane);
   auto u_slice = [&](int it, int chunk, int G) {
-    return upk + (((size_t)(it % NSPLIT) * NCHUNK + chunk) * 2 + G) * SU;
+    return upk + (((size_t)(it % NSPLIT) * NCHUNK + chunk) * NG + G) * SU;
   };
   // ---- prologue: halo(item, chunk 0) -> sIn[0]; U(item, 0, 0) -> sU[0]
   {
@@ -240,21 +261,23 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const float* __restrict__ 
     dma_u_slice(u_slice(item, 0, 0), su_bytes, tid, wave);
   }
   int ibuf = 0, ubuf = 0;
-  float V[16][4];      // transformed patch (4 channels) of the group about to be multiplied
+  float V[16][2 * NH]; // transformed patch (4 / 2 channels) of the group about to be multiplied
   bool first = true;   // only the very first group of the workgroup transforms its patch un-pipelined
 
   // every item of this workgroup has the same nsp (-> the same filter slices) when the grid is a multiple of NSPLIT
-  const bool u_resident = NCHUNK == 1 && gridDim.x % NSPLIT == 0;
+  const bool u_resident = NCHUNK == 1 && NG == 2 && gridDim.x % NSPLIT == 0;
   bool first_item = true;
   for (; item < nitems; item += gridDim.x) {
     const int next_item = item + gridDim.x;
-    f32x4 acc[16];
+    f32x4 acc[NB][16];
 #pragma unroll
-    for (int pt = 0; pt < 16; ++pt)
+    for (int cb = 0; cb < NB; ++cb)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) acc[pt][r] = 0.f;
+      for (int pt = 0; pt < 16; ++pt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[cb][pt][r] = 0.f;
 
-#pragma unroll
+#pragma unroll((WIDE || NCHUNK > 2) ? 1 : NCHUNK)   // (fully unrolled, the wide variants hoist DMA addresses and spill)
     for (int chunk = 0; chunk < NCHUNK; ++chunk) {
       const bool last_chunk = chunk + 1 == NCHUNK;
       const bool has_next = !last_chunk || next_item < nitems;
@@ -267,18 +290,18 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const float* __restrict__ 
       const float* sIn = smem + ibuf * SIN;
       const float* sInNext = smem + (ibuf ^ 1) * SIN;
 #pragma unroll
-      for (int G = 0; G < 2; ++G) {
+      for (int G = 0; G < NG; ++G) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every DMA issued so far has landed (all are >= 1 group old)
         __syncthreads();                                    // ... and is visible; the other buffers have no readers left
         const float* sU = sU0 + ubuf * SU;
         // filter slice of the next group -> the other buffer, while this group computes
         // (single-chunk layers: the two slices of the workgroup's 32 output channels stay resident after the first item)
         if (NCHUNK > 1 || !u_resident || first_item)
-          dma_u_slice(G == 0 ? u_slice(item, chunk, 1) : u_slice(n_item, n_chunk, 0), su_bytes + (unsigned)(ubuf ^ 1) * SU * 4u, tid, wave);
+          dma_u_slice(G + 1 < NG ? u_slice(item, chunk, G + 1) : u_slice(n_item, n_chunk, 0), su_bytes + (unsigned)(ubuf ^ 1) * SU * 4u, tid, wave);
         if (first) {
           first = false;
 #pragma unroll
-          for (int h = 0; h < 2; ++h) {
+          for (int h = 0; h < NH; ++h) {
             float2 d[16], t[16];
             read_pair<IN_UNPOOL>(d, sIn + pbase, reinterpret_cast<const uint8_t*>(sIn) + ibase, h);
 #pragma unroll
@@ -299,27 +322,32 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const float* __restrict__ 
         }
         // the NEXT group's patch comes from this chunk (G == 0) or from the next chunk's halo, which landed a group ago
         constexpr bool tnext = true;   // (at the very end this transforms a re-fetched tile that nobody consumes)
-        const float* sNx = (G == 0 ? sIn + 16 : sInNext) + pbase;
-        const uint8_t* sNi = reinterpret_cast<const uint8_t*>(G == 0 ? sIn + 4 : sInNext) + ibase;
+        const float* sNx = (G + 1 < NG ? sIn + GW * (G + 1) : sInNext) + pbase;
+        const uint8_t* sNi = reinterpret_cast<const uint8_t*>(G + 1 < NG ? sIn : sInNext) + (G + 1 < NG ? GW * (G + 1) : 0) + ibase;
         // The next group's transformed patch is built in the shadow of this group's MFMAs and written straight into the
         // V registers of points that have already been multiplied (V[4r..4r+3] are dead once point 4r+3 is done), so only
         // one V set plus the row-pass temporaries are live: the kernel must fit 256 arch VGPRs beside 128 accumulators.
-        float2 dn[16], tn0[16], tn1[16];
+        // (WIDE has a single channel pair per group: its row pass runs in place on dn, which frees 32 registers)
+        float2 dn[16], tn0s[16], tn1[16];
+        float2 (&tn0)[16] = *(WIDE ? &dn : &tn0s);
         auto rowpass = [&](float2 (&tn)[16], int c) {
-          tn[0 + c] = make_float2(dn[0 + c].x - dn[8 + c].x, dn[0 + c].y - dn[8 + c].y);
-          tn[4 + c] = make_float2(dn[4 + c].x + dn[8 + c].x, dn[4 + c].y + dn[8 + c].y);
-          tn[8 + c] = make_float2(dn[8 + c].x - dn[4 + c].x, dn[8 + c].y - dn[4 + c].y);
-          tn[12 + c] = make_float2(dn[4 + c].x - dn[12 + c].x, dn[4 + c].y - dn[12 + c].y);
+          const float2 d0 = dn[0 + c], d1 = dn[4 + c], d2 = dn[8 + c], d3 = dn[12 + c];
+          tn[0 + c] = make_float2(d0.x - d2.x, d0.y - d2.y);
+          tn[4 + c] = make_float2(d1.x + d2.x, d1.y + d2.y);
+          tn[8 + c] = make_float2(d2.x - d1.x, d2.y - d1.y);
+          tn[12 + c] = make_float2(d1.x - d3.x, d1.y - d3.y);
         };
         auto colpass = [&](int r) {
           V[r * 4 + 0][0] = tn0[r * 4 + 0].x - tn0[r * 4 + 2].x; V[r * 4 + 0][1] = tn0[r * 4 + 0].y - tn0[r * 4 + 2].y;
           V[r * 4 + 1][0] = tn0[r * 4 + 1].x + tn0[r * 4 + 2].x; V[r * 4 + 1][1] = tn0[r * 4 + 1].y + tn0[r * 4 + 2].y;
           V[r * 4 + 2][0] = tn0[r * 4 + 2].x - tn0[r * 4 + 1].x; V[r * 4 + 2][1] = tn0[r * 4 + 2].y - tn0[r * 4 + 1].y;
           V[r * 4 + 3][0] = tn0[r * 4 + 1].x - tn0[r * 4 + 3].x; V[r * 4 + 3][1] = tn0[r * 4 + 1].y - tn0[r * 4 + 3].y;
-          V[r * 4 + 0][2] = tn1[r * 4 + 0].x - tn1[r * 4 + 2].x; V[r * 4 + 0][3] = tn1[r * 4 + 0].y - tn1[r * 4 + 2].y;
-          V[r * 4 + 1][2] = tn1[r * 4 + 1].x + tn1[r * 4 + 2].x; V[r * 4 + 1][3] = tn1[r * 4 + 1].y + tn1[r * 4 + 2].y;
-          V[r * 4 + 2][2] = tn1[r * 4 + 2].x - tn1[r * 4 + 1].x; V[r * 4 + 2][3] = tn1[r * 4 + 2].y - tn1[r * 4 + 1].y;
-          V[r * 4 + 3][2] = tn1[r * 4 + 1].x - tn1[r * 4 + 3].x; V[r * 4 + 3][3] = tn1[r * 4 + 1].y - tn1[r * 4 + 3].y;
+          if constexpr (NH == 2) {
+            V[r * 4 + 0][2] = tn1[r * 4 + 0].x - tn1[r * 4 + 2].x; V[r * 4 + 0][3] = tn1[r * 4 + 0].y - tn1[r * 4 + 2].y;
+            V[r * 4 + 1][2] = tn1[r * 4 + 1].x + tn1[r * 4 + 2].x; V[r * 4 + 1][3] = tn1[r * 4 + 1].y + tn1[r * 4 + 2].y;
+            V[r * 4 + 2][2] = tn1[r * 4 + 2].x - tn1[r * 4 + 1].x; V[r * 4 + 2][3] = tn1[r * 4 + 2].y - tn1[r * 4 + 1].y;
+            V[r * 4 + 3][2] = tn1[r * 4 + 1].x - tn1[r * 4 + 3].x; V[r * 4 + 3][3] = tn1[r * 4 + 1].y - tn1[r * 4 + 3].y;
+          }
         };
         // points are multiplied in PAIRS with their 4 k-steps interleaved (pt0 s0, pt1 s0, pt0 s1, ...): consecutive
         // MFMAs on one accumulator would each wait out the 40-cycle dependent latency of v_mfma_f32_16x16x4_f32
@@ -333,15 +361,25 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const float* __restrict__ 
             u[nu][0] = *reinterpret_cast<const float4*>(sU + ubase + (2 * pp + 2) * 512);
             u[nu][1] = *reinterpret_cast<const float4*>(sU + ubase + (2 * pp + 3) * 512);
           }
+          if constexpr (WIDE) {   // u float4 = {cb0 s0, cb0 s1, cb1 s0, cb1 s1}
 #pragma unroll
-          for (int st = 0; st < 4; ++st) {
-            acc[2 * pp] = mfma16(V[2 * pp][st], u[cu][0][st], acc[2 * pp]);
-            acc[2 * pp + 1] = mfma16(V[2 * pp + 1][st], u[cu][1][st], acc[2 * pp + 1]);
+            for (int st = 0; st < 2; ++st)
+#pragma unroll
+              for (int cb = 0; cb < 2; ++cb) {
+                acc[cb][2 * pp] = mfma16(V[2 * pp][st], u[cu][0][cb * 2 + st], acc[cb][2 * pp]);
+                acc[cb][2 * pp + 1] = mfma16(V[2 * pp + 1][st], u[cu][1][cb * 2 + st], acc[cb][2 * pp + 1]);
+              }
+          } else {
+#pragma unroll
+            for (int st = 0; st < 4; ++st) {
+              acc[0][2 * pp] = mfma16(V[2 * pp][st], u[cu][0][st], acc[0][2 * pp]);
+              acc[0][2 * pp + 1] = mfma16(V[2 * pp + 1][st], u[cu][1][st], acc[0][2 * pp + 1]);
+            }
           }
 #pragma unroll
           for (int half = 0; half < 2; ++half) {
           const int pt = 2 * pp + half;
-          if (tnext && (pt == 0 || pt == 3)) read_pair<IN_UNPOOL>(dn, sNx, sNi, pt == 0 ? 0 : 1);   // channels 2kq.. / 8+2kq..
+          if (tnext && (pt == 0 || (NH == 2 && pt == 3))) read_pair<IN_UNPOOL>(dn, sNx, sNi, pt == 0 ? 0 : 1);   // channels 2kq.. / 8+2kq..
           // halo of the next stage: all pieces of this wave during the FIRST group of the chunk, so that they are
           // a full group old at the next barrier and the next chunk's first transform can be pipelined as well
           if constexpr (IN_UNPOOL) {
@@ -356,8 +394,8 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const float* __restrict__ 
           if (tnext) {
             if (pt == 1) { rowpass(tn0, 0); rowpass(tn0, 1); }
             if (pt == 2) { rowpass(tn0, 2); rowpass(tn0, 3); }   // pair 0 done before pair 1 is loaded at point 3
-            if (pt == 4) { rowpass(tn1, 0); rowpass(tn1, 1); }
-            if (pt == 5) { rowpass(tn1, 2); rowpass(tn1, 3); }
+            if (NH == 2 && pt == 4) { rowpass(tn1, 0); rowpass(tn1, 1); }
+            if (NH == 2 && pt == 5) { rowpass(tn1, 2); rowpass(tn1, 3); }
             if (pt == 6) colpass(0);
             if (pt == 8) colpass(1);
             if (pt == 12) colpass(2);
@@ -375,8 +413,9 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const float* __restrict__ 
     const int region = item / NSPLIT, nsp = item % NSPLIT;
     const int img = region / RPI, rrem = region % RPI;
     const int ry0 = (rrem / RPX) * 16, rx0 = (rrem % RPX) * 16;
-    {
-      const int co = nsp * 32 + ch * 16 + lj;
+#pragma unroll
+    for (int cb = 0; cb < NB; ++cb) {
+      const int co = nsp * (32 * NB) + ch * (16 * NB) + cb * 16 + lj;
       float y[4][4];     // [tile r][output (a,b) row-major]
       size_t o[4][4];
 #pragma unroll
@@ -385,8 +424,8 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const float* __restrict__ 
         float sm[2][4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-          sm[0][c] = acc[0 * 4 + c][r] + acc[1 * 4 + c][r] + acc[2 * 4 + c][r];
-          sm[1][c] = acc[1 * 4 + c][r] - acc[2 * 4 + c][r] - acc[3 * 4 + c][r];
+          sm[0][c] = acc[cb][0 * 4 + c][r] + acc[cb][1 * 4 + c][r] + acc[cb][2 * 4 + c][r];
+          sm[1][c] = acc[cb][1 * 4 + c][r] - acc[cb][2 * 4 + c][r] - acc[cb][3 * 4 + c][r];
         }
 #pragma unroll
         for (int a = 0; a < 2; ++a) {
@@ -474,7 +513,7 @@ int launch_wino(const float* in, const uint8_t* in_idx, const float* upk, float*
   }
   const float* zeros = zero_block();
   if (!zeros) { ugn_set_error("wino: cannot allocate the zero block"); return UGN_EINVAL; }
-  const int nitems = n * (HW / 16) * (HW / 16) * (NCF / 32);
+  const int nitems = n * (HW / 16) * (HW / 16) * (NCF / (wino_wide(KC, NCF, IN_UNPOOL) ? 64 : 32));
   const int grid = nitems < kGrid ? nitems : kGrid;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), LDS_BYTES, st, in, in_idx, upk, out, out_idx, act, addend, raw_out, zeros,
                      nitems);

@@ -106,14 +106,14 @@ class Encoder:
         """Refresh the kernel-ready copies of the 3x3 weights (after every optimizer step): one launch per branch."""
         if USE_WINOGRAD:
             jobs = []
-            for name, k, _, _, _, _ in CONV_SPECS:
+            for name, k, _, _, _, pool in CONV_SPECS:
                 if k != 3:
                     continue
                 w = self.W(name)
                 for store, dgrad in ((self.uf, False), (self.ud, True)):
                     if name not in store:
                         store[name] = torch.empty((16 * w.shape[2] * w.shape[3],), dtype=F32, device=w.device)
-                    jobs.append((w, store[name], dgrad))
+                    jobs.append((w, store[name], dgrad, pool))   # a pooled layer's dgrad takes dz at pooled resolution
             ops.wino_pack_multi(jobs)
         else:
             for name, k, _, _, _, _ in CONV_SPECS:

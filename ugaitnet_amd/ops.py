@@ -120,25 +120,31 @@ def conv3x3_dgrad(dz, w, hw, dz_idx=None, act=None, addend=None, out=None, raw_o
     return out
 
 
-def wino_pack(w, dgrad, out=None):
-    """HWIO [3,3,cin,cout] -> transformed filters G g G^T in the Winograd kernels' streaming order (16*cin*cout floats)."""
+def _pack_mode(dgrad, pooled_dz):
+    # 0: forward; 1: data gradient of a full-resolution dz; 3: data gradient of a pooled dz (+ argmax)
+    return (1 | (2 if pooled_dz else 0)) if dgrad else 0
+
+
+def wino_pack(w, dgrad, out=None, pooled_dz=False):
+    """HWIO [3,3,cin,cout] -> transformed filters G g G^T in the Winograd kernels' streaming order (16*cin*cout floats).
+    `pooled_dz`: the data gradient will be called with dz_idx (the layer is followed by MaxPool)."""
     _chk(w)
     cin, cout = w.shape[2], w.shape[3]
     out = torch.empty((16 * cin * cout,), dtype=F32, device=w.device) if out is None else out
-    call("ugn_wino_pack", ptr(w), ptr(out), cin, cout, int(bool(dgrad)), _stream())
+    call("ugn_wino_pack", ptr(w), ptr(out), cin, cout, _pack_mode(dgrad, pooled_dz), _stream())
     return out
 
 
 def wino_pack_multi(jobs):
-    """jobs: list of (w HWIO tensor, u_packed tensor, dgrad flag); one launch for up to 32 of them."""
+    """jobs: list of (w HWIO tensor, u_packed tensor, dgrad flag, pooled_dz flag); one launch for up to 32 of them."""
     for k in range(0, len(jobs), 32):
         part = jobs[k:k + 32]
         n = len(part)
-        ws = ptr_array([w for w, _, _ in part])
-        us = ptr_array([u for _, u, _ in part])
-        cin = (C.c_int * n)(*[w.shape[2] for w, _, _ in part])
-        cout = (C.c_int * n)(*[w.shape[3] for w, _, _ in part])
-        dg = (C.c_int * n)(*[int(bool(d)) for _, _, d in part])
+        ws = ptr_array([j[0] for j in part])
+        us = ptr_array([j[1] for j in part])
+        cin = (C.c_int * n)(*[j[0].shape[2] for j in part])
+        cout = (C.c_int * n)(*[j[0].shape[3] for j in part])
+        dg = (C.c_int * n)(*[_pack_mode(j[2], j[3]) for j in part])
         call("ugn_wino_pack_multi", ws, us, cin, cout, dg, n, _stream())
 
 
