@@ -165,7 +165,7 @@ def main():
                 oev = ops.TIMING.get(oname, [])
                 if oev:
                     oavg = float(np.mean([a.elapsed_time(b) for a, b in oev])) * 1e-3
-                    otf = oflops * frames / oavg / 1e12
+                    otf = oflops * (frames + B_PER_GPU) / oavg / 1e12   # launched together with its set-level twin (B more images)
                     others.append(dict(kernel=oname, achieved=round(otf, 2), frac=round(otf * 1e12 / PEAK_F32_MFMA, 4),
                                        avg_us=round(oavg * 1e6, 1), launches=len(oev)))
             roof["other_kernels"] = others

@@ -77,11 +77,24 @@ int ugn_conv3x3_fwd_wino(const float* in, const float* u_packed, float* out, uin
 int ugn_conv3x3_dgrad_wino(const float* dz, const uint8_t* dz_idx, const float* u_packed, const float* act,
                            const float* addend, float* out, float* raw_out, int n, int hw, int cin, int cout,
                            void* stream);
+/* The same two operators for TWO convolutions of one shape in a single launch (arrays of length 2: pointers and image
+ * counts per job).  The encoder of nets/mj_uwyhNets_ba.py:431-462 applies every 3x3 shape twice, to the L frames of a clip
+ * and to the set-pooled map of the global branch; the second has 1/L of the work and rides along with the first.  In the
+ * pair data gradient both jobs must use the same subset of act / addend / raw_out and both or neither a pooled dz. */
+int ugn_conv3x3_fwd_wino_pair(const float* const* in, const float* const* u_packed, float* const* out,
+                              uint8_t* const* out_idx, const int* n, int hw, int cin, int cout, int pool, void* stream);
+int ugn_conv3x3_dgrad_wino_pair(const float* const* dz, const uint8_t* const* dz_idx, const float* const* u_packed,
+                                const float* const* act, const float* const* addend, float* const* out,
+                                float* const* raw_out, const int* n, int hw, int cin, int cout, void* stream);
 /* Winograd F(2x2,3x3) weight gradient (Conv2DBackpropFilter of the same layers); arguments as ugn_conv3x3_wgrad,
  * workspace size from ugn_conv3x3_wgrad_wino_ws (0 = unsupported shape).  Deterministic (fixed summation order). */
 size_t ugn_conv3x3_wgrad_wino_ws(int n, int hw, int cin, int cout);
 int ugn_conv3x3_wgrad_wino(const float* in, const float* dz, const uint8_t* dz_idx, float* dw, int n, int hw, int cin,
                            int cout, void* ws, size_t ws_bytes, void* stream);
+/* Two weight gradients of one shape in a single launch (arrays of length 2); workspace: ugn_conv3x3_wgrad_wino_ws(n0 + n1). */
+int ugn_conv3x3_wgrad_wino_pair(const float* const* in, const float* const* dz, const uint8_t* const* dz_idx,
+                                float* const* dw, const int* n, int hw, int cin, int cout, void* ws, size_t ws_bytes,
+                                void* stream);
 
 /* ---- set pooling over the L frames: tf.math.reduce_max(x, axis=1), nets/mj_uwyhNets_ba.py:435,451,463 ----
  * p [b,l,s] -> m [b,s]; if addend != NULL also sum_out = m + addend (the Add layers :452,:465). */

@@ -126,6 +126,47 @@ def test_wino_pack_multi_matches_single(dev):
     assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("hw,cin,cout,pool", CONV_CFGS[1:])
+def test_winograd_pair_launch_equals_two_single_launches(dev, hw, cin, cout, pool):
+    """The frame-level layer and its set-level twin as two jobs of one launch: bit-identical to separate launches."""
+    from ugaitnet_amd import ops
+    rng = np.random.default_rng(4000 + hw + cin + cout)
+    ns = (7, 2)
+    ho = hw // 2 if pool else hw
+    xs = [T(rng.uniform(-1, 1, (n, hw, hw, cin)).astype(np.float32), dev) for n in ns]
+    ws = [T(rng.uniform(-0.2, 0.2, (3, 3, cin, cout)).astype(np.float32), dev) for _ in ns]
+    dzs = [T(rng.normal(size=(n, ho, ho, cout)).astype(np.float32), dev) for n in ns]
+    idxs = [T(rng.integers(0, 4, size=(n, ho, ho, cout)).astype(np.uint8), dev) for n in ns] if pool else None
+    acts = [T(rng.normal(size=(n, hw, hw, cin)).astype(np.float32), dev) for n in ns]
+    ufs = [ops.wino_pack(w, False) for w in ws]
+    uds = [ops.wino_pack(w, True, pooled_dz=bool(pool)) for w in ws]
+    # forward
+    outs = [torch.empty((n, ho, ho, cout), device=dev) for n in ns]
+    oidx = [torch.empty((n, ho, ho, cout), device=dev, dtype=torch.uint8) for n in ns] if pool else None
+    ops.conv3x3_fwd_wino_pair(xs, ufs, cout, pool, outs, oidx)
+    for k in range(2):
+        ref = ops.conv3x3_fwd_wino(xs[k], ufs[k], cout, pool)
+        if pool:
+            assert torch.equal(outs[k], ref[0]) and torch.equal(oidx[k], ref[1])
+        else:
+            assert torch.equal(outs[k], ref)
+    # data gradient with the LeakyReLU' epilogue
+    gouts = [torch.empty((n, hw, hw, cin), device=dev) for n in ns]
+    ops.conv3x3_dgrad_wino_pair(dzs, uds, hw, cin, cout, gouts, dz_idxs=idxs, acts=acts)
+    for k in range(2):
+        ref = ops.conv3x3_dgrad_wino(dzs[k], uds[k], hw, cin, cout, dz_idx=None if idxs is None else idxs[k], act=acts[k])
+        assert torch.equal(gouts[k], ref)
+    # weight gradient
+    dws = [torch.empty((3, 3, cin, cout), device=dev) for _ in ns]
+    ops.conv3x3_wgrad_wino_pair(xs, dzs, cout, dws, dz_idxs=idxs)
+    for k in range(2):
+        ref = ops.conv3x3_wgrad_wino(xs[k], dzs[k], cout, dz_idx=None if idxs is None else idxs[k])
+        # (the split of the persistent workgroups between the jobs changes the summation order)
+        close(dws[k], ref.cpu().numpy(), 2e-6, "pair wgrad job %d" % k)
+    with pytest.raises(ValueError):   # mixed epilogues are rejected
+        ops.conv3x3_dgrad_wino_pair(dzs, uds, hw, cin, cout, gouts, dz_idxs=idxs, acts=[acts[0], None])
+
+
 def test_conv3x3_pool_first_max_on_ties(dev):
     """Constant input -> every window is a 4-way tie in the interior: the FIRST element (index 0) must win."""
     from ugaitnet_amd import ops

@@ -33,6 +33,9 @@ PROTOTYPES = {
     "ugn_wino_pack_multi": (_i, [C.POINTER(_p), C.POINTER(_p), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), _i, _p]),
     "ugn_conv3x3_fwd_wino": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "ugn_conv3x3_dgrad_wino": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
+    "ugn_conv3x3_fwd_wino_pair": (_i, [C.POINTER(_p)] * 4 + [C.POINTER(_i), _i, _i, _i, _i, _p]),
+    "ugn_conv3x3_dgrad_wino_pair": (_i, [C.POINTER(_p)] * 7 + [C.POINTER(_i), _i, _i, _i, _p]),
+    "ugn_conv3x3_wgrad_wino_pair": (_i, [C.POINTER(_p)] * 4 + [C.POINTER(_i), _i, _i, _i, _p, _sz, _p]),
     "ugn_conv3x3_wgrad_wino_ws": (_sz, [_i, _i, _i, _i]),
     "ugn_conv3x3_wgrad_wino": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p, _sz, _p]),
     "ugn_setmax_fwd": (_i, [_p, _p, _p, _p, _i, _i, _sz, _p]),
@@ -97,7 +100,8 @@ def ptr(t):
 
 
 def ptr_array(tensors):
+    """Host array of device pointers (None entries -> NULL)."""
     arr = (C.c_void_p * len(tensors))()
     for i, t in enumerate(tensors):
-        arr[i] = t.data_ptr()
+        arr[i] = None if t is None else t.data_ptr()
     return arr

@@ -43,6 +43,19 @@ __device__ __forceinline__ constexpr int colpos(int col) { return (col & 1) ? 9 
 
 enum { EPI_LRELU = 0, EPI_LRELU_POOL = 1, EPI_DGRAD = 2 };
 
+// One launch serves up to two convolutions of the same shape (the frame-level layer and its set-level twin of the global
+// branch, which alone would leave most CUs idle): items [0, nitems0) belong to job 0, [nitems0, nitems) to job 1.
+struct WinoJob {
+  const float* in;
+  const uint8_t* in_idx;
+  const float* upk;
+  float* out;
+  uint8_t* out_idx;
+  const float* act;
+  const float* addend;
+  float* raw_out;
+};
+
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
   // lane l: A[i = l&15][k = l>>4], B[k = l>>4][j = l&15]; D reg r of lane l = D[i = 4*(l>>4) + r][j = l&15]
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
@@ -203,12 +216,8 @@ __device__ __forceinline__ void dma_u_slice(const float* __restrict__ us, unsign
 
 // KC: GEMM K channels, NCF: output channels of the layer (a workgroup owns 32 of them), HW: image size
 template <int KC, int NCF, int HW, int IN_UNPOOL, int EPI, int EFLAGS>
-__global__ __launch_bounds__(512, 2) void wino_kernel(const float* __restrict__ in, const uint8_t* __restrict__ in_idx,
-                                                      const float* __restrict__ upk,
-                                                      float* __restrict__ out, uint8_t* __restrict__ out_idx,
-                                                      const float* __restrict__ act, const float* __restrict__ addend,
-                                                      float* __restrict__ raw_out, const float* __restrict__ zeros,
-                                                      int nitems) {
+__global__ __launch_bounds__(512, 2) void wino_kernel(const WinoJob j0, const WinoJob j1, const float* __restrict__ zeros,
+                                                      int nitems0, int nitems) {
   // WIDE (NCF >= 64): the workgroup owns 64 output channels, a wave 16 tiles x 2 channel blocks, and a group is 8 input
   // channels (2 k-steps): per MFMA half the transform work, patch reads and halo traffic of the narrow variant.
   constexpr bool WIDE = wino_wide(KC, NCF, IN_UNPOOL);
@@ -243,12 +252,18 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const float* __restrict__ 
   int hgeo[6];
 #pragma unroll
   for (int j = 0; j < 6; ++j) hgeo[j] = halo_slot_geometry(wave * 6 + j, lane);
+  // item -> job-local item / pointers (all wave-uniform: scalar selects)
+  auto local = [&](int it) { return it >= nitems0 ? it - nitems0 : it; };
+  auto in_of = [&](int it) { return it >= nitems0 ? j1.in : j0.in; };
+  auto idx_of = [&](int it) { return it >= nitems0 ? j1.in_idx : j0.in_idx; };
   auto u_slice = [&](int it, int chunk, int G) {
-    return upk + (((size_t)(it % NSPLIT) * NCHUNK + chunk) * NG + G) * SU;
+    return (it >= nitems0 ? j1.upk : j0.upk) + (((size_t)(local(it) % NSPLIT) * NCHUNK + chunk) * NG + G) * SU;
   };
   // ---- prologue: halo(item, chunk 0) -> sIn[0]; U(item, 0, 0) -> sU[0]
   {
-    const int region = item / NSPLIT, img = region / RPI, rrem = region % RPI;
+    const int region = local(item) / NSPLIT, img = region / RPI, rrem = region % RPI;
+    const float* in = in_of(item);
+    const uint8_t* in_idx = idx_of(item);
     if constexpr (IN_UNPOOL) {
 #pragma unroll
       for (int j = 0; j < 3; ++j)
@@ -265,7 +280,7 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const float* __restrict__ 
   bool first = true;   // only the very first group of the workgroup transforms its patch un-pipelined
 
   // every item of this workgroup has the same nsp (-> the same filter slices) when the grid is a multiple of NSPLIT
-  const bool u_resident = NCHUNK == 1 && NG == 2 && gridDim.x % NSPLIT == 0;
+  const bool u_resident = NCHUNK == 1 && NG == 2 && gridDim.x % NSPLIT == 0 && nitems0 == nitems;
   bool first_item = true;
   for (; item < nitems; item += gridDim.x) {
     const int next_item = item + gridDim.x;
@@ -284,7 +299,9 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const float* __restrict__ 
       // no next stage (last chunk of the last item): the prefetches re-fetch the current stage into the free buffers
       // instead of branching around the DMA (keeps the MFMA stream one basic block)
       const int n_item = last_chunk ? (has_next ? next_item : item) : item, n_chunk = last_chunk ? (has_next ? 0 : chunk) : chunk + 1;
-      const int n_region = n_item / NSPLIT;
+      const int n_region = local(n_item) / NSPLIT;
+      const float* in = in_of(n_item);
+      const uint8_t* in_idx = idx_of(n_item);
       const int n_img = n_region / RPI, n_rrem = n_region % RPI;
       const int n_ry0 = (n_rrem / RPX) * 16, n_rx0 = (n_rrem % RPX) * 16;
       const float* sIn = smem + ibuf * SIN;
@@ -410,8 +427,14 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const float* __restrict__ 
     first_item = false;
 
     // ---- output transform + epilogue: lane holds tiles 4*kq + r (r = 0..3) x channels {lj, 16 + lj}, all 16 points
-    const int region = item / NSPLIT, nsp = item % NSPLIT;
+    const int region = local(item) / NSPLIT, nsp = local(item) % NSPLIT;
     const int img = region / RPI, rrem = region % RPI;
+    const bool jb = item >= nitems0;
+    float* out = jb ? j1.out : j0.out;
+    uint8_t* out_idx = jb ? j1.out_idx : j0.out_idx;
+    const float* act = jb ? j1.act : j0.act;
+    const float* addend = jb ? j1.addend : j0.addend;
+    float* raw_out = jb ? j1.raw_out : j0.raw_out;
     const int ry0 = (rrem / RPX) * 16, rx0 = (rrem % RPX) * 16;
 #pragma unroll
     for (int cb = 0; cb < NB; ++cb) {
@@ -502,8 +525,7 @@ inline const float* zero_block() {
 }
 
 template <int KC, int NCF, int HW, int IN_UNPOOL, int EPI, int EFLAGS>
-int launch_wino(const float* in, const uint8_t* in_idx, const float* upk, float* out, uint8_t* out_idx, const float* act,
-                const float* addend, float* raw_out, int n, hipStream_t st) {
+int launch_wino(const WinoJob* jobs, const int* n, int njobs, hipStream_t st) {
   auto kern = wino_kernel<KC, NCF, HW, IN_UNPOOL, EPI, EFLAGS>;
   static bool attr_done = false;
   if (!attr_done) {
@@ -513,27 +535,53 @@ int launch_wino(const float* in, const uint8_t* in_idx, const float* upk, float*
   }
   const float* zeros = zero_block();
   if (!zeros) { ugn_set_error("wino: cannot allocate the zero block"); return UGN_EINVAL; }
-  const int nitems = n * (HW / 16) * (HW / 16) * (NCF / (wino_wide(KC, NCF, IN_UNPOOL) ? 64 : 32));
+  constexpr int per_img = (HW / 16) * (HW / 16) * (NCF / (wino_wide(KC, NCF, IN_UNPOOL) ? 64 : 32));
+  const int nitems0 = n[0] * per_img, nitems = nitems0 + (njobs > 1 ? n[1] * per_img : 0);
   const int grid = nitems < kGrid ? nitems : kGrid;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), LDS_BYTES, st, in, in_idx, upk, out, out_idx, act, addend, raw_out, zeros,
-                     nitems);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), LDS_BYTES, st, jobs[0], jobs[njobs > 1 ? 1 : 0], zeros, nitems0, nitems);
   UGN_CHECK_LAUNCH("wino");
   return 0;
 }
 
 template <int KC, int NCF, int HW, int IN_UNPOOL>
-int launch_wino_dgrad(const float* in, const uint8_t* in_idx, const float* upk, float* out, const float* act,
-                      const float* addend, float* raw_out, int n, hipStream_t st) {
-  const int flags = (act ? 1 : 0) | (addend ? 2 : 0) | (raw_out ? 4 : 0);
-#define UGN_WDG(F_)                                                                                                  \
-  case F_:                                                                                                           \
-    return launch_wino<KC, NCF, HW, IN_UNPOOL, EPI_DGRAD, F_>(in, in_idx, upk, out, nullptr, act, addend, raw_out, n, st);
+int launch_wino_dgrad(const WinoJob* jobs, const int* n, int njobs, hipStream_t st) {
+  const int flags = (jobs[0].act ? 1 : 0) | (jobs[0].addend ? 2 : 0) | (jobs[0].raw_out ? 4 : 0);
+  if (njobs > 1) {
+    const int f1 = (jobs[1].act ? 1 : 0) | (jobs[1].addend ? 2 : 0) | (jobs[1].raw_out ? 4 : 0);
+    if (f1 != flags) {
+      ugn_set_error("ugn_conv3x3_dgrad_wino_pair: both jobs need the same set of act/addend/raw_out (%d vs %d)", flags, f1);
+      return UGN_EINVAL;
+    }
+  }
+#define UGN_WDG(F_) \
+  case F_:          \
+    return launch_wino<KC, NCF, HW, IN_UNPOOL, EPI_DGRAD, F_>(jobs, n, njobs, st);
   switch (flags) {
     UGN_WDG(0) UGN_WDG(1) UGN_WDG(3) UGN_WDG(5) UGN_WDG(7)
     default: break;
   }
 #undef UGN_WDG
   ugn_set_error("ugn_conv3x3_dgrad_wino: unsupported epilogue combination %d (addend/raw_out need act)", flags);
+  return UGN_EINVAL;
+}
+
+int dispatch_fwd(const WinoJob* jobs, const int* n, int njobs, int hw, int cin, int cout, int pool, hipStream_t st) {
+#define WF(KC_, NC_, HW_, P_)                                             \
+  if (cin == KC_ && cout == NC_ && hw == HW_ && (pool != 0) == (P_ != 0)) \
+    return launch_wino<KC_, NC_, HW_, 0, P_ ? EPI_LRELU_POOL : EPI_LRELU, 0>(jobs, n, njobs, st);
+  WF(32, 32, 64, 1) WF(32, 64, 32, 0) WF(64, 64, 32, 1) WF(64, 128, 16, 0) WF(128, 128, 16, 0)
+#undef WF
+  ugn_set_error("ugn_conv3x3_fwd_wino: unsupported shape cin=%d cout=%d hw=%d pool=%d", cin, cout, hw, pool);
+  return UGN_EINVAL;
+}
+
+int dispatch_dgrad(const WinoJob* jobs, const int* n, int njobs, int hw, int cin, int cout, int unpool, hipStream_t st) {
+#define WD(CI_, CO_, HW_, U_)                                 \
+  if (cin == CI_ && cout == CO_ && hw == HW_ && unpool == U_) \
+    return launch_wino_dgrad<CO_, CI_, HW_, U_>(jobs, n, njobs, st);
+  WD(32, 32, 64, 1) WD(32, 64, 32, 0) WD(64, 64, 32, 1) WD(64, 128, 16, 0) WD(128, 128, 16, 0)
+#undef WD
+  ugn_set_error("ugn_conv3x3_dgrad_wino: unsupported shape cin=%d cout=%d hw=%d unpool=%d", cin, cout, hw, unpool);
   return UGN_EINVAL;
 }
 
@@ -571,26 +619,41 @@ extern "C" int ugn_conv3x3_fwd_wino(const float* in, const float* u_packed, floa
                                     int cin, int cout, int pool, void* stream) {
   UGN_REQUIRE(in && u_packed && out && n > 0, "ugn_conv3x3_fwd_wino: null pointer or n <= 0");
   UGN_REQUIRE(!pool || out_idx, "ugn_conv3x3_fwd_wino: pool needs out_idx");
-  hipStream_t st = (hipStream_t)stream;
-#define WF(KC_, NC_, HW_, P_)                                                                                     \
-  if (cin == KC_ && cout == NC_ && hw == HW_ && (pool != 0) == (P_ != 0))                                          \
-    return launch_wino<KC_, NC_, HW_, 0, P_ ? EPI_LRELU_POOL : EPI_LRELU, 0>(in, nullptr, u_packed, out, out_idx, nullptr, \
-                                                                             nullptr, nullptr, n, st);
-  WF(32, 32, 64, 1) WF(32, 64, 32, 0) WF(64, 64, 32, 1) WF(64, 128, 16, 0) WF(128, 128, 16, 0)
-#undef WF
-  UGN_REQUIRE(false, "ugn_conv3x3_fwd_wino: unsupported shape cin=%d cout=%d hw=%d pool=%d", cin, cout, hw, pool);
+  const WinoJob job = {in, nullptr, u_packed, out, out_idx, nullptr, nullptr, nullptr};
+  return dispatch_fwd(&job, &n, 1, hw, cin, cout, pool, (hipStream_t)stream);
+}
+
+extern "C" int ugn_conv3x3_fwd_wino_pair(const float* const* in, const float* const* u_packed, float* const* out,
+                                         uint8_t* const* out_idx, const int* n, int hw, int cin, int cout, int pool,
+                                         void* stream) {
+  UGN_REQUIRE(in && u_packed && out && n, "ugn_conv3x3_fwd_wino_pair: null array");
+  WinoJob jobs[2];
+  for (int j = 0; j < 2; ++j) {
+    UGN_REQUIRE(in[j] && u_packed[j] && out[j] && n[j] > 0, "ugn_conv3x3_fwd_wino_pair: null pointer or n <= 0 in job %d", j);
+    UGN_REQUIRE(!pool || (out_idx && out_idx[j]), "ugn_conv3x3_fwd_wino_pair: pool needs out_idx");
+    jobs[j] = {in[j], nullptr, u_packed[j], out[j], pool ? out_idx[j] : nullptr, nullptr, nullptr, nullptr};
+  }
+  return dispatch_fwd(jobs, n, 2, hw, cin, cout, pool, (hipStream_t)stream);
 }
 
 extern "C" int ugn_conv3x3_dgrad_wino(const float* dz, const uint8_t* dz_idx, const float* u_packed, const float* act,
                                       const float* addend, float* out, float* raw_out, int n, int hw, int cin, int cout,
                                       void* stream) {
   UGN_REQUIRE(dz && u_packed && out && n > 0, "ugn_conv3x3_dgrad_wino: null pointer or n <= 0");
-  hipStream_t st = (hipStream_t)stream;
-  const int unpool = dz_idx != nullptr;
-#define WD(CI_, CO_, HW_, U_)                                 \
-  if (cin == CI_ && cout == CO_ && hw == HW_ && unpool == U_) \
-    return launch_wino_dgrad<CO_, CI_, HW_, U_>(dz, dz_idx, u_packed, out, act, addend, raw_out, n, st);
-  WD(32, 32, 64, 1) WD(32, 64, 32, 0) WD(64, 64, 32, 1) WD(64, 128, 16, 0) WD(128, 128, 16, 0)
-#undef WD
-  UGN_REQUIRE(false, "ugn_conv3x3_dgrad_wino: unsupported shape cin=%d cout=%d hw=%d unpool=%d", cin, cout, hw, unpool);
+  const WinoJob job = {dz, dz_idx, u_packed, out, nullptr, act, addend, raw_out};
+  return dispatch_dgrad(&job, &n, 1, hw, cin, cout, dz_idx != nullptr, (hipStream_t)stream);
+}
+
+extern "C" int ugn_conv3x3_dgrad_wino_pair(const float* const* dz, const uint8_t* const* dz_idx, const float* const* u_packed,
+                                           const float* const* act, const float* const* addend, float* const* out,
+                                           float* const* raw_out, const int* n, int hw, int cin, int cout, void* stream) {
+  UGN_REQUIRE(dz && u_packed && out && n, "ugn_conv3x3_dgrad_wino_pair: null array");
+  WinoJob jobs[2];
+  for (int j = 0; j < 2; ++j) {
+    UGN_REQUIRE(dz[j] && u_packed[j] && out[j] && n[j] > 0, "ugn_conv3x3_dgrad_wino_pair: null pointer or n <= 0 in job %d", j);
+    jobs[j] = {dz[j], dz_idx ? dz_idx[j] : nullptr, u_packed[j], out[j], nullptr, act ? act[j] : nullptr,
+               addend ? addend[j] : nullptr, raw_out ? raw_out[j] : nullptr};
+  }
+  UGN_REQUIRE((jobs[0].in_idx != nullptr) == (jobs[1].in_idx != nullptr), "ugn_conv3x3_dgrad_wino_pair: dz_idx for both jobs or none");
+  return dispatch_dgrad(jobs, n, 2, hw, cin, cout, jobs[0].in_idx != nullptr, (hipStream_t)stream);
 }

@@ -49,10 +49,18 @@ struct DzCfg {
   static constexpr int SDZ = PIECES * 256;            // floats per buffer
 };
 
+// One launch serves up to two weight gradients of the same shape (a frame-level layer and its set-level twin of the global
+// branch): the first NCOMBO * j0.groups workgroups belong to job 0, the rest to job 1.
+struct WgJob {
+  const float* in;
+  const float* dz;
+  const uint8_t* dz_idx;
+  float* slab;
+  int nregions, groups;
+};
+
 template <int CI, int CO, int HW, int COC, int DZ_UNPOOL>
-__global__ __launch_bounds__(512, 2) void wgrad_wino_kernel(const float* __restrict__ in, const float* __restrict__ dz,
-                                                            const uint8_t* __restrict__ dz_idx, float* __restrict__ slab,
-                                                            const float* __restrict__ zeros, int nregions, int groups) {
+__global__ __launch_bounds__(512, 2) void wgrad_wino_kernel(const WgJob j0, const WgJob j1, const float* __restrict__ zeros) {
   using D = DzCfg<COC, DZ_UNPOOL>;
   constexpr int COP = COC / 32;                       // 32-channel output pairs per workgroup (1 or 2)
   constexpr int KSPLIT = 8 / (2 * COP);               // waves sharing one output block (4 or 2)
@@ -70,7 +78,14 @@ __global__ __launch_bounds__(512, 2) void wgrad_wino_kernel(const float* __restr
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lj = lane & 15, kq = lane >> 4;
   const int cop = wave % COP, cib = (wave / COP) & 1, ks = wave / (2 * COP);
-  const int combo = blockIdx.x / groups, grp = blockIdx.x % groups;
+  const bool jb = (int)blockIdx.x >= (CI / 32) * (CO / COC) * j0.groups;
+  const int bx = jb ? (int)blockIdx.x - (CI / 32) * (CO / COC) * j0.groups : (int)blockIdx.x;
+  const float* __restrict__ in = jb ? j1.in : j0.in;
+  const float* __restrict__ dz = jb ? j1.dz : j0.dz;
+  const uint8_t* __restrict__ dz_idx = jb ? j1.dz_idx : j0.dz_idx;
+  float* __restrict__ slab = jb ? j1.slab : j0.slab;
+  const int nregions = jb ? j1.nregions : j0.nregions, groups = jb ? j1.groups : j0.groups;
+  const int combo = bx / groups, grp = bx % groups;
   const int cic = combo / NCO, coc = combo % NCO;
 
   // per-lane geometry of this wave's DMA pieces (region independent)
@@ -320,9 +335,34 @@ inline const float* zero_block_w() {
 
 constexpr int kWgs = 256;
 
+// Share of the 256 / NCOMBO workgroup groups per job: proportional to the regions, at least one each.
+inline void split_groups(int ncombo, const long* nregions, int njobs, int* groups) {
+  const int total = kWgs / ncombo;
+  if (njobs == 1) {
+    groups[0] = (long)total > nregions[0] ? (int)nregions[0] : total;
+    return;
+  }
+  const long all = nregions[0] + nregions[1];
+  int g1 = (int)((nregions[1] * total + all - 1) / all);   // ceil: the small job must not become the tail
+  if (g1 < 1) g1 = 1;
+  if (g1 > total - 1) g1 = total - 1;
+  if ((long)g1 > nregions[1]) g1 = (int)nregions[1];
+  int g0 = total - g1;
+  if ((long)g0 > nregions[0]) g0 = (int)nregions[0];
+  groups[0] = g0;
+  groups[1] = g1;
+}
+
+struct WgHostJob {
+  const float* in;
+  const float* dz;
+  const uint8_t* dz_idx;
+  float* dw;
+  int n;
+};
+
 template <int CI, int CO, int HW, int COC, int DZ_UNPOOL>
-int launch_wgrad_wino(const float* in, const float* dz, const uint8_t* dz_idx, float* dw, int n, float* ws, size_t ws_floats,
-                      hipStream_t st) {
+int launch_wgrad_wino(const WgHostJob* hj, int njobs, float* ws, size_t ws_floats, hipStream_t st) {
   using D = DzCfg<COC, DZ_UNPOOL>;
   constexpr int LDS = (2 * SIN + 2 * D::SDZ) * 4 > 8 * 16384 ? (2 * SIN + 2 * D::SDZ) * 4 : 8 * 16384;
   auto kern = wgrad_wino_kernel<CI, CO, HW, COC, DZ_UNPOOL>;
@@ -335,19 +375,30 @@ int launch_wgrad_wino(const float* in, const float* dz, const uint8_t* dz_idx, f
   const float* zeros = zero_block_w();
   if (!zeros) { ugn_set_error("wgrad wino: cannot allocate the zero block"); return UGN_EINVAL; }
   constexpr int NCOMBO = (CI / 32) * (CO / COC);
-  const int nregions = n * (HW / RH) * (HW / RW);
-  int groups = kWgs / NCOMBO;
-  if (groups > nregions) groups = nregions;
-  const size_t need = (size_t)NCOMBO * groups * 9 * 32 * COC;
+  long nreg[2] = {0, 0};
+  for (int j = 0; j < njobs; ++j) nreg[j] = (long)hj[j].n * (HW / RH) * (HW / RW);
+  int groups[2] = {0, 0};
+  split_groups(NCOMBO, nreg, njobs, groups);
+  const size_t slab_floats = (size_t)9 * 32 * COC;
+  const size_t need = (size_t)NCOMBO * (groups[0] + groups[1]) * slab_floats;
   if (ws_floats < need) {
     ugn_set_error("wgrad wino: workspace too small (%zu < %zu floats)", ws_floats, need);
     return UGN_EINVAL;
   }
-  hipLaunchKernelGGL(kern, dim3(NCOMBO * groups), dim3(512), LDS, st, in, dz, dz_idx, ws, zeros, nregions, groups);
+  WgJob dj[2];
+  float* slab = ws;
+  for (int j = 0; j < njobs; ++j) {
+    dj[j] = {hj[j].in, hj[j].dz, hj[j].dz_idx, slab, (int)nreg[j], groups[j]};
+    slab += (size_t)NCOMBO * groups[j] * slab_floats;
+  }
+  if (njobs == 1) dj[1] = dj[0];
+  hipLaunchKernelGGL(kern, dim3(NCOMBO * (groups[0] + groups[1])), dim3(512), LDS, st, dj[0], dj[1], zeros);
   UGN_CHECK_LAUNCH("wgrad wino");
-  hipLaunchKernelGGL(wino_wgrad_finish<COC>, dim3(9 * 32 * COC / 4 / 16, NCOMBO), dim3(256), 0, st, (const float4*)ws, dw,
-                     CI, CO, groups);
-  UGN_CHECK_LAUNCH("wgrad wino finish");
+  for (int j = 0; j < njobs; ++j) {
+    hipLaunchKernelGGL(wino_wgrad_finish<COC>, dim3(9 * 32 * COC / 4 / 16, NCOMBO), dim3(256), 0, st, (const float4*)dj[j].slab,
+                       hj[j].dw, CI, CO, groups[j]);
+    UGN_CHECK_LAUNCH("wgrad wino finish");
+  }
   return 0;
 }
 
@@ -360,31 +411,46 @@ bool wg_cfg(int hw, int cin, int cout, int* coc) {
   return false;
 }
 
-}  // namespace
-
-extern "C" size_t ugn_conv3x3_wgrad_wino_ws(int n, int hw, int cin, int cout) {
-  int coc;
-  if (!wg_cfg(hw, cin, cout, &coc) || n <= 0) return 0;
-  const int ncombo = (cin / 32) * (cout / coc);
-  const long nregions = (long)n * (hw / RH) * (hw / RW);
-  long groups = kWgs / ncombo;
-  if (groups > nregions) groups = nregions;
-  return (size_t)ncombo * groups * 9 * 32 * coc * sizeof(float);
-}
-
-extern "C" int ugn_conv3x3_wgrad_wino(const float* in, const float* dz, const uint8_t* dz_idx, float* dw, int n, int hw,
-                                      int cin, int cout, void* ws, size_t ws_bytes, void* stream) {
-  UGN_REQUIRE(in && dz && dw && ws && n > 0, "ugn_conv3x3_wgrad_wino: null pointer or n <= 0");
-  hipStream_t st = (hipStream_t)stream;
-  const int unpool = dz_idx != nullptr;
+int dispatch_wgrad(const WgHostJob* hj, int njobs, int hw, int cin, int cout, void* ws, size_t ws_bytes, hipStream_t st) {
+  const int unpool = hj[0].dz_idx != nullptr;
 #define WGW(CI_, CO_, HW_, COC_, U_)                          \
   if (cin == CI_ && cout == CO_ && hw == HW_ && unpool == U_) \
-    return launch_wgrad_wino<CI_, CO_, HW_, COC_, U_>(in, dz, dz_idx, dw, n, (float*)ws, ws_bytes / sizeof(float), st);
+    return launch_wgrad_wino<CI_, CO_, HW_, COC_, U_>(hj, njobs, (float*)ws, ws_bytes / sizeof(float), st);
   WGW(32, 32, 64, 32, 1)    // a2
   WGW(32, 64, 32, 64, 0)    // a3, b1
   WGW(64, 64, 32, 64, 1)    // a4, b2
   WGW(64, 128, 16, 64, 0)   // a5, b3
   WGW(128, 128, 16, 64, 0)  // a6, b4
 #undef WGW
-  UGN_REQUIRE(false, "ugn_conv3x3_wgrad_wino: unsupported shape cin=%d cout=%d hw=%d unpool=%d", cin, cout, hw, unpool);
+  ugn_set_error("ugn_conv3x3_wgrad_wino: unsupported shape cin=%d cout=%d hw=%d unpool=%d", cin, cout, hw, unpool);
+  return UGN_EINVAL;
+}
+
+}  // namespace
+
+extern "C" size_t ugn_conv3x3_wgrad_wino_ws(int n, int hw, int cin, int cout) {
+  // upper bound for one job of n images, and for a pair whose image counts sum to n
+  int coc;
+  if (!wg_cfg(hw, cin, cout, &coc) || n <= 0) return 0;
+  return (size_t)kWgs * 9 * 32 * coc * sizeof(float);
+}
+
+extern "C" int ugn_conv3x3_wgrad_wino(const float* in, const float* dz, const uint8_t* dz_idx, float* dw, int n, int hw,
+                                      int cin, int cout, void* ws, size_t ws_bytes, void* stream) {
+  UGN_REQUIRE(in && dz && dw && ws && n > 0, "ugn_conv3x3_wgrad_wino: null pointer or n <= 0");
+  const WgHostJob job = {in, dz, dz_idx, dw, n};
+  return dispatch_wgrad(&job, 1, hw, cin, cout, ws, ws_bytes, (hipStream_t)stream);
+}
+
+extern "C" int ugn_conv3x3_wgrad_wino_pair(const float* const* in, const float* const* dz, const uint8_t* const* dz_idx,
+                                           float* const* dw, const int* n, int hw, int cin, int cout, void* ws,
+                                           size_t ws_bytes, void* stream) {
+  UGN_REQUIRE(in && dz && dw && n && ws, "ugn_conv3x3_wgrad_wino_pair: null array");
+  WgHostJob jobs[2];
+  for (int j = 0; j < 2; ++j) {
+    UGN_REQUIRE(in[j] && dz[j] && dw[j] && n[j] > 0, "ugn_conv3x3_wgrad_wino_pair: null pointer or n <= 0 in job %d", j);
+    jobs[j] = {in[j], dz[j], dz_idx ? dz_idx[j] : nullptr, dw[j], n[j]};
+  }
+  UGN_REQUIRE((jobs[0].dz_idx != nullptr) == (jobs[1].dz_idx != nullptr), "ugn_conv3x3_wgrad_wino_pair: dz_idx for both jobs or none");
+  return dispatch_wgrad(jobs, 2, hw, cin, cout, ws, ws_bytes, (hipStream_t)stream);
 }

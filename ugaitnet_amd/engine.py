@@ -37,6 +37,7 @@ NBINS, FEAT, HIDDEN = 62, 128, 256
 USE_WINOGRAD = os.environ.get("UGN_WINO", "1") != "0"
 WINO_DGRAD = ("a2", "a3", "a4", "a5", "a6", "b1", "b2", "b3", "b4")
 _wgrad3x3 = ops.conv3x3_wgrad_wino if USE_WINOGRAD else ops.conv3x3_wgrad
+PAIR_LAUNCHES = os.environ.get("UGN_PAIR", "1") != "0"   # frame-level layer + set-level twin in one launch
 
 
 def glorot_uniform(gen, shape):
@@ -133,6 +134,30 @@ class Encoder:
             return ops.conv3x3_dgrad_wino(dz, self.ud[name], hw, w.shape[2], w.shape[3], **kw)
         return ops.conv3x3_dgrad(dz, self.W(name), hw, **kw)
 
+    # The global branch applies each 3x3 shape of the frame stack once more, to B set-level maps instead of B*L frames.
+    # Alone such a launch fills a fraction of the CUs, so the Winograd kernels take the frame-level layer and its set-level
+    # twin (a3|b1, a4|b2, a5|b3, a6|b4) as two jobs of ONE launch wherever the data dependencies allow it.
+    def conv_pair(self, names, xs, pool, outs, idxs=None):
+        if USE_WINOGRAD and PAIR_LAUNCHES:
+            return ops.conv3x3_fwd_wino_pair(list(xs), [self.uf[n] for n in names], self.W(names[0]).shape[3], pool, list(outs),
+                                             list(idxs) if pool else None)
+        res = [self.conv(n, x, pool, o, i) for n, x, o, i in zip(names, xs, outs, idxs or (None, None))]
+        return ([r[0] for r in res], [r[1] for r in res]) if pool else res
+
+    def dgrad_pair(self, names, dzs, hw, outs, dz_idxs=None, acts=None):
+        if USE_WINOGRAD and PAIR_LAUNCHES:
+            w = self.W(names[0])
+            return ops.conv3x3_dgrad_wino_pair(list(dzs), [self.ud[n] for n in names], hw, w.shape[2], w.shape[3], list(outs),
+                                               dz_idxs=dz_idxs, acts=acts)
+        return [self.dgrad(n, dz, hw, dz_idx=None if dz_idxs is None else dz_idxs[k], act=None if acts is None else acts[k],
+                           out=outs[k]) for k, (n, dz) in enumerate(zip(names, dzs))]
+
+    def wgrad_pair(self, names, xs, dzs, cout, dz_idxs=None):
+        if USE_WINOGRAD and PAIR_LAUNCHES:
+            return ops.conv3x3_wgrad_wino_pair(list(xs), list(dzs), cout, [self.G(n) for n in names], dz_idxs=dz_idxs)
+        return [_wgrad3x3(x, dz, cout, dz_idx=None if dz_idxs is None else dz_idxs[k], dw=self.G(n))
+                for k, (n, x, dz) in enumerate(zip(names, xs, dzs))]
+
     def _buf(self, pool, key, shape, dtype=F32):
         t = pool.get(key)
         if t is None or tuple(t.shape) != tuple(shape) or t.dtype != dtype:
@@ -156,18 +181,17 @@ class Encoder:
         p2, i2 = self.conv("a2", a1, True, self._buf(A, "p2", (n, 32, 32, 32)),
                                  self._buf(A, "i2", (n, 32, 32, 32), U8))
         m1 = ops.setmax_fwd(p2, b, l, m=self._buf(A, "m1", (b, 32, 32, 32)))
-        b1 = self.conv("b1", m1, False, self._buf(A, "b1", (b, 32, 32, 64)))
-        q2, j2 = self.conv("b2", b1, True, self._buf(A, "q2", (b, 16, 16, 64)),
-                                 self._buf(A, "j2", (b, 16, 16, 64), U8))
-        a3 = self.conv("a3", p2, False, self._buf(A, "a3", (n, 32, 32, 64)))
-        p4, i4 = self.conv("a4", a3, True, self._buf(A, "p4", (n, 16, 16, 64)),
-                                 self._buf(A, "i4", (n, 16, 16, 64), U8))
+        a3, b1 = self.conv_pair(("a3", "b1"), (p2, m1), False,
+                                (self._buf(A, "a3", (n, 32, 32, 64)), self._buf(A, "b1", (b, 32, 32, 64))))
+        (p4, q2), (i4, j2) = self.conv_pair(("a4", "b2"), (a3, b1), True,
+                                            (self._buf(A, "p4", (n, 16, 16, 64)), self._buf(A, "q2", (b, 16, 16, 64))),
+                                            (self._buf(A, "i4", (n, 16, 16, 64), U8), self._buf(A, "j2", (b, 16, 16, 64), U8)))
         _, s2 = ops.setmax_fwd(p4, b, l, addend=q2, m=self._buf(A, "m2", (b, 16, 16, 64)),
                                sum_out=self._buf(A, "s2", (b, 16, 16, 64)))
-        b3 = self.conv("b3", s2, False, self._buf(A, "b3", (b, 16, 16, 128)))
-        b4 = self.conv("b4", b3, False, self._buf(A, "b4", (b, 16, 16, 128)))
-        a5 = self.conv("a5", p4, False, self._buf(A, "a5", (n, 16, 16, 128)))
-        a6 = self.conv("a6", a5, False, self._buf(A, "a6", (n, 16, 16, 128)))
+        a5, b3 = self.conv_pair(("a5", "b3"), (p4, s2), False,
+                                (self._buf(A, "a5", (n, 16, 16, 128)), self._buf(A, "b3", (b, 16, 16, 128))))
+        a6, b4 = self.conv_pair(("a6", "b4"), (a5, b3), False,
+                                (self._buf(A, "a6", (n, 16, 16, 128)), self._buf(A, "b4", (b, 16, 16, 128))))
         m3, s3 = ops.setmax_fwd(a6, b, l, addend=b4, m=self._buf(A, "m3", (b, 16, 16, 128)),
                                 sum_out=self._buf(A, "s3", (b, 16, 16, 128)))
         feat = ops.hpp_fwd(m3, s3, self._buf(A, "feat", (NBINS, b, FEAT)))
@@ -184,28 +208,24 @@ class Encoder:
         ops.binfc_bwd(A["feat"], self.W("fc"), dout, self.G("fc"), buf("dfeat", (NBINS, b, FEAT)))
         dm3, dzb4 = ops.hpp_bwd(A["m3"], A["s3"], A["b4"], S["dfeat"], buf("dm3", (b, 16, 16, 128)),
                                 buf("dzb4", (b, 16, 16, 128)))
-        # global branch, block 2 (b3, b4)
-        _wgrad3x3(A["b3"], dzb4, 128, dw=self.G("b4"))
-        dzb3 = self.dgrad("b4", dzb4, 16, act=A["b3"], out=buf("dzb3", (b, 16, 16, 128)))
-        _wgrad3x3(A["s2"], dzb3, 128, dw=self.G("b3"))
+        # block 3 of the frame stack (a5, a6) with block 2 of the global branch (b3, b4)
+        dz6 = ops.setmax_bwd(A["a6"], dm3, b, l, True, buf("dz6", (n, 16, 16, 128)))
+        self.wgrad_pair(("a6", "b4"), (A["a5"], A["b3"]), (dz6, dzb4), 128)
+        dz5, dzb3 = self.dgrad_pair(("a6", "b4"), (dz6, dzb4), 16,
+                                    (buf("dz5", (n, 16, 16, 128)), buf("dzb3", (b, 16, 16, 128))), acts=(A["a5"], A["b3"]))
+        self.wgrad_pair(("a5", "b3"), (A["p4"], A["s2"]), (dz5, dzb3), 128)
         ds2 = buf("ds2", (b, 16, 16, 64))
         dq2 = self.dgrad("b3", dzb3, 16, act=A["q2"], out=buf("dq2", (b, 16, 16, 64)), raw_out=ds2)
-        # global branch, block 1 (b1, b2); b2 is pooled: dq2 is its gradient at pooled resolution, routed through j2
-        _wgrad3x3(A["b1"], dq2, 64, dz_idx=A["j2"], dw=self.G("b2"))
-        dzb1 = self.dgrad("b2", dq2, 32, dz_idx=A["j2"], act=A["b1"], out=buf("dzb1", (b, 32, 32, 64)))
-        _wgrad3x3(A["m1"], dzb1, 64, dw=self.G("b1"))
-        dm1 = self.dgrad("b1", dzb1, 32, out=buf("dm1", (b, 32, 32, 32)))
-        # frame stack, block 3 (a5, a6)
-        dz6 = ops.setmax_bwd(A["a6"], dm3, b, l, True, buf("dz6", (n, 16, 16, 128)))
-        _wgrad3x3(A["a5"], dz6, 128, dw=self.G("a6"))
-        dz5 = self.dgrad("a6", dz6, 16, act=A["a5"], out=buf("dz5", (n, 16, 16, 128)))
-        _wgrad3x3(A["p4"], dz5, 128, dw=self.G("a5"))
         g4 = ops.setmax_bwd(A["p4"], ds2, b, l, False, buf("g4", (n, 16, 16, 64)))
         dp4 = self.dgrad("a5", dz5, 16, act=A["p4"], addend=g4, out=g4)  # in place over the addend
-        # block 2 (a3, a4)
-        _wgrad3x3(A["a3"], dp4, 64, dz_idx=A["i4"], dw=self.G("a4"))
-        dz3 = self.dgrad("a4", dp4, 32, dz_idx=A["i4"], act=A["a3"], out=buf("dz3", (n, 32, 32, 64)))
-        _wgrad3x3(A["p2"], dz3, 64, dw=self.G("a3"))
+        # block 2 (a3, a4) with block 1 of the global branch (b1, b2); a4 / b2 are pooled: dp4 / dq2 are their gradients at
+        # pooled resolution, routed through the argmax maps i4 / j2
+        self.wgrad_pair(("a4", "b2"), (A["a3"], A["b1"]), (dp4, dq2), 64, dz_idxs=(A["i4"], A["j2"]))
+        dz3, dzb1 = self.dgrad_pair(("a4", "b2"), (dp4, dq2), 32,
+                                    (buf("dz3", (n, 32, 32, 64)), buf("dzb1", (b, 32, 32, 64))),
+                                    dz_idxs=(A["i4"], A["j2"]), acts=(A["a3"], A["b1"]))
+        self.wgrad_pair(("a3", "b1"), (A["p2"], A["m1"]), (dz3, dzb1), 64)
+        dm1 = self.dgrad("b1", dzb1, 32, out=buf("dm1", (b, 32, 32, 32)))
         g2 = ops.setmax_bwd(A["p2"], dm1, b, l, False, buf("g2", (n, 32, 32, 32)))
         dp2 = self.dgrad("a3", dz3, 32, act=A["p2"], addend=g2, out=g2)
         # block 1 (a1, a2)

@@ -184,6 +184,48 @@ def conv3x3_wgrad(x, dz, cout, dz_idx=None, dw=None):
     return dw
 
 
+def _opt_ptr_array(pair):
+    return None if pair is None or pair[0] is None else ptr_array(pair)
+
+
+def conv3x3_fwd_wino_pair(xs, upks, cout, pool, outs, idxs=None):
+    """Two forward convolutions of one shape (different inputs / filters / image counts) in a single launch."""
+    for t in xs + upks + outs:
+        _chk(t)
+    hw, cin = xs[0].shape[1], xs[0].shape[3]
+    assert xs[1].shape[1:] == xs[0].shape[1:] and (not pool or idxs is not None)
+    ns = (C.c_int * 2)(xs[0].shape[0], xs[1].shape[0])
+    call("ugn_conv3x3_fwd_wino_pair", ptr_array(xs), ptr_array(upks), ptr_array(outs), _opt_ptr_array(idxs if pool else None), ns,
+         hw, cin, cout, int(bool(pool)), _stream())
+    return (outs, idxs) if pool else outs
+
+
+def conv3x3_dgrad_wino_pair(dzs, upks, hw, cin, cout, outs, dz_idxs=None, acts=None, addends=None, raw_outs=None):
+    """Two data gradients of one shape in a single launch; the optional operands are given for both jobs or neither."""
+    for t in dzs + upks + outs:
+        _chk(t)
+    ns = (C.c_int * 2)(dzs[0].shape[0], dzs[1].shape[0])
+    call("ugn_conv3x3_dgrad_wino_pair", ptr_array(dzs), _opt_ptr_array(dz_idxs), ptr_array(upks), _opt_ptr_array(acts),
+         _opt_ptr_array(addends), ptr_array(outs), _opt_ptr_array(raw_outs), ns, hw, cin, cout, _stream())
+    return outs
+
+
+def conv3x3_wgrad_wino_pair(xs, dzs, cout, dws, dz_idxs=None):
+    """Two weight gradients of one shape in a single launch."""
+    for t in xs + dzs + dws:
+        _chk(t)
+    hw, cin = xs[0].shape[1], xs[0].shape[3]
+    ns = (C.c_int * 2)(xs[0].shape[0], xs[1].shape[0])
+    nbytes = _lib.load().ugn_conv3x3_wgrad_wino_ws(ns[0] + ns[1], hw, cin, cout)
+    if nbytes == 0:
+        raise ValueError("conv3x3_wgrad_wino_pair: unsupported shape hw=%d cin=%d cout=%d" % (hw, cin, cout))
+    ws = _WS.get(nbytes, xs[0].device)
+    with _Timed("conv3x3_wgrad[a4: 64->64 @32x32, pooled dz]", hw == 32 and cin == 64 and cout == 64 and ns[0] >= 100):
+        call("ugn_conv3x3_wgrad_wino_pair", ptr_array(xs), ptr_array(dzs), _opt_ptr_array(dz_idxs), ptr_array(dws), ns, hw, cin,
+             cout, ptr(ws), ws.numel(), _stream())
+    return dws
+
+
 def conv3x3_wgrad_wino(x, dz, cout, dz_idx=None, dw=None):
     """Winograd F(2x2,3x3) weight gradient; same contract as conv3x3_wgrad."""
     _chk(x), _chk(dz)
