@@ -66,6 +66,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dense-only", action="store_true", help="skip the secondary mask-skipping run (profiling target)")
     ap.add_argument("--skip-masked", action="store_true",
                     help="run each encoder only on the clips whose modality flag is 1 (exactly the same results; the default "
                          "line computes the masked pairs too)")
@@ -120,7 +121,7 @@ def main():
     # secondary figure, same workload: encoders run only on the clips whose modality flag is 1 (the gate multiplies the
     # rest by 0, so every result is unchanged; tests/test_fullsize_gpu.py).  Never reported as `value`.
     skip_rate = None
-    if not args.skip_masked:
+    if not args.skip_masked and not args.dense_only:
         del core
         torch.cuda.empty_cache()
         core2 = GaitCore([2, 1, 1], nclasses=NCLS, fuse_mode="sign_max", margin=0.2, loss_weights=(1.0, 0.1), device=dev,

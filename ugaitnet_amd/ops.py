@@ -195,8 +195,9 @@ def conv3x3_fwd_wino_pair(xs, upks, cout, pool, outs, idxs=None):
     hw, cin = xs[0].shape[1], xs[0].shape[3]
     assert xs[1].shape[1:] == xs[0].shape[1:] and (not pool or idxs is not None)
     ns = (C.c_int * 2)(xs[0].shape[0], xs[1].shape[0])
-    call("ugn_conv3x3_fwd_wino_pair", ptr_array(xs), ptr_array(upks), ptr_array(outs), _opt_ptr_array(idxs if pool else None), ns,
-         hw, cin, cout, int(bool(pool)), _stream())
+    with _Timed("conv3x3_fwd[a6: 128->128 @16x16 +LeakyReLU]", hw == 16 and cin == 128 and cout == 128 and ns[0] >= 100):
+        call("ugn_conv3x3_fwd_wino_pair", ptr_array(xs), ptr_array(upks), ptr_array(outs), _opt_ptr_array(idxs if pool else None),
+             ns, hw, cin, cout, int(bool(pool)), _stream())
     return (outs, idxs) if pool else outs
 
 
