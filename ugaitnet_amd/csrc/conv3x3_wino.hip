@@ -69,7 +69,7 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
 // dgrad: g[dy][dx] = w[2-dy][2-dx][n = cin][k = cout]        (kc = cout, nc = cin)
 // The WIDE variant pays off when there are at least two 32-channel chunks to stream and the input is a plain tile
 // (measured: a4/a5/a6 fwd and a5/a6 dgrad 12-17 % faster; a3 fwd and the pooled a4 dgrad slower).
-__host__ __device__ constexpr bool wino_wide(int kc, int nc, int unpool) { return nc >= 64 && kc >= 64 && !unpool; }
+__host__ __device__ constexpr bool wino_wide(int kc, int nc, int unpool) { return nc >= 64 && kc >= 64; }
 
 __device__ __forceinline__ void wino_pack_one(const float* __restrict__ w, float* __restrict__ u, int cin, int cout, int mode,
                                               int e) {
@@ -206,6 +206,28 @@ __device__ __forceinline__ void read_pair(float2 (&dn)[16], const float* base, c
       dn[e].y = (iw[q] >> 8) == pos ? pv[q].y : 0.f;
     }
   }
+}
+
+// Pooled input, one pooled ROW of the 3x3 pixels under the patch at a time (prow 0 -> patch row 0, 1 -> rows 1 and 2,
+// 2 -> row 3): 6 registers of raw data live instead of 27, which is what lets the wide variant fit 256 registers.
+template <int PROW>
+__device__ __forceinline__ void read_pair_pooled_row(float2 (&dn)[16], const float* base, const uint8_t* ibytes) {
+  float2 pv[3];
+  unsigned iw[3];
+#pragma unroll
+  for (int qc = 0; qc < 3; ++qc) {
+    pv[qc] = *reinterpret_cast<const float2*>(base + (PROW * UPW + qc) * UCS);
+    iw[qc] = *reinterpret_cast<const uint16_t*>(ibytes + (PROW * UPW + qc) * UCS * 4);
+  }
+#pragma unroll
+  for (int r = (PROW == 0 ? 0 : (PROW == 1 ? 1 : 3)); r <= (PROW == 0 ? 0 : (PROW == 1 ? 2 : 3)); ++r)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int qc = (c + 1) >> 1;
+      const unsigned pos = (((r + 1) & 1) << 1) | ((c + 1) & 1);
+      dn[r * 4 + c].x = (iw[qc] & 0xffu) == pos ? pv[qc].x : 0.f;
+      dn[r * 4 + c].y = (iw[qc] >> 8) == pos ? pv[qc].y : 0.f;
+    }
 }
 
 // 32 KB filter slice: linear in both spaces, 4 pieces of 1 KB per wave (8 waves)
@@ -396,7 +418,19 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const WinoJob j0, const Wi
 #pragma unroll
           for (int half = 0; half < 2; ++half) {
           const int pt = 2 * pp + half;
-          if (tnext && (pt == 0 || (NH == 2 && pt == 3))) read_pair<IN_UNPOOL>(dn, sNx, sNi, pt == 0 ? 0 : 1);   // channels 2kq.. / 8+2kq..
+          constexpr bool ROWWISE = IN_UNPOOL != 0;   // pooled tile: the patch arrives one pooled row per point
+          if constexpr (ROWWISE) {
+            if (pt == 0) read_pair_pooled_row<0>(dn, sNx, sNi);
+            if (pt == 1) read_pair_pooled_row<1>(dn, sNx, sNi);
+            if (pt == 2) read_pair_pooled_row<2>(dn, sNx, sNi);
+            if constexpr (NH == 2) {   // second channel pair (+8 channels = +8 floats / +8 argmax bytes)
+              if (pt == 5) read_pair_pooled_row<0>(dn, sNx + 8, sNi + 8);
+              if (pt == 6) read_pair_pooled_row<1>(dn, sNx + 8, sNi + 8);
+              if (pt == 7) read_pair_pooled_row<2>(dn, sNx + 8, sNi + 8);
+            }
+          } else {
+            if (tnext && (pt == 0 || (NH == 2 && pt == 3))) read_pair<IN_UNPOOL>(dn, sNx, sNi, pt == 0 ? 0 : 1);   // channels 2kq.. / 8+2kq..
+          }
           // halo of the next stage: all pieces of this wave during the FIRST group of the chunk, so that they are
           // a full group old at the next barrier and the next chunk's first transform can be pipelined as well
           if constexpr (IN_UNPOOL) {
@@ -409,12 +443,13 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const WinoJob j0, const Wi
                                      sin_bytes + (unsigned)(ibuf ^ 1) * SIN * 4u);
           }
           if (tnext) {
-            if (pt == 1) { rowpass(tn0, 0); rowpass(tn0, 1); }
-            if (pt == 2) { rowpass(tn0, 2); rowpass(tn0, 3); }   // pair 0 done before pair 1 is loaded at point 3
-            if (NH == 2 && pt == 4) { rowpass(tn1, 0); rowpass(tn1, 1); }
-            if (NH == 2 && pt == 5) { rowpass(tn1, 2); rowpass(tn1, 3); }
-            if (pt == 6) colpass(0);
-            if (pt == 8) colpass(1);
+            if (pt == (ROWWISE ? 3 : 1)) { rowpass(tn0, 0); rowpass(tn0, 1); }
+            if (pt == (ROWWISE ? 4 : 2)) { rowpass(tn0, 2); rowpass(tn0, 3); }   // pair 0 done before pair 1 is loaded at point 3
+            if (NH == 2 && pt == (ROWWISE ? 8 : 4)) { rowpass(tn1, 0); rowpass(tn1, 1); }
+            if (NH == 2 && pt == (ROWWISE ? 9 : 5)) { rowpass(tn1, 2); rowpass(tn1, 3); }
+            constexpr bool LATE = ROWWISE && NH == 2;   // both row passes end at point 9
+            if (pt == (LATE ? 10 : 6)) colpass(0);
+            if (pt == (LATE ? 11 : 8)) colpass(1);
             if (pt == 12) colpass(2);
             if (pt == 15) colpass(3);
           }
