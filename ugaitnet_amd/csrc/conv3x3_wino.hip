@@ -18,7 +18,9 @@
 //   * The output transform A^T M A is lane-local (a lane holds all 16 points of its 4 tiles x 2 channels), and a 2x2
 //     Winograd tile IS a pooling window, so LeakyReLU + MaxPool + argmax need no cross-lane traffic either.
 #include <stdlib.h>
-#include "common.h"
+#include "wino_common.h"
+
+using namespace ugn_wino;
 
 namespace {
 
@@ -39,27 +41,6 @@ constexpr int UPW = 12, UCS = 44, UPIX = 10 * UPW, USLOTS = UPIX * 11, UPIECES =
 // then the odd ones, so the 8 tile columns fall into 8 different bank quads (pixel stride 36 floats; pooled tile: 44);
 // (2) a wave's two tile rows are chosen 32 banks apart (see trow0 in the kernel); (3) lane kq owns channels
 // {2kq, 2kq+1, 8+2kq, 9+2kq} of a 16-channel group, so the two slots of a pass are the two halves of one quad.
-__device__ __forceinline__ constexpr int colpos(int col) { return (col & 1) ? 9 + (col >> 1) : (col >> 1); }
-
-enum { EPI_LRELU = 0, EPI_LRELU_POOL = 1, EPI_DGRAD = 2 };
-
-// One launch serves up to two convolutions of the same shape (the frame-level layer and its set-level twin of the global
-// branch, which alone would leave most CUs idle): items [0, nitems0) belong to job 0, [nitems0, nitems) to job 1.
-struct WinoJob {
-  const float* in;
-  const uint8_t* in_idx;
-  const float* upk;
-  float* out;
-  uint8_t* out_idx;
-  const float* act;
-  const float* addend;
-  float* raw_out;
-};
-
-__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
-  // lane l: A[i = l&15][k = l>>4], B[k = l>>4][j = l&15]; D reg r of lane l = D[i = 4*(l>>4) + r][j = l&15]
-  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
-}
 
 // U[pt][n][k] = (G g G^T)[pt] for filter g(k -> n).  Layout [nsp][chunk][G][pt][kq][32 n][4 s] with k = 32*chunk + 16*G +
 // 8*(s>>1) + 2*kq + (s&1): a 32 KB slice per 16-channel group, and the lane (n, kq) of an MFMA reads its 4 steps with one
@@ -67,13 +48,9 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
 // Layers with >= 64 output channels use the WIDE kernel variant (a wave owns 16 tiles x 32 channels) and its own layout.
 // fwd : g[dy][dx] = w[dy][dx][k = cin][n = cout]            (kc = cin, nc = cout)
 // dgrad: g[dy][dx] = w[2-dy][2-dx][n = cin][k = cout]        (kc = cout, nc = cin)
-// The WIDE variant pays off when there are at least two 32-channel chunks to stream and the input is a plain tile
-// (measured: a4/a5/a6 fwd and a5/a6 dgrad 12-17 % faster; a3 fwd and the pooled a4 dgrad slower).
-__host__ __device__ constexpr bool wino_wide(int kc, int nc, int unpool) { return nc >= 64 && kc >= 64; }
-
 __device__ __forceinline__ void wino_pack_one(const float* __restrict__ w, float* __restrict__ u, int cin, int cout, int mode,
                                               int e) {
-  const int dgrad = mode & 1, unpool = (mode >> 1) & 1;   // mode: 0 fwd, 1 dgrad of a full-resolution dz, 3 dgrad of a pooled dz
+  const int dgrad = mode & 1;   // mode: 0 fwd, 1 dgrad of a full-resolution dz, 3 dgrad of a pooled dz (same layout as 1)
   const int kc = dgrad ? cout : cin, nc = dgrad ? cin : cout;
   if (e >= kc * nc) return;
   const int k = e % kc, n = e / kc;
@@ -90,7 +67,20 @@ __device__ __forceinline__ void wino_pack_one(const float* __restrict__ w, float
   }
   const int nchunk = kc >> 5, chunk = k >> 5, kq = (k >> 1) & 3;
   float* dst;
-  if (wino_wide(kc, nc, unpool)) {
+  if (wino_tall(kc, nc)) {
+    // tall (conv3x3_wino_tall.hip): 8-channel groups gi = k >> 3, [gi][pt][kq][16 lj][cb][s], n = 16*cb + lj
+    dst = u + (size_t)(k >> 3) * 4096 + (kq * 16 + (n & 15)) * 4 + (n >> 4) * 2 + (k & 1);
+    for (int r = 0; r < 4; ++r) {
+      const float u0 = t[r][0], u1 = 0.5f * (t[r][0] + t[r][1] + t[r][2]), u2 = 0.5f * (t[r][0] - t[r][1] + t[r][2]),
+                  u3 = t[r][2];
+      dst[(r * 4 + 0) * 256] = u0;
+      dst[(r * 4 + 1) * 256] = u1;
+      dst[(r * 4 + 2) * 256] = u2;
+      dst[(r * 4 + 3) * 256] = u3;
+    }
+    return;
+  }
+  if (wino_wide(kc, nc)) {
     // wide: a workgroup owns 64 output channels, a wave 2 blocks of 16 (cb); 8-channel groups (k = 32*chunk + 8*G + 2*kq + s):
     // [nsp64][chunk][G 0..3][pt][kq][32 = 16*cp + lj][cb][s]
     const int nsp = n >> 6, nl = ((n >> 5) & 1) * 16 + (n & 15), cb = (n >> 4) & 1, G = (k >> 3) & 3;
@@ -122,17 +112,6 @@ struct WinoPackTable {   // up to 32 (layer, direction) jobs in one launch; job 
 __global__ void wino_pack_multi_kernel(WinoPackTable t) {
   const int j = blockIdx.y;
   wino_pack_one(t.w[j], t.u[j], t.cin[j], t.cout[j], t.dgrad[j], blockIdx.x * blockDim.x + threadIdx.x);
-}
-
-// global -> LDS, 16 B per lane, no VGPR destination (LDS address = M0 + lane * 16).  Inline asm: with the builtin hipcc
-// waits vmcnt(0) before the next ds_read (it cannot tell the DMA target from the buffers being read), which exposes the
-// whole global latency.  Completion is awaited by the caller (s_waitcnt vmcnt) before the barrier that publishes the data.
-__device__ __forceinline__ void dma16(const void* gsrc, unsigned lds_dst_uniform) {
-  unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep)
-               : "v"(gsrc), "s"(lds_dst_uniform)
-               : "memory");
 }
 
 // One 1 KB piece of the halo tile of (image, region origin, chunk): lane l fills 16-byte slot inst*64 + l; slot s =
@@ -242,7 +221,7 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const WinoJob j0, const Wi
                                                       int nitems0, int nitems) {
   // WIDE (NCF >= 64): the workgroup owns 64 output channels, a wave 16 tiles x 2 channel blocks, and a group is 8 input
   // channels (2 k-steps): per MFMA half the transform work, patch reads and halo traffic of the narrow variant.
-  constexpr bool WIDE = wino_wide(KC, NCF, IN_UNPOOL);
+  constexpr bool WIDE = wino_wide(KC, NCF);
   constexpr int NB = WIDE ? 2 : 1;          // 16-channel output blocks per wave
   constexpr int NG = WIDE ? 4 : 2;          // channel groups per 32-channel chunk
   constexpr int GW = 32 / NG;               // input channels per group
@@ -546,19 +525,6 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const WinoJob j0, const Wi
   }
 }
 
-constexpr int kGrid = 256;
-
-// 64 B of zeros in HBM: the LDS-DMA source for halo lanes outside the image.  Allocated once per process, never written.
-inline const float* zero_block() {
-  static float* z = nullptr;
-  if (!z) {
-    float* p = nullptr;
-    if (hipMalloc((void**)&p, 256) != hipSuccess || hipMemset(p, 0, 256) != hipSuccess) return nullptr;
-    z = p;
-  }
-  return z;
-}
-
 template <int KC, int NCF, int HW, int IN_UNPOOL, int EPI, int EFLAGS>
 int launch_wino(const WinoJob* jobs, const int* n, int njobs, hipStream_t st) {
   auto kern = wino_kernel<KC, NCF, HW, IN_UNPOOL, EPI, EFLAGS>;
@@ -570,7 +536,7 @@ int launch_wino(const WinoJob* jobs, const int* n, int njobs, hipStream_t st) {
   }
   const float* zeros = zero_block();
   if (!zeros) { ugn_set_error("wino: cannot allocate the zero block"); return UGN_EINVAL; }
-  constexpr int per_img = (HW / 16) * (HW / 16) * (NCF / (wino_wide(KC, NCF, IN_UNPOOL) ? 64 : 32));
+  constexpr int per_img = (HW / 16) * (HW / 16) * (NCF / (wino_wide(KC, NCF) ? 64 : 32));
   const int nitems0 = n[0] * per_img, nitems = nitems0 + (njobs > 1 ? n[1] * per_img : 0);
   const int grid = nitems < kGrid ? nitems : kGrid;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), LDS_BYTES, st, jobs[0], jobs[njobs > 1 ? 1 : 0], zeros, nitems0, nitems);
@@ -581,13 +547,6 @@ int launch_wino(const WinoJob* jobs, const int* n, int njobs, hipStream_t st) {
 template <int KC, int NCF, int HW, int IN_UNPOOL>
 int launch_wino_dgrad(const WinoJob* jobs, const int* n, int njobs, hipStream_t st) {
   const int flags = (jobs[0].act ? 1 : 0) | (jobs[0].addend ? 2 : 0) | (jobs[0].raw_out ? 4 : 0);
-  if (njobs > 1) {
-    const int f1 = (jobs[1].act ? 1 : 0) | (jobs[1].addend ? 2 : 0) | (jobs[1].raw_out ? 4 : 0);
-    if (f1 != flags) {
-      ugn_set_error("ugn_conv3x3_dgrad_wino_pair: both jobs need the same set of act/addend/raw_out (%d vs %d)", flags, f1);
-      return UGN_EINVAL;
-    }
-  }
 #define UGN_WDG(F_) \
   case F_:          \
     return launch_wino<KC, NCF, HW, IN_UNPOOL, EPI_DGRAD, F_>(jobs, n, njobs, st);
@@ -601,6 +560,7 @@ int launch_wino_dgrad(const WinoJob* jobs, const int* n, int njobs, hipStream_t 
 }
 
 int dispatch_fwd(const WinoJob* jobs, const int* n, int njobs, int hw, int cin, int cout, int pool, hipStream_t st) {
+  if (wino_tall(cin, cout)) return launch_tall(0, jobs, n, njobs, hw, cin, pool != 0, st);   // (the filter layout differs)
 #define WF(KC_, NC_, HW_, P_)                                             \
   if (cin == KC_ && cout == NC_ && hw == HW_ && (pool != 0) == (P_ != 0)) \
     return launch_wino<KC_, NC_, HW_, 0, P_ ? EPI_LRELU_POOL : EPI_LRELU, 0>(jobs, n, njobs, st);
@@ -611,6 +571,15 @@ int dispatch_fwd(const WinoJob* jobs, const int* n, int njobs, int hw, int cin, 
 }
 
 int dispatch_dgrad(const WinoJob* jobs, const int* n, int njobs, int hw, int cin, int cout, int unpool, hipStream_t st) {
+  if (njobs > 1) {   // one kernel instantiation serves both jobs: they must use the same epilogue operands
+    const int f0 = (jobs[0].act ? 1 : 0) | (jobs[0].addend ? 2 : 0) | (jobs[0].raw_out ? 4 : 0);
+    const int f1 = (jobs[1].act ? 1 : 0) | (jobs[1].addend ? 2 : 0) | (jobs[1].raw_out ? 4 : 0);
+    if (f0 != f1) {
+      ugn_set_error("ugn_conv3x3_dgrad_wino_pair: both jobs need the same set of act/addend/raw_out (%d vs %d)", f0, f1);
+      return UGN_EINVAL;
+    }
+  }
+  if (wino_tall(cout, cin)) return launch_tall(1, jobs, n, njobs, hw, cout, unpool, st);
 #define WD(CI_, CO_, HW_, U_)                                 \
   if (cin == CI_ && cout == CO_ && hw == HW_ && unpool == U_) \
     return launch_wino_dgrad<CO_, CI_, HW_, U_>(jobs, n, njobs, st);
@@ -621,6 +590,17 @@ int dispatch_dgrad(const WinoJob* jobs, const int* n, int njobs, int hw, int cin
 }
 
 }  // namespace
+
+// 256 B of zeros in HBM: the LDS-DMA source for halo lanes outside the image.  Allocated once per process, never written.
+const float* ugn_wino::zero_block() {
+  static float* z = nullptr;
+  if (!z) {
+    float* p = nullptr;
+    if (hipMalloc((void**)&p, 256) != hipSuccess || hipMemset(p, 0, 256) != hipSuccess) return nullptr;
+    z = p;
+  }
+  return z;
+}
 
 extern "C" int ugn_wino_pack(const float* w_hwio, float* u_packed, int cin, int cout, int dgrad, void* stream) {
   UGN_REQUIRE(w_hwio && u_packed, "ugn_wino_pack: null pointer");

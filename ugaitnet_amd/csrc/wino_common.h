@@ -1,0 +1,57 @@
+// Pieces shared by the Winograd F(2x2,3x3) forward / data-gradient kernels (conv3x3_wino.hip, conv3x3_wino_tall.hip).
+#pragma once
+#include "common.h"
+
+namespace ugn_wino {
+
+enum { EPI_LRELU = 0, EPI_LRELU_POOL = 1, EPI_DGRAD = 2 };
+
+// One launch serves up to two convolutions of the same shape (the frame-level layer and its set-level twin of the global
+// branch, which alone would leave most CUs idle): items [0, nitems0) belong to job 0, [nitems0, nitems) to job 1.
+struct WinoJob {
+  const float* in;
+  const uint8_t* in_idx;
+  const float* upk;
+  float* out;
+  uint8_t* out_idx;
+  const float* act;
+  const float* addend;
+  float* raw_out;
+};
+
+constexpr int kGrid = 256;   // persistent workgroups (one per CU: the kernels use the whole LDS)
+
+// filter layouts (decided from the GEMM dimensions alone, so that packer and kernels agree):
+//   tall  : 32 output channels            -> conv3x3_wino_tall.hip
+//   wide  : >= 64 output and K channels   -> wino_kernel, wide variant
+//   narrow: everything else               -> wino_kernel, narrow variant
+__host__ __device__ constexpr bool wino_tall(int kc, int nc) { return nc == 32; }
+__host__ __device__ constexpr bool wino_wide(int kc, int nc) { return nc >= 64 && kc >= 64; }
+
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+  // lane l: A[i = l&15][k = l>>4], B[k = l>>4][j = l&15]; D reg r of lane l = D[i = 4*(l>>4) + r][j = l&15]
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// global -> LDS, 16 B per lane, no VGPR destination (LDS address = M0 + lane * 16).  Inline asm: with the builtin hipcc
+// waits vmcnt(0) before the next ds_read (it cannot tell the DMA target from the buffers being read), which exposes the
+// whole global latency.  Completion is awaited by the caller (s_waitcnt vmcnt) before the barrier that publishes the data.
+__device__ __forceinline__ void dma16(const void* gsrc, unsigned lds_dst_uniform) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(gsrc), "s"(lds_dst_uniform)
+               : "memory");
+}
+
+// even pixel columns of a halo row first, then the odd ones (bank layout, see conv3x3_wino.hip)
+__device__ __forceinline__ constexpr int colpos(int col) { return (col & 1) ? 9 + (col >> 1) : (col >> 1); }
+
+// 256 B of zeros in HBM: the LDS-DMA source for halo lanes outside the image (defined in conv3x3_wino.hip)
+const float* zero_block();
+
+// tall variant (conv3x3_wino_tall.hip); kind: 0 forward, 1 data gradient
+bool tall_supported(int kind, int hw, int kc, int unpool_or_pool);
+int launch_tall(int kind, const WinoJob* jobs, const int* n, int njobs, int hw, int kc, int unpool_or_pool, hipStream_t st);
+
+}  // namespace ugn_wino
