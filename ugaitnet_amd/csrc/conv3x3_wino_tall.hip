@@ -175,8 +175,12 @@ __global__ __launch_bounds__(512, 2) void wino_tall_kernel(const WinoJob j0, con
       const float* sInNext = smem + (ibuf ^ 1) * TSIN;
 #pragma unroll
       for (int G = 0; G < 2; ++G) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        // Publish what the previous group's DMA brought.  With resident filters the first group of a stage consumes nothing
+        // new (its tile was published a group ago, and the buffer its DMA refills has had no reader since the last barrier).
+        if (G == 1 || !u_resident || first) {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          __syncthreads();
+        }
         const float* sU = sU0 + ubuf * TSUG;
         if (!u_resident)   // filter slice of the next group -> next ring slot, while this group computes
           tall_dma_u(G == 0 ? u_slice(item, 2 * st + 1) : u_slice(n_item, 2 * n_stage), su_bytes + (unsigned)((ubuf + 1) & (NUB - 1)) * TSUG * 4u,

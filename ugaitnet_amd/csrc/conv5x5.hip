@@ -83,15 +83,42 @@ __global__ __launch_bounds__(256) void conv5x5_fwd_kernel(const float* __restric
   }
 }
 
+// global -> LDS without a VGPR destination (LDS address = M0 + lane * 16 or + lane * 4); see conv3x3_wino.hip for why asm
+__device__ __forceinline__ void dma16_c5(const void* gsrc, unsigned lds_dst_uniform) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(gsrc), "s"(lds_dst_uniform)
+               : "memory");
+}
+__device__ __forceinline__ void dma4_c5(const void* gsrc, unsigned lds_dst_uniform) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(gsrc), "s"(lds_dst_uniform)
+               : "memory");
+}
+
 // dw[k][co] = sum_pixels patch[pixel + tap_k][c_k] * dz1[pixel][co]; persistent workgroups, slabs [groups][25*CIN][32].
+// The gradient tile (16x16 pixels x 32 channels, 36-float pixel stride) and the input patch of the NEXT tile stream into
+// the second LDS buffer by LDS-DMA (16-byte pieces for the gradient, dwords for the unaligned patch; lanes outside the image
+// or in the pad read a zero block) while the current tile is multiplied: the kernel runs at the rate dz1 can be read.
 template <int CIN>
 __global__ __launch_bounds__(256) void conv5x5_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dz1,
-                                                            float* __restrict__ slab, int tiles_total) {
+                                                            float* __restrict__ slab, const float* __restrict__ zeros,
+                                                            int tiles_total) {
   constexpr int K = 25 * CIN, MBK = (K + 31) / 32;
   constexpr int DS = 36;
-  __shared__ __attribute__((aligned(16))) float sP[P5 * P5 * CIN];
-  __shared__ __attribute__((aligned(16))) float sD[T5 * T5 * DS];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  constexpr int SDF = T5 * T5 * DS;                       // floats per gradient buffer (36,864 B = 36 pieces of 1 KB)
+  constexpr int PE = P5 * P5 * CIN, PPIECES = (PE + 63) / 64, SPF = PPIECES * 64;   // patch dwords, 256-B pieces
+  constexpr int DPW = 9, PPW = (PPIECES + 3) / 4;         // pieces per wave
+  extern __shared__ __attribute__((aligned(16))) float smem5[];
+  float* sD0 = smem5;                 // [2][SDF]
+  float* sP0 = smem5 + 2 * SDF;       // [2][SPF]
+  const unsigned sd_bytes = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)smem5);
+  const unsigned sp_bytes = sd_bytes + 2u * SDF * 4u;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, lh = lane >> 5;
 
   f32x16 acc[MBK];
@@ -107,27 +134,49 @@ __global__ __launch_bounds__(256) void conv5x5_wgrad_kernel(const float* __restr
   }
   const int bbase = (wave * 64 + lh) * DS + li;
 
-  for (int tile = blockIdx.x; tile < tiles_total; tile += gridDim.x) {
+  // per-lane geometry of this wave's DMA pieces (tile independent)
+  int dgeo[DPW], pgeo[PPW];
+#pragma unroll
+  for (int j = 0; j < DPW; ++j) {
+    const int slot = (wave * DPW + j) * 64 + lane;       // 4 waves x 9 pieces = 36 = all slots
+    const int p = slot / 9, c4 = slot - p * 9;
+    dgeo[j] = c4 < 8 ? ((p >> 4) * DOM + (p & 15)) * 32 + c4 * 4 : -1;
+  }
+#pragma unroll
+  for (int j = 0; j < PPW; ++j) {
+    int inst = wave * PPW + j;
+    inst = inst < PPIECES ? inst : PPIECES - 1;
+    const int e = inst * 64 + lane;
+    const int pe = e / CIN, ch = e - pe * CIN;
+    pgeo[j] = e < PE ? ((pe / P5) << 16) | ((pe % P5) << 8) | ch : -1;
+  }
+  auto issue_dma = [&](int tile, int buf) {
     const int img = tile >> 4, trem = tile & 15;
     const int ty0 = (trem >> 2) * T5, tx0 = (trem & 3) * T5;
-    __syncthreads();
-    stage_patch<CIN>(sP, x, img, ty0, tx0, tid);
-    {
-      float4 d[8];
+    const float* dzt = dz1 + (((size_t)img * DOM + ty0) * DOM + tx0) * 32;
 #pragma unroll
-      for (int it = 0; it < 8; ++it) {
-        const int e = tid + it * 256;
-        const int p = e >> 3, c4 = e & 7;
-        d[it] = *reinterpret_cast<const float4*>(dz1 + (((size_t)img * DOM + ty0 + (p >> 4)) * DOM + tx0 + (p & 15)) * 32 +
-                                                 c4 * 4);
-      }
+    for (int j = 0; j < DPW; ++j)
+      dma16_c5(dgeo[j] >= 0 ? dzt + dgeo[j] : zeros, sd_bytes + (unsigned)buf * SDF * 4u + (unsigned)(wave * DPW + j) * 1024u);
 #pragma unroll
-      for (int it = 0; it < 8; ++it) {
-        const int e = tid + it * 256;
-        *reinterpret_cast<float4*>(sD + (e >> 3) * DS + (e & 7) * 4) = d[it];
-      }
+    for (int j = 0; j < PPW; ++j) {
+      int inst = wave * PPW + j;
+      inst = inst < PPIECES ? inst : PPIECES - 1;
+      const int yy = pgeo[j] >> 16, xx = (pgeo[j] >> 8) & 0xff, ch = pgeo[j] & 0xff;
+      const int ry = ty0 - 4 + yy, rx = tx0 - 4 + xx;
+      const bool ok = pgeo[j] >= 0 && ry >= 0 && ry < RAW && rx >= 0 && rx < RAW;
+      dma4_c5(ok ? x + (((size_t)img * RAW + ry) * RAW + rx) * CIN + ch : zeros,
+              sp_bytes + (unsigned)buf * SPF * 4u + (unsigned)inst * 256u);
     }
-    __syncthreads();
+  };
+  int tile = blockIdx.x, buf = 0;
+  if (tile < tiles_total) issue_dma(tile, 0);
+  for (; tile < tiles_total; tile += gridDim.x, buf ^= 1) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of the current buffers have landed
+    __syncthreads();                                    // everyone's have; the other buffers have no readers left
+    const int nt = tile + (int)gridDim.x;
+    issue_dma(nt < tiles_total ? nt : tile, buf ^ 1);   // branch-free: past the end the current tile is fetched again
+    const float* sD = sD0 + buf * SDF;
+    const float* sP = sP0 + buf * SPF;
 #pragma unroll
     for (int kp = 0; kp < 32; ++kp) {  // wave's 64 pixels: p = 2*kp + lh, row = p/16, col = p%16
       const int po = ((2 * kp) / 16) * P5 + ((2 * kp) % 16);
@@ -136,19 +185,20 @@ __global__ __launch_bounds__(256) void conv5x5_wgrad_kernel(const float* __restr
       for (int mb = 0; mb < MBK; ++mb) acc[mb] = ugn_mfma(sP[abase[mb] + po * CIN], b, acc[mb]);
     }
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   // cross-wave reduction through LDS (reuse sD: 4 waves x MBK x 16 x 64 floats <= 8192 floats < 9216)
   __syncthreads();
 #pragma unroll
   for (int mb = 0; mb < MBK; ++mb)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) sD[((wave * MBK + mb) * 16 + r) * 64 + lane] = acc[mb][r];
+    for (int r = 0; r < 16; ++r) sD0[((wave * MBK + mb) * 16 + r) * 64 + lane] = acc[mb][r];
   __syncthreads();
   float* dst = slab + (size_t)blockIdx.x * K * 32;
   for (int e = tid; e < MBK * 16 * 64; e += 256) {
     const int l = e & 63, r = (e >> 6) & 15, mb = e >> 10;
     float s = 0.f;
 #pragma unroll
-    for (int wv = 0; wv < 4; ++wv) s += sD[((wv * MBK + mb) * 16 + r) * 64 + l];
+    for (int wv = 0; wv < 4; ++wv) s += sD0[((wv * MBK + mb) * 16 + r) * 64 + l];
     const int k = mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
     if (k < K) dst[k * 32 + (l & 31)] = s;
   }
@@ -203,10 +253,25 @@ extern "C" int ugn_conv5x5_in_wgrad(const float* x, const float* dz1, float* dw,
   hipStream_t st = (hipStream_t)stream;
   const int tiles = n * 16;
   const int groups = tiles < WG5_GROUPS ? tiles : WG5_GROUPS;
+  static float* zeros = nullptr;   // LDS-DMA source for the pad and the out-of-image lanes
+  if (!zeros) {
+    float* p = nullptr;
+    UGN_REQUIRE(hipMalloc((void**)&p, 256) == hipSuccess && hipMemset(p, 0, 256) == hipSuccess,
+                "ugn_conv5x5_in_wgrad: cannot allocate the zero block");
+    zeros = p;
+  }
+  const int lds = (2 * 256 * 36 + 2 * ((25 * 16 * cin + 63) / 64) * 64) * 4;
+  static bool attr_done[3] = {false, false, false};
+  if (!attr_done[cin]) {
+    hipError_t e = cin == 1 ? hipFuncSetAttribute((const void*)conv5x5_wgrad_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)
+                            : hipFuncSetAttribute((const void*)conv5x5_wgrad_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    UGN_REQUIRE(e == hipSuccess, "ugn_conv5x5_in_wgrad: hipFuncSetAttribute: %s", hipGetErrorString(e));
+    attr_done[cin] = true;
+  }
   if (cin == 1)
-    hipLaunchKernelGGL(conv5x5_wgrad_kernel<1>, dim3(groups), dim3(256), 0, st, x, dz1, (float*)ws, tiles);
+    hipLaunchKernelGGL(conv5x5_wgrad_kernel<1>, dim3(groups), dim3(256), lds, st, x, dz1, (float*)ws, (const float*)zeros, tiles);
   else
-    hipLaunchKernelGGL(conv5x5_wgrad_kernel<2>, dim3(groups), dim3(256), 0, st, x, dz1, (float*)ws, tiles);
+    hipLaunchKernelGGL(conv5x5_wgrad_kernel<2>, dim3(groups), dim3(256), lds, st, x, dz1, (float*)ws, (const float*)zeros, tiles);
   UGN_CHECK_LAUNCH("conv5x5_wgrad");
   const int nelem = 25 * cin * 32;
   hipLaunchKernelGGL(reduce5_kernel, dim3((nelem + 31) / 32), dim3(256), 0, st, (const float*)ws, dw, nelem, groups);
