@@ -30,7 +30,7 @@ constexpr int HSLOTS = NPIX * 9;                                // 16-byte slots
 constexpr int HPIECES = 46;                                     // 1 KB LDS-DMA pieces per halo tile (46 * 64 >= HSLOTS)
 constexpr int SIN = HPIECES * 256;                              // one halo buffer (floats) = 47,104 B
 constexpr int SU = 16 * 4 * 32 * 4;                             // one filter slice: [16 pts][4 kq][32 out][4 ch] = 32 KB
-constexpr int LDS_BYTES = (2 * SIN + 2 * SU) * 4;               // 159,744 B (of 163,840)
+constexpr int LDS_BYTES = (2 * SIN + 2 * SU) * 4 + 8 * 256;     // 159,744 B + a 256-B dump per wave (of 163,840)
 // pooled-resolution input (data gradient of a MaxPool'ed layer): the LDS tile holds the 10x10 POOLED pixels under the halo,
 // 40 floats per pixel = 32 gradient values + 32 argmax bytes; the scatter through the argmax happens when a lane reads
 // its 4x4 patch (3x3 pooled pixels), so the 4x larger un-pooled gradient is never materialised anywhere.
@@ -426,6 +426,22 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const WinoJob j0, const Wi
             if (pt == (ROWWISE ? 4 : 2)) { rowpass(tn0, 2); rowpass(tn0, 3); }   // pair 0 done before pair 1 is loaded at point 3
             if (NH == 2 && pt == (ROWWISE ? 8 : 4)) { rowpass(tn1, 0); rowpass(tn1, 1); }
             if (NH == 2 && pt == (ROWWISE ? 9 : 5)) { rowpass(tn1, 2); rowpass(tn1, 3); }
+            // The data-gradient epilogue reads act / addend at the item's output pixels; those loads are a dependent round
+            // trip to HBM per item.  Touch one dword of every line they will read while the last group still computes
+            // (LDS-DMA into a per-wave dump: no registers, nothing waits for it): the epilogue then hits L2.
+            if constexpr (EPI == EPI_DGRAD && (EFLAGS & 3) != 0 && !IN_UNPOOL) {   // (the pooled-input variants have no register to spare)
+              if (pt == 9 && G == NG - 1 && last_chunk) {
+                const int p_region = local(item) / NSPLIT, p_nsp = local(item) % NSPLIT;
+                const int p_img = p_region / RPI, p_rrem = p_region % RPI;
+                const int t = lane >> 2, q = lane & 3;
+                const int oy = (p_rrem / RPX) * 16 + 2 * (trow0 + TRSTEP * (t >> 3)) + (q >> 1);
+                const int ox = (p_rrem % RPX) * 16 + 2 * (t & 7) + (q & 1);
+                const size_t o = (((size_t)p_img * HW + oy) * HW + ox) * NCF + p_nsp * (32 * NB) + ch * (16 * NB);
+                const unsigned dump = sin_bytes + (unsigned)((2 * SIN + 2 * SU) * 4) + (unsigned)wave * 256u;
+                if constexpr (EFLAGS & 1) dma4((item >= nitems0 ? j1.act : j0.act) + o, dump);
+                if constexpr (EFLAGS & 2) dma4((item >= nitems0 ? j1.addend : j0.addend) + o, dump);
+              }
+            }
             constexpr bool LATE = ROWWISE && NH == 2;   // both row passes end at point 9
             if (pt == (LATE ? 10 : 6)) colpass(0);
             if (pt == (LATE ? 11 : 8)) colpass(1);

@@ -44,6 +44,15 @@ __device__ __forceinline__ void dma16(const void* gsrc, unsigned lds_dst_uniform
                : "memory");
 }
 
+// same, 4 B per lane (LDS address = M0 + lane * 4)
+__device__ __forceinline__ void dma4(const void* gsrc, unsigned lds_dst_uniform) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(gsrc), "s"(lds_dst_uniform)
+               : "memory");
+}
+
 // even pixel columns of a halo row first, then the odd ones (bank layout, see conv3x3_wino.hip)
 __device__ __forceinline__ constexpr int colpos(int col) { return (col & 1) ? 9 + (col >> 1) : (col >> 1); }
 
