@@ -149,6 +149,15 @@ int ugn_triplet_fwd_bwd(const float* sig, const int32_t* hp, const int32_t* hn, 
 int ugn_adam_step(float* p, const float* g, float* m, float* v, size_t n, float lr_t, float b1, float b2,
                   float eps, float grad_scale, void* stream);
 
+/* ---- evaluation: k-NN over gait signatures ----------------------------------------------
+ * Replaces sklearn KNeighborsClassifier(n_neighbors=k).fit(gallery, labels).predict(probes) of
+ * mains/mj_testUWYHGaitNet_open_tum.py:328-341: Euclidean, uniform weights, majority vote, smallest label on a tied
+ * vote (nearer-first, lower gallery index on equal distances).  gallery [ngallery,dim], probes [nprobe,dim] fp32;
+ * pred [nprobe]; neighbours (optional) [nprobe,k] gallery indices, nearest first.  1 <= k <= 16. */
+size_t ugn_knn_ws(int ngallery, int nprobe);
+int ugn_knn_predict(const float* gallery, const int32_t* gallery_labels, const float* probes, int ngallery, int nprobe,
+                    int dim, int k, int32_t* pred, int32_t* neighbours, void* ws, size_t ws_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
