@@ -149,6 +149,17 @@ int ugn_triplet_fwd_bwd(const float* sig, const int32_t* hp, const int32_t* hn, 
 int ugn_adam_step(float* p, const float* g, float* m, float* v, size_t n, float lr_t, float b1, float b2,
                   float eps, float grad_scale, void* stream);
 
+/* ---- device-side batch assembly ----------------------------------------------------------
+ * One modality of one batch: decode + re-layout + row expansion of data/mj_dataGeneratorMMUWYHsingle_repetitions.py
+ * (`__load_dd` :300-318, gaitset layout :746-753, expansion / disabling :732-737,776-806).
+ * raw: device array [nbase][60][60][25*channels], int16 (is_int16) or uint8, exactly the `data` array of a sample file.
+ * src_row [nrows] int32: the base sample an output row copies, or -1 for an absent / disabled modality.
+ * x_out [nrows][25][60][60][channels] = ((clip(v) / divisor) * post_mul) - offset, or `noise` everywhere for a -1 row;
+ * clip: |v| > clip_max -> 1e-8, |v| < clip_min -> 1e-8 (each only when > 0).  flag_out [nrows] = 1 / 0. */
+int ugn_assemble_modality(const void* raw, int is_int16, const int32_t* src_row, int nrows, int channels, float divisor,
+                          float offset, float post_mul, float clip_max, float clip_min, float noise, float* x_out,
+                          float* flag_out, void* stream);
+
 /* ---- evaluation: k-NN over gait signatures ----------------------------------------------
  * Replaces sklearn KNeighborsClassifier(n_neighbors=k).fit(gallery, labels).predict(probes) of
  * mains/mj_testUWYHGaitNet_open_tum.py:328-341: Euclidean, uniform weights, majority vote, smallest label on a tied

@@ -52,6 +52,7 @@ PROTOTYPES = {
     "ugn_head_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
     "ugn_triplet_indices_host": (_i, [_p, _i, _p, _p, C.POINTER(_i), C.POINTER(_i)]),
     "ugn_triplet_fwd_bwd": (_i, [_p, _p, _p, _i, _i, _f, _p, _p, _p, _f, _i, _p]),
+    "ugn_assemble_modality": (_i, [_p, _i, _p, _i, _i, _f, _f, _f, _f, _f, _f, _p, _p, _p]),
     "ugn_knn_ws": (_sz, [_i, _i]),
     "ugn_knn_predict": (_i, [_p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _sz, _p]),
     "ugn_adam_step": (_i, [_p, _p, _p, _p, _sz, _f, _f, _f, _f, _f, _p]),
