@@ -1,0 +1,44 @@
+"""The evaluation route of the reference (mains/mj_testUWYHGaitNet_open_tum.py:139-224, 328-341): signatures from
+`Model(model.input, model.get_layer('flatten').output)` under every modality combination, then k-NN over the gallery."""
+import itertools
+
+import numpy as np
+import pytest
+
+from tests.synth import make_batch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_signatures_for_all_seven_modality_combinations_and_knn(dev):
+    from ugaitnet_amd.knn import KNeighborsClassifier
+    from ugaitnet_amd.nets.mj_uwyhNets_ba import Model, UWYHSemiNet3Mods, optimizers, sign_max
+    shapes = [(5, 60, 60, 2), (5, 60, 60, 1), (5, 60, 60, 1)]
+    model = UWYHSemiNet3Mods.build_or_load(shapes, 4, [7, 5, 3, 2], [96, 192, 512, 4096], ndense_units=0,
+                                           optimizer=optimizers.Adam(lr=1e-3), margin=0.2, nclasses=6,
+                                           loss_weights=[1.0, 0.1], fMerge=sign_max, gaitset=True, seed=3)
+    model_code = Model(model.input, model.get_layer("flatten").output)
+    b = 8
+    xs, _, labels, _ = make_batch(("of", "gray", "depth"), b, 5, 6, ids=4, seed=11)
+    combos = [c for c in itertools.product((0, 1), repeat=3) if any(c)]        # the 7 test-time combinations (:599-601)
+    assert len(combos) == 7
+    codes = {}
+    for c in combos:
+        X = []
+        for m in range(3):
+            X += [xs[m], np.full((b, 1), float(c[m]), np.float32)]
+        codes[c] = model_code.predict(X)
+        assert codes[c].shape == (b, 62 * 256) and np.isfinite(codes[c]).all()
+    # a disabled modality's pixels never matter; an enabled one does
+    X = []
+    for m, flag in enumerate((1, 0, 1)):
+        X += [xs[m] if flag else np.full_like(xs[m], 7.0), np.full((b, 1), float(flag), np.float32)]
+    assert np.array_equal(model_code.predict(X), codes[(1, 0, 1)])
+    assert not np.array_equal(codes[(1, 0, 1)], codes[(1, 1, 1)])
+    # gallery = all-modality codes, probes = the same clips: every probe's nearest neighbour is itself
+    clf = KNeighborsClassifier(n_neighbors=1).fit(codes[(1, 1, 1)], labels.astype(np.float64))
+    nbr, pred = clf.kneighbors_and_predict(codes[(1, 1, 1)])
+    assert np.array_equal(nbr[:, 0], np.arange(b)) and np.array_equal(pred, labels.astype(np.float64))
+    # probes with a modality missing are classified by the same call the reference makes
+    pred2 = KNeighborsClassifier(n_neighbors=3).fit(codes[(1, 1, 1)], labels).predict(codes[(1, 1, 0)])
+    assert pred2.shape == (b,) and set(pred2.tolist()) <= set(labels.tolist())
