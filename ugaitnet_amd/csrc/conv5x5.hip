@@ -204,20 +204,21 @@ __global__ __launch_bounds__(256) void conv5x5_wgrad_kernel(const float* __restr
   }
 }
 
-// dst[e] = sum_g src[g][e]: 256 threads = 32 elements x 8 slab lanes, combined through LDS
+// dst[e] = sum_g src[g][e]: 256 threads = 8 elements x 32 slab lanes (lane ly sums slabs ly, ly+32, ...), combined in a fixed
+// order through LDS -> bitwise reproducible.  (800 / 1600 elements only: 32 lanes per element keep 100 / 200 workgroups busy.)
 __global__ __launch_bounds__(256) void reduce5_kernel(const float* __restrict__ src, float* __restrict__ dst, int nelem,
                                                       int nin) {
-  __shared__ float sR[8][32];
-  const int le = threadIdx.x & 31, ly = threadIdx.x >> 5;
-  const int e = blockIdx.x * 32 + le;
+  __shared__ float sR[32][9];
+  const int le = threadIdx.x & 7, ly = threadIdx.x >> 3;
+  const int e = blockIdx.x * 8 + le;
   float s = 0.f;
   if (e < nelem)
-    for (int g = ly; g < nin; g += 8) s += src[(size_t)g * nelem + e];
+    for (int g = ly; g < nin; g += 32) s += src[(size_t)g * nelem + e];
   sR[ly][le] = s;
   __syncthreads();
   if (ly == 0 && e < nelem) {
 #pragma unroll
-    for (int k = 1; k < 8; ++k) s += sR[k][le];
+    for (int k = 1; k < 32; ++k) s += sR[k][le];
     dst[e] = s;
   }
 }
@@ -274,7 +275,7 @@ extern "C" int ugn_conv5x5_in_wgrad(const float* x, const float* dz1, float* dw,
     hipLaunchKernelGGL(conv5x5_wgrad_kernel<2>, dim3(groups), dim3(256), lds, st, x, dz1, (float*)ws, (const float*)zeros, tiles);
   UGN_CHECK_LAUNCH("conv5x5_wgrad");
   const int nelem = 25 * cin * 32;
-  hipLaunchKernelGGL(reduce5_kernel, dim3((nelem + 31) / 32), dim3(256), 0, st, (const float*)ws, dw, nelem, groups);
+  hipLaunchKernelGGL(reduce5_kernel, dim3((nelem + 7) / 8), dim3(256), 0, st, (const float*)ws, dw, nelem, groups);
   UGN_CHECK_LAUNCH("conv5x5_wgrad reduce");
   return 0;
 }

@@ -298,10 +298,15 @@ __global__ __launch_bounds__(512, 2) void wgrad_wino_kernel(const WgJob j0, cons
 
 // dW[tap][cic*32 + ci][coc*COC + co] = sum_g slab[combo][g][tap][ci][co], in float4 units over co.
 // 256 threads = 16 elements x 16 slab lanes; lane gl sums groups gl, gl+16, ..., then the 16 lanes are added in order.
+// (blockIdx.z = job: both weight gradients of a pair launch are finished by one launch)
 template <int COC>
-__global__ __launch_bounds__(256) void wino_wgrad_finish(const float4* __restrict__ slab, float* __restrict__ dw, int CI,
-                                                         int CO, int groups) {
+__global__ __launch_bounds__(256) void wino_wgrad_finish(const float4* __restrict__ slab0, float* __restrict__ dw0, int groups0,
+                                                         const float4* __restrict__ slab1, float* __restrict__ dw1, int groups1,
+                                                         int CI, int CO) {
   __shared__ float4 sR[16][16];
+  const float4* __restrict__ slab = blockIdx.z ? slab1 : slab0;
+  float* __restrict__ dw = blockIdx.z ? dw1 : dw0;
+  const int groups = blockIdx.z ? groups1 : groups0;
   constexpr int E4 = 9 * 32 * COC / 4;
   const int le = threadIdx.x & 15, lg = threadIdx.x >> 4;
   const int combo = blockIdx.y, e = blockIdx.x * 16 + le;   // E4 is a multiple of 16
@@ -394,11 +399,10 @@ int launch_wgrad_wino(const WgHostJob* hj, int njobs, float* ws, size_t ws_float
   if (njobs == 1) dj[1] = dj[0];
   hipLaunchKernelGGL(kern, dim3(NCOMBO * (groups[0] + groups[1])), dim3(512), LDS, st, dj[0], dj[1], zeros);
   UGN_CHECK_LAUNCH("wgrad wino");
-  for (int j = 0; j < njobs; ++j) {
-    hipLaunchKernelGGL(wino_wgrad_finish<COC>, dim3(9 * 32 * COC / 4 / 16, NCOMBO), dim3(256), 0, st, (const float4*)dj[j].slab,
-                       hj[j].dw, CI, CO, groups[j]);
-    UGN_CHECK_LAUNCH("wgrad wino finish");
-  }
+  hipLaunchKernelGGL(wino_wgrad_finish<COC>, dim3(9 * 32 * COC / 4 / 16, NCOMBO, njobs), dim3(256), 0, st,
+                     (const float4*)dj[0].slab, hj[0].dw, groups[0], (const float4*)dj[1].slab, hj[njobs > 1 ? 1 : 0].dw, groups[1], CI,
+                     CO);
+  UGN_CHECK_LAUNCH("wgrad wino finish");
   return 0;
 }
 
