@@ -86,6 +86,13 @@ int ugn_conv3x3_fwd_wino_pair(const float* const* in, const float* const* u_pack
 int ugn_conv3x3_dgrad_wino_pair(const float* const* dz, const uint8_t* const* dz_idx, const float* const* u_packed,
                                 const float* const* act, const float* const* addend, float* const* out,
                                 float* const* raw_out, const int* n, int hw, int cin, int cout, void* stream);
+/* Data gradient whose addend is the set-max gradient of the layer's output (the Add of the two gradient paths into p2 / p4,
+ * nets/mj_uwyhNets_ba.py:435,451): out = (dgrad + ((act == smax_m[clip]) ? smax_g[clip] : 0)) * LeakyReLU'(act), clip =
+ * image / frames; smax_m [n/frames,hw,hw,cin] = the set maxima (ugn_setmax_fwd_cnt), smax_g = dL/dm / #maxima (ugn_div of
+ * the incoming gradient by the count).  Shapes: (hw 32, cin 32, cout 64) and (hw 16, cin 64, cout 128). */
+int ugn_conv3x3_dgrad_wino_routed(const float* dz, const float* u_packed, const float* act, const float* smax_m,
+                                  const float* smax_g, int frames, float* out, int n, int hw, int cin, int cout,
+                                  void* stream);
 /* Winograd F(2x2,3x3) weight gradient (Conv2DBackpropFilter of the same layers); arguments as ugn_conv3x3_wgrad,
  * workspace size from ugn_conv3x3_wgrad_wino_ws (0 = unsupported shape).  Deterministic (fixed summation order). */
 size_t ugn_conv3x3_wgrad_wino_ws(int n, int hw, int cin, int cout);
@@ -101,6 +108,11 @@ int ugn_conv3x3_wgrad_wino_pair(const float* const* in, const float* const* dz, 
 int ugn_setmax_fwd(const float* p, const float* addend, float* m, float* sum_out, int b, int l, size_t s,
                    void* stream);
 /* out[b,l,s] = (p == max_l p) ? dm / (#maxima) : 0, times LeakyReLU'(p) when apply_lrelu != 0. */
+/* Forward that also returns cnt [b,s] = the number of frames holding the maximum (fp32; l <= 32). */
+int ugn_setmax_fwd_cnt(const float* p, const float* addend, float* m, float* sum_out, float* cnt, int b, int l, size_t s,
+                       void* stream);
+/* out = a / b elementwise (n a multiple of 4): dL/dm divided by the number of maxima (TF's reduce_max gradient). */
+int ugn_div(const float* a, const float* b, float* out, size_t n, void* stream);
 int ugn_setmax_bwd(const float* p, const float* dm, float* out, int b, int l, size_t s, int apply_lrelu,
                    void* stream);
 

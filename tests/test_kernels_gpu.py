@@ -167,6 +167,32 @@ def test_winograd_pair_launch_equals_two_single_launches(dev, hw, cin, cout, poo
         ops.conv3x3_dgrad_wino_pair(dzs, uds, hw, cin, cout, gouts, dz_idxs=idxs, acts=[acts[0], None])
 
 
+@pytest.mark.parametrize("hw,cin,cout", [(32, 32, 64), (16, 64, 128)])
+def test_routed_data_gradient_equals_setmax_bwd_plus_addend(dev, hw, cin, cout):
+    """(dgrad + set-max gradient of the layer's output) * LeakyReLU': formed in the epilogue vs materialised by setmax_bwd."""
+    from ugaitnet_amd import ops
+    rng = np.random.default_rng(60 + hw)
+    b, l = 3, 5
+    n = b * l
+    p = rng.normal(size=(n, hw, hw, cin)).astype(np.float32)
+    p[:, :4] = 0.0                                   # blank rows: every frame ties at the maximum there
+    p[1::2, 10] = p[0::2, 10][: p[1::2, 10].shape[0]]   # and some two-way ties
+    dm = rng.normal(size=(b, hw, hw, cin)).astype(np.float32)
+    dz = rng.normal(size=(n, hw, hw, cout)).astype(np.float32)
+    w = rng.uniform(-0.2, 0.2, (3, 3, cin, cout)).astype(np.float32)
+    ud = ops.wino_pack(T(w, dev), True)
+    p_t, dm_t, dz_t = T(p, dev), T(dm, dev), T(dz, dev)
+    m, cnt = ops.setmax_fwd_cnt(p_t, b, l)
+    m_ref = ops.setmax_fwd(p_t, b, l)
+    assert torch.equal(m, m_ref)
+    cnt_ref = (p.reshape(b, l, hw, hw, cin) == p.reshape(b, l, hw, hw, cin).max(1, keepdims=True)).sum(1)
+    assert np.array_equal(cnt.cpu().numpy(), cnt_ref.astype(np.float32))
+    g = ops.setmax_bwd(p_t, dm_t, b, l, False)
+    ref = ops.conv3x3_dgrad_wino(dz_t, ud, hw, cin, cout, act=p_t, addend=g)
+    got = ops.conv3x3_dgrad_wino_routed(dz_t, ud, hw, cin, cout, p_t, m, ops.div(dm_t, cnt), l)
+    assert torch.equal(got, ref)                     # same arithmetic: dm / cnt, added before the LeakyReLU' factor
+
+
 def test_conv3x3_pool_first_max_on_ties(dev):
     """Constant input -> every window is a 4-way tie in the interior: the FIRST element (index 0) must win."""
     from ugaitnet_amd import ops

@@ -465,12 +465,29 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const WinoJob j0, const Wi
     const float* act = jb ? j1.act : j0.act;
     const float* addend = jb ? j1.addend : j0.addend;
     float* raw_out = jb ? j1.raw_out : j0.raw_out;
+    const float* sm_m = jb ? j1.smax_m : j0.smax_m;
+    const float* sm_g = jb ? j1.smax_g : j0.smax_g;
+    {   // advance every tensor to this image (pooled outputs are a quarter of the size; set-level tensors are per clip)
+      constexpr size_t IMG = (size_t)HW * HW * NCF, OIMG = EPI == EPI_LRELU_POOL ? IMG / 4 : IMG;
+      out += (size_t)img * OIMG;
+      if constexpr (EPI == EPI_LRELU_POOL) out_idx += (size_t)img * OIMG;
+      if constexpr (EPI == EPI_DGRAD) {
+        if constexpr (EFLAGS & 1) act += (size_t)img * IMG;
+        if constexpr (EFLAGS & 2) addend += (size_t)img * IMG;
+        if constexpr (EFLAGS & 4) raw_out += (size_t)img * IMG;
+        if constexpr (EFLAGS & 8) {
+          const int clip = img / (jb ? j1.frames : j0.frames);
+          sm_m += (size_t)clip * IMG;
+          sm_g += (size_t)clip * IMG;
+        }
+      }
+    }
     const int ry0 = (rrem / RPX) * 16, rx0 = (rrem % RPX) * 16;
 #pragma unroll
     for (int cb = 0; cb < NB; ++cb) {
       const int co = nsp * (32 * NB) + ch * (16 * NB) + cb * 16 + lj;
       float y[4][4];     // [tile r][output (a,b) row-major]
-      size_t o[4][4];
+      unsigned o[4][4];   // element offsets inside the image: the image base is wave-uniform and rides in SGPRs
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int ti = 4 * kq + r, tr = ti >> 3, tc = ti & 7;
@@ -488,10 +505,10 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const WinoJob j0, const Wi
         const int oy = ry0 + 2 * (trow0 + TRSTEP * tr), ox = rx0 + 2 * tc;
         if constexpr (EPI == EPI_LRELU_POOL) {
           constexpr int HP = HW / 2;
-          o[r][0] = (((size_t)img * HP + oy / 2) * HP + ox / 2) * NCF + co;
+          o[r][0] = (unsigned)(((oy / 2) * HP + ox / 2) * NCF + co);
         } else {
 #pragma unroll
-          for (int q = 0; q < 4; ++q) o[r][q] = (((size_t)img * HW + oy + (q >> 1)) * HW + ox + (q & 1)) * NCF + co;
+          for (int q = 0; q < 4; ++q) o[r][q] = (unsigned)(((oy + (q >> 1)) * HW + ox + (q & 1)) * NCF + co);
         }
       }
       if constexpr (EPI == EPI_LRELU_POOL) {
@@ -526,12 +543,23 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const WinoJob j0, const Wi
 #pragma unroll
             for (int q = 0; q < 4; ++q) dv[r][q] = addend[o[r][q]];
         }
+        float mv[4][4], gv[4][4];
+        if constexpr (EFLAGS & 8) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              mv[r][q] = sm_m[o[r][q]];
+              gv[r][q] = sm_g[o[r][q]];
+            }
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             float v = y[r][q];
             if constexpr (EFLAGS & 2) v += dv[r][q];
+            if constexpr (EFLAGS & 8) v += av[r][q] == mv[r][q] ? gv[r][q] : 0.f;   // set-max gradient -> the frames holding the maximum
             if constexpr (EFLAGS & 4) raw_out[o[r][q]] = v;
             if constexpr (EFLAGS & 1) v *= ugn_lrelu_slope(av[r][q]);
             out[o[r][q]] = v;
@@ -562,7 +590,9 @@ int launch_wino(const WinoJob* jobs, const int* n, int njobs, hipStream_t st) {
 
 template <int KC, int NCF, int HW, int IN_UNPOOL>
 int launch_wino_dgrad(const WinoJob* jobs, const int* n, int njobs, hipStream_t st) {
-  const int flags = (jobs[0].act ? 1 : 0) | (jobs[0].addend ? 2 : 0) | (jobs[0].raw_out ? 4 : 0);
+  const int flags = (jobs[0].act ? 1 : 0) | (jobs[0].addend ? 2 : 0) | (jobs[0].raw_out ? 4 : 0) | (jobs[0].smax_m ? 8 : 0);
+  if constexpr (KC == 128 && NCF == 64 && HW == 16 && !IN_UNPOOL)   // a5: act + routed set-max gradient
+    if (flags == 9) return launch_wino<KC, NCF, HW, IN_UNPOOL, EPI_DGRAD, 9>(jobs, n, njobs, st);
 #define UGN_WDG(F_) \
   case F_:          \
     return launch_wino<KC, NCF, HW, IN_UNPOOL, EPI_DGRAD, F_>(jobs, n, njobs, st);
@@ -588,8 +618,8 @@ int dispatch_fwd(const WinoJob* jobs, const int* n, int njobs, int hw, int cin, 
 
 int dispatch_dgrad(const WinoJob* jobs, const int* n, int njobs, int hw, int cin, int cout, int unpool, hipStream_t st) {
   if (njobs > 1) {   // one kernel instantiation serves both jobs: they must use the same epilogue operands
-    const int f0 = (jobs[0].act ? 1 : 0) | (jobs[0].addend ? 2 : 0) | (jobs[0].raw_out ? 4 : 0);
-    const int f1 = (jobs[1].act ? 1 : 0) | (jobs[1].addend ? 2 : 0) | (jobs[1].raw_out ? 4 : 0);
+    const int f0 = (jobs[0].act ? 1 : 0) | (jobs[0].addend ? 2 : 0) | (jobs[0].raw_out ? 4 : 0) | (jobs[0].smax_m ? 8 : 0);
+    const int f1 = (jobs[1].act ? 1 : 0) | (jobs[1].addend ? 2 : 0) | (jobs[1].raw_out ? 4 : 0) | (jobs[1].smax_m ? 8 : 0);
     if (f0 != f1) {
       ugn_set_error("ugn_conv3x3_dgrad_wino_pair: both jobs need the same set of act/addend/raw_out (%d vs %d)", f0, f1);
       return UGN_EINVAL;
@@ -673,6 +703,18 @@ extern "C" int ugn_conv3x3_dgrad_wino(const float* dz, const uint8_t* dz_idx, co
   UGN_REQUIRE(dz && u_packed && out && n > 0, "ugn_conv3x3_dgrad_wino: null pointer or n <= 0");
   const WinoJob job = {dz, dz_idx, u_packed, out, nullptr, act, addend, raw_out};
   return dispatch_dgrad(&job, &n, 1, hw, cin, cout, dz_idx != nullptr, (hipStream_t)stream);
+}
+
+extern "C" int ugn_conv3x3_dgrad_wino_routed(const float* dz, const float* u_packed, const float* act, const float* smax_m,
+                                             const float* smax_g, int frames, float* out, int n, int hw, int cin, int cout,
+                                             void* stream) {
+  UGN_REQUIRE(dz && u_packed && act && smax_m && smax_g && out && n > 0, "ugn_conv3x3_dgrad_wino_routed: null pointer or n <= 0");
+  UGN_REQUIRE(frames > 0 && n % frames == 0, "ugn_conv3x3_dgrad_wino_routed: n (%d) must be a multiple of frames (%d)", n, frames);
+  WinoJob job = {dz, nullptr, u_packed, out, nullptr, act, nullptr, nullptr};
+  job.smax_m = smax_m;
+  job.smax_g = smax_g;
+  job.frames = frames;
+  return dispatch_dgrad(&job, &n, 1, hw, cin, cout, 0, (hipStream_t)stream);
 }
 
 extern "C" int ugn_conv3x3_dgrad_wino_pair(const float* const* dz, const uint8_t* const* dz_idx, const float* const* u_packed,

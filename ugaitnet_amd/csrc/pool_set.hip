@@ -24,6 +24,46 @@ __global__ void setmax_fwd_kernel(const float4* __restrict__ p, const float4* __
   }
 }
 
+// Forward that also counts the maxima (the frames stay in registers, as in the backward): with the count the set-max
+// gradient of a frame-level tensor can be formed inside the epilogue of the data gradient that consumes it
+// ((p == m) ? dm / cnt : 0) instead of being materialised by setmax_bwd.
+__global__ __launch_bounds__(128) void setmax_fwd_cnt_kernel(const float4* __restrict__ p, const float4* __restrict__ addend,
+                                                             float4* __restrict__ m, float4* __restrict__ sum_out,
+                                                             float4* __restrict__ cnt_out, int l, size_t s4) {
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= s4) return;
+  const int b = blockIdx.y;
+  const float4* src = p + (size_t)b * l * s4 + e;
+  float4 v[32];
+#pragma unroll
+  for (int t = 0; t < 32; ++t)
+    if (t < l) v[t] = src[(size_t)t * s4];
+  float4 mx = v[0];
+#pragma unroll
+  for (int t = 1; t < 32; ++t)
+    if (t < l) { mx.x = fmaxf(mx.x, v[t].x); mx.y = fmaxf(mx.y, v[t].y); mx.z = fmaxf(mx.z, v[t].z); mx.w = fmaxf(mx.w, v[t].w); }
+  float4 cnt = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int t = 0; t < 32; ++t)
+    if (t < l) {
+      cnt.x += v[t].x == mx.x ? 1.f : 0.f; cnt.y += v[t].y == mx.y ? 1.f : 0.f;
+      cnt.z += v[t].z == mx.z ? 1.f : 0.f; cnt.w += v[t].w == mx.w ? 1.f : 0.f;
+    }
+  m[(size_t)b * s4 + e] = mx;
+  cnt_out[(size_t)b * s4 + e] = cnt;
+  if (addend) {
+    const float4 a = addend[(size_t)b * s4 + e];
+    sum_out[(size_t)b * s4 + e] = make_float4(mx.x + a.x, mx.y + a.y, mx.z + a.z, mx.w + a.w);
+  }
+}
+
+__global__ void div_kernel(const float4* __restrict__ a, const float4* __restrict__ b, float4* __restrict__ out, size_t n4) {
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n4) return;
+  const float4 x = a[e], y = b[e];
+  out[e] = make_float4(x.x / y.x, x.y / y.y, x.z / y.z, x.w / y.w);
+}
+
 __device__ __forceinline__ float sm_route(float v, float mx, float g, int lrelu) {
   float o = v == mx ? g : 0.f;
   if (lrelu) o *= ugn_lrelu_slope(v);
@@ -180,6 +220,26 @@ extern "C" int ugn_setmax_fwd(const float* p, const float* addend, float* m, flo
   hipLaunchKernelGGL(setmax_fwd_kernel, dim3((unsigned)((s4 + 255) / 256), b), dim3(256), 0, (hipStream_t)stream,
                      (const float4*)p, (const float4*)addend, (float4*)m, (float4*)sum_out, l, s4);
   UGN_CHECK_LAUNCH("setmax_fwd");
+  return 0;
+}
+
+extern "C" int ugn_setmax_fwd_cnt(const float* p, const float* addend, float* m, float* sum_out, float* cnt, int b, int l,
+                                  size_t s, void* stream) {
+  UGN_REQUIRE(p && m && cnt && b > 0 && s > 0 && s % 4 == 0, "ugn_setmax_fwd_cnt: bad arguments (s must be a multiple of 4)");
+  UGN_REQUIRE(l > 0 && l <= MAXL, "ugn_setmax_fwd_cnt: l must be in 1..%d (got %d)", MAXL, l);
+  UGN_REQUIRE(!addend || sum_out, "ugn_setmax_fwd_cnt: addend needs sum_out");
+  const size_t s4 = s / 4;
+  hipLaunchKernelGGL(setmax_fwd_cnt_kernel, dim3((unsigned)((s4 + 127) / 128), b), dim3(128), 0, (hipStream_t)stream,
+                     (const float4*)p, (const float4*)addend, (float4*)m, (float4*)sum_out, (float4*)cnt, l, s4);
+  UGN_CHECK_LAUNCH("setmax_fwd_cnt");
+  return 0;
+}
+
+extern "C" int ugn_div(const float* a, const float* b, float* out, size_t n, void* stream) {
+  UGN_REQUIRE(a && b && out && n > 0 && n % 4 == 0, "ugn_div: bad arguments (n must be a multiple of 4)");
+  hipLaunchKernelGGL(div_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const float4*)a,
+                     (const float4*)b, (float4*)out, n / 4);
+  UGN_CHECK_LAUNCH("div");
   return 0;
 }
 

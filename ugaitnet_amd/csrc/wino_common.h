@@ -17,6 +17,11 @@ struct WinoJob {
   const float* act;
   const float* addend;
   float* raw_out;
+  // "routed" addend (epilogue flag 8, needs act): the set-max gradient of the layer's output, formed on the fly as
+  // (act == smax_m[clip]) ? smax_g[clip] : 0 with clip = image / frames  (smax_g = dL/dm / #maxima)
+  const float* smax_m;
+  const float* smax_g;
+  int frames;
 };
 
 constexpr int kGrid = 256;   // persistent workgroups (one per CU: the kernels use the whole LDS)

@@ -38,6 +38,9 @@ USE_WINOGRAD = os.environ.get("UGN_WINO", "1") != "0"
 WINO_DGRAD = ("a2", "a3", "a4", "a5", "a6", "b1", "b2", "b3", "b4")
 _wgrad3x3 = ops.conv3x3_wgrad_wino if USE_WINOGRAD else ops.conv3x3_wgrad
 PAIR_LAUNCHES = os.environ.get("UGN_PAIR", "1") != "0"   # frame-level layer + set-level twin in one launch
+# UGN_ROUTED=1: form the set-max gradient inside the a3 / a5 data-gradient epilogues instead of materialising it with
+# setmax_bwd (bit-identical; measured 2.5 % SLOWER on MI355X: three operand loads per element make those epilogues spill).
+ROUTED = USE_WINOGRAD and os.environ.get("UGN_ROUTED", "0") == "1"
 
 
 def glorot_uniform(gen, shape):
@@ -180,14 +183,21 @@ class Encoder:
         a1 = ops.conv5x5_in_fwd(xf, self.W("a1"), self._buf(A, "a1", (n, 64, 64, 32)))
         p2, i2 = self.conv("a2", a1, True, self._buf(A, "p2", (n, 32, 32, 32)),
                                  self._buf(A, "i2", (n, 32, 32, 32), U8))
-        m1 = ops.setmax_fwd(p2, b, l, m=self._buf(A, "m1", (b, 32, 32, 32)))
+        if ROUTED:   # also count the maxima: the set-max gradient is then formed inside the a3 / a5 data-gradient epilogues
+            m1, _ = ops.setmax_fwd_cnt(p2, b, l, m=self._buf(A, "m1", (b, 32, 32, 32)), cnt=self._buf(A, "c1", (b, 32, 32, 32)))
+        else:
+            m1 = ops.setmax_fwd(p2, b, l, m=self._buf(A, "m1", (b, 32, 32, 32)))
         a3, b1 = self.conv_pair(("a3", "b1"), (p2, m1), False,
                                 (self._buf(A, "a3", (n, 32, 32, 64)), self._buf(A, "b1", (b, 32, 32, 64))))
         (p4, q2), (i4, j2) = self.conv_pair(("a4", "b2"), (a3, b1), True,
                                             (self._buf(A, "p4", (n, 16, 16, 64)), self._buf(A, "q2", (b, 16, 16, 64))),
                                             (self._buf(A, "i4", (n, 16, 16, 64), U8), self._buf(A, "j2", (b, 16, 16, 64), U8)))
-        _, s2 = ops.setmax_fwd(p4, b, l, addend=q2, m=self._buf(A, "m2", (b, 16, 16, 64)),
-                               sum_out=self._buf(A, "s2", (b, 16, 16, 64)))
+        if ROUTED:
+            _, s2, _ = ops.setmax_fwd_cnt(p4, b, l, addend=q2, m=self._buf(A, "m2", (b, 16, 16, 64)),
+                                          sum_out=self._buf(A, "s2", (b, 16, 16, 64)), cnt=self._buf(A, "c2", (b, 16, 16, 64)))
+        else:
+            _, s2 = ops.setmax_fwd(p4, b, l, addend=q2, m=self._buf(A, "m2", (b, 16, 16, 64)),
+                                   sum_out=self._buf(A, "s2", (b, 16, 16, 64)))
         a5, b3 = self.conv_pair(("a5", "b3"), (p4, s2), False,
                                 (self._buf(A, "a5", (n, 16, 16, 128)), self._buf(A, "b3", (b, 16, 16, 128))))
         a6, b4 = self.conv_pair(("a6", "b4"), (a5, b3), False,
@@ -216,8 +226,13 @@ class Encoder:
         self.wgrad_pair(("a5", "b3"), (A["p4"], A["s2"]), (dz5, dzb3), 128)
         ds2 = buf("ds2", (b, 16, 16, 64))
         dq2 = self.dgrad("b3", dzb3, 16, act=A["q2"], out=buf("dq2", (b, 16, 16, 64)), raw_out=ds2)
-        g4 = ops.setmax_bwd(A["p4"], ds2, b, l, False, buf("g4", (n, 16, 16, 64)))
-        dp4 = self.dgrad("a5", dz5, 16, act=A["p4"], addend=g4, out=g4)  # in place over the addend
+        if ROUTED:
+            dms2 = ops.div(ds2, A["c2"], buf("dms2", (b, 16, 16, 64)))   # dL/dm2 / #maxima (TF reduce_max gradient)
+            dp4 = ops.conv3x3_dgrad_wino_routed(dz5, self.ud["a5"], 16, 64, 128, A["p4"], A["m2"], dms2, l,
+                                                out=buf("g4", (n, 16, 16, 64)))
+        else:
+            g4 = ops.setmax_bwd(A["p4"], ds2, b, l, False, buf("g4", (n, 16, 16, 64)))
+            dp4 = self.dgrad("a5", dz5, 16, act=A["p4"], addend=g4, out=g4)  # in place over the addend
         # block 2 (a3, a4) with block 1 of the global branch (b1, b2); a4 / b2 are pooled: dp4 / dq2 are their gradients at
         # pooled resolution, routed through the argmax maps i4 / j2
         self.wgrad_pair(("a4", "b2"), (A["a3"], A["b1"]), (dp4, dq2), 64, dz_idxs=(A["i4"], A["j2"]))
@@ -226,8 +241,13 @@ class Encoder:
                                     dz_idxs=(A["i4"], A["j2"]), acts=(A["a3"], A["b1"]))
         self.wgrad_pair(("a3", "b1"), (A["p2"], A["m1"]), (dz3, dzb1), 64)
         dm1 = self.dgrad("b1", dzb1, 32, out=buf("dm1", (b, 32, 32, 32)))
-        g2 = ops.setmax_bwd(A["p2"], dm1, b, l, False, buf("g2", (n, 32, 32, 32)))
-        dp2 = self.dgrad("a3", dz3, 32, act=A["p2"], addend=g2, out=g2)
+        if ROUTED:
+            dms1 = ops.div(dm1, A["c1"], buf("dms1", (b, 32, 32, 32)))
+            dp2 = ops.conv3x3_dgrad_wino_routed(dz3, self.ud["a3"], 32, 32, 64, A["p2"], A["m1"], dms1, l,
+                                                out=buf("g2", (n, 32, 32, 32)))
+        else:
+            g2 = ops.setmax_bwd(A["p2"], dm1, b, l, False, buf("g2", (n, 32, 32, 32)))
+            dp2 = self.dgrad("a3", dz3, 32, act=A["p2"], addend=g2, out=g2)
         # block 1 (a1, a2)
         _wgrad3x3(A["a1"], dp2, 32, dz_idx=A["i2"], dw=self.G("a2"))
         dz1 = self.dgrad("a2", dp2, 64, dz_idx=A["i2"], act=A["a1"], out=buf("dz1", (n, 64, 64, 32)))

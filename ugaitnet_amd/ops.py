@@ -253,6 +253,37 @@ def setmax_fwd(p, b, l, addend=None, m=None, sum_out=None):
     return (m, sum_out) if addend is not None else m
 
 
+def setmax_fwd_cnt(p, b, l, addend=None, m=None, sum_out=None, cnt=None):
+    """setmax_fwd that also returns the number of frames holding each maximum (for the routed data gradient)."""
+    _chk(p)
+    s = p.numel() // (b * l)
+    shape = tuple(p.shape[1:])
+    m = torch.empty((b,) + shape, dtype=F32, device=p.device) if m is None else m
+    cnt = torch.empty((b,) + shape, dtype=F32, device=p.device) if cnt is None else cnt
+    if addend is not None and sum_out is None:
+        sum_out = torch.empty_like(m)
+    call("ugn_setmax_fwd_cnt", ptr(p), ptr(addend), ptr(m), ptr(sum_out), ptr(cnt), b, l, s, _stream())
+    return (m, sum_out, cnt) if addend is not None else (m, cnt)
+
+
+def div(a, b, out=None):
+    _chk(a), _chk(b)
+    out = torch.empty_like(a) if out is None else out
+    call("ugn_div", ptr(a), ptr(b), ptr(out), a.numel(), _stream())
+    return out
+
+
+def conv3x3_dgrad_wino_routed(dz, upk, hw, cin, cout, act, smax_m, smax_g, frames, out=None):
+    """Data gradient + set-max gradient of the layer's output formed in the epilogue + LeakyReLU' (see the header)."""
+    for t in (dz, upk, act, smax_m, smax_g):
+        _chk(t)
+    n = dz.shape[0]
+    out = torch.empty((n, hw, hw, cin), dtype=F32, device=dz.device) if out is None else out
+    call("ugn_conv3x3_dgrad_wino_routed", ptr(dz), ptr(upk), ptr(act), ptr(smax_m), ptr(smax_g), int(frames), ptr(out), n, hw, cin,
+         cout, _stream())
+    return out
+
+
 def setmax_bwd(p, dm, b, l, apply_lrelu, out=None):
     _chk(p), _chk(dm)
     s = p.numel() // (b * l)
