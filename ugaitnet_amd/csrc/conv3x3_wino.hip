@@ -250,9 +250,8 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const WinoJob j0, const Wi
 
   int item = blockIdx.x;
   if (item >= nitems) return;
-  int hgeo[6];
-#pragma unroll
-  for (int j = 0; j < 6; ++j) hgeo[j] = halo_slot_geometry(wave * 6 + j, lane);
+  // (the slot geometry of a DMA piece is recomputed where the piece is issued: ~10 VALU per piece, but six fewer live
+  //  registers in a kernel that sits at the 256-register limit)
   // item -> job-local item / pointers (all wave-uniform: scalar selects)
   auto local = [&](int it) { return it >= nitems0 ? it - nitems0 : it; };
   auto in_of = [&](int it) { return it >= nitems0 ? j1.in : j0.in; };
@@ -272,7 +271,7 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const WinoJob j0, const Wi
     } else {
 #pragma unroll
       for (int j = 0; j < 6; ++j)
-        dma_halo_piece<KC, HW>(in, zeros, img, (rrem / RPX) * 16, (rrem % RPX) * 16, 0, wave * 6 + j, hgeo[j], sin_bytes);
+        dma_halo_piece<KC, HW>(in, zeros, img, (rrem / RPX) * 16, (rrem % RPX) * 16, 0, wave * 6 + j, halo_slot_geometry(wave * 6 + j, lane), sin_bytes);
     }
     dma_u_slice(u_slice(item, 0, 0), su_bytes, tid, wave);
   }
@@ -418,7 +417,7 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const WinoJob j0, const Wi
                                        sin_bytes + (unsigned)(ibuf ^ 1) * SIN * 4u);
           } else {
             if (G == 0 && pt >= 1 && pt < 7)   // early in the group: the pieces must have landed by the group's end
-              dma_halo_piece<KC, HW>(in, zeros, n_img, n_ry0, n_rx0, n_chunk, wave * 6 + (pt - 1), hgeo[pt - 1],
+              dma_halo_piece<KC, HW>(in, zeros, n_img, n_ry0, n_rx0, n_chunk, wave * 6 + (pt - 1), halo_slot_geometry(wave * 6 + (pt - 1), lane),
                                      sin_bytes + (unsigned)(ibuf ^ 1) * SIN * 4u);
           }
           if (tnext) {
