@@ -36,11 +36,14 @@ const char* ugn_last_error(void);
 
 /* ---- first layer: ZeroPadding2D(2) + Conv2D(32, 5x5, same, no bias) + LeakyReLU(0.3) ---------------
  * nets/mj_uwyhNets_ba.py:428-430.  x [n,60,60,cin] (cin 1 or 2), w HWIO [5,5,cin,32], a1 [n,64,64,32]. */
-int ugn_conv5x5_in_fwd(const float* x, const float* w, float* a1, int n, int cin, void* stream);
-/* dw [5,5,cin,32] = sum over frames/pixels of x (padded) * dz1 [n,64,64,32].  ws: >= ugn_conv5x5_in_wgrad_ws(). */
+int ugn_conv5x5_in_fwd(const float* x, const float* w, float* a1, uint32_t* a1_sign, int n, int cin, void* stream);
+/* a1_sign (optional, [n,64,64] words): bit c of a pixel's word = (a1[..,c] > 0).  With it the backward never re-reads a1 for
+ * its LeakyReLU' factor: the a2 data gradient leaves dL/da1 in dz1 and ugn_conv5x5_in_wgrad applies the factor from the bits.
+ * dw [5,5,cin,32] = sum over frames/pixels of x (padded) * dz1 [n,64,64,32] (* LeakyReLU'(a1) when a1_sign is given).
+ * ws: >= ugn_conv5x5_in_wgrad_ws(). */
 size_t ugn_conv5x5_in_wgrad_ws(int n, int cin);
-int ugn_conv5x5_in_wgrad(const float* x, const float* dz1, float* dw, int n, int cin, void* ws, size_t ws_bytes,
-                         void* stream);
+int ugn_conv5x5_in_wgrad(const float* x, const float* dz1, const uint32_t* a1_sign, float* dw, int n, int cin, void* ws,
+                         size_t ws_bytes, void* stream);
 
 /* ---- 3x3 convolutions (TimeDistributed Conv2D / Conv2D, same, no bias), nets/mj_uwyhNets_ba.py:431-462 --
  * Forward weights are consumed in packed [9][cout][cin] order produced by ugn_pack3x3 from HWIO. */

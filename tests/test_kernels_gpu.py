@@ -37,6 +37,16 @@ def test_conv5x5_in_fwd_and_wgrad(dev, cin):
     dw_ref, _ = O.conv2d_same_bwd(xf.astype(np.float64), w.astype(np.float64), dz.astype(np.float64), need_dx=False)
     dw = ops.conv5x5_in_wgrad(T(x, dev), T(dz, dev))
     close(dw, dw_ref, 5e-6, "conv5x5 wgrad")
+    # LeakyReLU' of a1 from sign bits: fwd emits one bit per element, wgrad(dL/da1, bits) == wgrad(dL/da1 * slope(a1))
+    sign = torch.empty((n, 64, 64), dtype=torch.int32, device=dev)
+    got2 = ops.conv5x5_in_fwd(T(x, dev), T(w, dev), sign=sign)
+    assert torch.equal(got2, got)
+    bits = ((sign.cpu().numpy().astype(np.uint32)[..., None] >> np.arange(32, dtype=np.uint32)) & 1).astype(bool)
+    assert np.array_equal(bits, got.cpu().numpy() > 0)
+    dz_scaled = dz * np.where(got.cpu().numpy() > 0, 1.0, 0.3).astype(np.float32)
+    dw_a = ops.conv5x5_in_wgrad(T(x, dev), T(dz, dev), sign=sign)
+    dw_b = ops.conv5x5_in_wgrad(T(x, dev), T(dz_scaled, dev))
+    assert torch.equal(dw_a, dw_b)
 
 
 @pytest.mark.parametrize("hw,cin,cout,pool", CONV_CFGS)

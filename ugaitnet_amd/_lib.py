@@ -21,9 +21,9 @@ _sz = C.c_size_t
 PROTOTYPES = {
     "ugn_abi_version": (_i, []),
     "ugn_last_error": (C.c_char_p, []),
-    "ugn_conv5x5_in_fwd": (_i, [_p, _p, _p, _i, _i, _p]),
+    "ugn_conv5x5_in_fwd": (_i, [_p, _p, _p, _p, _i, _i, _p]),
     "ugn_conv5x5_in_wgrad_ws": (_sz, [_i, _i]),
-    "ugn_conv5x5_in_wgrad": (_i, [_p, _p, _p, _i, _i, _p, _sz, _p]),
+    "ugn_conv5x5_in_wgrad": (_i, [_p, _p, _p, _p, _i, _i, _p, _sz, _p]),
     "ugn_pack3x3": (_i, [_p, _p, _i, _i, _p]),
     "ugn_conv3x3_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "ugn_conv3x3_dgrad": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),

@@ -32,9 +32,9 @@ __device__ __forceinline__ void stage_patch(float* sP, const float* __restrict__
   }
 }
 
-template <int CIN>
+template <int CIN, bool SIGN>
 __global__ __launch_bounds__(256) void conv5x5_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                          float* __restrict__ a1) {
+                                                          float* __restrict__ a1, uint32_t* __restrict__ sign_out) {
   constexpr int K = 25 * CIN, KP = (K + 1) / 2;  // k-pairs
   __shared__ __attribute__((aligned(16))) float sP[P5 * P5 * CIN];
   __shared__ __attribute__((aligned(16))) float sW[2 * KP * 32];
@@ -74,11 +74,23 @@ __global__ __launch_bounds__(256) void conv5x5_fwd_kernel(const float* __restric
 #pragma unroll
   for (int m = 0; m < 2; ++m) {
     const int mbi = wave * 2 + m;
+    uint32_t myword = 0;   // SIGN: lane li < 16 of each half collects the word of register r = li
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int y = ty0 + 2 * mbi + ((r >> 1) & 1);
       const int xx = tx0 + 2 * (lh + 2 * (r >> 2)) + (r & 1);
       a1[(((size_t)img * DOM + y) * DOM + xx) * 32 + li] = ugn_lrelu(acc[m][r]);
+      if constexpr (SIGN) {   // bit c of a pixel's word = (a1 > 0): all the layer's backward needs of a1 besides its values
+        const unsigned long long bal = __ballot(acc[m][r] > 0.f);   // lanes 0..31: pixel of lh = 0, 32..63: lh = 1
+        if (li == r) myword = (uint32_t)(bal >> (32 * lh));
+      }
+    }
+    if constexpr (SIGN) {
+      if (li < 16) {   // one store per half wave and row block instead of sixteen single-lane ones
+        const int y = ty0 + 2 * mbi + ((li >> 1) & 1);
+        const int xx = tx0 + 2 * (lh + 2 * (li >> 2)) + (li & 1);
+        sign_out[((size_t)img * DOM + y) * DOM + xx] = myword;
+      }
     }
   }
 }
@@ -103,10 +115,10 @@ __device__ __forceinline__ void dma4_c5(const void* gsrc, unsigned lds_dst_unifo
 // The gradient tile (16x16 pixels x 32 channels, 36-float pixel stride) and the input patch of the NEXT tile stream into
 // the second LDS buffer by LDS-DMA (16-byte pieces for the gradient, dwords for the unaligned patch; lanes outside the image
 // or in the pad read a zero block) while the current tile is multiplied: the kernel runs at the rate dz1 can be read.
-template <int CIN>
+template <int CIN, bool SIGN>
 __global__ __launch_bounds__(256) void conv5x5_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dz1,
                                                             float* __restrict__ slab, const float* __restrict__ zeros,
-                                                            int tiles_total) {
+                                                            const uint32_t* __restrict__ a1_sign, int tiles_total) {
   constexpr int K = 25 * CIN, MBK = (K + 31) / 32;
   constexpr int DS = 36;
   constexpr int SDF = T5 * T5 * DS;                       // floats per gradient buffer (36,864 B = 36 pieces of 1 KB)
@@ -115,6 +127,9 @@ __global__ __launch_bounds__(256) void conv5x5_wgrad_kernel(const float* __restr
   extern __shared__ __attribute__((aligned(16))) float smem5[];
   float* sD0 = smem5;                 // [2][SDF]
   float* sP0 = smem5 + 2 * SDF;       // [2][SPF]
+  const uint32_t* sS0 = reinterpret_cast<const uint32_t*>(smem5 + 2 * SDF + 2 * SPF);   // [2][256] sign words (optional)
+  const unsigned ss_bytes = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)smem5) +
+                            (2u * SDF + 2u * SPF) * 4u;
   const unsigned sd_bytes = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)smem5);
   const unsigned sp_bytes = sd_bytes + 2u * SDF * 4u;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -167,6 +182,8 @@ __global__ __launch_bounds__(256) void conv5x5_wgrad_kernel(const float* __restr
       dma4_c5(ok ? x + (((size_t)img * RAW + ry) * RAW + rx) * CIN + ch : zeros,
               sp_bytes + (unsigned)buf * SPF * 4u + (unsigned)inst * 256u);
     }
+    if (SIGN && wave == 0)   // 256 sign words of the tile: lane -> row lane/4, words 4*(lane%4)..+3
+      dma16_c5(a1_sign + ((size_t)img * DOM + ty0 + (lane >> 2)) * DOM + tx0 + (lane & 3) * 4, ss_bytes + (unsigned)buf * 1024u);
   };
   int tile = blockIdx.x, buf = 0;
   if (tile < tiles_total) issue_dma(tile, 0);
@@ -180,7 +197,11 @@ __global__ __launch_bounds__(256) void conv5x5_wgrad_kernel(const float* __restr
 #pragma unroll
     for (int kp = 0; kp < 32; ++kp) {  // wave's 64 pixels: p = 2*kp + lh, row = p/16, col = p%16
       const int po = ((2 * kp) / 16) * P5 + ((2 * kp) % 16);
-      const float b = sD[bbase + 2 * kp * DS];
+      float b = sD[bbase + 2 * kp * DS];
+      if constexpr (SIGN) {   // dz1 arrives as dL/da1: the LeakyReLU' factor of a1 is applied here, from one bit per element
+        const uint32_t wbits = sS0[buf * 256 + wave * 64 + 2 * kp + lh];
+        b *= ((wbits >> li) & 1u) ? 1.f : UGN_LRELU_ALPHA;
+      }
 #pragma unroll
       for (int mb = 0; mb < MBK; ++mb) acc[mb] = ugn_mfma(sP[abase[mb] + po * CIN], b, acc[mb]);
     }
@@ -227,14 +248,17 @@ constexpr int WG5_GROUPS = 512;
 
 }  // namespace
 
-extern "C" int ugn_conv5x5_in_fwd(const float* x, const float* w, float* a1, int n, int cin, void* stream) {
+extern "C" int ugn_conv5x5_in_fwd(const float* x, const float* w, float* a1, uint32_t* a1_sign, int n, int cin, void* stream) {
   UGN_REQUIRE(x && w && a1 && n > 0, "ugn_conv5x5_in_fwd: null pointer or n <= 0");
   UGN_REQUIRE(cin == 1 || cin == 2, "ugn_conv5x5_in_fwd: cin must be 1 or 2 (got %d)", cin);
   hipStream_t st = (hipStream_t)stream;
-  if (cin == 1)
-    hipLaunchKernelGGL(conv5x5_fwd_kernel<1>, dim3(n * 16), dim3(256), 0, st, x, w, a1);
-  else
-    hipLaunchKernelGGL(conv5x5_fwd_kernel<2>, dim3(n * 16), dim3(256), 0, st, x, w, a1);
+#define UGN_C5F(C_, S_) hipLaunchKernelGGL((conv5x5_fwd_kernel<C_, S_>), dim3(n * 16), dim3(256), 0, st, x, w, a1, a1_sign)
+  if (cin == 1) {
+    if (a1_sign) UGN_C5F(1, true); else UGN_C5F(1, false);
+  } else {
+    if (a1_sign) UGN_C5F(2, true); else UGN_C5F(2, false);
+  }
+#undef UGN_C5F
   UGN_CHECK_LAUNCH("conv5x5_fwd");
   return 0;
 }
@@ -246,8 +270,8 @@ extern "C" size_t ugn_conv5x5_in_wgrad_ws(int n, int cin) {
   return (size_t)groups * 25 * cin * 32 * sizeof(float);
 }
 
-extern "C" int ugn_conv5x5_in_wgrad(const float* x, const float* dz1, float* dw, int n, int cin, void* ws, size_t ws_bytes,
-                                    void* stream) {
+extern "C" int ugn_conv5x5_in_wgrad(const float* x, const float* dz1, const uint32_t* a1_sign, float* dw, int n, int cin,
+                                    void* ws, size_t ws_bytes, void* stream) {
   UGN_REQUIRE(x && dz1 && dw && ws && n > 0, "ugn_conv5x5_in_wgrad: null pointer or n <= 0");
   UGN_REQUIRE(cin == 1 || cin == 2, "ugn_conv5x5_in_wgrad: cin must be 1 or 2 (got %d)", cin);
   UGN_REQUIRE(ws_bytes >= ugn_conv5x5_in_wgrad_ws(n, cin), "ugn_conv5x5_in_wgrad: workspace too small");
@@ -261,18 +285,26 @@ extern "C" int ugn_conv5x5_in_wgrad(const float* x, const float* dz1, float* dw,
                 "ugn_conv5x5_in_wgrad: cannot allocate the zero block");
     zeros = p;
   }
-  const int lds = (2 * 256 * 36 + 2 * ((25 * 16 * cin + 63) / 64) * 64) * 4;
+  const int lds = (2 * 256 * 36 + 2 * ((25 * 16 * cin + 63) / 64) * 64 + 2 * 256) * 4;
   static bool attr_done[3] = {false, false, false};
   if (!attr_done[cin]) {
-    hipError_t e = cin == 1 ? hipFuncSetAttribute((const void*)conv5x5_wgrad_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)
-                            : hipFuncSetAttribute((const void*)conv5x5_wgrad_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    UGN_REQUIRE(e == hipSuccess, "ugn_conv5x5_in_wgrad: hipFuncSetAttribute: %s", hipGetErrorString(e));
+    const void* fns[4] = {(const void*)conv5x5_wgrad_kernel<1, false>, (const void*)conv5x5_wgrad_kernel<1, true>,
+                          (const void*)conv5x5_wgrad_kernel<2, false>, (const void*)conv5x5_wgrad_kernel<2, true>};
+    for (int v = 0; v < 2; ++v) {
+      hipError_t e = hipFuncSetAttribute(fns[(cin - 1) * 2 + v], hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      UGN_REQUIRE(e == hipSuccess, "ugn_conv5x5_in_wgrad: hipFuncSetAttribute: %s", hipGetErrorString(e));
+    }
     attr_done[cin] = true;
   }
-  if (cin == 1)
-    hipLaunchKernelGGL(conv5x5_wgrad_kernel<1>, dim3(groups), dim3(256), lds, st, x, dz1, (float*)ws, (const float*)zeros, tiles);
-  else
-    hipLaunchKernelGGL(conv5x5_wgrad_kernel<2>, dim3(groups), dim3(256), lds, st, x, dz1, (float*)ws, (const float*)zeros, tiles);
+#define UGN_C5W(C_, S_)                                                                                                     \
+  hipLaunchKernelGGL((conv5x5_wgrad_kernel<C_, S_>), dim3(groups), dim3(256), lds, st, x, dz1, (float*)ws, (const float*)zeros, \
+                     a1_sign, tiles)
+  if (cin == 1) {
+    if (a1_sign) UGN_C5W(1, true); else UGN_C5W(1, false);
+  } else {
+    if (a1_sign) UGN_C5W(2, true); else UGN_C5W(2, false);
+  }
+#undef UGN_C5W
   UGN_CHECK_LAUNCH("conv5x5_wgrad");
   const int nelem = 25 * cin * 32;
   hipLaunchKernelGGL(reduce5_kernel, dim3((nelem + 7) / 8), dim3(256), 0, st, (const float*)ws, dw, nelem, groups);

@@ -38,6 +38,7 @@ USE_WINOGRAD = os.environ.get("UGN_WINO", "1") != "0"
 WINO_DGRAD = ("a2", "a3", "a4", "a5", "a6", "b1", "b2", "b3", "b4")
 _wgrad3x3 = ops.conv3x3_wgrad_wino if USE_WINOGRAD else ops.conv3x3_wgrad
 PAIR_LAUNCHES = os.environ.get("UGN_PAIR", "1") != "0"   # frame-level layer + set-level twin in one launch
+A1_SIGN_BITS = os.environ.get("UGN_A1_BITS", "1") != "0"   # LeakyReLU' of the first layer from 1 bit per element
 # UGN_ROUTED=1: form the set-max gradient inside the a3 / a5 data-gradient epilogues instead of materialising it with
 # setmax_bwd (bit-identical; measured 2.5 % SLOWER on MI355X: three operand loads per element make those epilogues spill).
 ROUTED = USE_WINOGRAD and os.environ.get("UGN_ROUTED", "0") == "1"
@@ -180,7 +181,10 @@ class Encoder:
             self.repack()
         xf = x.reshape(n, 60, 60, self.cin)
         A["x"] = xf
-        a1 = ops.conv5x5_in_fwd(xf, self.W("a1"), self._buf(A, "a1", (n, 64, 64, 32)))
+        # a1's LeakyReLU' factor travels as one bit per element: the a2 data gradient then skips re-reading a1 (315 MB per
+        # modality) and the 5x5 weight gradient applies the factor while it multiplies
+        a1 = ops.conv5x5_in_fwd(xf, self.W("a1"), self._buf(A, "a1", (n, 64, 64, 32)),
+                                sign=self._buf(A, "a1s", (n, 64, 64), torch.int32) if A1_SIGN_BITS else None)
         p2, i2 = self.conv("a2", a1, True, self._buf(A, "p2", (n, 32, 32, 32)),
                                  self._buf(A, "i2", (n, 32, 32, 32), U8))
         if ROUTED:   # also count the maxima: the set-max gradient is then formed inside the a3 / a5 data-gradient epilogues
@@ -250,8 +254,12 @@ class Encoder:
             dp2 = self.dgrad("a3", dz3, 32, act=A["p2"], addend=g2, out=g2)
         # block 1 (a1, a2)
         _wgrad3x3(A["a1"], dp2, 32, dz_idx=A["i2"], dw=self.G("a2"))
-        dz1 = self.dgrad("a2", dp2, 64, dz_idx=A["i2"], act=A["a1"], out=buf("dz1", (n, 64, 64, 32)))
-        ops.conv5x5_in_wgrad(A["x"], dz1, self.G("a1"))
+        if A1_SIGN_BITS:
+            dz1 = self.dgrad("a2", dp2, 64, dz_idx=A["i2"], out=buf("dz1", (n, 64, 64, 32)))   # dL/da1
+            ops.conv5x5_in_wgrad(A["x"], dz1, self.G("a1"), sign=A["a1s"])
+        else:
+            dz1 = self.dgrad("a2", dp2, 64, dz_idx=A["i2"], act=A["a1"], out=buf("dz1", (n, 64, 64, 32)))
+            ops.conv5x5_in_wgrad(A["x"], dz1, self.G("a1"))
 
 
 class GaitCore:

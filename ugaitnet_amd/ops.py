@@ -69,21 +69,27 @@ class _Timed:
             TIMING.setdefault(self.name, []).append((self.e0, self.e1))
 
 
-def conv5x5_in_fwd(x, w, out=None):
+def conv5x5_in_fwd(x, w, out=None, sign=None):
+    """sign (optional int32 [n,64,64]): receives one bit per output element, (a1 > 0), for conv5x5_in_wgrad."""
     n, cin = x.shape[0], x.shape[3]
     _chk(x), _chk(w)
     out = torch.empty((n, 64, 64, 32), dtype=F32, device=x.device) if out is None else out
-    call("ugn_conv5x5_in_fwd", ptr(x), ptr(w), ptr(out), n, cin, _stream())
+    if sign is not None:
+        _chk(sign, torch.int32)
+    call("ugn_conv5x5_in_fwd", ptr(x), ptr(w), ptr(out), ptr(sign), n, cin, _stream())
     return out
 
 
-def conv5x5_in_wgrad(x, dz1, dw=None):
+def conv5x5_in_wgrad(x, dz1, dw=None, sign=None):
+    """sign given: dz1 is dL/da1 and the LeakyReLU' factor of a1 is applied inside, from the bits of conv5x5_in_fwd."""
     n, cin = x.shape[0], x.shape[3]
     _chk(x), _chk(dz1)
     dw = torch.empty((5, 5, cin, 32), dtype=F32, device=x.device) if dw is None else dw
     nbytes = _lib.load().ugn_conv5x5_in_wgrad_ws(n, cin)
     ws = _WS.get(nbytes, x.device)
-    call("ugn_conv5x5_in_wgrad", ptr(x), ptr(dz1), ptr(dw), n, cin, ptr(ws), ws.numel(), _stream())
+    if sign is not None:
+        _chk(sign, torch.int32)
+    call("ugn_conv5x5_in_wgrad", ptr(x), ptr(dz1), ptr(sign), ptr(dw), n, cin, ptr(ws), ws.numel(), _stream())
     return dw
 
 
