@@ -13,13 +13,17 @@ constexpr int NBINS = 62, FEAT = 128, HID = 256;
 // ------------------------------------------------------------------------------------------------------
 // per-bin FC
 // ------------------------------------------------------------------------------------------------------
-constexpr int FC_BT = 8;
+constexpr int FC_BT = 24;   // samples per pass (the reference batch per GPU)
 
+// out[k][b][o] = sum_i feat[k][b][i] * W[k][i][o].  Workgroup (bin k, output quarter oq): 256 threads = 64 outputs x 4
+// input quarters, so a thread streams 32 weights instead of 128 and 248 workgroups instead of 62 share the 8 MB of weights;
+// the four partial sums are combined in a fixed order through LDS (bitwise reproducible).
 __global__ __launch_bounds__(256) void binfc_fwd_kernel(const float* __restrict__ feat, const float* __restrict__ w,
                                                         float* __restrict__ out, int bsz) {
-  __shared__ float sF[FC_BT][FEAT];
-  const int k = blockIdx.x, o = threadIdx.x;
-  const float* wk = w + (size_t)k * FEAT * HID;
+  __shared__ float sF[FC_BT][FEAT];          // 12 KB
+  __shared__ float sR[3][FC_BT][64];         // partials of input quarters 1..3
+  const int k = blockIdx.x, oq = blockIdx.y, ol = threadIdx.x & 63, iq = threadIdx.x >> 6;
+  const float* wk = w + ((size_t)k * FEAT + iq * 32) * HID + oq * 64 + ol;
   for (int b0 = 0; b0 < bsz; b0 += FC_BT) {
     __syncthreads();
     for (int e = threadIdx.x; e < FC_BT * FEAT; e += 256) {
@@ -30,14 +34,23 @@ __global__ __launch_bounds__(256) void binfc_fwd_kernel(const float* __restrict_
     float acc[FC_BT];
 #pragma unroll
     for (int bb = 0; bb < FC_BT; ++bb) acc[bb] = 0.f;
-    for (int i = 0; i < FEAT; ++i) {
-      const float wv = wk[(size_t)i * HID + o];
+#pragma unroll 8
+    for (int i = 0; i < 32; ++i) {
+      const float wv = wk[(size_t)i * HID];
 #pragma unroll
-      for (int bb = 0; bb < FC_BT; ++bb) acc[bb] = fmaf(sF[bb][i], wv, acc[bb]);
+      for (int bb = 0; bb < FC_BT; ++bb) acc[bb] = fmaf(sF[bb][iq * 32 + i], wv, acc[bb]);
     }
+    if (iq > 0) {
 #pragma unroll
-    for (int bb = 0; bb < FC_BT; ++bb)
-      if (b0 + bb < bsz) out[((size_t)k * bsz + b0 + bb) * HID + o] = acc[bb];
+      for (int bb = 0; bb < FC_BT; ++bb) sR[iq - 1][bb][ol] = acc[bb];
+    }
+    __syncthreads();
+    if (iq == 0) {
+#pragma unroll
+      for (int bb = 0; bb < FC_BT; ++bb)
+        if (b0 + bb < bsz)
+          out[((size_t)k * bsz + b0 + bb) * HID + oq * 64 + ol] = ((acc[bb] + sR[0][bb][ol]) + sR[1][bb][ol]) + sR[2][bb][ol];
+    }
   }
 }
 
@@ -185,7 +198,7 @@ __global__ void l2norm_bwd_kernel(const float* __restrict__ f, const float* __re
 // ------------------------------------------------------------------------------------------------------
 // classification head
 // ------------------------------------------------------------------------------------------------------
-constexpr int HD_BT = 8;
+constexpr int HD_BT = 24;                    // samples per pass: one pass for the reference batch, weights read once
 constexpr int HD_DQ = 64;                    // features per workgroup
 constexpr int HD_PARTS = NBINS * (HID / HD_DQ);   // 248 partial-logit slabs
 
@@ -234,17 +247,24 @@ __device__ __forceinline__ float block_reduce(float v, float* sRed, bool is_max)
 }
 
 // one workgroup per sample: logits = bc + sum_k part; softmax; loss; dlogits; top-1 hit
-__global__ __launch_bounds__(256) void head_softmax_kernel(const float* __restrict__ part, const float* __restrict__ bc,
+__global__ __launch_bounds__(1024) void head_softmax_kernel(const float* __restrict__ part, const float* __restrict__ bc,
                                                            const float* __restrict__ onehot, float* __restrict__ probs,
                                                            float* __restrict__ row_loss, float* __restrict__ dlogits,
                                                            float* __restrict__ hit, float grad_scale, int bsz, int ncls) {
   __shared__ float sRed[4];
   __shared__ int sArg[2];
-  const int b = blockIdx.x, c = threadIdx.x;
+  __shared__ float sZ[3][256];
+  // 1024 threads: slab lane sl sums slabs sl, sl+4, ...; lanes 1..3 hand their sums to lane 0 (fixed order), which goes on
+  const int b = blockIdx.x, c = threadIdx.x & 255, sl = threadIdx.x >> 8;
+  float zp = 0.f;
+  if (c < ncls)
+    for (int k = sl; k < HD_PARTS; k += 4) zp += part[((size_t)k * bsz + b) * ncls + c];
+  if (sl > 0) sZ[sl - 1][c] = zp;
+  __syncthreads();
+  if (sl > 0) return;
   float z = -INFINITY, t = 0.f;
   if (c < ncls) {
-    z = bc[c];
-    for (int k = 0; k < HD_PARTS; ++k) z += part[((size_t)k * bsz + b) * ncls + c];
+    z = bc[c] + (((zp + sZ[0][c]) + sZ[1][c]) + sZ[2][c]);
     t = onehot[(size_t)b * ncls + c];
   }
   const float zmax = block_reduce(z, sRed, true);
@@ -279,8 +299,11 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
                                                        int bsz, int ncls) {
   __shared__ float sS[HB_BT][HD_DQ];    // 4 KB
   __shared__ float sL[HB_BT][HID];      // dlogits rows (ncls <= 256), 16 KB
+  extern __shared__ float sWc[];        // [HD_DQ][ncls + 1]: this workgroup's slice of wc, read coalesced once
   const int k = blockIdx.x, q = blockIdx.y, tid = threadIdx.x;
   const int d0 = q * HD_DQ;
+  const int ldw = ncls + 1;
+  for (int e = tid; e < HD_DQ * ncls; e += 256) sWc[(e / ncls) * ldw + e % ncls] = wc[((size_t)k * HID + d0) * ncls + e];
   float bsum = 0.f;
   for (int b0 = 0; b0 < bsz; b0 += HB_BT) {
     const int nb = min(HB_BT, bsz - b0);
@@ -310,7 +333,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
     {   // dsig[k][b][d] (+)= sum_c dlogits[b][c] * wc[k*256+d][c]; thread = (d, sample quad): 64 x 4 threads
       const int d = tid & 63, bq = tid >> 6;
       float acc[4] = {0.f, 0.f, 0.f, 0.f};
-      const float* wrow = wc + ((size_t)k * HID + d0 + d) * ncls;
+      const float* wrow = sWc + d * ldw;
       for (int c = 0; c < ncls; ++c) {
         const float wv = wrow[c];
 #pragma unroll
@@ -452,7 +475,7 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
 
 extern "C" int ugn_binfc_fwd(const float* feat, const float* w, float* out, int b, void* stream) {
   UGN_REQUIRE(feat && w && out && b > 0, "ugn_binfc_fwd: bad arguments");
-  hipLaunchKernelGGL(binfc_fwd_kernel, dim3(NBINS), dim3(256), 0, (hipStream_t)stream, feat, w, out, b);
+  hipLaunchKernelGGL(binfc_fwd_kernel, dim3(NBINS, HID / 64), dim3(256), 0, (hipStream_t)stream, feat, w, out, b);
   UGN_CHECK_LAUNCH("binfc_fwd");
   return 0;
 }
@@ -514,7 +537,7 @@ extern "C" int ugn_head_fwd(const float* sig, const float* wc, const float* bc, 
   UGN_REQUIRE(ncls >= 1 && ncls <= 256, "ugn_head_fwd: ncls must be 1..256 (got %d)", ncls);
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(head_partial_kernel, dim3(NBINS, HID / HD_DQ), dim3(256), 0, st, sig, wc, part, b, ncls);
-  hipLaunchKernelGGL(head_softmax_kernel, dim3(b), dim3(256), 0, st, part, bc, onehot, probs, row_loss, dlogits, hit,
+  hipLaunchKernelGGL(head_softmax_kernel, dim3(b), dim3(1024), 0, st, part, bc, onehot, probs, row_loss, dlogits, hit,
                      grad_scale, b, ncls);
   UGN_CHECK_LAUNCH("head_fwd");
   return 0;
@@ -524,7 +547,8 @@ extern "C" int ugn_head_bwd(const float* sig, const float* wc, const float* dlog
                             int accumulate, int b, int ncls, void* stream) {
   UGN_REQUIRE(sig && wc && dlogits && dwc && dbc && dsig && b > 0, "ugn_head_bwd: bad arguments");
   UGN_REQUIRE(ncls >= 1 && ncls <= 256, "ugn_head_bwd: ncls must be 1..256 (got %d)", ncls);
-  hipLaunchKernelGGL(head_bwd_kernel, dim3(NBINS, HID / HD_DQ), dim3(256), 0, (hipStream_t)stream, sig, wc, dlogits, dwc, dbc, dsig,
+  hipLaunchKernelGGL(head_bwd_kernel, dim3(NBINS, HID / HD_DQ), dim3(256), (size_t)HD_DQ * (ncls + 1) * sizeof(float),
+                     (hipStream_t)stream, sig, wc, dlogits, dwc, dbc, dsig,
                      accumulate, b, ncls);
   UGN_CHECK_LAUNCH("head_bwd");
   return 0;
