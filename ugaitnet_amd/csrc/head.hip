@@ -54,7 +54,7 @@ __global__ __launch_bounds__(256) void binfc_fwd_kernel(const float* __restrict_
   }
 }
 
-constexpr int FCB_BT = 16;   // samples per pass
+constexpr int FCB_BT = 24;   // samples per pass (one pass for the reference batch: dW is written once, not read-modified)
 constexpr int FCB_IQ = 32;   // input features per workgroup (grid.y = 128 / FCB_IQ)
 
 // dW[k][i][o] = sum_b feat[k][b][i] * dout[k][b][o];  dfeat[k][b][i] = sum_o dout[k][b][o] * W[k][i][o].
@@ -94,17 +94,19 @@ __global__ __launch_bounds__(256) void binfc_bwd_kernel(const float* __restrict_
         else dwk[(size_t)i * HID + tid] += acc;
       }
     }
-    {   // dfeat for this slice; thread = (i, sample pair): 32 x 8 threads, 2 samples each
+    {   // dfeat for this slice; thread = (i, sample triple): 32 x 8 threads, 3 samples each
       const int i = tid & 31, bq = tid >> 5;
-      float a0 = 0.f, a1 = 0.f;
+      float a0 = 0.f, a1 = 0.f, a2 = 0.f;
 #pragma unroll 8
       for (int o = 0; o < HID; ++o) {
         const float wv = sW[i][o];
-        a0 = fmaf(sD[2 * bq][o], wv, a0);
-        a1 = fmaf(sD[2 * bq + 1][o], wv, a1);
+        a0 = fmaf(sD[3 * bq][o], wv, a0);
+        a1 = fmaf(sD[3 * bq + 1][o], wv, a1);
+        a2 = fmaf(sD[3 * bq + 2][o], wv, a2);
       }
-      if (2 * bq < nb) dfeat[((size_t)k * bsz + b0 + 2 * bq) * FEAT + i0 + i] = a0;
-      if (2 * bq + 1 < nb) dfeat[((size_t)k * bsz + b0 + 2 * bq + 1) * FEAT + i0 + i] = a1;
+      if (3 * bq < nb) dfeat[((size_t)k * bsz + b0 + 3 * bq) * FEAT + i0 + i] = a0;
+      if (3 * bq + 1 < nb) dfeat[((size_t)k * bsz + b0 + 3 * bq + 1) * FEAT + i0 + i] = a1;
+      if (3 * bq + 2 < nb) dfeat[((size_t)k * bsz + b0 + 3 * bq + 2) * FEAT + i0 + i] = a2;
     }
   }
 }
@@ -290,7 +292,7 @@ __global__ __launch_bounds__(1024) void head_softmax_kernel(const float* __restr
   }
 }
 
-constexpr int HB_BT = 16;
+constexpr int HB_BT = 24;   // one pass for the reference batch: dwc is written once
 
 // Workgroup (k, q) owns features d in [64q, 64q+64) of bin k: rows (k*256 + d) of wc / dwc and columns d of dsig.
 __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__ sig, const float* __restrict__ wc,
@@ -330,19 +332,19 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
         if (b0 == 0) dwc[o] = acc; else dwc[o] += acc;
       }
     }
-    {   // dsig[k][b][d] (+)= sum_c dlogits[b][c] * wc[k*256+d][c]; thread = (d, sample quad): 64 x 4 threads
+    {   // dsig[k][b][d] (+)= sum_c dlogits[b][c] * wc[k*256+d][c]; thread = (d, sample sextet): 64 x 4 threads
       const int d = tid & 63, bq = tid >> 6;
-      float acc[4] = {0.f, 0.f, 0.f, 0.f};
+      float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
       const float* wrow = sWc + d * ldw;
       for (int c = 0; c < ncls; ++c) {
         const float wv = wrow[c];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[j] = fmaf(sL[4 * bq + j][c], wv, acc[j]);
+        for (int j = 0; j < 6; ++j) acc[j] = fmaf(sL[6 * bq + j][c], wv, acc[j]);
       }
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
-        if (4 * bq + j < nb) {
-          const size_t o = ((size_t)k * bsz + b0 + 4 * bq + j) * HID + d0 + d;
+      for (int j = 0; j < 6; ++j)
+        if (6 * bq + j < nb) {
+          const size_t o = ((size_t)k * bsz + b0 + 6 * bq + j) * HID + d0 + d;
           dsig[o] = accumulate ? dsig[o] + acc[j] : acc[j];
         }
     }
@@ -547,6 +549,12 @@ extern "C" int ugn_head_bwd(const float* sig, const float* wc, const float* dlog
                             int accumulate, int b, int ncls, void* stream) {
   UGN_REQUIRE(sig && wc && dlogits && dwc && dbc && dsig && b > 0, "ugn_head_bwd: bad arguments");
   UGN_REQUIRE(ncls >= 1 && ncls <= 256, "ugn_head_bwd: ncls must be 1..256 (got %d)", ncls);
+  static bool attr_done = false;
+  if (!attr_done) {   // static 30 KB + up to 64 x 257 floats of dynamic LDS
+    hipError_t e = hipFuncSetAttribute((const void*)head_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, HD_DQ * 257 * 4);
+    UGN_REQUIRE(e == hipSuccess, "ugn_head_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
+    attr_done = true;
+  }
   hipLaunchKernelGGL(head_bwd_kernel, dim3(NBINS, HID / HD_DQ), dim3(256), (size_t)HD_DQ * (ncls + 1) * sizeof(float),
                      (hipStream_t)stream, sig, wc, dlogits, dwc, dbc, dsig,
                      accumulate, b, ncls);
