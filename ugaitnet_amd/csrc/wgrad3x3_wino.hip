@@ -19,10 +19,13 @@ namespace {
 
 constexpr int RH = 8, RW = 16;                      // region: 8 x 16 output pixels = 4 x 8 tiles
 constexpr int PW = RW + 2, PHH = RH + 2, NPIX = PHH * PW;   // 10 x 18 halo
-constexpr int CS = 40;                               // halo pixel stride (floats), 32 channels + 8 pad: the 4 tiles of an
-                                                     // MFMA step sit 2 pixels = 80 floats apart -> banks 0/16, conflict-free
+constexpr int CS = 32;                               // halo pixel stride (floats): 32 channels, NO padding.  The 4 tiles of an
+// MFMA step sit 2 pixels apart, i.e. on the same banks; instead of padding the pixel (which costs LDS-DMA pieces: an LDS-DMA
+// instruction is the most expensive thing the loop issues) the 16-byte quads of a pixel are XOR-swizzled by 4 when bit 1 of
+// the pixel index is set: neighbouring tiles land 16 banks apart, conflict-free, and every DMA lane carries payload.
 constexpr int SPX = CS / 4;                          // 16-byte slots per halo pixel
-constexpr int HSLOTS = NPIX * SPX, HPIECES = (HSLOTS + 63) / 64;   // 1800 slots -> 29 pieces of 1 KB
+constexpr int HSLOTS = NPIX * SPX, HPIECES = (HSLOTS + 63) / 64;   // 1440 slots -> 23 pieces of 1 KB
+__device__ __forceinline__ constexpr int swz(int p) { return ((p >> 1) & 1) * 4; }   // quad XOR of pixel p
 constexpr int SIN = HPIECES * 256;                   // floats per halo buffer
 
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
@@ -39,11 +42,11 @@ __device__ __forceinline__ void dma16(const void* gsrc, unsigned lds_dst_uniform
 
 template <int COC, int DZ_UNPOOL>
 struct DzCfg {
-  // plain : [128 px][COC + 8] floats                              -> (COC/4 + 2) 16-byte slots per pixel
+  // plain : [128 px][COC] floats, quads XOR-swizzled like the halo -> COC/4 16-byte slots per pixel
   // pooled: [32 pooled px][COC values + COC argmax bytes (+ pad)]  -> 20 (COC = 64) / 12 (COC = 32) slots per pooled pixel
   // (strides chosen so that the 4 tiles of an MFMA step fall into different bank halves)
   static constexpr int PX = DZ_UNPOOL ? 32 : 128;
-  static constexpr int SPP = DZ_UNPOOL ? (COC == 64 ? 20 : 12) : (COC / 4 + 2);
+  static constexpr int SPP = DZ_UNPOOL ? (COC == 64 ? 20 : 12) : COC / 4;
   static constexpr int STRIDE = SPP * 4;              // floats per (pooled) pixel
   static constexpr int SLOTS = PX * SPP, PIECES = (SLOTS + 63) / 64;
   static constexpr int SDZ = PIECES * 256;            // floats per buffer
@@ -96,7 +99,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_wino_kernel(const WgJob j0, cons
     inst = inst < HPIECES ? inst : HPIECES - 1;
     int slot = inst * 64 + lane;
     slot = slot < HSLOTS ? slot : HSLOTS - 1;
-    const int p = slot / SPX, c4 = slot - p * SPX;
+    const int p = slot / SPX, c4 = (slot - p * SPX) ^ swz(p);   // the quad that belongs at this LDS position
     hgeo[j] = ((p / PW) << 16) | ((p % PW) << 8) | c4;
   }
 #pragma unroll
@@ -105,7 +108,8 @@ __global__ __launch_bounds__(512, 2) void wgrad_wino_kernel(const WgJob j0, cons
     inst = inst < D::PIECES ? inst : D::PIECES - 1;
     int slot = inst * 64 + lane;
     slot = slot < D::SLOTS ? slot : D::SLOTS - 1;
-    dgeo[j] = ((slot / D::SPP) << 8) | (slot % D::SPP);
+    const int dp = slot / D::SPP, dq = slot % D::SPP;
+    dgeo[j] = (dp << 8) | (DZ_UNPOOL ? dq : (dq ^ swz(dp)));
   }
   auto issue_dma = [&](int region, int buf) {
     const int img = region / RPI, rrem = region % RPI;
@@ -116,7 +120,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_wino_kernel(const WgJob j0, cons
       inst = inst < HPIECES ? inst : HPIECES - 1;
       const int yy = hgeo[j] >> 16, xx = (hgeo[j] >> 8) & 0xff, c4 = hgeo[j] & 0xff;
       const int gy = ry0 - 1 + yy, gx = rx0 - 1 + xx;
-      const bool ok = c4 < 8 && (unsigned)gy < (unsigned)HW && (unsigned)gx < (unsigned)HW;
+      const bool ok = (unsigned)gy < (unsigned)HW && (unsigned)gx < (unsigned)HW;
       const float* src = ok ? in + (((size_t)img * HW + gy) * HW + gx) * CI + cic * 32 + c4 * 4 : zeros;
       dma16(src, sin_bytes + (unsigned)buf * SIN * 4u + (unsigned)inst * 1024u);
     }
@@ -133,7 +137,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_wino_kernel(const WgJob j0, cons
                           : (q < COC / 4 + COC / 16 ? (const void*)(dz_idx + o + (q - COC / 4) * 16) : (const void*)zeros);
       } else {
         const size_t o = (((size_t)img * HW + ry0 + (p >> 4)) * HW + rx0 + (p & 15)) * CO + coc * COC;
-        src = q < COC / 4 ? (const void*)(dz + o + q * 4) : (const void*)zeros;
+        src = (const void*)(dz + o + q * 4);
       }
       dma16(src, sdz_bytes + (unsigned)buf * D::SDZ * 4u + (unsigned)inst * 1024u);
     }
@@ -164,9 +168,15 @@ __global__ __launch_bounds__(512, 2) void wgrad_wino_kernel(const WgJob j0, cons
     auto load_raw = [&](int st) {
       const int t = ks * TPW + st * 4 + kq;             // this lane's tile of the step: row t>>3 (0..3), col t&7
       const int tr = t >> 3, tc = t & 7;
-      const float* pb = sIn + ((2 * tr) * PW + 2 * tc) * CS + cib * 16 + lj;
+      // pixel p0 + off: p0 is even, so its swizzle bit is bit1(p0) ^ bit1(off): two lane bases, compile-time choice per element
+      const int p0 = (2 * tr) * PW + 2 * tc, cq = cib * 16 + lj;
+      const float* pb0 = sIn + p0 * CS + (((cq >> 2) ^ swz(p0)) << 2) + (cq & 3);
+      const float* pb1 = sIn + p0 * CS + (((cq >> 2) ^ swz(p0) ^ 4) << 2) + (cq & 3);
 #pragma unroll
-      for (int e = 0; e < 16; ++e) d[e] = pb[((e >> 2) * PW + (e & 3)) * CS];
+      for (int e = 0; e < 16; ++e) {
+        const int off = (e >> 2) * PW + (e & 3);
+        d[e] = (swz(off) ? pb1 : pb0)[off * CS];
+      }
 #pragma unroll
       for (int cb = 0; cb < 2; ++cb) {
         const int co = cop * 32 + cb * 16 + lj;
@@ -175,7 +185,9 @@ __global__ __launch_bounds__(512, 2) void wgrad_wino_kernel(const WgJob j0, cons
           yv[cb][0] = pp[co];
           ypos[cb] = reinterpret_cast<const uint8_t*>(pp + COC)[co];
         } else {
-          const float* pp = sDz + ((2 * tr) * RW + 2 * tc) * D::STRIDE + co;
+          // pixels q0, q0+1, q0+16, q0+17 (q0 even): the same swizzle bit for all four (bit 1 of 16 and 17 is 0)
+          const int q0 = (2 * tr) * RW + 2 * tc;
+          const float* pp = sDz + q0 * D::STRIDE + (((co >> 2) ^ swz(q0)) << 2) + (co & 3);
           yv[cb][0] = pp[0]; yv[cb][1] = pp[D::STRIDE]; yv[cb][2] = pp[RW * D::STRIDE]; yv[cb][3] = pp[(RW + 1) * D::STRIDE];
         }
       }
