@@ -73,6 +73,9 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # torch ships its own libamdhip64; it must be the copy already in the process when ours is resolved, or the library binds
+    # to a second HIP runtime that knows no device ("no ROCm-capable device is detected" at the first launch)
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise UgnError(
             "libugaitnet_hip.so is missing (%s). Build it with `python -m ugaitnet_amd.build`; "
