@@ -166,17 +166,21 @@ __global__ __launch_bounds__(512, 2) void wgrad_wino_kernel(const WgJob j0, cons
     float d[16], yv[2][4];
     unsigned ypos[2];
     auto load_raw = [&](int st) {
-      const int t = ks * TPW + st * 4 + kq;             // this lane's tile of the step: row t>>3 (0..3), col t&7
-      const int tr = t >> 3, tc = t & 7;
-      // pixel p0 + off: p0 is even, so its swizzle bit is bit1(p0) ^ bit1(off): two lane bases, compile-time choice per element
-      const int p0 = (2 * tr) * PW + 2 * tc, cq = cib * 16 + lj;
-      const float* pb0 = sIn + p0 * CS + (((cq >> 2) ^ swz(p0)) << 2) + (cq & 3);
-      const float* pb1 = sIn + p0 * CS + (((cq >> 2) ^ swz(p0) ^ 4) << 2) + (cq & 3);
+      // this lane's tile of the step: t = ks*TPW + st*4 + kq, row t>>3 (0..3), col t&7.  Split into a lane part (kq, ks) and
+      // a compile-time step part so that no address arithmetic is left inside the loop: the tile origin p0 = 2*(18*tr + tc)
+      // has swizzle bit (18*tr + tc) & 1 = tc & 1 = kq & 1 -- a lane constant.
+      const int tr0 = (ks * TPW) >> 3, tc0 = ((ks * TPW) & 7) + kq;          // step 0 tile (kq < 4, TPW is 8 or 16)
+      const int dtr = (st * 4) >> 3, dtc = (st * 4) & 7;                      // compile-time step advance (tc0 + dtc < 8)
+      const int cq = cib * 16 + lj, sw = (kq & 1) * 4;
+      const float* pl0 = sIn + ((2 * tr0) * PW + 2 * tc0) * CS + (((cq >> 2) ^ sw) << 2) + (cq & 3);   // lane constants
+      const float* pl1 = sIn + ((2 * tr0) * PW + 2 * tc0) * CS + (((cq >> 2) ^ sw ^ 4) << 2) + (cq & 3);
+      const int pst = ((2 * dtr) * PW + 2 * dtc) * CS;                        // compile-time
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int off = (e >> 2) * PW + (e & 3);
-        d[e] = (swz(off) ? pb1 : pb0)[off * CS];
+        d[e] = (swz(off) ? pl1 : pl0)[pst + off * CS];
       }
+      const int tr = tr0 + dtr, tc = tc0 + dtc;
 #pragma unroll
       for (int cb = 0; cb < 2; ++cb) {
         const int co = cop * 32 + cb * 16 + lj;
@@ -186,8 +190,8 @@ __global__ __launch_bounds__(512, 2) void wgrad_wino_kernel(const WgJob j0, cons
           ypos[cb] = reinterpret_cast<const uint8_t*>(pp + COC)[co];
         } else {
           // pixels q0, q0+1, q0+16, q0+17 (q0 even): the same swizzle bit for all four (bit 1 of 16 and 17 is 0)
-          const int q0 = (2 * tr) * RW + 2 * tc;
-          const float* pp = sDz + q0 * D::STRIDE + (((co >> 2) ^ swz(q0)) << 2) + (co & 3);
+          const int q0 = (2 * tr) * RW + 2 * tc;          // swizzle bit of q0 = (16*tr + tc) & 1 = kq & 1 as well
+          const float* pp = sDz + q0 * D::STRIDE + (((co >> 2) ^ sw) << 2) + (co & 3);
           yv[cb][0] = pp[0]; yv[cb][1] = pp[D::STRIDE]; yv[cb][2] = pp[RW * D::STRIDE]; yv[cb][3] = pp[(RW + 1) * D::STRIDE];
         }
       }
@@ -232,17 +236,20 @@ __global__ __launch_bounds__(512, 2) void wgrad_wino_kernel(const WgJob j0, cons
           }
         } else {
           const float y00 = yv[cb][0], y01 = yv[cb][1], y10 = yv[cb][2], y11 = yv[cb][3];
-          float q[4][2];   // A dY : rows (y0, y0+y1, y0-y1, -y1)
+          // A dY A^T has rows (y0, y0+y1, y0-y1, -y1) and the same pattern in the columns.  The two negations are NOT
+          // materialised (an MFMA operand takes no sign modifier: 8 v_xor per step): points of row 3 / column 3 accumulate
+          // with the opposite sign and the final G^T Z G subtracts them instead of adding (see the epilogue).
+          float q[4][2];
           q[0][0] = y00; q[0][1] = y01;
           q[1][0] = y00 + y10; q[1][1] = y01 + y11;
           q[2][0] = y00 - y10; q[2][1] = y01 - y11;
-          q[3][0] = -y10; q[3][1] = -y11;
+          q[3][0] = y10; q[3][1] = y11;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             Q[cb][r * 4 + 0] = q[r][0];
             Q[cb][r * 4 + 1] = q[r][0] + q[r][1];
             Q[cb][r * 4 + 2] = q[r][0] - q[r][1];
-            Q[cb][r * 4 + 3] = -q[r][1];
+            Q[cb][r * 4 + 3] = q[r][1];
           }
         }
       }
@@ -295,14 +302,14 @@ __global__ __launch_bounds__(512, 2) void wgrad_wino_kernel(const WgJob j0, cons
           const float z0 = acc[0 + c][cb][r], z1 = acc[4 + c][cb][r], z2 = acc[8 + c][cb][r], z3 = acc[12 + c][cb][r];
           t[0][c] = z0 + 0.5f * (z1 + z2);
           t[1][c] = 0.5f * (z1 - z2);
-          t[2][c] = 0.5f * (z1 + z2) + z3;
+          t[2][c] = DZ_UNPOOL ? 0.5f * (z1 + z2) + z3 : 0.5f * (z1 + z2) - z3;   // plain dz: row 3 was accumulated negated
         }
         float* o = dst + ((size_t)cib * 16 + 4 * kq + r) * COC + cop * 32 + cb * 16 + lj;
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
           o[(size_t)(a * 3 + 0) * 32 * COC] = t[a][0] + 0.5f * (t[a][1] + t[a][2]);
           o[(size_t)(a * 3 + 1) * 32 * COC] = 0.5f * (t[a][1] - t[a][2]);
-          o[(size_t)(a * 3 + 2) * 32 * COC] = 0.5f * (t[a][1] + t[a][2]) + t[a][3];
+          o[(size_t)(a * 3 + 2) * 32 * COC] = DZ_UNPOOL ? 0.5f * (t[a][1] + t[a][2]) + t[a][3] : 0.5f * (t[a][1] + t[a][2]) - t[a][3];
         }
       }
   }
