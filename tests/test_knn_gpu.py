@@ -17,7 +17,8 @@ def _data(rng, ncls, ng, nq, d, spread):
     return g, yg, q, yq
 
 
-@pytest.mark.parametrize("k,ng,nq,d", [(1, 70, 33, 64), (3, 500, 129, 256), (5, 200, 64, 100), (16, 100, 10, 36)])
+@pytest.mark.parametrize("k,ng,nq,d", [(1, 70, 33, 64), (3, 500, 129, 256), (5, 200, 64, 100), (16, 100, 10, 36), (3, 90, 40, 50),
+                                       (2, 65, 65, 33)])
 def test_knn_matches_oracle(k, ng, nq, d):
     from ugaitnet_amd.knn import KNeighborsClassifier
     rng = np.random.default_rng(k * 1000 + ng)

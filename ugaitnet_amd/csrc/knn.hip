@@ -44,21 +44,40 @@ __global__ __launch_bounds__(256) void knn_dist_kernel(const float* __restrict__
   const int qa = q0 + sr < nq ? q0 + sr : nq - 1, ga = g0 + sr < ng ? g0 + sr : ng - 1;   // clamped rows are never stored
   const float* pa = q + (size_t)qa * d + sk;
   const float* pb = g + (size_t)ga * d + sk;
+  // software pipeline: the global loads of K-tile t+1 are in flight while tile t is multiplied out of LDS
+  float4 va[2], vb[2];
+  const bool vec_ok = (d & 3) == 0;   // rows are 16-byte aligned only then
+  auto load_tile = [&](int k0) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int kk = k0 + sk + 4 * h;
+      if (vec_ok && kk + 3 < d) {
+        va[h] = *reinterpret_cast<const float4*>(pa + k0 + 4 * h);
+        vb[h] = *reinterpret_cast<const float4*>(pb + k0 + 4 * h);
+      } else {   // ragged tail of K or unaligned rows (the signature path has d = 15,872)
+        float ta[4], tb[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          ta[e] = kk + e < d ? pa[k0 + 4 * h + e] : 0.f;
+          tb[e] = kk + e < d ? pb[k0 + 4 * h + e] : 0.f;
+        }
+        va[h] = make_float4(ta[0], ta[1], ta[2], ta[3]);
+        vb[h] = make_float4(tb[0], tb[1], tb[2], tb[3]);
+      }
+    }
+  };
+  load_tile(0);
   for (int k0 = 0; k0 < d; k0 += KT) {
-    float va[8], vb[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const bool ok = k0 + sk + e < d;
-      va[e] = ok ? pa[k0 + e] : 0.f;
-      vb[e] = ok ? pb[k0 + e] : 0.f;
-    }
     __syncthreads();
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      sA[sr * LDT + sk + e] = va[e];
-      sB[sr * LDT + sk + e] = vb[e];
+    for (int h = 0; h < 2; ++h) {
+      float* da = sA + sr * LDT + sk + 4 * h;
+      float* db = sB + sr * LDT + sk + 4 * h;
+      da[0] = va[h].x; da[1] = va[h].y; da[2] = va[h].z; da[3] = va[h].w;
+      db[0] = vb[h].x; db[1] = vb[h].y; db[2] = vb[h].z; db[3] = vb[h].w;
     }
     __syncthreads();
+    if (k0 + KT < d) load_tile(k0 + KT);
 #pragma unroll
     for (int s = 0; s < KT / 2; ++s)
       acc = ugn_mfma(sA[(wm * 32 + li) * LDT + 2 * s + lh], sB[(wn * 32 + li) * LDT + 2 * s + lh], acc);
