@@ -116,8 +116,10 @@ int ugn_setmax_fwd_cnt(const float* p, const float* addend, float* m, float* sum
                        void* stream);
 /* out = a / b elementwise (n a multiple of 4): dL/dm divided by the number of maxima (TF's reduce_max gradient). */
 int ugn_div(const float* a, const float* b, float* out, size_t n, void* stream);
-int ugn_setmax_bwd(const float* p, const float* dm, float* out, int b, int l, size_t s, int apply_lrelu,
-                   void* stream);
+/* addend (optional, [b,l,s], may alias out): a second gradient path into p, summed before the LeakyReLU' factor:
+ * out = ((p == m) ? dm / #maxima : 0) + addend) * (apply_lrelu ? LeakyReLU'(p) : 1). */
+int ugn_setmax_bwd(const float* p, const float* dm, const float* addend, float* out, int b, int l, size_t s,
+                   int apply_lrelu, void* stream);
 
 /* ---- horizontal pyramid pooling, nets/mj_uwyhNets_ba.py:468-481.  a, s3 [b,16,16,128] -> feat [62,b,128] */
 int ugn_hpp_fwd(const float* a, const float* s3, float* feat, int b, void* stream);

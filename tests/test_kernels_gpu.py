@@ -312,6 +312,12 @@ def test_setmax(dev, with_add):
     close(got, ref, 1e-6, "setmax bwd")
     got = ops.setmax_bwd(T(p, dev), T(dm, dev), b, l, True)
     close(got, O.leaky_bwd_from_out(p, ref), 1e-6, "setmax bwd + lrelu'")
+    # second gradient path added before the LeakyReLU' factor, in place over the addend
+    extra = rng.normal(size=p.shape).astype(np.float32)
+    buf = T(extra, dev)
+    got = ops.setmax_bwd(T(p, dev), T(dm, dev), b, l, True, out=buf, addend=buf)
+    assert got.data_ptr() == buf.data_ptr()
+    close(got, O.leaky_bwd_from_out(p, ref + extra), 1e-6, "setmax bwd + addend + lrelu'")
 
 
 def test_hpp(dev):

@@ -64,15 +64,18 @@ __global__ void div_kernel(const float4* __restrict__ a, const float4* __restric
   out[e] = make_float4(x.x / y.x, x.y / y.y, x.z / y.z, x.w / y.w);
 }
 
-__device__ __forceinline__ float sm_route(float v, float mx, float g, int lrelu) {
-  float o = v == mx ? g : 0.f;
+__device__ __forceinline__ float sm_route(float v, float mx, float g, float add, int lrelu) {
+  float o = (v == mx ? g : 0.f) + add;
   if (lrelu) o *= ugn_lrelu_slope(v);
   return o;
 }
 
 // TF reduce_max gradient: the incoming gradient is divided equally among all maxima.
-__global__ __launch_bounds__(128) void setmax_bwd_kernel(const float4* __restrict__ p, const float4* __restrict__ dm, float4* __restrict__ out,
-                                  int l, size_t s4, int lrelu) {
+// `addend` (optional, may alias `out`): a second gradient path into p (the data gradient of the next frame-level layer);
+// out = (routed + addend) * LeakyReLU'(p): the Add of the two paths and the activation derivative cost one pass here instead
+// of two extra operand streams in that data gradient's epilogue.
+__global__ __launch_bounds__(128) void setmax_bwd_kernel(const float4* __restrict__ p, const float4* __restrict__ dm,
+                                                         const float4* addend, float4* out, int l, size_t s4, int lrelu) {
   const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= s4) return;
   const int b = blockIdx.y;
@@ -95,11 +98,14 @@ __global__ __launch_bounds__(128) void setmax_bwd_kernel(const float4* __restric
     }
   const float4 g = dm[(size_t)b * s4 + e];
   const float4 gs = make_float4(g.x / cnt.x, g.y / cnt.y, g.z / cnt.z, g.w / cnt.w);
+  const float4* asrc = addend ? addend + (size_t)b * l * s4 + e : nullptr;
 #pragma unroll
   for (int t = 0; t < MAXL; ++t)
-    if (t < l)
-      dst[(size_t)t * s4] = make_float4(sm_route(v[t].x, mx.x, gs.x, lrelu), sm_route(v[t].y, mx.y, gs.y, lrelu),
-                                        sm_route(v[t].z, mx.z, gs.z, lrelu), sm_route(v[t].w, mx.w, gs.w, lrelu));
+    if (t < l) {
+      const float4 a = asrc ? asrc[(size_t)t * s4] : make_float4(0.f, 0.f, 0.f, 0.f);
+      dst[(size_t)t * s4] = make_float4(sm_route(v[t].x, mx.x, gs.x, a.x, lrelu), sm_route(v[t].y, mx.y, gs.y, a.y, lrelu),
+                                        sm_route(v[t].z, mx.z, gs.z, a.z, lrelu), sm_route(v[t].w, mx.w, gs.w, a.w, lrelu));
+    }
 }
 
 // ---- HPP ------------------------------------------------------------------------------------------------
@@ -243,13 +249,13 @@ extern "C" int ugn_div(const float* a, const float* b, float* out, size_t n, voi
   return 0;
 }
 
-extern "C" int ugn_setmax_bwd(const float* p, const float* dm, float* out, int b, int l, size_t s, int apply_lrelu,
-                              void* stream) {
+extern "C" int ugn_setmax_bwd(const float* p, const float* dm, const float* addend, float* out, int b, int l, size_t s,
+                              int apply_lrelu, void* stream) {
   UGN_REQUIRE(p && dm && out && b > 0 && s > 0 && s % 4 == 0, "ugn_setmax_bwd: bad arguments");
   UGN_REQUIRE(l > 0 && l <= MAXL, "ugn_setmax_bwd: l must be in 1..%d (got %d)", MAXL, l);
   const size_t s4 = s / 4;
   hipLaunchKernelGGL(setmax_bwd_kernel, dim3((unsigned)((s4 + 127) / 128), b), dim3(128), 0, (hipStream_t)stream,
-                     (const float4*)p, (const float4*)dm, (float4*)out, l, s4, apply_lrelu);
+                     (const float4*)p, (const float4*)dm, (const float4*)addend, (float4*)out, l, s4, apply_lrelu);
   UGN_CHECK_LAUNCH("setmax_bwd");
   return 0;
 }

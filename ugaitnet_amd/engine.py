@@ -234,6 +234,11 @@ class Encoder:
             dms2 = ops.div(ds2, A["c2"], buf("dms2", (b, 16, 16, 64)))   # dL/dm2 / #maxima (TF reduce_max gradient)
             dp4 = ops.conv3x3_dgrad_wino_routed(dz5, self.ud["a5"], 16, 64, 128, A["p4"], A["m2"], dms2, l,
                                                 out=buf("g4", (n, 16, 16, 64)))
+        elif USE_WINOGRAD:
+            # dp4 = (dgrad_a5(dz5) + set-max gradient of p4) * LeakyReLU'(p4): the sum and the factor are applied by the
+            # set-max backward pass over the plain data gradient (one extra read there instead of two in the conv epilogue)
+            raw4 = self.dgrad("a5", dz5, 16, out=buf("g4", (n, 16, 16, 64)))
+            dp4 = ops.setmax_bwd(A["p4"], ds2, b, l, True, out=raw4, addend=raw4)
         else:
             g4 = ops.setmax_bwd(A["p4"], ds2, b, l, False, buf("g4", (n, 16, 16, 64)))
             dp4 = self.dgrad("a5", dz5, 16, act=A["p4"], addend=g4, out=g4)  # in place over the addend
@@ -249,6 +254,9 @@ class Encoder:
             dms1 = ops.div(dm1, A["c1"], buf("dms1", (b, 32, 32, 32)))
             dp2 = ops.conv3x3_dgrad_wino_routed(dz3, self.ud["a3"], 32, 32, 64, A["p2"], A["m1"], dms1, l,
                                                 out=buf("g2", (n, 32, 32, 32)))
+        elif USE_WINOGRAD:
+            raw2 = self.dgrad("a3", dz3, 32, out=buf("g2", (n, 32, 32, 32)))
+            dp2 = ops.setmax_bwd(A["p2"], dm1, b, l, True, out=raw2, addend=raw2)
         else:
             g2 = ops.setmax_bwd(A["p2"], dm1, b, l, False, buf("g2", (n, 32, 32, 32)))
             dp2 = self.dgrad("a3", dz3, 32, act=A["p2"], addend=g2, out=g2)

@@ -290,11 +290,14 @@ def conv3x3_dgrad_wino_routed(dz, upk, hw, cin, cout, act, smax_m, smax_g, frame
     return out
 
 
-def setmax_bwd(p, dm, b, l, apply_lrelu, out=None):
+def setmax_bwd(p, dm, b, l, apply_lrelu, out=None, addend=None):
+    """addend (may be `out` itself): a second gradient path into p, added before the LeakyReLU' factor."""
     _chk(p), _chk(dm)
     s = p.numel() // (b * l)
     out = torch.empty_like(p) if out is None else out
-    call("ugn_setmax_bwd", ptr(p), ptr(dm), ptr(out), b, l, s, int(bool(apply_lrelu)), _stream())
+    if addend is not None:
+        _chk(addend)
+    call("ugn_setmax_bwd", ptr(p), ptr(dm), ptr(addend), ptr(out), b, l, s, int(bool(apply_lrelu)), _stream())
     return out
 
 
