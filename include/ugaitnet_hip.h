@@ -114,6 +114,9 @@ int ugn_setmax_fwd(const float* p, const float* addend, float* m, float* sum_out
 /* Forward that also returns cnt [b,s] = the number of frames holding the maximum (fp32; l <= 32). */
 int ugn_setmax_fwd_cnt(const float* p, const float* addend, float* m, float* sum_out, float* cnt, int b, int l, size_t s,
                        void* stream);
+/* out = g * LeakyReLU'(act) elementwise (n a multiple of 4; out may alias g): the LeakyReluGrad of a set-level map whose
+ * data gradient was computed with a plain epilogue so that it could share a launch with its frame-level twin. */
+int ugn_lrelu_bwd(const float* g, const float* act, float* out, size_t n, void* stream);
 /* out = a / b elementwise (n a multiple of 4): dL/dm divided by the number of maxima (TF's reduce_max gradient). */
 int ugn_div(const float* a, const float* b, float* out, size_t n, void* stream);
 /* addend (optional, [b,l,s], may alias out): a second gradient path into p, summed before the LeakyReLU' factor:

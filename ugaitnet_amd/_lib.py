@@ -42,6 +42,7 @@ PROTOTYPES = {
     "ugn_setmax_fwd": (_i, [_p, _p, _p, _p, _i, _i, _sz, _p]),
     "ugn_setmax_fwd_cnt": (_i, [_p, _p, _p, _p, _p, _i, _i, _sz, _p]),
     "ugn_div": (_i, [_p, _p, _p, _sz, _p]),
+    "ugn_lrelu_bwd": (_i, [_p, _p, _p, _sz, _p]),
     "ugn_setmax_bwd": (_i, [_p, _p, _p, _p, _i, _i, _sz, _i, _p]),
     "ugn_hpp_fwd": (_i, [_p, _p, _p, _i, _p]),
     "ugn_hpp_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _p]),

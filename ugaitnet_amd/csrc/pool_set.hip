@@ -57,6 +57,14 @@ __global__ __launch_bounds__(128) void setmax_fwd_cnt_kernel(const float4* __res
   }
 }
 
+// out = g * LeakyReLU'(act) elementwise (act is a LeakyReLU OUTPUT: same sign as its input)
+__global__ void lrelu_bwd_kernel(const float4* __restrict__ g, const float4* __restrict__ act, float4* __restrict__ out, size_t n4) {
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n4) return;
+  const float4 x = g[e], a = act[e];
+  out[e] = make_float4(x.x * ugn_lrelu_slope(a.x), x.y * ugn_lrelu_slope(a.y), x.z * ugn_lrelu_slope(a.z), x.w * ugn_lrelu_slope(a.w));
+}
+
 __global__ void div_kernel(const float4* __restrict__ a, const float4* __restrict__ b, float4* __restrict__ out, size_t n4) {
   const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= n4) return;
@@ -238,6 +246,14 @@ extern "C" int ugn_setmax_fwd_cnt(const float* p, const float* addend, float* m,
   hipLaunchKernelGGL(setmax_fwd_cnt_kernel, dim3((unsigned)((s4 + 127) / 128), b), dim3(128), 0, (hipStream_t)stream,
                      (const float4*)p, (const float4*)addend, (float4*)m, (float4*)sum_out, (float4*)cnt, l, s4);
   UGN_CHECK_LAUNCH("setmax_fwd_cnt");
+  return 0;
+}
+
+extern "C" int ugn_lrelu_bwd(const float* g, const float* act, float* out, size_t n, void* stream) {
+  UGN_REQUIRE(g && act && out && n > 0 && n % 4 == 0, "ugn_lrelu_bwd: bad arguments (n must be a multiple of 4)");
+  hipLaunchKernelGGL(lrelu_bwd_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const float4*)g,
+                     (const float4*)act, (float4*)out, n / 4);
+  UGN_CHECK_LAUNCH("lrelu_bwd");
   return 0;
 }
 

@@ -229,19 +229,25 @@ class Encoder:
                                     (buf("dz5", (n, 16, 16, 128)), buf("dzb3", (b, 16, 16, 128))), acts=(A["a5"], A["b3"]))
         self.wgrad_pair(("a5", "b3"), (A["p4"], A["s2"]), (dz5, dzb3), 128)
         ds2 = buf("ds2", (b, 16, 16, 64))
-        dq2 = self.dgrad("b3", dzb3, 16, act=A["q2"], out=buf("dq2", (b, 16, 16, 64)), raw_out=ds2)
-        if ROUTED:
-            dms2 = ops.div(ds2, A["c2"], buf("dms2", (b, 16, 16, 64)))   # dL/dm2 / #maxima (TF reduce_max gradient)
-            dp4 = ops.conv3x3_dgrad_wino_routed(dz5, self.ud["a5"], 16, 64, 128, A["p4"], A["m2"], dms2, l,
-                                                out=buf("g4", (n, 16, 16, 64)))
-        elif USE_WINOGRAD:
-            # dp4 = (dgrad_a5(dz5) + set-max gradient of p4) * LeakyReLU'(p4): the sum and the factor are applied by the
-            # set-max backward pass over the plain data gradient (one extra read there instead of two in the conv epilogue)
-            raw4 = self.dgrad("a5", dz5, 16, out=buf("g4", (n, 16, 16, 64)))
+        if USE_WINOGRAD and PAIR_LAUNCHES and not ROUTED:
+            # Both data gradients of the pair run with a PLAIN epilogue in one launch; what the frame-level one still needs
+            # (+ set-max gradient of p4, * LeakyReLU'(p4)) is applied by the set-max backward pass, what the set-level one
+            # needs (* LeakyReLU'(q2), the raw copy for the set-max path) by a tiny elementwise kernel.
+            raw4, _ = self.dgrad_pair(("a5", "b3"), (dz5, dzb3), 16, (buf("g4", (n, 16, 16, 64)), ds2))
+            dq2 = ops.lrelu_bwd(ds2, A["q2"], buf("dq2", (b, 16, 16, 64)))
             dp4 = ops.setmax_bwd(A["p4"], ds2, b, l, True, out=raw4, addend=raw4)
         else:
-            g4 = ops.setmax_bwd(A["p4"], ds2, b, l, False, buf("g4", (n, 16, 16, 64)))
-            dp4 = self.dgrad("a5", dz5, 16, act=A["p4"], addend=g4, out=g4)  # in place over the addend
+            dq2 = self.dgrad("b3", dzb3, 16, act=A["q2"], out=buf("dq2", (b, 16, 16, 64)), raw_out=ds2)
+            if ROUTED:
+                dms2 = ops.div(ds2, A["c2"], buf("dms2", (b, 16, 16, 64)))   # dL/dm2 / #maxima (TF reduce_max gradient)
+                dp4 = ops.conv3x3_dgrad_wino_routed(dz5, self.ud["a5"], 16, 64, 128, A["p4"], A["m2"], dms2, l,
+                                                    out=buf("g4", (n, 16, 16, 64)))
+            elif USE_WINOGRAD:
+                raw4 = self.dgrad("a5", dz5, 16, out=buf("g4", (n, 16, 16, 64)))
+                dp4 = ops.setmax_bwd(A["p4"], ds2, b, l, True, out=raw4, addend=raw4)
+            else:
+                g4 = ops.setmax_bwd(A["p4"], ds2, b, l, False, buf("g4", (n, 16, 16, 64)))
+                dp4 = self.dgrad("a5", dz5, 16, act=A["p4"], addend=g4, out=g4)  # in place over the addend
         # block 2 (a3, a4) with block 1 of the global branch (b1, b2); a4 / b2 are pooled: dp4 / dq2 are their gradients at
         # pooled resolution, routed through the argmax maps i4 / j2
         self.wgrad_pair(("a4", "b2"), (A["a3"], A["b1"]), (dp4, dq2), 64, dz_idxs=(A["i4"], A["j2"]))
@@ -249,17 +255,21 @@ class Encoder:
                                     (buf("dz3", (n, 32, 32, 64)), buf("dzb1", (b, 32, 32, 64))),
                                     dz_idxs=(A["i4"], A["j2"]), acts=(A["a3"], A["b1"]))
         self.wgrad_pair(("a3", "b1"), (A["p2"], A["m1"]), (dz3, dzb1), 64)
-        dm1 = self.dgrad("b1", dzb1, 32, out=buf("dm1", (b, 32, 32, 32)))
-        if ROUTED:
-            dms1 = ops.div(dm1, A["c1"], buf("dms1", (b, 32, 32, 32)))
-            dp2 = ops.conv3x3_dgrad_wino_routed(dz3, self.ud["a3"], 32, 32, 64, A["p2"], A["m1"], dms1, l,
-                                                out=buf("g2", (n, 32, 32, 32)))
-        elif USE_WINOGRAD:
-            raw2 = self.dgrad("a3", dz3, 32, out=buf("g2", (n, 32, 32, 32)))
+        if USE_WINOGRAD and PAIR_LAUNCHES and not ROUTED:
+            raw2, dm1 = self.dgrad_pair(("a3", "b1"), (dz3, dzb1), 32, (buf("g2", (n, 32, 32, 32)), buf("dm1", (b, 32, 32, 32))))
             dp2 = ops.setmax_bwd(A["p2"], dm1, b, l, True, out=raw2, addend=raw2)
         else:
-            g2 = ops.setmax_bwd(A["p2"], dm1, b, l, False, buf("g2", (n, 32, 32, 32)))
-            dp2 = self.dgrad("a3", dz3, 32, act=A["p2"], addend=g2, out=g2)
+            dm1 = self.dgrad("b1", dzb1, 32, out=buf("dm1", (b, 32, 32, 32)))
+            if ROUTED:
+                dms1 = ops.div(dm1, A["c1"], buf("dms1", (b, 32, 32, 32)))
+                dp2 = ops.conv3x3_dgrad_wino_routed(dz3, self.ud["a3"], 32, 32, 64, A["p2"], A["m1"], dms1, l,
+                                                    out=buf("g2", (n, 32, 32, 32)))
+            elif USE_WINOGRAD:
+                raw2 = self.dgrad("a3", dz3, 32, out=buf("g2", (n, 32, 32, 32)))
+                dp2 = ops.setmax_bwd(A["p2"], dm1, b, l, True, out=raw2, addend=raw2)
+            else:
+                g2 = ops.setmax_bwd(A["p2"], dm1, b, l, False, buf("g2", (n, 32, 32, 32)))
+                dp2 = self.dgrad("a3", dz3, 32, act=A["p2"], addend=g2, out=g2)
         # block 1 (a1, a2)
         _wgrad3x3(A["a1"], dp2, 32, dz_idx=A["i2"], dw=self.G("a2"))
         if A1_SIGN_BITS:

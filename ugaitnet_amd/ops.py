@@ -272,6 +272,14 @@ def setmax_fwd_cnt(p, b, l, addend=None, m=None, sum_out=None, cnt=None):
     return (m, sum_out, cnt) if addend is not None else (m, cnt)
 
 
+def lrelu_bwd(g, act, out=None):
+    """g * LeakyReLU'(act), act being the LeakyReLU output."""
+    _chk(g), _chk(act)
+    out = torch.empty_like(g) if out is None else out
+    call("ugn_lrelu_bwd", ptr(g), ptr(act), ptr(out), g.numel(), _stream())
+    return out
+
+
 def div(a, b, out=None):
     _chk(a), _chk(b)
     out = torch.empty_like(a) if out is None else out
