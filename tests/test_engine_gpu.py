@@ -72,6 +72,33 @@ def test_three_modalities_forward_backward(dev, mode):
     assert not bad, bad
 
 
+@pytest.mark.parametrize("b,l,ids", [(2, 1, 1), (3, 5, 3), (6, 7, 2)])
+def test_ragged_batches_and_set_lengths(dev, b, l, ids):
+    """Edge shapes: a single frame per clip (set-max over one element), odd clip counts and set lengths, a batch that
+    fills only a few of the persistent workgroups, identities with a single sample (no positive pair besides itself)."""
+    kinds, ncls = ('of', 'gray', 'depth'), 5
+    xs, uses, labels, onehot = make_batch(kinds, b, l, ncls, ids=ids, seed=40 + b)
+    p64 = oracle_params(kinds, ncls)
+    core = build(kinds, ncls, "sign_max", p64)
+    r, g = O.model_loss_and_grads([x.astype(np.float64) for x in xs], [u.astype(np.float64) for u in uses], labels,
+                                  onehot.astype(np.float64), p64, margin=0.2, loss_weights=(1.0, 0.1), mode="sign_max")
+    core.forward_backward(xs, uses, labels, onehot)
+    torch.cuda.synchronize()
+    for enc, ref in zip(core.encoders, r['outs']):
+        assert relmax(enc.act['out'].cpu().numpy(), ref) <= 1e-5
+    assert np.abs(core.sig.cpu().numpy() - r['signature']).max() <= 1e-3
+    ls = core.losses()
+    assert abs(ls['loss'] - float(r['loss'])) <= 1e-4
+    got = core.get_grads_numpy()
+    bad = {}
+    for mi in range(3):
+        for k, ref in g['branches'][mi].items():
+            e = rell2(got['branches'][mi][k], ref)
+            if e > 2e-2:   # one flipped argmax (fp32 vs fp64 tie) weighs ~1/batch: looser than the 8-clip test's 5e-3
+                bad['m%d.%s' % (mi, k)] = e
+    assert not bad, bad
+
+
 def test_single_modality_graph(dev):
     """BL-single gray: no gate, no normalisation, raw [62,B,256] to both heads (nets/mj_uwyhNets_ba.py:893-903)."""
     kinds, b, l, ncls = ('gray',), 6, 5, 12

@@ -53,7 +53,8 @@ __device__ __forceinline__ void wino_pack_one(const float* __restrict__ w, float
   const int dgrad = mode & 1;   // mode: 0 fwd, 1 dgrad of a full-resolution dz, 3 dgrad of a pooled dz (same layout as 1)
   const int kc = dgrad ? cout : cin, nc = dgrad ? cin : cout;
   if (e >= kc * nc) return;
-  const int k = e % kc, n = e / kc;
+  // consecutive threads walk the contiguous axis of the HWIO filter: cout = n in the forward, cout = k in the data gradient
+  const int k = dgrad ? e % kc : e / nc, n = dgrad ? e / kc : e % nc;
   float g[3][3];
   for (int dy = 0; dy < 3; ++dy)
     for (int dx = 0; dx < 3; ++dx)

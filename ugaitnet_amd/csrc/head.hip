@@ -580,9 +580,18 @@ extern "C" int ugn_triplet_indices_host(const int32_t* labels, int m, int32_t* h
 
 extern "C" int ugn_triplet_fwd_bwd(const float* sig, const int32_t* hp, const int32_t* hn, int kp, int kn, float margin,
                                    float* bin_loss, float* bin_num, float* dsig, float grad_scale, int m, void* stream) {
-  UGN_REQUIRE(sig && hp && hn && bin_loss && bin_num && dsig, "ugn_triplet_fwd_bwd: null pointer");
+  UGN_REQUIRE(sig && bin_loss && bin_num && dsig, "ugn_triplet_fwd_bwd: null pointer");
   UGN_REQUIRE(m >= 1 && m <= 128, "ugn_triplet_fwd_bwd: batch size must be 1..128 (got %d)", m);
   UGN_REQUIRE(kp >= 0 && kn >= 0 && kp + kn == m, "ugn_triplet_fwd_bwd: kp + kn must equal m (kp=%d kn=%d m=%d)", kp, kn, m);
+  if (kp == 0 || kn == 0) {   // a batch without negatives (or positives) has no triplet: loss 0, count 0, zero gradient
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(bin_loss, 0, NBINS * sizeof(float), st);
+    if (e == hipSuccess) e = hipMemsetAsync(bin_num, 0, NBINS * sizeof(float), st);
+    if (e == hipSuccess) e = hipMemsetAsync(dsig, 0, (size_t)NBINS * m * HID * sizeof(float), st);
+    if (e != hipSuccess) { ugn_set_error("triplet: hipMemsetAsync: %s", hipGetErrorString(e)); return (int)e; }
+    return 0;
+  }
+  UGN_REQUIRE(hp && hn, "ugn_triplet_fwd_bwd: null index list");
   const int lds = (2 * m * m + m * (TR_DC + 1)) * (int)sizeof(float);
   static int lds_set = 0;
   if (lds > lds_set) {
