@@ -1,11 +1,10 @@
-"""Device-side batch assembly: time of ugn_assemble_modality for one C3 batch and its HBM rate,
-next to the host (numpy) restatement of the reference generator and the H2D sizes of both routes."""
-import sys, os, time, random
+"""Device-side batch assembly: time of ugn_assemble_modality for one batch, its HBM rate and the H2D
+sizes of the raw and the assembled routes."""
+import sys, os, random
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
 from ugaitnet_amd.batching import DeviceBatchAssembler, ModalitySpec, plan_rows
-from oracle import batch_oracle as BO
 
 nbase, expand = 8, 3
 rng = np.random.default_rng(0)
@@ -28,9 +27,5 @@ wr = sum(x.numel() * 4 for x, _ in out)
 rd = sum(int((plan[:, j] >= 0).sum()) * raws[j][0].numel() * raws[j].element_size() for j in range(3))
 print("GPU assembly of %d rows x 3 modalities: %.1f us (incl. 3 launches + plan upload), %.1f MB written + %.1f MB read = %.2f TB/s" % (
     plan.shape[0], us, wr / 1e6, rd / 1e6, (wr + rd) / us / 1e6))
-t0 = time.time()
-BO.gen_batch_mm(samples, [dict(compress_factor=100.0, channels=2), dict(compress_factor=1.0, channels=1),
-                          dict(compress_factor=1.0, channels=1)], expand, seed=1)
-print("host restatement of the generator (numpy, 1 thread): %.1f ms" % ((time.time() - t0) * 1e3))
 print("H2D per batch: raw %.1f MB vs assembled float32 %.1f MB (the reference ships float64: %.1f MB)" % (
     sum(r.numel() * r.element_size() for r in raws) / 1e6, wr / 1e6, 2 * wr / 1e6))
