@@ -4,19 +4,23 @@
 //
 //   Y = A^T [ sum_cin (G g G^T) .* (B^T d B) ] A      per 2x2 output tile, 4x4 input patch d, 3x3 filter g
 //
-// Mapping.  A workgroup (4 waves, one per SIMD, persistent: 256 workgroups stride over the items) owns a 16x16 output
-// region (64 Winograd tiles) and 32 output channels; wave w owns the 16 tiles of region rows 4w..4w+3.  The GEMM of each
-// of the 16 Winograd points is [16 tiles] x [32 channels] x [K channels] on 16x16x4 MFMAs: 16 points x 2 channel blocks
-// = 32 independent accumulators (128 registers) per wave.
-//   * The transformed filters U = G g G^T are precomputed once per step (wino_pack_kernel) in the order the kernel
-//     consumes them: [32-channel chunk][8-channel group][point][32 out][8 in]; one 16 KB group slice is double-buffered
-//     in LDS, prefetched through registers -> one barrier per 8-channel group (64 MFMAs per wave).
-//   * The input transform B^T d B is computed IN REGISTERS by the lane that feeds it to the MFMA (lane = tile x
-//     channel pair), straight from the fp32 halo tile in LDS: transformed activations never touch LDS or HBM.
-//   * The halo tile of the next chunk / next item is fetched into registers while the current chunk computes and
-//     written to the other LDS buffer, so global latency is never exposed.
-//   * The output transform A^T M A is lane-local (a lane holds all 16 points of its 4 tiles x 2 channels), and a 2x2
-//     Winograd tile IS a pooling window, so LeakyReLU + MaxPool + argmax need no cross-lane traffic either.
+// Mapping.  A 512-thread workgroup (8 waves, two per SIMD; persistent: 256 workgroups stride over the items) owns a 16x16
+// output region (64 Winograd tiles).  The GEMM of each of the 16 Winograd points is [tiles] x [out channels] x [K channels] on
+// 16x16x4 MFMAs.  Two variants (chosen from the GEMM dimensions, wino_common.h): NARROW -- the workgroup owns 32 output
+// channels, a wave 16 tiles x 16 channels (64 accumulator registers), 16-channel K groups; WIDE -- 64 output channels, a wave
+// 16 tiles x 32 channels (128 accumulators), 8-channel K groups, so one transformed patch feeds two channel blocks.  The
+// layers with 32 output channels use the TALL kernel of conv3x3_wino_tall.hip.
+//   * The transformed filters U = G g G^T are precomputed once per step (wino_pack_multi) in the order the kernel consumes
+//     them; a 32 KB slice per K group is double-buffered in LDS by LDS-DMA (global_load_lds_dwordx4) -> one barrier per group
+//     (64 MFMAs per wave).  Single-chunk narrow layers keep both slices resident.
+//   * The input transform B^T d B is computed IN REGISTERS by the lane that feeds it to the MFMA (lane = tile x channel
+//     pair), straight from the fp32 halo tile in LDS and in the shadow of the previous group's MFMAs: transformed
+//     activations never touch LDS or HBM.
+//   * The halo tile of the next chunk / next item streams in by LDS-DMA (per-lane source addresses; lanes outside the image
+//     read a zero block) early in the first group of a chunk, so global latency is never exposed.
+//   * The output transform A^T M A is lane-local (a lane holds all 16 points of its 4 tiles), and a 2x2 Winograd tile IS a
+//     pooling window, so LeakyReLU + MaxPool + argmax need no cross-lane traffic either.
+//   * One launch can carry two jobs of the same shape (the frame-level layer and its set-level twin of the global branch).
 #include <stdlib.h>
 #include "wino_common.h"
 
