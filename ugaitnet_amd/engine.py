@@ -15,6 +15,7 @@ import math
 import numpy as np
 import torch
 
+import contextlib
 import os
 
 from . import dp, ops
@@ -39,6 +40,60 @@ WINO_DGRAD = ("a2", "a3", "a4", "a5", "a6", "b1", "b2", "b3", "b4")
 _wgrad3x3 = ops.conv3x3_wgrad_wino if USE_WINOGRAD else ops.conv3x3_wgrad
 PAIR_LAUNCHES = os.environ.get("UGN_PAIR", "1") != "0"   # frame-level layer + set-level twin in one launch
 A1_SIGN_BITS = os.environ.get("UGN_A1_BITS", "1") != "0"   # LeakyReLU' of the first layer from 1 bit per element
+# Weight gradients on a side stream: a layer's weight gradient and data gradient only share their inputs, so the two
+# persistent launches may overlap -- the tail of one (last, partly filled round of work items) and the prologue of the other
+# fill each other's idle CUs.  Results are unchanged (no kernel's inputs depend on the order).
+WGRAD_STREAM = os.environ.get("UGN_WSTREAM", "1") != "0"
+# UGN_BSTREAMS=1 additionally puts the backward chains of the modalities, which are independent of each other after the
+# fusion gradient, on streams of their own (each with its weight-gradient stream).  Measured slower (9.51 vs 9.40 ms): six
+# LDS-filling kernels contending for the CUs thrash more than they fill.  The forward stays on one stream: bench.py times it.
+BRANCH_STREAMS = WGRAD_STREAM and os.environ.get("UGN_BSTREAMS", "0") == "1"
+_WSTREAM = {}
+_BSTREAM = {}
+
+
+def _wgrad_stream(device):
+    # one weight-gradient stream per stream that issues backward chains
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    st = _WSTREAM.get(key)
+    if st is None:
+        st = _WSTREAM[key] = torch.cuda.Stream(device=device)
+    return st
+
+
+def _branch_stream(device, mi):
+    st = _BSTREAM.get((device, mi))
+    if st is None:
+        st = _BSTREAM[(device, mi)] = torch.cuda.Stream(device=device)
+    return st
+
+
+class _side:
+    """`with _side(device):` -- run the enclosed launches on the weight-gradient stream, after everything issued so far."""
+
+    def __init__(self, device):
+        self.device = device
+
+    def __enter__(self):
+        if WGRAD_STREAM:
+            st = _wgrad_stream(self.device)
+            st.wait_stream(torch.cuda.current_stream(self.device))
+            self.ctx = torch.cuda.stream(st)
+            self.ctx.__enter__()
+
+    def __exit__(self, *exc):
+        if WGRAD_STREAM:
+            self.ctx.__exit__(*exc)
+
+
+def join_backward_streams(device):
+    """The current stream waits for every backward chain and weight gradient issued so far."""
+    cur = torch.cuda.current_stream(device)
+    for (dev, _), st in list(_BSTREAM.items()) + list(_WSTREAM.items()):
+        if dev == device:
+            cur.wait_stream(st)
+
+
 # UGN_ROUTED=1: form the set-max gradient inside the a3 / a5 data-gradient epilogues instead of materialising it with
 # setmax_bwd (bit-identical; measured 2.5 % SLOWER on MI355X: three operand loads per element make those epilogues spill).
 ROUTED = USE_WINOGRAD and os.environ.get("UGN_ROUTED", "0") == "1"
@@ -224,10 +279,13 @@ class Encoder:
                                 buf("dzb4", (b, 16, 16, 128)))
         # block 3 of the frame stack (a5, a6) with block 2 of the global branch (b3, b4)
         dz6 = ops.setmax_bwd(A["a6"], dm3, b, l, True, buf("dz6", (n, 16, 16, 128)))
-        self.wgrad_pair(("a6", "b4"), (A["a5"], A["b3"]), (dz6, dzb4), 128)
+        dev = self.store.device
+        with _side(dev):
+            self.wgrad_pair(("a6", "b4"), (A["a5"], A["b3"]), (dz6, dzb4), 128)
         dz5, dzb3 = self.dgrad_pair(("a6", "b4"), (dz6, dzb4), 16,
                                     (buf("dz5", (n, 16, 16, 128)), buf("dzb3", (b, 16, 16, 128))), acts=(A["a5"], A["b3"]))
-        self.wgrad_pair(("a5", "b3"), (A["p4"], A["s2"]), (dz5, dzb3), 128)
+        with _side(dev):
+            self.wgrad_pair(("a5", "b3"), (A["p4"], A["s2"]), (dz5, dzb3), 128)
         ds2 = buf("ds2", (b, 16, 16, 64))
         if USE_WINOGRAD and PAIR_LAUNCHES and not ROUTED:
             # Both data gradients of the pair run with a PLAIN epilogue in one launch; what the frame-level one still needs
@@ -250,11 +308,13 @@ class Encoder:
                 dp4 = self.dgrad("a5", dz5, 16, act=A["p4"], addend=g4, out=g4)  # in place over the addend
         # block 2 (a3, a4) with block 1 of the global branch (b1, b2); a4 / b2 are pooled: dp4 / dq2 are their gradients at
         # pooled resolution, routed through the argmax maps i4 / j2
-        self.wgrad_pair(("a4", "b2"), (A["a3"], A["b1"]), (dp4, dq2), 64, dz_idxs=(A["i4"], A["j2"]))
+        with _side(dev):
+            self.wgrad_pair(("a4", "b2"), (A["a3"], A["b1"]), (dp4, dq2), 64, dz_idxs=(A["i4"], A["j2"]))
         dz3, dzb1 = self.dgrad_pair(("a4", "b2"), (dp4, dq2), 32,
                                     (buf("dz3", (n, 32, 32, 64)), buf("dzb1", (b, 32, 32, 64))),
                                     dz_idxs=(A["i4"], A["j2"]), acts=(A["a3"], A["b1"]))
-        self.wgrad_pair(("a3", "b1"), (A["p2"], A["m1"]), (dz3, dzb1), 64)
+        with _side(dev):
+            self.wgrad_pair(("a3", "b1"), (A["p2"], A["m1"]), (dz3, dzb1), 64)
         if USE_WINOGRAD and PAIR_LAUNCHES and not ROUTED:
             raw2, dm1 = self.dgrad_pair(("a3", "b1"), (dz3, dzb1), 32, (buf("g2", (n, 32, 32, 32)), buf("dm1", (b, 32, 32, 32))))
             dp2 = ops.setmax_bwd(A["p2"], dm1, b, l, True, out=raw2, addend=raw2)
@@ -271,13 +331,16 @@ class Encoder:
                 g2 = ops.setmax_bwd(A["p2"], dm1, b, l, False, buf("g2", (n, 32, 32, 32)))
                 dp2 = self.dgrad("a3", dz3, 32, act=A["p2"], addend=g2, out=g2)
         # block 1 (a1, a2)
-        _wgrad3x3(A["a1"], dp2, 32, dz_idx=A["i2"], dw=self.G("a2"))
+        with _side(dev):
+            _wgrad3x3(A["a1"], dp2, 32, dz_idx=A["i2"], dw=self.G("a2"))
         if A1_SIGN_BITS:
             dz1 = self.dgrad("a2", dp2, 64, dz_idx=A["i2"], out=buf("dz1", (n, 64, 64, 32)))   # dL/da1
-            ops.conv5x5_in_wgrad(A["x"], dz1, self.G("a1"), sign=A["a1s"])
+            with _side(dev):
+                ops.conv5x5_in_wgrad(A["x"], dz1, self.G("a1"), sign=A["a1s"])
         else:
             dz1 = self.dgrad("a2", dp2, 64, dz_idx=A["i2"], act=A["a1"], out=buf("dz1", (n, 64, 64, 32)))
-            ops.conv5x5_in_wgrad(A["x"], dz1, self.G("a1"))
+            with _side(dev):
+                ops.conv5x5_in_wgrad(A["x"], dz1, self.G("a1"))
 
 
 class GaitCore:
@@ -456,15 +519,26 @@ class GaitCore:
                                       [self._buf("dout%d" % m, (NBINS, b, HIDDEN)) for m in range(self.nmod)])
         else:
             douts = [dsig]
+        main = torch.cuda.current_stream(self.device)
         for mi, (enc, d) in enumerate(zip(self.encoders, douts)):
             idx = self._active[mi] if self._active is not None else None
-            if idx is None:
-                enc.backward(d, self.scratch)
-            elif idx.numel() == 0:
-                for name, _ in branch_param_shapes(enc.cin):   # no active clip: this branch's gradient is exactly zero
-                    enc.G(name).zero_()
+            # (frame-sized gradient scratch per branch: the branches' backward chains overlap)
+            scratch = self.scratch.setdefault(mi, {})
+            if BRANCH_STREAMS and mi > 0:
+                st = _branch_stream(self.device, mi)
+                st.wait_stream(main)           # the fusion gradient is ready
+                ctx = torch.cuda.stream(st)
             else:
-                enc.backward(d.index_select(1, idx).contiguous(), self.scratch)
+                ctx = contextlib.nullcontext()
+            with ctx:
+                if idx is None:
+                    enc.backward(d, scratch)
+                elif idx.numel() == 0:
+                    for name, _ in branch_param_shapes(enc.cin):   # no active clip: this branch's gradient is exactly zero
+                        enc.G(name).zero_()
+                else:
+                    enc.backward(d.index_select(1, idx).contiguous(), scratch)
+        join_backward_streams(self.device)
 
     def forward_loss_only(self, xs, uses, labels, onehot):
         """Validation step: forward + both losses/metrics, no parameter gradients."""

@@ -27,15 +27,18 @@ def _chk(t, dtype=F32):
 
 
 class Workspace:
-    """Grow-only scratch buffer for the weight-gradient partial slabs."""
+    """Grow-only scratch buffers for the weight-gradient partial slabs."""
 
     def __init__(self):
-        self.buf = None
+        self.bufs = {}
 
     def get(self, nbytes, device):
-        if self.buf is None or self.buf.numel() < nbytes or self.buf.device != device:
-            self.buf = torch.empty(max(int(nbytes), 1), dtype=U8, device=device)
-        return self.buf
+        # one buffer per (device, stream): launches on different streams may run concurrently
+        key = (device, torch.cuda.current_stream(device).cuda_stream)
+        buf = self.bufs.get(key)
+        if buf is None or buf.numel() < nbytes:
+            buf = self.bufs[key] = torch.empty(max(int(nbytes), 1), dtype=U8, device=device)
+        return buf
 
 
 _WS = Workspace()
@@ -47,8 +50,10 @@ TIMING = {}
 ROOFLINE_OP = "conv3x3_fwd[a2: 32->32 @64x64 +LeakyReLU +MaxPool]"
 ROOFLINE_FLOPS_PER_FRAME = 2.0 * 9 * 32 * 32 * 64 * 64   # algorithmic FLOPs of that layer per frame (a.c2)
 # further kernels timed the same way (reported beside the roofline object): name -> algorithmic FLOPs per frame
+# (forward kernels only: the backward overlaps weight gradients with data gradients on two streams, so an event pair
+# around one of its launches no longer measures that kernel alone)
 EXTRA_TIMED = {
-    "conv3x3_wgrad[a4: 64->64 @32x32, pooled dz]": 2.0 * 9 * 64 * 64 * 32 * 32,
+    "conv3x3_fwd[a4: 64->64 @32x32 +LeakyReLU +MaxPool]": 2.0 * 9 * 64 * 64 * 32 * 32,
     "conv3x3_fwd[a6: 128->128 @16x16 +LeakyReLU]": 2.0 * 9 * 128 * 128 * 16 * 16,
 }
 
@@ -185,8 +190,7 @@ def conv3x3_wgrad(x, dz, cout, dz_idx=None, dw=None):
     if nbytes == 0:
         raise ValueError("conv3x3_wgrad: unsupported shape hw=%d cin=%d cout=%d" % (hw, cin, cout))
     ws = _WS.get(nbytes, x.device)
-    with _Timed("conv3x3_wgrad[a4: 64->64 @32x32, pooled dz]", hw == 32 and cin == 64 and cout == 64 and n >= 100):
-        call("ugn_conv3x3_wgrad", ptr(x), ptr(dz), ptr(dz_idx), ptr(dw), n, hw, cin, cout, ptr(ws), ws.numel(), _stream())
+    call("ugn_conv3x3_wgrad", ptr(x), ptr(dz), ptr(dz_idx), ptr(dw), n, hw, cin, cout, ptr(ws), ws.numel(), _stream())
     return dw
 
 
@@ -201,7 +205,8 @@ def conv3x3_fwd_wino_pair(xs, upks, cout, pool, outs, idxs=None):
     hw, cin = xs[0].shape[1], xs[0].shape[3]
     assert xs[1].shape[1:] == xs[0].shape[1:] and (not pool or idxs is not None)
     ns = (C.c_int * 2)(xs[0].shape[0], xs[1].shape[0])
-    with _Timed("conv3x3_fwd[a6: 128->128 @16x16 +LeakyReLU]", hw == 16 and cin == 128 and cout == 128 and ns[0] >= 100):
+    name = "conv3x3_fwd[a6: 128->128 @16x16 +LeakyReLU]" if hw == 16 else "conv3x3_fwd[a4: 64->64 @32x32 +LeakyReLU +MaxPool]"
+    with _Timed(name, ns[0] >= 100 and ((hw == 16 and cin == 128 and cout == 128) or (hw == 32 and cin == 64 and cout == 64 and pool))):
         call("ugn_conv3x3_fwd_wino_pair", ptr_array(xs), ptr_array(upks), ptr_array(outs), _opt_ptr_array(idxs if pool else None),
              ns, hw, cin, cout, int(bool(pool)), _stream())
     return (outs, idxs) if pool else outs
@@ -227,9 +232,8 @@ def conv3x3_wgrad_wino_pair(xs, dzs, cout, dws, dz_idxs=None):
     if nbytes == 0:
         raise ValueError("conv3x3_wgrad_wino_pair: unsupported shape hw=%d cin=%d cout=%d" % (hw, cin, cout))
     ws = _WS.get(nbytes, xs[0].device)
-    with _Timed("conv3x3_wgrad[a4: 64->64 @32x32, pooled dz]", hw == 32 and cin == 64 and cout == 64 and ns[0] >= 100):
-        call("ugn_conv3x3_wgrad_wino_pair", ptr_array(xs), ptr_array(dzs), _opt_ptr_array(dz_idxs), ptr_array(dws), ns, hw, cin,
-             cout, ptr(ws), ws.numel(), _stream())
+    call("ugn_conv3x3_wgrad_wino_pair", ptr_array(xs), ptr_array(dzs), _opt_ptr_array(dz_idxs), ptr_array(dws), ns, hw, cin, cout,
+         ptr(ws), ws.numel(), _stream())
     return dws
 
 
@@ -242,9 +246,7 @@ def conv3x3_wgrad_wino(x, dz, cout, dz_idx=None, dw=None):
     if nbytes == 0:
         raise ValueError("conv3x3_wgrad_wino: unsupported shape hw=%d cin=%d cout=%d" % (hw, cin, cout))
     ws = _WS.get(nbytes, x.device)
-    with _Timed("conv3x3_wgrad[a4: 64->64 @32x32, pooled dz]", hw == 32 and cin == 64 and cout == 64 and n >= 100):
-        call("ugn_conv3x3_wgrad_wino", ptr(x), ptr(dz), ptr(dz_idx), ptr(dw), n, hw, cin, cout, ptr(ws), ws.numel(),
-             _stream())
+    call("ugn_conv3x3_wgrad_wino", ptr(x), ptr(dz), ptr(dz_idx), ptr(dw), n, hw, cin, cout, ptr(ws), ws.numel(), _stream())
     return dw
 
 
