@@ -48,6 +48,10 @@ WGRAD_STREAM = os.environ.get("UGN_WSTREAM", "1") != "0"
 # fusion gradient, on streams of their own (each with its weight-gradient stream).  Measured slower (9.51 vs 9.40 ms): six
 # LDS-filling kernels contending for the CUs thrash more than they fill.  The forward stays on one stream: bench.py times it.
 BRANCH_STREAMS = WGRAD_STREAM and os.environ.get("UGN_BSTREAMS", "0") == "1"
+# UGN_FSTREAMS=1|2: also run the forward chains of modalities 1.. on that many side streams.  Worth 1.6 % / 2.7 % of the
+# step (9.29 / 9.19 ms against 9.44), but off by default: event pairs around a forward launch then time the contention with
+# the other chains, not the kernel, and bench.py's roofline figure is taken from exactly those pairs.
+FWD_STREAMS = int(os.environ.get("UGN_FSTREAMS", "0"))
 _WSTREAM = {}
 _BSTREAM = {}
 
@@ -466,6 +470,17 @@ class GaitCore:
                 if len(rows):
                     full.index_copy_(1, idx, enc.forward(x.index_select(0, idx).contiguous()))
                 outs.append(full)
+        elif FWD_STREAMS and len(self.encoders) > 1:
+            main = torch.cuda.current_stream(self.device)
+            outs = [None] * len(self.encoders)
+            for mi in range(1, len(self.encoders)):
+                st = _branch_stream(self.device, 100 + (mi % FWD_STREAMS))
+                st.wait_stream(main)
+                with torch.cuda.stream(st):
+                    outs[mi] = self.encoders[mi].forward(xs[mi])
+            outs[0] = self.encoders[0].forward(xs[0])
+            for mi in range(1, len(self.encoders)):
+                main.wait_stream(_branch_stream(self.device, 100 + (mi % FWD_STREAMS)))
         else:
             outs = [enc.forward(x) for enc, x in zip(self.encoders, xs)]
         self.last_b = b
