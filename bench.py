@@ -70,6 +70,9 @@ def main():
     ap.add_argument("--skip-masked", action="store_true",
                     help="run each encoder only on the clips whose modality flag is 1 (exactly the same results; the default "
                          "line computes the masked pairs too)")
+    ap.add_argument("--dp-mode", choices=("replica", "global"), default="replica",
+                    help="N > 1: 'replica' = the reference's MirroredStrategy (losses per replica slice, one gradient "
+                         "all-reduce); 'global' = all-gather the fused features so the losses see the whole batch")
     args = ap.parse_args()
 
     import torch
@@ -91,7 +94,7 @@ def main():
 
     xs, uses, labels, onehot = make_batch(KINDS, B_PER_GPU, L, NCLS, seed=232323 + rank)
     core = GaitCore([2, 1, 1], nclasses=NCLS, fuse_mode="sign_max", margin=0.2, loss_weights=(1.0, 0.1), device=dev,
-                    seed=232323, lr=1e-4, world_size=world, skip_masked=args.skip_masked)
+                    seed=232323, lr=1e-4, world_size=world, skip_masked=args.skip_masked, dp_mode=args.dp_mode)
     dxs = [torch.from_numpy(x).to(dev) for x in xs]
     dus = uses if args.skip_masked else [torch.from_numpy(u).to(dev) for u in uses]   # flags: host copies when they steer the launch
     doh = torch.from_numpy(onehot).to(dev)
@@ -125,7 +128,7 @@ def main():
         del core
         torch.cuda.empty_cache()
         core2 = GaitCore([2, 1, 1], nclasses=NCLS, fuse_mode="sign_max", margin=0.2, loss_weights=(1.0, 0.1), device=dev,
-                         seed=232323, lr=1e-4, world_size=world, skip_masked=True)
+                         seed=232323, lr=1e-4, world_size=world, skip_masked=True, dp_mode=args.dp_mode)
         for _ in range(args.warmup):
             core2.train_step(dxs, uses, labels, doh)
         sync_all()
@@ -175,7 +178,7 @@ def main():
                    higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
                    config=dict(workload="C3: 3 modalities (of 2ch + gray + depth), 25x60x60, 24 clips/GPU, 12 ids x 2, "
                                         "150 classes, sign_max, 7-pattern masks, triplet(0.2)+0.1*xent, Adam 1e-4",
-                               clips_per_gpu=B_PER_GPU, parallelism="dp%d" % world, masked_pairs_skipped=bool(args.skip_masked)),
+                               clips_per_gpu=B_PER_GPU, parallelism="dp%d" % world, dp_mode=args.dp_mode, masked_pairs_skipped=bool(args.skip_masked)),
                    whole_step_tflops=round(value * FLOP_PER_CLIP / 1e12, 2),
                    whole_step_frac_of_f32_mfma_peak=round(value * FLOP_PER_CLIP / world / PEAK_F32_MFMA, 4),
                    loss=round(losses["loss"], 5), roofline=roof)

@@ -44,6 +44,15 @@ def _worker(rank, world, port, out):
     flat = torch.from_numpy(_replica_grads(rank, world))
     scale = dp.allreduce_sum_(flat)
     out[rank] = (flat * scale).numpy()
+    # global-batch mode's exchange: equal slices concatenated along the batch axis in rank order; ragged slices are refused
+    part = torch.full((3, 2, 4), float(rank)) + torch.arange(4.0)
+    whole = dp.gather_batch_axis(part, 1)
+    out["gather%d" % rank] = whole.numpy()
+    try:
+        dp.gather_batch_axis(torch.zeros(3, 2 + rank, 4), 1)
+        out["ragged%d" % rank] = "accepted"
+    except ValueError:
+        out["ragged%d" % rank] = "refused"
     dist.barrier()
     dist.destroy_process_group()
 
@@ -72,3 +81,7 @@ def test_two_replicas_average_gradients_over_gloo():
     for r in range(world):
         assert np.abs(out[r] - expect).max() <= 1e-12 * max(1.0, np.abs(expect).max())
     assert np.array_equal(out[0], out[1])    # every replica applies the same update
+    expect_g = np.concatenate([np.full((3, 2, 4), float(r)) + np.arange(4.0) for r in range(world)], axis=1)
+    for r in range(world):
+        assert np.array_equal(out["gather%d" % r], expect_g)
+        assert out["ragged%d" % r] == "refused"

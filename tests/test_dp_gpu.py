@@ -1,0 +1,67 @@
+"""Data parallelism on the GPU path: two replicas (two processes sharing the test box's one GPU, gloo rendezvous) against
+one process.
+
+* dp_mode="global" (all-gather of the fused features, normalisation + losses on the whole batch,
+  gradients summed): 2 replicas x 4 clips must reproduce 1 device x 8 clips -- same loss, same gradient.
+* dp_mode="replica" (the reference's MirroredStrategy, mains/mj_trainUWYHGaitNet_DataGen_CasiaB.py:342-349): the applied
+  gradient is the mean of the two per-slice gradients.
+"""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+
+def _run_replicas(mode, tmp_path, world=2):
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    out = str(tmp_path / ("dp_%s.npz" % mode))
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(r), WORLD_SIZE=str(world),
+                   LOCAL_RANK=str(r), UGN_DP_BACKEND="gloo")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tools", "dp_worker.py"), mode, out], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    logs = [p.communicate(timeout=600)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(l[-2000:] for l in logs)
+    return np.load(out)
+
+
+def _single(rows):
+    import dp_worker as W
+    xs, uses, labels, onehot = W.job_batch()
+    core = W.make_core(1, "replica")
+    cut = lambda a: torch.from_numpy(np.ascontiguousarray(a[rows])).cuda()
+    core.forward_backward([cut(x) for x in xs], [cut(u) for u in uses], labels[rows], cut(onehot))
+    return core.store.grad.cpu().numpy().copy(), core.losses()
+
+
+def _rel(a, b):
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+
+
+@pytest.mark.timeout(900)
+def test_global_batch_replicas_equal_one_device(dev, tmp_path):
+    got = _run_replicas("global", tmp_path)
+    grad, losses = _single(slice(0, 8))
+    assert abs(float(got["loss"]) - losses["loss"]) <= 1e-6 * max(1.0, abs(losses["loss"]))
+    assert abs(float(got["triplet"]) - losses["triplet"]) <= 1e-6
+    assert _rel(got["grad"], grad) <= 1e-5      # only the order of the fp32 sums over clips differs
+    assert np.isfinite(got["params"]).all()
+
+
+@pytest.mark.timeout(900)
+def test_replica_mode_averages_the_slice_gradients(dev, tmp_path):
+    got = _run_replicas("replica", tmp_path)
+    g0, l0 = _single(slice(0, 4))
+    g1, l1 = _single(slice(4, 8))
+    assert _rel(got["grad"], 0.5 * (g0 + g1)) <= 1e-6
+    assert abs(float(got["loss"]) - l0["loss"]) <= 1e-6 * max(1.0, abs(l0["loss"]))   # rank 0 reports its own slice

@@ -4,7 +4,15 @@ Replaces the reference's `tf.distribute.MirroredStrategy()` scope (mains/mj_trai
 458-461): every replica owns a contiguous slice of the batch, evaluates the loss on ITS slice (Keras per-replica loss,
 scaled by 1/replicas) and the parameter gradients are summed across replicas.  The only exchange on the path is that
 gradient all-reduce: one collective over the flat fp32 gradient buffer (35.8-40.7 MB); the 1/world
-factor is folded into the Adam kernel.  These helpers are backend-agnostic so that the logic is testable with gloo on CPU.
+factor is folded into the Adam kernel.
+
+Global-batch mode (`GaitCore(dp_mode="global")`, SURVEY.md section 8e collective (1)): the two places where samples are
+coupled -- the batch-axis l2_normalize (nets/mj_uwyhNets_ba.py:817,1191) and the triplet loss
+(nets/triplet_loss_all.py:8-77) -- are evaluated on the batch of ALL replicas, so that G GPUs x B/G clips compute exactly
+what one device computes on B clips.  That costs one extra all-gather of the fused features [62, B/G, 256]
+(`gather_batch_axis`, 0.3-1 MB per rank) and the gradients are then summed, not averaged.
+
+These helpers are backend-agnostic so that the logic is testable with gloo on CPU.
 """
 from __future__ import annotations
 
@@ -59,3 +67,29 @@ def allreduce_sum_(flat, group=None):
         return 1.0
     dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
     return 1.0 / world
+
+
+def gather_batch_axis(t, axis, group=None, check=True):
+    """All-gather `t` over the replicas and concatenate along `axis` in rank order.  Every replica must hold the same
+    shape (equal slices of the global batch); with check=True a mismatch is an error on every rank, not a hang (the
+    comparison synchronises with the host: the engine checks on the label exchange, before the step's kernels are queued,
+    and gathers the features of the same step unchecked)."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return t
+    world = dist.get_world_size(group)
+    if check:
+        shape = torch.tensor(list(t.shape), dtype=torch.int64, device=t.device)
+        shapes = [torch.empty_like(shape) for _ in range(world)]
+        dist.all_gather(shapes, shape, group=group)
+        if any(not torch.equal(s, shape) for s in shapes):
+            raise ValueError("global-batch mode needs equal per-replica shapes, got %r" % ([s.tolist() for s in shapes],))
+    parts = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(parts, t.contiguous(), group=group)
+    return torch.cat(parts, dim=axis)
+
+
+def group_rank(group=None):
+    import torch.distributed as dist
+    return dist.get_rank(group) if dist.is_available() and dist.is_initialized() else 0
