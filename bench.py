@@ -25,6 +25,15 @@ sys.path.insert(0, ROOT)
 
 KINDS = ("of", "gray", "depth")
 B_PER_GPU, L, NCLS = 24, 25, 150
+# secondary workloads (never the headline line): --workload c4 = SURVEY 8(d) "C4", the CASIA-B shape
+WORKLOADS = {
+    "c3": dict(kinds=("of", "gray", "depth"), clips=24, ncls=150, ids_per=2,
+               text="C3: 3 modalities (of 2ch + gray + depth), 25x60x60, %d clips/GPU, %d ids x %d, 150 classes, sign_max, "
+                    "7-pattern masks, triplet(0.2)+0.1*xent, Adam 1e-4"),
+    "c4": dict(kinds=("of", "gray", "sil"), clips=40, ncls=74, ids_per=10,
+               text="C4: 3 modalities (of 2ch + gray + silhouette), 25x60x60, %d clips/GPU, %d ids x %d, 74 classes, sign_max, "
+                    "7-pattern masks, triplet(0.2)+0.1*xent, Adam 1e-4"),
+}
 # algorithmic FLOPs: forward per clip per modality, exact from the layer shapes
 F_FWD = {1: 7.944e9, 2: 8.108e9}
 F_FIRST = {1: 0.164e9, 2: 0.328e9}
@@ -73,7 +82,17 @@ def main():
     ap.add_argument("--dp-mode", choices=("replica", "global"), default="replica",
                     help="N > 1: 'replica' = the reference's MirroredStrategy (losses per replica slice, one gradient "
                          "all-reduce); 'global' = all-gather the fused features so the losses see the whole batch")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c3", help="c3 is the headline workload")
+    ap.add_argument("--clips-per-gpu", type=int, default=0,
+                    help="override the workload's batch (e.g. 96 = the generator-expanded C3 batch); 0 = the workload's own")
     args = ap.parse_args()
+    wl = WORKLOADS[args.workload]
+    global KINDS, B_PER_GPU, NCLS
+    KINDS, NCLS = wl["kinds"], wl["ncls"]
+    B_PER_GPU = args.clips_per_gpu or wl["clips"]
+    if B_PER_GPU % wl["ids_per"]:
+        raise SystemExit("--clips-per-gpu must be a multiple of %d for workload %s" % (wl["ids_per"], args.workload))
+    n_ids = B_PER_GPU // wl["ids_per"]
 
     import torch
     import torch.distributed as dist
@@ -92,7 +111,7 @@ def main():
                                 device_id=torch.device("cuda", local))
     dev = torch.device("cuda", local)
 
-    xs, uses, labels, onehot = make_batch(KINDS, B_PER_GPU, L, NCLS, seed=232323 + rank)
+    xs, uses, labels, onehot = make_batch(KINDS, B_PER_GPU, L, NCLS, ids=n_ids, seed=232323 + rank)
     core = GaitCore([2, 1, 1], nclasses=NCLS, fuse_mode="sign_max", margin=0.2, loss_weights=(1.0, 0.1), device=dev,
                     seed=232323, lr=1e-4, world_size=world, skip_masked=args.skip_masked, dp_mode=args.dp_mode)
     dxs = [torch.from_numpy(x).to(dev) for x in xs]
@@ -176,8 +195,7 @@ def main():
         out = dict(metric="clips/sec (3-mod, L=25, 60x60) fwd+bwd+Adam", value=round(value, 2), unit="clips/s",
                    n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(dt / args.steps * 1e3, 3),
                    higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
-                   config=dict(workload="C3: 3 modalities (of 2ch + gray + depth), 25x60x60, 24 clips/GPU, 12 ids x 2, "
-                                        "150 classes, sign_max, 7-pattern masks, triplet(0.2)+0.1*xent, Adam 1e-4",
+                   config=dict(workload=wl["text"] % (B_PER_GPU, n_ids, wl["ids_per"]),
                                clips_per_gpu=B_PER_GPU, parallelism="dp%d" % world, dp_mode=args.dp_mode, masked_pairs_skipped=bool(args.skip_masked)),
                    whole_step_tflops=round(value * FLOP_PER_CLIP / 1e12, 2),
                    whole_step_frac_of_f32_mfma_peak=round(value * FLOP_PER_CLIP / world / PEAK_F32_MFMA, 4),
