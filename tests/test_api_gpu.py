@@ -100,3 +100,56 @@ def test_unsupported_configurations_fail_loudly(dev):
         UWYHSemiNet.build((3, 60, 60, 1), 4, [7], [96], optimizer=optimizers.SGD(0.001, 0.9), gaitset=True)
     with pytest.raises(ValueError):
         UWYHSemiNet.build((3, 50, 60, 1), 4, [7], [96], optimizer=optimizers.Adam(), gaitset=True)
+
+
+def test_checkpoints_are_keras_hdf5_files(dev, tmp_path):
+    """save_weights / save write the Keras HDF5 layout (ugaitnet_amd/keras_h5.py); load_weights restores from it by the
+    reference's layer names, takes the legacy npz container too, and honours by_name / skip_mismatch."""
+    from ugaitnet_amd import h5lite, keras_h5
+    from ugaitnet_amd.nets.mj_uwyhNets_ba import UWYHSemiNet, optimizers, sign_max
+    shapes = [(3, 60, 60, 2), (3, 60, 60, 1)]
+    mk = lambda seed, ncls: UWYHSemiNet.build_or_load(shapes, 4, [7, 5, 3, 2], [96, 192, 512, 4096], nclasses=ncls,
+                                                      optimizer=optimizers.Adam(lr=1e-3), loss_weights=[1.0, 0.1],
+                                                      fMerge=sign_max, gaitset=True, seed=seed)
+    a, b = mk(1, 5), mk(2, 5)
+    xs, uses, labels, onehot = make_batch(("of", "gray"), 4, 3, 5, ids=2, seed=8)
+    X, y = [xs[0], uses[0], xs[1], uses[1]], [labels.reshape(-1, 1), onehot]
+    a.train_on_batch(X, y)
+    wpath = os.path.join(tmp_path, "model-final-0001_weights.hdf5")
+    a.save_weights(wpath)
+    f = h5lite.File(wpath)
+    names = [n.decode() for n in f.attrs["layer_names"]]
+    assert names[:4] == ["time_distributed_1", "time_distributed_3", "conv2d_2", "conv2d_3"] and names[-1] == "classprob"
+    assert "time_distributed_16" in names and "mat_mul_1" in names            # second modality's counters
+    assert f["time_distributed_1/time_distributed_1/kernel:0"].shape == (5, 5, 2, 32)
+    assert f["classprob/classprob/kernel:0"].shape == (15872, 5)
+    sa = a.predict(X)
+    assert not np.array_equal(b.predict(X)[0], sa[0])
+    b.load_weights(wpath, by_name=True)
+    sb = b.predict(X)
+    assert np.array_equal(sb[0], sa[0]) and np.array_equal(sb[1], sa[1])
+    # classifier of another width: refused without skip_mismatch, encoders taken with it
+    c = mk(3, 7)
+    with pytest.raises(ValueError):
+        c.load_weights(wpath, by_name=True)
+    c2 = mk(3, 7)
+    c2.load_weights(wpath, by_name=True, skip_mismatch=True)
+    assert np.array_equal(c2.predict(X)[0], sa[0])
+    # full model: optimizer state and step counter survive, training continues identically
+    mpath = os.path.join(tmp_path, "model-state-0001.hdf5")
+    a.save(mpath)
+    a2 = UWYHSemiNet.loadnet(mpath)
+    assert a2.core.iterations == a.core.iterations == 1
+    la, la2 = a.train_on_batch(X, y), a2.train_on_batch(X, y)
+    assert la == la2 and np.array_equal(a.core.store.flat.cpu().numpy(), a2.core.store.flat.cpu().numpy())
+    # the npz container of earlier checkpoints still loads
+    npz = os.path.join(tmp_path, "old.npz")
+    a.save_weights(npz)
+    d = mk(4, 5)
+    d.load_weights(npz)
+    assert np.array_equal(d.predict(X)[0], a.predict(X)[0])
+    # a weights file is complete for by_name=False; an encoder-only file is not
+    e = mk(5, 5)
+    e.load_weights(wpath)
+    layers = [l for l in keras_h5.read_layers(wpath) if l[0] != "classprob"]
+    assert len(layers) == 22

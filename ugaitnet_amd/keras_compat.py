@@ -339,37 +339,83 @@ class GaitSetModel:
     def _weights_dict(self):
         return {"w/" + n: self.core.store.get(n) for n in self.core.store.names}
 
+    def _params(self):
+        return {n: self.core.store.get(n) for n in self.core.store.names}
+
     def save_weights(self, path):
-        _savez(path, self._weights_dict())
+        """`*.h5` / `*.hdf5`: the Keras HDF5 weights layout under the layer names the reference's graph carries
+        (ugaitnet_amd/keras_h5.py), readable by its `load_weights(by_name=True)`; any other name: an npz container."""
+        if _is_h5_name(path):
+            from . import keras_h5
+            keras_h5.write_weights(os.fspath(path), self._params(), self.core.in_channels, self.nclasses)
+        else:
+            _savez(path, self._weights_dict())
 
     def save(self, path):
+        """Weights + configuration + optimizer state (`model.save`).  HDF5 names: the weights below /model_weights as Keras
+        lays them out, this build's configuration in the root attribute `ugaitnet_config`, Adam's state below
+        /optimizer_weights."""
+        opt = {"m": self.core.store.m.cpu().numpy(), "v": self.core.store.v.cpu().numpy(),
+               "iterations": np.array([self.core.iterations], dtype=np.int64)}
+        if _is_h5_name(path):
+            from . import keras_h5
+            extra = {"optimizer_weights/" + k: v for k, v in opt.items()}
+            extra["ugaitnet_config"] = json.dumps(self.get_config())
+            keras_h5.write_weights(os.fspath(path), self._params(), self.core.in_channels, self.nclasses, extra=extra,
+                                   below="model_weights")
+            return
         d = self._weights_dict()
         d["config_json"] = np.frombuffer(json.dumps(self.get_config()).encode(), dtype=np.uint8)
-        d["opt/m"] = self.core.store.m.cpu().numpy()
-        d["opt/v"] = self.core.store.v.cpu().numpy()
-        d["opt/iterations"] = np.array([self.core.iterations], dtype=np.int64)
+        d.update({"opt/" + k: v for k, v in opt.items()})
         _savez(path, d)
 
+    def _set_opt_state(self, m, v, iterations):
+        import torch
+        if m.shape[0] == self.core.store.numel:
+            self.core.store.m.copy_(torch.from_numpy(np.ascontiguousarray(m)))
+            self.core.store.v.copy_(torch.from_numpy(np.ascontiguousarray(v)))
+            self.core.iterations = int(np.asarray(iterations).reshape(-1)[0])
+
     def load_weights(self, path, by_name=False, skip_mismatch=False):
-        with np.load(path, allow_pickle=False) as z:
-            for n in self.core.store.names:
-                key = "w/" + n
-                if key not in z.files:
-                    if by_name:
-                        continue
-                    raise ValueError("weight %s missing in %s" % (n, path))
-                a = z[key]
-                if tuple(a.shape) != tuple(self.core.store.shapes[n]):
-                    if skip_mismatch:
-                        continue
-                    raise ValueError("shape mismatch for %s: %r vs %r" % (n, a.shape, self.core.store.shapes[n]))
-                self.core.store.set(n, a)
-            if "opt/m" in z.files and z["opt/m"].shape[0] == self.core.store.numel:
-                import torch
-                self.core.store.m.copy_(torch.from_numpy(z["opt/m"]))
-                self.core.store.v.copy_(torch.from_numpy(z["opt/v"]))
-                self.core.iterations = int(z["opt/iterations"][0])
+        """Keras semantics: by_name=False wants every weight of the model in the file; by_name=True takes what is there;
+        skip_mismatch=True (by_name only in Keras) leaves a weight of a different shape untouched instead of failing.
+        Reads Keras HDF5 weight / model files (the reference's checkpoints) and this build's npz containers."""
+        shapes = self.core.store.shapes
+        if _file_is_h5(path):
+            from . import h5lite, keras_h5
+            found = keras_h5.assign(keras_h5.read_layers(os.fspath(path)), len(self.input_shapes), self.nclasses)
+            f = h5lite.File(os.fspath(path))
+            opt = None
+            if "optimizer_weights" in f and "m" in f["optimizer_weights"]:
+                g = f["optimizer_weights"]
+                opt = (g["m"].read(), g["v"].read(), g["iterations"].read())
+        else:
+            with np.load(path, allow_pickle=False) as z:
+                found = {k[2:]: z[k] for k in z.files if k.startswith("w/")}
+                opt = (z["opt/m"], z["opt/v"], z["opt/iterations"]) if "opt/m" in z.files else None
+        for n in self.core.store.names:
+            a = found.get(n)
+            if a is None:
+                if by_name:
+                    continue
+                raise ValueError("weight %s missing in %s" % (n, path))
+            if tuple(a.shape) != tuple(shapes[n]):
+                if skip_mismatch:
+                    continue
+                raise ValueError("shape mismatch for %s: %r vs %r" % (n, a.shape, shapes[n]))
+            self.core.store.set(n, a)
+        if opt is not None:
+            self._set_opt_state(*opt)
         self.core.weights_changed()
+
+
+def _is_h5_name(path):
+    return os.path.splitext(os.fspath(path))[1].lower() in (".h5", ".hdf5", ".hdf")
+
+
+def _file_is_h5(path):
+    with open(os.fspath(path), "rb") as fh:
+        return fh.read(8) == b"\x89HDF\r\n\x1a\n"
 
 
 def _savez(path, arrays):
@@ -404,9 +450,20 @@ def Model(inputs=None, outputs=None):
 
 
 def load_model(path, custom_objects=None, compile=False):
-    """Counterpart of keras load_model for files written by GaitSetModel.save()."""
-    with np.load(path, allow_pickle=False) as z:
-        cfg = json.loads(bytes(z["config_json"]).decode())
+    """Counterpart of keras load_model for files written by GaitSetModel.save() (HDF5 or npz).  A model file written by
+    Keras itself carries a Keras graph description this build cannot execute: rebuild the model with `build_or_load` and
+    restore its arrays with `load_weights(path, by_name=True)`, as the reference's own restore path does (:610-630)."""
+    if _file_is_h5(path):
+        from . import h5lite
+        attrs = h5lite.File(os.fspath(path)).attrs
+        if "ugaitnet_config" not in attrs:
+            raise ValueError("%s holds no ugaitnet_config attribute (a Keras-written model file?): build the model with "
+                             "build_or_load(...) and call load_weights(path, by_name=True)" % path)
+        c = attrs["ugaitnet_config"]
+        cfg = json.loads(c.decode() if isinstance(c, bytes) else str(c))
+    else:
+        with np.load(path, allow_pickle=False) as z:
+            cfg = json.loads(bytes(z["config_json"]).decode())
     fm = {"sign_max": sign_max, "max": Maximum, "avg": Average}[cfg["fmerge"]]
     oc = cfg["optimizer"]
     opt = Adam(lr=oc["lr"], beta_1=oc["beta_1"], beta_2=oc["beta_2"], epsilon=oc["epsilon"])
