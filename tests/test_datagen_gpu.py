@@ -1,0 +1,74 @@
+"""Sample files -> label-cycling sampler -> device-side batch assembly -> model.fit (SURVEY 8(f) ranks 2-4 together)."""
+import os
+import random
+import shutil
+
+import numpy as np
+import pytest
+
+from oracle import batch_oracle as BO
+from ugaitnet_amd import h5lite
+
+pytestmark = pytest.mark.gpu
+
+H5 = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "h5")
+SPECS = [dict(compress_factor=100.0, channels=2), dict(compress_factor=1.0, channels=1), dict(compress_factor=1.0, channels=1)]
+
+
+def _write_sample(path, data, label, gait):
+    w = h5lite.Writer()
+    w.create_dataset("data", data)
+    for k, v in (("label", np.uint16(label)), ("videoId", np.uint16(7)), ("gait", np.uint8(gait)),
+                 ("compressFactor", np.uint8(100 if data.dtype == np.int16 else 1))):
+        w.set_attr("", k, v)
+    w.save(path)
+
+
+def test_generator_feeds_fit_from_sample_files(dev, tmp_path):
+    from ugaitnet_amd.batching import ModalitySpec
+    from ugaitnet_amd.nets.mj_uwyhNets_ba import UWYHSemiNet3Mods, optimizers, sign_max
+    from ugaitnet_amd.sampler import DeviceDataGenerator
+    rng = np.random.default_rng(12)
+    dirs = [str(tmp_path / m) for m in ("of", "gray", "depth")]
+    for d in dirs:
+        os.makedirs(d)
+    all_samples, gaits, arrays = [], [], []
+    labels = [3, 3, 3, 3, 8, 8, 8, 8]
+    for i, lab in enumerate(labels):
+        of = rng.integers(-3000, 3000, (60, 60, 50)).astype(np.int16)
+        gray = rng.integers(0, 256, (60, 60, 25)).astype(np.uint8)
+        depth = rng.integers(0, 256, (60, 60, 25)).astype(np.uint8)
+        names = ["s%02d.h5" % i] * 3
+        if i == 0:     # a file as deepdish / PyTables lay it out (chunked, shuffled, deflated), written by the HDF5 library
+            shutil.copy(os.path.join(H5, "dd_sample_of.h5"), os.path.join(dirs[0], names[0]))
+            of = np.load(os.path.join(H5, "dd_sample_of.npz"))["data"]
+        else:
+            _write_sample(os.path.join(dirs[0], names[0]), of, lab, i % 2)
+        _write_sample(os.path.join(dirs[1], names[1]), gray, lab, i % 2)
+        row = [of, gray, depth]
+        if i == 5:     # no depth recording for this sample
+            names[2] = -1
+            row[2] = None
+        else:
+            _write_sample(os.path.join(dirs[2], names[2]), depth, lab, i % 2)
+        all_samples.append((tuple(names), lab))
+        gaits.append(i % 2)
+        arrays.append(row)
+    specs = [ModalitySpec("of", 2, compress_factor=100.0), ModalitySpec("gray", 1), ModalitySpec("depth", 1)]
+    labmap = {3: 0, 8: 1}
+    gen = DeviceDataGenerator(all_samples, gaits, dirs, specs, batch_size=8, n_classes=2, labmap=labmap, expand_level=2,
+                              repetition=2, shuffle=False, mask_rng=random.Random(41))
+    X, y = gen[0]
+    ids = [0, 1, 2, 3, 4, 5, 6, 7]     # 2 labels x (2 gait types x 2 pairs): records in label order, gait types alternating
+    assert y[0].reshape(-1).tolist() == [0, 0] * 4 + [1, 1] * 4 and y[1].shape == (16, 2)
+    x_ref, _ = BO.gen_batch_mm([arrays[i] for i in ids], SPECS, 2, seed=41)
+    for k in range(6):
+        assert np.array_equal(X[k].cpu().numpy(), x_ref[k]), "input %d" % k
+    model = UWYHSemiNet3Mods.build_or_load([(25, 60, 60, 2), (25, 60, 60, 1), (25, 60, 60, 1)], 4, [7, 5, 3, 2],
+                                           [96, 192, 512, 4096], optimizer=optimizers.Adam(lr=1e-4), nclasses=2,
+                                           loss_weights=[1.0, 0.1], fMerge=sign_max, gaitset=True, seed=1)
+    hist = model.fit(gen, epochs=2, steps_per_epoch=1, verbose=0)
+    assert len(hist.history["loss"]) == 2 and np.isfinite(hist.history["loss"]).all()
+    ck = str(tmp_path / "model-final-0002_weights.hdf5")
+    model.save_weights(ck)
+    assert h5lite.File(ck)["mat_mul_2"].keys() == ["MatMul_kernel[2]:0"]
