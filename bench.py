@@ -82,6 +82,9 @@ def main():
     ap.add_argument("--dp-mode", choices=("replica", "global"), default="replica",
                     help="N > 1: 'replica' = the reference's MirroredStrategy (losses per replica slice, one gradient "
                          "all-reduce); 'global' = all-gather the fused features so the losses see the whole batch")
+    ap.add_argument("--dtype", choices=("f32", "bf16"), default="f32",
+                    help="bf16 = BASELINE configs[4] / SURVEY C5 arithmetic: bf16 operands in the MFMA of the 3x3 forward "
+                         "convolutions and data gradients, fp32 accumulate, fp32 tensors and weight gradients; never the headline")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c3", help="c3 is the headline workload")
     ap.add_argument("--clips-per-gpu", type=int, default=0,
                     help="override the workload's batch (e.g. 96 = the generator-expanded C3 batch); 0 = the workload's own")
@@ -113,7 +116,7 @@ def main():
 
     xs, uses, labels, onehot = make_batch(KINDS, B_PER_GPU, L, NCLS, ids=n_ids, seed=232323 + rank)
     core = GaitCore([2, 1, 1], nclasses=NCLS, fuse_mode="sign_max", margin=0.2, loss_weights=(1.0, 0.1), device=dev,
-                    seed=232323, lr=1e-4, world_size=world, skip_masked=args.skip_masked, dp_mode=args.dp_mode)
+                    seed=232323, lr=1e-4, world_size=world, skip_masked=args.skip_masked, dp_mode=args.dp_mode, conv_precision=args.dtype)
     dxs = [torch.from_numpy(x).to(dev) for x in xs]
     dus = uses if args.skip_masked else [torch.from_numpy(u).to(dev) for u in uses]   # flags: host copies when they steer the launch
     doh = torch.from_numpy(onehot).to(dev)
@@ -147,7 +150,7 @@ def main():
         del core
         torch.cuda.empty_cache()
         core2 = GaitCore([2, 1, 1], nclasses=NCLS, fuse_mode="sign_max", margin=0.2, loss_weights=(1.0, 0.1), device=dev,
-                         seed=232323, lr=1e-4, world_size=world, skip_masked=True, dp_mode=args.dp_mode)
+                         seed=232323, lr=1e-4, world_size=world, skip_masked=True, dp_mode=args.dp_mode, conv_precision=args.dtype)
         for _ in range(args.warmup):
             core2.train_step(dxs, uses, labels, doh)
         sync_all()
@@ -194,7 +197,9 @@ def main():
             roof["other_kernels"] = others
         out = dict(metric="clips/sec (3-mod, L=25, 60x60) fwd+bwd+Adam", value=round(value, 2), unit="clips/s",
                    n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(dt / args.steps * 1e3, 3),
-                   higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
+                   higher_is_better=True, scaling="weak", vs_baseline=None,
+                   dtype="f32" if args.dtype == "f32" else "bf16 MFMA operands in the 3x3 fwd/dgrad (f32 tensors, accumulate, wgrad)",
+                   data="synthetic",
                    config=dict(workload=wl["text"] % (B_PER_GPU, n_ids, wl["ids_per"]),
                                clips_per_gpu=B_PER_GPU, parallelism="dp%d" % world, dp_mode=args.dp_mode, masked_pairs_skipped=bool(args.skip_masked)),
                    whole_step_tflops=round(value * FLOP_PER_CLIP / 1e12, 2),

@@ -89,6 +89,20 @@ int ugn_conv3x3_fwd_wino_pair(const float* const* in, const float* const* u_pack
 int ugn_conv3x3_dgrad_wino_pair(const float* const* dz, const uint8_t* const* dz_idx, const float* const* u_packed,
                                 const float* const* act, const float* const* addend, float* const* out,
                                 float* const* raw_out, const int* n, int hw, int cin, int cout, void* stream);
+/* bf16-operand variants (BASELINE.json configs[4] / SURVEY 8(d) "C5": bf16 operands in the MFMA, fp32 accumulate): same
+ * arguments, tensors stay fp32 in HBM; the Winograd-domain operands are rounded to bf16 (round to nearest even) and multiplied
+ * on v_mfma_f32_16x16x16_bf16.  u_packed must come from ugn_wino_pack with 4 added to `dgrad` (bf16 elements, first half of
+ * the buffer).  The data gradient supports the plain epilogue and `act` (no addend / raw_out). */
+int ugn_conv3x3_fwd_wino_bf16(const float* in, const float* u_packed, float* out, uint8_t* out_idx, int n, int hw, int cin,
+                              int cout, int pool, void* stream);
+int ugn_conv3x3_dgrad_wino_bf16(const float* dz, const uint8_t* dz_idx, const float* u_packed, const float* act,
+                                const float* addend, float* out, float* raw_out, int n, int hw, int cin, int cout,
+                                void* stream);
+int ugn_conv3x3_fwd_wino_pair_bf16(const float* const* in, const float* const* u_packed, float* const* out,
+                                   uint8_t* const* out_idx, const int* n, int hw, int cin, int cout, int pool, void* stream);
+int ugn_conv3x3_dgrad_wino_pair_bf16(const float* const* dz, const uint8_t* const* dz_idx, const float* const* u_packed,
+                                     const float* const* act, const float* const* addend, float* const* out,
+                                     float* const* raw_out, const int* n, int hw, int cin, int cout, void* stream);
 /* Data gradient whose addend is the set-max gradient of the layer's output (the Add of the two gradient paths into p2 / p4,
  * nets/mj_uwyhNets_ba.py:435,451): out = (dgrad + ((act == smax_m[clip]) ? smax_g[clip] : 0)) * LeakyReLU'(act), clip =
  * image / frames; smax_m [n/frames,hw,hw,cin] = the set maxima (ugn_setmax_fwd_cnt), smax_g = dL/dm / #maxima (ugn_div of

@@ -17,6 +17,7 @@ SOURCES = ["conv3x3.hip", "conv3x3_wino.hip", "conv3x3_wino_tall.hip", "wgrad3x3
 HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "wino_common.h"), os.path.join(HERE, "..", "include", "ugaitnet_hip.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-fno-slp-vectorize"]
+FLAGS += os.environ.get("UGN_EXTRA_HIPCC_FLAGS", "").split()   # experiments only (e.g. -DUGN_...); the default build sets none
 
 
 def _stale(target, deps):

@@ -55,6 +55,11 @@ constexpr int UPW = 12, UCS = 44, UPIX = 10 * UPW, USLOTS = UPIX * 11, UPIECES =
 __device__ __forceinline__ void wino_pack_one(const float* __restrict__ w, float* __restrict__ u, int cin, int cout, int mode,
                                               int e) {
   const int dgrad = mode & 1;   // mode: 0 fwd, 1 dgrad of a full-resolution dz, 3 dgrad of a pooled dz (same layout as 1)
+  const bool bf = (mode & 4) != 0;   // + 4: bf16 elements in the same element order (the buffer is then half used)
+  auto put = [&](float* base, int off, float v) {
+    if (bf) reinterpret_cast<__bf16*>(u)[(base - u) + off] = (__bf16)v;
+    else base[off] = v;
+  };
   const int kc = dgrad ? cout : cin, nc = dgrad ? cin : cout;
   if (e >= kc * nc) return;
   // consecutive threads walk the contiguous axis of the HWIO filter: cout = n in the forward, cout = k in the data gradient
@@ -78,10 +83,10 @@ __device__ __forceinline__ void wino_pack_one(const float* __restrict__ w, float
     for (int r = 0; r < 4; ++r) {
       const float u0 = t[r][0], u1 = 0.5f * (t[r][0] + t[r][1] + t[r][2]), u2 = 0.5f * (t[r][0] - t[r][1] + t[r][2]),
                   u3 = t[r][2];
-      dst[(r * 4 + 0) * 256] = u0;
-      dst[(r * 4 + 1) * 256] = u1;
-      dst[(r * 4 + 2) * 256] = u2;
-      dst[(r * 4 + 3) * 256] = u3;
+      put(dst, (r * 4 + 0) * 256, u0);
+      put(dst, (r * 4 + 1) * 256, u1);
+      put(dst, (r * 4 + 2) * 256, u2);
+      put(dst, (r * 4 + 3) * 256, u3);
     }
     return;
   }
@@ -97,10 +102,10 @@ __device__ __forceinline__ void wino_pack_one(const float* __restrict__ w, float
   for (int r = 0; r < 4; ++r) {
     const float u0 = t[r][0], u1 = 0.5f * (t[r][0] + t[r][1] + t[r][2]), u2 = 0.5f * (t[r][0] - t[r][1] + t[r][2]),
                 u3 = t[r][2];
-    dst[(r * 4 + 0) * 512] = u0;
-    dst[(r * 4 + 1) * 512] = u1;
-    dst[(r * 4 + 2) * 512] = u2;
-    dst[(r * 4 + 3) * 512] = u3;
+    put(dst, (r * 4 + 0) * 512, u0);
+    put(dst, (r * 4 + 1) * 512, u1);
+    put(dst, (r * 4 + 2) * 512, u2);
+    put(dst, (r * 4 + 3) * 512, u3);
   }
 }
 
@@ -214,14 +219,15 @@ __device__ __forceinline__ void read_pair_pooled_row(float2 (&dn)[16], const flo
     }
 }
 
-// 32 KB filter slice: linear in both spaces, 4 pieces of 1 KB per wave (8 waves)
+// 32 KB filter slice (16 KB of bf16 elements): linear in both spaces, 4 (2) pieces of 1 KB per wave (8 waves)
+template <bool BF>
 __device__ __forceinline__ void dma_u_slice(const float* __restrict__ us, unsigned lds_byte_base, int tid, int wave) {
 #pragma unroll
-  for (int q = 0; q < 4; ++q) dma16(us + (q * 512 + tid) * 4, lds_byte_base + (unsigned)(q * 512 + wave * 64) * 16u);
+  for (int q = 0; q < (BF ? 2 : 4); ++q) dma16(us + (q * 512 + tid) * 4, lds_byte_base + (unsigned)(q * 512 + wave * 64) * 16u);
 }
 
 // KC: GEMM K channels, NCF: output channels of the layer (a workgroup owns 32 of them), HW: image size
-template <int KC, int NCF, int HW, int IN_UNPOOL, int EPI, int EFLAGS>
+template <int KC, int NCF, int HW, int IN_UNPOOL, int EPI, int EFLAGS, bool BF = false>
 __global__ __launch_bounds__(512, 2) void wino_kernel(const WinoJob j0, const WinoJob j1, const float* __restrict__ zeros,
                                                       int nitems0, int nitems) {
   // WIDE (NCF >= 64): the workgroup owns 64 output channels, a wave 16 tiles x 2 channel blocks, and a group is 8 input
@@ -262,7 +268,7 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const WinoJob j0, const Wi
   auto in_of = [&](int it) { return it >= nitems0 ? j1.in : j0.in; };
   auto idx_of = [&](int it) { return it >= nitems0 ? j1.in_idx : j0.in_idx; };
   auto u_slice = [&](int it, int chunk, int G) {
-    return (it >= nitems0 ? j1.upk : j0.upk) + (((size_t)(local(it) % NSPLIT) * NCHUNK + chunk) * NG + G) * SU;
+    return (it >= nitems0 ? j1.upk : j0.upk) + (((size_t)(local(it) % NSPLIT) * NCHUNK + chunk) * NG + G) * (BF ? SU / 2 : SU);
   };
   // ---- prologue: halo(item, chunk 0) -> sIn[0]; U(item, 0, 0) -> sU[0]
   {
@@ -278,7 +284,7 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const WinoJob j0, const Wi
       for (int j = 0; j < 6; ++j)
         dma_halo_piece<KC, HW>(in, zeros, img, (rrem / RPX) * 16, (rrem % RPX) * 16, 0, wave * 6 + j, halo_slot_geometry(wave * 6 + j, lane), sin_bytes);
     }
-    dma_u_slice(u_slice(item, 0, 0), su_bytes, tid, wave);
+    dma_u_slice<BF>(u_slice(item, 0, 0), su_bytes, tid, wave);
   }
   int ibuf = 0, ubuf = 0;
   float V[16][2 * NH]; // transformed patch (4 / 2 channels) of the group about to be multiplied
@@ -319,7 +325,7 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const WinoJob j0, const Wi
         // filter slice of the next group -> the other buffer, while this group computes
         // (single-chunk layers: the two slices of the workgroup's 32 output channels stay resident after the first item)
         if (NCHUNK > 1 || !u_resident || first_item)
-          dma_u_slice(G + 1 < NG ? u_slice(item, chunk, G + 1) : u_slice(n_item, n_chunk, 0), su_bytes + (unsigned)(ubuf ^ 1) * SU * 4u, tid, wave);
+          dma_u_slice<BF>(G + 1 < NG ? u_slice(item, chunk, G + 1) : u_slice(n_item, n_chunk, 0), su_bytes + (unsigned)(ubuf ^ 1) * SU * 4u, tid, wave);
         if (first) {
           first = false;
 #pragma unroll
@@ -374,16 +380,38 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const WinoJob j0, const Wi
         // points are multiplied in PAIRS with their 4 k-steps interleaved (pt0 s0, pt1 s0, pt0 s1, ...): consecutive
         // MFMAs on one accumulator would each wait out the 40-cycle dependent latency of v_mfma_f32_16x16x4_f32
         float4 u[2][2];
-        u[0][0] = *reinterpret_cast<const float4*>(sU + ubase);
-        u[0][1] = *reinterpret_cast<const float4*>(sU + ubase + 512);
+        uint2 ub[2][2];   // BF: the same 4 elements as bf16 (8 bytes per point)
+        if constexpr (BF) {
+          ub[0][0] = *reinterpret_cast<const uint2*>(sU + ubase / 2);
+          ub[0][1] = *reinterpret_cast<const uint2*>(sU + ubase / 2 + 256);
+        } else {
+          u[0][0] = *reinterpret_cast<const float4*>(sU + ubase);
+          u[0][1] = *reinterpret_cast<const float4*>(sU + ubase + 512);
+        }
 #pragma unroll
         for (int pp = 0; pp < 8; ++pp) {
           const int cu = pp & 1, nu = cu ^ 1;
           if (pp < 7) {
-            u[nu][0] = *reinterpret_cast<const float4*>(sU + ubase + (2 * pp + 2) * 512);
-            u[nu][1] = *reinterpret_cast<const float4*>(sU + ubase + (2 * pp + 3) * 512);
+            if constexpr (BF) {
+              ub[nu][0] = *reinterpret_cast<const uint2*>(sU + ubase / 2 + (2 * pp + 2) * 256);
+              ub[nu][1] = *reinterpret_cast<const uint2*>(sU + ubase / 2 + (2 * pp + 3) * 256);
+            } else {
+              u[nu][0] = *reinterpret_cast<const float4*>(sU + ubase + (2 * pp + 2) * 512);
+              u[nu][1] = *reinterpret_cast<const float4*>(sU + ubase + (2 * pp + 3) * 512);
+            }
           }
-          if constexpr (WIDE) {   // u float4 = {cb0 s0, cb0 s1, cb1 s0, cb1 s1}
+          if constexpr (BF && WIDE) {   // ub = {cb0 (s0, s1), cb1 (s0, s1)}: one bf16 MFMA per block, k-slots 2, 3 empty
+            const uint32_t a0 = pk_bf16(V[2 * pp][0], V[2 * pp][1]), a1 = pk_bf16(V[2 * pp + 1][0], V[2 * pp + 1][1]);
+            acc[0][2 * pp] = mfma_bf16(a0, 0u, ub[cu][0].x, 0u, acc[0][2 * pp]);
+            acc[0][2 * pp + 1] = mfma_bf16(a1, 0u, ub[cu][1].x, 0u, acc[0][2 * pp + 1]);
+            acc[1][2 * pp] = mfma_bf16(a0, 0u, ub[cu][0].y, 0u, acc[1][2 * pp]);
+            acc[1][2 * pp + 1] = mfma_bf16(a1, 0u, ub[cu][1].y, 0u, acc[1][2 * pp + 1]);
+          } else if constexpr (BF) {    // the lane's 4 channels in one bf16 MFMA
+            acc[0][2 * pp] = mfma_bf16(pk_bf16(V[2 * pp][0], V[2 * pp][1]), pk_bf16(V[2 * pp][2], V[2 * pp][3]), ub[cu][0].x,
+                                       ub[cu][0].y, acc[0][2 * pp]);
+            acc[0][2 * pp + 1] = mfma_bf16(pk_bf16(V[2 * pp + 1][0], V[2 * pp + 1][1]), pk_bf16(V[2 * pp + 1][2], V[2 * pp + 1][3]),
+                                           ub[cu][1].x, ub[cu][1].y, acc[0][2 * pp + 1]);
+          } else if constexpr (WIDE) {   // u float4 = {cb0 s0, cb0 s1, cb1 s0, cb1 s1}
 #pragma unroll
             for (int st = 0; st < 2; ++st)
 #pragma unroll
@@ -573,9 +601,9 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const WinoJob j0, const Wi
   }
 }
 
-template <int KC, int NCF, int HW, int IN_UNPOOL, int EPI, int EFLAGS>
+template <int KC, int NCF, int HW, int IN_UNPOOL, int EPI, int EFLAGS, bool BF = false>
 int launch_wino(const WinoJob* jobs, const int* n, int njobs, hipStream_t st) {
-  auto kern = wino_kernel<KC, NCF, HW, IN_UNPOOL, EPI, EFLAGS>;
+  auto kern = wino_kernel<KC, NCF, HW, IN_UNPOOL, EPI, EFLAGS, BF>;
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
@@ -593,8 +621,14 @@ int launch_wino(const WinoJob* jobs, const int* n, int njobs, hipStream_t st) {
 }
 
 template <int KC, int NCF, int HW, int IN_UNPOOL>
-int launch_wino_dgrad(const WinoJob* jobs, const int* n, int njobs, hipStream_t st) {
+int launch_wino_dgrad(const WinoJob* jobs, const int* n, int njobs, bool bf, hipStream_t st) {
   const int flags = (jobs[0].act ? 1 : 0) | (jobs[0].addend ? 2 : 0) | (jobs[0].raw_out ? 4 : 0) | (jobs[0].smax_m ? 8 : 0);
+  if (bf) {   // bf16 operands: the two epilogues the training step uses (plain, and LeakyReLU' of the layer's input)
+    if (flags == 0) return launch_wino<KC, NCF, HW, IN_UNPOOL, EPI_DGRAD, 0, true>(jobs, n, njobs, st);
+    if (flags == 1) return launch_wino<KC, NCF, HW, IN_UNPOOL, EPI_DGRAD, 1, true>(jobs, n, njobs, st);
+    ugn_set_error("ugn_conv3x3_dgrad_wino_bf16: epilogue combination %d is not built for bf16 operands (plain or act only)", flags);
+    return UGN_EINVAL;
+  }
   if constexpr (KC == 128 && NCF == 64 && HW == 16 && !IN_UNPOOL)   // a5: act + routed set-max gradient
     if (flags == 9) return launch_wino<KC, NCF, HW, IN_UNPOOL, EPI_DGRAD, 9>(jobs, n, njobs, st);
 #define UGN_WDG(F_) \
@@ -609,18 +643,19 @@ int launch_wino_dgrad(const WinoJob* jobs, const int* n, int njobs, hipStream_t 
   return UGN_EINVAL;
 }
 
-int dispatch_fwd(const WinoJob* jobs, const int* n, int njobs, int hw, int cin, int cout, int pool, hipStream_t st) {
-  if (wino_tall(cin, cout)) return launch_tall(0, jobs, n, njobs, hw, cin, pool != 0, st);   // (the filter layout differs)
-#define WF(KC_, NC_, HW_, P_)                                             \
-  if (cin == KC_ && cout == NC_ && hw == HW_ && (pool != 0) == (P_ != 0)) \
-    return launch_wino<KC_, NC_, HW_, 0, P_ ? EPI_LRELU_POOL : EPI_LRELU, 0>(jobs, n, njobs, st);
+int dispatch_fwd(const WinoJob* jobs, const int* n, int njobs, int hw, int cin, int cout, int pool, bool bf, hipStream_t st) {
+  if (wino_tall(cin, cout)) return launch_tall(0, jobs, n, njobs, hw, cin, pool != 0, bf, st);   // (the filter layout differs)
+#define WF(KC_, NC_, HW_, P_)                                                                                     \
+  if (cin == KC_ && cout == NC_ && hw == HW_ && (pool != 0) == (P_ != 0))                                         \
+    return bf ? launch_wino<KC_, NC_, HW_, 0, P_ ? EPI_LRELU_POOL : EPI_LRELU, 0, true>(jobs, n, njobs, st)       \
+              : launch_wino<KC_, NC_, HW_, 0, P_ ? EPI_LRELU_POOL : EPI_LRELU, 0>(jobs, n, njobs, st);
   WF(32, 32, 64, 1) WF(32, 64, 32, 0) WF(64, 64, 32, 1) WF(64, 128, 16, 0) WF(128, 128, 16, 0)
 #undef WF
   ugn_set_error("ugn_conv3x3_fwd_wino: unsupported shape cin=%d cout=%d hw=%d pool=%d", cin, cout, hw, pool);
   return UGN_EINVAL;
 }
 
-int dispatch_dgrad(const WinoJob* jobs, const int* n, int njobs, int hw, int cin, int cout, int unpool, hipStream_t st) {
+int dispatch_dgrad(const WinoJob* jobs, const int* n, int njobs, int hw, int cin, int cout, int unpool, bool bf, hipStream_t st) {
   if (njobs > 1) {   // one kernel instantiation serves both jobs: they must use the same epilogue operands
     const int f0 = (jobs[0].act ? 1 : 0) | (jobs[0].addend ? 2 : 0) | (jobs[0].raw_out ? 4 : 0) | (jobs[0].smax_m ? 8 : 0);
     const int f1 = (jobs[1].act ? 1 : 0) | (jobs[1].addend ? 2 : 0) | (jobs[1].raw_out ? 4 : 0) | (jobs[1].smax_m ? 8 : 0);
@@ -629,10 +664,10 @@ int dispatch_dgrad(const WinoJob* jobs, const int* n, int njobs, int hw, int cin
       return UGN_EINVAL;
     }
   }
-  if (wino_tall(cout, cin)) return launch_tall(1, jobs, n, njobs, hw, cout, unpool, st);
+  if (wino_tall(cout, cin)) return launch_tall(1, jobs, n, njobs, hw, cout, unpool, bf, st);
 #define WD(CI_, CO_, HW_, U_)                                 \
   if (cin == CI_ && cout == CO_ && hw == HW_ && unpool == U_) \
-    return launch_wino_dgrad<CO_, CI_, HW_, U_>(jobs, n, njobs, st);
+    return launch_wino_dgrad<CO_, CI_, HW_, U_>(jobs, n, njobs, bf, st);
   WD(32, 32, 64, 1) WD(32, 64, 32, 0) WD(64, 64, 32, 1) WD(64, 128, 16, 0) WD(128, 128, 16, 0)
 #undef WD
   ugn_set_error("ugn_conv3x3_dgrad_wino: unsupported shape cin=%d cout=%d hw=%d unpool=%d", cin, cout, hw, unpool);
@@ -680,17 +715,24 @@ extern "C" int ugn_wino_pack_multi(const float* const* w_hwio_host, float* const
   return 0;
 }
 
-extern "C" int ugn_conv3x3_fwd_wino(const float* in, const float* u_packed, float* out, uint8_t* out_idx, int n, int hw,
-                                    int cin, int cout, int pool, void* stream) {
+static int fwd_one(const float* in, const float* u_packed, float* out, uint8_t* out_idx, int n, int hw, int cin, int cout,
+                   int pool, bool bf, void* stream) {
   UGN_REQUIRE(in && u_packed && out && n > 0, "ugn_conv3x3_fwd_wino: null pointer or n <= 0");
   UGN_REQUIRE(!pool || out_idx, "ugn_conv3x3_fwd_wino: pool needs out_idx");
   const WinoJob job = {in, nullptr, u_packed, out, out_idx, nullptr, nullptr, nullptr};
-  return dispatch_fwd(&job, &n, 1, hw, cin, cout, pool, (hipStream_t)stream);
+  return dispatch_fwd(&job, &n, 1, hw, cin, cout, pool, bf, (hipStream_t)stream);
+}
+extern "C" int ugn_conv3x3_fwd_wino(const float* in, const float* u_packed, float* out, uint8_t* out_idx, int n, int hw,
+                                    int cin, int cout, int pool, void* stream) {
+  return fwd_one(in, u_packed, out, out_idx, n, hw, cin, cout, pool, false, stream);
+}
+extern "C" int ugn_conv3x3_fwd_wino_bf16(const float* in, const float* u_packed, float* out, uint8_t* out_idx, int n, int hw,
+                                         int cin, int cout, int pool, void* stream) {
+  return fwd_one(in, u_packed, out, out_idx, n, hw, cin, cout, pool, true, stream);
 }
 
-extern "C" int ugn_conv3x3_fwd_wino_pair(const float* const* in, const float* const* u_packed, float* const* out,
-                                         uint8_t* const* out_idx, const int* n, int hw, int cin, int cout, int pool,
-                                         void* stream) {
+static int fwd_pair(const float* const* in, const float* const* u_packed, float* const* out, uint8_t* const* out_idx,
+                    const int* n, int hw, int cin, int cout, int pool, bool bf, void* stream) {
   UGN_REQUIRE(in && u_packed && out && n, "ugn_conv3x3_fwd_wino_pair: null array");
   WinoJob jobs[2];
   for (int j = 0; j < 2; ++j) {
@@ -698,15 +740,34 @@ extern "C" int ugn_conv3x3_fwd_wino_pair(const float* const* in, const float* co
     UGN_REQUIRE(!pool || (out_idx && out_idx[j]), "ugn_conv3x3_fwd_wino_pair: pool needs out_idx");
     jobs[j] = {in[j], nullptr, u_packed[j], out[j], pool ? out_idx[j] : nullptr, nullptr, nullptr, nullptr};
   }
-  return dispatch_fwd(jobs, n, 2, hw, cin, cout, pool, (hipStream_t)stream);
+  return dispatch_fwd(jobs, n, 2, hw, cin, cout, pool, bf, (hipStream_t)stream);
+}
+extern "C" int ugn_conv3x3_fwd_wino_pair(const float* const* in, const float* const* u_packed, float* const* out,
+                                         uint8_t* const* out_idx, const int* n, int hw, int cin, int cout, int pool,
+                                         void* stream) {
+  return fwd_pair(in, u_packed, out, out_idx, n, hw, cin, cout, pool, false, stream);
+}
+extern "C" int ugn_conv3x3_fwd_wino_pair_bf16(const float* const* in, const float* const* u_packed, float* const* out,
+                                              uint8_t* const* out_idx, const int* n, int hw, int cin, int cout, int pool,
+                                              void* stream) {
+  return fwd_pair(in, u_packed, out, out_idx, n, hw, cin, cout, pool, true, stream);
 }
 
+static int dgrad_one(const float* dz, const uint8_t* dz_idx, const float* u_packed, const float* act, const float* addend,
+                     float* out, float* raw_out, int n, int hw, int cin, int cout, bool bf, void* stream) {
+  UGN_REQUIRE(dz && u_packed && out && n > 0, "ugn_conv3x3_dgrad_wino: null pointer or n <= 0");
+  const WinoJob job = {dz, dz_idx, u_packed, out, nullptr, act, addend, raw_out};
+  return dispatch_dgrad(&job, &n, 1, hw, cin, cout, dz_idx != nullptr, bf, (hipStream_t)stream);
+}
 extern "C" int ugn_conv3x3_dgrad_wino(const float* dz, const uint8_t* dz_idx, const float* u_packed, const float* act,
                                       const float* addend, float* out, float* raw_out, int n, int hw, int cin, int cout,
                                       void* stream) {
-  UGN_REQUIRE(dz && u_packed && out && n > 0, "ugn_conv3x3_dgrad_wino: null pointer or n <= 0");
-  const WinoJob job = {dz, dz_idx, u_packed, out, nullptr, act, addend, raw_out};
-  return dispatch_dgrad(&job, &n, 1, hw, cin, cout, dz_idx != nullptr, (hipStream_t)stream);
+  return dgrad_one(dz, dz_idx, u_packed, act, addend, out, raw_out, n, hw, cin, cout, false, stream);
+}
+extern "C" int ugn_conv3x3_dgrad_wino_bf16(const float* dz, const uint8_t* dz_idx, const float* u_packed, const float* act,
+                                           const float* addend, float* out, float* raw_out, int n, int hw, int cin, int cout,
+                                           void* stream) {
+  return dgrad_one(dz, dz_idx, u_packed, act, addend, out, raw_out, n, hw, cin, cout, true, stream);
 }
 
 extern "C" int ugn_conv3x3_dgrad_wino_routed(const float* dz, const float* u_packed, const float* act, const float* smax_m,
@@ -718,12 +779,12 @@ extern "C" int ugn_conv3x3_dgrad_wino_routed(const float* dz, const float* u_pac
   job.smax_m = smax_m;
   job.smax_g = smax_g;
   job.frames = frames;
-  return dispatch_dgrad(&job, &n, 1, hw, cin, cout, 0, (hipStream_t)stream);
+  return dispatch_dgrad(&job, &n, 1, hw, cin, cout, 0, false, (hipStream_t)stream);
 }
 
-extern "C" int ugn_conv3x3_dgrad_wino_pair(const float* const* dz, const uint8_t* const* dz_idx, const float* const* u_packed,
-                                           const float* const* act, const float* const* addend, float* const* out,
-                                           float* const* raw_out, const int* n, int hw, int cin, int cout, void* stream) {
+static int dgrad_pair(const float* const* dz, const uint8_t* const* dz_idx, const float* const* u_packed,
+                      const float* const* act, const float* const* addend, float* const* out, float* const* raw_out,
+                      const int* n, int hw, int cin, int cout, bool bf, void* stream) {
   UGN_REQUIRE(dz && u_packed && out && n, "ugn_conv3x3_dgrad_wino_pair: null array");
   WinoJob jobs[2];
   for (int j = 0; j < 2; ++j) {
@@ -732,5 +793,16 @@ extern "C" int ugn_conv3x3_dgrad_wino_pair(const float* const* dz, const uint8_t
                addend ? addend[j] : nullptr, raw_out ? raw_out[j] : nullptr};
   }
   UGN_REQUIRE((jobs[0].in_idx != nullptr) == (jobs[1].in_idx != nullptr), "ugn_conv3x3_dgrad_wino_pair: dz_idx for both jobs or none");
-  return dispatch_dgrad(jobs, n, 2, hw, cin, cout, jobs[0].in_idx != nullptr, (hipStream_t)stream);
+  return dispatch_dgrad(jobs, n, 2, hw, cin, cout, jobs[0].in_idx != nullptr, bf, (hipStream_t)stream);
+}
+extern "C" int ugn_conv3x3_dgrad_wino_pair(const float* const* dz, const uint8_t* const* dz_idx, const float* const* u_packed,
+                                           const float* const* act, const float* const* addend, float* const* out,
+                                           float* const* raw_out, const int* n, int hw, int cin, int cout, void* stream) {
+  return dgrad_pair(dz, dz_idx, u_packed, act, addend, out, raw_out, n, hw, cin, cout, false, stream);
+}
+extern "C" int ugn_conv3x3_dgrad_wino_pair_bf16(const float* const* dz, const uint8_t* const* dz_idx,
+                                                const float* const* u_packed, const float* const* act,
+                                                const float* const* addend, float* const* out, float* const* raw_out,
+                                                const int* n, int hw, int cin, int cout, void* stream) {
+  return dgrad_pair(dz, dz_idx, u_packed, act, addend, out, raw_out, n, hw, cin, cout, true, stream);
 }

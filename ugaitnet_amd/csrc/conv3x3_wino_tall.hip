@@ -94,14 +94,15 @@ __device__ __forceinline__ void tall_read_pooled_row(float2 (&dn)[16], const flo
     }
 }
 
-// 16 KB filter slice: 2 pieces of 1 KB per wave
+// 16 KB filter slice: 2 pieces of 1 KB per wave (bf16 elements: 8 KB, 1 piece)
+template <bool BF>
 __device__ __forceinline__ void tall_dma_u(const float* __restrict__ us, unsigned lds_byte_base, int tid, int wave) {
 #pragma unroll
-  for (int q = 0; q < 2; ++q) dma16(us + (q * 512 + tid) * 4, lds_byte_base + (unsigned)(q * 512 + wave * 64) * 16u);
+  for (int q = 0; q < (BF ? 1 : 2); ++q) dma16(us + (q * 512 + tid) * 4, lds_byte_base + (unsigned)(q * 512 + wave * 64) * 16u);
 }
 
 // KC: GEMM K channels (32 or 64); 32 output channels; HW: image size
-template <int KC, int HW, int IN_UNPOOL, int EPI, int EFLAGS>
+template <int KC, int HW, int IN_UNPOOL, int EPI, int EFLAGS, bool BF = false>
 __global__ __launch_bounds__(512, 2) void wino_tall_kernel(const WinoJob j0, const WinoJob j1, const float* __restrict__ zeros,
                                                            int nitems0, int nitems) {
   constexpr int NST = KC / 16;                 // 16-channel stages per item
@@ -131,7 +132,7 @@ __global__ __launch_bounds__(512, 2) void wino_tall_kernel(const WinoJob j0, con
   auto local = [&](int it) { return it >= nitems0 ? it - nitems0 : it; };
   auto in_of = [&](int it) { return it >= nitems0 ? j1.in : j0.in; };
   auto idx_of = [&](int it) { return it >= nitems0 ? j1.in_idx : j0.in_idx; };
-  auto u_slice = [&](int it, int gi) { return (it >= nitems0 ? j1.upk : j0.upk) + (size_t)gi * TSUG; };
+  auto u_slice = [&](int it, int gi) { return (it >= nitems0 ? j1.upk : j0.upk) + (size_t)gi * (BF ? TSUG / 2 : TSUG); };
   auto dma_stage = [&](int it, int stage, int j, unsigned lds) {   // piece j (0..5 plain, 0..2 pooled) of this wave
     const int region = local(it), img = region / RPI, rrem = region % RPI;
     const int ry0 = (rrem / RPX) * 32, rx0 = (rrem % RPX) * 16;
@@ -147,9 +148,9 @@ __global__ __launch_bounds__(512, 2) void wino_tall_kernel(const WinoJob j0, con
   for (int j = 0; j < (IN_UNPOOL ? 3 : 6); ++j) dma_stage(item, 0, j, sin_bytes);
   if (u_resident) {
 #pragma unroll
-    for (int gi = 0; gi < NUB; ++gi) tall_dma_u(u_slice(item, gi), su_bytes + (unsigned)gi * TSUG * 4u, tid, wave);
+    for (int gi = 0; gi < NUB; ++gi) tall_dma_u<BF>(u_slice(item, gi), su_bytes + (unsigned)gi * TSUG * 4u, tid, wave);
   } else {
-    tall_dma_u(u_slice(item, 0), su_bytes, tid, wave);
+    tall_dma_u<BF>(u_slice(item, 0), su_bytes, tid, wave);
   }
   int ibuf = 0, ubuf = 0;
   float V[16][2];      // transformed patch (2 channels) of the group about to be multiplied
@@ -183,7 +184,7 @@ __global__ __launch_bounds__(512, 2) void wino_tall_kernel(const WinoJob j0, con
         }
         const float* sU = sU0 + ubuf * TSUG;
         if (!u_resident)   // filter slice of the next group -> next ring slot, while this group computes
-          tall_dma_u(G == 0 ? u_slice(item, 2 * st + 1) : u_slice(n_item, 2 * n_stage), su_bytes + (unsigned)((ubuf + 1) & (NUB - 1)) * TSUG * 4u,
+          tall_dma_u<BF>(G == 0 ? u_slice(item, 2 * st + 1) : u_slice(n_item, 2 * n_stage), su_bytes + (unsigned)((ubuf + 1) & (NUB - 1)) * TSUG * 4u,
                      tid, wave);
         if (first) {
           first = false;
@@ -229,22 +230,41 @@ __global__ __launch_bounds__(512, 2) void wino_tall_kernel(const WinoJob j0, con
         };
         // points in PAIRS, their k-steps and channel blocks interleaved: no MFMA waits on its predecessor
         float4 u[2][2];   // {cb0 s0, cb0 s1, cb1 s0, cb1 s1}
-        u[0][0] = *reinterpret_cast<const float4*>(sU + ubase);
-        u[0][1] = *reinterpret_cast<const float4*>(sU + ubase + 256);
+        uint2 ub[2][2];   // BF: the same 4 elements as bf16
+        if constexpr (BF) {
+          ub[0][0] = *reinterpret_cast<const uint2*>(sU + ubase / 2);
+          ub[0][1] = *reinterpret_cast<const uint2*>(sU + ubase / 2 + 128);
+        } else {
+          u[0][0] = *reinterpret_cast<const float4*>(sU + ubase);
+          u[0][1] = *reinterpret_cast<const float4*>(sU + ubase + 256);
+        }
 #pragma unroll
         for (int pp = 0; pp < 8; ++pp) {
           const int cu = pp & 1, nu = cu ^ 1;
           if (pp < 7) {
-            u[nu][0] = *reinterpret_cast<const float4*>(sU + ubase + (2 * pp + 2) * 256);
-            u[nu][1] = *reinterpret_cast<const float4*>(sU + ubase + (2 * pp + 3) * 256);
-          }
-#pragma unroll
-          for (int s = 0; s < 2; ++s)
-#pragma unroll
-            for (int cb = 0; cb < 2; ++cb) {
-              acc[cb][2 * pp] = mfma16(V[2 * pp][s], u[cu][0][cb * 2 + s], acc[cb][2 * pp]);
-              acc[cb][2 * pp + 1] = mfma16(V[2 * pp + 1][s], u[cu][1][cb * 2 + s], acc[cb][2 * pp + 1]);
+            if constexpr (BF) {
+              ub[nu][0] = *reinterpret_cast<const uint2*>(sU + ubase / 2 + (2 * pp + 2) * 128);
+              ub[nu][1] = *reinterpret_cast<const uint2*>(sU + ubase / 2 + (2 * pp + 3) * 128);
+            } else {
+              u[nu][0] = *reinterpret_cast<const float4*>(sU + ubase + (2 * pp + 2) * 256);
+              u[nu][1] = *reinterpret_cast<const float4*>(sU + ubase + (2 * pp + 3) * 256);
             }
+          }
+          if constexpr (BF) {   // one bf16 MFMA per channel block: the lane's 2 channels in k-slots 0, 1 (2, 3 empty)
+            const uint32_t a0 = pk_bf16(V[2 * pp][0], V[2 * pp][1]), a1 = pk_bf16(V[2 * pp + 1][0], V[2 * pp + 1][1]);
+            acc[0][2 * pp] = mfma_bf16(a0, 0u, ub[cu][0].x, 0u, acc[0][2 * pp]);
+            acc[0][2 * pp + 1] = mfma_bf16(a1, 0u, ub[cu][1].x, 0u, acc[0][2 * pp + 1]);
+            acc[1][2 * pp] = mfma_bf16(a0, 0u, ub[cu][0].y, 0u, acc[1][2 * pp]);
+            acc[1][2 * pp + 1] = mfma_bf16(a1, 0u, ub[cu][1].y, 0u, acc[1][2 * pp + 1]);
+          } else {
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+              for (int cb = 0; cb < 2; ++cb) {
+                acc[cb][2 * pp] = mfma16(V[2 * pp][s], u[cu][0][cb * 2 + s], acc[cb][2 * pp]);
+                acc[cb][2 * pp + 1] = mfma16(V[2 * pp + 1][s], u[cu][1][cb * 2 + s], acc[cb][2 * pp + 1]);
+              }
+          }
 #pragma unroll
           for (int half = 0; half < 2; ++half) {
             const int pt = 2 * pp + half;
@@ -385,9 +405,9 @@ __global__ __launch_bounds__(512, 2) void wino_tall_kernel(const WinoJob j0, con
   }
 }
 
-template <int KC, int HW, int IN_UNPOOL, int EPI, int EFLAGS>
+template <int KC, int HW, int IN_UNPOOL, int EPI, int EFLAGS, bool BF = false>
 int launch_tall_t(const WinoJob* jobs, const int* n, int njobs, hipStream_t st) {
-  auto kern = wino_tall_kernel<KC, HW, IN_UNPOOL, EPI, EFLAGS>;
+  auto kern = wino_tall_kernel<KC, HW, IN_UNPOOL, EPI, EFLAGS, BF>;
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, TLDS);
@@ -405,8 +425,14 @@ int launch_tall_t(const WinoJob* jobs, const int* n, int njobs, hipStream_t st) 
 }
 
 template <int KC, int HW, int IN_UNPOOL>
-int launch_tall_dgrad(const WinoJob* jobs, const int* n, int njobs, hipStream_t st) {
+int launch_tall_dgrad(const WinoJob* jobs, const int* n, int njobs, bool bf, hipStream_t st) {
   const int flags = (jobs[0].act ? 1 : 0) | (jobs[0].addend ? 2 : 0) | (jobs[0].raw_out ? 4 : 0) | (jobs[0].smax_m ? 8 : 0);
+  if (bf) {
+    if (flags == 0) return launch_tall_t<KC, HW, IN_UNPOOL, EPI_DGRAD, 0, true>(jobs, n, njobs, st);
+    if (flags == 1) return launch_tall_t<KC, HW, IN_UNPOOL, EPI_DGRAD, 1, true>(jobs, n, njobs, st);
+    ugn_set_error("ugn_conv3x3_dgrad_wino_bf16: epilogue combination %d is not built for bf16 operands (plain or act only)", flags);
+    return UGN_EINVAL;
+  }
   if constexpr (KC == 64 && HW == 32 && !IN_UNPOOL)   // a3: act + routed set-max gradient
     if (flags == 9) return launch_tall_t<KC, HW, IN_UNPOOL, EPI_DGRAD, 9>(jobs, n, njobs, st);
 #define UGN_TDG(F_) \
@@ -429,10 +455,12 @@ bool tall_supported(int kind, int hw, int kc, int flag) {
   return (hw == 64 && kc == 32 && flag) || (hw == 32 && kc == 64 && !flag);              // a2, a3 / b1 data gradient
 }
 
-int launch_tall(int kind, const WinoJob* jobs, const int* n, int njobs, int hw, int kc, int flag, hipStream_t st) {
-  if (kind == 0 && hw == 64 && kc == 32 && flag) return launch_tall_t<32, 64, 0, EPI_LRELU_POOL, 0>(jobs, n, njobs, st);
-  if (kind == 1 && hw == 64 && kc == 32 && flag) return launch_tall_dgrad<32, 64, 1>(jobs, n, njobs, st);
-  if (kind == 1 && hw == 32 && kc == 64 && !flag) return launch_tall_dgrad<64, 32, 0>(jobs, n, njobs, st);
+int launch_tall(int kind, const WinoJob* jobs, const int* n, int njobs, int hw, int kc, int flag, bool bf, hipStream_t st) {
+  if (kind == 0 && hw == 64 && kc == 32 && flag)
+    return bf ? launch_tall_t<32, 64, 0, EPI_LRELU_POOL, 0, true>(jobs, n, njobs, st)
+              : launch_tall_t<32, 64, 0, EPI_LRELU_POOL, 0>(jobs, n, njobs, st);
+  if (kind == 1 && hw == 64 && kc == 32 && flag) return launch_tall_dgrad<32, 64, 1>(jobs, n, njobs, bf, st);
+  if (kind == 1 && hw == 32 && kc == 64 && !flag) return launch_tall_dgrad<64, 32, 0>(jobs, n, njobs, bf, st);
   ugn_set_error("wino tall: unsupported shape kind=%d hw=%d kc=%d flag=%d", kind, hw, kc, flag);
   return UGN_EINVAL;
 }

@@ -40,6 +40,24 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
+// bf16-operand variant (template flag BF of the kernels; SURVEY 8(d) "C5": bf16 operands in the MFMA, fp32 accumulate, fp32
+// tensors in HBM).  A lane owns 4 (narrow) or 2 (wide / tall) channels of a group: their transformed values are rounded to
+// bf16 and fed to ONE v_mfma_f32_16x16x16_bf16 (k-slot i of lane kq = the lane's i-th channel; unused slots hold zeros on both
+// operands) in place of 4 / 2 v_mfma_f32_16x16x4_f32; the filters are packed as bf16 in the same element order
+// (ugn_wino_pack mode bit 4), which halves their LDS-DMA traffic.  D layout as mfma16.
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint32_t pk_bf16(float a, float b) {   // v_cvt_pk_bf16_f32 (round to nearest even)
+  bf16x2_t r;
+  r[0] = (__bf16)a;
+  r[1] = (__bf16)b;
+  return __builtin_bit_cast(uint32_t, r);
+}
+__device__ __forceinline__ f32x4 mfma_bf16(uint32_t a01, uint32_t a23, uint32_t b01, uint32_t b23, f32x4 c) {
+  const uint2 a = make_uint2(a01, a23), b = make_uint2(b01, b23);
+  return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(bf16x4_t, a), __builtin_bit_cast(bf16x4_t, b), c, 0, 0, 0);
+}
+
 // global -> LDS, 16 B per lane, no VGPR destination (LDS address = M0 + lane * 16).  Inline asm: with the builtin hipcc
 // waits vmcnt(0) before the next ds_read (it cannot tell the DMA target from the buffers being read), which exposes the
 // whole global latency.  Completion is awaited by the caller (s_waitcnt vmcnt) before the barrier that publishes the data.
@@ -68,6 +86,6 @@ const float* zero_block();
 
 // tall variant (conv3x3_wino_tall.hip); kind: 0 forward, 1 data gradient
 bool tall_supported(int kind, int hw, int kc, int unpool_or_pool);
-int launch_tall(int kind, const WinoJob* jobs, const int* n, int njobs, int hw, int kc, int unpool_or_pool, hipStream_t st);
+int launch_tall(int kind, const WinoJob* jobs, const int* n, int njobs, int hw, int kc, int unpool_or_pool, bool bf, hipStream_t st);
 
 }  // namespace ugn_wino

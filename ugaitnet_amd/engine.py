@@ -151,8 +151,13 @@ class ParamStore:
 class Encoder:
     """One modality branch: build_gaitset_branch (nets/mj_uwyhNets_ba.py:419-484), forward and backward."""
 
-    def __init__(self, store, prefix, cin):
+    def __init__(self, store, prefix, cin, bf16=False):
         self.store, self.prefix, self.cin = store, prefix, cin
+        # bf16: the 3x3 forward convolutions and data gradients multiply bf16-rounded Winograd-domain operands (fp32
+        # accumulate, fp32 tensors); weight gradients, the 5x5 layer and everything else stay fp32 (DESIGN section 4)
+        self.bf16 = bool(bf16)
+        if self.bf16 and not (USE_WINOGRAD and PAIR_LAUNCHES and not ROUTED):
+            raise ValueError("conv_precision='bf16' needs the default Winograd pair-launch path")
         self.wp = {}       # packed forward weights of the 3x3 layers (direct kernels)
         self.uf = {}       # Winograd-transformed filters, forward
         self.ud = {}       # Winograd-transformed filters, data gradient
@@ -178,7 +183,7 @@ class Encoder:
                     if name not in store:
                         store[name] = torch.empty((16 * w.shape[2] * w.shape[3],), dtype=F32, device=w.device)
                     jobs.append((w, store[name], dgrad, pool))   # a pooled layer's dgrad takes dz at pooled resolution
-            ops.wino_pack_multi(jobs)
+            ops.wino_pack_multi(jobs, bf16=self.bf16)
         else:
             for name, k, _, _, _, _ in CONV_SPECS:
                 if k == 3:
@@ -187,14 +192,14 @@ class Encoder:
     def conv(self, name, x, pool, out, idx=None):
         """3x3 conv + LeakyReLU (+ MaxPool) of layer `name`."""
         if USE_WINOGRAD:
-            return ops.conv3x3_fwd_wino(x, self.uf[name], self.W(name).shape[3], pool, out, idx)
+            return ops.conv3x3_fwd_wino(x, self.uf[name], self.W(name).shape[3], pool, out, idx, bf16=self.bf16)
         return ops.conv3x3_fwd(x, self.wp[name], pool, out, idx)
 
     def dgrad(self, name, dz, hw, **kw):
         """Data gradient of layer `name` (fused epilogue options as in ops.conv3x3_dgrad)."""
         if USE_WINOGRAD and name in WINO_DGRAD:
             w = self.W(name)
-            return ops.conv3x3_dgrad_wino(dz, self.ud[name], hw, w.shape[2], w.shape[3], **kw)
+            return ops.conv3x3_dgrad_wino(dz, self.ud[name], hw, w.shape[2], w.shape[3], bf16=self.bf16, **kw)
         return ops.conv3x3_dgrad(dz, self.W(name), hw, **kw)
 
     # The global branch applies each 3x3 shape of the frame stack once more, to B set-level maps instead of B*L frames.
@@ -203,7 +208,7 @@ class Encoder:
     def conv_pair(self, names, xs, pool, outs, idxs=None):
         if USE_WINOGRAD and PAIR_LAUNCHES:
             return ops.conv3x3_fwd_wino_pair(list(xs), [self.uf[n] for n in names], self.W(names[0]).shape[3], pool, list(outs),
-                                             list(idxs) if pool else None)
+                                             list(idxs) if pool else None, bf16=self.bf16)
         res = [self.conv(n, x, pool, o, i) for n, x, o, i in zip(names, xs, outs, idxs or (None, None))]
         return ([r[0] for r in res], [r[1] for r in res]) if pool else res
 
@@ -211,7 +216,7 @@ class Encoder:
         if USE_WINOGRAD and PAIR_LAUNCHES:
             w = self.W(names[0])
             return ops.conv3x3_dgrad_wino_pair(list(dzs), [self.ud[n] for n in names], hw, w.shape[2], w.shape[3], list(outs),
-                                               dz_idxs=dz_idxs, acts=acts)
+                                               dz_idxs=dz_idxs, acts=acts, bf16=self.bf16)
         return [self.dgrad(n, dz, hw, dz_idx=None if dz_idxs is None else dz_idxs[k], act=None if acts is None else acts[k],
                            out=outs[k]) for k, (n, dz) in enumerate(zip(names, dzs))]
 
@@ -352,7 +357,7 @@ class GaitCore:
 
     def __init__(self, in_channels, nclasses=0, multimodal=None, fuse_mode="sign_max", margin=0.2,
                  loss_weights=(1.0, 1.0), device=None, seed=None, lr=1e-4, beta_1=0.9, beta_2=0.999, epsilon=1e-7,
-                 process_group=None, world_size=1, skip_masked=False, dp_mode="replica"):
+                 process_group=None, world_size=1, skip_masked=False, dp_mode="replica", conv_precision="f32"):
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         self.in_channels = tuple(int(c) for c in in_channels)
         self.nmod = len(self.in_channels)
@@ -386,7 +391,11 @@ class GaitCore:
         if self.nclasses > 0:
             named += [("head.wc", (NBINS * HIDDEN, self.nclasses)), ("head.bc", (self.nclasses,))]
         self.store = ParamStore(named, self.device)
-        self.encoders = [Encoder(self.store, "m%d." % mi, cin) for mi, cin in enumerate(self.in_channels)]
+        if conv_precision not in ("f32", "bf16"):
+            raise ValueError("conv_precision must be 'f32' or 'bf16', got %r" % (conv_precision,))
+        self.conv_precision = conv_precision
+        self.encoders = [Encoder(self.store, "m%d." % mi, cin, bf16=conv_precision == "bf16")
+                         for mi, cin in enumerate(self.in_channels)]
         self.scratch = {}
         self.bufs = {}
         self._tri_cache = {}

@@ -131,22 +131,23 @@ def conv3x3_dgrad(dz, w, hw, dz_idx=None, act=None, addend=None, out=None, raw_o
     return out
 
 
-def _pack_mode(dgrad, pooled_dz):
-    # 0: forward; 1: data gradient of a full-resolution dz; 3: data gradient of a pooled dz (+ argmax)
-    return (1 | (2 if pooled_dz else 0)) if dgrad else 0
+def _pack_mode(dgrad, pooled_dz, bf16=False):
+    # 0: forward; 1: data gradient of a full-resolution dz; 3: data gradient of a pooled dz (+ argmax); + 4: bf16 elements
+    return ((1 | (2 if pooled_dz else 0)) if dgrad else 0) | (4 if bf16 else 0)
 
 
-def wino_pack(w, dgrad, out=None, pooled_dz=False):
+def wino_pack(w, dgrad, out=None, pooled_dz=False, bf16=False):
     """HWIO [3,3,cin,cout] -> transformed filters G g G^T in the Winograd kernels' streaming order (16*cin*cout floats).
-    `pooled_dz`: the data gradient will be called with dz_idx (the layer is followed by MaxPool)."""
+    `pooled_dz`: the data gradient will be called with dz_idx (the layer is followed by MaxPool).  `bf16`: elements rounded
+    to bf16 (first half of the buffer), for the *_bf16 convolution entry points."""
     _chk(w)
     cin, cout = w.shape[2], w.shape[3]
     out = torch.empty((16 * cin * cout,), dtype=F32, device=w.device) if out is None else out
-    call("ugn_wino_pack", ptr(w), ptr(out), cin, cout, _pack_mode(dgrad, pooled_dz), _stream())
+    call("ugn_wino_pack", ptr(w), ptr(out), cin, cout, _pack_mode(dgrad, pooled_dz, bf16), _stream())
     return out
 
 
-def wino_pack_multi(jobs):
+def wino_pack_multi(jobs, bf16=False):
     """jobs: list of (w HWIO tensor, u_packed tensor, dgrad flag, pooled_dz flag); one launch for up to 32 of them."""
     for k in range(0, len(jobs), 32):
         part = jobs[k:k + 32]
@@ -155,11 +156,11 @@ def wino_pack_multi(jobs):
         us = ptr_array([j[1] for j in part])
         cin = (C.c_int * n)(*[j[0].shape[2] for j in part])
         cout = (C.c_int * n)(*[j[0].shape[3] for j in part])
-        dg = (C.c_int * n)(*[_pack_mode(j[2], j[3]) for j in part])
+        dg = (C.c_int * n)(*[_pack_mode(j[2], j[3], bf16) for j in part])
         call("ugn_wino_pack_multi", ws, us, cin, cout, dg, n, _stream())
 
 
-def conv3x3_fwd_wino(x, upk, cout, pool, out=None, idx=None):
+def conv3x3_fwd_wino(x, upk, cout, pool, out=None, idx=None, bf16=False):
     _chk(x), _chk(upk)
     n, hw, cin = x.shape[0], x.shape[1], x.shape[3]
     ho = hw // 2 if pool else hw
@@ -168,16 +169,16 @@ def conv3x3_fwd_wino(x, upk, cout, pool, out=None, idx=None):
         idx = torch.empty((n, ho, ho, cout), dtype=U8, device=x.device)
     name = ROOFLINE_OP if (hw == 64 and cin == 32 and cout == 32) else "conv3x3_fwd[a6: 128->128 @16x16 +LeakyReLU]"
     with _Timed(name, (hw == 64 and cin == 32 and cout == 32) or (hw == 16 and cin == 128 and cout == 128 and n >= 100)):
-        call("ugn_conv3x3_fwd_wino", ptr(x), ptr(upk), ptr(out), ptr(idx) if pool else None, n, hw, cin, cout,
+        call("ugn_conv3x3_fwd_wino" + ("_bf16" if bf16 else ""), ptr(x), ptr(upk), ptr(out), ptr(idx) if pool else None, n, hw, cin, cout,
              int(bool(pool)), _stream())
     return (out, idx) if pool else out
 
 
-def conv3x3_dgrad_wino(dz, upk, hw, cin, cout, dz_idx=None, act=None, addend=None, out=None, raw_out=None):
+def conv3x3_dgrad_wino(dz, upk, hw, cin, cout, dz_idx=None, act=None, addend=None, out=None, raw_out=None, bf16=False):
     _chk(dz), _chk(upk)
     n = dz.shape[0]
     out = torch.empty((n, hw, hw, cin), dtype=F32, device=dz.device) if out is None else out
-    call("ugn_conv3x3_dgrad_wino", ptr(dz), ptr(dz_idx), ptr(upk), ptr(act), ptr(addend), ptr(out), ptr(raw_out), n, hw,
+    call("ugn_conv3x3_dgrad_wino" + ("_bf16" if bf16 else ""), ptr(dz), ptr(dz_idx), ptr(upk), ptr(act), ptr(addend), ptr(out), ptr(raw_out), n, hw,
          cin, cout, _stream())
     return out
 
@@ -198,7 +199,7 @@ def _opt_ptr_array(pair):
     return None if pair is None or pair[0] is None else ptr_array(pair)
 
 
-def conv3x3_fwd_wino_pair(xs, upks, cout, pool, outs, idxs=None):
+def conv3x3_fwd_wino_pair(xs, upks, cout, pool, outs, idxs=None, bf16=False):
     """Two forward convolutions of one shape (different inputs / filters / image counts) in a single launch."""
     for t in xs + upks + outs:
         _chk(t)
@@ -207,17 +208,17 @@ def conv3x3_fwd_wino_pair(xs, upks, cout, pool, outs, idxs=None):
     ns = (C.c_int * 2)(xs[0].shape[0], xs[1].shape[0])
     name = "conv3x3_fwd[a6: 128->128 @16x16 +LeakyReLU]" if hw == 16 else "conv3x3_fwd[a4: 64->64 @32x32 +LeakyReLU +MaxPool]"
     with _Timed(name, ns[0] >= 100 and ((hw == 16 and cin == 128 and cout == 128) or (hw == 32 and cin == 64 and cout == 64 and pool))):
-        call("ugn_conv3x3_fwd_wino_pair", ptr_array(xs), ptr_array(upks), ptr_array(outs), _opt_ptr_array(idxs if pool else None),
+        call("ugn_conv3x3_fwd_wino_pair" + ("_bf16" if bf16 else ""), ptr_array(xs), ptr_array(upks), ptr_array(outs), _opt_ptr_array(idxs if pool else None),
              ns, hw, cin, cout, int(bool(pool)), _stream())
     return (outs, idxs) if pool else outs
 
 
-def conv3x3_dgrad_wino_pair(dzs, upks, hw, cin, cout, outs, dz_idxs=None, acts=None, addends=None, raw_outs=None):
+def conv3x3_dgrad_wino_pair(dzs, upks, hw, cin, cout, outs, dz_idxs=None, acts=None, addends=None, raw_outs=None, bf16=False):
     """Two data gradients of one shape in a single launch; the optional operands are given for both jobs or neither."""
     for t in dzs + upks + outs:
         _chk(t)
     ns = (C.c_int * 2)(dzs[0].shape[0], dzs[1].shape[0])
-    call("ugn_conv3x3_dgrad_wino_pair", ptr_array(dzs), _opt_ptr_array(dz_idxs), ptr_array(upks), _opt_ptr_array(acts),
+    call("ugn_conv3x3_dgrad_wino_pair" + ("_bf16" if bf16 else ""), ptr_array(dzs), _opt_ptr_array(dz_idxs), ptr_array(upks), _opt_ptr_array(acts),
          _opt_ptr_array(addends), ptr_array(outs), _opt_ptr_array(raw_outs), ns, hw, cin, cout, _stream())
     return outs
 
