@@ -288,6 +288,11 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const WinoJob j0, const Wi
   }
   int ibuf = 0, ubuf = 0;
   float V[16][2 * NH]; // transformed patch (4 / 2 channels) of the group about to be multiplied
+  uint32_t Vp[16][NH]; // BF: the same, rounded to bf16 as it is produced (channel pairs packed: half the registers)
+  auto setV = [&](int pt, int h, float x, float y) {
+    if constexpr (BF) Vp[pt][h] = pk_bf16(x, y);
+    else { V[pt][2 * h] = x; V[pt][2 * h + 1] = y; }
+  };
   bool first = true;   // only the very first group of the workgroup transforms its patch un-pipelined
 
   // every item of this workgroup has the same nsp (-> the same filter slices) when the grid is a multiple of NSPLIT
@@ -341,10 +346,10 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const WinoJob j0, const Wi
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-              V[r * 4 + 0][2 * h] = t[r * 4 + 0].x - t[r * 4 + 2].x; V[r * 4 + 0][2 * h + 1] = t[r * 4 + 0].y - t[r * 4 + 2].y;
-              V[r * 4 + 1][2 * h] = t[r * 4 + 1].x + t[r * 4 + 2].x; V[r * 4 + 1][2 * h + 1] = t[r * 4 + 1].y + t[r * 4 + 2].y;
-              V[r * 4 + 2][2 * h] = t[r * 4 + 2].x - t[r * 4 + 1].x; V[r * 4 + 2][2 * h + 1] = t[r * 4 + 2].y - t[r * 4 + 1].y;
-              V[r * 4 + 3][2 * h] = t[r * 4 + 1].x - t[r * 4 + 3].x; V[r * 4 + 3][2 * h + 1] = t[r * 4 + 1].y - t[r * 4 + 3].y;
+              setV(r * 4 + 0, h, t[r * 4 + 0].x - t[r * 4 + 2].x, t[r * 4 + 0].y - t[r * 4 + 2].y);
+              setV(r * 4 + 1, h, t[r * 4 + 1].x + t[r * 4 + 2].x, t[r * 4 + 1].y + t[r * 4 + 2].y);
+              setV(r * 4 + 2, h, t[r * 4 + 2].x - t[r * 4 + 1].x, t[r * 4 + 2].y - t[r * 4 + 1].y);
+              setV(r * 4 + 3, h, t[r * 4 + 1].x - t[r * 4 + 3].x, t[r * 4 + 1].y - t[r * 4 + 3].y);
             }
           }
         }
@@ -366,15 +371,15 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const WinoJob j0, const Wi
           tn[12 + c] = make_float2(d1.x - d3.x, d1.y - d3.y);
         };
         auto colpass = [&](int r) {
-          V[r * 4 + 0][0] = tn0[r * 4 + 0].x - tn0[r * 4 + 2].x; V[r * 4 + 0][1] = tn0[r * 4 + 0].y - tn0[r * 4 + 2].y;
-          V[r * 4 + 1][0] = tn0[r * 4 + 1].x + tn0[r * 4 + 2].x; V[r * 4 + 1][1] = tn0[r * 4 + 1].y + tn0[r * 4 + 2].y;
-          V[r * 4 + 2][0] = tn0[r * 4 + 2].x - tn0[r * 4 + 1].x; V[r * 4 + 2][1] = tn0[r * 4 + 2].y - tn0[r * 4 + 1].y;
-          V[r * 4 + 3][0] = tn0[r * 4 + 1].x - tn0[r * 4 + 3].x; V[r * 4 + 3][1] = tn0[r * 4 + 1].y - tn0[r * 4 + 3].y;
+          setV(r * 4 + 0, 0, tn0[r * 4 + 0].x - tn0[r * 4 + 2].x, tn0[r * 4 + 0].y - tn0[r * 4 + 2].y);
+          setV(r * 4 + 1, 0, tn0[r * 4 + 1].x + tn0[r * 4 + 2].x, tn0[r * 4 + 1].y + tn0[r * 4 + 2].y);
+          setV(r * 4 + 2, 0, tn0[r * 4 + 2].x - tn0[r * 4 + 1].x, tn0[r * 4 + 2].y - tn0[r * 4 + 1].y);
+          setV(r * 4 + 3, 0, tn0[r * 4 + 1].x - tn0[r * 4 + 3].x, tn0[r * 4 + 1].y - tn0[r * 4 + 3].y);
           if constexpr (NH == 2) {
-            V[r * 4 + 0][2] = tn1[r * 4 + 0].x - tn1[r * 4 + 2].x; V[r * 4 + 0][3] = tn1[r * 4 + 0].y - tn1[r * 4 + 2].y;
-            V[r * 4 + 1][2] = tn1[r * 4 + 1].x + tn1[r * 4 + 2].x; V[r * 4 + 1][3] = tn1[r * 4 + 1].y + tn1[r * 4 + 2].y;
-            V[r * 4 + 2][2] = tn1[r * 4 + 2].x - tn1[r * 4 + 1].x; V[r * 4 + 2][3] = tn1[r * 4 + 2].y - tn1[r * 4 + 1].y;
-            V[r * 4 + 3][2] = tn1[r * 4 + 1].x - tn1[r * 4 + 3].x; V[r * 4 + 3][3] = tn1[r * 4 + 1].y - tn1[r * 4 + 3].y;
+            setV(r * 4 + 0, 1, tn1[r * 4 + 0].x - tn1[r * 4 + 2].x, tn1[r * 4 + 0].y - tn1[r * 4 + 2].y);
+            setV(r * 4 + 1, 1, tn1[r * 4 + 1].x + tn1[r * 4 + 2].x, tn1[r * 4 + 1].y + tn1[r * 4 + 2].y);
+            setV(r * 4 + 2, 1, tn1[r * 4 + 2].x - tn1[r * 4 + 1].x, tn1[r * 4 + 2].y - tn1[r * 4 + 1].y);
+            setV(r * 4 + 3, 1, tn1[r * 4 + 1].x - tn1[r * 4 + 3].x, tn1[r * 4 + 1].y - tn1[r * 4 + 3].y);
           }
         };
         // points are multiplied in PAIRS with their 4 k-steps interleaved (pt0 s0, pt1 s0, pt0 s1, ...): consecutive
@@ -401,16 +406,15 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const WinoJob j0, const Wi
             }
           }
           if constexpr (BF && WIDE) {   // ub = {cb0 (s0, s1), cb1 (s0, s1)}: one bf16 MFMA per block, k-slots 2, 3 empty
-            const uint32_t a0 = pk_bf16(V[2 * pp][0], V[2 * pp][1]), a1 = pk_bf16(V[2 * pp + 1][0], V[2 * pp + 1][1]);
-            acc[0][2 * pp] = mfma_bf16(a0, 0u, ub[cu][0].x, 0u, acc[0][2 * pp]);
-            acc[0][2 * pp + 1] = mfma_bf16(a1, 0u, ub[cu][1].x, 0u, acc[0][2 * pp + 1]);
-            acc[1][2 * pp] = mfma_bf16(a0, 0u, ub[cu][0].y, 0u, acc[1][2 * pp]);
-            acc[1][2 * pp + 1] = mfma_bf16(a1, 0u, ub[cu][1].y, 0u, acc[1][2 * pp + 1]);
+            const uint32_t a0 = Vp[2 * pp][0], a1 = Vp[2 * pp + 1][0];
+            // B is the register pair as loaded: k-slots 0, 1 = block 0's filters, 2, 3 = block 1's; A selects the block
+            acc[0][2 * pp] = mfma_bf16(a0, 0u, ub[cu][0].x, ub[cu][0].y, acc[0][2 * pp]);
+            acc[0][2 * pp + 1] = mfma_bf16(a1, 0u, ub[cu][1].x, ub[cu][1].y, acc[0][2 * pp + 1]);
+            acc[1][2 * pp] = mfma_bf16(0u, a0, ub[cu][0].x, ub[cu][0].y, acc[1][2 * pp]);
+            acc[1][2 * pp + 1] = mfma_bf16(0u, a1, ub[cu][1].x, ub[cu][1].y, acc[1][2 * pp + 1]);
           } else if constexpr (BF) {    // the lane's 4 channels in one bf16 MFMA
-            acc[0][2 * pp] = mfma_bf16(pk_bf16(V[2 * pp][0], V[2 * pp][1]), pk_bf16(V[2 * pp][2], V[2 * pp][3]), ub[cu][0].x,
-                                       ub[cu][0].y, acc[0][2 * pp]);
-            acc[0][2 * pp + 1] = mfma_bf16(pk_bf16(V[2 * pp + 1][0], V[2 * pp + 1][1]), pk_bf16(V[2 * pp + 1][2], V[2 * pp + 1][3]),
-                                           ub[cu][1].x, ub[cu][1].y, acc[0][2 * pp + 1]);
+            acc[0][2 * pp] = mfma_bf16(Vp[2 * pp][0], Vp[2 * pp][NH - 1], ub[cu][0].x, ub[cu][0].y, acc[0][2 * pp]);
+            acc[0][2 * pp + 1] = mfma_bf16(Vp[2 * pp + 1][0], Vp[2 * pp + 1][NH - 1], ub[cu][1].x, ub[cu][1].y, acc[0][2 * pp + 1]);
           } else if constexpr (WIDE) {   // u float4 = {cb0 s0, cb0 s1, cb1 s0, cb1 s1}
 #pragma unroll
             for (int st = 0; st < 2; ++st)

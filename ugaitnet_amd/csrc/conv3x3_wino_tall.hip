@@ -154,6 +154,11 @@ __global__ __launch_bounds__(512, 2) void wino_tall_kernel(const WinoJob j0, con
   }
   int ibuf = 0, ubuf = 0;
   float V[16][2];      // transformed patch (2 channels) of the group about to be multiplied
+  uint32_t Vp[16];     // BF: the same as a bf16 pair, rounded as it is produced
+  auto setV = [&](int pt, float x, float y) {
+    if constexpr (BF) Vp[pt] = pk_bf16(x, y);
+    else { V[pt][0] = x; V[pt][1] = y; }
+  };
   bool first = true;
 
   for (; item < nitems; item += gridDim.x) {
@@ -205,10 +210,10 @@ __global__ __launch_bounds__(512, 2) void wino_tall_kernel(const WinoJob j0, con
           }
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            V[r * 4 + 0][0] = t[r * 4 + 0].x - t[r * 4 + 2].x; V[r * 4 + 0][1] = t[r * 4 + 0].y - t[r * 4 + 2].y;
-            V[r * 4 + 1][0] = t[r * 4 + 1].x + t[r * 4 + 2].x; V[r * 4 + 1][1] = t[r * 4 + 1].y + t[r * 4 + 2].y;
-            V[r * 4 + 2][0] = t[r * 4 + 2].x - t[r * 4 + 1].x; V[r * 4 + 2][1] = t[r * 4 + 2].y - t[r * 4 + 1].y;
-            V[r * 4 + 3][0] = t[r * 4 + 1].x - t[r * 4 + 3].x; V[r * 4 + 3][1] = t[r * 4 + 1].y - t[r * 4 + 3].y;
+            setV(r * 4 + 0, t[r * 4 + 0].x - t[r * 4 + 2].x, t[r * 4 + 0].y - t[r * 4 + 2].y);
+            setV(r * 4 + 1, t[r * 4 + 1].x + t[r * 4 + 2].x, t[r * 4 + 1].y + t[r * 4 + 2].y);
+            setV(r * 4 + 2, t[r * 4 + 2].x - t[r * 4 + 1].x, t[r * 4 + 2].y - t[r * 4 + 1].y);
+            setV(r * 4 + 3, t[r * 4 + 1].x - t[r * 4 + 3].x, t[r * 4 + 1].y - t[r * 4 + 3].y);
           }
         }
         // the NEXT group's patch: second half of this stage (G == 0) or the next stage's tile, which landed a group ago
@@ -223,10 +228,10 @@ __global__ __launch_bounds__(512, 2) void wino_tall_kernel(const WinoJob j0, con
           dn[12 + c] = make_float2(d1.x - d3.x, d1.y - d3.y);
         };
         auto colpass = [&](int r) {
-          V[r * 4 + 0][0] = dn[r * 4 + 0].x - dn[r * 4 + 2].x; V[r * 4 + 0][1] = dn[r * 4 + 0].y - dn[r * 4 + 2].y;
-          V[r * 4 + 1][0] = dn[r * 4 + 1].x + dn[r * 4 + 2].x; V[r * 4 + 1][1] = dn[r * 4 + 1].y + dn[r * 4 + 2].y;
-          V[r * 4 + 2][0] = dn[r * 4 + 2].x - dn[r * 4 + 1].x; V[r * 4 + 2][1] = dn[r * 4 + 2].y - dn[r * 4 + 1].y;
-          V[r * 4 + 3][0] = dn[r * 4 + 1].x - dn[r * 4 + 3].x; V[r * 4 + 3][1] = dn[r * 4 + 1].y - dn[r * 4 + 3].y;
+          setV(r * 4 + 0, dn[r * 4 + 0].x - dn[r * 4 + 2].x, dn[r * 4 + 0].y - dn[r * 4 + 2].y);
+          setV(r * 4 + 1, dn[r * 4 + 1].x + dn[r * 4 + 2].x, dn[r * 4 + 1].y + dn[r * 4 + 2].y);
+          setV(r * 4 + 2, dn[r * 4 + 2].x - dn[r * 4 + 1].x, dn[r * 4 + 2].y - dn[r * 4 + 1].y);
+          setV(r * 4 + 3, dn[r * 4 + 1].x - dn[r * 4 + 3].x, dn[r * 4 + 1].y - dn[r * 4 + 3].y);
         };
         // points in PAIRS, their k-steps and channel blocks interleaved: no MFMA waits on its predecessor
         float4 u[2][2];   // {cb0 s0, cb0 s1, cb1 s0, cb1 s1}
@@ -251,11 +256,12 @@ __global__ __launch_bounds__(512, 2) void wino_tall_kernel(const WinoJob j0, con
             }
           }
           if constexpr (BF) {   // one bf16 MFMA per channel block: the lane's 2 channels in k-slots 0, 1 (2, 3 empty)
-            const uint32_t a0 = pk_bf16(V[2 * pp][0], V[2 * pp][1]), a1 = pk_bf16(V[2 * pp + 1][0], V[2 * pp + 1][1]);
-            acc[0][2 * pp] = mfma_bf16(a0, 0u, ub[cu][0].x, 0u, acc[0][2 * pp]);
-            acc[0][2 * pp + 1] = mfma_bf16(a1, 0u, ub[cu][1].x, 0u, acc[0][2 * pp + 1]);
-            acc[1][2 * pp] = mfma_bf16(a0, 0u, ub[cu][0].y, 0u, acc[1][2 * pp]);
-            acc[1][2 * pp + 1] = mfma_bf16(a1, 0u, ub[cu][1].y, 0u, acc[1][2 * pp + 1]);
+            const uint32_t a0 = Vp[2 * pp], a1 = Vp[2 * pp + 1];
+            // B is the register pair as loaded: k-slots 0, 1 = block 0's filters, 2, 3 = block 1's; A selects the block
+            acc[0][2 * pp] = mfma_bf16(a0, 0u, ub[cu][0].x, ub[cu][0].y, acc[0][2 * pp]);
+            acc[0][2 * pp + 1] = mfma_bf16(a1, 0u, ub[cu][1].x, ub[cu][1].y, acc[0][2 * pp + 1]);
+            acc[1][2 * pp] = mfma_bf16(0u, a0, ub[cu][0].x, ub[cu][0].y, acc[1][2 * pp]);
+            acc[1][2 * pp + 1] = mfma_bf16(0u, a1, ub[cu][1].x, ub[cu][1].y, acc[1][2 * pp + 1]);
           } else {
 #pragma unroll
             for (int s = 0; s < 2; ++s)
