@@ -39,6 +39,7 @@ F_FWD = {1: 7.944e9, 2: 8.108e9}
 F_FIRST = {1: 0.164e9, 2: 0.328e9}
 FLOP_PER_CLIP = sum(3 * F_FWD[c] - F_FIRST[c] for c in (2, 1, 1))   # fwd + dgrad + wgrad, no dgrad for layer 1
 PEAK_F32_MFMA = 157.3e12   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_BF16_MFMA = 16 * PEAK_F32_MFMA   # same guide: the f32 MFMA rate is 1/16 of the dense bf16 rate (~2.5 PFLOP/s)
 
 
 def cpu_baseline(seconds_budget=25.0):
@@ -181,8 +182,9 @@ def main():
             tfile = os.path.join(ROOT, "profiles", "roofline_traffic.json")
             if os.path.exists(tfile):
                 traffic = json.load(open(tfile)).get("hbm_bytes_per_launch")
-            roof = dict(bound="mfma", achieved=round(achieved, 2), peak=PEAK_F32_MFMA / 1e12, unit="TFLOP/s",
-                        frac=round(achieved * 1e12 / PEAK_F32_MFMA, 4), traffic=traffic, kernel=name,
+            peak = PEAK_F32_MFMA if args.dtype == "f32" else PEAK_BF16_MFMA
+            roof = dict(bound="mfma", achieved=round(achieved, 2), peak=round(peak / 1e12, 1), unit="TFLOP/s",
+                        frac=round(achieved * 1e12 / peak, 4), traffic=traffic if args.dtype == "f32" else None, kernel=name,
                         launches=len(evs), avg_us=round(avg_s * 1e6, 1),
                         note="achieved = direct-convolution (algorithmic) FLOPs / time; the kernel is Winograd F(2x2,3x3) and "
                              "executes 1/2.25 of them on the fp32 MFMA, so frac can exceed 1")
@@ -192,7 +194,7 @@ def main():
                 if oev:
                     oavg = float(np.mean([a.elapsed_time(b) for a, b in oev])) * 1e-3
                     otf = oflops * (frames + B_PER_GPU) / oavg / 1e12   # launched together with its set-level twin (B more images)
-                    others.append(dict(kernel=oname, achieved=round(otf, 2), frac=round(otf * 1e12 / PEAK_F32_MFMA, 4),
+                    others.append(dict(kernel=oname, achieved=round(otf, 2), frac=round(otf * 1e12 / peak, 4),
                                        avg_us=round(oavg * 1e6, 1), launches=len(oev)))
             roof["other_kernels"] = others
         out = dict(metric="clips/sec (3-mod, L=25, 60x60) fwd+bwd+Adam", value=round(value, 2), unit="clips/s",
@@ -203,7 +205,7 @@ def main():
                    config=dict(workload=wl["text"] % (B_PER_GPU, n_ids, wl["ids_per"]),
                                clips_per_gpu=B_PER_GPU, parallelism="dp%d" % world, dp_mode=args.dp_mode, masked_pairs_skipped=bool(args.skip_masked)),
                    whole_step_tflops=round(value * FLOP_PER_CLIP / 1e12, 2),
-                   whole_step_frac_of_f32_mfma_peak=round(value * FLOP_PER_CLIP / world / PEAK_F32_MFMA, 4),
+                   whole_step_frac_of_f32_mfma_peak=round(value * FLOP_PER_CLIP / world / PEAK_F32_MFMA, 4),   # (always the f32 peak)
                    loss=round(losses["loss"], 5), roofline=roof)
         if skip_rate is not None:
             out["value_skip_masked"] = round(skip_rate, 2)   # 29 of the 72 (clip, modality) pairs of this batch are masked
