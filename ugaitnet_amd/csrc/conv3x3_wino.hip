@@ -90,7 +90,7 @@ __device__ __forceinline__ void wino_pack_one(const float* __restrict__ w, float
     }
     return;
   }
-  if (wino_wide(kc, nc)) {
+  if (wino_wide_ex(kc, nc, bf, (mode & 3) == 3)) {
     // wide: a workgroup owns 64 output channels, a wave 2 blocks of 16 (cb); 8-channel groups (k = 32*chunk + 8*G + 2*kq + s):
     // [nsp64][chunk][G 0..3][pt][kq][32 = 16*cp + lj][cb][s]
     const int nsp = n >> 6, nl = ((n >> 5) & 1) * 16 + (n & 15), cb = (n >> 4) & 1, G = (k >> 3) & 3;
@@ -232,7 +232,7 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const WinoJob j0, const Wi
                                                       int nitems0, int nitems) {
   // WIDE (NCF >= 64): the workgroup owns 64 output channels, a wave 16 tiles x 2 channel blocks, and a group is 8 input
   // channels (2 k-steps): per MFMA half the transform work, patch reads and halo traffic of the narrow variant.
-  constexpr bool WIDE = wino_wide(KC, NCF);
+  constexpr bool WIDE = wino_wide_ex(KC, NCF, BF, IN_UNPOOL != 0);
   constexpr int NB = WIDE ? 2 : 1;          // 16-channel output blocks per wave
   constexpr int NG = WIDE ? 4 : 2;          // channel groups per 32-channel chunk
   constexpr int GW = 32 / NG;               // input channels per group
@@ -616,7 +616,7 @@ int launch_wino(const WinoJob* jobs, const int* n, int njobs, hipStream_t st) {
   }
   const float* zeros = zero_block();
   if (!zeros) { ugn_set_error("wino: cannot allocate the zero block"); return UGN_EINVAL; }
-  constexpr int per_img = (HW / 16) * (HW / 16) * (NCF / (wino_wide(KC, NCF) ? 64 : 32));
+  constexpr int per_img = (HW / 16) * (HW / 16) * (NCF / (wino_wide_ex(KC, NCF, BF, IN_UNPOOL != 0) ? 64 : 32));
   const int nitems0 = n[0] * per_img, nitems = nitems0 + (njobs > 1 ? n[1] * per_img : 0);
   const int grid = nitems < kGrid ? nitems : kGrid;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), LDS_BYTES, st, jobs[0], jobs[njobs > 1 ? 1 : 0], zeros, nitems0, nitems);

@@ -34,6 +34,11 @@ __host__ __device__ constexpr bool wino_tall(int kc, int nc) { return nc == 32; 
 // (128 -> 64 channels at 16x16 stays narrow: wide would leave 600 frame-level items for 256 persistent workgroups, 2.34
 //  rounds of which the last is a third full; narrow makes 1200 items = 4.7 rounds, and 48 instead of 24 for the set-level twin)
 __host__ __device__ constexpr bool wino_wide(int kc, int nc) { return nc >= 64 && kc >= 64 && !(kc == 128 && nc == 64); }
+// bf16 operands: the data gradient of a POOLED 64 -> 64 layer (a4 / b2) runs narrow -- the wide pooled variant sits at 254
+// registers in fp32 and spills with the zero-padded operand pairs of the bf16 form
+__host__ __device__ constexpr bool wino_wide_ex(int kc, int nc, bool bf, bool pooled_dgrad) {
+  return wino_wide(kc, nc) && !(bf && pooled_dgrad && kc == 64 && nc == 64);
+}
 
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
   // lane l: A[i = l&15][k = l>>4], B[k = l>>4][j = l&15]; D reg r of lane l = D[i = 4*(l>>4) + r][j = l&15]
