@@ -33,6 +33,10 @@ WORKLOADS = {
     "c4": dict(kinds=("of", "gray", "sil"), clips=40, ncls=74, ids_per=10,
                text="C4: 3 modalities (of 2ch + gray + silhouette), 25x60x60, %d clips/GPU, %d ids x %d, 74 classes, sign_max, "
                     "7-pattern masks, triplet(0.2)+0.1*xent, Adam 1e-4"),
+    # C5 = C4 at 128 clips per 8-GPU node with bf16 MFMA operands: 16 clips per GPU; always run with --dtype bf16
+    "c5": dict(kinds=("of", "gray", "sil"), clips=16, ncls=74, ids_per=8,
+               text="C5: 3 modalities (of 2ch + gray + silhouette), 25x60x60, %d clips/GPU, %d ids x %d, 74 classes, sign_max, "
+                    "7-pattern masks, triplet(0.2)+0.1*xent, Adam 1e-4, bf16 MFMA operands"),
 }
 # algorithmic FLOPs: forward per clip per modality, exact from the layer shapes
 F_FWD = {1: 7.944e9, 2: 8.108e9}
@@ -91,6 +95,8 @@ def main():
                     help="override the workload's batch (e.g. 96 = the generator-expanded C3 batch); 0 = the workload's own")
     args = ap.parse_args()
     wl = WORKLOADS[args.workload]
+    if args.workload == "c5":
+        args.dtype = "bf16"
     global KINDS, B_PER_GPU, NCLS
     KINDS, NCLS = wl["kinds"], wl["ncls"]
     B_PER_GPU = args.clips_per_gpu or wl["clips"]
