@@ -32,6 +32,21 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
+// bf16 operands (template flag BF, shapes with 16 tiles per wave and region): the 4 k-steps of a region become the 4 k-slots
+// of ONE v_mfma_f32_16x16x16_bf16 per (point, channel block) -- slot j = the lane's tile of step j on both operands.
+typedef __bf16 wg_bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 wg_bf16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint32_t wg_pk(float a, float b) {
+  wg_bf16x2 r;
+  r[0] = (__bf16)a;
+  r[1] = (__bf16)b;
+  return __builtin_bit_cast(uint32_t, r);
+}
+__device__ __forceinline__ f32x4 wg_mfma_bf16(uint32_t a01, uint32_t a23, uint32_t b01, uint32_t b23, f32x4 c) {
+  const uint2 a = make_uint2(a01, a23), b = make_uint2(b01, b23);
+  return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(wg_bf16x4, a), __builtin_bit_cast(wg_bf16x4, b), c, 0, 0, 0);
+}
+
 __device__ __forceinline__ void dma16(const void* gsrc, unsigned lds_dst_uniform) {
   unsigned keep;
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
@@ -62,7 +77,7 @@ struct WgJob {
   int nregions, groups;
 };
 
-template <int CI, int CO, int HW, int COC, int DZ_UNPOOL>
+template <int CI, int CO, int HW, int COC, int DZ_UNPOOL, bool BF = false>
 __global__ __launch_bounds__(512, 2) void wgrad_wino_kernel(const WgJob j0, const WgJob j1, const float* __restrict__ zeros) {
   using D = DzCfg<COC, DZ_UNPOOL>;
   constexpr int COP = COC / 32;                       // 32-channel output pairs per workgroup (1 or 2)
@@ -196,6 +211,116 @@ __global__ __launch_bounds__(512, 2) void wgrad_wino_kernel(const WgJob j0, cons
         }
       }
     };
+    // (bf16 form: the same reads, split by operand)
+    auto load_d = [&](int st) {
+      const int tr0 = (ks * TPW) >> 3, tc0 = ((ks * TPW) & 7) + kq;
+      const int dtr = (st * 4) >> 3, dtc = (st * 4) & 7;
+      const int cq = cib * 16 + lj, sw = (kq & 1) * 4;
+      const float* pl0 = sIn + ((2 * tr0) * PW + 2 * tc0) * CS + (((cq >> 2) ^ sw) << 2) + (cq & 3);
+      const float* pl1 = sIn + ((2 * tr0) * PW + 2 * tc0) * CS + (((cq >> 2) ^ sw ^ 4) << 2) + (cq & 3);
+      const int pst = ((2 * dtr) * PW + 2 * dtc) * CS;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int off = (e >> 2) * PW + (e & 3);
+        d[e] = (swz(off) ? pl1 : pl0)[pst + off * CS];
+      }
+    };
+    auto load_y = [&](int st, int cb) {
+      const int tr0 = (ks * TPW) >> 3, tc0 = ((ks * TPW) & 7) + kq;
+      const int tr = tr0 + ((st * 4) >> 3), tc = tc0 + ((st * 4) & 7);
+      const int sw = (kq & 1) * 4;
+      const int co = cop * 32 + cb * 16 + lj;
+      if constexpr (DZ_UNPOOL) {
+        const float* pp = sDz + (tr * 8 + tc) * D::STRIDE;
+        yv[cb][0] = pp[co];
+        ypos[cb] = reinterpret_cast<const uint8_t*>(pp + COC)[co];
+      } else {
+        const int q0 = (2 * tr) * RW + 2 * tc;
+        const float* pp = sDz + q0 * D::STRIDE + (((co >> 2) ^ sw) << 2) + (co & 3);
+        yv[cb][0] = pp[0]; yv[cb][1] = pp[D::STRIDE]; yv[cb][2] = pp[RW * D::STRIDE]; yv[cb][3] = pp[(RW + 1) * D::STRIDE];
+      }
+    };
+    if constexpr (BF) {
+      static_assert(!BF || STEPS == 4, "the bf16 form packs the 4 k-steps of a region into one MFMA");
+      // ---- A operand of all 4 steps: V = B^T d B of (tile of step j, input channel cib*16 + lj), packed as it is produced
+      uint32_t Vlo[16], Vhi[16];
+      {
+        float Ve[16];
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {
+          load_d(st);
+          float tt[16], V[16];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            tt[0 + c] = d[0 + c] - d[8 + c];
+            tt[4 + c] = d[4 + c] + d[8 + c];
+            tt[8 + c] = d[8 + c] - d[4 + c];
+            tt[12 + c] = d[4 + c] - d[12 + c];
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            V[r * 4 + 0] = tt[r * 4 + 0] - tt[r * 4 + 2];
+            V[r * 4 + 1] = tt[r * 4 + 1] + tt[r * 4 + 2];
+            V[r * 4 + 2] = tt[r * 4 + 2] - tt[r * 4 + 1];
+            V[r * 4 + 3] = tt[r * 4 + 1] - tt[r * 4 + 3];
+          }
+#pragma unroll
+          for (int pt = 0; pt < 16; ++pt) {
+            if (st == 1) Vlo[pt] = wg_pk(Ve[pt], V[pt]);
+            else if (st == 3) Vhi[pt] = wg_pk(Ve[pt], V[pt]);
+            else Ve[pt] = V[pt];
+          }
+        }
+      }
+      // ---- per channel block: B operand of all 4 steps (Q = A dY A^T), then the block's 16 MFMAs
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb) {
+        uint32_t Qlo[16], Qhi[16];
+        float Qe[16];
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {
+          load_y(st, cb);
+          float Q[16];
+          if constexpr (DZ_UNPOOL) {
+            const float v = yv[cb][0];
+            const bool ay = (ypos[cb] >> 1) != 0, ax = (ypos[cb] & 1) != 0;
+            float ty[4];
+            ty[0] = ay ? 0.f : v; ty[1] = v; ty[2] = ay ? -v : v; ty[3] = ay ? -v : 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              Q[r * 4 + 0] = ax ? 0.f : ty[r];
+              Q[r * 4 + 1] = ty[r];
+              Q[r * 4 + 2] = ax ? -ty[r] : ty[r];
+              Q[r * 4 + 3] = ax ? -ty[r] : 0.f;
+            }
+          } else {
+            const float y00 = yv[cb][0], y01 = yv[cb][1], y10 = yv[cb][2], y11 = yv[cb][3];
+            float q[4][2];   // (row 3 / column 3 keep the sign convention of the fp32 form: see below)
+            q[0][0] = y00; q[0][1] = y01;
+            q[1][0] = y00 + y10; q[1][1] = y01 + y11;
+            q[2][0] = y00 - y10; q[2][1] = y01 - y11;
+            q[3][0] = y10; q[3][1] = y11;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              Q[r * 4 + 0] = q[r][0];
+              Q[r * 4 + 1] = q[r][0] + q[r][1];
+              Q[r * 4 + 2] = q[r][0] - q[r][1];
+              Q[r * 4 + 3] = q[r][1];
+            }
+          }
+#pragma unroll
+          for (int pt = 0; pt < 16; ++pt) {
+            if (st == 1) Qlo[pt] = wg_pk(Qe[pt], Q[pt]);
+            else if (st == 3) Qhi[pt] = wg_pk(Qe[pt], Q[pt]);
+            else Qe[pt] = Q[pt];
+          }
+        }
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int pt = 0; pt < 16; ++pt) acc[pt][cb] = wg_mfma_bf16(Vlo[pt], Vhi[pt], Qlo[pt], Qhi[pt], acc[pt][cb]);
+        __builtin_amdgcn_s_setprio(0);
+      }
+    } else {
     load_raw(0);
 #pragma unroll
     for (int st = 0; st < STEPS; ++st) {
@@ -262,6 +387,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_wino_kernel(const WgJob j0, cons
       }
       __builtin_amdgcn_s_setprio(0);
     }
+    }   // !BF
   }
 
   // ---- combine the KSPLIT waves that share an output block (through LDS, fixed order), then write the slab
@@ -385,11 +511,11 @@ struct WgHostJob {
   int n;
 };
 
-template <int CI, int CO, int HW, int COC, int DZ_UNPOOL>
+template <int CI, int CO, int HW, int COC, int DZ_UNPOOL, bool BF = false>
 int launch_wgrad_wino(const WgHostJob* hj, int njobs, float* ws, size_t ws_floats, hipStream_t st) {
   using D = DzCfg<COC, DZ_UNPOOL>;
   constexpr int LDS = (2 * SIN + 2 * D::SDZ) * 4 > 8 * 16384 ? (2 * SIN + 2 * D::SDZ) * 4 : 8 * 16384;
-  auto kern = wgrad_wino_kernel<CI, CO, HW, COC, DZ_UNPOOL>;
+  auto kern = wgrad_wino_kernel<CI, CO, HW, COC, DZ_UNPOOL, BF>;
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -434,8 +560,15 @@ bool wg_cfg(int hw, int cin, int cout, int* coc) {
   return false;
 }
 
-int dispatch_wgrad(const WgHostJob* hj, int njobs, int hw, int cin, int cout, void* ws, size_t ws_bytes, hipStream_t st) {
+int dispatch_wgrad(const WgHostJob* hj, int njobs, int hw, int cin, int cout, void* ws, size_t ws_bytes, bool bf, hipStream_t st) {
   const int unpool = hj[0].dz_idx != nullptr;
+  if (bf) {   // bf16 operands: the shapes with 16 tiles per wave and region (64 output channels per workgroup); a2 stays fp32
+#define WGB(CI_, CO_, HW_, COC_, U_)                          \
+  if (cin == CI_ && cout == CO_ && hw == HW_ && unpool == U_) \
+    return launch_wgrad_wino<CI_, CO_, HW_, COC_, U_, true>(hj, njobs, (float*)ws, ws_bytes / sizeof(float), st);
+    WGB(32, 64, 32, 64, 0) WGB(64, 64, 32, 64, 1) WGB(64, 128, 16, 64, 0) WGB(128, 128, 16, 64, 0)
+#undef WGB
+  }
 #define WGW(CI_, CO_, HW_, COC_, U_)                          \
   if (cin == CI_ && cout == CO_ && hw == HW_ && unpool == U_) \
     return launch_wgrad_wino<CI_, CO_, HW_, COC_, U_>(hj, njobs, (float*)ws, ws_bytes / sizeof(float), st);
@@ -458,16 +591,23 @@ extern "C" size_t ugn_conv3x3_wgrad_wino_ws(int n, int hw, int cin, int cout) {
   return (size_t)kWgs * 9 * 32 * coc * sizeof(float);
 }
 
-extern "C" int ugn_conv3x3_wgrad_wino(const float* in, const float* dz, const uint8_t* dz_idx, float* dw, int n, int hw,
-                                      int cin, int cout, void* ws, size_t ws_bytes, void* stream) {
+static int wgrad_one(const float* in, const float* dz, const uint8_t* dz_idx, float* dw, int n, int hw, int cin, int cout,
+                     void* ws, size_t ws_bytes, bool bf, void* stream) {
   UGN_REQUIRE(in && dz && dw && ws && n > 0, "ugn_conv3x3_wgrad_wino: null pointer or n <= 0");
   const WgHostJob job = {in, dz, dz_idx, dw, n};
-  return dispatch_wgrad(&job, 1, hw, cin, cout, ws, ws_bytes, (hipStream_t)stream);
+  return dispatch_wgrad(&job, 1, hw, cin, cout, ws, ws_bytes, bf, (hipStream_t)stream);
+}
+extern "C" int ugn_conv3x3_wgrad_wino(const float* in, const float* dz, const uint8_t* dz_idx, float* dw, int n, int hw,
+                                      int cin, int cout, void* ws, size_t ws_bytes, void* stream) {
+  return wgrad_one(in, dz, dz_idx, dw, n, hw, cin, cout, ws, ws_bytes, false, stream);
+}
+extern "C" int ugn_conv3x3_wgrad_wino_bf16(const float* in, const float* dz, const uint8_t* dz_idx, float* dw, int n, int hw,
+                                           int cin, int cout, void* ws, size_t ws_bytes, void* stream) {
+  return wgrad_one(in, dz, dz_idx, dw, n, hw, cin, cout, ws, ws_bytes, true, stream);
 }
 
-extern "C" int ugn_conv3x3_wgrad_wino_pair(const float* const* in, const float* const* dz, const uint8_t* const* dz_idx,
-                                           float* const* dw, const int* n, int hw, int cin, int cout, void* ws,
-                                           size_t ws_bytes, void* stream) {
+static int wgrad_pair(const float* const* in, const float* const* dz, const uint8_t* const* dz_idx, float* const* dw,
+                      const int* n, int hw, int cin, int cout, void* ws, size_t ws_bytes, bool bf, void* stream) {
   UGN_REQUIRE(in && dz && dw && n && ws, "ugn_conv3x3_wgrad_wino_pair: null array");
   WgHostJob jobs[2];
   for (int j = 0; j < 2; ++j) {
@@ -475,5 +615,15 @@ extern "C" int ugn_conv3x3_wgrad_wino_pair(const float* const* in, const float* 
     jobs[j] = {in[j], dz[j], dz_idx ? dz_idx[j] : nullptr, dw[j], n[j]};
   }
   UGN_REQUIRE((jobs[0].dz_idx != nullptr) == (jobs[1].dz_idx != nullptr), "ugn_conv3x3_wgrad_wino_pair: dz_idx for both jobs or none");
-  return dispatch_wgrad(jobs, 2, hw, cin, cout, ws, ws_bytes, (hipStream_t)stream);
+  return dispatch_wgrad(jobs, 2, hw, cin, cout, ws, ws_bytes, bf, (hipStream_t)stream);
+}
+extern "C" int ugn_conv3x3_wgrad_wino_pair(const float* const* in, const float* const* dz, const uint8_t* const* dz_idx,
+                                           float* const* dw, const int* n, int hw, int cin, int cout, void* ws,
+                                           size_t ws_bytes, void* stream) {
+  return wgrad_pair(in, dz, dz_idx, dw, n, hw, cin, cout, ws, ws_bytes, false, stream);
+}
+extern "C" int ugn_conv3x3_wgrad_wino_pair_bf16(const float* const* in, const float* const* dz, const uint8_t* const* dz_idx,
+                                                float* const* dw, const int* n, int hw, int cin, int cout, void* ws,
+                                                size_t ws_bytes, void* stream) {
+  return wgrad_pair(in, dz, dz_idx, dw, n, hw, cin, cout, ws, ws_bytes, true, stream);
 }

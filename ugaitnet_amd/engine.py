@@ -153,8 +153,8 @@ class Encoder:
 
     def __init__(self, store, prefix, cin, bf16=False):
         self.store, self.prefix, self.cin = store, prefix, cin
-        # bf16: the 3x3 forward convolutions and data gradients multiply bf16-rounded Winograd-domain operands (fp32
-        # accumulate, fp32 tensors); weight gradients, the 5x5 layer and everything else stay fp32
+        # bf16: the 3x3 convolutions, data gradients and weight gradients (but a2's) multiply bf16-rounded Winograd-domain
+        # operands (fp32 accumulate, fp32 tensors); the 5x5 layer and everything else stay fp32
         self.bf16 = bool(bf16)
         if self.bf16 and not (USE_WINOGRAD and PAIR_LAUNCHES and not ROUTED):
             raise ValueError("conv_precision='bf16' needs the default Winograd pair-launch path")
@@ -222,7 +222,8 @@ class Encoder:
 
     def wgrad_pair(self, names, xs, dzs, cout, dz_idxs=None):
         if USE_WINOGRAD and PAIR_LAUNCHES:
-            return ops.conv3x3_wgrad_wino_pair(list(xs), list(dzs), cout, [self.G(n) for n in names], dz_idxs=dz_idxs)
+            return ops.conv3x3_wgrad_wino_pair(list(xs), list(dzs), cout, [self.G(n) for n in names], dz_idxs=dz_idxs,
+                                               bf16=self.bf16)
         return [_wgrad3x3(x, dz, cout, dz_idx=None if dz_idxs is None else dz_idxs[k], dw=self.G(n))
                 for k, (n, x, dz) in enumerate(zip(names, xs, dzs))]
 

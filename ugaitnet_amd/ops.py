@@ -223,7 +223,7 @@ def conv3x3_dgrad_wino_pair(dzs, upks, hw, cin, cout, outs, dz_idxs=None, acts=N
     return outs
 
 
-def conv3x3_wgrad_wino_pair(xs, dzs, cout, dws, dz_idxs=None):
+def conv3x3_wgrad_wino_pair(xs, dzs, cout, dws, dz_idxs=None, bf16=False):
     """Two weight gradients of one shape in a single launch."""
     for t in xs + dzs + dws:
         _chk(t)
@@ -233,12 +233,12 @@ def conv3x3_wgrad_wino_pair(xs, dzs, cout, dws, dz_idxs=None):
     if nbytes == 0:
         raise ValueError("conv3x3_wgrad_wino_pair: unsupported shape hw=%d cin=%d cout=%d" % (hw, cin, cout))
     ws = _WS.get(nbytes, xs[0].device)
-    call("ugn_conv3x3_wgrad_wino_pair", ptr_array(xs), ptr_array(dzs), _opt_ptr_array(dz_idxs), ptr_array(dws), ns, hw, cin, cout,
+    call("ugn_conv3x3_wgrad_wino_pair" + ("_bf16" if bf16 else ""), ptr_array(xs), ptr_array(dzs), _opt_ptr_array(dz_idxs), ptr_array(dws), ns, hw, cin, cout,
          ptr(ws), ws.numel(), _stream())
     return dws
 
 
-def conv3x3_wgrad_wino(x, dz, cout, dz_idx=None, dw=None):
+def conv3x3_wgrad_wino(x, dz, cout, dz_idx=None, dw=None, bf16=False):
     """Winograd F(2x2,3x3) weight gradient; same contract as conv3x3_wgrad."""
     _chk(x), _chk(dz)
     n, hw, cin = x.shape[0], x.shape[1], x.shape[3]
@@ -247,7 +247,7 @@ def conv3x3_wgrad_wino(x, dz, cout, dz_idx=None, dw=None):
     if nbytes == 0:
         raise ValueError("conv3x3_wgrad_wino: unsupported shape hw=%d cin=%d cout=%d" % (hw, cin, cout))
     ws = _WS.get(nbytes, x.device)
-    call("ugn_conv3x3_wgrad_wino", ptr(x), ptr(dz), ptr(dz_idx), ptr(dw), n, hw, cin, cout, ptr(ws), ws.numel(), _stream())
+    call("ugn_conv3x3_wgrad_wino" + ("_bf16" if bf16 else ""), ptr(x), ptr(dz), ptr(dz_idx), ptr(dw), n, hw, cin, cout, ptr(ws), ws.numel(), _stream())
     return dw
 
 
