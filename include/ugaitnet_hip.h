@@ -122,7 +122,7 @@ int ugn_conv3x3_wgrad_wino_pair(const float* const* in, const float* const* dz, 
 
 /* bf16-operand weight gradient (see ugn_conv3x3_fwd_wino_bf16): the transformed inputs and output gradients of 16 tiles are
  * rounded to bf16 and contracted by one v_mfma_f32_16x16x16_bf16 per Winograd point; fp32 accumulate, fp32 tensors, same
- * workspace.  Built for the shapes with >= 64 output channels; the 32 -> 32 layer at 64x64 runs the fp32 kernel. */
+ * workspace (the 32 -> 32 layer at 64x64 has 8 tiles per wave and region: half of the MFMA's k-slots stay empty). */
 int ugn_conv3x3_wgrad_wino_bf16(const float* in, const float* dz, const uint8_t* dz_idx, float* dw, int n, int hw, int cin,
                                 int cout, void* ws, size_t ws_bytes, void* stream);
 int ugn_conv3x3_wgrad_wino_pair_bf16(const float* const* in, const float* const* dz, const uint8_t* const* dz_idx,

@@ -241,13 +241,15 @@ __global__ __launch_bounds__(512, 2) void wgrad_wino_kernel(const WgJob j0, cons
       }
     };
     if constexpr (BF) {
-      static_assert(!BF || STEPS == 4, "the bf16 form packs the 4 k-steps of a region into one MFMA");
+      // (STEPS == 2, the 32-channel workgroup shape: 8 tiles per wave and region fill k-slots 0, 1; slots 2, 3 stay empty)
       // ---- A operand of all 4 steps: V = B^T d B of (tile of step j, input channel cib*16 + lj), packed as it is produced
       uint32_t Vlo[16], Vhi[16];
+#pragma unroll
+      for (int pt = 0; pt < 16; ++pt) Vhi[pt] = 0u;
       {
         float Ve[16];
 #pragma unroll
-        for (int st = 0; st < 4; ++st) {
+        for (int st = 0; st < STEPS; ++st) {
           load_d(st);
           float tt[16], V[16];
 #pragma unroll
@@ -278,7 +280,9 @@ __global__ __launch_bounds__(512, 2) void wgrad_wino_kernel(const WgJob j0, cons
         uint32_t Qlo[16], Qhi[16];
         float Qe[16];
 #pragma unroll
-        for (int st = 0; st < 4; ++st) {
+        for (int pt = 0; pt < 16; ++pt) Qhi[pt] = 0u;
+#pragma unroll
+        for (int st = 0; st < STEPS; ++st) {
           load_y(st, cb);
           float Q[16];
           if constexpr (DZ_UNPOOL) {
@@ -562,11 +566,11 @@ bool wg_cfg(int hw, int cin, int cout, int* coc) {
 
 int dispatch_wgrad(const WgHostJob* hj, int njobs, int hw, int cin, int cout, void* ws, size_t ws_bytes, bool bf, hipStream_t st) {
   const int unpool = hj[0].dz_idx != nullptr;
-  if (bf) {   // bf16 operands: the shapes with 16 tiles per wave and region (64 output channels per workgroup); a2 stays fp32
+  if (bf) {
 #define WGB(CI_, CO_, HW_, COC_, U_)                          \
   if (cin == CI_ && cout == CO_ && hw == HW_ && unpool == U_) \
     return launch_wgrad_wino<CI_, CO_, HW_, COC_, U_, true>(hj, njobs, (float*)ws, ws_bytes / sizeof(float), st);
-    WGB(32, 64, 32, 64, 0) WGB(64, 64, 32, 64, 1) WGB(64, 128, 16, 64, 0) WGB(128, 128, 16, 64, 0)
+    WGB(32, 32, 64, 32, 1) WGB(32, 64, 32, 64, 0) WGB(64, 64, 32, 64, 1) WGB(64, 128, 16, 64, 0) WGB(128, 128, 16, 64, 0)
 #undef WGB
   }
 #define WGW(CI_, CO_, HW_, COC_, U_)                          \

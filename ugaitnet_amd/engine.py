@@ -153,7 +153,7 @@ class Encoder:
 
     def __init__(self, store, prefix, cin, bf16=False):
         self.store, self.prefix, self.cin = store, prefix, cin
-        # bf16: the 3x3 convolutions, data gradients and weight gradients (but a2's) multiply bf16-rounded Winograd-domain
+        # bf16: the 3x3 convolutions, data gradients and weight gradients multiply bf16-rounded Winograd-domain
         # operands (fp32 accumulate, fp32 tensors); the 5x5 layer and everything else stay fp32
         self.bf16 = bool(bf16)
         if self.bf16 and not (USE_WINOGRAD and PAIR_LAUNCHES and not ROUTED):
@@ -342,7 +342,7 @@ class Encoder:
                 dp2 = self.dgrad("a3", dz3, 32, act=A["p2"], addend=g2, out=g2)
         # block 1 (a1, a2)
         with _side(dev):
-            _wgrad3x3(A["a1"], dp2, 32, dz_idx=A["i2"], dw=self.G("a2"))
+            _wgrad3x3(A["a1"], dp2, 32, dz_idx=A["i2"], dw=self.G("a2"), **({"bf16": True} if self.bf16 else {}))
         if A1_SIGN_BITS:
             dz1 = self.dgrad("a2", dp2, 64, dz_idx=A["i2"], out=buf("dz1", (n, 64, 64, 32)))   # dL/da1
             with _side(dev):
