@@ -168,7 +168,8 @@ class GaitSetModel:
                              loss_weights=(self.loss_weights[0], self.loss_weights[1] if len(self.loss_weights) > 1 else 0.0),
                              seed=seed, lr=optimizer.lr, beta_1=optimizer.beta_1, beta_2=optimizer.beta_2,
                              epsilon=optimizer.epsilon, world_size=world,
-                             dp_mode=os.environ.get("UGN_DP_MODE", "replica"))
+                             dp_mode=os.environ.get("UGN_DP_MODE", "replica"),
+                             conv_precision=os.environ.get("UGN_CONV_PRECISION", "f32"))
         if world > 1:  # replicas start from identical weights (MirroredStrategy semantics)
             torch.distributed.broadcast(self.core.store.flat, src=0)
             self.core.weights_changed()
