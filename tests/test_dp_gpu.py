@@ -21,13 +21,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 
-def _run_replicas(mode, tmp_path, world=2):
+def _run_replicas(mode, tmp_path, world=2, overlap="1"):
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    out = str(tmp_path / ("dp_%s.npz" % mode))
+    out = str(tmp_path / ("dp_%s_%s.npz" % (mode, overlap)))
     procs = []
     for r in range(world):
         env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(r), WORLD_SIZE=str(world),
-                   LOCAL_RANK=str(r), UGN_DP_BACKEND="gloo")
+                   LOCAL_RANK=str(r), UGN_DP_BACKEND="gloo", UGN_AR_OVERLAP=overlap)
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tools", "dp_worker.py"), mode, out], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     logs = [p.communicate(timeout=600)[0] for p in procs]
@@ -65,3 +65,12 @@ def test_replica_mode_averages_the_slice_gradients(dev, tmp_path):
     g1, l1 = _single(slice(4, 8))
     assert _rel(got["grad"], 0.5 * (g0 + g1)) <= 1e-6
     assert abs(float(got["loss"]) - l0["loss"]) <= 1e-6 * max(1.0, abs(l0["loss"]))   # rank 0 reports its own slice
+
+
+@pytest.mark.timeout(900)
+def test_bucketed_allreduce_equals_the_single_one(dev, tmp_path):
+    """The gradient leaves in buckets (head, then one per branch) while the backward pass still runs; the reduced gradient and
+    the updated parameters are those of one all-reduce after the backward pass, bit for bit."""
+    a = _run_replicas("replica", tmp_path, overlap="1")
+    b = _run_replicas("replica", tmp_path, overlap="0")
+    assert np.array_equal(a["grad"], b["grad"]) and np.array_equal(a["params"], b["params"])

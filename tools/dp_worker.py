@@ -41,11 +41,8 @@ def main():
     args = ([cut(x) for x in xs], [cut(u) for u in uses], labels[lo:hi], cut(onehot))
     core.forward_backward(*args)
     losses = core.losses()
-    grad = core.store.grad.clone()
-    scale = dp.allreduce_sum_(grad)
-    if core.global_batch:
-        scale = 1.0
-    grad = (grad * scale).cpu().numpy()
+    scale = core.finish_gradient_allreduce()      # bucketed, overlapped with the backward pass (UGN_AR_OVERLAP=0: one call)
+    grad = (core.store.grad * scale).cpu().numpy()
     core.train_step(*args)
     torch.cuda.synchronize()
     if rank == 0:

@@ -3,8 +3,9 @@
 Replaces the reference's `tf.distribute.MirroredStrategy()` scope (mains/mj_trainUWYHGaitNet_DataGen_CasiaB.py:342-349,
 458-461): every replica owns a contiguous slice of the batch, evaluates the loss on ITS slice (Keras per-replica loss,
 scaled by 1/replicas) and the parameter gradients are summed across replicas.  The only exchange on the path is that
-gradient all-reduce: one collective over the flat fp32 gradient buffer (35.8-40.7 MB); the 1/world
-factor is folded into the Adam kernel.
+gradient all-reduce over the flat fp32 gradient buffer (35.8-40.7 MB), issued in four buckets (head,
+then one per branch) as the backward pass produces them (`allreduce_sum_async`, GaitCore._reduce_bucket); the 1/world factor
+is folded into the Adam kernel.
 
 Global-batch mode (`GaitCore(dp_mode="global")`, SURVEY.md section 8e collective (1)): the two places where samples are
 coupled -- the batch-axis l2_normalize (nets/mj_uwyhNets_ba.py:817,1191) and the triplet loss
@@ -93,3 +94,13 @@ def gather_batch_axis(t, axis, group=None, check=True):
 def group_rank(group=None):
     import torch.distributed as dist
     return dist.get_rank(group) if dist.is_available() and dist.is_initialized() else 0
+
+
+def allreduce_sum_async(t, group=None):
+    """SUM all-reduce of `t` (a slice of the flat gradient buffer) issued behind the CURRENT stream's work and left running
+    on the communication stream; returns the work handle (`.wait()` orders the caller's stream after it) or None for a single
+    process."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return None
+    return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group, async_op=True)

@@ -98,6 +98,11 @@ def join_backward_streams(device):
             cur.wait_stream(st)
 
 
+# UGN_AR_OVERLAP=1 (default): data parallelism reduces the gradient in buckets -- the head's as soon as the head's backward is
+# queued, each branch's as soon as that branch's backward is -- so that RCCL moves them over xGMI while the remaining branches
+# still compute; 0: one all-reduce over the whole flat buffer after the backward pass.
+AR_OVERLAP = os.environ.get("UGN_AR_OVERLAP", "1") != "0"
+
 # UGN_ROUTED=1: form the set-max gradient inside the a3 / a5 data-gradient epilogues instead of materialising it with
 # setmax_bwd (bit-identical; measured 2.5 % SLOWER on MI355X: three operand loads per element make those epilogues spill).
 ROUTED = USE_WINOGRAD and os.environ.get("UGN_ROUTED", "0") == "1"
@@ -400,6 +405,12 @@ class GaitCore:
         self.scratch = {}
         self.bufs = {}
         self._tri_cache = {}
+        # gradient buckets of the flat buffer: one per branch, one for the head
+        offs = self.store.offsets
+        starts = [offs["m%d.a1" % mi] for mi in range(self.nmod)] + ([offs["head.wc"]] if self.nclasses > 0 else [])
+        ends = starts[1:] + [self.store.numel]
+        self._buckets = list(zip(starts, ends))
+        self._ar_pending = None     # work handles of the bucket all-reduces of the current step
         self.init_weights(seed)
 
     # ---- parameters -------------------------------------------------------------------------------------
@@ -549,6 +560,7 @@ class GaitCore:
             labels, onehot = self._gather_targets(labels, onehot)
         sig = self.forward(xs, uses, gather=self.global_batch)
         b = sig.shape[1]
+        self._ar_pending = [] if (self.world > 1 and AR_OVERLAP and not BRANCH_STREAMS) else None
         hp, hn, kp, kn = self._triplet_lists(labels)
         w_tri, w_id = self.loss_weights
         self.bin_loss, self.bin_num, dsig = ops.triplet_fwd_bwd(
@@ -563,6 +575,7 @@ class GaitCore:
             if self.global_batch:   # every replica holds the head gradient of the whole batch; the all-reduce sums them
                 self.store.g["head.wc"].mul_(1.0 / self.world)
                 self.store.g["head.bc"].mul_(1.0 / self.world)
+            self._reduce_bucket(self.nmod)
         bl, lo = self.last_b, self.row0
         own = (lambda t: t[:, lo:lo + bl].contiguous()) if self.global_batch else (lambda t: t)
         if self.multimodal:
@@ -590,6 +603,7 @@ class GaitCore:
                         enc.G(name).zero_()
                 else:
                     enc.backward(d.index_select(1, idx).contiguous(), scratch)
+            self._reduce_bucket(mi)
         join_backward_streams(self.device)
 
     def forward_loss_only(self, xs, uses, labels, onehot):
@@ -606,11 +620,33 @@ class GaitCore:
             oh = self._dev(onehot, (b, self.nclasses))
             self.head = ops.head_fwd(sig, self.store.p["head.wc"], self.store.p["head.bc"], oh, 0.0, self._head_bufs(b))
 
+    def _reduce_bucket(self, k):
+        """Queue the all-reduce of gradient bucket k behind everything issued so far (both backward streams)."""
+        if self._ar_pending is None:
+            return
+        lo, hi = self._buckets[k]
+        with _side(self.device):    # the weight-gradient stream, ordered after the main stream's work up to here
+            w = dp.allreduce_sum_async(self.store.grad[lo:hi], self.pg)
+        if w is not None:
+            self._ar_pending.append(w)
+
+    def finish_gradient_allreduce(self):
+        """Complete the step's gradient reduction; returns the factor Adam applies to the summed gradient."""
+        if self.world <= 1:
+            return 1.0
+        if self._ar_pending is not None:
+            for w in self._ar_pending:
+                w.wait()
+            self._ar_pending = None
+            scale = 1.0 / self.world
+        else:
+            scale = dp.allreduce_sum_(self.store.grad, self.pg)
+        # global mode: the loss already is the whole batch's, the replicas' gradients add up to its gradient
+        return 1.0 if self.global_batch else scale
+
     def apply_gradients(self):
         """Gradient all-reduce over RCCL (data parallel) + keras Adam, one launch over the flat buffer."""
-        scale = dp.allreduce_sum_(self.store.grad, self.pg) if self.world > 1 else 1.0
-        if self.global_batch:
-            scale = 1.0   # the loss already is the whole batch's: the replicas' gradients add up to its gradient
+        scale = self.finish_gradient_allreduce()
         self.iterations += 1
         t = self.iterations
         lr_t = self.lr * math.sqrt(1.0 - self.beta_2 ** t) / (1.0 - self.beta_1 ** t)
