@@ -21,7 +21,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 
-def _run_replicas(mode, tmp_path, world=2, overlap="1"):
+def _run_replicas(mode, tmp_path, world=2, overlap="0"):
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     out = str(tmp_path / ("dp_%s_%s.npz" % (mode, overlap)))
     procs = []

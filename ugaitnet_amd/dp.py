@@ -3,9 +3,9 @@
 Replaces the reference's `tf.distribute.MirroredStrategy()` scope (mains/mj_trainUWYHGaitNet_DataGen_CasiaB.py:342-349,
 458-461): every replica owns a contiguous slice of the batch, evaluates the loss on ITS slice (Keras per-replica loss,
 scaled by 1/replicas) and the parameter gradients are summed across replicas.  The only exchange on the path is that
-gradient all-reduce over the flat fp32 gradient buffer (35.8-40.7 MB), issued in four buckets (head,
-then one per branch) as the backward pass produces them (`allreduce_sum_async`, GaitCore._reduce_bucket); the 1/world factor
-is folded into the Adam kernel.
+gradient all-reduce over the flat fp32 gradient buffer (35.8-40.7 MB): one collective after the
+backward pass, or with UGN_AR_OVERLAP=1 four buckets (head, then one per branch) issued as the backward pass produces them
+(`allreduce_sum_async`, GaitCore._reduce_bucket); the 1/world factor is folded into the Adam kernel.
 
 Global-batch mode (`GaitCore(dp_mode="global")`, SURVEY.md section 8e collective (1)): the two places where samples are
 coupled -- the batch-axis l2_normalize (nets/mj_uwyhNets_ba.py:817,1191) and the triplet loss

@@ -98,10 +98,13 @@ def join_backward_streams(device):
             cur.wait_stream(st)
 
 
-# UGN_AR_OVERLAP=1 (default): data parallelism reduces the gradient in buckets -- the head's as soon as the head's backward is
-# queued, each branch's as soon as that branch's backward is -- so that RCCL moves them over xGMI while the remaining branches
-# still compute; 0: one all-reduce over the whole flat buffer after the backward pass.
-AR_OVERLAP = os.environ.get("UGN_AR_OVERLAP", "1") != "0"
+# UGN_AR_OVERLAP=1: data parallelism reduces the gradient in buckets -- the head's as soon as the head's backward is queued,
+# each branch's as soon as that branch's backward is -- so that RCCL moves them over xGMI while the remaining branches still
+# compute.  Default 0 (one all-reduce over the whole flat buffer after the backward pass): the convolution kernels are
+# persistent launches of exactly one workgroup per CU that own the CU's whole LDS, so every CU an RCCL channel holds sends one
+# of their workgroups into a second round, and whether the hidden 0.3-0.5 ms outweigh that could not be measured on the
+# single-GPU boxes this round ran on.
+AR_OVERLAP = os.environ.get("UGN_AR_OVERLAP", "0") == "1"
 
 # UGN_ROUTED=1: form the set-max gradient inside the a3 / a5 data-gradient epilogues instead of materialising it with
 # setmax_bwd (bit-identical; measured 2.5 % SLOWER on MI355X: three operand loads per element make those epilogues spill).
