@@ -115,10 +115,15 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    # UGN_DIST_BACKEND=gloo rehearses the N > 1 path on a box with fewer GPUs than ranks (ranks share devices); the real
+    # launch is one rank per GPU over RCCL ("nccl")
+    backend = os.environ.get("UGN_DIST_BACKEND", "nccl")
+    if backend != "nccl":
+        local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local))
+        kw = dict(device_id=torch.device("cuda", local)) if backend == "nccl" else {}
+        dist.init_process_group(backend, rank=rank, world_size=world, **kw)
     dev = torch.device("cuda", local)
 
     xs, uses, labels, onehot = make_batch(KINDS, B_PER_GPU, L, NCLS, ids=n_ids, seed=232323 + rank)

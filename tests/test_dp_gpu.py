@@ -74,3 +74,21 @@ def test_bucketed_allreduce_equals_the_single_one(dev, tmp_path):
     a = _run_replicas("replica", tmp_path, overlap="1")
     b = _run_replicas("replica", tmp_path, overlap="0")
     assert np.array_equal(a["grad"], b["grad"]) and np.array_equal(a["params"], b["params"])
+
+
+@pytest.mark.timeout(900)
+def test_bench_contract_with_two_ranks(dev):
+    """bench.py as the driver launches it for N = 2 (torch.distributed.run, one JSON line from rank 0), rehearsed over gloo
+    with both ranks on the box's one GPU (UGN_DIST_BACKEND=gloo; the real launch is one rank per GPU over RCCL)."""
+    import json
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, UGN_DIST_BACKEND="gloo")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2",
+                        "--warmup", "1", "--no-cpu-baseline", "--dense-only"], env=env, capture_output=True, text=True, timeout=800)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["config"]["parallelism"] == "dp2" and d["roofline"]["achieved"] > 0
