@@ -191,6 +191,9 @@ int ugn_triplet_fwd_bwd(const float* sig, const int32_t* hp, const int32_t* hn, 
 /* ---- keras Adam (mains/mj_trainUWYHGaitNet_DataGen_CasiaB.py:227): p -= lr_t * m / (sqrt(v) + eps) -------- */
 int ugn_adam_step(float* p, const float* g, float* m, float* v, size_t n, float lr_t, float b1, float b2,
                   float eps, float grad_scale, void* stream);
+/* Same update, lr_t read from device memory (one float): the launch can be captured in a hipGraph and replayed every step. */
+int ugn_adam_step_dev(float* p, const float* g, float* m, float* v, size_t n, const float* lr_t_dev, float b1, float b2,
+                      float eps, float grad_scale, void* stream);
 
 /* ---- device-side batch assembly ----------------------------------------------------------
  * One modality of one batch: decode + re-layout + row expansion of data/mj_dataGeneratorMMUWYHsingle_repetitions.py

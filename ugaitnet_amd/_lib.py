@@ -66,6 +66,7 @@ PROTOTYPES = {
     "ugn_knn_ws": (_sz, [_i, _i]),
     "ugn_knn_predict": (_i, [_p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _sz, _p]),
     "ugn_adam_step": (_i, [_p, _p, _p, _p, _sz, _f, _f, _f, _f, _f, _p]),
+    "ugn_adam_step_dev": (_i, [_p, _p, _p, _p, _sz, _p, _f, _f, _f, _f, _p]),
 }
 
 _lib = None

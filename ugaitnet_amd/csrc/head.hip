@@ -473,6 +473,21 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
   p[e] = p[e] - lr_t * mv / (sqrtf(vv) + eps);
 }
 
+// the same update with the step-dependent learning rate read from device memory: the launch can then live in a captured
+// hipGraph that is replayed every step while the host only rewrites that one float
+__global__ void adam_dev_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                size_t n, const float* __restrict__ lr_t_dev, float b1, float b2, float eps, float gscale) {
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n) return;
+  const float lr_t = *lr_t_dev;
+  const float gv = g[e] * gscale;
+  const float mv = b1 * m[e] + (1.f - b1) * gv;
+  const float vv = b2 * v[e] + (1.f - b2) * gv * gv;
+  m[e] = mv;
+  v[e] = vv;
+  p[e] = p[e] - lr_t * mv / (sqrtf(vv) + eps);
+}
+
 }  // namespace
 
 extern "C" int ugn_binfc_fwd(const float* feat, const float* w, float* out, int b, void* stream) {
@@ -612,5 +627,15 @@ extern "C" int ugn_adam_step(float* p, const float* g, float* m, float* v, size_
   hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr_t,
                      b1, b2, eps, grad_scale);
   UGN_CHECK_LAUNCH("adam");
+  return 0;
+}
+
+extern "C" int ugn_adam_step_dev(float* p, const float* g, float* m, float* v, size_t n, const float* lr_t_dev, float b1,
+                                 float b2, float eps, float grad_scale, void* stream) {
+  UGN_REQUIRE(p && g && m && v && lr_t_dev, "ugn_adam_step_dev: null pointer");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(adam_dev_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n,
+                     lr_t_dev, b1, b2, eps, grad_scale);
+  UGN_CHECK_LAUNCH("adam (device lr)");
   return 0;
 }

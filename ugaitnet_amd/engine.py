@@ -671,3 +671,75 @@ class GaitCore:
             acc = float(self.head["hit"].cpu().numpy().mean())
             out.update(xent=xent, acc=acc, loss=w_tri * tri + w_id * xent)
         return out
+
+
+class GraphedTrainStep:
+    """One training step of a GaitCore as two captured HIP graphs (torch.cuda.CUDAGraph is a hipGraph on ROCm): forward + loss
+    + backward, and Adam + filter repack; under data parallelism the gradient all-reduce runs between the two replays.
+
+    A step is ~150 kernel launches; at 24 clips per GPU the GPU needs 9 ms for them and the host 2 ms, but at 4-8 clips (the
+    8-GPU split of the reference's 40-clip batch is 5 per GPU) the launches themselves set the pace.  Replaying a graph removes
+    the per-launch host cost; the arithmetic, the kernels and the two-stream dependency structure (captured as graph edges) are
+    exactly those of `GaitCore.train_step`, so parameters stay bit-identical (tests/test_graph_gpu.py).
+
+    The graph is captured for ONE batch geometry: shapes, the equality structure of the labels (which rows share an identity
+    -- what the triplet index lists depend on; the sampler's P x K batches all share it) and dense encoders (no skip_masked).
+    `step()` copies the new batch into the captured buffers and replays; a batch of another geometry raises ValueError."""
+
+    def __init__(self, core, xs, uses, labels, onehot):
+        if core.skip_masked or core.global_batch or BRANCH_STREAMS or FWD_STREAMS:
+            raise ValueError("graph capture needs the dense single-chain step with per-replica losses")
+        if ops.TIMING_ENABLED:
+            raise ValueError("per-kernel event timing cannot be captured")
+        self.core = core
+        dev = core.device
+        self.xs = [core._dev(x).clone() for x in xs]
+        self.uses = None if uses is None else [core._dev(u).reshape(-1, 1).clone() for u in uses]
+        self.onehot = None if onehot is None else core._dev(onehot).clone()
+        self.labels = np.asarray(labels).reshape(-1).copy()
+        self.pattern = self._pattern(self.labels)
+        self.lr = torch.zeros(1, dtype=F32, device=dev)
+        cur = torch.cuda.current_stream(dev)
+        warm = torch.cuda.Stream(device=dev)
+        warm.wait_stream(cur)
+        with torch.cuda.stream(warm):   # allocations, function attributes, triplet lists: all outside the capture
+            for _ in range(2):
+                core.forward_backward(self.xs, self.uses, self.labels, self.onehot)
+                core.finish_gradient_allreduce()
+        cur.wait_stream(warm)
+        torch.cuda.synchronize(dev)
+        self.g_fb = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.g_fb):
+            core.forward_backward(self.xs, self.uses, self.labels, self.onehot)
+        core._ar_pending = None     # (bucket all-reduces are not captured: the reduction runs between the two graphs)
+        scale = (1.0 / core.world) if core.world > 1 else 1.0
+        self.g_up = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.g_up):
+            ops.adam_step_dev(core.store.flat, core.store.grad, core.store.m, core.store.v, self.lr, core.beta_1, core.beta_2,
+                              core.epsilon, scale)
+            core.weights_changed()
+
+    @staticmethod
+    def _pattern(labels):
+        _, first, inv = np.unique(labels, return_index=True, return_inverse=True)
+        return np.argsort(np.argsort(first))[inv]     # identities renumbered in order of first appearance
+
+    def step(self, xs, uses, labels, onehot):
+        core = self.core
+        labels = np.asarray(labels).reshape(-1)
+        if labels.shape != self.labels.shape or not np.array_equal(self._pattern(labels), self.pattern):
+            raise ValueError("batch geometry differs from the captured one (labels' equality structure)")
+        for dst, src in zip(self.xs, xs):
+            dst.copy_(core._dev(src).reshape(dst.shape), non_blocking=True)
+        if self.uses is not None:
+            for dst, src in zip(self.uses, uses):
+                dst.copy_(core._dev(src).reshape(dst.shape), non_blocking=True)
+        if self.onehot is not None:
+            self.onehot.copy_(core._dev(onehot).reshape(self.onehot.shape), non_blocking=True)
+        self.g_fb.replay()
+        if core.world > 1:
+            dp.allreduce_sum_(core.store.grad, core.pg)
+        core.iterations += 1
+        t = core.iterations
+        self.lr.fill_(core.lr * math.sqrt(1.0 - core.beta_2 ** t) / (1.0 - core.beta_1 ** t))
+        self.g_up.replay()

@@ -421,3 +421,9 @@ def triplet_fwd_bwd(sig, hp, hn, kp, kn, margin, grad_scale, bin_loss=None, bin_
 def adam_step(p, g, m, v, lr_t, b1=0.9, b2=0.999, eps=1e-7, grad_scale=1.0):
     call("ugn_adam_step", ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), float(lr_t), float(b1), float(b2), float(eps),
          float(grad_scale), _stream())
+
+
+def adam_step_dev(p, g, m, v, lr_t_dev, b1=0.9, b2=0.999, eps=1e-7, grad_scale=1.0):
+    """adam_step with lr_t in device memory (a 1-element fp32 tensor): capturable in a hipGraph."""
+    call("ugn_adam_step_dev", ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), ptr(_chk(lr_t_dev)), float(b1), float(b2), float(eps),
+         float(grad_scale), _stream())
