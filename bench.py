@@ -125,6 +125,9 @@ def main():
         kw = dict(device_id=torch.device("cuda", local)) if backend == "nccl" else {}
         dist.init_process_group(backend, rank=rank, world_size=world, **kw)
     dev = torch.device("cuda", local)
+    if world > 1:   # create the communicator now, so that a run with --warmup 0 does not time its construction
+        dist.all_reduce(torch.zeros(1, device=dev))
+        torch.cuda.synchronize()
 
     xs, uses, labels, onehot = make_batch(KINDS, B_PER_GPU, L, NCLS, ids=n_ids, seed=232323 + rank)
     core = GaitCore([2, 1, 1], nclasses=NCLS, fuse_mode="sign_max", margin=0.2, loss_weights=(1.0, 0.1), device=dev,
