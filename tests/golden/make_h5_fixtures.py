@@ -12,6 +12,7 @@ is checked against files it did not write itself.
   chunked + shuffle + deflate int16 array `data` [60,60,50], small arrays, numpy scalars as root attributes.
 * features.h5             -- format features: nested groups, >8 and >64 entries in a group, scalar / empty / big-endian /
   float64 / int8 datasets, chunked datasets with edge chunks and fletcher32, fixed- and variable-length string attributes.
+* latest.h5              -- the same kind of content written with libver='latest' (what the reader takes of it, and what it refuses).
 The expected contents are stored beside each file as <name>.npz by this script (read back through h5py).
 """
 import os
@@ -142,6 +143,16 @@ def main():
         f["scalar"].attrs["on_dataset"] = np.float32(0.5)
         f.attrs["vlen_list"] = np.array(["x", "yy", "zzz"], dtype=h5py.string_dtype())
     np.savez_compressed(os.path.join(OUT, "features.npz"), **exp)
+    # libver='latest': version-2 superblock and object headers, compact link messages; dense groups and version-4 chunk
+    # indexes are outside the reader's subset and must be refused by name
+    with h5py.File(os.path.join(OUT, "latest.h5"), "w", libver="latest") as f:
+        f.attrs["layer_names"] = [b"a", b"bb"]
+        g = f.create_group("a")
+        g.attrs["weight_names"] = [b"a/kernel:0"]
+        g.create_dataset("a/kernel:0", data=np.arange(12, dtype=np.float32).reshape(3, 4))
+        f.create_dataset("chunked", data=np.arange(100, dtype=np.int16).reshape(10, 10), chunks=(4, 4), compression="gzip")
+        for i in range(20):
+            f.create_dataset("many/d%d" % i, data=np.float32(i))
     print("wrote", sorted(os.listdir(OUT)))
 
 

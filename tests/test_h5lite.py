@@ -56,6 +56,17 @@ def test_reader_refuses_what_it_does_not_understand(tmp_path):
         samples.load_sample(str(tmp_path / "cut.h5"))["data"]
 
 
+def test_libver_latest_files():
+    f = h5lite.File(os.path.join(H5, "latest.h5"))           # version-2 superblock / object headers, compact links
+    assert f.keys() == ["a", "chunked", "many"] and list(f.attrs["layer_names"]) == [b"a", b"bb"]
+    assert np.array_equal(f["a/a/kernel:0"].read(), np.arange(12, dtype=np.float32).reshape(3, 4))
+    assert list(f["a"].attrs["weight_names"]) == [b"a/kernel:0"]
+    with pytest.raises(h5lite.H5Error, match="fractal heap"):
+        f["many"].keys()
+    with pytest.raises(h5lite.H5Error, match="version-4 chunked"):
+        f["chunked"].read()
+
+
 def test_deepdish_sample():
     s = samples.load_sample(os.path.join(H5, "dd_sample_of.h5"))
     exp = np.load(os.path.join(H5, "dd_sample_of.npz"))

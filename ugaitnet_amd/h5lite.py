@@ -198,7 +198,9 @@ class Dataset(Object):
         count = int(np.prod(self.shape, dtype=np.int64)) if self.shape else 1
         lay = self._node.first(0x0008)
         ver = lay[0]
-        if ver == 3:
+        if ver == 4 and lay[1] == 2:
+            raise H5Error("version-4 chunked layout (chunk index types of libver='latest') on %s" % self.name)
+        if ver in (3, 4):   # (version 4 keeps the compact and contiguous forms of version 3)
             cls = lay[1]
             if cls == 0:
                 size = struct.unpack_from("<H", lay, 2)[0]
