@@ -72,3 +72,37 @@ def test_generator_feeds_fit_from_sample_files(dev, tmp_path):
     ck = str(tmp_path / "model-final-0002_weights.hdf5")
     model.save_weights(ck)
     assert h5lite.File(ck)["mat_mul_2"].keys() == ["MatMul_kernel[2]:0"]
+
+
+def test_reference_constructor_surface(dev, tmp_path):
+    """The class the mains instantiate, with their keyword arguments."""
+    from ugaitnet_amd.data.mj_dataGeneratorMMUWYHsingle_repetitions import DataGeneratorGaitMMUWYH
+    rng = np.random.default_rng(3)
+    dirs = [str(tmp_path / m) for m in ("of25_60x60", "gray25_60x60", "silhouette25_60x60")]
+    for d in dirs:
+        os.makedirs(d)
+    all_samples, gaits = [], []
+    for i, lab in enumerate([5, 5, 9, 9]):
+        name = "p%03d.h5" % i
+        _write_sample(os.path.join(dirs[0], name), rng.integers(-3000, 3000, (60, 60, 50)).astype(np.int16), lab, 1)
+        _write_sample(os.path.join(dirs[1], name), rng.integers(0, 256, (60, 60, 25)).astype(np.uint8), lab, 1)
+        _write_sample(os.path.join(dirs[2], name), (rng.integers(0, 2, (60, 60, 25)) * 255).astype(np.uint8), lab, 1)
+        all_samples.append(((name, name, name), lab))
+        gaits.append(1)
+    _write_sample(os.path.join(dirs[0], "empty.h5"), np.zeros((0,), np.int16), 5, 1)      # a recording without detections
+    all_samples.append((("empty.h5", -1, -1), 5))
+    gaits.append(1)
+    kw = dict(batch_size=4, dim=[(50, 60, 60), (25, 60, 60), (25, 60, 60)], n_classes=2, datadir=dirs, labmap={5: 0, 9: 1},
+              gait=gaits, ntype=2, augmentation_x=0, expand_level=3, nmods=3, gaitset=True, repetition=1, shuffle=False)
+    gen = DataGeneratorGaitMMUWYH(all_samples, **kw)
+    assert len(gen.allSamples) == 4 and len(gen) == 1                  # the empty file is dropped (:118-146)
+    X, y = gen[0]
+    assert [tuple(t.shape) for t in X] == [(12, 25, 60, 60, 2), (12, 1), (12, 25, 60, 60, 1), (12, 1), (12, 25, 60, 60, 1), (12, 1)]
+    assert y[0].reshape(-1).tolist() == [0] * 6 + [1] * 6 and y[1].shape == (12, 2)
+    sil = X[4][0].cpu().numpy()
+    assert set(np.unique(sil)) <= {0.0, 1.0}                           # "silhouette" in the directory name: data / 255, no offset
+    assert abs(float(X[0][0].abs().max().cpu()) - 3.0) < 0.01          # int16 / compressFactor 100 * 0.1
+    with pytest.raises(NotImplementedError):
+        DataGeneratorGaitMMUWYH(all_samples, **dict(kw, augmentation_x=1))
+    with pytest.raises(NotImplementedError):
+        DataGeneratorGaitMMUWYH(all_samples, **dict(kw, nmods=2, dim=kw["dim"][:2], datadir=dirs[:2]))
