@@ -91,3 +91,39 @@ def gen_batch_mm(samples, specs, expand, seed, clip=(0, 0)):
                         x[2 * j + 1][(ex + 1) + i * expand,] = 1.0
                         plan[(ex + 1) + i * expand, j] = i
     return [a.astype(np.float32) for a in x], plan
+
+
+def gen_batch_2mod(samples, specs, expand, seed):
+    """The two-modality generator `__gen_batch` (:347-545) with augmentation off, gaitset=True: row 0 of a sample carries what
+    exists; row 1 disables ONE randomly chosen modality and copies the other (flag 1 even when the copy is noise); row 2
+    (expand > 2) swaps the choice.  expand is 1, 2 or 3 (the reference fills no further rows)."""
+    rng = random.Random(seed)
+    nbase = len(samples)
+    expand = max(1, min(expand, 3))
+    dim0 = nbase * expand
+    x = []
+    for sp in specs:
+        x += [np.empty((dim0, 25, 60, 60, sp["channels"])), np.empty((dim0, 1))]
+    plan = np.full((dim0, 2), -1, np.int32)
+    for i in range(nbase):
+        for mix in range(2):
+            d = samples[i][mix]
+            if d is None:                                                   # :414-415, 439-441, 471-472
+                x[2 * mix][i * expand,] = NOISE
+                x[2 * mix + 1][i * expand,] = 0.0
+            else:
+                sp = specs[mix]
+                x[2 * mix][i * expand,] = gaitset_layout(load_dd(d, sp["compress_factor"], sp.get("silhouette", False), 2))
+                x[2 * mix + 1][i * expand,] = 1.0
+                plan[i * expand, mix] = i
+        if expand > 1:                                                       # :485-528
+            choice = rng.randrange(0, 2, 1)
+            for row in range(1, expand):
+                off, on = choice, 1 - choice
+                x[2 * off][row + i * expand,] = NOISE
+                x[2 * off + 1][row + i * expand,] = 0.0
+                x[2 * on][row + i * expand,] = np.copy(x[2 * on][i * expand,])
+                x[2 * on + 1][row + i * expand,] = 1.0
+                plan[row + i * expand, on] = i
+                choice = 1 - choice
+    return [a.astype(np.float32) for a in x], plan

@@ -36,6 +36,34 @@ def test_plan_rows_follows_the_generator(expand):
     assert np.array_equal(plan, plan_ref)
 
 
+@pytest.mark.parametrize("expand", [1, 2, 3])
+def test_plan_rows_two_modalities_follows_the_generator(expand):
+    from ugaitnet_amd.batching import plan_rows_2mod
+    rng = np.random.default_rng(20 + expand)
+    samples = [[s[0], s[1]] for s in _samples(rng, 5, {(1, 0), (3, 1)})]
+    present = np.array([[s is not None for s in row] for row in samples])
+    _, plan_ref = BO.gen_batch_2mod(samples, SPECS[:2], expand, seed=31)
+    assert np.array_equal(plan_rows_2mod(present, expand, rng=random.Random(31)), plan_ref)
+    with pytest.raises(ValueError):
+        plan_rows_2mod(present, 4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("expand", [2, 3])
+def test_device_assembly_two_modalities(expand):
+    from ugaitnet_amd.batching import DeviceBatchAssembler, ModalitySpec, plan_rows_2mod
+    rng = np.random.default_rng(40 + expand)
+    samples = [[s[0], s[1]] for s in _samples(rng, 4, {(2, 0), (3, 1)})]
+    present = np.array([[s is not None for s in row] for row in samples])
+    x_ref, _ = BO.gen_batch_2mod(samples, SPECS[:2], expand, seed=6)
+    plan = plan_rows_2mod(present, expand, rng=random.Random(6))
+    raws = [np.stack([s[j] if s[j] is not None else np.zeros(shape, dt) for s in samples])
+            for j, shape, dt in ((0, (60, 60, 50), np.int16), (1, (60, 60, 25), np.uint8))]
+    got = DeviceBatchAssembler([ModalitySpec("of", 2, compress_factor=100.0), ModalitySpec("gray", 1)]).assemble(raws, plan, present=present)
+    for m in range(2):
+        assert np.array_equal(got[m][0].cpu().numpy(), x_ref[2 * m]) and np.array_equal(got[m][1].cpu().numpy(), x_ref[2 * m + 1])
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("expand,clip", [(1, (0, 0)), (2, (0, 0)), (3, (2300, 50))])
 def test_device_assembly_matches_oracle_bit_for_bit(expand, clip):

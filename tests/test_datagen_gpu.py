@@ -104,5 +104,10 @@ def test_reference_constructor_surface(dev, tmp_path):
     assert abs(float(X[0][0].abs().max().cpu()) - 3.0) < 0.01          # int16 / compressFactor 100 * 0.1
     with pytest.raises(NotImplementedError):
         DataGeneratorGaitMMUWYH(all_samples, **dict(kw, augmentation_x=1))
+    two = DataGeneratorGaitMMUWYH(all_samples, **dict(kw, nmods=2, dim=kw["dim"][:2], datadir=dirs[:2]))   # __gen_batch rules
+    X2, y2 = two[0]
+    assert [tuple(t.shape) for t in X2] == [(12, 25, 60, 60, 2), (12, 1), (12, 25, 60, 60, 1), (12, 1)]
+    u = np.concatenate([X2[1].cpu().numpy(), X2[3].cpu().numpy()], axis=1).reshape(4, 3, 2)
+    assert (u[:, 0] == 1).all() and (u[:, 1].sum(axis=1) == 1).all() and (u[:, 1] + u[:, 2] == 1).all()   # one off, then the other
     with pytest.raises(NotImplementedError):
-        DataGeneratorGaitMMUWYH(all_samples, **dict(kw, nmods=2, dim=kw["dim"][:2], datadir=dirs[:2]))
+        DataGeneratorGaitMMUWYH(all_samples, **dict(kw, nmods=1, dim=kw["dim"][:1], datadir=dirs[:1]))

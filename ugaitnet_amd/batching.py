@@ -66,6 +66,30 @@ def plan_rows(present, expand, rng=_random):
     return src
 
 
+def plan_rows_2mod(present, expand, rng=_random):
+    """Row plan of the TWO-modality generator `__gen_batch` (:485-528): row i*expand carries what exists; the next row turns one
+    randomly drawn modality off and copies the other, a third row (expand > 2) swaps the two; the reference fills no more
+    than three rows per sample."""
+    present = np.asarray(present, bool)
+    nbase, nmods = present.shape
+    if nmods != 2:
+        raise ValueError("plan_rows_2mod is the two-modality rule")
+    expand = max(1, int(expand))
+    if expand > 3:
+        raise ValueError("the two-modality generator defines at most 3 rows per sample (expand_level <= 3)")
+    src = np.full((nbase * expand, 2), -1, np.int32)
+    for i in range(nbase):
+        for j in range(2):
+            if present[i, j]:
+                src[i * expand, j] = i
+        if expand > 1:
+            choice = rng.randrange(0, 2, 1)
+            for row in range(1, expand):
+                src[row + i * expand, 1 - choice] = i
+                choice = 1 - choice
+    return src
+
+
 class DeviceBatchAssembler:
     def __init__(self, specs, device=None):
         self.specs = list(specs)

@@ -2,9 +2,9 @@
 by ugaitnet_amd.sampler.DeviceDataGenerator: the mains' `DataGeneratorGaitMMUWYH(allSamples, ..., datadir=[...], labmap=...,
 gait=..., nmods=3, gaitset=True, repetition=r, expand_level=e)` keeps working and yields batches that already live in HBM.
 
-Implemented: the three-modality gaitset generator without augmentation (`nmods=3, gaitset=True, augmentation_x=0`), the label
-cycling of `__getitem__`, `__len__`, `on_epoch_end`, `keep_data`.  Everything else the reference's class can do (two-modality
-and single-modality batch rules, affine / mirror augmentation, sample weights, auxiliary / per-FC label lists, 3-D inputs, debug
+Implemented: the two- and three-modality gaitset generators without augmentation (`nmods=2|3, gaitset=True,
+augmentation_x=0`), the label cycling of `__getitem__`, `__len__`, `on_epoch_end`, `keep_data`.  Everything else the
+reference's class can do (the single-modality batch rule, affine / mirror augmentation, sample weights, auxiliary / per-FC label lists, 3-D inputs, debug
 batches) raises NotImplementedError instead of silently producing different batches."""
 from __future__ import annotations
 
@@ -23,7 +23,7 @@ class DataGeneratorGaitMMUWYH(DeviceDataGenerator):
                  expand_level=2, balanced_classes=True, isTriplet=False, use3D=False, isDebug=False, softlabel=False, camera=[],
                  nmods=2, use_weights=False, meanSample=0.0, aux_losses=False, triplet_all_fc=False, nfcs=0, keep_data=False,
                  gaitset=False, repetition=4):
-        unsupported = [name for name, bad in (("nmods != 3", nmods != 3), ("gaitset=False", not gaitset), ("use3D", use3D),
+        unsupported = [name for name, bad in (("nmods == 1", nmods not in (2, 3)), ("gaitset=False", not gaitset), ("use3D", use3D),
                                               ("isDebug", isDebug), ("softlabel", softlabel), ("use_weights", use_weights),
                                               ("aux_losses", aux_losses), ("triplet_all_fc", triplet_all_fc),
                                               ("augmentation_x > 0", augmentation_x > 0), ("ntype != 2", ntype != 2)) if bad]

@@ -22,7 +22,7 @@ import random as _random
 import numpy as np
 
 from . import samples as _samples
-from .batching import DeviceBatchAssembler, plan_rows
+from .batching import DeviceBatchAssembler, plan_rows, plan_rows_2mod
 
 
 class LabelCyclingSampler:
@@ -131,7 +131,7 @@ class DeviceDataGenerator:
                     present[i, m] = True
             lb = self.labmap[int(label)] if self.labmap else label
             labels[i * self.expand:(i + 1) * self.expand, 0] = lb
-        plan = plan_rows(present, self.expand, rng=self.mask_rng)
+        plan = (plan_rows_2mod if nmod == 2 else plan_rows)(present, self.expand, rng=self.mask_rng)
         X = []
         for x, u in self.assembler.assemble(raws, plan, present=present):
             X += [x, u]
