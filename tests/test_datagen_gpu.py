@@ -109,5 +109,10 @@ def test_reference_constructor_surface(dev, tmp_path):
     assert [tuple(t.shape) for t in X2] == [(12, 25, 60, 60, 2), (12, 1), (12, 25, 60, 60, 1), (12, 1)]
     u = np.concatenate([X2[1].cpu().numpy(), X2[3].cpu().numpy()], axis=1).reshape(4, 3, 2)
     assert (u[:, 0] == 1).all() and (u[:, 1].sum(axis=1) == 1).all() and (u[:, 1] + u[:, 2] == 1).all()   # one off, then the other
+    one = DataGeneratorGaitMMUWYH(all_samples, **dict(kw, nmods=1, dim=(25, 60, 60), datadir=dirs[1:2] + dirs[:1]))
+    assert one.specs[0].kind == "gray"
+    X1, y1 = one[0]                                                    # __gen_batchSingle: the tensor itself, no expansion
+    assert tuple(X1.shape) == (4, 25, 60, 60, 1) and y1[0].reshape(-1).tolist() == [0, 0, 1, 1]
+    assert float(X1.min().cpu()) >= -0.5 and float(X1.max().cpu()) <= 0.5
     with pytest.raises(NotImplementedError):
-        DataGeneratorGaitMMUWYH(all_samples, **dict(kw, nmods=1, dim=kw["dim"][:1], datadir=dirs[:1]))
+        DataGeneratorGaitMMUWYH(all_samples, **dict(kw, gaitset=False))

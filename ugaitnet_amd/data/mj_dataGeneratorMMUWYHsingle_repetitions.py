@@ -2,9 +2,9 @@
 by ugaitnet_amd.sampler.DeviceDataGenerator: the mains' `DataGeneratorGaitMMUWYH(allSamples, ..., datadir=[...], labmap=...,
 gait=..., nmods=3, gaitset=True, repetition=r, expand_level=e)` keeps working and yields batches that already live in HBM.
 
-Implemented: the two- and three-modality gaitset generators without augmentation (`nmods=2|3, gaitset=True,
+Implemented: the one-, two- and three-modality gaitset generators without augmentation (`nmods=1|2|3, gaitset=True,
 augmentation_x=0`), the label cycling of `__getitem__`, `__len__`, `on_epoch_end`, `keep_data`.  Everything else the
-reference's class can do (the single-modality batch rule, affine / mirror augmentation, sample weights, auxiliary / per-FC label lists, 3-D inputs, debug
+reference's class can do (affine / mirror augmentation, sample weights, auxiliary / per-FC label lists, 3-D inputs, debug
 batches) raises NotImplementedError instead of silently producing different batches."""
 from __future__ import annotations
 
@@ -23,7 +23,10 @@ class DataGeneratorGaitMMUWYH(DeviceDataGenerator):
                  expand_level=2, balanced_classes=True, isTriplet=False, use3D=False, isDebug=False, softlabel=False, camera=[],
                  nmods=2, use_weights=False, meanSample=0.0, aux_losses=False, triplet_all_fc=False, nfcs=0, keep_data=False,
                  gaitset=False, repetition=4):
-        unsupported = [name for name, bad in (("nmods == 1", nmods not in (2, 3)), ("gaitset=False", not gaitset), ("use3D", use3D),
+        if nmods == 1:      # `dim` is one (frames, 60, 60) tuple there (:66-69), the file is allSamples[i][0][0] under datadir[0]
+            dim = [tuple(dim)] if not isinstance(dim[0], (tuple, list)) else [tuple(dim[0])]
+            datadir = list(datadir[:1])
+        unsupported = [name for name, bad in (("nmods > 3", nmods not in (1, 2, 3)), ("gaitset=False", not gaitset), ("use3D", use3D),
                                               ("isDebug", isDebug), ("softlabel", softlabel), ("use_weights", use_weights),
                                               ("aux_losses", aux_losses), ("triplet_all_fc", triplet_all_fc),
                                               ("augmentation_x > 0", augmentation_x > 0), ("ntype != 2", ntype != 2)) if bad]
@@ -43,7 +46,7 @@ class DataGeneratorGaitMMUWYH(DeviceDataGenerator):
         self.dim, self.n_classes, self.batch_size = dim, n_classes, batch_size
         kept, kept_gait = self._drop_empty(allSamples, gait, datadir)          # __remove_empty_files (:118-146)
         super().__init__(kept, kept_gait, datadir, specs, batch_size, n_classes, labmap=labmap or None, expand_level=expand_level,
-                         repetition=repetition, shuffle=shuffle, is_test=isTest, keep_data=keep_data)
+                         repetition=repetition, shuffle=shuffle, is_test=isTest, keep_data=keep_data, single_input=nmods == 1)
         self.allSamples, self.gait = kept, kept_gait
 
     @staticmethod
@@ -61,7 +64,8 @@ class DataGeneratorGaitMMUWYH(DeviceDataGenerator):
             return os.path.exists(p) and len(_samples.load_sample(p)["data"]) > 0
         kept, kept_gait = [], []
         for i, rec in enumerate(all_samples):
-            f0, f1 = rec[0][0], rec[0][1]
+            f0 = rec[0][0]
+            f1 = rec[0][1] if len(datadir) > 1 and len(rec[0]) > 1 else -1
             if f0 != -1:
                 good = ok(0, f0) and (f1 == -1 or ok(1, f1))
             else:

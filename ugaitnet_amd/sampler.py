@@ -91,7 +91,7 @@ class DeviceDataGenerator:
     x_1, use_1, ...] device tensors and y = [labels [rows,1], one-hot [rows,n_classes]] (labels alone when n_classes == 0)."""
 
     def __init__(self, all_samples, gaits, datadirs, specs, batch_size, n_classes, labmap=None, expand_level=2, repetition=4,
-                 shuffle=True, is_test=False, keep_data=False, rng=np.random, mask_rng=_random, device=None):
+                 shuffle=True, is_test=False, keep_data=False, rng=np.random, mask_rng=_random, device=None, single_input=False):
         self.all_samples = list(all_samples)
         self.datadirs, self.specs = list(datadirs), list(specs)
         if len(self.datadirs) != len(self.specs):
@@ -100,6 +100,12 @@ class DeviceDataGenerator:
         self.sampler = LabelCyclingSampler([s[1] for s in self.all_samples], gaits, batch_size, repetition, shuffle, is_test, rng)
         self.assembler = DeviceBatchAssembler(self.specs, device)
         self.mask_rng = mask_rng
+        # single-modality graph (`__gen_batchSingle`, :548-656): X is the tensor itself, no flags, no expansion
+        self.single_input = bool(single_input)
+        if self.single_input:
+            if len(self.specs) != 1:
+                raise ValueError("single_input needs exactly one modality")
+            self.expand = 1
         self.cache = {} if keep_data else None
 
     def __len__(self):
@@ -135,6 +141,10 @@ class DeviceDataGenerator:
         X = []
         for x, u in self.assembler.assemble(raws, plan, present=present):
             X += [x, u]
+        if self.single_input:
+            if not present.all():
+                raise ValueError("single-modality batch with a missing sample file")     # (the reference stops in pdb here)
+            X = X[0]
         if self.n_classes > 0:
             onehot = np.zeros((labels.shape[0], self.n_classes), np.float32)
             onehot[np.arange(labels.shape[0]), labels[:, 0].astype(np.int64)] = 1.0      # keras.utils.to_categorical (:812)
