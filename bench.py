@@ -6,15 +6,23 @@
 Workload (BASELINE.json configs[2], SURVEY.md section 8d "C3"): 3 modalities (optical flow 2ch + gray + depth),
 25 frames of 60x60, 24 clips per GPU, 12 ids x 2, 150 classes, sign_max fusion with the 7-pattern missing-modality
 masks, loss = 1.0*batch-all triplet(0.2) + 0.1*cross-entropy, Adam(1e-4).  Synthetic data, seed 232323, random-init
-weights.  One process per GPU; for N > 1 every rank processes its own 24 clips (weak scaling), per-replica loss as the
-reference's MirroredStrategy does, gradients averaged with one RCCL all-reduce over the flat gradient buffer.
-Inputs are resident in HBM before the timed region starts.
+weights.  Inputs are resident in HBM before the timed region starts.
+
+N > 1: one process per GPU over RCCL (torch.distributed backend "nccl").  Started by the driver's torchrun line, or --
+when WORLD_SIZE is not in the environment -- by this script itself, which then spawns
+`python -m torch.distributed.run --nproc-per-node N bench.py ...` as CHILD processes before anything touches the GPU, relays
+rank 0's JSON line and exits with the children's code.  Default = weak scaling: every rank processes its own 24 clips with
+per-replica losses as the reference's MirroredStrategy does (mains/mj_trainUWYHGaitNet_DataGen_CasiaB.py:342-349), gradients
+averaged by one all-reduce of the flat gradient buffer.  `--scaling strong` = the reference's own sharding of a fixed batch
+(mains/...CasiaB.py:458-461: batchsize / multigpu): the workload's clips are split over the N ranks, C4 = 40 / N per GPU.
 
 One JSON line is printed by rank 0; see DESIGN.md "Measurement" for the definition of every field.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -23,8 +31,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-KINDS = ("of", "gray", "depth")
-B_PER_GPU, L, NCLS = 24, 25, 150
+L = 25
 # secondary workloads (never the headline line): --workload c4 = SURVEY 8(d) "C4", the CASIA-B shape
 WORKLOADS = {
     "c3": dict(kinds=("of", "gray", "depth"), clips=24, ncls=150, ids_per=2,
@@ -42,39 +49,44 @@ WORKLOADS = {
 F_FWD = {1: 7.944e9, 2: 8.108e9}
 F_FIRST = {1: 0.164e9, 2: 0.328e9}
 FLOP_PER_CLIP = sum(3 * F_FWD[c] - F_FIRST[c] for c in (2, 1, 1))   # fwd + dgrad + wgrad, no dgrad for layer 1
-PEAK_F32_MFMA = 157.3e12   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_F32_MFMA = 157.3e12   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 / 16x16x4_f32 dense peak
 PEAK_BF16_MFMA = 16 * PEAK_F32_MFMA   # same guide: the f32 MFMA rate is 1/16 of the dense bf16 rate (~2.5 PFLOP/s)
+PEAK_HBM = 8.0e12          # same guide: HBM3E spec peak (6.3 TB/s is what a float4 copy achieves)
 
 
-def cpu_baseline(seconds_budget=25.0):
-    """The CPU restatement (torch CPU ops, oneDNN) timed on this host on a bounded sample of the same workload."""
+def cpu_baseline(kinds, ncls, clips, n_ids, seconds_budget=30.0):
+    """The CPU restatement (torch CPU ops, oneDNN) timed on this host on a bounded sample of the same workload: the SAME
+    batch shape (all clips of one step), one warm-up on a small batch (pages in oneDNN's kernels), then whole steps until the
+    budget is spent (at least one)."""
     import torch
     from oracle import torch_ref as T
     from oracle import ugaitnet_oracle as O
     from tests.synth import make_batch
-    b = 8  # 4 ids x 2, the first 8 rows of the 7-pattern mask cycle
-    xs, uses, labels, onehot = make_batch(KINDS, b, L, NCLS, ids=4, seed=232323)
     rng = np.random.default_rng(0)
-    params = dict(branches=[O.init_branch_params(rng, 2 if k == "of" else 1) for k in KINDS],
-                  head=O.init_head_params(rng, NCLS))
+    params = dict(branches=[O.init_branch_params(rng, 2 if k == "of" else 1) for k in kinds],
+                  head=O.init_head_params(rng, ncls))
     tr = T.TorchTrainer(T.params_from_numpy(params), lr=1e-4, margin=0.2, loss_weights=(1.0, 0.1))
-    txs = [torch.from_numpy(x) for x in xs]
-    tus = [torch.from_numpy(u) for u in uses]
-    tl, to = torch.from_numpy(labels), torch.from_numpy(onehot)
-    tr.step(txs, tus, tl, to)  # warm-up
+
+    def tensors(b, ids):
+        xs, uses, labels, onehot = make_batch(kinds, b, L, ncls, ids=ids, seed=232323)
+        return ([torch.from_numpy(x) for x in xs], [torch.from_numpy(u) for u in uses], torch.from_numpy(labels),
+                torch.from_numpy(onehot))
+    tr.step(*tensors(4, 2))  # warm-up
+    batch = tensors(clips, n_ids)
     times = []
     t_start = time.perf_counter()
-    while len(times) < 2 or (time.perf_counter() - t_start < seconds_budget and len(times) < 10):
+    while not times or (time.perf_counter() - t_start + times[-1] < seconds_budget and len(times) < 5):
         t0 = time.perf_counter()
-        tr.step(txs, tus, tl, to)
+        tr.step(*batch)
         times.append(time.perf_counter() - t0)
     med = float(np.median(times))
-    return dict(value=b / med, unit="clips/s", cores=int(torch.get_num_threads()), kind="port",
-                sample="%d clips (same 3-modality shape, masks, L=25), %d timed steps after 1 warm-up, median; "
-                       "torch-CPU (oneDNN) restatement oracle/torch_ref.py, fwd+bwd+Adam" % (b, len(times)))
+    return dict(value=clips / med, unit="clips/s", cores=int(torch.get_num_threads()), kind="port",
+                sample="%d whole step(s) of the same %d-clip batch (3 modalities, masks, L=25) after a 4-clip warm-up, median; "
+                       "torch-CPU (oneDNN) restatement oracle/torch_ref.py, fwd+bwd+Adam; the TF-2.3 reference cannot run here"
+                       % (len(times), clips))
 
 
-def main():
+def build_parser():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -84,150 +96,269 @@ def main():
     ap.add_argument("--skip-masked", action="store_true",
                     help="run each encoder only on the clips whose modality flag is 1 (exactly the same results; the default "
                          "line computes the masked pairs too)")
-    ap.add_argument("--dp-mode", choices=("replica", "global"), default="replica",
+    ap.add_argument("--dp-mode", choices=("replica", "global"), default=None,
                     help="N > 1: 'replica' = the reference's MirroredStrategy (losses per replica slice, one gradient "
-                         "all-reduce); 'global' = all-gather the fused features so the losses see the whole batch")
+                         "all-reduce; default for weak scaling); 'global' = all-gather the fused features so the losses see the "
+                         "whole batch (default for --scaling strong: N GPUs then compute the one-GPU step)")
     ap.add_argument("--dtype", choices=("f32", "bf16"), default="f32",
-                    help="bf16 = BASELINE configs[4] / SURVEY C5 arithmetic: bf16 operands in the MFMA of the 3x3 forward "
-                         "convolutions and data gradients, fp32 accumulate, fp32 tensors and weight gradients; never the headline")
+                    help="bf16 = BASELINE configs[4] / SURVEY C5 arithmetic; never the headline")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c3", help="c3 is the headline workload")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="strong: the workload's batch is split over the ranks (c4: 40 / N clips per GPU)")
     ap.add_argument("--clips-per-gpu", type=int, default=0,
-                    help="override the workload's batch (e.g. 96 = the generator-expanded C3 batch); 0 = the workload's own")
-    args = ap.parse_args()
+                    help="override the per-GPU batch (e.g. 96 = the generator-expanded C3 batch; 5 = one rank's share of C4 on 8 "
+                         "GPUs); 0 = the workload's own")
+    ap.add_argument("--serial", action="store_true",
+                    help="run the timed region itself with every launch on one stream (the rocprofv3 kernel-trace target: "
+                         "per-kernel durations are then clean); never the headline")
+    ap.add_argument("--no-roofline-pass", action="store_true", help="skip the serialised per-kernel timing pass")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise torch.distributed and run the gradient collectives even with one rank (rehearses the RCCL "
+                         "code path on a one-GPU box)")
+    return ap
+
+
+def launch_ranks(args, argv):
+    """--gpus N > 1 without a torchrun environment: start the N ranks as children (never exec), relay rank 0's line."""
+    import torch   # device_count() does not initialise the GPU on this image
+    backend = os.environ.get("UGN_DIST_BACKEND", "nccl")
+    have = torch.cuda.device_count()
+    if backend == "nccl" and have < args.gpus:
+        raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible; one rank per GPU over RCCL needs %d "
+                         "(UGN_DIST_BACKEND=gloo rehearses more ranks than GPUs)" % (args.gpus, have, args.gpus))
+    if have < 1:
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, text=True)   # (stderr passes through)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    for ln in r.stdout.splitlines():
+        if not ln.startswith("{"):
+            print(ln, file=sys.stderr)
+    if r.returncode != 0 or len(lines) != 1:
+        print("bench.py: the %d-rank launch failed (exit code %d, %d JSON lines)" % (args.gpus, r.returncode, len(lines)),
+              file=sys.stderr)
+        raise SystemExit(r.returncode or 1)
+    print(lines[0], flush=True)
+
+
+def roofline_pass(core, batch, steps, dtype):
+    """Per-kernel durations from a fully serialised pass (one stream, HIP-event pair on that stream around every launch),
+    taken AFTER the timed region; returns the roofline object of the kernel with the largest total duration."""
+    import torch
+    from ugaitnet_amd import _lib, engine
+    with engine.serial_launches():
+        core.train_step(*batch)            # un-timed: first step on the one-stream schedule
+        torch.cuda.synchronize()
+        _lib.PROFILE, _lib.WORK = {}, {}
+        try:
+            for _ in range(steps):
+                core.train_step(*batch)
+            torch.cuda.synchronize()
+            prof, work = _lib.PROFILE, _lib.WORK
+        finally:
+            _lib.PROFILE = None
+    rows = []
+    for label, evs in prof.items():
+        us = [a.elapsed_time(b) * 1e3 for a, b in evs]
+        rows.append((float(np.sum(us)), float(np.mean(us)), len(us), label))
+    rows.sort(reverse=True)
+    total = sum(r[0] for r in rows)
+
+    def describe(row):
+        tot, avg, n, label = row
+        w = work.get(label)
+        d = dict(kernel=label, launches_per_step=n // steps, avg_us=round(avg, 1), share_of_step=round(tot / total, 4))
+        if w and w["bound"] == "mfma":
+            peak = PEAK_BF16_MFMA if w["dtype"] == "bf16" else PEAK_F32_MFMA
+            d.update(bound="mfma", unit="TFLOP/s", peak=round(peak / 1e12, 1), achieved=round(w["mfma_flops"] / avg / 1e6, 2),
+                     frac=round(w["mfma_flops"] / (avg * 1e-6) / peak, 4), algorithmic_tflops=round(w["flops"] / avg / 1e6, 2),
+                     rocprof_kernel=w["kernel"], images_per_launch=w["images"])
+        elif w and w["bound"] == "hbm":
+            d.update(bound="hbm", unit="GB/s", peak=PEAK_HBM / 1e9, achieved=round(w["bytes"] / avg / 1e3, 1),
+                     frac=round(w["bytes"] / (avg * 1e-6) / PEAK_HBM, 4), rocprof_kernel=w["kernel"])
+        return d
+    top = describe(rows[0])
+    roof = dict(bound=top.get("bound"), achieved=top.get("achieved"), peak=top.get("peak"), unit=top.get("unit"),
+                frac=top.get("frac"), traffic=None)
+    roof.update({k: v for k, v in top.items() if k not in roof})
+    roof["how"] = ("dominant kernel = largest total duration in a serialised pass of %d steps after the timed region (every "
+                   "launch on one stream, HIP-event pairs on that stream); achieved = FLOPs executed on the matrix pipe "
+                   "(Winograd F(2x2,3x3): 16/36 of the direct-convolution count, which is `algorithmic_tflops`) / avg duration"
+                   % steps)
+    tfile = os.path.join(ROOT, "profiles", "roofline_traffic.json")
+    if os.path.exists(tfile) and dtype == "f32":
+        t = json.load(open(tfile))
+        if t.get("rocprof_kernel") == top.get("rocprof_kernel") and t.get("images_per_launch") == top.get("images_per_launch"):
+            roof["traffic"] = t.get("hbm_bytes_per_launch")
+    roof["serial_step_us"] = round(total / steps, 1)
+    roof["other_kernels"] = [describe(r) for r in rows[1:10]]
+    return roof
+
+
+def run(args):
     wl = WORKLOADS[args.workload]
     if args.workload == "c5":
         args.dtype = "bf16"
-    global KINDS, B_PER_GPU, NCLS
-    KINDS, NCLS = wl["kinds"], wl["ncls"]
-    B_PER_GPU = args.clips_per_gpu or wl["clips"]
-    if B_PER_GPU % wl["ids_per"]:
-        raise SystemExit("--clips-per-gpu must be a multiple of %d for workload %s" % (wl["ids_per"], args.workload))
-    n_ids = B_PER_GPU // wl["ids_per"]
+    kinds, ncls = wl["kinds"], wl["ncls"]
 
     import torch
     import torch.distributed as dist
     from tests.synth import make_batch
-    from ugaitnet_amd import ops
+    from ugaitnet_amd import engine
     from ugaitnet_amd.engine import GaitCore
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py --gpus %d was started with WORLD_SIZE=%d: launch one rank per GPU" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    if args.scaling == "strong":
+        if args.clips_per_gpu:
+            raise SystemExit("--scaling strong splits the workload's batch; --clips-per-gpu does not apply")
+        if wl["clips"] % world:
+            raise SystemExit("--scaling strong: %d clips do not split over %d ranks" % (wl["clips"], world))
+        b_gpu = wl["clips"] // world
+    else:
+        b_gpu = args.clips_per_gpu or wl["clips"]
+    dp_mode = args.dp_mode or ("global" if args.scaling == "strong" and world > 1 else "replica")
     # UGN_DIST_BACKEND=gloo rehearses the N > 1 path on a box with fewer GPUs than ranks (ranks share devices); the real
     # launch is one rank per GPU over RCCL ("nccl")
     backend = os.environ.get("UGN_DIST_BACKEND", "nccl")
+    if backend == "nccl" and torch.cuda.device_count() < world:
+        raise SystemExit("bench.py: %d ranks but %d GPU(s): RCCL needs one GPU per rank" % (world, torch.cuda.device_count()))
     if backend != "nccl":
         local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
-    if world > 1:
-        kw = dict(device_id=torch.device("cuda", local)) if backend == "nccl" else {}
-        dist.init_process_group(backend, rank=rank, world_size=world, **kw)
     dev = torch.device("cuda", local)
-    if world > 1:   # create the communicator now, so that a run with --warmup 0 does not time its construction
-        dist.all_reduce(torch.zeros(1, device=dev))
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
+        if "MASTER_ADDR" not in os.environ:     # --force-dist outside torchrun: a private one-rank rendezvous
+            s = socket.socket()
+            s.bind(("127.0.0.1", 0))
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(s.getsockname()[1]))
+            s.close()
+        kw = dict(device_id=dev) if backend == "nccl" else {}
+        dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+        dist.all_reduce(torch.zeros(1, device=dev))   # create the communicator now: --warmup 0 must not time its construction
         torch.cuda.synchronize()
 
-    xs, uses, labels, onehot = make_batch(KINDS, B_PER_GPU, L, NCLS, ids=n_ids, seed=232323 + rank)
-    core = GaitCore([2, 1, 1], nclasses=NCLS, fuse_mode="sign_max", margin=0.2, loss_weights=(1.0, 0.1), device=dev,
-                    seed=232323, lr=1e-4, world_size=world, skip_masked=args.skip_masked, dp_mode=args.dp_mode, conv_precision=args.dtype)
-    dxs = [torch.from_numpy(x).to(dev) for x in xs]
-    dus = uses if args.skip_masked else [torch.from_numpy(u).to(dev) for u in uses]   # flags: host copies when they steer the launch
-    doh = torch.from_numpy(onehot).to(dev)
+    if args.scaling == "strong":
+        # ONE global batch, every rank owns a contiguous slice of it (dp.shard_bounds), as MirroredStrategy splits a batch
+        from ugaitnet_amd import dp
+        gx, gu, glab, goh = make_batch(kinds, wl["clips"], L, ncls, ids=wl["clips"] // wl["ids_per"], seed=232323)
+        lo, hi = dp.shard_bounds(wl["clips"], rank, world)
+        xs, uses, labels, onehot = [x[lo:hi] for x in gx], [u[lo:hi] for u in gu], glab[lo:hi], goh[lo:hi]
+        n_ids = wl["clips"] // wl["ids_per"]
+    else:
+        if b_gpu % wl["ids_per"]:
+            ids_per = 1 if b_gpu < wl["ids_per"] else None
+            if ids_per is None:
+                raise SystemExit("--clips-per-gpu must be a multiple of %d for workload %s" % (wl["ids_per"], args.workload))
+            n_ids = b_gpu          # fewer clips than one identity's share: every clip its own identity
+        else:
+            n_ids = b_gpu // wl["ids_per"]
+        xs, uses, labels, onehot = make_batch(kinds, b_gpu, L, ncls, ids=n_ids, seed=232323 + rank)
+
+    def make_core(skip):
+        return GaitCore([2, 1, 1], nclasses=ncls, fuse_mode="sign_max", margin=0.2, loss_weights=(1.0, 0.1), device=dev,
+                        seed=232323, lr=1e-4, world_size=world, skip_masked=skip, dp_mode=dp_mode, conv_precision=args.dtype,
+                        force_collectives=args.force_dist)
+
+    core = make_core(args.skip_masked)
+    dxs = [torch.from_numpy(np.ascontiguousarray(x)).to(dev) for x in xs]
+    dus_dev = [torch.from_numpy(np.ascontiguousarray(u)).to(dev) for u in uses]
+    doh = torch.from_numpy(np.ascontiguousarray(onehot)).to(dev)
+    batch = (dxs, uses if args.skip_masked else dus_dev, labels, doh)   # flags: host copies when they steer the launch
 
     def sync_all():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        core.train_step(dxs, dus, labels, doh)
-    sync_all()
-    ops.TIMING.clear()
-    ops.TIMING_ENABLED = True   # HIP-event pairs around the dominant kernel's launches, on the launch stream
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        core.train_step(dxs, dus, labels, doh)
-    sync_all()
-    dt = time.perf_counter() - t0
-    ops.TIMING_ENABLED = False
-    if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    def timed(c, bt):
+        for _ in range(args.warmup):
+            c.train_step(*bt)
+        sync_all()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            c.train_step(*bt)
+        sync_all()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
+    ctx = engine.serial_launches() if args.serial else None
+    if ctx:
+        ctx.__enter__()
+    dt = timed(core, batch)
+    if ctx:
+        ctx.__exit__(None, None, None)
     losses = core.losses()
+
+    roof = None
+    if not args.no_roofline_pass:
+        roof = roofline_pass(core, batch, 3, args.dtype)
 
     # secondary figure, same workload: encoders run only on the clips whose modality flag is 1 (the gate multiplies the
     # rest by 0, so every result is unchanged; tests/test_fullsize_gpu.py).  Never reported as `value`.
     skip_rate = None
-    if not args.skip_masked and not args.dense_only:
+    if not args.skip_masked and not args.dense_only and not args.serial:
         del core
         torch.cuda.empty_cache()
-        core2 = GaitCore([2, 1, 1], nclasses=NCLS, fuse_mode="sign_max", margin=0.2, loss_weights=(1.0, 0.1), device=dev,
-                         seed=232323, lr=1e-4, world_size=world, skip_masked=True, dp_mode=args.dp_mode, conv_precision=args.dtype)
-        for _ in range(args.warmup):
-            core2.train_step(dxs, uses, labels, doh)
-        sync_all()
-        t1 = time.perf_counter()
-        for _ in range(args.steps):
-            core2.train_step(dxs, uses, labels, doh)
-        sync_all()
-        dt2 = time.perf_counter() - t1
-        if world > 1:
-            t = torch.tensor([dt2], device=dev, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt2 = float(t.item())
-        skip_rate = world * B_PER_GPU * args.steps / dt2
+        core2 = make_core(True)
+        dt2 = timed(core2, (dxs, uses, labels, doh))
+        skip_rate = world * b_gpu * args.steps / dt2
 
     if rank == 0:
-        clips = world * B_PER_GPU * args.steps
-        value = clips / dt
-        # roofline of the dominant kernel: the 3x3 32->32 conv at 64x64 (layer a2), forward launch
-        name, flops = ops.ROOFLINE_OP, ops.ROOFLINE_FLOPS_PER_FRAME
-        evs = ops.TIMING.get(name, [])
-        roof = None
-        if evs:
-            ms = [a.elapsed_time(b) for a, b in evs]
-            avg_s = float(np.mean(ms)) * 1e-3
-            frames = B_PER_GPU * L
-            achieved = flops * frames / avg_s / 1e12
-            traffic = None
-            tfile = os.path.join(ROOT, "profiles", "roofline_traffic.json")
-            if os.path.exists(tfile):
-                traffic = json.load(open(tfile)).get("hbm_bytes_per_launch")
-            peak = PEAK_F32_MFMA if args.dtype == "f32" else PEAK_BF16_MFMA
-            roof = dict(bound="mfma", achieved=round(achieved, 2), peak=round(peak / 1e12, 1), unit="TFLOP/s",
-                        frac=round(achieved * 1e12 / peak, 4), traffic=traffic if args.dtype == "f32" else None, kernel=name,
-                        launches=len(evs), avg_us=round(avg_s * 1e6, 1),
-                        note="achieved = direct-convolution (algorithmic) FLOPs / time; the kernel is Winograd F(2x2,3x3) and "
-                             "executes 1/2.25 of them on the fp32 MFMA, so frac can exceed 1")
-            others = []
-            for oname, oflops in ops.EXTRA_TIMED.items():
-                oev = ops.TIMING.get(oname, [])
-                if oev:
-                    oavg = float(np.mean([a.elapsed_time(b) for a, b in oev])) * 1e-3
-                    otf = oflops * (frames + B_PER_GPU) / oavg / 1e12   # launched together with its set-level twin (B more images)
-                    others.append(dict(kernel=oname, achieved=round(otf, 2), frac=round(otf * 1e12 / peak, 4),
-                                       avg_us=round(oavg * 1e6, 1), launches=len(oev)))
-            roof["other_kernels"] = others
+        value = world * b_gpu * args.steps / dt
+        dist_info = None
+        if use_dist:
+            dist_info = dict(backend=dist.get_backend(), world_size=dist.get_world_size(),
+                             allreduce="bucketed, overlapped with backward" if engine.AR_OVERLAP else "one call after backward")
         out = dict(metric="clips/sec (3-mod, L=25, 60x60) fwd+bwd+Adam", value=round(value, 2), unit="clips/s",
                    n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(dt / args.steps * 1e3, 3),
-                   higher_is_better=True, scaling="weak", vs_baseline=None,
-                   dtype="f32" if args.dtype == "f32" else "bf16 MFMA operands in the 3x3 fwd/dgrad (f32 tensors, accumulate, wgrad)",
+                   higher_is_better=True, scaling=args.scaling, vs_baseline=None,
+                   dtype="f32" if args.dtype == "f32" else "bf16 MFMA operands in the 3x3 fwd/dgrad/wgrad (f32 accumulate)",
                    data="synthetic",
-                   config=dict(workload=wl["text"] % (B_PER_GPU, n_ids, wl["ids_per"]),
-                               clips_per_gpu=B_PER_GPU, parallelism="dp%d" % world, dp_mode=args.dp_mode, masked_pairs_skipped=bool(args.skip_masked)),
+                   config=dict(workload=wl["text"] % (b_gpu, n_ids, max(1, b_gpu // n_ids) if args.scaling == "weak" else wl["ids_per"]),
+                               clips_per_gpu=b_gpu, global_batch=world * b_gpu, parallelism="dp%d" % world, dp_mode=dp_mode,
+                               masked_pairs_skipped=bool(args.skip_masked), distributed=dist_info,
+                               launch_schedule="serial (one stream)" if args.serial else
+                               "fwd chains on %d side streams, wgrad beside dgrad" % engine.FWD_STREAMS),
                    whole_step_tflops=round(value * FLOP_PER_CLIP / 1e12, 2),
-                   whole_step_frac_of_f32_mfma_peak=round(value * FLOP_PER_CLIP / world / PEAK_F32_MFMA, 4),   # (always the f32 peak)
+                   whole_step_frac_of_f32_mfma_peak=round(value * FLOP_PER_CLIP * (16.0 / 36.0) / world / PEAK_F32_MFMA, 4),
                    loss=round(losses["loss"], 5), roofline=roof)
+        out["whole_step_note"] = ("whole_step_tflops prices the step with SURVEY 8(d)'s 71.3 algorithmic GFLOP per 3-modality "
+                                  "clip; the fraction beside it counts 16/36 of them (what Winograd executes) against the f32 peak")
         if skip_rate is not None:
-            out["value_skip_masked"] = round(skip_rate, 2)   # 29 of the 72 (clip, modality) pairs of this batch are masked
+            out["value_skip_masked"] = round(skip_rate, 2)   # 29 of the 72 (clip, modality) pairs of the C3 batch are masked
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline()
+            big = b_gpu > 40      # (the generator-expanded batches: time the workload's own batch on the CPU)
+            out["cpu_baseline"] = cpu_baseline(kinds, ncls, wl["clips"] if big else b_gpu, wl["clips"] // wl["ids_per"] if big else n_ids)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
+
+
+def main():
+    argv = sys.argv[1:]
+    args = build_parser().parse_args(argv)
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        launch_ranks(args, argv)     # children only; this process never touches the GPU
+        return
+    run(args)
 
 
 if __name__ == "__main__":

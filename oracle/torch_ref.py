@@ -83,7 +83,8 @@ def batch_dist(x):
     return d * (~err).to(x.dtype)
 
 
-def triplet(labels, emb, margin):
+def triplet(labels, emb, margin, return_counts=False):
+    """return_counts: also the per-bin number of active (> 0) hinges, the `num` of nets/triplet_loss_all.py:54-55."""
     n, m, _ = emb.shape
     lab = labels.reshape(1, m).repeat(n, 1)
     hp = (lab[:, None, :] == lab[:, :, None]).reshape(-1)
@@ -95,6 +96,8 @@ def triplet(labels, emb, margin):
     s = h.sum(dim=1)
     num = (h > 0).to(torch.float32).sum(dim=1)
     mean = torch.where(num != 0, s / num.to(s.dtype).clamp_min(1.0), torch.zeros_like(s))
+    if return_counts:
+        return mean.mean(), num.detach()
     return mean.mean()
 
 
@@ -130,7 +133,7 @@ def loss_and_grads(xs, uses, labels, onehot, params, margin=0.2, loss_weights=(1
         t.requires_grad_(True)
         t.grad = None
     res = forward(xs, uses, params, mode, multimodal)
-    tri = triplet(labels, res['signature'], margin)
+    tri, res['tri_counts'] = triplet(labels, res['signature'], margin, return_counts=True)
     total = loss_weights[0] * tri
     res['triplet'] = tri.detach()
     if 'head' in params:

@@ -1,0 +1,76 @@
+"""bench.py's own multi-rank launch (no external torchrun): `--gpus N` must start N ranks or fail loudly, never report a
+one-rank number as an N-GPU one."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _env(**kw):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(kw)
+    return env
+
+
+@pytest.mark.skipif(torch.cuda.device_count() >= 2, reason="needs a box with fewer than 2 GPUs")
+def test_more_ranks_than_gpus_is_an_error_not_a_one_rank_run():
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "1", "--warmup", "0"], env=_env(), capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode != 0
+    assert "GPU" in r.stderr and "--gpus 2" in r.stderr
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_world_size_must_match_gpus():
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=_env(WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"), capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_bench_spawns_its_own_ranks(dev):
+    """`python bench.py --gpus 2` alone (gloo rehearsal: both ranks share the box's GPU) prints ONE line with n_gpus 2."""
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--dense-only",
+                        "--clips-per-gpu", "4", "--no-roofline-pass"], env=_env(UGN_DIST_BACKEND="gloo"), capture_output=True,
+                       text=True, timeout=800)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "dp2" and d["config"]["distributed"]["world_size"] == 2
+    assert d["config"]["distributed"]["backend"] == "gloo" and d["value"] > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_strong_scaling_splits_the_c4_batch(dev):
+    """--workload c4 --scaling strong with 2 ranks: 20 clips per rank, losses on the gathered 40-clip batch."""
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--workload", "c4", "--scaling", "strong", "--steps", "1", "--warmup",
+                        "1", "--no-cpu-baseline", "--dense-only", "--no-roofline-pass"], env=_env(UGN_DIST_BACKEND="gloo"),
+                       capture_output=True, text=True, timeout=800)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert d["scaling"] == "strong" and d["config"]["clips_per_gpu"] == 20 and d["config"]["global_batch"] == 40
+    assert d["config"]["dp_mode"] == "global"
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_rccl_path_with_one_rank(dev):
+    """The RCCL calls of the data-parallel path (process group with device_id, the flat-buffer all-reduce, the bucketed
+    all-reduce on the side stream) executed for real -- one rank, because a test box has one GPU."""
+    for overlap in ("0", "1"):
+        r = subprocess.run([sys.executable, BENCH, "--gpus", "1", "--force-dist", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+                            "--dense-only", "--clips-per-gpu", "4", "--no-roofline-pass"], env=_env(UGN_AR_OVERLAP=overlap),
+                           capture_output=True, text=True, timeout=800)
+        assert r.returncode == 0, r.stderr[-3000:]
+        d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+        assert d["config"]["distributed"]["backend"] == "nccl" and d["config"]["distributed"]["world_size"] == 1
+        assert d["value"] > 0 and d["loss"] == d["loss"]

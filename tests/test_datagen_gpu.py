@@ -92,6 +92,14 @@ def test_reference_constructor_surface(dev, tmp_path):
     _write_sample(os.path.join(dirs[0], "empty.h5"), np.zeros((0,), np.int16), 5, 1)      # a recording without detections
     all_samples.append((("empty.h5", -1, -1), 5))
     gaits.append(1)
+    # ... and the same as deepdish stores it: the SHAPE as an int64 array + the node attribute `zeroarray_dtype`
+    w = h5lite.Writer()
+    w.create_dataset("data", np.array([0], np.int64))
+    w.set_attr("data", "zeroarray_dtype", np.bytes_(b"<i2"))
+    w.set_attr("", "label", np.uint16(5))
+    w.save(os.path.join(dirs[0], "empty_dd.h5"))
+    all_samples.append((("empty_dd.h5", -1, -1), 5))
+    gaits.append(1)
     kw = dict(batch_size=4, dim=[(50, 60, 60), (25, 60, 60), (25, 60, 60)], n_classes=2, datadir=dirs, labmap={5: 0, 9: 1},
               gait=gaits, ntype=2, augmentation_x=0, expand_level=3, nmods=3, gaitset=True, repetition=1, shuffle=False)
     gen = DataGeneratorGaitMMUWYH(all_samples, **kw)
@@ -102,8 +110,15 @@ def test_reference_constructor_surface(dev, tmp_path):
     sil = X[4][0].cpu().numpy()
     assert set(np.unique(sil)) <= {0.0, 1.0}                           # "silhouette" in the directory name: data / 255, no offset
     assert abs(float(X[0][0].abs().max().cpu()) - 3.0) < 0.01          # int16 / compressFactor 100 * 0.1
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(NotImplementedError, match="augmentation_x"):
         DataGeneratorGaitMMUWYH(all_samples, **dict(kw, augmentation_x=1))
+    with pytest.raises(NotImplementedError, match="augmentation_x"):    # the reference's default, as its gaitset main leaves it
+        DataGeneratorGaitMMUWYH(all_samples, **{k: v for k, v in kw.items() if k != "augmentation_x"})
+    # `dim` as the CASIA-B gaitset main passes it (mains/mj_trainUWYHGaitNet_DataGen_CasiaB.py:213,465): the input shapes
+    casia = DataGeneratorGaitMMUWYH(all_samples, **dict(kw, nmods=2, dim=[(25, 60, 60, 2), (25, 60, 60, 1)], datadir=dirs[:2]))
+    assert [(sp.kind, sp.channels) for sp in casia.specs] == [("of", 2), ("gray", 1)]
+    Xc, _ = casia[0]
+    assert [tuple(t.shape) for t in Xc] == [(12, 25, 60, 60, 2), (12, 1), (12, 25, 60, 60, 1), (12, 1)]
     two = DataGeneratorGaitMMUWYH(all_samples, **dict(kw, nmods=2, dim=kw["dim"][:2], datadir=dirs[:2]))   # __gen_batch rules
     X2, y2 = two[0]
     assert [tuple(t.shape) for t in X2] == [(12, 25, 60, 60, 2), (12, 1), (12, 25, 60, 60, 1), (12, 1)]

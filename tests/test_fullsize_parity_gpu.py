@@ -1,0 +1,74 @@
+"""BASELINE.json's full sizes against the oracle itself: one whole training step (forward, both losses, every parameter
+gradient) of C3 (of + gray + depth, 24 clips = 12 ids x 2, 150 classes) and C4 (of + gray + silhouette, 40 clips = 4 ids x 10,
+74 classes) on the default HIP path, compared with oracle/torch_ref.py evaluated in fp64 on the host's cores (the independent
+torch-autograd statement that pins the numpy oracle, tests/test_oracle_crosscheck.py; the numpy oracle itself needs minutes at
+these sizes).
+
+Bars: loss <= 1e-4, signature <= 1e-3 (north_star's tolerance; observed ~1e-5), active-triplet counts equal up to hinges that
+sit within fp32 rounding of zero (C3: exact; C4 has 744k hinges per step: at most 1 per bin, 3 in all), every parameter
+gradient <= 5e-3 relative L2 (an fp32-vs-fp64 near-tie can flip a MaxPool / set-max / HPP / sign_max routing decision)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import torch_ref as T
+from oracle import ugaitnet_oracle as O
+from tests.synth import make_batch
+
+pytestmark = pytest.mark.gpu
+
+CASES = {
+    "C3": dict(kinds=("of", "gray", "depth"), b=24, ids=12, ncls=150),
+    "C4": dict(kinds=("of", "gray", "sil"), b=40, ids=4, ncls=74),
+}
+
+
+def _rell2(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))
+
+
+@pytest.mark.timeout(1500)
+@pytest.mark.parametrize("name", ["C3", "C4"])
+def test_whole_step_matches_the_fp64_oracle(dev, name):
+    from ugaitnet_amd.engine import GaitCore
+    c = CASES[name]
+    kinds, b, ncls = c["kinds"], c["b"], c["ncls"]
+    xs, uses, labels, onehot = make_batch(kinds, b, 25, ncls, ids=c["ids"], seed=232323)
+    rng = np.random.default_rng(11)
+    p64 = dict(branches=[O.init_branch_params(rng, 2 if k == "of" else 1, np.float64) for k in kinds],
+               head=O.init_head_params(rng, ncls, np.float64))
+    p64["head"]["bc"] = rng.normal(size=ncls) * 0.01
+    core = GaitCore([2, 1, 1], nclasses=ncls, fuse_mode="sign_max", margin=0.2, loss_weights=(1.0, 0.1), device=dev)
+    core.set_params_numpy(O.cast_params(p64, np.float32))
+    core.forward_backward(xs, uses, labels, onehot)
+    torch.cuda.synchronize()
+    got = core.get_grads_numpy()
+    sig = core.sig.cpu().numpy()
+    ls = core.losses()
+    counts = core.bin_num.cpu().numpy()
+
+    torch.set_num_threads(max(1, torch.get_num_threads()))
+    tp = T.params_from_numpy(p64, dtype=torch.float64)
+    res, g = T.loss_and_grads([torch.from_numpy(x.astype(np.float64)) for x in xs],
+                              [torch.from_numpy(u.astype(np.float64)) for u in uses], torch.from_numpy(labels),
+                              torch.from_numpy(onehot.astype(np.float64)), tp, margin=0.2, loss_weights=(1.0, 0.1))
+    assert abs(ls["loss"] - float(res["loss"])) <= 1e-4, (ls, float(res["loss"]))
+    assert abs(ls["triplet"] - float(res["triplet"])) <= 1e-4 and abs(ls["xent"] - float(res["xent"])) <= 1e-4
+    assert np.abs(sig - res["signature"].detach().numpy()).max() <= 1e-3
+    dcount = np.abs(counts.astype(np.int64) - res["tri_counts"].numpy().astype(np.int64))
+    if name == "C3":
+        assert dcount.max() == 0, dcount
+    else:
+        assert dcount.max() <= 1 and dcount.sum() <= 3, dcount
+    worst = {}
+    for mi in range(3):
+        for k, ref in g["branches"][mi].items():
+            worst["m%d.%s" % (mi, k)] = _rell2(got["branches"][mi][k], ref.numpy())
+    for k, ref in g["head"].items():
+        worst["head." + k] = _rell2(got["head"][k], ref.numpy())
+    bad = {k: v for k, v in worst.items() if v > 5e-3}
+    assert not bad, (bad, worst)
+    print("%s: loss %.6f (oracle %.6f), max |sig - oracle| %.2e, worst gradient rel-L2 %.2e (%s)"
+          % (name, ls["loss"], float(res["loss"]), np.abs(sig - res["signature"].detach().numpy()).max(),
+             max(worst.values()), max(worst, key=worst.get)))

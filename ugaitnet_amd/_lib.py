@@ -107,8 +107,29 @@ def check(rc, what):
         raise UgnError("%s failed (code %d): %s" % (what, rc, msg))
 
 
-def call(name, *args):
-    check(getattr(load(), name)(*args), name)
+# Per-launch timing for bench.py's serialised roofline pass: while PROFILE is a dict, every C-ABI launch is bracketed by a
+# HIP-event pair on the stream it is launched on (torch's current stream) and filed under its label.  WORK holds, per
+# label, what one such launch does: dict(flops=algorithmic FLOPs, mfma_flops=FLOPs executed on the matrix pipe,
+# bytes=algorithmic HBM bytes, kernel=the device kernel rocprofv3 shows for it).  None (the default) = no events at all.
+PROFILE = None
+WORK = {}
+
+
+def call(name, *args, label=None, work=None):
+    fn = getattr(load(), name)
+    if PROFILE is None:
+        check(fn(*args), name)
+        return
+    import torch
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    rc = fn(*args)
+    e1.record()
+    key = label or name
+    PROFILE.setdefault(key, []).append((e0, e1))
+    if work is not None:
+        WORK[key] = work
+    check(rc, name)
 
 
 def ptr(t):

@@ -26,6 +26,12 @@ class DataGeneratorGaitMMUWYH(DeviceDataGenerator):
         if nmods == 1:      # `dim` is one (frames, 60, 60) tuple there (:66-69), the file is allSamples[i][0][0] under datadir[0]
             dim = [tuple(dim)] if not isinstance(dim[0], (tuple, list)) else [tuple(dim[0])]
             datadir = list(datadir[:1])
+        if augmentation_x > 0:
+            # the reference's default is augmentation_x=1 and its gaitset mains leave it there (mains/mj_trainUWYHGaitNet_
+            # DataGen_CasiaB.py:465): name the argument, the random affine augmentation (:706-728) is not built on this path
+            raise NotImplementedError("DataGeneratorGaitMMUWYH on the MI355X path: augmentation_x=%r (random affine / mirror "
+                                      "augmentation, the reference's default) is not implemented; pass augmentation_x=0"
+                                      % (augmentation_x,))
         unsupported = [name for name, bad in (("nmods > 3", nmods not in (1, 2, 3)), ("gaitset=False", not gaitset), ("use3D", use3D),
                                               ("isDebug", isDebug), ("softlabel", softlabel), ("use_weights", use_weights),
                                               ("aux_losses", aux_losses), ("triplet_all_fc", triplet_all_fc),
@@ -36,7 +42,16 @@ class DataGeneratorGaitMMUWYH(DeviceDataGenerator):
             raise ValueError("one datadir and one dim per modality")
         specs = []
         for m in range(nmods):
-            frames = dim[m][0]
+            # two spellings of `dim` reach this class: the legacy (frames, 60, 60) with 50 = 25 frames x (x, y) flow, and the
+            # gaitset input shape the CASIA-B main passes, (25, 60, 60, channels) with channels = 2 for optical flow
+            # (mains/mj_trainUWYHGaitNet_DataGen_CasiaB.py:213,465: input_shape = [(25, 60, 60, 2), (25, 60, 60, 1)])
+            d = tuple(dim[m])
+            if len(d) == 4:
+                if d[0] != 25 or d[3] not in (1, 2):
+                    raise ValueError("dim[%d] must be (25, 60, 60, 1 | 2), got %r" % (m, d))
+                frames = 50 if d[3] == 2 else 25
+            else:
+                frames = d[0]
             if frames not in (25, 50):
                 raise ValueError("dim[%d][0] must be 25 or 50 frames, got %r" % (m, frames))
             if frames == 50:      # x/y optical flow interleaved; compressFactor travels in the sample files (:300-309)

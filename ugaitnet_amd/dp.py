@@ -57,27 +57,28 @@ def shard_batch(X, y, rank, world):
     return Xs, ys
 
 
-def allreduce_sum_(flat, group=None):
+def allreduce_sum_(flat, group=None, force=False):
     """In-place SUM all-reduce of the flat gradient buffer; returns the factor that turns the sum into the
-    replica mean (applied inside ugn_adam_step)."""
+    replica mean (applied inside ugn_adam_step).  `force`: issue the collective even in a one-rank group (rehearsal of the
+    RCCL path on a one-GPU box)."""
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()):
         return 1.0
     world = dist.get_world_size(group)
-    if world == 1:
+    if world == 1 and not force:
         return 1.0
     dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
     return 1.0 / world
 
 
-def gather_batch_axis(t, axis, group=None, check=True):
+def gather_batch_axis(t, axis, group=None, check=True, force=False):
     """All-gather `t` over the replicas and concatenate along `axis` in rank order.  Every replica must hold the same
     shape (equal slices of the global batch); with check=True a mismatch is an error on every rank, not a hang (the
     comparison synchronises with the host: the engine checks on the label exchange, before the step's kernels are queued,
     and gathers the features of the same step unchecked)."""
     import torch
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size(group) == 1 and not force):
         return t
     world = dist.get_world_size(group)
     if check:
@@ -96,11 +97,11 @@ def group_rank(group=None):
     return dist.get_rank(group) if dist.is_available() and dist.is_initialized() else 0
 
 
-def allreduce_sum_async(t, group=None):
+def allreduce_sum_async(t, group=None, force=False):
     """SUM all-reduce of `t` (a slice of the flat gradient buffer) issued behind the CURRENT stream's work and left running
     on the communication stream; returns the work handle (`.wait()` orders the caller's stream after it) or None for a single
     process."""
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size(group) == 1 and not force):
         return None
     return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group, async_op=True)

@@ -18,7 +18,7 @@ import torch
 import contextlib
 import os
 
-from . import dp, ops
+from . import _lib, dp, ops
 
 F32 = torch.float32
 
@@ -48,10 +48,10 @@ WGRAD_STREAM = os.environ.get("UGN_WSTREAM", "1") != "0"
 # fusion gradient, on streams of their own (each with its weight-gradient stream).  Measured slower (9.51 vs 9.40 ms): six
 # LDS-filling kernels contending for the CUs thrash more than they fill.  The forward stays on one stream: bench.py times it.
 BRANCH_STREAMS = WGRAD_STREAM and os.environ.get("UGN_BSTREAMS", "0") == "1"
-# UGN_FSTREAMS=1|2: also run the forward chains of modalities 1.. on that many side streams.  Worth 1.6 % / 2.7 % of the
-# step (9.29 / 9.19 ms against 9.44), but off by default: event pairs around a forward launch then time the contention with
-# the other chains, not the kernel, and bench.py's roofline figure is taken from exactly those pairs.
-FWD_STREAMS = int(os.environ.get("UGN_FSTREAMS", "0"))
+# UGN_FSTREAMS=1|2: the forward chains of modalities 1.. run on that many side streams (default 2; 0 = one stream).  Worth
+# 1.6 % / 2.7 % of the step (9.29 / 9.19 ms against 9.44).  Per-kernel durations are then no longer clean -- bench.py takes
+# its roofline figures from a separate, fully serialised pass after the timed region (`serial_launches()`).
+FWD_STREAMS = int(os.environ.get("UGN_FSTREAMS", "2"))
 _WSTREAM = {}
 _BSTREAM = {}
 
@@ -70,6 +70,19 @@ def _branch_stream(device, mi):
     if st is None:
         st = _BSTREAM[(device, mi)] = torch.cuda.Stream(device=device)
     return st
+
+
+@contextlib.contextmanager
+def serial_launches():
+    """Every launch on ONE stream (no weight-gradient / branch / forward side streams) while the context is active: the
+    per-kernel durations bench.py's roofline pass and the rocprofv3 kernel-trace summaries quote.  Results are unchanged."""
+    global WGRAD_STREAM, BRANCH_STREAMS, FWD_STREAMS
+    saved = (WGRAD_STREAM, BRANCH_STREAMS, FWD_STREAMS)
+    WGRAD_STREAM, BRANCH_STREAMS, FWD_STREAMS = False, False, 0
+    try:
+        yield
+    finally:
+        WGRAD_STREAM, BRANCH_STREAMS, FWD_STREAMS = saved
 
 
 class _side:
@@ -366,7 +379,8 @@ class GaitCore:
 
     def __init__(self, in_channels, nclasses=0, multimodal=None, fuse_mode="sign_max", margin=0.2,
                  loss_weights=(1.0, 1.0), device=None, seed=None, lr=1e-4, beta_1=0.9, beta_2=0.999, epsilon=1e-7,
-                 process_group=None, world_size=1, skip_masked=False, dp_mode="replica", conv_precision="f32"):
+                 process_group=None, world_size=1, skip_masked=False, dp_mode="replica", conv_precision="f32",
+                 force_collectives=False):
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         self.in_channels = tuple(int(c) for c in in_channels)
         self.nmod = len(self.in_channels)
@@ -381,13 +395,16 @@ class GaitCore:
         self.lr, self.beta_1, self.beta_2, self.epsilon = float(lr), float(beta_1), float(beta_2), float(epsilon)
         self.iterations = 0
         self.pg, self.world = process_group, int(world_size)
+        # force_collectives: issue the data-parallel collectives even with one rank (a one-GPU rehearsal of the RCCL calls)
+        self.force = bool(force_collectives)
+        self.dp_active = self.world > 1 or self.force
         # dp_mode "replica": the reference's MirroredStrategy semantics (normalisation + losses per replica slice, gradients
         # averaged).  "global": the fused features of all replicas are all-gathered, normalisation + losses see the whole
         # batch, gradients are summed -- G replicas x B/G clips then equal one device on B clips (ugaitnet_amd/dp.py).
         if dp_mode not in ("replica", "global"):
             raise ValueError("dp_mode must be 'replica' or 'global', got %r" % (dp_mode,))
         self.dp_mode = dp_mode
-        self.global_batch = dp_mode == "global" and self.world > 1
+        self.global_batch = dp_mode == "global" and self.dp_active
         # skip_masked: run each encoder only on the clips whose modality flag is 1.  A masked (clip, modality) pair is
         # multiplied by 0 in the gate (nets/mj_uwyhNets_ba.py:51-54), so its branch output contributes exactly 0 forward
         # and receives exactly 0 gradient: skipping it changes no result, only the work done.
@@ -519,22 +536,22 @@ class GaitCore:
         self.row0 = dp.group_rank(self.pg) * b if gather else 0      # first row of this replica in the gathered batch
         if not self.multimodal:
             # single-modality graph: no gate, no normalisation (:893-903)
-            self.sig = dp.gather_batch_axis(outs[0], 1, self.pg, check=False) if gather else outs[0]
+            self.sig = dp.gather_batch_axis(outs[0], 1, self.pg, check=False, force=self.force) if gather else outs[0]
             return self.sig
         self.uses = [self._dev(u, (b,)) for u in uses]
         self.fused, self.sel = ops.gate_fuse_fwd(outs, self.uses, self.fuse_mode, self._buf("fused", (NBINS, b, HIDDEN)),
                                                  self._buf("sel", (NBINS, b, HIDDEN), torch.uint8))
         if gather:
-            self.fused = dp.gather_batch_axis(self.fused, 1, self.pg, check=False)   # (b checked with the labels)
+            self.fused = dp.gather_batch_axis(self.fused, 1, self.pg, check=False, force=self.force)   # (b checked with the labels)
         self.sig = ops.l2norm_batch_fwd(self.fused, self._buf("sig", (NBINS, self.fused.shape[1], HIDDEN)))
         return self.sig
 
     def _gather_targets(self, labels, onehot):
         """Global-batch mode: labels / one-hot rows of all replicas, rank-major like the gathered features."""
         lab = torch.from_numpy(np.ascontiguousarray(np.asarray(labels).reshape(-1).astype(np.int64))).to(self.device)
-        labels = dp.gather_batch_axis(lab, 0, self.pg).cpu().numpy()
+        labels = dp.gather_batch_axis(lab, 0, self.pg, force=self.force).cpu().numpy()
         if onehot is not None:
-            onehot = dp.gather_batch_axis(self._dev(onehot, (lab.shape[0], -1)), 0, self.pg)
+            onehot = dp.gather_batch_axis(self._dev(onehot, (lab.shape[0], -1)), 0, self.pg, force=self.force)
         return labels, onehot
 
     def predict(self, xs, uses=None):
@@ -563,7 +580,7 @@ class GaitCore:
             labels, onehot = self._gather_targets(labels, onehot)
         sig = self.forward(xs, uses, gather=self.global_batch)
         b = sig.shape[1]
-        self._ar_pending = [] if (self.world > 1 and AR_OVERLAP and not BRANCH_STREAMS) else None
+        self._ar_pending = [] if (self.dp_active and AR_OVERLAP and not BRANCH_STREAMS) else None
         hp, hn, kp, kn = self._triplet_lists(labels)
         w_tri, w_id = self.loss_weights
         self.bin_loss, self.bin_num, dsig = ops.triplet_fwd_bwd(
@@ -629,13 +646,13 @@ class GaitCore:
             return
         lo, hi = self._buckets[k]
         with _side(self.device):    # the weight-gradient stream, ordered after the main stream's work up to here
-            w = dp.allreduce_sum_async(self.store.grad[lo:hi], self.pg)
+            w = dp.allreduce_sum_async(self.store.grad[lo:hi], self.pg, force=self.force)
         if w is not None:
             self._ar_pending.append(w)
 
     def finish_gradient_allreduce(self):
         """Complete the step's gradient reduction; returns the factor Adam applies to the summed gradient."""
-        if self.world <= 1:
+        if not self.dp_active:
             return 1.0
         if self._ar_pending is not None:
             for w in self._ar_pending:
@@ -643,7 +660,7 @@ class GaitCore:
             self._ar_pending = None
             scale = 1.0 / self.world
         else:
-            scale = dp.allreduce_sum_(self.store.grad, self.pg)
+            scale = dp.allreduce_sum_(self.store.grad, self.pg, force=self.force)
         # global mode: the loss already is the whole batch's, the replicas' gradients add up to its gradient
         return 1.0 if self.global_batch else scale
 
@@ -687,9 +704,12 @@ class GraphedTrainStep:
     `step()` copies the new batch into the captured buffers and replays; a batch of another geometry raises ValueError."""
 
     def __init__(self, core, xs, uses, labels, onehot):
-        if core.skip_masked or core.global_batch or BRANCH_STREAMS or FWD_STREAMS:
-            raise ValueError("graph capture needs the dense single-chain step with per-replica losses")
-        if ops.TIMING_ENABLED:
+        if core.skip_masked or core.global_batch or BRANCH_STREAMS:
+            raise ValueError("graph capture needs the dense step with per-replica losses")
+        if AR_OVERLAP and core.world > 1:
+            # the bucket all-reduces would be issued inside the capture and a second reduction would follow in step()
+            raise ValueError("graph capture and UGN_AR_OVERLAP=1 exclude each other under data parallelism")
+        if _lib.PROFILE is not None:
             raise ValueError("per-kernel event timing cannot be captured")
         self.core = core
         dev = core.device
@@ -702,15 +722,20 @@ class GraphedTrainStep:
         cur = torch.cuda.current_stream(dev)
         warm = torch.cuda.Stream(device=dev)
         warm.wait_stream(cur)
-        with torch.cuda.stream(warm):   # allocations, function attributes, triplet lists: all outside the capture
-            for _ in range(2):
+        global FWD_STREAMS
+        fwd_streams, FWD_STREAMS = FWD_STREAMS, 0     # the captured forward pass is one chain (the backward keeps its two streams)
+        try:
+            with torch.cuda.stream(warm):   # allocations, function attributes, triplet lists: all outside the capture
+                for _ in range(2):
+                    core.forward_backward(self.xs, self.uses, self.labels, self.onehot)
+                    core.finish_gradient_allreduce()
+            cur.wait_stream(warm)
+            torch.cuda.synchronize(dev)
+            self.g_fb = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.g_fb):
                 core.forward_backward(self.xs, self.uses, self.labels, self.onehot)
-                core.finish_gradient_allreduce()
-        cur.wait_stream(warm)
-        torch.cuda.synchronize(dev)
-        self.g_fb = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.g_fb):
-            core.forward_backward(self.xs, self.uses, self.labels, self.onehot)
+        finally:
+            FWD_STREAMS = fwd_streams
         core._ar_pending = None     # (bucket all-reduces are not captured: the reduction runs between the two graphs)
         scale = (1.0 / core.world) if core.world > 1 else 1.0
         self.g_up = torch.cuda.CUDAGraph()

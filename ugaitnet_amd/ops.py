@@ -43,35 +43,33 @@ class Workspace:
 
 _WS = Workspace()
 
-# bench.py's roofline leg: HIP-event pairs recorded around the launches of ONE named kernel, on the stream the kernel
-# is launched on (torch's current stream).  Disabled outside the timed region of the benchmark.
-TIMING_ENABLED = False
-TIMING = {}
-ROOFLINE_OP = "conv3x3_fwd[a2: 32->32 @64x64 +LeakyReLU +MaxPool]"
-ROOFLINE_FLOPS_PER_FRAME = 2.0 * 9 * 32 * 32 * 64 * 64   # algorithmic FLOPs of that layer per frame (a.c2)
-# further kernels timed the same way (reported beside the roofline object): name -> algorithmic FLOPs per frame
-# (forward kernels only: the backward overlaps weight gradients with data gradients on two streams, so an event pair
-# around one of its launches no longer measures that kernel alone)
-EXTRA_TIMED = {
-    "conv3x3_fwd[a4: 64->64 @32x32 +LeakyReLU +MaxPool]": 2.0 * 9 * 64 * 64 * 32 * 32,
-    "conv3x3_fwd[a6: 128->128 @16x16 +LeakyReLU]": 2.0 * 9 * 128 * 128 * 16 * 16,
-}
+# bench.py's serialised roofline pass (ugaitnet_amd._lib.PROFILE): every launch is filed under a label that names the device
+# kernel it runs -- one label per template instantiation, so that the totals line up with rocprofv3's kernel-trace stats --
+# together with what one launch does: algorithmic FLOPs (direct-convolution count), the FLOPs the matrix pipe
+# executes (Winograd F(2x2,3x3): 16 multiplies per 2x2 outputs instead of 36 -> 16/36 of the algorithmic count) and, for the
+# HBM-bound kernels, the algorithmic bytes.
+def _conv_work(kind, hw, cin, cout, pooled, ns, bf16=False, wino=True, flags=0):
+    n = int(sum(ns))
+    flops = 2.0 * 9 * cin * cout * hw * hw * n
+    bf = ", true" if bf16 else ""
+    if kind == "fwd":
+        epi = 1 if pooled else 0
+        kern = ("wino_tall_kernel<%d, %d, 0, %d, 0%s>" % (cin, hw, epi, bf) if cout == 32
+                else "wino_kernel<%d, %d, %d, 0, %d, 0%s>" % (cin, cout, hw, epi, bf))
+    elif kind == "dgrad":
+        kern = ("wino_tall_kernel<%d, %d, %d, 2, %d%s>" % (cout, hw, int(pooled), flags, bf) if cin == 32
+                else "wino_kernel<%d, %d, %d, %d, 2, %d%s>" % (cout, cin, hw, int(pooled), flags, bf))
+    else:
+        kern = "wgrad_wino_kernel<%d, %d, %d, %d, %d%s>" % (cin, cout, hw, 64 if cout >= 64 else 32, int(pooled), bf)
+    if not wino:
+        kern = "conv3x3_kernel / wgrad3x3_kernel (direct)"
+    label = "conv3x3_%s[%d->%d @%dx%d%s%s] %s" % (kind, cin, cout, hw, hw, " pooled" if pooled else "", " bf16" if bf16 else "", kern)
+    return label, dict(flops=flops, mfma_flops=flops * (16.0 / 36.0 if wino else 1.0), bytes=None, kernel=kern, bound="mfma",
+                       images=n, dtype="bf16" if bf16 else "f32")
 
 
-class _Timed:
-    def __init__(self, name, active):
-        self.name, self.active = name, active and TIMING_ENABLED
-
-    def __enter__(self):
-        if self.active:
-            self.e0 = torch.cuda.Event(enable_timing=True)
-            self.e1 = torch.cuda.Event(enable_timing=True)
-            self.e0.record()
-
-    def __exit__(self, *exc):
-        if self.active:
-            self.e1.record()
-            TIMING.setdefault(self.name, []).append((self.e0, self.e1))
+def _hbm_work(kernel, nbytes):
+    return dict(flops=None, mfma_flops=None, bytes=float(nbytes), kernel=kernel, bound="hbm")
 
 
 def conv5x5_in_fwd(x, w, out=None, sign=None):
@@ -81,7 +79,9 @@ def conv5x5_in_fwd(x, w, out=None, sign=None):
     out = torch.empty((n, 64, 64, 32), dtype=F32, device=x.device) if out is None else out
     if sign is not None:
         _chk(sign, torch.int32)
-    call("ugn_conv5x5_in_fwd", ptr(x), ptr(w), ptr(out), ptr(sign), n, cin, _stream())
+    call("ugn_conv5x5_in_fwd", ptr(x), ptr(w), ptr(out), ptr(sign), n, cin, _stream(), label="conv5x5_fwd[cin=%d]" % cin,
+         work=_hbm_work("conv5x5_fwd_kernel<%d, %s>" % (cin, "true" if sign is not None else "false"),
+                        n * (3600.0 * cin * 4 + 4096 * 32 * 4 + (4096 * 4 if sign is not None else 0))))
     return out
 
 
@@ -94,7 +94,10 @@ def conv5x5_in_wgrad(x, dz1, dw=None, sign=None):
     ws = _WS.get(nbytes, x.device)
     if sign is not None:
         _chk(sign, torch.int32)
-    call("ugn_conv5x5_in_wgrad", ptr(x), ptr(dz1), ptr(sign), ptr(dw), n, cin, ptr(ws), ws.numel(), _stream())
+    call("ugn_conv5x5_in_wgrad", ptr(x), ptr(dz1), ptr(sign), ptr(dw), n, cin, ptr(ws), ws.numel(), _stream(),
+         label="conv5x5_wgrad[cin=%d]" % cin,
+         work=_hbm_work("conv5x5_wgrad_kernel<%d, %s>" % (cin, "true" if sign is not None else "false"),
+                        n * (3600.0 * cin * 4 + 4096 * 32 * 4 + (4096 * 4 if sign is not None else 0))))
     return dw
 
 
@@ -115,9 +118,9 @@ def conv3x3_fwd(x, wp, pool, out=None, idx=None):
     out = torch.empty((n, ho, ho, cout), dtype=F32, device=x.device) if out is None else out
     if pool and idx is None:
         idx = torch.empty((n, ho, ho, cout), dtype=U8, device=x.device)
-    with _Timed(ROOFLINE_OP, hw == 64 and cin == 32 and cout == 32):
-        call("ugn_conv3x3_fwd", ptr(x), ptr(wp), ptr(out), ptr(idx) if pool else None, n, hw, cin, cout,
-             int(bool(pool)), _stream())
+    label, work = _conv_work("fwd", hw, cin, cout, pool, [n], wino=False)
+    call("ugn_conv3x3_fwd", ptr(x), ptr(wp), ptr(out), ptr(idx) if pool else None, n, hw, cin, cout,
+         int(bool(pool)), _stream(), label=label, work=work)
     return (out, idx) if pool else out
 
 
@@ -126,9 +129,15 @@ def conv3x3_dgrad(dz, w, hw, dz_idx=None, act=None, addend=None, out=None, raw_o
     _chk(dz), _chk(w)
     n, cin, cout = dz.shape[0], w.shape[2], w.shape[3]
     out = torch.empty((n, hw, hw, cin), dtype=F32, device=dz.device) if out is None else out
+    label, work = _conv_work("dgrad", hw, cin, cout, dz_idx is not None, [n], wino=False)
     call("ugn_conv3x3_dgrad", ptr(dz), ptr(dz_idx), ptr(w), ptr(act), ptr(addend), ptr(out), ptr(raw_out), n, hw, cin,
-         cout, _stream())
+         cout, _stream(), label=label, work=work)
     return out
+
+
+def _epi_flags(act, addend, raw_out):
+    """The EFLAGS template argument of the data-gradient kernels (which epilogue operands are present)."""
+    return (1 if act is not None else 0) | (2 if addend is not None else 0) | (4 if raw_out is not None else 0)
 
 
 def _pack_mode(dgrad, pooled_dz, bf16=False):
@@ -167,10 +176,9 @@ def conv3x3_fwd_wino(x, upk, cout, pool, out=None, idx=None, bf16=False):
     out = torch.empty((n, ho, ho, cout), dtype=F32, device=x.device) if out is None else out
     if pool and idx is None:
         idx = torch.empty((n, ho, ho, cout), dtype=U8, device=x.device)
-    name = ROOFLINE_OP if (hw == 64 and cin == 32 and cout == 32) else "conv3x3_fwd[a6: 128->128 @16x16 +LeakyReLU]"
-    with _Timed(name, (hw == 64 and cin == 32 and cout == 32) or (hw == 16 and cin == 128 and cout == 128 and n >= 100)):
-        call("ugn_conv3x3_fwd_wino" + ("_bf16" if bf16 else ""), ptr(x), ptr(upk), ptr(out), ptr(idx) if pool else None, n, hw, cin, cout,
-             int(bool(pool)), _stream())
+    label, work = _conv_work("fwd", hw, cin, cout, pool, [n], bf16)
+    call("ugn_conv3x3_fwd_wino" + ("_bf16" if bf16 else ""), ptr(x), ptr(upk), ptr(out), ptr(idx) if pool else None, n, hw, cin, cout,
+         int(bool(pool)), _stream(), label=label, work=work)
     return (out, idx) if pool else out
 
 
@@ -178,8 +186,9 @@ def conv3x3_dgrad_wino(dz, upk, hw, cin, cout, dz_idx=None, act=None, addend=Non
     _chk(dz), _chk(upk)
     n = dz.shape[0]
     out = torch.empty((n, hw, hw, cin), dtype=F32, device=dz.device) if out is None else out
+    label, work = _conv_work("dgrad", hw, cin, cout, dz_idx is not None, [n], bf16, flags=_epi_flags(act, addend, raw_out))
     call("ugn_conv3x3_dgrad_wino" + ("_bf16" if bf16 else ""), ptr(dz), ptr(dz_idx), ptr(upk), ptr(act), ptr(addend), ptr(out), ptr(raw_out), n, hw,
-         cin, cout, _stream())
+         cin, cout, _stream(), label=label, work=work)
     return out
 
 
@@ -191,7 +200,9 @@ def conv3x3_wgrad(x, dz, cout, dz_idx=None, dw=None):
     if nbytes == 0:
         raise ValueError("conv3x3_wgrad: unsupported shape hw=%d cin=%d cout=%d" % (hw, cin, cout))
     ws = _WS.get(nbytes, x.device)
-    call("ugn_conv3x3_wgrad", ptr(x), ptr(dz), ptr(dz_idx), ptr(dw), n, hw, cin, cout, ptr(ws), ws.numel(), _stream())
+    label, work = _conv_work("wgrad", hw, cin, cout, dz_idx is not None, [n], wino=False)
+    call("ugn_conv3x3_wgrad", ptr(x), ptr(dz), ptr(dz_idx), ptr(dw), n, hw, cin, cout, ptr(ws), ws.numel(), _stream(),
+         label=label, work=work)
     return dw
 
 
@@ -206,10 +217,9 @@ def conv3x3_fwd_wino_pair(xs, upks, cout, pool, outs, idxs=None, bf16=False):
     hw, cin = xs[0].shape[1], xs[0].shape[3]
     assert xs[1].shape[1:] == xs[0].shape[1:] and (not pool or idxs is not None)
     ns = (C.c_int * 2)(xs[0].shape[0], xs[1].shape[0])
-    name = "conv3x3_fwd[a6: 128->128 @16x16 +LeakyReLU]" if hw == 16 else "conv3x3_fwd[a4: 64->64 @32x32 +LeakyReLU +MaxPool]"
-    with _Timed(name, ns[0] >= 100 and ((hw == 16 and cin == 128 and cout == 128) or (hw == 32 and cin == 64 and cout == 64 and pool))):
-        call("ugn_conv3x3_fwd_wino_pair" + ("_bf16" if bf16 else ""), ptr_array(xs), ptr_array(upks), ptr_array(outs), _opt_ptr_array(idxs if pool else None),
-             ns, hw, cin, cout, int(bool(pool)), _stream())
+    label, work = _conv_work("fwd", hw, cin, cout, pool, list(ns), bf16)
+    call("ugn_conv3x3_fwd_wino_pair" + ("_bf16" if bf16 else ""), ptr_array(xs), ptr_array(upks), ptr_array(outs), _opt_ptr_array(idxs if pool else None),
+         ns, hw, cin, cout, int(bool(pool)), _stream(), label=label, work=work)
     return (outs, idxs) if pool else outs
 
 
@@ -218,8 +228,10 @@ def conv3x3_dgrad_wino_pair(dzs, upks, hw, cin, cout, outs, dz_idxs=None, acts=N
     for t in dzs + upks + outs:
         _chk(t)
     ns = (C.c_int * 2)(dzs[0].shape[0], dzs[1].shape[0])
+    flags = _epi_flags(acts and acts[0], addends and addends[0], raw_outs and raw_outs[0])
+    label, work = _conv_work("dgrad", hw, cin, cout, bool(dz_idxs) and dz_idxs[0] is not None, list(ns), bf16, flags=flags)
     call("ugn_conv3x3_dgrad_wino_pair" + ("_bf16" if bf16 else ""), ptr_array(dzs), _opt_ptr_array(dz_idxs), ptr_array(upks), _opt_ptr_array(acts),
-         _opt_ptr_array(addends), ptr_array(outs), _opt_ptr_array(raw_outs), ns, hw, cin, cout, _stream())
+         _opt_ptr_array(addends), ptr_array(outs), _opt_ptr_array(raw_outs), ns, hw, cin, cout, _stream(), label=label, work=work)
     return outs
 
 
@@ -233,8 +245,9 @@ def conv3x3_wgrad_wino_pair(xs, dzs, cout, dws, dz_idxs=None, bf16=False):
     if nbytes == 0:
         raise ValueError("conv3x3_wgrad_wino_pair: unsupported shape hw=%d cin=%d cout=%d" % (hw, cin, cout))
     ws = _WS.get(nbytes, xs[0].device)
+    label, work = _conv_work("wgrad", hw, cin, cout, bool(dz_idxs) and dz_idxs[0] is not None, list(ns), bf16)
     call("ugn_conv3x3_wgrad_wino_pair" + ("_bf16" if bf16 else ""), ptr_array(xs), ptr_array(dzs), _opt_ptr_array(dz_idxs), ptr_array(dws), ns, hw, cin, cout,
-         ptr(ws), ws.numel(), _stream())
+         ptr(ws), ws.numel(), _stream(), label=label, work=work)
     return dws
 
 
@@ -247,7 +260,9 @@ def conv3x3_wgrad_wino(x, dz, cout, dz_idx=None, dw=None, bf16=False):
     if nbytes == 0:
         raise ValueError("conv3x3_wgrad_wino: unsupported shape hw=%d cin=%d cout=%d" % (hw, cin, cout))
     ws = _WS.get(nbytes, x.device)
-    call("ugn_conv3x3_wgrad_wino" + ("_bf16" if bf16 else ""), ptr(x), ptr(dz), ptr(dz_idx), ptr(dw), n, hw, cin, cout, ptr(ws), ws.numel(), _stream())
+    label, work = _conv_work("wgrad", hw, cin, cout, dz_idx is not None, [n], bf16)
+    call("ugn_conv3x3_wgrad_wino" + ("_bf16" if bf16 else ""), ptr(x), ptr(dz), ptr(dz_idx), ptr(dw), n, hw, cin, cout, ptr(ws), ws.numel(), _stream(),
+         label=label, work=work)
     return dw
 
 
@@ -258,7 +273,8 @@ def setmax_fwd(p, b, l, addend=None, m=None, sum_out=None):
     m = torch.empty((b,) + shape, dtype=F32, device=p.device) if m is None else m
     if addend is not None and sum_out is None:
         sum_out = torch.empty_like(m)
-    call("ugn_setmax_fwd", ptr(p), ptr(addend), ptr(m), ptr(sum_out), b, l, s, _stream())
+    call("ugn_setmax_fwd", ptr(p), ptr(addend), ptr(m), ptr(sum_out), b, l, s, _stream(), label="setmax_fwd[%d x %d x %d]" % (b, l, s),
+         work=_hbm_work("setmax_fwd_kernel", 4.0 * s * b * (l + 1 + (2 if addend is not None else 0))))
     return (m, sum_out) if addend is not None else m
 
 
@@ -308,7 +324,8 @@ def setmax_bwd(p, dm, b, l, apply_lrelu, out=None, addend=None):
     out = torch.empty_like(p) if out is None else out
     if addend is not None:
         _chk(addend)
-    call("ugn_setmax_bwd", ptr(p), ptr(dm), ptr(addend), ptr(out), b, l, s, int(bool(apply_lrelu)), _stream())
+    call("ugn_setmax_bwd", ptr(p), ptr(dm), ptr(addend), ptr(out), b, l, s, int(bool(apply_lrelu)), _stream(),
+         label="setmax_bwd[%d x %d x %d%s]" % (b, l, s, " +addend" if addend is not None else ""), work=_hbm_work("setmax_bwd_kernel", 4.0 * s * b * (2 * l + 1 + (l if addend is not None else 0))))
     return out
 
 
@@ -420,7 +437,7 @@ def triplet_fwd_bwd(sig, hp, hn, kp, kn, margin, grad_scale, bin_loss=None, bin_
 
 def adam_step(p, g, m, v, lr_t, b1=0.9, b2=0.999, eps=1e-7, grad_scale=1.0):
     call("ugn_adam_step", ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), float(lr_t), float(b1), float(b2), float(eps),
-         float(grad_scale), _stream())
+         float(grad_scale), _stream(), work=_hbm_work("adam_kernel", 28.0 * p.numel()))
 
 
 def adam_step_dev(p, g, m, v, lr_t_dev, b1=0.9, b2=0.999, eps=1e-7, grad_scale=1.0):

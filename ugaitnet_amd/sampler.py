@@ -118,7 +118,10 @@ class DeviceDataGenerator:
         key = (m, name)
         if self.cache is not None and key in self.cache:
             return self.cache[key]
-        a = _samples.load_sample(os.path.join(self.datadirs[m], name))["data"]
+        a = np.asarray(_samples.load_sample(os.path.join(self.datadirs[m], name))["data"])
+        want = (60, 60, 25 * self.specs[m].channels)
+        if a.shape != want:     # (never rely on numpy broadcasting a short or empty array into the batch buffer)
+            raise ValueError("%s: data of shape %r, expected %r for modality %d" % (name, a.shape, want, m))
         if self.cache is not None:
             self.cache[key] = a
         return a

@@ -24,7 +24,14 @@ def load_sample(path):
     for k in f.keys():
         node = f[k]
         if isinstance(node, h5lite.Dataset):
-            out[k] = node.read()
+            a = node.read()
+            # deepdish cannot store a zero-sized array as a node: it stores the array's SHAPE (int64) plus the node attribute
+            # `zeroarray_dtype`, and dd.io.load rebuilds np.zeros(shape, dtype) -- an empty recording (generateOFData.py:164-176)
+            zdt = node.attrs.get("zeroarray_dtype") if hasattr(node.attrs, "get") else None
+            if zdt is not None:
+                zdt = zdt.decode("ascii") if isinstance(zdt, (bytes, np.bytes_)) else str(zdt)
+                a = np.zeros(tuple(int(v) for v in np.asarray(a).reshape(-1)), dtype=np.dtype(zdt))
+            out[k] = a
     return out
 
 
