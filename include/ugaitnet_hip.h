@@ -89,6 +89,18 @@ int ugn_conv3x3_fwd_wino_pair(const float* const* in, const float* const* u_pack
 int ugn_conv3x3_dgrad_wino_pair(const float* const* dz, const uint8_t* const* dz_idx, const float* const* u_packed,
                                 const float* const* act, const float* const* addend, float* const* out,
                                 float* const* raw_out, const int* n, int hw, int cin, int cout, void* stream);
+/* The same for up to 6 convolutions of one shape in a single launch (arrays of length njobs): the three modality encoders
+ * of nets/mj_uwyhNets_ba.py:1102-1140 are the same ten layer shapes, so a 3-modality step issues ONE launch per layer for the
+ * frame-level convolutions of all modalities and their set-level twins.  Items of all jobs form one list that the
+ * persistent workgroups stride over; a job's filter slices stay resident in LDS across its items where they fit.  bf16 != 0
+ * selects the bf16-operand kernels (see below).  Rules for act / addend / raw_out / dz_idx as in the pair form. */
+int ugn_conv3x3_fwd_wino_multi(const float* const* in, const float* const* u_packed, float* const* out,
+                               uint8_t* const* out_idx, const int* n, int njobs, int hw, int cin, int cout, int pool, int bf16,
+                               void* stream);
+int ugn_conv3x3_dgrad_wino_multi(const float* const* dz, const uint8_t* const* dz_idx, const float* const* u_packed,
+                                 const float* const* act, const float* const* addend, float* const* out,
+                                 float* const* raw_out, const int* n, int njobs, int hw, int cin, int cout, int bf16,
+                                 void* stream);
 /* bf16-operand variants (BASELINE.json configs[4] / SURVEY 8(d) "C5": bf16 operands in the MFMA, fp32 accumulate): same
  * arguments, tensors stay fp32 in HBM; the Winograd-domain operands are rounded to bf16 (round to nearest even) and multiplied
  * on v_mfma_f32_16x16x16_bf16.  u_packed must come from ugn_wino_pack with 4 added to `dgrad` (bf16 elements, first half of
@@ -119,6 +131,12 @@ int ugn_conv3x3_wgrad_wino(const float* in, const float* dz, const uint8_t* dz_i
 int ugn_conv3x3_wgrad_wino_pair(const float* const* in, const float* const* dz, const uint8_t* const* dz_idx,
                                 float* const* dw, const int* n, int hw, int cin, int cout, void* ws, size_t ws_bytes,
                                 void* stream);
+/* Up to 6 weight gradients of one shape in a single launch.  The 8x16-pixel regions of all jobs form one list and every
+ * workgroup group owns an equal contiguous share of it (balanced to one region whatever the jobs' sizes); a share that crosses
+ * a job boundary leaves one partial-sum slab per job.  Workspace: ugn_conv3x3_wgrad_wino_ws (independent of n). */
+int ugn_conv3x3_wgrad_wino_multi(const float* const* in, const float* const* dz, const uint8_t* const* dz_idx,
+                                 float* const* dw, const int* n, int njobs, int hw, int cin, int cout, void* ws,
+                                 size_t ws_bytes, int bf16, void* stream);
 
 /* bf16-operand weight gradient (see ugn_conv3x3_fwd_wino_bf16): the transformed inputs and output gradients of 16 tiles are
  * rounded to bf16 and contracted by one v_mfma_f32_16x16x16_bf16 per Winograd point; fp32 accumulate, fp32 tensors, same
@@ -140,6 +158,9 @@ int ugn_setmax_fwd_cnt(const float* p, const float* addend, float* m, float* sum
 /* out = g * LeakyReLU'(act) elementwise (n a multiple of 4; out may alias g): the LeakyReluGrad of a set-level map whose
  * data gradient was computed with a plain epilogue so that it could share a launch with its frame-level twin. */
 int ugn_lrelu_bwd(const float* g, const float* act, float* out, size_t n, void* stream);
+/* x *= factor elementwise, in place (global-batch data parallelism: every replica holds the head's gradient of the WHOLE
+ * batch, so it is pre-scaled by 1/replicas before the summing all-reduce). */
+int ugn_scale(float* x, float factor, size_t n, void* stream);
 /* out = a / b elementwise (n a multiple of 4): dL/dm divided by the number of maxima (TF's reduce_max gradient). */
 int ugn_div(const float* a, const float* b, float* out, size_t n, void* stream);
 /* addend (optional, [b,l,s], may alias out): a second gradient path into p, summed before the LeakyReLU' factor:

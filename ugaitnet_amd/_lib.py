@@ -34,6 +34,10 @@ PROTOTYPES = {
     "ugn_conv3x3_fwd_wino": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "ugn_conv3x3_dgrad_wino": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "ugn_conv3x3_fwd_wino_pair": (_i, [C.POINTER(_p)] * 4 + [C.POINTER(_i), _i, _i, _i, _i, _p]),
+    "ugn_conv3x3_fwd_wino_multi": (_i, [C.POINTER(_p)] * 4 + [C.POINTER(_i), _i, _i, _i, _i, _i, _i, _p]),
+    "ugn_conv3x3_dgrad_wino_multi": (_i, [C.POINTER(_p)] * 7 + [C.POINTER(_i), _i, _i, _i, _i, _i, _p]),
+    "ugn_conv3x3_wgrad_wino_multi": (_i, [C.POINTER(_p)] * 4 + [C.POINTER(_i), _i, _i, _i, _i, _p, _sz, _i, _p]),
+    "ugn_scale": (_i, [_p, _f, _sz, _p]),
     "ugn_conv3x3_dgrad_wino_routed": (_i, [_p, _p, _p, _p, _p, _i, _p, _i, _i, _i, _i, _p]),
     "ugn_conv3x3_dgrad_wino_pair": (_i, [C.POINTER(_p)] * 7 + [C.POINTER(_i), _i, _i, _i, _p]),
     "ugn_conv3x3_fwd_wino_bf16": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),

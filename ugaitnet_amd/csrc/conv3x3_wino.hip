@@ -138,6 +138,14 @@ __device__ __forceinline__ int halo_slot_geometry(int inst, int lane) {
   return (yy << 16) | (xx << 8) | c4;
 }
 
+// The compiler may not hoist what is derived from the result out of a loop: the per-lane slot geometry of a DMA piece is
+// RECOMPUTED where the piece is issued (~10 VALU) instead of living in registers across the MFMA loop -- hoisted, the 64-bit
+// address parts of three pieces spill to scratch, and a scratch reload in the loop waits for vmcnt(0), i.e. for every DMA.
+__device__ __forceinline__ int opaque(int v) {
+  asm volatile("" : "+v"(v));
+  return v;
+}
+
 template <int KC, int HW>
 __device__ __forceinline__ void dma_halo_piece(const float* __restrict__ in, const float* __restrict__ zeros, int img, int ry0,
                                                int rx0, int chunk, int inst, int geom, unsigned lds_byte_base) {
@@ -228,8 +236,7 @@ __device__ __forceinline__ void dma_u_slice(const float* __restrict__ us, unsign
 
 // KC: GEMM K channels, NCF: output channels of the layer (a workgroup owns 32 of them), HW: image size
 template <int KC, int NCF, int HW, int IN_UNPOOL, int EPI, int EFLAGS, bool BF = false>
-__global__ __launch_bounds__(512, 2) void wino_kernel(const WinoJob j0, const WinoJob j1, const float* __restrict__ zeros,
-                                                      int nitems0, int nitems) {
+__global__ __launch_bounds__(512, 2) void wino_kernel(const WinoJobs jt, const float* __restrict__ zeros) {
   // WIDE (NCF >= 64): the workgroup owns 64 output channels, a wave 16 tiles x 2 channel blocks, and a group is 8 input
   // channels (2 k-steps): per MFMA half the transform work, patch reads and halo traffic of the narrow variant.
   constexpr bool WIDE = wino_wide_ex(KC, NCF, BF, IN_UNPOOL != 0);
@@ -260,21 +267,20 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const WinoJob j0, const Wi
   const int ubase = (kq * 32 + ch * 16 + lj) * 4;
 
   int item = blockIdx.x;
+  const int nitems = jt.start[kMaxJobs];
   if (item >= nitems) return;
   // (the slot geometry of a DMA piece is recomputed where the piece is issued: ~10 VALU per piece, but six fewer live
   //  registers in a kernel that sits at the 256-register limit)
-  // item -> job-local item / pointers (all wave-uniform: scalar selects)
-  auto local = [&](int it) { return it >= nitems0 ? it - nitems0 : it; };
-  auto in_of = [&](int it) { return it >= nitems0 ? j1.in : j0.in; };
-  auto idx_of = [&](int it) { return it >= nitems0 ? j1.in_idx : j0.in_idx; };
-  auto u_slice = [&](int it, int chunk, int G) {
-    return (it >= nitems0 ? j1.upk : j0.upk) + (((size_t)(local(it) % NSPLIT) * NCHUNK + chunk) * NG + G) * (BF ? SU / 2 : SU);
+  // item -> job (wave-uniform: the table is read with scalar loads, once per item, at the item boundary)
+  int jb = wino_job_of(jt, item), lit = item - jt.start[jb];   // job and job-local number of the current item
+  auto u_slice = [&](const float* upk, int lit_, int chunk, int G) {
+    return upk + (((size_t)(lit_ % NSPLIT) * NCHUNK + chunk) * NG + G) * (BF ? SU / 2 : SU);
   };
   // ---- prologue: halo(item, chunk 0) -> sIn[0]; U(item, 0, 0) -> sU[0]
   {
-    const int region = local(item) / NSPLIT, img = region / RPI, rrem = region % RPI;
-    const float* in = in_of(item);
-    const uint8_t* in_idx = idx_of(item);
+    const int region = lit / NSPLIT, img = region / RPI, rrem = region % RPI;
+    const float* in = jt.job[jb].in;
+    const uint8_t* in_idx = jt.job[jb].in_idx;
     if constexpr (IN_UNPOOL) {
 #pragma unroll
       for (int j = 0; j < 3; ++j)
@@ -284,7 +290,7 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const WinoJob j0, const Wi
       for (int j = 0; j < 6; ++j)
         dma_halo_piece<KC, HW>(in, zeros, img, (rrem / RPX) * 16, (rrem % RPX) * 16, 0, wave * 6 + j, halo_slot_geometry(wave * 6 + j, lane), sin_bytes);
     }
-    dma_u_slice<BF>(u_slice(item, 0, 0), su_bytes, tid, wave);
+    dma_u_slice<BF>(u_slice(jt.job[jb].upk, lit, 0, 0), su_bytes, tid, wave);
   }
   int ibuf = 0, ubuf = 0;
   float V[16][2 * NH]; // transformed patch (4 / 2 channels) of the group about to be multiplied
@@ -295,11 +301,16 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const WinoJob j0, const Wi
   };
   bool first = true;   // only the very first group of the workgroup transforms its patch un-pipelined
 
-  // every item of this workgroup has the same nsp (-> the same filter slices) when the grid is a multiple of NSPLIT
-  const bool u_resident = NCHUNK == 1 && NG == 2 && gridDim.x % NSPLIT == 0 && nitems0 == nitems;
-  bool first_item = true;
+  // Single-chunk narrow layers: the two filter slices of (job, nsp) stay RESIDENT in the two slots; every item of this
+  // workgroup has the same nsp when the grid is a multiple of NSPLIT (each job's items are one).  res0 / res1 = the job whose
+  // slice 0 / 1 sits in slot 0 / 1: a slice is fetched only when the group about to need it belongs to another job.
+  const bool u_resident = NCHUNK == 1 && NG == 2 && gridDim.x % NSPLIT == 0;
+  int res0 = jb, res1 = -1;
   for (; item < nitems; item += gridDim.x) {
     const int next_item = item + gridDim.x;
+    // the next item's job: its first halo tile and filter slice are fetched during this item's last chunk
+    const bool more = next_item < nitems;
+    const int jn = more ? wino_job_of(jt, next_item) : jb, nlit = more ? next_item - jt.start[jn] : lit;
     f32x4 acc[NB][16];
 #pragma unroll
     for (int cb = 0; cb < NB; ++cb)
@@ -314,10 +325,14 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const WinoJob j0, const Wi
       const bool has_next = !last_chunk || next_item < nitems;
       // no next stage (last chunk of the last item): the prefetches re-fetch the current stage into the free buffers
       // instead of branching around the DMA (keeps the MFMA stream one basic block)
-      const int n_item = last_chunk ? (has_next ? next_item : item) : item, n_chunk = last_chunk ? (has_next ? 0 : chunk) : chunk + 1;
-      const int n_region = local(n_item) / NSPLIT;
-      const float* in = in_of(n_item);
-      const uint8_t* in_idx = idx_of(n_item);
+      const bool to_next = last_chunk && has_next;      // the prefetches of this chunk belong to the next item
+      const int n_chunk = last_chunk ? (has_next ? 0 : chunk) : chunk + 1;
+      const int n_lit = to_next ? nlit : lit;
+      const int n_region = n_lit / NSPLIT;
+      const int nx_job = to_next ? jn : jb;             // (ONE table entry is read: selecting between two pointers instead
+      const float* in = jt.job[nx_job].in;               //  makes the compiler form both sets of DMA addresses)
+      const uint8_t* in_idx = jt.job[nx_job].in_idx;
+      const float* nx_upk = jt.job[nx_job].upk;
       const int n_img = n_region / RPI, n_rrem = n_region % RPI;
       const int n_ry0 = (n_rrem / RPX) * 16, n_rx0 = (n_rrem % RPX) * 16;
       const float* sIn = smem + ibuf * SIN;
@@ -329,8 +344,17 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const WinoJob j0, const Wi
         const float* sU = sU0 + ubuf * SU;
         // filter slice of the next group -> the other buffer, while this group computes
         // (single-chunk layers: the two slices of the workgroup's 32 output channels stay resident after the first item)
-        if (NCHUNK > 1 || !u_resident || first_item)
-          dma_u_slice<BF>(G + 1 < NG ? u_slice(item, chunk, G + 1) : u_slice(n_item, n_chunk, 0), su_bytes + (unsigned)(ubuf ^ 1) * SU * 4u, tid, wave);
+        if (G + 1 < NG) {
+          if (!u_resident || res1 != jb) {
+            dma_u_slice<BF>(u_slice(jt.job[jb].upk, lit, chunk, G + 1), su_bytes + (unsigned)(ubuf ^ 1) * SU * 4u, tid, wave);
+            res1 = jb;
+          }
+        } else {
+          if (!u_resident || res0 != nx_job) {
+            dma_u_slice<BF>(u_slice(nx_upk, n_lit, n_chunk, 0), su_bytes + (unsigned)(ubuf ^ 1) * SU * 4u, tid, wave);
+            res0 = nx_job;
+          }
+        }
         if (first) {
           first = false;
 #pragma unroll
@@ -450,11 +474,11 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const WinoJob j0, const Wi
           // a full group old at the next barrier and the next chunk's first transform can be pipelined as well
           if constexpr (IN_UNPOOL) {
             if (G == 0 && pt >= 1 && pt <= 3)
-              dma_pooled_piece<KC, HW>(in, in_idx, zeros, n_img, n_ry0, n_rx0, n_chunk, wave * 3 + (pt - 1), lane,
+              dma_pooled_piece<KC, HW>(in, in_idx, zeros, n_img, n_ry0, n_rx0, n_chunk, wave * 3 + (pt - 1), opaque(lane),
                                        sin_bytes + (unsigned)(ibuf ^ 1) * SIN * 4u);
           } else {
             if (G == 0 && pt >= 1 && pt < 7)   // early in the group: the pieces must have landed by the group's end
-              dma_halo_piece<KC, HW>(in, zeros, n_img, n_ry0, n_rx0, n_chunk, wave * 6 + (pt - 1), halo_slot_geometry(wave * 6 + (pt - 1), lane),
+              dma_halo_piece<KC, HW>(in, zeros, n_img, n_ry0, n_rx0, n_chunk, wave * 6 + (pt - 1), halo_slot_geometry(wave * 6 + (pt - 1), opaque(lane)),
                                      sin_bytes + (unsigned)(ibuf ^ 1) * SIN * 4u);
           }
           if (tnext) {
@@ -467,15 +491,15 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const WinoJob j0, const Wi
             // (LDS-DMA into a per-wave dump: no registers, nothing waits for it): the epilogue then hits L2.
             if constexpr (EPI == EPI_DGRAD && (EFLAGS & 3) != 0 && !IN_UNPOOL) {   // (the pooled-input variants have no register to spare)
               if (pt == 9 && G == NG - 1 && last_chunk) {
-                const int p_region = local(item) / NSPLIT, p_nsp = local(item) % NSPLIT;
+                const int p_region = lit / NSPLIT, p_nsp = lit % NSPLIT;
                 const int p_img = p_region / RPI, p_rrem = p_region % RPI;
                 const int t = lane >> 2, q = lane & 3;
                 const int oy = (p_rrem / RPX) * 16 + 2 * (trow0 + TRSTEP * (t >> 3)) + (q >> 1);
                 const int ox = (p_rrem % RPX) * 16 + 2 * (t & 7) + (q & 1);
                 const size_t o = (((size_t)p_img * HW + oy) * HW + ox) * NCF + p_nsp * (32 * NB) + ch * (16 * NB);
                 const unsigned dump = sin_bytes + (unsigned)((2 * SIN + 2 * SU) * 4) + (unsigned)wave * 256u;
-                if constexpr (EFLAGS & 1) dma4((item >= nitems0 ? j1.act : j0.act) + o, dump);
-                if constexpr (EFLAGS & 2) dma4((item >= nitems0 ? j1.addend : j0.addend) + o, dump);
+                if constexpr (EFLAGS & 1) dma4(jt.job[jb].act + o, dump);
+                if constexpr (EFLAGS & 2) dma4(jt.job[jb].addend + o, dump);
               }
             }
             constexpr bool LATE = ROWWISE && NH == 2;   // both row passes end at point 9
@@ -490,19 +514,17 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const WinoJob j0, const Wi
       }
       ibuf ^= 1;
     }
-    first_item = false;
 
     // ---- output transform + epilogue: lane holds tiles 4*kq + r (r = 0..3) x channels {lj, 16 + lj}, all 16 points
-    const int region = local(item) / NSPLIT, nsp = local(item) % NSPLIT;
+    const int region = lit / NSPLIT, nsp = lit % NSPLIT;
     const int img = region / RPI, rrem = region % RPI;
-    const bool jb = item >= nitems0;
-    float* out = jb ? j1.out : j0.out;
-    uint8_t* out_idx = jb ? j1.out_idx : j0.out_idx;
-    const float* act = jb ? j1.act : j0.act;
-    const float* addend = jb ? j1.addend : j0.addend;
-    float* raw_out = jb ? j1.raw_out : j0.raw_out;
-    const float* sm_m = jb ? j1.smax_m : j0.smax_m;
-    const float* sm_g = jb ? j1.smax_g : j0.smax_g;
+    float* out = jt.job[jb].out;
+    uint8_t* out_idx = jt.job[jb].out_idx;
+    const float* act = jt.job[jb].act;
+    const float* addend = jt.job[jb].addend;
+    float* raw_out = jt.job[jb].raw_out;
+    const float* sm_m = jt.job[jb].smax_m;
+    const float* sm_g = jt.job[jb].smax_g;
     {   // advance every tensor to this image (pooled outputs are a quarter of the size; set-level tensors are per clip)
       constexpr size_t IMG = (size_t)HW * HW * NCF, OIMG = EPI == EPI_LRELU_POOL ? IMG / 4 : IMG;
       out += (size_t)img * OIMG;
@@ -512,7 +534,7 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const WinoJob j0, const Wi
         if constexpr (EFLAGS & 2) addend += (size_t)img * IMG;
         if constexpr (EFLAGS & 4) raw_out += (size_t)img * IMG;
         if constexpr (EFLAGS & 8) {
-          const int clip = img / (jb ? j1.frames : j0.frames);
+          const int clip = img / jt.job[jb].frames;
           sm_m += (size_t)clip * IMG;
           sm_g += (size_t)clip * IMG;
         }
@@ -602,6 +624,7 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const WinoJob j0, const Wi
           }
       }
     }
+    jb = jn; lit = nlit;
   }
 }
 
@@ -617,9 +640,10 @@ int launch_wino(const WinoJob* jobs, const int* n, int njobs, hipStream_t st) {
   const float* zeros = zero_block();
   if (!zeros) { ugn_set_error("wino: cannot allocate the zero block"); return UGN_EINVAL; }
   constexpr int per_img = (HW / 16) * (HW / 16) * (NCF / (wino_wide_ex(KC, NCF, BF, IN_UNPOOL != 0) ? 64 : 32));
-  const int nitems0 = n[0] * per_img, nitems = nitems0 + (njobs > 1 ? n[1] * per_img : 0);
+  WinoJobs jt;
+  const int nitems = make_job_table(jt, jobs, n, njobs, per_img);
   const int grid = nitems < kGrid ? nitems : kGrid;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), LDS_BYTES, st, jobs[0], jobs[njobs > 1 ? 1 : 0], zeros, nitems0, nitems);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), LDS_BYTES, st, jt, zeros);
   UGN_CHECK_LAUNCH("wino");
   return 0;
 }
@@ -660,11 +684,11 @@ int dispatch_fwd(const WinoJob* jobs, const int* n, int njobs, int hw, int cin, 
 }
 
 int dispatch_dgrad(const WinoJob* jobs, const int* n, int njobs, int hw, int cin, int cout, int unpool, bool bf, hipStream_t st) {
-  if (njobs > 1) {   // one kernel instantiation serves both jobs: they must use the same epilogue operands
+  for (int j = 1; j < njobs; ++j) {   // one kernel instantiation serves all jobs: they must use the same epilogue operands
     const int f0 = (jobs[0].act ? 1 : 0) | (jobs[0].addend ? 2 : 0) | (jobs[0].raw_out ? 4 : 0) | (jobs[0].smax_m ? 8 : 0);
-    const int f1 = (jobs[1].act ? 1 : 0) | (jobs[1].addend ? 2 : 0) | (jobs[1].raw_out ? 4 : 0) | (jobs[1].smax_m ? 8 : 0);
+    const int f1 = (jobs[j].act ? 1 : 0) | (jobs[j].addend ? 2 : 0) | (jobs[j].raw_out ? 4 : 0) | (jobs[j].smax_m ? 8 : 0);
     if (f0 != f1) {
-      ugn_set_error("ugn_conv3x3_dgrad_wino_pair: both jobs need the same set of act/addend/raw_out (%d vs %d)", f0, f1);
+      ugn_set_error("ugn_conv3x3_dgrad_wino: all jobs of a launch need the same set of act/addend/raw_out (%d vs %d in job %d)", f0, f1, j);
       return UGN_EINVAL;
     }
   }
@@ -735,16 +759,26 @@ extern "C" int ugn_conv3x3_fwd_wino_bf16(const float* in, const float* u_packed,
   return fwd_one(in, u_packed, out, out_idx, n, hw, cin, cout, pool, true, stream);
 }
 
-static int fwd_pair(const float* const* in, const float* const* u_packed, float* const* out, uint8_t* const* out_idx,
-                    const int* n, int hw, int cin, int cout, int pool, bool bf, void* stream) {
-  UGN_REQUIRE(in && u_packed && out && n, "ugn_conv3x3_fwd_wino_pair: null array");
-  WinoJob jobs[2];
-  for (int j = 0; j < 2; ++j) {
-    UGN_REQUIRE(in[j] && u_packed[j] && out[j] && n[j] > 0, "ugn_conv3x3_fwd_wino_pair: null pointer or n <= 0 in job %d", j);
-    UGN_REQUIRE(!pool || (out_idx && out_idx[j]), "ugn_conv3x3_fwd_wino_pair: pool needs out_idx");
+static int fwd_multi(const float* const* in, const float* const* u_packed, float* const* out, uint8_t* const* out_idx,
+                     const int* n, int njobs, int hw, int cin, int cout, int pool, bool bf, void* stream) {
+  UGN_REQUIRE(in && u_packed && out && n, "ugn_conv3x3_fwd_wino_multi: null array");
+  UGN_REQUIRE(njobs >= 1 && njobs <= kMaxJobs, "ugn_conv3x3_fwd_wino_multi: njobs must be 1..%d (got %d)", kMaxJobs, njobs);
+  WinoJob jobs[kMaxJobs];
+  for (int j = 0; j < njobs; ++j) {
+    UGN_REQUIRE(in[j] && u_packed[j] && out[j] && n[j] > 0, "ugn_conv3x3_fwd_wino_multi: null pointer or n <= 0 in job %d", j);
+    UGN_REQUIRE(!pool || (out_idx && out_idx[j]), "ugn_conv3x3_fwd_wino_multi: pool needs out_idx");
     jobs[j] = {in[j], nullptr, u_packed[j], out[j], pool ? out_idx[j] : nullptr, nullptr, nullptr, nullptr};
   }
-  return dispatch_fwd(jobs, n, 2, hw, cin, cout, pool, bf, (hipStream_t)stream);
+  return dispatch_fwd(jobs, n, njobs, hw, cin, cout, pool, bf, (hipStream_t)stream);
+}
+static int fwd_pair(const float* const* in, const float* const* u_packed, float* const* out, uint8_t* const* out_idx,
+                    const int* n, int hw, int cin, int cout, int pool, bool bf, void* stream) {
+  return fwd_multi(in, u_packed, out, out_idx, n, 2, hw, cin, cout, pool, bf, stream);
+}
+extern "C" int ugn_conv3x3_fwd_wino_multi(const float* const* in, const float* const* u_packed, float* const* out,
+                                          uint8_t* const* out_idx, const int* n, int njobs, int hw, int cin, int cout, int pool,
+                                          int bf16, void* stream) {
+  return fwd_multi(in, u_packed, out, out_idx, n, njobs, hw, cin, cout, pool, bf16 != 0, stream);
 }
 extern "C" int ugn_conv3x3_fwd_wino_pair(const float* const* in, const float* const* u_packed, float* const* out,
                                          uint8_t* const* out_idx, const int* n, int hw, int cin, int cout, int pool,
@@ -786,18 +820,30 @@ extern "C" int ugn_conv3x3_dgrad_wino_routed(const float* dz, const float* u_pac
   return dispatch_dgrad(&job, &n, 1, hw, cin, cout, 0, false, (hipStream_t)stream);
 }
 
+static int dgrad_multi(const float* const* dz, const uint8_t* const* dz_idx, const float* const* u_packed,
+                       const float* const* act, const float* const* addend, float* const* out, float* const* raw_out,
+                       const int* n, int njobs, int hw, int cin, int cout, bool bf, void* stream) {
+  UGN_REQUIRE(dz && u_packed && out && n, "ugn_conv3x3_dgrad_wino_multi: null array");
+  UGN_REQUIRE(njobs >= 1 && njobs <= kMaxJobs, "ugn_conv3x3_dgrad_wino_multi: njobs must be 1..%d (got %d)", kMaxJobs, njobs);
+  WinoJob jobs[kMaxJobs];
+  for (int j = 0; j < njobs; ++j) {
+    UGN_REQUIRE(dz[j] && u_packed[j] && out[j] && n[j] > 0, "ugn_conv3x3_dgrad_wino_multi: null pointer or n <= 0 in job %d", j);
+    jobs[j] = {dz[j], dz_idx ? dz_idx[j] : nullptr, u_packed[j], out[j], nullptr, act ? act[j] : nullptr,
+               addend ? addend[j] : nullptr, raw_out ? raw_out[j] : nullptr};
+    UGN_REQUIRE((jobs[0].in_idx != nullptr) == (jobs[j].in_idx != nullptr), "ugn_conv3x3_dgrad_wino_multi: dz_idx for all jobs or none");
+  }
+  return dispatch_dgrad(jobs, n, njobs, hw, cin, cout, jobs[0].in_idx != nullptr, bf, (hipStream_t)stream);
+}
 static int dgrad_pair(const float* const* dz, const uint8_t* const* dz_idx, const float* const* u_packed,
                       const float* const* act, const float* const* addend, float* const* out, float* const* raw_out,
                       const int* n, int hw, int cin, int cout, bool bf, void* stream) {
-  UGN_REQUIRE(dz && u_packed && out && n, "ugn_conv3x3_dgrad_wino_pair: null array");
-  WinoJob jobs[2];
-  for (int j = 0; j < 2; ++j) {
-    UGN_REQUIRE(dz[j] && u_packed[j] && out[j] && n[j] > 0, "ugn_conv3x3_dgrad_wino_pair: null pointer or n <= 0 in job %d", j);
-    jobs[j] = {dz[j], dz_idx ? dz_idx[j] : nullptr, u_packed[j], out[j], nullptr, act ? act[j] : nullptr,
-               addend ? addend[j] : nullptr, raw_out ? raw_out[j] : nullptr};
-  }
-  UGN_REQUIRE((jobs[0].in_idx != nullptr) == (jobs[1].in_idx != nullptr), "ugn_conv3x3_dgrad_wino_pair: dz_idx for both jobs or none");
-  return dispatch_dgrad(jobs, n, 2, hw, cin, cout, jobs[0].in_idx != nullptr, bf, (hipStream_t)stream);
+  return dgrad_multi(dz, dz_idx, u_packed, act, addend, out, raw_out, n, 2, hw, cin, cout, bf, stream);
+}
+extern "C" int ugn_conv3x3_dgrad_wino_multi(const float* const* dz, const uint8_t* const* dz_idx, const float* const* u_packed,
+                                            const float* const* act, const float* const* addend, float* const* out,
+                                            float* const* raw_out, const int* n, int njobs, int hw, int cin, int cout, int bf16,
+                                            void* stream) {
+  return dgrad_multi(dz, dz_idx, u_packed, act, addend, out, raw_out, n, njobs, hw, cin, cout, bf16 != 0, stream);
 }
 extern "C" int ugn_conv3x3_dgrad_wino_pair(const float* const* dz, const uint8_t* const* dz_idx, const float* const* u_packed,
                                            const float* const* act, const float* const* addend, float* const* out,

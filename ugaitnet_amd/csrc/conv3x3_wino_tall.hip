@@ -103,8 +103,7 @@ __device__ __forceinline__ void tall_dma_u(const float* __restrict__ us, unsigne
 
 // KC: GEMM K channels (32 or 64); 32 output channels; HW: image size
 template <int KC, int HW, int IN_UNPOOL, int EPI, int EFLAGS, bool BF = false>
-__global__ __launch_bounds__(512, 2) void wino_tall_kernel(const WinoJob j0, const WinoJob j1, const float* __restrict__ zeros,
-                                                           int nitems0, int nitems) {
+__global__ __launch_bounds__(512, 2) void wino_tall_kernel(const WinoJobs jt, const float* __restrict__ zeros) {
   constexpr int NST = KC / 16;                 // 16-channel stages per item
   constexpr int NGI = 2 * NST;                 // 8-channel groups per item
   constexpr int NCF = 32;
@@ -125,33 +124,40 @@ __global__ __launch_bounds__(512, 2) void wino_tall_kernel(const WinoJob j0, con
   const int ubase = (kq * 16 + lj) * 4;
 
   int item = blockIdx.x;
+  const int nitems = jt.start[kMaxJobs];
   if (item >= nitems) return;
   int hgeo[6];
 #pragma unroll
   for (int j = 0; j < 6; ++j) hgeo[j] = tall_halo_geometry(wave * 6 + j, lane);
-  auto local = [&](int it) { return it >= nitems0 ? it - nitems0 : it; };
-  auto in_of = [&](int it) { return it >= nitems0 ? j1.in : j0.in; };
-  auto idx_of = [&](int it) { return it >= nitems0 ? j1.in_idx : j0.in_idx; };
-  auto u_slice = [&](int it, int gi) { return (it >= nitems0 ? j1.upk : j0.upk) + (size_t)gi * (BF ? TSUG / 2 : TSUG); };
-  auto dma_stage = [&](int it, int stage, int j, unsigned lds) {   // piece j (0..5 plain, 0..2 pooled) of this wave
-    const int region = local(it), img = region / RPI, rrem = region % RPI;
+  // item -> job (wave-uniform: the table is read with scalar loads, once per item, at the item boundary)
+  int jb = wino_job_of(jt, item), lit = item - jt.start[jb];
+  auto u_slice = [&](const float* upk, int gi) { return upk + (size_t)gi * (BF ? TSUG / 2 : TSUG); };
+  auto dma_stage = [&](const float* in, const uint8_t* in_idx, int region, int stage, int j, unsigned lds) {   // piece j (0..5 plain, 0..2 pooled) of this wave
+    const int img = region / RPI, rrem = region % RPI;
     const int ry0 = (rrem / RPX) * 32, rx0 = (rrem % RPX) * 16;
     if constexpr (IN_UNPOOL)
-      tall_dma_pooled<KC, HW>(in_of(it), idx_of(it), zeros, img, ry0, rx0, stage, wave * 3 + j, lane, lds);
+      tall_dma_pooled<KC, HW>(in, in_idx, zeros, img, ry0, rx0, stage, wave * 3 + j, lane, lds);
     else
-      tall_dma_halo<KC, HW>(in_of(it), zeros, img, ry0, rx0, stage, wave * 6 + j, hgeo[j], lds);
+      tall_dma_halo<KC, HW>(in, zeros, img, ry0, rx0, stage, wave * 6 + j, hgeo[j], lds);
   };
-  // the transformed filter of a 32-channel layer fits the ring: resident when every item reads the same filter
-  const bool u_resident = NGI == NUB && nitems0 == nitems;
+  // The transformed filter of a 32-channel layer fits the ring: its NUB slices stay RESIDENT while the workgroup's items
+  // belong to one job.  res[s] = the job whose slice s sits in ring slot s (an item walks the slots 0..NUB-1 in order): a
+  // slice is fetched only when the group about to need it belongs to another job, i.e. at a job boundary.
+  constexpr bool u_resident = NGI == NUB;
+  int res[NUB];
   // ---- prologue: halo(item, stage 0) -> sIn[0]; filter slice(s) -> ring
 #pragma unroll
-  for (int j = 0; j < (IN_UNPOOL ? 3 : 6); ++j) dma_stage(item, 0, j, sin_bytes);
+  for (int j = 0; j < (IN_UNPOOL ? 3 : 6); ++j) dma_stage(jt.job[jb].in, jt.job[jb].in_idx, lit, 0, j, sin_bytes);
   if (u_resident) {
 #pragma unroll
-    for (int gi = 0; gi < NUB; ++gi) tall_dma_u<BF>(u_slice(item, gi), su_bytes + (unsigned)gi * TSUG * 4u, tid, wave);
+    for (int gi = 0; gi < NUB; ++gi) {
+      tall_dma_u<BF>(u_slice(jt.job[jb].upk, gi), su_bytes + (unsigned)gi * TSUG * 4u, tid, wave);
+      res[gi] = jb;
+    }
   } else {
-    tall_dma_u<BF>(u_slice(item, 0), su_bytes, tid, wave);
+    tall_dma_u<BF>(u_slice(jt.job[jb].upk, 0), su_bytes, tid, wave);
   }
+  bool upend = false;   // a filter slice was fetched during the previous group (resident mode): publish it
   int ibuf = 0, ubuf = 0;
   float V[16][2];      // transformed patch (2 channels) of the group about to be multiplied
   uint32_t Vp[16];     // BF: the same as a bf16 pair, rounded as it is produced
@@ -163,6 +169,9 @@ __global__ __launch_bounds__(512, 2) void wino_tall_kernel(const WinoJob j0, con
 
   for (; item < nitems; item += gridDim.x) {
     const int next_item = item + gridDim.x;
+    // the next item's job: its first halo stage and filter slice are fetched during this item's last stage
+    const bool more = next_item < nitems;
+    const int jn = more ? wino_job_of(jt, next_item) : jb, nlit = more ? next_item - jt.start[jn] : lit;
     f32x4 acc[2][16];
 #pragma unroll
     for (int cb = 0; cb < 2; ++cb)
@@ -176,21 +185,37 @@ __global__ __launch_bounds__(512, 2) void wino_tall_kernel(const WinoJob j0, con
       const bool last_stage = st + 1 == NST;
       const bool has_next = !last_stage || next_item < nitems;
       // no next stage (last stage of the last item): re-fetch the current one into the free buffers (branch-free MFMA stream)
-      const int n_item = last_stage ? (has_next ? next_item : item) : item, n_stage = last_stage ? (has_next ? 0 : st) : st + 1;
+      const bool to_next = last_stage && has_next;      // the prefetches of this stage belong to the next item
+      const int n_stage = last_stage ? (has_next ? 0 : st) : st + 1;
+      const int n_lit = to_next ? nlit : lit;
+      const int nx_job = to_next ? jn : jb;             // (ONE table entry is read: selecting between two pointers instead
+      const float* nx_in = jt.job[nx_job].in;            //  makes the compiler form both sets of DMA addresses)
+      const uint8_t* nx_idx = jt.job[nx_job].in_idx;
+      const float* nx_upk = jt.job[nx_job].upk;
       const float* sIn = smem + ibuf * TSIN;
       const float* sInNext = smem + (ibuf ^ 1) * TSIN;
 #pragma unroll
       for (int G = 0; G < 2; ++G) {
         // Publish what the previous group's DMA brought.  With resident filters the first group of a stage consumes nothing
         // new (its tile was published a group ago, and the buffer its DMA refills has had no reader since the last barrier).
-        if (G == 1 || !u_resident || first) {
+        if (G == 1 || !u_resident || first || upend) {
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           __syncthreads();
+          upend = false;
         }
         const float* sU = sU0 + ubuf * TSUG;
-        if (!u_resident)   // filter slice of the next group -> next ring slot, while this group computes
-          tall_dma_u<BF>(G == 0 ? u_slice(item, 2 * st + 1) : u_slice(n_item, 2 * n_stage), su_bytes + (unsigned)((ubuf + 1) & (NUB - 1)) * TSUG * 4u,
-                     tid, wave);
+        {   // filter slice of the next group -> next ring slot, while this group computes (resident: only if another job's)
+          const int nslot = (ubuf + 1) & (NUB - 1);
+          const int want = G == 0 ? jb : nx_job;
+          bool fetch = true;
+          if constexpr (u_resident) {   // (ubuf is the compile-time 2 * st + G here: an item walks the ring exactly once)
+            fetch = res[(2 * st + G + 1) & (NUB - 1)] != want;
+            res[(2 * st + G + 1) & (NUB - 1)] = want;
+            upend = fetch;
+          }
+          if (fetch)
+            tall_dma_u<BF>(G == 0 ? u_slice(jt.job[jb].upk, 2 * st + 1) : u_slice(nx_upk, 2 * n_stage), su_bytes + (unsigned)nslot * TSUG * 4u, tid, wave);
+        }
         if (first) {
           first = false;
           float2 d[16], t[16];
@@ -278,12 +303,12 @@ __global__ __launch_bounds__(512, 2) void wino_tall_kernel(const WinoJob j0, con
               if (pt == 0) tall_read_pooled_row<0>(dn, sNx, sNi);
               if (pt == 1) tall_read_pooled_row<1>(dn, sNx, sNi);
               if (pt == 2) tall_read_pooled_row<2>(dn, sNx, sNi);
-              if (G == 0 && pt >= 1 && pt <= 3) dma_stage(n_item, n_stage, pt - 1, sin_bytes + (unsigned)(ibuf ^ 1) * TSIN * 4u);
+              if (G == 0 && pt >= 1 && pt <= 3) dma_stage(nx_in, nx_idx, n_lit, n_stage, pt - 1, sin_bytes + (unsigned)(ibuf ^ 1) * TSIN * 4u);
               if (pt == 3) { rowpass(0); rowpass(1); }
               if (pt == 4) { rowpass(2); rowpass(3); }
             } else {
               if (pt == 0) tall_read_plain(dn, sNx);
-              if (G == 0 && pt >= 1 && pt < 7) dma_stage(n_item, n_stage, pt - 1, sin_bytes + (unsigned)(ibuf ^ 1) * TSIN * 4u);
+              if (G == 0 && pt >= 1 && pt < 7) dma_stage(nx_in, nx_idx, n_lit, n_stage, pt - 1, sin_bytes + (unsigned)(ibuf ^ 1) * TSIN * 4u);
               if (pt == 1) { rowpass(0); rowpass(1); }
               if (pt == 2) { rowpass(2); rowpass(3); }
             }
@@ -299,17 +324,16 @@ __global__ __launch_bounds__(512, 2) void wino_tall_kernel(const WinoJob j0, con
     }
 
     // ---- output transform + epilogue: lane holds tiles 4*kq + r (r = 0..3) x channels {lj, 16 + lj}, all 16 points
-    const int region = local(item);
+    const int region = lit;
     const int img = region / RPI, rrem = region % RPI;
     const int ry0 = (rrem / RPX) * 32, rx0 = (rrem % RPX) * 16;
-    const bool jb = item >= nitems0;
-    float* out = jb ? j1.out : j0.out;
-    uint8_t* out_idx = jb ? j1.out_idx : j0.out_idx;
-    const float* act = jb ? j1.act : j0.act;
-    const float* addend = jb ? j1.addend : j0.addend;
-    float* raw_out = jb ? j1.raw_out : j0.raw_out;
-    const float* sm_m = jb ? j1.smax_m : j0.smax_m;
-    const float* sm_g = jb ? j1.smax_g : j0.smax_g;
+    float* out = jt.job[jb].out;
+    uint8_t* out_idx = jt.job[jb].out_idx;
+    const float* act = jt.job[jb].act;
+    const float* addend = jt.job[jb].addend;
+    float* raw_out = jt.job[jb].raw_out;
+    const float* sm_m = jt.job[jb].smax_m;
+    const float* sm_g = jt.job[jb].smax_g;
     {   // advance every tensor to this image (pooled outputs are a quarter of the size; set-level tensors are per clip)
       constexpr size_t IMG = (size_t)HW * HW * NCF, OIMG = EPI == EPI_LRELU_POOL ? IMG / 4 : IMG;
       out += (size_t)img * OIMG;
@@ -319,7 +343,7 @@ __global__ __launch_bounds__(512, 2) void wino_tall_kernel(const WinoJob j0, con
         if constexpr (EFLAGS & 2) addend += (size_t)img * IMG;
         if constexpr (EFLAGS & 4) raw_out += (size_t)img * IMG;
         if constexpr (EFLAGS & 8) {
-          const int clip = img / (jb ? j1.frames : j0.frames);
+          const int clip = img / jt.job[jb].frames;
           sm_m += (size_t)clip * IMG;
           sm_g += (size_t)clip * IMG;
         }
@@ -408,6 +432,7 @@ __global__ __launch_bounds__(512, 2) void wino_tall_kernel(const WinoJob j0, con
           }
       }
     }
+    jb = jn; lit = nlit;
   }
 }
 
@@ -423,9 +448,10 @@ int launch_tall_t(const WinoJob* jobs, const int* n, int njobs, hipStream_t st) 
   const float* zeros = zero_block();
   if (!zeros) { ugn_set_error("wino tall: cannot allocate the zero block"); return UGN_EINVAL; }
   constexpr int per_img = (HW / 16) * (HW / 32);
-  const int nitems0 = n[0] * per_img, nitems = nitems0 + (njobs > 1 ? n[1] * per_img : 0);
+  WinoJobs jt;
+  const int nitems = make_job_table(jt, jobs, n, njobs, per_img);
   const int grid = nitems < kGrid ? nitems : kGrid;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), TLDS, st, jobs[0], jobs[njobs > 1 ? 1 : 0], zeros, nitems0, nitems);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), TLDS, st, jt, zeros);
   UGN_CHECK_LAUNCH("wino tall");
   return 0;
 }

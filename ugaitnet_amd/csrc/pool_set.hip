@@ -65,6 +65,11 @@ __global__ void lrelu_bwd_kernel(const float4* __restrict__ g, const float4* __r
   out[e] = make_float4(x.x * ugn_lrelu_slope(a.x), x.y * ugn_lrelu_slope(a.y), x.z * ugn_lrelu_slope(a.z), x.w * ugn_lrelu_slope(a.w));
 }
 
+__global__ void scale_kernel(float* __restrict__ x, float f, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) x[i] *= f;
+}
+
 __global__ void div_kernel(const float4* __restrict__ a, const float4* __restrict__ b, float4* __restrict__ out, size_t n4) {
   const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= n4) return;
@@ -254,6 +259,13 @@ extern "C" int ugn_lrelu_bwd(const float* g, const float* act, float* out, size_
   hipLaunchKernelGGL(lrelu_bwd_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const float4*)g,
                      (const float4*)act, (float4*)out, n / 4);
   UGN_CHECK_LAUNCH("lrelu_bwd");
+  return 0;
+}
+
+extern "C" int ugn_scale(float* x, float factor, size_t n, void* stream) {
+  UGN_REQUIRE(x && n > 0, "ugn_scale: bad arguments");
+  hipLaunchKernelGGL(scale_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, factor, n);
+  UGN_CHECK_LAUNCH("scale");
   return 0;
 }
 

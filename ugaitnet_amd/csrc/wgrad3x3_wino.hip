@@ -67,18 +67,33 @@ struct DzCfg {
   static constexpr int SDZ = PIECES * 256;            // floats per buffer
 };
 
-// One launch serves up to two weight gradients of the same shape (a frame-level layer and its set-level twin of the global
-// branch): the first NCOMBO * j0.groups workgroups belong to job 0, the rest to job 1.
+// One launch serves up to kWgMaxJobs weight gradients of the same shape (a frame-level layer and its set-level twin of the
+// global branch, for every modality).  The regions of all jobs form ONE list; each of the `groups` workgroup groups of a
+// (ci, co) block combination owns a contiguous 1/groups share of it, so the work is balanced to one region whatever the
+// jobs' sizes.  A group whose share crosses a job boundary writes its partial sums for the finished job (a slab) and starts
+// the next job from zero.  Slabs of job j: [combo][ng_j] at job[j].slab, written by the groups g0_j .. g0_j + ng_j - 1.
+constexpr int kWgMaxJobs = 6;
 struct WgJob {
   const float* in;
   const float* dz;
   const uint8_t* dz_idx;
   float* slab;
-  int nregions, groups;
+  int g0, ng;
 };
+struct WgJobs {
+  WgJob job[kWgMaxJobs];
+  int rstart[kWgMaxJobs + 1];   // first region of job j in the list; entries from the job count onwards hold the total
+  int groups;
+};
+__device__ __forceinline__ int wg_job_of(const WgJobs& jt, int r) {
+  int jb = 0;
+#pragma unroll
+  for (int j = 1; j < kWgMaxJobs; ++j) jb += r >= jt.rstart[j] ? 1 : 0;
+  return jb;
+}
 
 template <int CI, int CO, int HW, int COC, int DZ_UNPOOL, bool BF = false>
-__global__ __launch_bounds__(512, 2) void wgrad_wino_kernel(const WgJob j0, const WgJob j1, const float* __restrict__ zeros) {
+__global__ __launch_bounds__(512, 2) void wgrad_wino_kernel(const WgJobs jt, const float* __restrict__ zeros) {
   using D = DzCfg<COC, DZ_UNPOOL>;
   constexpr int COP = COC / 32;                       // 32-channel output pairs per workgroup (1 or 2)
   constexpr int KSPLIT = 8 / (2 * COP);               // waves sharing one output block (4 or 2)
@@ -96,15 +111,11 @@ __global__ __launch_bounds__(512, 2) void wgrad_wino_kernel(const WgJob j0, cons
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lj = lane & 15, kq = lane >> 4;
   const int cop = wave % COP, cib = (wave / COP) & 1, ks = wave / (2 * COP);
-  const bool jb = (int)blockIdx.x >= (CI / 32) * (CO / COC) * j0.groups;
-  const int bx = jb ? (int)blockIdx.x - (CI / 32) * (CO / COC) * j0.groups : (int)blockIdx.x;
-  const float* __restrict__ in = jb ? j1.in : j0.in;
-  const float* __restrict__ dz = jb ? j1.dz : j0.dz;
-  const uint8_t* __restrict__ dz_idx = jb ? j1.dz_idx : j0.dz_idx;
-  float* __restrict__ slab = jb ? j1.slab : j0.slab;
-  const int nregions = jb ? j1.nregions : j0.nregions, groups = jb ? j1.groups : j0.groups;
-  const int combo = bx / groups, grp = bx % groups;
+  const int groups = jt.groups, total = jt.rstart[kWgMaxJobs];
+  const int combo = (int)blockIdx.x / groups, grp = (int)blockIdx.x % groups;
   const int cic = combo / NCO, coc = combo % NCO;
+  // this group's share of the region list (groups <= total: never empty)
+  const int r_begin = (int)((long)grp * total / groups), r_end = (int)((long)(grp + 1) * total / groups);
 
   // per-lane geometry of this wave's DMA pieces (region independent)
   int hgeo[HPW], dgeo[DPW];
@@ -126,7 +137,11 @@ __global__ __launch_bounds__(512, 2) void wgrad_wino_kernel(const WgJob j0, cons
     const int dp = slot / D::SPP, dq = slot % D::SPP;
     dgeo[j] = (dp << 8) | (DZ_UNPOOL ? dq : (dq ^ swz(dp)));
   }
-  auto issue_dma = [&](int region, int buf) {
+  auto issue_dma = [&](int job, int gregion, int buf) {   // (ONE table entry is read per call: scalar loads)
+    const float* __restrict__ in = jt.job[job].in;
+    const float* __restrict__ dz = jt.job[job].dz;
+    const uint8_t* __restrict__ dz_idx = jt.job[job].dz_idx;
+    const int region = gregion - jt.rstart[job];
     const int img = region / RPI, rrem = region % RPI;
     const int ry0 = (rrem / RPX) * RH, rx0 = (rrem % RPX) * RW;
 #pragma unroll
@@ -166,14 +181,17 @@ __global__ __launch_bounds__(512, 2) void wgrad_wino_kernel(const WgJob j0, cons
 #pragma unroll
       for (int r = 0; r < 4; ++r) acc[pt][cb][r] = 0.f;
 
-  int region = grp;
-  if (region < nregions) issue_dma(region, 0);
+  int jb = wg_job_of(jt, r_begin);
+  issue_dma(jb, r_begin, 0);
   int buf = 0;
-  for (; region < nregions; region += groups, buf ^= 1) {
+  for (int region = r_begin; region < r_end; ++region, buf ^= 1) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of the current buffers have landed
     __syncthreads();                                    // everyone's have; the other buffers have no readers left
-    const int next = region + groups;
-    issue_dma(next < nregions ? next : region, buf ^ 1);   // branch-free: at the end re-fetch the current region
+    const int next = region + 1;
+    const bool has_next = next < r_end;
+    const int jn = has_next ? wg_job_of(jt, next) : jb;
+    const bool flush = !has_next || jn != jb;            // the accumulators leave after this region (wave-uniform)
+    if (!flush) issue_dma(jb, next, buf ^ 1);            // (a flush reuses the tile buffers: the next region is fetched after it)
     const float* sIn = sIn0 + buf * SIN;
     const float* sDz = sDz0 + buf * D::SDZ;
     // raw operands of one MFMA step: the lane's 4x4 input patch and its two 2x2 gradient tiles (or pooled pixel + argmax);
@@ -392,9 +410,9 @@ __global__ __launch_bounds__(512, 2) void wgrad_wino_kernel(const WgJob j0, cons
       __builtin_amdgcn_s_setprio(0);
     }
     }   // !BF
-  }
+    if (!flush) continue;
 
-  // ---- combine the KSPLIT waves that share an output block (through LDS, fixed order), then write the slab
+  // ---- job (or share) finished: combine the KSPLIT waves that share an output block (through LDS, fixed order), write the slab
   __syncthreads();
   float* sRed = smem;   // 16 points x 4 registers x 64 lanes = 16 KB per (wave, channel block)
 #pragma unroll
@@ -421,7 +439,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_wino_kernel(const WgJob j0, cons
   }
   if (ks == 0) {
     // G^T Z G is lane-local (a lane holds all 16 points of its (ci, co) elements): the slab carries the 9 taps
-    float* dst = slab + ((size_t)combo * groups + grp) * 9 * 32 * COC;
+    float* dst = jt.job[jb].slab + ((size_t)combo * jt.job[jb].ng + (grp - jt.job[jb].g0)) * 9 * 32 * COC;
 #pragma unroll
     for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
@@ -443,19 +461,34 @@ __global__ __launch_bounds__(512, 2) void wgrad_wino_kernel(const WgJob j0, cons
         }
       }
   }
+    if (!has_next) break;
+    // ---- the share continues with the next job: zero sums, refill the tile buffer the combine overwrote
+#pragma unroll
+    for (int pt = 0; pt < 16; ++pt)
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[pt][cb][r] = 0.f;
+    jb = jn;
+    __syncthreads();                     // the combine's last LDS reads are done before the DMA writes there
+    issue_dma(jb, next, buf ^ 1);
+  }
 }
 
 // dW[tap][cic*32 + ci][coc*COC + co] = sum_g slab[combo][g][tap][ci][co], in float4 units over co.
 // 256 threads = 16 elements x 16 slab lanes; lane gl sums groups gl, gl+16, ..., then the 16 lanes are added in order.
 // (blockIdx.z = job: both weight gradients of a pair launch are finished by one launch)
+struct WgFinish {
+  const float4* slab[kWgMaxJobs];
+  float* dw[kWgMaxJobs];
+  int ng[kWgMaxJobs];
+};
 template <int COC>
-__global__ __launch_bounds__(256) void wino_wgrad_finish(const float4* __restrict__ slab0, float* __restrict__ dw0, int groups0,
-                                                         const float4* __restrict__ slab1, float* __restrict__ dw1, int groups1,
-                                                         int CI, int CO) {
+__global__ __launch_bounds__(256) void wino_wgrad_finish(const WgFinish ft, int CI, int CO) {
   __shared__ float4 sR[16][16];
-  const float4* __restrict__ slab = blockIdx.z ? slab1 : slab0;
-  float* __restrict__ dw = blockIdx.z ? dw1 : dw0;
-  const int groups = blockIdx.z ? groups1 : groups0;
+  const float4* __restrict__ slab = ft.slab[blockIdx.z];
+  float* __restrict__ dw = ft.dw[blockIdx.z];
+  const int groups = ft.ng[blockIdx.z];
   constexpr int E4 = 9 * 32 * COC / 4;
   const int le = threadIdx.x & 15, lg = threadIdx.x >> 4;
   const int combo = blockIdx.y, e = blockIdx.x * 16 + le;   // E4 is a multiple of 16
@@ -489,24 +522,6 @@ inline const float* zero_block_w() {
 
 constexpr int kWgs = 256;
 
-// Share of the 256 / NCOMBO workgroup groups per job: proportional to the regions, at least one each.
-inline void split_groups(int ncombo, const long* nregions, int njobs, int* groups) {
-  const int total = kWgs / ncombo;
-  if (njobs == 1) {
-    groups[0] = (long)total > nregions[0] ? (int)nregions[0] : total;
-    return;
-  }
-  const long all = nregions[0] + nregions[1];
-  int g1 = (int)((nregions[1] * total + all - 1) / all);   // ceil: the small job must not become the tail
-  if (g1 < 1) g1 = 1;
-  if (g1 > total - 1) g1 = total - 1;
-  if ((long)g1 > nregions[1]) g1 = (int)nregions[1];
-  int g0 = total - g1;
-  if ((long)g0 > nregions[0]) g0 = (int)nregions[0];
-  groups[0] = g0;
-  groups[1] = g1;
-}
-
 struct WgHostJob {
   const float* in;
   const float* dz;
@@ -529,28 +544,47 @@ int launch_wgrad_wino(const WgHostJob* hj, int njobs, float* ws, size_t ws_float
   const float* zeros = zero_block_w();
   if (!zeros) { ugn_set_error("wgrad wino: cannot allocate the zero block"); return UGN_EINVAL; }
   constexpr int NCOMBO = (CI / 32) * (CO / COC);
-  long nreg[2] = {0, 0};
-  for (int j = 0; j < njobs; ++j) nreg[j] = (long)hj[j].n * (HW / RH) * (HW / RW);
-  int groups[2] = {0, 0};
-  split_groups(NCOMBO, nreg, njobs, groups);
+  WgJobs jt;
+  long total = 0;
+  for (int j = 0; j < kWgMaxJobs; ++j) {
+    jt.rstart[j] = (int)total;
+    if (j < njobs) total += (long)hj[j].n * (HW / RH) * (HW / RW);
+  }
+  jt.rstart[kWgMaxJobs] = (int)total;
+  if (total > 0x3fffffff) { ugn_set_error("wgrad wino: too many regions (%ld)", total); return UGN_EINVAL; }
+  const int groups = (long)(kWgs / NCOMBO) > total ? (int)total : kWgs / NCOMBO;
+  jt.groups = groups;
+  // which groups touch which job: group g owns regions [g * total / groups, (g + 1) * total / groups)
   const size_t slab_floats = (size_t)9 * 32 * COC;
-  const size_t need = (size_t)NCOMBO * (groups[0] + groups[1]) * slab_floats;
-  if (ws_floats < need) {
-    ugn_set_error("wgrad wino: workspace too small (%zu < %zu floats)", ws_floats, need);
-    return UGN_EINVAL;
-  }
-  WgJob dj[2];
+  WgFinish ft = {};
   float* slab = ws;
-  for (int j = 0; j < njobs; ++j) {
-    dj[j] = {hj[j].in, hj[j].dz, hj[j].dz_idx, slab, (int)nreg[j], groups[j]};
-    slab += (size_t)NCOMBO * groups[j] * slab_floats;
+  size_t need = 0;
+  for (int j = 0; j < kWgMaxJobs; ++j) {
+    const int jj = j < njobs ? j : njobs - 1;
+    jt.job[j] = {hj[jj].in, hj[jj].dz, hj[jj].dz_idx, nullptr, 0, 0};
+    if (j >= njobs) continue;
+    int g0 = -1, g1 = -1;
+    for (int g = 0; g < groups; ++g) {
+      const long b0 = (long)g * total / groups, b1 = (long)(g + 1) * total / groups;
+      if (b0 < jt.rstart[j + 1] && b1 > jt.rstart[j]) { if (g0 < 0) g0 = g; g1 = g; }
+    }
+    const int ng = g1 - g0 + 1;
+    need += (size_t)NCOMBO * ng * slab_floats;
+    if (ws_floats < need) {
+      ugn_set_error("wgrad wino: workspace too small (%zu < %zu floats)", ws_floats, need);
+      return UGN_EINVAL;
+    }
+    jt.job[j].slab = slab;
+    jt.job[j].g0 = g0;
+    jt.job[j].ng = ng;
+    ft.slab[j] = (const float4*)slab;
+    ft.dw[j] = hj[j].dw;
+    ft.ng[j] = ng;
+    slab += (size_t)NCOMBO * ng * slab_floats;
   }
-  if (njobs == 1) dj[1] = dj[0];
-  hipLaunchKernelGGL(kern, dim3(NCOMBO * (groups[0] + groups[1])), dim3(512), LDS, st, dj[0], dj[1], zeros);
+  hipLaunchKernelGGL(kern, dim3(NCOMBO * groups), dim3(512), LDS, st, jt, zeros);
   UGN_CHECK_LAUNCH("wgrad wino");
-  hipLaunchKernelGGL(wino_wgrad_finish<COC>, dim3(9 * 32 * COC / 4 / 16, NCOMBO, njobs), dim3(256), 0, st,
-                     (const float4*)dj[0].slab, hj[0].dw, groups[0], (const float4*)dj[1].slab, hj[njobs > 1 ? 1 : 0].dw, groups[1], CI,
-                     CO);
+  hipLaunchKernelGGL(wino_wgrad_finish<COC>, dim3(9 * 32 * COC / 4 / 16, NCOMBO, njobs), dim3(256), 0, st, ft, CI, CO);
   UGN_CHECK_LAUNCH("wgrad wino finish");
   return 0;
 }
@@ -592,7 +626,8 @@ extern "C" size_t ugn_conv3x3_wgrad_wino_ws(int n, int hw, int cin, int cout) {
   // upper bound for one job of n images, and for a pair whose image counts sum to n
   int coc;
   if (!wg_cfg(hw, cin, cout, &coc) || n <= 0) return 0;
-  return (size_t)kWgs * 9 * 32 * coc * sizeof(float);
+  // every group writes one slab per job it touches: at most 256 + (jobs - 1) per block combination
+  return (size_t)(kWgs + 8 * (kWgMaxJobs - 1)) * 9 * 32 * coc * sizeof(float);
 }
 
 static int wgrad_one(const float* in, const float* dz, const uint8_t* dz_idx, float* dw, int n, int hw, int cin, int cout,
@@ -610,16 +645,26 @@ extern "C" int ugn_conv3x3_wgrad_wino_bf16(const float* in, const float* dz, con
   return wgrad_one(in, dz, dz_idx, dw, n, hw, cin, cout, ws, ws_bytes, true, stream);
 }
 
+static int wgrad_multi(const float* const* in, const float* const* dz, const uint8_t* const* dz_idx, float* const* dw,
+                       const int* n, int njobs, int hw, int cin, int cout, void* ws, size_t ws_bytes, bool bf, void* stream) {
+  UGN_REQUIRE(in && dz && dw && n && ws, "ugn_conv3x3_wgrad_wino_multi: null array");
+  UGN_REQUIRE(njobs >= 1 && njobs <= kWgMaxJobs, "ugn_conv3x3_wgrad_wino_multi: njobs must be 1..%d (got %d)", kWgMaxJobs, njobs);
+  WgHostJob jobs[kWgMaxJobs];
+  for (int j = 0; j < njobs; ++j) {
+    UGN_REQUIRE(in[j] && dz[j] && dw[j] && n[j] > 0, "ugn_conv3x3_wgrad_wino_multi: null pointer or n <= 0 in job %d", j);
+    jobs[j] = {in[j], dz[j], dz_idx ? dz_idx[j] : nullptr, dw[j], n[j]};
+    UGN_REQUIRE((jobs[0].dz_idx != nullptr) == (jobs[j].dz_idx != nullptr), "ugn_conv3x3_wgrad_wino_multi: dz_idx for all jobs or none");
+  }
+  return dispatch_wgrad(jobs, njobs, hw, cin, cout, ws, ws_bytes, bf, (hipStream_t)stream);
+}
 static int wgrad_pair(const float* const* in, const float* const* dz, const uint8_t* const* dz_idx, float* const* dw,
                       const int* n, int hw, int cin, int cout, void* ws, size_t ws_bytes, bool bf, void* stream) {
-  UGN_REQUIRE(in && dz && dw && n && ws, "ugn_conv3x3_wgrad_wino_pair: null array");
-  WgHostJob jobs[2];
-  for (int j = 0; j < 2; ++j) {
-    UGN_REQUIRE(in[j] && dz[j] && dw[j] && n[j] > 0, "ugn_conv3x3_wgrad_wino_pair: null pointer or n <= 0 in job %d", j);
-    jobs[j] = {in[j], dz[j], dz_idx ? dz_idx[j] : nullptr, dw[j], n[j]};
-  }
-  UGN_REQUIRE((jobs[0].dz_idx != nullptr) == (jobs[1].dz_idx != nullptr), "ugn_conv3x3_wgrad_wino_pair: dz_idx for both jobs or none");
-  return dispatch_wgrad(jobs, 2, hw, cin, cout, ws, ws_bytes, bf, (hipStream_t)stream);
+  return wgrad_multi(in, dz, dz_idx, dw, n, 2, hw, cin, cout, ws, ws_bytes, bf, stream);
+}
+extern "C" int ugn_conv3x3_wgrad_wino_multi(const float* const* in, const float* const* dz, const uint8_t* const* dz_idx,
+                                            float* const* dw, const int* n, int njobs, int hw, int cin, int cout, void* ws,
+                                            size_t ws_bytes, int bf16, void* stream) {
+  return wgrad_multi(in, dz, dz_idx, dw, n, njobs, hw, cin, cout, ws, ws_bytes, bf16 != 0, stream);
 }
 extern "C" int ugn_conv3x3_wgrad_wino_pair(const float* const* in, const float* const* dz, const uint8_t* const* dz_idx,
                                            float* const* dw, const int* n, int hw, int cin, int cout, void* ws,

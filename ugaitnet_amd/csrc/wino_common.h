@@ -6,8 +6,10 @@ namespace ugn_wino {
 
 enum { EPI_LRELU = 0, EPI_LRELU_POOL = 1, EPI_DGRAD = 2 };
 
-// One launch serves up to two convolutions of the same shape (the frame-level layer and its set-level twin of the global
-// branch, which alone would leave most CUs idle): items [0, nitems0) belong to job 0, [nitems0, nitems) to job 1.
+// One launch serves up to kMaxJobs convolutions of the same shape -- the frame-level layer and its set-level twin of the
+// global branch (which alone would leave most CUs idle), for every modality of the model: the three encoders run the same
+// ten layer shapes, so a 3-modality step issues one launch per layer instead of six.  Items [start[j], start[j+1]) belong
+// to job j.
 struct WinoJob {
   const float* in;
   const uint8_t* in_idx;
@@ -25,6 +27,20 @@ struct WinoJob {
 };
 
 constexpr int kGrid = 256;   // persistent workgroups (one per CU: the kernels use the whole LDS)
+constexpr int kMaxJobs = 6;
+
+// The job table travels in the kernel-argument segment; a job is looked up per ITEM (wave-uniform: scalar loads).
+struct WinoJobs {
+  WinoJob job[kMaxJobs];
+  int start[kMaxJobs + 1];   // first item of job j; entries from the job count onwards hold the total item count
+};
+
+__device__ __forceinline__ int wino_job_of(const WinoJobs& jt, int it) {
+  int jb = 0;
+#pragma unroll
+  for (int j = 1; j < kMaxJobs; ++j) jb += it >= jt.start[j] ? 1 : 0;
+  return jb;
+}
 
 // filter layouts (decided from the GEMM dimensions alone, so that packer and kernels agree):
 //   tall  : 32 output channels            -> conv3x3_wino_tall.hip
@@ -92,5 +108,18 @@ const float* zero_block();
 // tall variant (conv3x3_wino_tall.hip); kind: 0 forward, 1 data gradient
 bool tall_supported(int kind, int hw, int kc, int unpool_or_pool);
 int launch_tall(int kind, const WinoJob* jobs, const int* n, int njobs, int hw, int kc, int unpool_or_pool, bool bf, hipStream_t st);
+
+// host: the table of a launch (per_img items per image); returns the item count
+inline int make_job_table(WinoJobs& jt, const WinoJob* jobs, const int* n, int njobs, int per_img) {
+  int total = 0;
+  for (int j = 0; j < kMaxJobs; ++j) {
+    jt.job[j] = jobs[j < njobs ? j : njobs - 1];
+    jt.start[j] = total;
+    if (j < njobs) total += n[j] * per_img;
+  }
+  jt.start[kMaxJobs] = total;
+  for (int j = njobs; j < kMaxJobs; ++j) jt.start[j] = total;
+  return total;
+}
 
 }  // namespace ugn_wino

@@ -374,6 +374,134 @@ class Encoder:
                 ops.conv5x5_in_wgrad(A["x"], dz1, self.G("a1"))
 
 
+# One launch per layer for ALL modalities (UGN_MERGE=0: one launch per layer and modality).  The three encoders of
+# nets/mj_uwyhNets_ba.py:1102-1140 are the same ten layer shapes, so the Winograd kernels take the frame-level layer and the
+# set-level twin of every modality as up to six jobs of one launch: a third of the convolution launches of a step (what a
+# 5-clip-per-GPU step of the 8-GPU C4 split mostly consists of), items of all modalities in one work list (no per-modality
+# tail), and no need for side streams in the forward pass.
+MERGE_MODALITIES = os.environ.get("UGN_MERGE", "1") != "0"
+
+
+def _merged_ok():
+    return MERGE_MODALITIES and USE_WINOGRAD and PAIR_LAUNCHES and not ROUTED
+
+
+def forward_merged(encs, xs):
+    """Encoder.forward of several modality branches in lockstep: [x_m [B_m,L,60,60,C_m]] -> [[62,B_m,256]]."""
+    U8 = torch.uint8
+    bf16 = encs[0].bf16
+    geo = []
+    for e, x in zip(encs, xs):
+        b, l = x.shape[0], x.shape[1]
+        if e.act is None or e.shape != (b, l):
+            e.act, e.shape = {}, (b, l)
+        if not e.uf:
+            e.repack()
+        geo.append((b, l, b * l))
+    A = [e.act for e in encs]
+    B = lambda e, A_, key, shape, dtype=F32: e._buf(A_, key, shape, dtype)
+    # block 1: the 5x5 layer per modality (its kernel is specialised on the input channels), a2 for all of them
+    a1s = []
+    for e, x, (b, l, n) in zip(encs, xs, geo):
+        xf = x.reshape(n, 60, 60, e.cin)
+        e.act["x"] = xf
+        a1s.append(ops.conv5x5_in_fwd(xf, e.W("a1"), B(e, e.act, "a1", (n, 64, 64, 32)),
+                                      sign=B(e, e.act, "a1s", (n, 64, 64), torch.int32) if A1_SIGN_BITS else None))
+    p2s, i2s = ops.conv3x3_fwd_wino_multi(a1s, [e.uf["a2"] for e in encs], 32, True,
+                                          [B(e, e.act, "p2", (g[2], 32, 32, 32)) for e, g in zip(encs, geo)],
+                                          [B(e, e.act, "i2", (g[2], 32, 32, 32), U8) for e, g in zip(encs, geo)], bf16=bf16)
+    m1s = [ops.setmax_fwd(p2, b, l, m=B(e, e.act, "m1", (b, 32, 32, 32))) for e, p2, (b, l, n) in zip(encs, p2s, geo)]
+
+    def pair_layer(na, nb, xa, xb, cout, hw, pool, ka, kb, ia=None, ib=None):
+        """frame-level layer `na` on xa and set-level twin `nb` on xb, all modalities: jobs = [frame..., set...]"""
+        ho = hw // 2 if pool else hw
+        outs = [B(e, e.act, ka, (g[2], ho, ho, cout)) for e, g in zip(encs, geo)] + \
+               [B(e, e.act, kb, (g[0], ho, ho, cout)) for e, g in zip(encs, geo)]
+        idxs = None
+        if pool:
+            idxs = [B(e, e.act, ia, (g[2], ho, ho, cout), U8) for e, g in zip(encs, geo)] + \
+                   [B(e, e.act, ib, (g[0], ho, ho, cout), U8) for e, g in zip(encs, geo)]
+        ops.conv3x3_fwd_wino_multi(list(xa) + list(xb), [e.uf[na] for e in encs] + [e.uf[nb] for e in encs], cout, pool, outs, idxs,
+                                   bf16=bf16)
+        k = len(encs)
+        return outs[:k], outs[k:]
+
+    a3s, b1s = pair_layer("a3", "b1", p2s, m1s, 64, 32, False, "a3", "b1")
+    p4s, q2s = pair_layer("a4", "b2", a3s, b1s, 64, 32, True, "p4", "q2", "i4", "j2")
+    s2s = []
+    for e, p4, q2, (b, l, n) in zip(encs, p4s, q2s, geo):
+        _, s2 = ops.setmax_fwd(p4, b, l, addend=q2, m=B(e, e.act, "m2", (b, 16, 16, 64)), sum_out=B(e, e.act, "s2", (b, 16, 16, 64)))
+        s2s.append(s2)
+    a5s, b3s = pair_layer("a5", "b3", p4s, s2s, 128, 16, False, "a5", "b3")
+    a6s, b4s = pair_layer("a6", "b4", a5s, b3s, 128, 16, False, "a6", "b4")
+    outs = []
+    for e, a6, b4, (b, l, n) in zip(encs, a6s, b4s, geo):
+        m3, s3 = ops.setmax_fwd(a6, b, l, addend=b4, m=B(e, e.act, "m3", (b, 16, 16, 128)), sum_out=B(e, e.act, "s3", (b, 16, 16, 128)))
+        feat = ops.hpp_fwd(m3, s3, B(e, e.act, "feat", (NBINS, b, FEAT)))
+        outs.append(ops.binfc_fwd(feat, e.W("fc"), B(e, e.act, "out", (NBINS, b, HIDDEN))))
+    return outs
+
+
+def backward_merged(encs, douts, scratches):
+    """Encoder.backward of several modality branches in lockstep (same arithmetic, one launch per layer for all of them)."""
+    bf16 = encs[0].bf16
+    dev = encs[0].store.device
+    geo = [(e.shape[0], e.shape[1], e.shape[0] * e.shape[1]) for e in encs]
+    A = [e.act for e in encs]
+    k = len(encs)
+    buf = lambda i, key, shape: encs[i]._buf(scratches[i], key, shape)
+    R = range(k)
+    dz6, dzb4 = [], []
+    for i, e in enumerate(encs):
+        b, l, n = geo[i]
+        ops.binfc_bwd(A[i]["feat"], e.W("fc"), douts[i], e.G("fc"), buf(i, "dfeat", (NBINS, b, FEAT)))
+        dm3, d4 = ops.hpp_bwd(A[i]["m3"], A[i]["s3"], A[i]["b4"], scratches[i]["dfeat"], buf(i, "dm3", (b, 16, 16, 128)),
+                              buf(i, "dzb4", (b, 16, 16, 128)))
+        dz6.append(ops.setmax_bwd(A[i]["a6"], dm3, b, l, True, buf(i, "dz6", (n, 16, 16, 128))))
+        dzb4.append(d4)
+
+    def wgrad(na, nb, xa, xb, dza, dzb, cout, ia=None, ib=None):
+        with _side(dev):
+            ops.conv3x3_wgrad_wino_multi(list(xa) + list(xb), list(dza) + list(dzb), cout, [e.G(na) for e in encs] + [e.G(nb) for e in encs],
+                                         dz_idxs=None if ia is None else list(ia) + list(ib), bf16=bf16)
+
+    def dgrad(na, nb, dza, dzb, hw, cin, cout, outa, outb, ia=None, ib=None, acta=None, actb=None):
+        ops.conv3x3_dgrad_wino_multi(list(dza) + list(dzb), [e.ud[na] for e in encs] + [e.ud[nb] for e in encs], hw, cin, cout,
+                                     list(outa) + list(outb), dz_idxs=None if ia is None else list(ia) + list(ib),
+                                     acts=None if acta is None else list(acta) + list(actb), bf16=bf16)
+        return outa, outb
+
+    # block 3 of the frame stack (a5, a6) with block 2 of the global branch (b3, b4)
+    wgrad("a6", "b4", [a["a5"] for a in A], [a["b3"] for a in A], dz6, dzb4, 128)
+    dz5, dzb3 = dgrad("a6", "b4", dz6, dzb4, 16, 128, 128, [buf(i, "dz5", (geo[i][2], 16, 16, 128)) for i in R],
+                      [buf(i, "dzb3", (geo[i][0], 16, 16, 128)) for i in R], acta=[a["a5"] for a in A], actb=[a["b3"] for a in A])
+    wgrad("a5", "b3", [a["p4"] for a in A], [a["s2"] for a in A], dz5, dzb3, 128)
+    # plain epilogue for both data gradients of the pair; the set-max backward pass adds the frame-level extras (+ set-max
+    # gradient of p4, * LeakyReLU'(p4)), a small elementwise kernel the set-level one (* LeakyReLU'(q2))
+    raw4, ds2 = dgrad("a5", "b3", dz5, dzb3, 16, 64, 128, [buf(i, "g4", (geo[i][2], 16, 16, 64)) for i in R],
+                      [buf(i, "ds2", (geo[i][0], 16, 16, 64)) for i in R])
+    dq2 = [ops.lrelu_bwd(ds2[i], A[i]["q2"], buf(i, "dq2", (geo[i][0], 16, 16, 64))) for i in R]
+    dp4 = [ops.setmax_bwd(A[i]["p4"], ds2[i], geo[i][0], geo[i][1], True, out=raw4[i], addend=raw4[i]) for i in R]
+    # block 2 (a3, a4) with block 1 of the global branch (b1, b2); a4 / b2 are pooled
+    i4, j2 = [a["i4"] for a in A], [a["j2"] for a in A]
+    wgrad("a4", "b2", [a["a3"] for a in A], [a["b1"] for a in A], dp4, dq2, 64, i4, j2)
+    dz3, dzb1 = dgrad("a4", "b2", dp4, dq2, 32, 64, 64, [buf(i, "dz3", (geo[i][2], 32, 32, 64)) for i in R],
+                      [buf(i, "dzb1", (geo[i][0], 32, 32, 64)) for i in R], i4, j2, [a["a3"] for a in A], [a["b1"] for a in A])
+    wgrad("a3", "b1", [a["p2"] for a in A], [a["m1"] for a in A], dz3, dzb1, 64)
+    raw2, dm1 = dgrad("a3", "b1", dz3, dzb1, 32, 32, 64, [buf(i, "g2", (geo[i][2], 32, 32, 32)) for i in R],
+                      [buf(i, "dm1", (geo[i][0], 32, 32, 32)) for i in R])
+    dp2 = [ops.setmax_bwd(A[i]["p2"], dm1[i], geo[i][0], geo[i][1], True, out=raw2[i], addend=raw2[i]) for i in R]
+    # block 1 (a1, a2)
+    i2 = [a["i2"] for a in A]
+    with _side(dev):
+        ops.conv3x3_wgrad_wino_multi([a["a1"] for a in A], dp2, 32, [e.G("a2") for e in encs], dz_idxs=i2, bf16=bf16)
+    dz1 = ops.conv3x3_dgrad_wino_multi(dp2, [e.ud["a2"] for e in encs], 64, 32, 32, [buf(i, "dz1", (geo[i][2], 64, 64, 32)) for i in R],
+                                       dz_idxs=i2, acts=None if A1_SIGN_BITS else [a["a1"] for a in A], bf16=bf16)
+    with _side(dev):
+        for i, e in enumerate(encs):
+            ops.conv5x5_in_wgrad(A[i]["x"], dz1[i], e.G("a1"), sign=A[i]["a1s"] if A1_SIGN_BITS else None)
+
+
 class GaitCore:
     """Encoders + gate/fusion/normalisation + heads + losses + Adam, for 1, 2 or 3 modalities."""
 
@@ -502,23 +630,35 @@ class GaitCore:
         xs = [self._dev(x) for x in xs]
         b = xs[0].shape[0]
         self._active = None
+        merged = _merged_ok() and len(self.encoders) > 1
         if self.multimodal and self.skip_masked:
-            outs, self._active = [], []
+            outs, self._active = [None] * self.nmod, []
+            sub = []      # (modality, rows tensor or None, input of the active clips)
             for mi, (enc, x) in enumerate(zip(self.encoders, xs)):
                 u = uses[mi]
                 uh = (u.detach().cpu().numpy() if isinstance(u, torch.Tensor) else np.asarray(u)).reshape(-1)
                 rows = np.nonzero(uh != 0)[0]
-                full = self._buf("out_full%d" % mi, (NBINS, b, HIDDEN))
                 if len(rows) == b:
                     self._active.append(None)
-                    outs.append(enc.forward(x))
+                    sub.append((mi, None, x))
                     continue
                 idx = torch.from_numpy(rows).to(self.device)
                 self._active.append(idx)
-                full.zero_()
+                outs[mi] = self._buf("out_full%d" % mi, (NBINS, b, HIDDEN))
+                outs[mi].zero_()
                 if len(rows):
-                    full.index_copy_(1, idx, enc.forward(x.index_select(0, idx).contiguous()))
-                outs.append(full)
+                    sub.append((mi, idx, x.index_select(0, idx).contiguous()))
+            if merged and len(sub) > 1:
+                res = forward_merged([self.encoders[mi] for mi, _, _ in sub], [x for _, _, x in sub])
+            else:
+                res = [self.encoders[mi].forward(x) for mi, _, x in sub]
+            for (mi, idx, _), o in zip(sub, res):
+                if idx is None:
+                    outs[mi] = o
+                else:
+                    outs[mi].index_copy_(1, idx, o)
+        elif merged:
+            outs = forward_merged(self.encoders, xs)
         elif FWD_STREAMS and len(self.encoders) > 1:
             main = torch.cuda.current_stream(self.device)
             outs = [None] * len(self.encoders)
@@ -593,8 +733,8 @@ class GaitCore:
             ops.head_bwd(sig, self.store.p["head.wc"], self.head["dlogits"], dsig, True, self.store.g["head.wc"],
                          self.store.g["head.bc"])
             if self.global_batch:   # every replica holds the head gradient of the whole batch; the all-reduce sums them
-                self.store.g["head.wc"].mul_(1.0 / self.world)
-                self.store.g["head.bc"].mul_(1.0 / self.world)
+                ops.scale_(self.store.g["head.wc"], 1.0 / self.world)
+                ops.scale_(self.store.g["head.bc"], 1.0 / self.world)
             self._reduce_bucket(self.nmod)
         bl, lo = self.last_b, self.row0
         own = (lambda t: t[:, lo:lo + bl].contiguous()) if self.global_batch else (lambda t: t)
@@ -604,6 +744,27 @@ class GaitCore:
                                       [self._buf("dout%d" % m, (NBINS, bl, HIDDEN)) for m in range(self.nmod)])
         else:
             douts = [own(dsig)]
+        if _merged_ok() and self.nmod > 1 and not BRANCH_STREAMS:
+            encs, ds = [], []
+            for mi, (enc, d) in enumerate(zip(self.encoders, douts)):
+                idx = self._active[mi] if self._active is not None else None
+                if idx is None:
+                    encs.append(enc)
+                    ds.append(d)
+                elif idx.numel() == 0:
+                    for name, _ in branch_param_shapes(enc.cin):   # no active clip: this branch's gradient is exactly zero
+                        enc.G(name).zero_()
+                else:
+                    encs.append(enc)
+                    ds.append(d.index_select(1, idx).contiguous())
+            if len(encs) > 1:
+                backward_merged(encs, ds, [self.scratch.setdefault(self.encoders.index(e), {}) for e in encs])
+            elif encs:
+                encs[0].backward(ds[0], self.scratch.setdefault(self.encoders.index(encs[0]), {}))
+            for mi in range(self.nmod):
+                self._reduce_bucket(mi)
+            join_backward_streams(self.device)
+            return
         main = torch.cuda.current_stream(self.device)
         for mi, (enc, d) in enumerate(zip(self.encoders, douts)):
             idx = self._active[mi] if self._active is not None else None

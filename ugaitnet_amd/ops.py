@@ -207,7 +207,7 @@ def conv3x3_wgrad(x, dz, cout, dz_idx=None, dw=None):
 
 
 def _opt_ptr_array(pair):
-    return None if pair is None or pair[0] is None else ptr_array(pair)
+    return None if pair is None or pair[0] is None else ptr_array(list(pair))
 
 
 def conv3x3_fwd_wino_pair(xs, upks, cout, pool, outs, idxs=None, bf16=False):
@@ -249,6 +249,65 @@ def conv3x3_wgrad_wino_pair(xs, dzs, cout, dws, dz_idxs=None, bf16=False):
     call("ugn_conv3x3_wgrad_wino_pair" + ("_bf16" if bf16 else ""), ptr_array(xs), ptr_array(dzs), _opt_ptr_array(dz_idxs), ptr_array(dws), ns, hw, cin, cout,
          ptr(ws), ws.numel(), _stream(), label=label, work=work)
     return dws
+
+
+MAX_JOBS = 6   # jobs per multi launch (wino_common.h kMaxJobs): 3 modalities x (frame-level layer + set-level twin)
+
+
+def _int_array(vals):
+    return (C.c_int * len(vals))(*[int(v) for v in vals])
+
+
+def conv3x3_fwd_wino_multi(xs, upks, cout, pool, outs, idxs=None, bf16=False):
+    """Up to 6 forward convolutions of one shape (own inputs / filters / image counts) in a single launch."""
+    assert 1 <= len(xs) <= MAX_JOBS and len(upks) == len(outs) == len(xs) and (not pool or idxs is not None)
+    for t in list(xs) + list(upks) + list(outs):
+        _chk(t)
+    hw, cin = xs[0].shape[1], xs[0].shape[3]
+    assert all(x.shape[1:] == xs[0].shape[1:] for x in xs)
+    ns = [x.shape[0] for x in xs]
+    label, work = _conv_work("fwd", hw, cin, cout, pool, ns, bf16)
+    call("ugn_conv3x3_fwd_wino_multi", ptr_array(xs), ptr_array(upks), ptr_array(outs), ptr_array(idxs) if pool else None,
+         _int_array(ns), len(xs), hw, cin, cout, int(bool(pool)), int(bool(bf16)), _stream(), label=label, work=work)
+    return (outs, idxs) if pool else outs
+
+
+def conv3x3_dgrad_wino_multi(dzs, upks, hw, cin, cout, outs, dz_idxs=None, acts=None, addends=None, raw_outs=None, bf16=False):
+    """Up to 6 data gradients of one shape in a single launch; optional operands for all jobs or none."""
+    assert 1 <= len(dzs) <= MAX_JOBS and len(upks) == len(outs) == len(dzs)
+    for t in list(dzs) + list(upks) + list(outs):
+        _chk(t)
+    ns = [d.shape[0] for d in dzs]
+    flags = _epi_flags(acts and acts[0], addends and addends[0], raw_outs and raw_outs[0])
+    label, work = _conv_work("dgrad", hw, cin, cout, bool(dz_idxs) and dz_idxs[0] is not None, ns, bf16, flags=flags)
+    call("ugn_conv3x3_dgrad_wino_multi", ptr_array(dzs), _opt_ptr_array(dz_idxs), ptr_array(upks), _opt_ptr_array(acts),
+         _opt_ptr_array(addends), ptr_array(outs), _opt_ptr_array(raw_outs), _int_array(ns), len(dzs), hw, cin, cout,
+         int(bool(bf16)), _stream(), label=label, work=work)
+    return outs
+
+
+def conv3x3_wgrad_wino_multi(xs, dzs, cout, dws, dz_idxs=None, bf16=False):
+    """Up to 6 weight gradients of one shape in a single launch."""
+    assert 1 <= len(xs) <= MAX_JOBS and len(dzs) == len(dws) == len(xs)
+    for t in list(xs) + list(dzs) + list(dws):
+        _chk(t)
+    hw, cin = xs[0].shape[1], xs[0].shape[3]
+    ns = [x.shape[0] for x in xs]
+    nbytes = _lib.load().ugn_conv3x3_wgrad_wino_ws(sum(ns), hw, cin, cout)
+    if nbytes == 0:
+        raise ValueError("conv3x3_wgrad_wino_multi: unsupported shape hw=%d cin=%d cout=%d" % (hw, cin, cout))
+    ws = _WS.get(nbytes, xs[0].device)
+    label, work = _conv_work("wgrad", hw, cin, cout, bool(dz_idxs) and dz_idxs[0] is not None, ns, bf16)
+    call("ugn_conv3x3_wgrad_wino_multi", ptr_array(xs), ptr_array(dzs), _opt_ptr_array(dz_idxs), ptr_array(dws), _int_array(ns),
+         len(xs), hw, cin, cout, ptr(ws), ws.numel(), int(bool(bf16)), _stream(), label=label, work=work)
+    return dws
+
+
+def scale_(x, factor):
+    """x *= factor in place (a HIP kernel, not torch arithmetic)."""
+    _chk(x)
+    call("ugn_scale", ptr(x), float(factor), x.numel(), _stream())
+    return x
 
 
 def conv3x3_wgrad_wino(x, dz, cout, dz_idx=None, dw=None, bf16=False):
