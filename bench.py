@@ -112,6 +112,7 @@ def build_parser():
                     help="run the timed region itself with every launch on one stream (the rocprofv3 kernel-trace target: "
                          "per-kernel durations are then clean); never the headline")
     ap.add_argument("--no-roofline-pass", action="store_true", help="skip the serialised per-kernel timing pass")
+    ap.add_argument("--kernel-table", default="", help="write every row of the serialised per-kernel pass to this CSV file")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed and run the gradient collectives even with one rank (rehearses the RCCL "
                          "code path on a one-GPU box)")
@@ -146,7 +147,7 @@ def launch_ranks(args, argv):
     print(lines[0], flush=True)
 
 
-def roofline_pass(core, batch, steps, dtype):
+def roofline_pass(core, batch, steps, dtype, table_path=""):
     """Per-kernel durations from a fully serialised pass (one stream, HIP-event pair on that stream around every launch),
     taken AFTER the timed region; returns the roofline object of the kernel with the largest total duration."""
     import torch
@@ -182,6 +183,14 @@ def roofline_pass(core, batch, steps, dtype):
             d.update(bound="hbm", unit="GB/s", peak=PEAK_HBM / 1e9, achieved=round(w["bytes"] / avg / 1e3, 1),
                      frac=round(w["bytes"] / (avg * 1e-6) / PEAK_HBM, 4), rocprof_kernel=w["kernel"])
         return d
+    if table_path:
+        with open(table_path, "w") as f:
+            f.write("label,launches_per_step,avg_us,total_us_per_step,share,bound,achieved,peak,unit,frac,rocprof_kernel\n")
+            for row in rows:
+                d = describe(row)
+                f.write('"%s",%d,%.1f,%.1f,%.4f,%s,%s,%s,%s,%s,"%s"\n' % (
+                    d["kernel"], d["launches_per_step"], d["avg_us"], row[0] / steps, d["share_of_step"], d.get("bound", ""),
+                    d.get("achieved", ""), d.get("peak", ""), d.get("unit", ""), d.get("frac", ""), d.get("rocprof_kernel", "")))
     top = describe(rows[0])
     roof = dict(bound=top.get("bound"), achieved=top.get("achieved"), peak=top.get("peak"), unit=top.get("unit"),
                 frac=top.get("frac"), traffic=None)
@@ -307,7 +316,7 @@ def run(args):
 
     roof = None
     if not args.no_roofline_pass:
-        roof = roofline_pass(core, batch, 3, args.dtype)
+        roof = roofline_pass(core, batch, 3, args.dtype, args.kernel_table if rank == 0 else "")
 
     # secondary figure, same workload: encoders run only on the clips whose modality flag is 1 (the gate multiplies the
     # rest by 0, so every result is unchanged; tests/test_fullsize_gpu.py).  Never reported as `value`.

@@ -23,11 +23,17 @@ print(h.hexdigest(), core.losses()["loss"])
 
 if __name__ == "__main__":
     steps = sys.argv[1] if len(sys.argv) > 1 else "20"
-    outs = []
-    for env in ({"UGN_WSTREAM": "0"}, {"UGN_WSTREAM": "1"}, {"UGN_WSTREAM": "1", "UGN_FSTREAMS": "2", "UGN_BSTREAMS": "1"}):
-        e = dict(os.environ, **env)
-        r = subprocess.run([sys.executable, "-c", CHILD, steps], env=e, capture_output=True, text=True)
-        print(env, r.stdout.strip().splitlines()[-1] if r.stdout.strip() else r.stderr[-500:])
-        outs.append(r.stdout.strip().splitlines()[-1].split()[0] if r.stdout.strip() else None)
-    assert outs[0] is not None and outs[0] == outs[1] == outs[2], "parameter trajectories differ between stream modes"
+    # Two launch shapes -- one launch per layer for all modalities (default) and one per layer and modality (UGN_MERGE=0) -- sum
+    # the weight gradients in different orders, so each is compared with itself under its stream modes.
+    groups = (({"UGN_WSTREAM": "0"}, {"UGN_WSTREAM": "1"}),
+              ({"UGN_MERGE": "0", "UGN_WSTREAM": "0", "UGN_FSTREAMS": "0"}, {"UGN_MERGE": "0", "UGN_WSTREAM": "1", "UGN_FSTREAMS": "2"},
+               {"UGN_MERGE": "0", "UGN_WSTREAM": "1", "UGN_FSTREAMS": "2", "UGN_BSTREAMS": "1"}))
+    for envs in groups:
+        outs = []
+        for env in envs:
+            e = dict(os.environ, **env)
+            r = subprocess.run([sys.executable, "-c", CHILD, steps], env=e, capture_output=True, text=True)
+            print(env, r.stdout.strip().splitlines()[-1] if r.stdout.strip() else r.stderr[-500:])
+            outs.append(r.stdout.strip().splitlines()[-1].split()[0] if r.stdout.strip() else None)
+        assert outs[0] is not None and all(o == outs[0] for o in outs), "parameter trajectories differ between stream modes"
     print("identical trajectories over %s steps" % steps)
