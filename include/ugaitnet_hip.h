@@ -168,16 +168,33 @@ int ugn_div(const float* a, const float* b, float* out, size_t n, void* stream);
 int ugn_setmax_bwd(const float* p, const float* dm, const float* addend, float* out, int b, int l, size_t s,
                    int apply_lrelu, void* stream);
 
+/* The pooling / elementwise steps above for up to 4 tensors of one shape in a single launch (arrays of length njobs; b[j] clips
+ * in job j): the modality branches of nets/mj_uwyhNets_ba.py:1102-1140 run the same steps on their own tensors. */
+int ugn_setmax_fwd_multi(const float* const* p, const float* const* addend, float* const* m, float* const* sum_out,
+                         const int* b, int njobs, int l, size_t s, void* stream);
+int ugn_setmax_bwd_multi(const float* const* p, const float* const* dm, const float* const* addend, float* const* out,
+                         const int* b, int njobs, int l, size_t s, int apply_lrelu, void* stream);
+int ugn_lrelu_bwd_multi(const float* const* g, const float* const* act, float* const* out, const size_t* n, int njobs,
+                        void* stream);
+
 /* ---- horizontal pyramid pooling, nets/mj_uwyhNets_ba.py:468-481.  a, s3 [b,16,16,128] -> feat [62,b,128] */
 int ugn_hpp_fwd(const float* a, const float* s3, float* feat, int b, void* stream);
 /* dfeat [62,b,128] -> dm3 = dL/da + dL/ds3 (a also feeds s3 = b4 + a), dzb4 = dL/ds3 * LeakyReLU'(b4). */
 int ugn_hpp_bwd(const float* a, const float* s3, const float* b4, const float* dfeat, float* dm3, float* dzb4,
                 int b, void* stream);
+/* the same for up to 4 modality branches in one launch (arrays of length njobs) */
+int ugn_hpp_fwd_multi(const float* const* a, const float* const* s3, float* const* feat, const int* b, int njobs, void* stream);
+int ugn_hpp_bwd_multi(const float* const* a, const float* const* s3, const float* const* b4, const float* const* dfeat,
+                      float* const* dm3, float* const* dzb4, const int* b, int njobs, void* stream);
 
 /* ---- MatMul layer (62 per-bin FCs), nets/mj_uwyhNets_ba.py:23-40: feat [62,b,128] x w [62,128,256] ------- */
 int ugn_binfc_fwd(const float* feat, const float* w, float* out, int b, void* stream);
 int ugn_binfc_bwd(const float* feat, const float* w, const float* dout, float* dw, float* dfeat, int b,
                   void* stream);
+/* the same for up to 4 modality branches in one launch (arrays of length njobs) */
+int ugn_binfc_fwd_multi(const float* const* feat, const float* const* w, float* const* out, const int* b, int njobs, void* stream);
+int ugn_binfc_bwd_multi(const float* const* feat, const float* const* w, const float* const* dout, float* const* dw,
+                        float* const* dfeat, const int* b, int njobs, void* stream);
 
 /* ---- gate (:51-54) + fMerge (:814,:1189).  outs/uses: HOST arrays of nmod device pointers; x_m [62,b,256],
  * use_m [b].  fused [62,b,256]; sel uint8 (selected modality). */

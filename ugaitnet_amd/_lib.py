@@ -38,6 +38,13 @@ PROTOTYPES = {
     "ugn_conv3x3_dgrad_wino_multi": (_i, [C.POINTER(_p)] * 7 + [C.POINTER(_i), _i, _i, _i, _i, _i, _p]),
     "ugn_conv3x3_wgrad_wino_multi": (_i, [C.POINTER(_p)] * 4 + [C.POINTER(_i), _i, _i, _i, _i, _p, _sz, _i, _p]),
     "ugn_scale": (_i, [_p, _f, _sz, _p]),
+    "ugn_setmax_fwd_multi": (_i, [C.POINTER(_p)] * 4 + [C.POINTER(_i), _i, _i, _sz, _p]),
+    "ugn_setmax_bwd_multi": (_i, [C.POINTER(_p)] * 4 + [C.POINTER(_i), _i, _i, _sz, _i, _p]),
+    "ugn_lrelu_bwd_multi": (_i, [C.POINTER(_p)] * 3 + [C.POINTER(_sz), _i, _p]),
+    "ugn_hpp_fwd_multi": (_i, [C.POINTER(_p)] * 3 + [C.POINTER(_i), _i, _p]),
+    "ugn_hpp_bwd_multi": (_i, [C.POINTER(_p)] * 6 + [C.POINTER(_i), _i, _p]),
+    "ugn_binfc_fwd_multi": (_i, [C.POINTER(_p)] * 3 + [C.POINTER(_i), _i, _p]),
+    "ugn_binfc_bwd_multi": (_i, [C.POINTER(_p)] * 5 + [C.POINTER(_i), _i, _p]),
     "ugn_conv3x3_dgrad_wino_routed": (_i, [_p, _p, _p, _p, _p, _i, _p, _i, _i, _i, _i, _p]),
     "ugn_conv3x3_dgrad_wino_pair": (_i, [C.POINTER(_p)] * 7 + [C.POINTER(_i), _i, _i, _i, _p]),
     "ugn_conv3x3_fwd_wino_bf16": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),

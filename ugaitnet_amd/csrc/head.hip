@@ -18,10 +18,23 @@ constexpr int FC_BT = 24;   // samples per pass (the reference batch per GPU)
 // out[k][b][o] = sum_i feat[k][b][i] * W[k][i][o].  Workgroup (bin k, output quarter oq): 256 threads = 64 outputs x 4
 // input quarters, so a thread streams 32 weights instead of 128 and 248 workgroups instead of 62 share the 8 MB of weights;
 // the four partial sums are combined in a fixed order through LDS (bitwise reproducible).
-__global__ __launch_bounds__(256) void binfc_fwd_kernel(const float* __restrict__ feat, const float* __restrict__ w,
-                                                        float* __restrict__ out, int bsz) {
+// (blockIdx.z = job: the per-bin FCs of up to kFcJobs modality branches in one launch)
+constexpr int kFcJobs = 4;
+struct FcJobs {
+  const float* feat[kFcJobs];
+  const float* w[kFcJobs];
+  const float* dout[kFcJobs];
+  float* out[kFcJobs];       // fwd: out; bwd: dW
+  float* dfeat[kFcJobs];
+  int b[kFcJobs];
+};
+__global__ __launch_bounds__(256) void binfc_fwd_kernel(const FcJobs jt) {
   __shared__ float sF[FC_BT][FEAT];          // 12 KB
   __shared__ float sR[3][FC_BT][64];         // partials of input quarters 1..3
+  const float* __restrict__ feat = jt.feat[blockIdx.z];
+  const float* __restrict__ w = jt.w[blockIdx.z];
+  float* __restrict__ out = jt.out[blockIdx.z];
+  const int bsz = jt.b[blockIdx.z];
   const int k = blockIdx.x, oq = blockIdx.y, ol = threadIdx.x & 63, iq = threadIdx.x >> 6;
   const float* wk = w + ((size_t)k * FEAT + iq * 32) * HID + oq * 64 + ol;
   for (int b0 = 0; b0 < bsz; b0 += FC_BT) {
@@ -59,9 +72,13 @@ constexpr int FCB_IQ = 32;   // input features per workgroup (grid.y = 128 / FCB
 
 // dW[k][i][o] = sum_b feat[k][b][i] * dout[k][b][o];  dfeat[k][b][i] = sum_o dout[k][b][o] * W[k][i][o].
 // Workgroup (k, iq) owns input features i in [32*iq, 32*iq + 32): 248 workgroups instead of 62.
-__global__ __launch_bounds__(256) void binfc_bwd_kernel(const float* __restrict__ feat, const float* __restrict__ w,
-                                                        const float* __restrict__ dout, float* __restrict__ dw,
-                                                        float* __restrict__ dfeat, int bsz) {
+__global__ __launch_bounds__(256) void binfc_bwd_kernel(const FcJobs jt) {
+  const float* __restrict__ feat = jt.feat[blockIdx.z];
+  const float* __restrict__ w = jt.w[blockIdx.z];
+  const float* __restrict__ dout = jt.dout[blockIdx.z];
+  float* __restrict__ dw = jt.out[blockIdx.z];
+  float* __restrict__ dfeat = jt.dfeat[blockIdx.z];
+  const int bsz = jt.b[blockIdx.z];
   __shared__ float sF[FCB_BT][FCB_IQ];      // 2 KB
   __shared__ float sD[FCB_BT][HID];         // 16 KB
   __shared__ float sW[FCB_IQ][HID + 1];     // 32.9 KB: this workgroup's slice of W[k]
@@ -490,19 +507,40 @@ __global__ void adam_dev_kernel(float* __restrict__ p, const float* __restrict__
 
 }  // namespace
 
-extern "C" int ugn_binfc_fwd(const float* feat, const float* w, float* out, int b, void* stream) {
-  UGN_REQUIRE(feat && w && out && b > 0, "ugn_binfc_fwd: bad arguments");
-  hipLaunchKernelGGL(binfc_fwd_kernel, dim3(NBINS, HID / 64), dim3(256), 0, (hipStream_t)stream, feat, w, out, b);
+extern "C" int ugn_binfc_fwd_multi(const float* const* feat, const float* const* w, float* const* out, const int* b, int njobs,
+                                   void* stream) {
+  UGN_REQUIRE(feat && w && out && b && njobs >= 1 && njobs <= kFcJobs, "ugn_binfc_fwd_multi: bad arguments (1..%d jobs)", kFcJobs);
+  FcJobs jt = {};
+  for (int j = 0; j < njobs; ++j) {
+    UGN_REQUIRE(feat[j] && w[j] && out[j] && b[j] > 0, "ugn_binfc_fwd_multi: bad job %d", j);
+    jt.feat[j] = feat[j]; jt.w[j] = w[j]; jt.out[j] = out[j]; jt.b[j] = b[j];
+  }
+  hipLaunchKernelGGL(binfc_fwd_kernel, dim3(NBINS, HID / 64, njobs), dim3(256), 0, (hipStream_t)stream, jt);
   UGN_CHECK_LAUNCH("binfc_fwd");
+  return 0;
+}
+
+extern "C" int ugn_binfc_fwd(const float* feat, const float* w, float* out, int b, void* stream) {
+  return ugn_binfc_fwd_multi(&feat, &w, &out, &b, 1, stream);
+}
+
+extern "C" int ugn_binfc_bwd_multi(const float* const* feat, const float* const* w, const float* const* dout, float* const* dw,
+                                   float* const* dfeat, const int* b, int njobs, void* stream) {
+  UGN_REQUIRE(feat && w && dout && dw && dfeat && b && njobs >= 1 && njobs <= kFcJobs,
+              "ugn_binfc_bwd_multi: bad arguments (1..%d jobs)", kFcJobs);
+  FcJobs jt = {};
+  for (int j = 0; j < njobs; ++j) {
+    UGN_REQUIRE(feat[j] && w[j] && dout[j] && dw[j] && dfeat[j] && b[j] > 0, "ugn_binfc_bwd_multi: bad job %d", j);
+    jt.feat[j] = feat[j]; jt.w[j] = w[j]; jt.dout[j] = dout[j]; jt.out[j] = dw[j]; jt.dfeat[j] = dfeat[j]; jt.b[j] = b[j];
+  }
+  hipLaunchKernelGGL(binfc_bwd_kernel, dim3(NBINS, FEAT / FCB_IQ, njobs), dim3(256), 0, (hipStream_t)stream, jt);
+  UGN_CHECK_LAUNCH("binfc_bwd");
   return 0;
 }
 
 extern "C" int ugn_binfc_bwd(const float* feat, const float* w, const float* dout, float* dw, float* dfeat, int b,
                              void* stream) {
-  UGN_REQUIRE(feat && w && dout && dw && dfeat && b > 0, "ugn_binfc_bwd: bad arguments");
-  hipLaunchKernelGGL(binfc_bwd_kernel, dim3(NBINS, FEAT / FCB_IQ), dim3(256), 0, (hipStream_t)stream, feat, w, dout, dw, dfeat, b);
-  UGN_CHECK_LAUNCH("binfc_bwd");
-  return 0;
+  return ugn_binfc_bwd_multi(&feat, &w, &dout, &dw, &dfeat, &b, 1, stream);
 }
 
 extern "C" int ugn_gate_fuse_fwd(const float* const* outs_host, const float* const* uses_host, int nmod, int mode,

@@ -6,21 +6,39 @@ namespace {
 
 constexpr int MAXL = 32;  // frames kept in registers by the backward (L = 25 in the reference)
 
-__global__ void setmax_fwd_kernel(const float4* __restrict__ p, const float4* __restrict__ addend,
-                                  float4* __restrict__ m, float4* __restrict__ sum_out, int l, size_t s4) {
+// Up to kPoolJobs tensors of one shape per launch (blockIdx.z): the modality branches run the same pooling steps on their own
+// tensors, and one launch for all of them costs what one of them costs when the tensors are small (5 clips per GPU).
+constexpr int kPoolJobs = 4;
+struct SetmaxJobs {
+  const float4* p[kPoolJobs];
+  const float4* addend[kPoolJobs];   // fwd: optional addend [b,s]; bwd: optional second gradient path [b,l,s]
+  const float4* dm[kPoolJobs];       // bwd only
+  float4* m[kPoolJobs];              // fwd: maxima; bwd: out
+  float4* sum_out[kPoolJobs];
+  int b[kPoolJobs];
+};
+
+__device__ __forceinline__ float4 max4(float4 a, float4 v) {
+  return make_float4(fmaxf(a.x, v.x), fmaxf(a.y, v.y), fmaxf(a.z, v.z), fmaxf(a.w, v.w));
+}
+
+__global__ void setmax_fwd_kernel(const SetmaxJobs jt, int l, size_t s4) {
   const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= s4) return;
-  const int b = blockIdx.y;
-  const float4* src = p + (size_t)b * l * s4 + e;
+  const int j = blockIdx.z, b = blockIdx.y;
+  if (e >= s4 || b >= jt.b[j]) return;
+  const float4* src = jt.p[j] + (size_t)b * l * s4 + e;
   float4 mx = src[0];
-  for (int t = 1; t < l; ++t) {
-    const float4 v = src[(size_t)t * s4];
-    mx.x = fmaxf(mx.x, v.x); mx.y = fmaxf(mx.y, v.y); mx.z = fmaxf(mx.z, v.z); mx.w = fmaxf(mx.w, v.w);
+  int t = 1;
+  for (; t + 6 <= l; t += 6) {    // six independent 16-byte loads in flight per lane (L = 25: 1 + 4 x 6)
+    const float4 v0 = src[(size_t)t * s4], v1 = src[(size_t)(t + 1) * s4], v2 = src[(size_t)(t + 2) * s4];
+    const float4 v3 = src[(size_t)(t + 3) * s4], v4 = src[(size_t)(t + 4) * s4], v5 = src[(size_t)(t + 5) * s4];
+    mx = max4(max4(max4(mx, v0), max4(v1, v2)), max4(max4(v3, v4), v5));
   }
-  m[(size_t)b * s4 + e] = mx;
-  if (addend) {
-    const float4 a = addend[(size_t)b * s4 + e];
-    sum_out[(size_t)b * s4 + e] = make_float4(mx.x + a.x, mx.y + a.y, mx.z + a.z, mx.w + a.w);
+  for (; t < l; ++t) mx = max4(mx, src[(size_t)t * s4]);
+  jt.m[j][(size_t)b * s4 + e] = mx;
+  if (jt.addend[j]) {
+    const float4 a = jt.addend[j][(size_t)b * s4 + e];
+    jt.sum_out[j][(size_t)b * s4 + e] = make_float4(mx.x + a.x, mx.y + a.y, mx.z + a.z, mx.w + a.w);
   }
 }
 
@@ -58,11 +76,18 @@ __global__ __launch_bounds__(128) void setmax_fwd_cnt_kernel(const float4* __res
 }
 
 // out = g * LeakyReLU'(act) elementwise (act is a LeakyReLU OUTPUT: same sign as its input)
-__global__ void lrelu_bwd_kernel(const float4* __restrict__ g, const float4* __restrict__ act, float4* __restrict__ out, size_t n4) {
+struct EltJobs {
+  const float4* a[kPoolJobs];
+  const float4* b[kPoolJobs];
+  float4* out[kPoolJobs];
+  size_t n4[kPoolJobs];
+};
+__global__ void lrelu_bwd_kernel(const EltJobs jt) {
   const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= n4) return;
-  const float4 x = g[e], a = act[e];
-  out[e] = make_float4(x.x * ugn_lrelu_slope(a.x), x.y * ugn_lrelu_slope(a.y), x.z * ugn_lrelu_slope(a.z), x.w * ugn_lrelu_slope(a.w));
+  const int j = blockIdx.y;
+  if (e >= jt.n4[j]) return;
+  const float4 x = jt.a[j][e], a = jt.b[j][e];
+  jt.out[j][e] = make_float4(x.x * ugn_lrelu_slope(a.x), x.y * ugn_lrelu_slope(a.y), x.z * ugn_lrelu_slope(a.z), x.w * ugn_lrelu_slope(a.w));
 }
 
 __global__ void scale_kernel(float* __restrict__ x, float f, size_t n) {
@@ -87,13 +112,14 @@ __device__ __forceinline__ float sm_route(float v, float mx, float g, float add,
 // `addend` (optional, may alias `out`): a second gradient path into p (the data gradient of the next frame-level layer);
 // out = (routed + addend) * LeakyReLU'(p): the Add of the two paths and the activation derivative cost one pass here instead
 // of two extra operand streams in that data gradient's epilogue.
-__global__ __launch_bounds__(128) void setmax_bwd_kernel(const float4* __restrict__ p, const float4* __restrict__ dm,
-                                                         const float4* addend, float4* out, int l, size_t s4, int lrelu) {
+__global__ __launch_bounds__(128) void setmax_bwd_kernel(const SetmaxJobs jt, int l, size_t s4, int lrelu) {
   const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= s4) return;
-  const int b = blockIdx.y;
-  const float4* src = p + (size_t)b * l * s4 + e;
-  float4* dst = out + (size_t)b * l * s4 + e;
+  const int j = blockIdx.z, b = blockIdx.y;
+  if (e >= s4 || b >= jt.b[j]) return;
+  const float4* dm = jt.dm[j];
+  const float4* addend = jt.addend[j];
+  const float4* src = jt.p[j] + (size_t)b * l * s4 + e;
+  float4* dst = jt.m[j] + (size_t)b * l * s4 + e;
   float4 v[MAXL];
 #pragma unroll
   for (int t = 0; t < MAXL; ++t)
@@ -126,9 +152,23 @@ __global__ __launch_bounds__(128) void setmax_bwd_kernel(const float4* __restric
 __device__ __constant__ int kHppOff[5] = {0, 2, 6, 14, 30};
 
 // one thread per (b, tensor, channel): 256 positions, coalesced over the 128 channels.
-__global__ void hpp_fwd_kernel(const float* __restrict__ a, const float* __restrict__ s3, float* __restrict__ feat, int bsz) {
+struct HppJobs {
+  const float* a[kPoolJobs];
+  const float* s3[kPoolJobs];
+  const float* b4[kPoolJobs];
+  const float* dfeat[kPoolJobs];
+  float* feat[kPoolJobs];      // fwd output
+  float* dm3[kPoolJobs];
+  float* dzb4[kPoolJobs];
+  int b[kPoolJobs];
+};
+__global__ void hpp_fwd_kernel(const HppJobs jt) {
   const int c = threadIdx.x & 127, t = threadIdx.x >> 7;  // 256 threads: tensor 0 = a, 1 = s3
-  const int b = blockIdx.x;
+  const int b = blockIdx.x, j = blockIdx.y, bsz = jt.b[j];
+  if (b >= bsz) return;
+  const float* a = jt.a[j];
+  const float* s3 = jt.s3[j];
+  float* feat = jt.feat[j];
   const float* src = (t ? s3 : a) + (size_t)b * 256 * 128 + c;
   float sum[16], mx[16];
 #pragma unroll
@@ -166,12 +206,17 @@ __global__ void hpp_fwd_kernel(const float* __restrict__ a, const float* __restr
 // owns the 16 positions of one finest strip for BOTH tensors (a and s3), so dm3 = dL/da + dL/ds3 needs no exchange.
 // Level l (0..4) has 2^l strips of 256 / 2^l positions; strip maxima and tie counts of the coarser levels are combined
 // through LDS.  mean: g / n ; max: g / (#maxima) to every maximum (TF reduce_max gradient).
-__global__ __launch_bounds__(512) void hpp_bwd_kernel(const float* __restrict__ a, const float* __restrict__ s3,
-                                                      const float* __restrict__ b4, const float* __restrict__ dfeat,
-                                                      float* __restrict__ dm3, float* __restrict__ dzb4, int bsz) {
+__global__ __launch_bounds__(512) void hpp_bwd_kernel(const HppJobs jt) {
   __shared__ float sMx[2][16][32];
   __shared__ float sCnt[2][5][16][32];
-  const int b = blockIdx.x >> 2, cc = blockIdx.x & 3;
+  const int b = blockIdx.x >> 2, cc = blockIdx.x & 3, j = blockIdx.y, bsz = jt.b[j];
+  if (b >= bsz) return;      // (whole workgroup: no barrier is skipped by a part of it)
+  const float* a = jt.a[j];
+  const float* s3 = jt.s3[j];
+  const float* b4 = jt.b4[j];
+  const float* dfeat = jt.dfeat[j];
+  float* dm3 = jt.dm3[j];
+  float* dzb4 = jt.dzb4[j];
   const int st = threadIdx.x >> 5, lc = threadIdx.x & 31, c = cc * 32 + lc;
   const size_t base = ((size_t)b * 256 + st * 16) * 128 + c;
   float v[2][16];
@@ -231,15 +276,29 @@ __global__ __launch_bounds__(512) void hpp_bwd_kernel(const float* __restrict__ 
 
 }  // namespace
 
-extern "C" int ugn_setmax_fwd(const float* p, const float* addend, float* m, float* sum_out, int b, int l, size_t s,
-                              void* stream) {
-  UGN_REQUIRE(p && m && b > 0 && l > 0 && s > 0 && s % 4 == 0, "ugn_setmax_fwd: bad arguments (s must be a multiple of 4)");
-  UGN_REQUIRE(!addend || sum_out, "ugn_setmax_fwd: addend needs sum_out");
+extern "C" int ugn_setmax_fwd_multi(const float* const* p, const float* const* addend, float* const* m, float* const* sum_out,
+                                    const int* b, int njobs, int l, size_t s, void* stream) {
+  UGN_REQUIRE(p && m && b && njobs >= 1 && njobs <= kPoolJobs, "ugn_setmax_fwd_multi: bad arguments (1..%d jobs)", kPoolJobs);
+  UGN_REQUIRE(l > 0 && s > 0 && s % 4 == 0, "ugn_setmax_fwd_multi: s must be a multiple of 4, l > 0");
+  SetmaxJobs jt = {};
+  int bmax = 0;
+  for (int j = 0; j < njobs; ++j) {
+    UGN_REQUIRE(p[j] && m[j] && b[j] > 0, "ugn_setmax_fwd_multi: null pointer or b <= 0 in job %d", j);
+    const float* ad = addend ? addend[j] : nullptr;
+    UGN_REQUIRE(!ad || (sum_out && sum_out[j]), "ugn_setmax_fwd_multi: addend needs sum_out");
+    jt.p[j] = (const float4*)p[j]; jt.addend[j] = (const float4*)ad; jt.m[j] = (float4*)m[j];
+    jt.sum_out[j] = ad ? (float4*)sum_out[j] : nullptr; jt.b[j] = b[j];
+    if (b[j] > bmax) bmax = b[j];
+  }
   const size_t s4 = s / 4;
-  hipLaunchKernelGGL(setmax_fwd_kernel, dim3((unsigned)((s4 + 255) / 256), b), dim3(256), 0, (hipStream_t)stream,
-                     (const float4*)p, (const float4*)addend, (float4*)m, (float4*)sum_out, l, s4);
+  hipLaunchKernelGGL(setmax_fwd_kernel, dim3((unsigned)((s4 + 127) / 128), bmax, njobs), dim3(128), 0, (hipStream_t)stream, jt, l, s4);
   UGN_CHECK_LAUNCH("setmax_fwd");
   return 0;
+}
+
+extern "C" int ugn_setmax_fwd(const float* p, const float* addend, float* m, float* sum_out, int b, int l, size_t s,
+                              void* stream) {
+  return ugn_setmax_fwd_multi(&p, &addend, &m, &sum_out, &b, 1, l, s, stream);
 }
 
 extern "C" int ugn_setmax_fwd_cnt(const float* p, const float* addend, float* m, float* sum_out, float* cnt, int b, int l,
@@ -254,12 +313,23 @@ extern "C" int ugn_setmax_fwd_cnt(const float* p, const float* addend, float* m,
   return 0;
 }
 
-extern "C" int ugn_lrelu_bwd(const float* g, const float* act, float* out, size_t n, void* stream) {
-  UGN_REQUIRE(g && act && out && n > 0 && n % 4 == 0, "ugn_lrelu_bwd: bad arguments (n must be a multiple of 4)");
-  hipLaunchKernelGGL(lrelu_bwd_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const float4*)g,
-                     (const float4*)act, (float4*)out, n / 4);
+extern "C" int ugn_lrelu_bwd_multi(const float* const* g, const float* const* act, float* const* out, const size_t* n, int njobs,
+                                   void* stream) {
+  UGN_REQUIRE(g && act && out && n && njobs >= 1 && njobs <= kPoolJobs, "ugn_lrelu_bwd_multi: bad arguments (1..%d jobs)", kPoolJobs);
+  EltJobs jt = {};
+  size_t nmax = 0;
+  for (int j = 0; j < njobs; ++j) {
+    UGN_REQUIRE(g[j] && act[j] && out[j] && n[j] > 0 && n[j] % 4 == 0, "ugn_lrelu_bwd_multi: bad job %d (n must be a multiple of 4)", j);
+    jt.a[j] = (const float4*)g[j]; jt.b[j] = (const float4*)act[j]; jt.out[j] = (float4*)out[j]; jt.n4[j] = n[j] / 4;
+    if (n[j] / 4 > nmax) nmax = n[j] / 4;
+  }
+  hipLaunchKernelGGL(lrelu_bwd_kernel, dim3((unsigned)((nmax + 255) / 256), njobs), dim3(256), 0, (hipStream_t)stream, jt);
   UGN_CHECK_LAUNCH("lrelu_bwd");
   return 0;
+}
+
+extern "C" int ugn_lrelu_bwd(const float* g, const float* act, float* out, size_t n, void* stream) {
+  return ugn_lrelu_bwd_multi(&g, &act, &out, &n, 1, stream);
 }
 
 extern "C" int ugn_scale(float* x, float factor, size_t n, void* stream) {
@@ -277,28 +347,68 @@ extern "C" int ugn_div(const float* a, const float* b, float* out, size_t n, voi
   return 0;
 }
 
-extern "C" int ugn_setmax_bwd(const float* p, const float* dm, const float* addend, float* out, int b, int l, size_t s,
-                              int apply_lrelu, void* stream) {
-  UGN_REQUIRE(p && dm && out && b > 0 && s > 0 && s % 4 == 0, "ugn_setmax_bwd: bad arguments");
+extern "C" int ugn_setmax_bwd_multi(const float* const* p, const float* const* dm, const float* const* addend, float* const* out,
+                                    const int* b, int njobs, int l, size_t s, int apply_lrelu, void* stream) {
+  UGN_REQUIRE(p && dm && out && b && njobs >= 1 && njobs <= kPoolJobs, "ugn_setmax_bwd_multi: bad arguments (1..%d jobs)", kPoolJobs);
+  UGN_REQUIRE(s > 0 && s % 4 == 0, "ugn_setmax_bwd_multi: s must be a multiple of 4");
   UGN_REQUIRE(l > 0 && l <= MAXL, "ugn_setmax_bwd: l must be in 1..%d (got %d)", MAXL, l);
+  SetmaxJobs jt = {};
+  int bmax = 0;
+  for (int j = 0; j < njobs; ++j) {
+    UGN_REQUIRE(p[j] && dm[j] && out[j] && b[j] > 0, "ugn_setmax_bwd_multi: null pointer or b <= 0 in job %d", j);
+    jt.p[j] = (const float4*)p[j]; jt.dm[j] = (const float4*)dm[j]; jt.addend[j] = (const float4*)(addend ? addend[j] : nullptr);
+    jt.m[j] = (float4*)out[j]; jt.b[j] = b[j];
+    if (b[j] > bmax) bmax = b[j];
+  }
   const size_t s4 = s / 4;
-  hipLaunchKernelGGL(setmax_bwd_kernel, dim3((unsigned)((s4 + 127) / 128), b), dim3(128), 0, (hipStream_t)stream,
-                     (const float4*)p, (const float4*)dm, (const float4*)addend, (float4*)out, l, s4, apply_lrelu);
+  hipLaunchKernelGGL(setmax_bwd_kernel, dim3((unsigned)((s4 + 127) / 128), bmax, njobs), dim3(128), 0, (hipStream_t)stream, jt, l,
+                     s4, apply_lrelu);
   UGN_CHECK_LAUNCH("setmax_bwd");
   return 0;
 }
 
-extern "C" int ugn_hpp_fwd(const float* a, const float* s3, float* feat, int b, void* stream) {
-  UGN_REQUIRE(a && s3 && feat && b > 0, "ugn_hpp_fwd: bad arguments");
-  hipLaunchKernelGGL(hpp_fwd_kernel, dim3(b), dim3(256), 0, (hipStream_t)stream, a, s3, feat, b);
+extern "C" int ugn_setmax_bwd(const float* p, const float* dm, const float* addend, float* out, int b, int l, size_t s,
+                              int apply_lrelu, void* stream) {
+  return ugn_setmax_bwd_multi(&p, &dm, &addend, &out, &b, 1, l, s, apply_lrelu, stream);
+}
+
+extern "C" int ugn_hpp_fwd_multi(const float* const* a, const float* const* s3, float* const* feat, const int* b, int njobs,
+                                 void* stream) {
+  UGN_REQUIRE(a && s3 && feat && b && njobs >= 1 && njobs <= kPoolJobs, "ugn_hpp_fwd_multi: bad arguments (1..%d jobs)", kPoolJobs);
+  HppJobs jt = {};
+  int bmax = 0;
+  for (int j = 0; j < njobs; ++j) {
+    UGN_REQUIRE(a[j] && s3[j] && feat[j] && b[j] > 0, "ugn_hpp_fwd_multi: bad job %d", j);
+    jt.a[j] = a[j]; jt.s3[j] = s3[j]; jt.feat[j] = feat[j]; jt.b[j] = b[j];
+    if (b[j] > bmax) bmax = b[j];
+  }
+  hipLaunchKernelGGL(hpp_fwd_kernel, dim3(bmax, njobs), dim3(256), 0, (hipStream_t)stream, jt);
   UGN_CHECK_LAUNCH("hpp_fwd");
+  return 0;
+}
+
+extern "C" int ugn_hpp_fwd(const float* a, const float* s3, float* feat, int b, void* stream) {
+  return ugn_hpp_fwd_multi(&a, &s3, &feat, &b, 1, stream);
+}
+
+extern "C" int ugn_hpp_bwd_multi(const float* const* a, const float* const* s3, const float* const* b4, const float* const* dfeat,
+                                 float* const* dm3, float* const* dzb4, const int* b, int njobs, void* stream) {
+  UGN_REQUIRE(a && s3 && b4 && dfeat && dm3 && dzb4 && b && njobs >= 1 && njobs <= kPoolJobs,
+              "ugn_hpp_bwd_multi: bad arguments (1..%d jobs)", kPoolJobs);
+  HppJobs jt = {};
+  int bmax = 0;
+  for (int j = 0; j < njobs; ++j) {
+    UGN_REQUIRE(a[j] && s3[j] && b4[j] && dfeat[j] && dm3[j] && dzb4[j] && b[j] > 0, "ugn_hpp_bwd_multi: bad job %d", j);
+    jt.a[j] = a[j]; jt.s3[j] = s3[j]; jt.b4[j] = b4[j]; jt.dfeat[j] = dfeat[j]; jt.dm3[j] = dm3[j]; jt.dzb4[j] = dzb4[j];
+    jt.b[j] = b[j];
+    if (b[j] > bmax) bmax = b[j];
+  }
+  hipLaunchKernelGGL(hpp_bwd_kernel, dim3(bmax * 4, njobs), dim3(512), 0, (hipStream_t)stream, jt);
+  UGN_CHECK_LAUNCH("hpp_bwd");
   return 0;
 }
 
 extern "C" int ugn_hpp_bwd(const float* a, const float* s3, const float* b4, const float* dfeat, float* dm3, float* dzb4,
                            int b, void* stream) {
-  UGN_REQUIRE(a && s3 && b4 && dfeat && dm3 && dzb4 && b > 0, "ugn_hpp_bwd: bad arguments");
-  hipLaunchKernelGGL(hpp_bwd_kernel, dim3(b * 4), dim3(512), 0, (hipStream_t)stream, a, s3, b4, dfeat, dm3, dzb4, b);
-  UGN_CHECK_LAUNCH("hpp_bwd");
-  return 0;
+  return ugn_hpp_bwd_multi(&a, &s3, &b4, &dfeat, &dm3, &dzb4, &b, 1, stream);
 }

@@ -410,7 +410,9 @@ def forward_merged(encs, xs):
     p2s, i2s = ops.conv3x3_fwd_wino_multi(a1s, [e.uf["a2"] for e in encs], 32, True,
                                           [B(e, e.act, "p2", (g[2], 32, 32, 32)) for e, g in zip(encs, geo)],
                                           [B(e, e.act, "i2", (g[2], 32, 32, 32), U8) for e, g in zip(encs, geo)], bf16=bf16)
-    m1s = [ops.setmax_fwd(p2, b, l, m=B(e, e.act, "m1", (b, 32, 32, 32))) for e, p2, (b, l, n) in zip(encs, p2s, geo)]
+    bs, l0 = [g[0] for g in geo], geo[0][1]
+    assert all(g[1] == l0 for g in geo), "the modalities of a batch share the set length"
+    m1s = ops.setmax_fwd_multi(p2s, bs, l0, [B(e, e.act, "m1", (g[0], 32, 32, 32)) for e, g in zip(encs, geo)])
 
     def pair_layer(na, nb, xa, xb, cout, hw, pool, ka, kb, ia=None, ib=None):
         """frame-level layer `na` on xa and set-level twin `nb` on xb, all modalities: jobs = [frame..., set...]"""
@@ -428,18 +430,14 @@ def forward_merged(encs, xs):
 
     a3s, b1s = pair_layer("a3", "b1", p2s, m1s, 64, 32, False, "a3", "b1")
     p4s, q2s = pair_layer("a4", "b2", a3s, b1s, 64, 32, True, "p4", "q2", "i4", "j2")
-    s2s = []
-    for e, p4, q2, (b, l, n) in zip(encs, p4s, q2s, geo):
-        _, s2 = ops.setmax_fwd(p4, b, l, addend=q2, m=B(e, e.act, "m2", (b, 16, 16, 64)), sum_out=B(e, e.act, "s2", (b, 16, 16, 64)))
-        s2s.append(s2)
+    _, s2s = ops.setmax_fwd_multi(p4s, bs, l0, [B(e, e.act, "m2", (g[0], 16, 16, 64)) for e, g in zip(encs, geo)], addends=q2s,
+                                  sum_outs=[B(e, e.act, "s2", (g[0], 16, 16, 64)) for e, g in zip(encs, geo)])
     a5s, b3s = pair_layer("a5", "b3", p4s, s2s, 128, 16, False, "a5", "b3")
     a6s, b4s = pair_layer("a6", "b4", a5s, b3s, 128, 16, False, "a6", "b4")
-    outs = []
-    for e, a6, b4, (b, l, n) in zip(encs, a6s, b4s, geo):
-        m3, s3 = ops.setmax_fwd(a6, b, l, addend=b4, m=B(e, e.act, "m3", (b, 16, 16, 128)), sum_out=B(e, e.act, "s3", (b, 16, 16, 128)))
-        feat = ops.hpp_fwd(m3, s3, B(e, e.act, "feat", (NBINS, b, FEAT)))
-        outs.append(ops.binfc_fwd(feat, e.W("fc"), B(e, e.act, "out", (NBINS, b, HIDDEN))))
-    return outs
+    m3s, s3s = ops.setmax_fwd_multi(a6s, bs, l0, [B(e, e.act, "m3", (g[0], 16, 16, 128)) for e, g in zip(encs, geo)], addends=b4s,
+                                    sum_outs=[B(e, e.act, "s3", (g[0], 16, 16, 128)) for e, g in zip(encs, geo)])
+    feats = ops.hpp_fwd_multi(m3s, s3s, [B(e, e.act, "feat", (NBINS, g[0], FEAT)) for e, g in zip(encs, geo)])
+    return ops.binfc_fwd_multi(feats, [e.W("fc") for e in encs], [B(e, e.act, "out", (NBINS, g[0], HIDDEN)) for e, g in zip(encs, geo)])
 
 
 def backward_merged(encs, douts, scratches):
@@ -451,14 +449,12 @@ def backward_merged(encs, douts, scratches):
     k = len(encs)
     buf = lambda i, key, shape: encs[i]._buf(scratches[i], key, shape)
     R = range(k)
-    dz6, dzb4 = [], []
-    for i, e in enumerate(encs):
-        b, l, n = geo[i]
-        ops.binfc_bwd(A[i]["feat"], e.W("fc"), douts[i], e.G("fc"), buf(i, "dfeat", (NBINS, b, FEAT)))
-        dm3, d4 = ops.hpp_bwd(A[i]["m3"], A[i]["s3"], A[i]["b4"], scratches[i]["dfeat"], buf(i, "dm3", (b, 16, 16, 128)),
-                              buf(i, "dzb4", (b, 16, 16, 128)))
-        dz6.append(ops.setmax_bwd(A[i]["a6"], dm3, b, l, True, buf(i, "dz6", (n, 16, 16, 128))))
-        dzb4.append(d4)
+    bs, l0 = [g[0] for g in geo], geo[0][1]
+    _, dfeats = ops.binfc_bwd_multi([a["feat"] for a in A], [e.W("fc") for e in encs], douts, [e.G("fc") for e in encs],
+                                    [buf(i, "dfeat", (NBINS, geo[i][0], FEAT)) for i in R])
+    dm3, dzb4 = ops.hpp_bwd_multi([a["m3"] for a in A], [a["s3"] for a in A], [a["b4"] for a in A], dfeats,
+                                  [buf(i, "dm3", (geo[i][0], 16, 16, 128)) for i in R], [buf(i, "dzb4", (geo[i][0], 16, 16, 128)) for i in R])
+    dz6 = ops.setmax_bwd_multi([a["a6"] for a in A], dm3, bs, l0, True, [buf(i, "dz6", (geo[i][2], 16, 16, 128)) for i in R])
 
     def wgrad(na, nb, xa, xb, dza, dzb, cout, ia=None, ib=None):
         with _side(dev):
@@ -480,8 +476,8 @@ def backward_merged(encs, douts, scratches):
     # gradient of p4, * LeakyReLU'(p4)), a small elementwise kernel the set-level one (* LeakyReLU'(q2))
     raw4, ds2 = dgrad("a5", "b3", dz5, dzb3, 16, 64, 128, [buf(i, "g4", (geo[i][2], 16, 16, 64)) for i in R],
                       [buf(i, "ds2", (geo[i][0], 16, 16, 64)) for i in R])
-    dq2 = [ops.lrelu_bwd(ds2[i], A[i]["q2"], buf(i, "dq2", (geo[i][0], 16, 16, 64))) for i in R]
-    dp4 = [ops.setmax_bwd(A[i]["p4"], ds2[i], geo[i][0], geo[i][1], True, out=raw4[i], addend=raw4[i]) for i in R]
+    dq2 = ops.lrelu_bwd_multi(ds2, [a["q2"] for a in A], [buf(i, "dq2", (geo[i][0], 16, 16, 64)) for i in R])
+    dp4 = ops.setmax_bwd_multi([a["p4"] for a in A], ds2, bs, l0, True, raw4, addends=raw4)
     # block 2 (a3, a4) with block 1 of the global branch (b1, b2); a4 / b2 are pooled
     i4, j2 = [a["i4"] for a in A], [a["j2"] for a in A]
     wgrad("a4", "b2", [a["a3"] for a in A], [a["b1"] for a in A], dp4, dq2, 64, i4, j2)
@@ -490,7 +486,7 @@ def backward_merged(encs, douts, scratches):
     wgrad("a3", "b1", [a["p2"] for a in A], [a["m1"] for a in A], dz3, dzb1, 64)
     raw2, dm1 = dgrad("a3", "b1", dz3, dzb1, 32, 32, 64, [buf(i, "g2", (geo[i][2], 32, 32, 32)) for i in R],
                       [buf(i, "dm1", (geo[i][0], 32, 32, 32)) for i in R])
-    dp2 = [ops.setmax_bwd(A[i]["p2"], dm1[i], geo[i][0], geo[i][1], True, out=raw2[i], addend=raw2[i]) for i in R]
+    dp2 = ops.setmax_bwd_multi([a["p2"] for a in A], dm1, bs, l0, True, raw2, addends=raw2)
     # block 1 (a1, a2)
     i2 = [a["i2"] for a in A]
     with _side(dev):

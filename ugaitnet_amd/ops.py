@@ -388,6 +388,67 @@ def setmax_bwd(p, dm, b, l, apply_lrelu, out=None, addend=None):
     return out
 
 
+# ---- the per-branch pooling / FC steps for several modality branches in one launch (lists of equal length; the tensors of
+# a list share their trailing shape, the clip counts may differ)
+def setmax_fwd_multi(ps, bs, l, ms, addends=None, sum_outs=None):
+    for t in list(ps) + list(ms):
+        _chk(t)
+    s = ps[0].numel() // (bs[0] * l)
+    nb = sum(4.0 * s * b * (l + 1 + (2 if addends is not None else 0)) for b in bs)
+    call("ugn_setmax_fwd_multi", ptr_array(ps), _opt_ptr_array(addends), ptr_array(ms), _opt_ptr_array(sum_outs), _int_array(bs),
+         len(ps), l, s, _stream(), label="setmax_fwd[%s x %d x %d]" % ("+".join(str(b) for b in bs), l, s),
+         work=_hbm_work("setmax_fwd_kernel", nb))
+    return (ms, sum_outs) if addends is not None else ms
+
+
+def setmax_bwd_multi(ps, dms, bs, l, apply_lrelu, outs, addends=None):
+    for t in list(ps) + list(dms) + list(outs):
+        _chk(t)
+    s = ps[0].numel() // (bs[0] * l)
+    nb = sum(4.0 * s * b * (2 * l + 1 + (l if addends is not None else 0)) for b in bs)
+    call("ugn_setmax_bwd_multi", ptr_array(ps), ptr_array(dms), _opt_ptr_array(addends), ptr_array(outs), _int_array(bs), len(ps),
+         l, s, int(bool(apply_lrelu)), _stream(),
+         label="setmax_bwd[%s x %d x %d%s]" % ("+".join(str(b) for b in bs), l, s, " +addend" if addends is not None else ""),
+         work=_hbm_work("setmax_bwd_kernel", nb))
+    return outs
+
+
+def lrelu_bwd_multi(gs, acts, outs):
+    for t in list(gs) + list(acts) + list(outs):
+        _chk(t)
+    ns = (C.c_size_t * len(gs))(*[g.numel() for g in gs])
+    call("ugn_lrelu_bwd_multi", ptr_array(gs), ptr_array(acts), ptr_array(outs), ns, len(gs), _stream())
+    return outs
+
+
+def hpp_fwd_multi(as_, s3s, feats):
+    bs = [a.shape[0] for a in as_]
+    call("ugn_hpp_fwd_multi", ptr_array([_chk(a) for a in as_]), ptr_array([_chk(t) for t in s3s]), ptr_array(feats), _int_array(bs),
+         len(as_), _stream())
+    return feats
+
+
+def hpp_bwd_multi(as_, s3s, b4s, dfeats, dm3s, dzb4s):
+    bs = [a.shape[0] for a in as_]
+    call("ugn_hpp_bwd_multi", ptr_array([_chk(a) for a in as_]), ptr_array([_chk(t) for t in s3s]), ptr_array([_chk(t) for t in b4s]),
+         ptr_array([_chk(t) for t in dfeats]), ptr_array(dm3s), ptr_array(dzb4s), _int_array(bs), len(as_), _stream())
+    return dm3s, dzb4s
+
+
+def binfc_fwd_multi(feats, ws, outs):
+    bs = [f.shape[1] for f in feats]
+    call("ugn_binfc_fwd_multi", ptr_array([_chk(f) for f in feats]), ptr_array([_chk(w) for w in ws]), ptr_array(outs),
+         _int_array(bs), len(feats), _stream())
+    return outs
+
+
+def binfc_bwd_multi(feats, ws, douts, dws, dfeats):
+    bs = [f.shape[1] for f in feats]
+    call("ugn_binfc_bwd_multi", ptr_array([_chk(f) for f in feats]), ptr_array([_chk(w) for w in ws]),
+         ptr_array([_chk(d) for d in douts]), ptr_array(dws), ptr_array(dfeats), _int_array(bs), len(feats), _stream())
+    return dws, dfeats
+
+
 def hpp_fwd(a, s3, feat=None):
     b = a.shape[0]
     feat = torch.empty((62, b, 128), dtype=F32, device=a.device) if feat is None else feat
