@@ -225,6 +225,14 @@ int ugn_triplet_indices_host(const int32_t* labels_host, int m, int32_t* hp_host
  * dsig = grad_scale/(62*num_k) * d(sum_k)/dsig (written, not accumulated).  m <= 128. */
 int ugn_triplet_fwd_bwd(const float* sig, const int32_t* hp, const int32_t* hn, int kp, int kn, float margin,
                         float* bin_loss, float* bin_num, float* dsig, float grad_scale, int m, void* stream);
+/* Batch-HARD triplet loss per bin, the mode `compile_hard` names (nets/mj_uwyhNets_ba.py:1301-1306, tfa.losses.TripletHardLoss
+ * with soft = False and L2 distances): per anchor the largest distance to another sample of its identity and the smallest to a
+ * sample of another identity (tfa's masked maximum / minimum, including their empty-set values), L_bin = mean_a max(hp - hn +
+ * margin, 0), mean over the 62 bins.  labels: int32 [m] in device memory.  bin_num = anchors with a positive hinge.  The
+ * reference itself never calls compile_hard, and tfa's loss takes [batch, dim] embeddings: applying it per bin is this
+ * build's reading of north_star's "batch-hard triplet". */
+int ugn_triplet_hard_fwd_bwd(const float* sig, const int32_t* labels, float margin, float* bin_loss, float* bin_num,
+                             float* dsig, float grad_scale, int m, void* stream);
 
 /* ---- keras Adam (mains/mj_trainUWYHGaitNet_DataGen_CasiaB.py:227): p -= lr_t * m / (sqrt(v) + eps) -------- */
 int ugn_adam_step(float* p, const float* g, float* m, float* v, size_t n, float lr_t, float b1, float b2,

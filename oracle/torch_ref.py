@@ -101,6 +101,23 @@ def triplet(labels, emb, margin, return_counts=False):
     return mean.mean()
 
 
+def triplet_hard(labels, emb, margin):
+    """tfa.losses.TripletHardLoss (soft=False, L2) per bin, written with torch ops the way tensorflow_addons writes it
+    (pairwise_distance with a zeroed diagonal, _masked_maximum / _masked_minimum); autograd supplies the gradient."""
+    n, m, _ = emb.shape
+    lab = labels.reshape(m, 1)
+    adj = lab == lab.t()
+    eye = torch.eye(m, dtype=emb.dtype)
+    pd = batch_dist(emb) * (1.0 - eye)
+    mneg = (~adj).to(emb.dtype)
+    mpos = adj.to(emb.dtype) - eye
+    rmax = pd.amax(dim=2, keepdim=True)
+    hn = ((pd - rmax) * mneg).amin(dim=2, keepdim=True) + rmax
+    rmin = pd.amin(dim=2, keepdim=True)
+    hp = ((pd - rmin) * mpos).amax(dim=2, keepdim=True) + rmin
+    return torch.clamp_min(hp - hn + margin, 0.0).mean(dim=(1, 2)).mean()
+
+
 def forward(xs, uses, params, mode='sign_max', multimodal=True):
     outs = [branch(x, bp) for x, bp in zip(xs, params['branches'])]
     if multimodal:

@@ -271,6 +271,58 @@ def triplet_all_bwd(emb, aux, dloss=1.0):
     return 2 * (rows[:, :, None] * emb - np.matmul(s, emb))
 
 
+def triplet_hard(labels, emb, margin):
+    """Batch-hard triplet loss per bin: tfa.losses.TripletHardLoss (soft=False, L2), the loss `compile_hard` names
+    (nets/mj_uwyhNets_ba.py:1301-1306), restated from tensorflow_addons' published triplet_hard_loss and applied to each of the
+    n bins of emb [n,m,d] (tfa itself takes [batch, dim]; the reference never calls compile_hard), mean over bins.
+      pdist: as batch_dist, diagonal set to zero
+      hard_positives = masked_maximum(pdist, adjacency - I)  = max((pdist - rowmin) * mask) + rowmin
+      hard_negatives = masked_minimum(pdist, 1 - adjacency)  = min((pdist - rowmax) * mask) + rowmax
+      loss = mean_a max(hp - hn + margin, 0)
+    Returns (loss, aux)."""
+    n, m, _ = emb.shape
+    dt = emb.dtype.type
+    lab = np.asarray(labels).reshape(-1)
+    adj = lab[:, None] == lab[None, :]
+    dist = batch_dist(emb) * (1 - np.eye(m, dtype=emb.dtype))[None]
+    mpos = (adj & ~np.eye(m, dtype=bool)).astype(emb.dtype)[None]
+    mneg = (~adj).astype(emb.dtype)[None]
+    rmin = dist.min(axis=2, keepdims=True)
+    rmax = dist.max(axis=2, keepdims=True)
+    vp = (dist - rmin) * mpos
+    vn = (dist - rmax) * mneg
+    hp = vp.max(axis=2, keepdims=True) + rmin
+    hn = vn.min(axis=2, keepdims=True) + rmax
+    h = np.maximum(hp - hn + dt(margin), dt(0))[:, :, 0]
+    return h.mean(axis=1).mean(), dict(dist=dist, vp=vp, vn=vn, mpos=mpos, mneg=mneg, h=h, num=(h > 0).sum(axis=1).astype(np.float32))
+
+
+def triplet_hard_bwd(emb, aux, dloss=1.0):
+    """Gradient of triplet_hard: reduce_max / reduce_min split their gradient equally among tied extrema (TF), the mask
+    multiplies it, the row minimum / maximum receive the balance; then through the distances as in triplet_all_bwd."""
+    n, m, _ = emb.shape
+    dist, vp, vn, mpos, mneg = aux['dist'], aux['vp'], aux['vn'], aux['mpos'], aux['mneg']
+    act = (aux['h'] > 0).astype(emb.dtype)[:, :, None] * emb.dtype.type(dloss / (m * n))
+    ep = (vp == vp.max(axis=2, keepdims=True)).astype(emb.dtype)
+    ep = ep / ep.sum(axis=2, keepdims=True)
+    en = (vn == vn.min(axis=2, keepdims=True)).astype(emb.dtype)
+    en = en / en.sum(axis=2, keepdims=True)
+    emin = (dist == dist.min(axis=2, keepdims=True)).astype(emb.dtype)
+    emin = emin / emin.sum(axis=2, keepdims=True)
+    emax = (dist == dist.max(axis=2, keepdims=True)).astype(emb.dtype)
+    emax = emax / emax.sum(axis=2, keepdims=True)
+    gp = ep * mpos                     # d hp / d dist through (dist - rmin) * mask
+    gp = gp + emin * (1 - gp.sum(axis=2, keepdims=True))      # ... and through rmin (-sum of the above + 1)
+    gn = en * mneg
+    gn = gn + emax * (1 - gn.sum(axis=2, keepdims=True))
+    dmat = act * (gp - gn) * (1 - np.eye(m, dtype=emb.dtype))[None]
+    with np.errstate(divide='ignore', invalid='ignore'):
+        dq = np.where(dist > 0, dmat / (2 * dist), 0).astype(emb.dtype)
+    s_ = dq + dq.transpose(0, 2, 1)
+    rows = s_.sum(axis=2)
+    return 2 * (rows[:, :, None] * emb - np.matmul(s_, emb))
+
+
 def adam_step(p, g, m, v, t, lr=1e-4, b1=0.9, b2=0.999, eps=1e-7):
     """keras Adam (mains/mj_trainUWYHGaitNet_DataGen_CasiaB.py:227), t = 1-based step.
     As in TF's resource-apply kernel the hyper-parameters are cast to the variable dtype first, so
@@ -422,14 +474,18 @@ def model_forward(xs, uses, params, mode='sign_max', multimodal=True):
 
 
 def model_loss_and_grads(xs, uses, labels, onehot, params, margin=0.2, loss_weights=(1.0, 0.1),
-                         mode='sign_max', multimodal=True):
+                         mode='sign_max', multimodal=True, triplet_mode='all'):
     """Total loss L = w0*triplet + w1*xent (nets/mj_uwyhNets_ba.py:865,933) and all parameter grads."""
     r = model_forward(xs, uses, params, mode, multimodal)
     sig = r['signature']
     dt = sig.dtype.type
-    tri, aux = triplet_all(labels, sig, margin)
+    if triplet_mode == 'hard':      # the loss compile_hard would install (nets/mj_uwyhNets_ba.py:1301-1306)
+        tri, aux = triplet_hard(labels, sig, margin)
+        dsig = triplet_hard_bwd(sig, aux, dloss=loss_weights[0])
+    else:
+        tri, aux = triplet_all(labels, sig, margin)
+        dsig = triplet_all_bwd(sig, aux, dloss=loss_weights[0])
     r['triplet'], r['tri_aux'] = tri, aux
-    dsig = triplet_all_bwd(sig, aux, dloss=loss_weights[0])
     total = dt(loss_weights[0]) * tri
     grads = dict(branches=[])
     if 'head' in params:

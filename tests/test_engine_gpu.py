@@ -99,6 +99,27 @@ def test_ragged_batches_and_set_lengths(dev, b, l, ids):
     assert not bad, bad
 
 
+def test_batch_hard_mode_end_to_end(dev):
+    """triplet_mode='hard' (what UWYHSemiNet3Mods.compile_hard installs): loss and every parameter gradient against the oracle."""
+    kinds, b, l, ncls = ('of', 'gray', 'depth'), 8, 3, 6
+    xs, uses, labels, onehot = make_batch(kinds, b, l, ncls, ids=4, seed=3)
+    p64 = oracle_params(kinds, ncls)
+    core = build(kinds, ncls, "sign_max", p64, triplet_mode="hard")
+    r, g = O.model_loss_and_grads([x.astype(np.float64) for x in xs], [u.astype(np.float64) for u in uses], labels,
+                                  onehot.astype(np.float64), p64, margin=0.2, loss_weights=(1.0, 0.1), triplet_mode="hard")
+    core.forward_backward(xs, uses, labels, onehot)
+    ls = core.losses()
+    assert abs(ls['triplet'] - float(r['triplet'])) <= 2e-5 and abs(ls['loss'] - float(r['loss'])) <= 3e-5
+    got = core.get_grads_numpy()
+    bad = {}
+    for mi in range(3):
+        for k, ref in g['branches'][mi].items():
+            e = rell2(got['branches'][mi][k], ref)
+            if e > 5e-3:
+                bad['m%d.%s' % (mi, k)] = e
+    assert not bad, bad
+
+
 def test_single_modality_graph(dev):
     """BL-single gray: no gate, no normalisation, raw [62,B,256] to both heads (nets/mj_uwyhNets_ba.py:893-903)."""
     kinds, b, l, ncls = ('gray',), 6, 5, 12

@@ -506,6 +506,25 @@ def test_triplet(dev, labels):
     close(dsig, O.triplet_all_bwd(sig.astype(np.float64), aux), 2e-4, "triplet dsig")
 
 
+@pytest.mark.parametrize("labels", [np.repeat(np.arange(12), 2), np.repeat(np.arange(4), 10), np.array([0, 0, 0, 1, 2, 2, 3]),
+                                    np.array([7, 7, 7, 7]), np.arange(5)])
+def test_triplet_hard(dev, labels):
+    """Batch-hard triplet loss per bin (compile_hard's TripletHardLoss): balanced and ragged label sets, an identity with one
+    sample (no positive), a batch with one identity (no negative), all-singleton identities."""
+    from ugaitnet_amd import ops
+    rng = np.random.default_rng(13)
+    m = labels.shape[0]
+    f = rng.normal(size=(62, m, 256)).astype(np.float32)
+    sig, _ = O.l2norm_batch(f)
+    sig = (sig * 0.6).astype(np.float32)
+    loss_ref, aux = O.triplet_hard(labels, sig.astype(np.float64), 0.2)
+    bl, bn, dsig = ops.triplet_hard_fwd_bwd(T(sig, dev), T(labels.astype(np.int32), dev), 0.2, 1.0)
+    fragile = (np.abs(aux["h"]) < 1e-5).sum(axis=1) + ((aux["h"] == 0).sum(axis=1) > 0) * 0   # hinges within rounding of 0
+    assert np.all(np.abs(bn.cpu().numpy() - aux["num"]) <= fragile + (np.abs(aux["h"] - 0.0) < 1e-5).sum(axis=1))
+    assert abs(float(bl.mean()) - loss_ref) <= 2e-5 * max(1.0, abs(loss_ref))
+    close(dsig, O.triplet_hard_bwd(sig.astype(np.float64), aux), 2e-4, "triplet hard dsig")
+
+
 def test_triplet_rejects_indivisible_labels(dev):
     from ugaitnet_amd import ops
     with pytest.raises(ValueError):

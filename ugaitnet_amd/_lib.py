@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libugaitnet_hip.so")
+# UGN_LIB (experiments only): another build of the same sources (python -m ugaitnet_amd.build --variant NAME ...)
+LIB_PATH = os.environ.get("UGN_LIB") or os.path.join(_HERE, "libugaitnet_hip.so")
 
 FUSE_MODES = {"sign_max": 0, "max": 1, "avg": 2}
 
@@ -73,6 +74,7 @@ PROTOTYPES = {
     "ugn_head_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
     "ugn_triplet_indices_host": (_i, [_p, _i, _p, _p, C.POINTER(_i), C.POINTER(_i)]),
     "ugn_triplet_fwd_bwd": (_i, [_p, _p, _p, _i, _i, _f, _p, _p, _p, _f, _i, _p]),
+    "ugn_triplet_hard_fwd_bwd": (_i, [_p, _p, _f, _p, _p, _p, _f, _i, _p]),
     "ugn_assemble_modality": (_i, [_p, _i, _p, _i, _i, _f, _f, _f, _f, _f, _f, _p, _p, _p]),
     "ugn_knn_ws": (_sz, [_i, _i]),
     "ugn_knn_predict": (_i, [_p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _sz, _p]),

@@ -27,11 +27,11 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def _compile(src):
-    obj = os.path.join(OBJ, os.path.splitext(src)[0] + ".o")
+def _compile(src, objdir=None, extra=()):
+    obj = os.path.join(objdir or OBJ, os.path.splitext(src)[0] + ".o")
     path = os.path.join(CSRC, src)
     if _stale(obj, [path] + HEADERS):
-        cmd = [HIPCC] + FLAGS + (["-x", "hip"] if src.endswith(".cpp") else []) + ["-c", path, "-o", obj]
+        cmd = [HIPCC] + FLAGS + list(extra) + (["-x", "hip"] if src.endswith(".cpp") else []) + ["-c", path, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("hipcc failed for %s:\n%s" % (src, r.stderr))
@@ -39,13 +39,17 @@ def _compile(src):
     return obj, False
 
 
-def build(force=False, verbose=True):
-    os.makedirs(OBJ, exist_ok=True)
+def build(force=False, verbose=True, variant=None, extra=()):
+    """variant (experiments only): build libugaitnet_hip_<variant>.so with `extra` compiler flags into its own object directory;
+    ugaitnet_amd._lib loads it when UGN_LIB names it (tools/ab_ops.py times two builds side by side on one GPU box)."""
+    objdir = OBJ if variant is None else OBJ + "_" + variant
+    LIB = globals()["LIB"] if variant is None else os.path.join(HERE, "libugaitnet_hip_%s.so" % variant)
+    os.makedirs(objdir, exist_ok=True)
     if force:
-        for f in os.listdir(OBJ):
-            os.remove(os.path.join(OBJ, f))
+        for f in os.listdir(objdir):
+            os.remove(os.path.join(objdir, f))
     with ThreadPoolExecutor(max_workers=4) as ex:
-        res = list(ex.map(_compile, SOURCES))
+        res = list(ex.map(lambda src: _compile(src, objdir, extra), SOURCES))
     objs = [o for o, _ in res]
     if any(c for _, c in res) or _stale(LIB, objs):
         cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
@@ -60,4 +64,8 @@ def build(force=False, verbose=True):
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
+    args = [a for a in sys.argv[1:] if a != "--force"]
+    if args and args[0] == "--variant":      # python -m ugaitnet_amd.build --variant NAME -DFLAG ...
+        build(force="--force" in sys.argv, variant=args[1], extra=args[2:])
+    else:
+        build(force="--force" in sys.argv)

@@ -10,6 +10,12 @@
 
 namespace {
 
+#ifndef UGN_C5_WAVES
+#define UGN_C5_WAVES 4     // waves per SIMD the forward kernel is compiled for (measured: 4 and 6 equal, 8 spills)
+#endif
+#ifndef UGN_C5_GRID
+#define UGN_C5_GRID 1024   // persistent workgroups of the forward kernel (256 CUs x 4 workgroups of 256 threads)
+#endif
 constexpr int T5 = 16;          // 16x16 output tile
 constexpr int P5 = T5 + 4;      // 20x20 input patch
 constexpr int RAW = 60, DOM = 64;
@@ -32,64 +38,108 @@ __device__ __forceinline__ void stage_patch(float* sP, const float* __restrict__
   }
 }
 
+// Persistent form: gridDim.x workgroups stride over the n * 16 tiles.  The filter is staged once per workgroup; the raw patch
+// of the NEXT tile is fetched into registers before the current tile is multiplied and written to LDS after it, so the
+// global-load latency of the staging hides behind the MFMAs and the stores of the tile before.
 template <int CIN, bool SIGN>
-__global__ __launch_bounds__(256) void conv5x5_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                          float* __restrict__ a1, uint32_t* __restrict__ sign_out) {
+__global__ __launch_bounds__(256, UGN_C5_WAVES) void conv5x5_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                                        float* __restrict__ a1, uint32_t* __restrict__ sign_out,
+                                                                        int ntiles) {
   constexpr int K = 25 * CIN, KP = (K + 1) / 2;  // k-pairs
-  __shared__ __attribute__((aligned(16))) float sP[P5 * P5 * CIN];
+  constexpr int PE = P5 * P5;                     // patch pixels
+  constexpr int PPT = (PE + 255) / 256;           // patch pixels per thread (2)
+  __shared__ __attribute__((aligned(16))) float sP[PE * CIN];
   __shared__ __attribute__((aligned(16))) float sW[2 * KP * 32];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
-  const int img = blockIdx.x >> 4, trem = blockIdx.x & 15;
-  const int ty0 = (trem >> 2) * T5, tx0 = (trem & 3) * T5;
 
-  stage_patch<CIN>(sP, x, img, ty0, tx0, tid);
   for (int e = tid; e < 2 * KP * 32; e += 256) sW[e] = e < K * 32 ? w[e] : 0.f;
-  __syncthreads();
-
+  // patch pixel e = tid + 256 * j of tile t: (yy, xx) = (e / 20, e % 20) -> raw pixel (ty0 - 4 + yy, tx0 - 4 + xx)
+  int pyy[PPT], pxx[PPT];
+#pragma unroll
+  for (int j = 0; j < PPT; ++j) {
+    const int e = tid + 256 * j;
+    pyy[j] = e / P5;
+    pxx[j] = e % P5;
+  }
+  float pv[PPT][CIN];
+  auto fetch = [&](int tile) {
+    const int img = tile >> 4, trem = tile & 15;
+    const int ty0 = (trem >> 2) * T5, tx0 = (trem & 3) * T5;
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) {
+      const int ry = ty0 - 4 + pyy[j], rx = tx0 - 4 + pxx[j];
+      const bool ok = tid + 256 * j < PE && ry >= 0 && ry < RAW && rx >= 0 && rx < RAW;
+      const size_t o = (((size_t)img * RAW + ry) * RAW + rx) * CIN;
+      if constexpr (CIN == 1) {
+        pv[j][0] = ok ? x[o] : 0.f;
+      } else {
+        float2 v = make_float2(0.f, 0.f);
+        if (ok) v = *reinterpret_cast<const float2*>(x + o);
+        pv[j][0] = v.x;
+        pv[j][1] = v.y;
+      }
+    }
+  };
   const int py = (li >> 1) & 1, px = 2 * (li >> 2) + (li & 1);
-  f32x16 acc[2];
-#pragma unroll
-  for (int m = 0; m < 2; ++m)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
   int pb[2];
 #pragma unroll
   for (int m = 0; m < 2; ++m) pb[m] = ((2 * (wave * 2 + m) + py) * P5 + px) * CIN + (CIN == 2 ? lh : 0);
 
+  int tile = blockIdx.x;
+  if (tile < ntiles) fetch(tile);
+  for (; tile < ntiles; tile += gridDim.x) {
+    __syncthreads();            // the previous tile's MFMAs have read sP
 #pragma unroll
-  for (int s = 0; s < KP; ++s) {
-    int off;
-    if constexpr (CIN == 2) {
-      off = ((s / 5) * P5 + (s % 5)) * 2;  // tap s, channel = lane half
-    } else {
-      const int k0 = 2 * s, k1 = (2 * s + 1 < K) ? 2 * s + 1 : K - 1;
-      const int o0 = (k0 / 5) * P5 + (k0 % 5), o1 = (k1 / 5) * P5 + (k1 % 5);
-      off = lh ? o1 : o0;
-    }
-    const float b = sW[(2 * s + lh) * 32 + li];
+    for (int j = 0; j < PPT; ++j)
+      if (tid + 256 * j < PE) {
 #pragma unroll
-    for (int m = 0; m < 2; ++m) acc[m] = ugn_mfma(sP[pb[m] + off], b, acc[m]);
-  }
-#pragma unroll
-  for (int m = 0; m < 2; ++m) {
-    const int mbi = wave * 2 + m;
-    uint32_t myword = 0;   // SIGN: lane li < 16 of each half collects the word of register r = li
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int y = ty0 + 2 * mbi + ((r >> 1) & 1);
-      const int xx = tx0 + 2 * (lh + 2 * (r >> 2)) + (r & 1);
-      a1[(((size_t)img * DOM + y) * DOM + xx) * 32 + li] = ugn_lrelu(acc[m][r]);
-      if constexpr (SIGN) {   // bit c of a pixel's word = (a1 > 0): all the layer's backward needs of a1 besides its values
-        const unsigned long long bal = __ballot(acc[m][r] > 0.f);   // lanes 0..31: pixel of lh = 0, 32..63: lh = 1
-        if (li == r) myword = (uint32_t)(bal >> (32 * lh));
+        for (int c = 0; c < CIN; ++c) sP[(tid + 256 * j) * CIN + c] = pv[j][c];
       }
+    __syncthreads();
+    const int nt = tile + (int)gridDim.x;
+    if (nt < ntiles) fetch(nt);
+    const int img = tile >> 4, trem = tile & 15;
+    const int ty0 = (trem >> 2) * T5, tx0 = (trem & 3) * T5;
+    f32x16 acc[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < KP; ++s) {
+      int off;
+      if constexpr (CIN == 2) {
+        off = ((s / 5) * P5 + (s % 5)) * 2;  // tap s, channel = lane half
+      } else {
+        const int k0 = 2 * s, k1 = (2 * s + 1 < K) ? 2 * s + 1 : K - 1;
+        const int o0 = (k0 / 5) * P5 + (k0 % 5), o1 = (k1 / 5) * P5 + (k1 % 5);
+        off = lh ? o1 : o0;
+      }
+      const float b = sW[(2 * s + lh) * 32 + li];
+#pragma unroll
+      for (int m = 0; m < 2; ++m) acc[m] = ugn_mfma(sP[pb[m] + off], b, acc[m]);
     }
-    if constexpr (SIGN) {
-      if (li < 16) {   // one store per half wave and row block instead of sixteen single-lane ones
-        const int y = ty0 + 2 * mbi + ((li >> 1) & 1);
-        const int xx = tx0 + 2 * (lh + 2 * (li >> 2)) + (li & 1);
-        sign_out[((size_t)img * DOM + y) * DOM + xx] = myword;
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      const int mbi = wave * 2 + m;
+      uint32_t myword = 0;   // SIGN: lane li < 16 of each half collects the word of register r = li
+      float* __restrict__ orow = a1 + (((size_t)img * DOM + ty0 + 2 * mbi) * DOM + tx0 + 2 * lh) * 32 + li;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        // pixel (2 * mbi + ((r >> 1) & 1), 2 * (lh + 2 * (r >> 2)) + (r & 1)) of the tile: compile-time offset from orow
+        orow[(((r >> 1) & 1) * DOM + 4 * (r >> 2) + (r & 1)) * 32] = ugn_lrelu(acc[m][r]);
+        if constexpr (SIGN) {   // bit c of a pixel's word = (a1 > 0): all the layer's backward needs of a1 besides its values
+          const unsigned long long bal = __ballot(acc[m][r] > 0.f);   // lanes 0..31: pixel of lh = 0, 32..63: lh = 1
+          if (li == r) myword = (uint32_t)(bal >> (32 * lh));
+        }
+      }
+      if constexpr (SIGN) {
+        if (li < 16) {   // one store per half wave and row block instead of sixteen single-lane ones
+          const int y = ty0 + 2 * mbi + ((li >> 1) & 1);
+          const int xx = tx0 + 2 * (lh + 2 * (li >> 2)) + (li & 1);
+          sign_out[((size_t)img * DOM + y) * DOM + xx] = myword;
+        }
       }
     }
   }
@@ -252,7 +302,9 @@ extern "C" int ugn_conv5x5_in_fwd(const float* x, const float* w, float* a1, uin
   UGN_REQUIRE(x && w && a1 && n > 0, "ugn_conv5x5_in_fwd: null pointer or n <= 0");
   UGN_REQUIRE(cin == 1 || cin == 2, "ugn_conv5x5_in_fwd: cin must be 1 or 2 (got %d)", cin);
   hipStream_t st = (hipStream_t)stream;
-#define UGN_C5F(C_, S_) hipLaunchKernelGGL((conv5x5_fwd_kernel<C_, S_>), dim3(n * 16), dim3(256), 0, st, x, w, a1, a1_sign)
+  const int ntiles = n * 16;
+  const int grid = ntiles < UGN_C5_GRID ? ntiles : UGN_C5_GRID;
+#define UGN_C5F(C_, S_) hipLaunchKernelGGL((conv5x5_fwd_kernel<C_, S_>), dim3(grid), dim3(256), 0, st, x, w, a1, a1_sign, ntiles)
   if (cin == 1) {
     if (a1_sign) UGN_C5F(1, true); else UGN_C5F(1, false);
   } else {

@@ -370,23 +370,13 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
 }
 
 // ------------------------------------------------------------------------------------------------------
-// batch-all triplet loss: one workgroup per bin, Gram/distance matrix in LDS (m <= 128)
-// ------------------------------------------------------------------------------------------------------
 constexpr int TR_DC = 32;  // feature chunk staged in LDS
 
-__global__ __launch_bounds__(256) void triplet_kernel(const float* __restrict__ sig, const int32_t* __restrict__ hp,
-                                                      const int32_t* __restrict__ hn, int kp, int kn, float margin,
-                                                      float* __restrict__ bin_loss, float* __restrict__ bin_num,
-                                                      float* __restrict__ dsig, float grad_scale, int m) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* sD = smem;                 // [m*m] Gram -> distance -> S
-  float* sG = smem + m * m;         // [m*m] dL/d(dist) -> dL/d(sqdist)
-  float* sY = sG + m * m;           // [m][TR_DC+1]
-  __shared__ float sRed[4];
-  const int k = blockIdx.x, tid = threadIdx.x;
-  const float* Y = sig + (size_t)k * m * HID;
+// The part every triplet variant shares (nets/triplet_loss_all.py:70-77 `batch_dist`): Gram matrix of a bin's m embeddings in
+// LDS, then d_ij = sqrt(max(|y_i|^2 + |y_j|^2 - 2 y_i.y_j, 0)), exactly 0 where the argument is <= 0.  Leaves sD = distances,
+// sG = 0; sY is scratch ([m][TR_DC+1], its first m floats are reused as a vector afterwards).
+__device__ __forceinline__ void bin_distances(const float* __restrict__ Y, float* sD, float* sG, float* sY, int m, int tid) {
   const int mm = m * m;
-
   for (int p = tid; p < mm; p += 256) { sD[p] = 0.f; sG[p] = 0.f; }
   for (int d0 = 0; d0 < HID; d0 += TR_DC) {
     __syncthreads();
@@ -418,6 +408,55 @@ __global__ __launch_bounds__(256) void triplet_kernel(const float* __restrict__ 
     sD[p] = q > 0.f ? sqrtf(q) : 0.f;
   }
   __syncthreads();
+}
+
+// From sG = dL/d(dist) (unscaled) to dL/dY of the bin: dL/d(sqdist) = dL/d(dist) * scale / (2 dist) (0 where dist == 0),
+// S = dq + dq^T, dY_i = 2 * (rowsum_i * Y_i - sum_j S_ij Y_j); thread = feature d.
+__device__ __forceinline__ void bin_backprop(const float* __restrict__ Y, float* __restrict__ dY, float* sD, float* sG, float* sN,
+                                             float scale, int m, int tid) {
+  const int mm = m * m;
+  // dL/d(sqdist) = dL/d(dist) / (2 dist), 0 where dist == 0
+  for (int p = tid; p < mm; p += 256) {
+    const float d = sD[p];
+    sG[p] = d > 0.f ? sG[p] * scale / (2.f * d) : 0.f;
+  }
+  __syncthreads();
+  // S = dq + dq^T into sD; row sums into sN
+  for (int p = tid; p < mm; p += 256) {
+    const int i = p / m, j = p % m;
+    sD[p] = sG[p] + sG[j * m + i];
+  }
+  __syncthreads();
+  for (int i = tid; i < m; i += 256) {
+    float s = 0.f;
+    for (int j = 0; j < m; ++j) s += sD[i * m + j];
+    sN[i] = s;
+  }
+  __syncthreads();
+  // dY_i = 2 * (rows_i * Y_i - sum_j S_ij Y_j); thread = feature d
+  for (int i = 0; i < m; ++i) {
+    float acc = sN[i] * Y[(size_t)i * HID + tid];
+    for (int j = 0; j < m; ++j) acc = fmaf(-sD[i * m + j], Y[(size_t)j * HID + tid], acc);
+    dY[(size_t)i * HID + tid] = 2.f * acc;
+  }
+}
+
+// batch-all triplet loss: one workgroup per bin, Gram/distance matrix in LDS (m <= 128)
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void triplet_kernel(const float* __restrict__ sig, const int32_t* __restrict__ hp,
+                                                      const int32_t* __restrict__ hn, int kp, int kn, float margin,
+                                                      float* __restrict__ bin_loss, float* __restrict__ bin_num,
+                                                      float* __restrict__ dsig, float grad_scale, int m) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* sD = smem;                 // [m*m] Gram -> distance -> S
+  float* sG = smem + m * m;         // [m*m] dL/d(dist) -> dL/d(sqdist)
+  float* sY = sG + m * m;           // [m][TR_DC+1]
+  __shared__ float sRed[4];
+  const int k = blockIdx.x, tid = threadIdx.x;
+  const float* Y = sig + (size_t)k * m * HID;
+
+  bin_distances(Y, sD, sG, sY, m, tid);
+  float* sN = sY;
   // pass A: items (row r, positive a): hinge sum, active count, gradient of the positive distance
   float lsum = 0.f, lnum = 0.f;
   for (int it = tid; it < m * kp; it += 256) {
@@ -452,30 +491,70 @@ __global__ __launch_bounds__(256) void triplet_kernel(const float* __restrict__ 
   }
   const float scale = tnum != 0.f ? grad_scale / (tnum * (float)NBINS) : 0.f;
   __syncthreads();
-  // dL/d(sqdist) = dL/d(dist) / (2 dist), 0 where dist == 0
-  for (int p = tid; p < mm; p += 256) {
-    const float d = sD[p];
-    sG[p] = d > 0.f ? sG[p] * scale / (2.f * d) : 0.f;
+  bin_backprop(Y, dsig + (size_t)k * m * HID, sD, sG, sN, scale, m, tid);
+}
+
+// Batch-HARD triplet loss per bin (the mode nets/mj_uwyhNets_ba.py:1301-1306 `compile_hard` names: tfa.losses.TripletHardLoss,
+// soft = False, L2 distances), applied to each of the 62 bins of the signature like the batch-all loss and averaged over them:
+//   hp_a = max over the OTHER samples of a's identity of d_ap   (tfa _masked_maximum; no such sample: the row minimum = d_aa = 0)
+//   hn_a = min over the samples of other identities of d_an     (tfa _masked_minimum; no such sample: the row maximum)
+//   L_bin = mean_a max(hp_a - hn_a + margin, 0)
+// Gradient: reduce_max / reduce_min split it equally among tied extrema.  bin_num = anchors with a positive hinge.
+__global__ __launch_bounds__(256) void triplet_hard_kernel(const float* __restrict__ sig, const int32_t* __restrict__ labels,
+                                                           float margin, float* __restrict__ bin_loss,
+                                                           float* __restrict__ bin_num, float* __restrict__ dsig,
+                                                           float grad_scale, int m) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* sD = smem;
+  float* sG = smem + m * m;
+  float* sY = sG + m * m;
+  __shared__ float sRed[4];
+  const int k = blockIdx.x, tid = threadIdx.x;
+  const float* Y = sig + (size_t)k * m * HID;
+  bin_distances(Y, sD, sG, sY, m, tid);
+  float* sN = sY;
+  float lsum = 0.f, lnum = 0.f;
+  for (int a = tid; a < m; a += 256) {
+    const int la = labels[a];
+    float hp = -INFINITY, hn = INFINITY, rmax = -INFINITY;
+    int np = 0, nn = 0;
+    for (int j = 0; j < m; ++j) {
+      const float d = sD[a * m + j];
+      rmax = fmaxf(rmax, d);
+      if (labels[j] == la) { if (j != a) { hp = fmaxf(hp, d); ++np; } }
+      else { hn = fminf(hn, d); ++nn; }
+    }
+    if (np == 0) hp = 0.f;         // row minimum: the zeroed diagonal
+    if (nn == 0) hn = rmax;
+    const float h = hp - hn + margin;
+    if (h > 0.f) {
+      lsum += h;
+      lnum += 1.f;
+      float cp = 0.f, cn = 0.f;
+      for (int j = 0; j < m; ++j) {
+        const float d = sD[a * m + j];
+        const bool same = labels[j] == la;
+        if (np > 0 && same && j != a && d == hp) cp += 1.f;
+        if (nn > 0 ? (!same && d == hn) : (d == hn)) cn += 1.f;
+      }
+      for (int j = 0; j < m; ++j) {
+        const float d = sD[a * m + j];
+        const bool same = labels[j] == la;
+        float g = 0.f;
+        if (np > 0 && same && j != a && d == hp) g += 1.f / cp;
+        if (nn > 0 ? (!same && d == hn) : (d == hn)) g -= 1.f / cn;
+        sG[a * m + j] = g;
+      }
+    }
+  }
+  const float tsum = block_reduce(lsum, sRed, false);
+  const float tnum = block_reduce(lnum, sRed, false);
+  if (tid == 0) {
+    bin_loss[k] = tsum / (float)m;
+    bin_num[k] = tnum;
   }
   __syncthreads();
-  // S = dq + dq^T into sD; row sums into sN
-  for (int p = tid; p < mm; p += 256) {
-    const int i = p / m, j = p % m;
-    sD[p] = sG[p] + sG[j * m + i];
-  }
-  __syncthreads();
-  for (int i = tid; i < m; i += 256) {
-    float s = 0.f;
-    for (int j = 0; j < m; ++j) s += sD[i * m + j];
-    sN[i] = s;
-  }
-  __syncthreads();
-  // dY_i = 2 * (rows_i * Y_i - sum_j S_ij Y_j); thread = feature d
-  for (int i = 0; i < m; ++i) {
-    float acc = sN[i] * Y[(size_t)i * HID + tid];
-    for (int j = 0; j < m; ++j) acc = fmaf(-sD[i * m + j], Y[(size_t)j * HID + tid], acc);
-    dsig[((size_t)k * m + i) * HID + tid] = 2.f * acc;
-  }
+  bin_backprop(Y, dsig + (size_t)k * m * HID, sD, sG, sN, grad_scale / ((float)m * (float)NBINS), m, tid);
 }
 
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
@@ -655,6 +734,23 @@ extern "C" int ugn_triplet_fwd_bwd(const float* sig, const int32_t* hp, const in
   hipLaunchKernelGGL(triplet_kernel, dim3(NBINS), dim3(256), lds, (hipStream_t)stream, sig, hp, hn, kp, kn, margin,
                      bin_loss, bin_num, dsig, grad_scale, m);
   UGN_CHECK_LAUNCH("triplet");
+  return 0;
+}
+
+extern "C" int ugn_triplet_hard_fwd_bwd(const float* sig, const int32_t* labels, float margin, float* bin_loss, float* bin_num,
+                                        float* dsig, float grad_scale, int m, void* stream) {
+  UGN_REQUIRE(sig && labels && bin_loss && bin_num && dsig, "ugn_triplet_hard_fwd_bwd: null pointer");
+  UGN_REQUIRE(m >= 1 && m <= 128, "ugn_triplet_hard_fwd_bwd: batch size must be 1..128 (got %d)", m);
+  const int lds = (2 * m * m + m * (TR_DC + 1)) * (int)sizeof(float);
+  static int lds_set = 0;
+  if (lds > lds_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)triplet_hard_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) { ugn_set_error("triplet hard: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
+    lds_set = lds;
+  }
+  hipLaunchKernelGGL(triplet_hard_kernel, dim3(NBINS), dim3(256), lds, (hipStream_t)stream, sig, labels, margin, bin_loss, bin_num,
+                     dsig, grad_scale, m);
+  UGN_CHECK_LAUNCH("triplet hard");
   return 0;
 }
 

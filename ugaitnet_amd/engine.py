@@ -504,7 +504,7 @@ class GaitCore:
     def __init__(self, in_channels, nclasses=0, multimodal=None, fuse_mode="sign_max", margin=0.2,
                  loss_weights=(1.0, 1.0), device=None, seed=None, lr=1e-4, beta_1=0.9, beta_2=0.999, epsilon=1e-7,
                  process_group=None, world_size=1, skip_masked=False, dp_mode="replica", conv_precision="f32",
-                 force_collectives=False):
+                 force_collectives=False, triplet_mode="all"):
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         self.in_channels = tuple(int(c) for c in in_channels)
         self.nmod = len(self.in_channels)
@@ -514,6 +514,11 @@ class GaitCore:
         self.nclasses = int(nclasses)
         self.fuse_mode = fuse_mode
         self.margin = float(margin)
+        # "all": the compiled loss of the reference, batch-all with its literal flatten -> reshape (nets/triplet_loss_all.py:8-67);
+        # "hard": the batch-hard loss `compile_hard` names (nets/mj_uwyhNets_ba.py:1301-1306), per bin
+        if triplet_mode not in ("all", "hard"):
+            raise ValueError("triplet_mode must be 'all' or 'hard', got %r" % (triplet_mode,))
+        self.triplet_mode = triplet_mode
         lw = list(loss_weights) if isinstance(loss_weights, (list, tuple)) else [float(loss_weights)]
         self.loss_weights = (float(lw[0]), float(lw[1]) if len(lw) > 1 else float(lw[0]))
         self.lr, self.beta_1, self.beta_2, self.epsilon = float(lr), float(beta_1), float(beta_2), float(epsilon)
@@ -619,6 +624,21 @@ class GaitCore:
             self._tri_cache[key] = hit
         return hit
 
+    def _triplet(self, sig, labels, grad_scale):
+        b = sig.shape[1]
+        bufs = (self._buf("bin_loss", (NBINS,)), self._buf("bin_num", (NBINS,)), self._buf("dsig", (NBINS, b, HIDDEN)))
+        if self.triplet_mode == "hard":
+            lab = np.ascontiguousarray(np.asarray(labels).reshape(-1).astype(np.int32))
+            key = b"hard" + lab.tobytes()
+            dev_lab = self._tri_cache.get(key)
+            if dev_lab is None:
+                if len(self._tri_cache) > 64:
+                    self._tri_cache.clear()
+                dev_lab = self._tri_cache[key] = torch.from_numpy(lab).to(self.device)
+            return ops.triplet_hard_fwd_bwd(sig, dev_lab, self.margin, grad_scale, *bufs)
+        hp, hn, kp, kn = self._triplet_lists(labels)
+        return ops.triplet_fwd_bwd(sig, hp, hn, kp, kn, self.margin, grad_scale, *bufs)
+
     # ---- forward ----------------------------------------------------------------------------------------
     def forward(self, xs, uses=None, gather=False):
         """xs: list of [B,L,60,60,C_m]; uses: list of [B,1] / [B] (multimodal only).  Returns the signature [62,B,256];
@@ -717,11 +737,8 @@ class GaitCore:
         sig = self.forward(xs, uses, gather=self.global_batch)
         b = sig.shape[1]
         self._ar_pending = [] if (self.dp_active and AR_OVERLAP and not BRANCH_STREAMS) else None
-        hp, hn, kp, kn = self._triplet_lists(labels)
         w_tri, w_id = self.loss_weights
-        self.bin_loss, self.bin_num, dsig = ops.triplet_fwd_bwd(
-            sig, hp, hn, kp, kn, self.margin, w_tri, self._buf("bin_loss", (NBINS,)), self._buf("bin_num", (NBINS,)),
-            self._buf("dsig", (NBINS, b, HIDDEN)))
+        self.bin_loss, self.bin_num, dsig = self._triplet(sig, labels, w_tri)
         if self.nclasses > 0:
             oh = self._dev(onehot, (b, self.nclasses))
             self.head = ops.head_fwd(sig, self.store.p["head.wc"], self.store.p["head.bc"], oh, w_id / b,
@@ -789,10 +806,7 @@ class GaitCore:
             labels, onehot = self._gather_targets(labels, onehot)
         sig = self.forward(xs, uses, gather=self.global_batch)
         b = sig.shape[1]
-        hp, hn, kp, kn = self._triplet_lists(labels)
-        self.bin_loss, self.bin_num, _ = ops.triplet_fwd_bwd(
-            sig, hp, hn, kp, kn, self.margin, 0.0, self._buf("bin_loss", (NBINS,)), self._buf("bin_num", (NBINS,)),
-            self._buf("dsig", (NBINS, b, HIDDEN)))
+        self.bin_loss, self.bin_num, _ = self._triplet(sig, labels, 0.0)
         if self.nclasses > 0:
             oh = self._dev(onehot, (b, self.nclasses))
             self.head = ops.head_fwd(sig, self.store.p["head.wc"], self.store.p["head.bc"], oh, 0.0, self._head_bufs(b))

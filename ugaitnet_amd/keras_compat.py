@@ -134,6 +134,16 @@ class LayerHandle:
 _MOD_NAMES = ("of", "gray", "depth")
 
 
+class TripletHardLoss:
+    """Stand-in for tfa.losses.TripletHardLoss(margin) in `model.compile(loss=[...])`: selects the batch-hard kernel
+    (ugn_triplet_hard_fwd_bwd; soft=False, L2 distances, per bin of the [62,B,256] signature)."""
+
+    def __init__(self, margin=1.0, soft=False, distance_metric="L2", name=None):
+        if soft or distance_metric != "L2":
+            raise NotImplementedError("TripletHardLoss on the MI355X path: soft=False and distance_metric='L2' only")
+        self.margin = float(margin)
+
+
 class GaitSetModel:
     """What `UWYHSemiNet.build(..., gaitset=True)` returns: a compiled model driving the HIP engine."""
 
@@ -203,6 +213,15 @@ class GaitSetModel:
         raise ValueError("No such layer: %s" % name)
 
     def compile(self, optimizer=None, loss=None, loss_weights=None, metrics=None):
+        # `loss`: the first entry may be a TripletHardLoss marker (compile_hard, nets/mj_uwyhNets_ba.py:1301-1306) or the
+        # reference's triplet_loss(margin) closure; anything carrying `.margin` updates the margin
+        first = loss[0] if isinstance(loss, (list, tuple)) and loss else loss
+        if first is not None:
+            if getattr(first, "margin", None) is not None:
+                self.margin = self.core.margin = float(first.margin)
+            hard = isinstance(first, TripletHardLoss)
+            self.core.triplet_mode = "hard" if hard else "all"
+            self.loss[0] = ("TripletHardLoss(margin=%g)" if hard else "triplet_loss(margin=%g)") % self.margin
         if optimizer is not None:
             if not isinstance(optimizer, Adam):
                 raise NotImplementedError("only optimizers.Adam is implemented")

@@ -179,6 +179,14 @@ class UWYHSemiNet3Mods(UWYHSemiNet):
         return GaitSetModel(shapes, nclasses, loss_weights, margin, optimizer, fMerge, True, seed=seed)
 
     @staticmethod
+    def compile_hard(model, optimizer, loss_weights, margin):
+        """Reference :1301-1306: recompile with tfa.losses.TripletHardLoss(margin) in place of the batch-all loss."""
+        from ..keras_compat import TripletHardLoss
+        model.compile(optimizer=optimizer, loss=[TripletHardLoss(margin=margin)] + list(model.loss[1:]), loss_weights=loss_weights,
+                      metrics=[[], 'acc'])
+        return model
+
+    @staticmethod
     def build_or_load(input_shapes, number_convolutional_layers, filters_size, filters_numbers, ndense_units=512,
                       weight_decay=1e-4, dropout=0.4, optimizer=None, margin=0.2, nclasses=0, loss_weights=[1.0, 1.0],
                       initnet="", freeze_convs=False, use3D=False, smoothlabels=0, freeze_all=False, postriplet=1,

@@ -555,6 +555,18 @@ def triplet_fwd_bwd(sig, hp, hn, kp, kn, margin, grad_scale, bin_loss=None, bin_
     return bin_loss, bin_num, dsig
 
 
+def triplet_hard_fwd_bwd(sig, labels_dev, margin, grad_scale, bin_loss=None, bin_num=None, dsig=None):
+    """Batch-hard triplet loss per bin (tfa.losses.TripletHardLoss semantics); labels_dev: int32 [m] on the device."""
+    m = sig.shape[1]
+    dev = sig.device
+    bin_loss = torch.empty((62,), dtype=F32, device=dev) if bin_loss is None else bin_loss
+    bin_num = torch.empty((62,), dtype=F32, device=dev) if bin_num is None else bin_num
+    dsig = torch.empty_like(sig) if dsig is None else dsig
+    call("ugn_triplet_hard_fwd_bwd", ptr(_chk(sig)), ptr(_chk(labels_dev, torch.int32)), float(margin), ptr(bin_loss), ptr(bin_num),
+         ptr(dsig), float(grad_scale), m, _stream())
+    return bin_loss, bin_num, dsig
+
+
 def adam_step(p, g, m, v, lr_t, b1=0.9, b2=0.999, eps=1e-7, grad_scale=1.0):
     call("ugn_adam_step", ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), float(lr_t), float(b1), float(b2), float(eps),
          float(grad_scale), _stream(), work=_hbm_work("adam_kernel", 28.0 * p.numel()))
