@@ -78,8 +78,9 @@ __device__ __forceinline__ void wino_pack_one(const float* __restrict__ w, float
   const int nchunk = kc >> 5, chunk = k >> 5, kq = (k >> 1) & 3;
   float* dst;
   if (wino_tall(kc, nc)) {
-    // tall (conv3x3_wino_tall.hip): 8-channel groups gi = k >> 3, [gi][pt][kq][16 lj][cb][s], n = 16*cb + lj
-    dst = u + (size_t)(k >> 3) * 4096 + (kq * 16 + (n & 15)) * 4 + (n >> 4) * 2 + (k & 1);
+    // tall (conv3x3_wino_tall.hip): 8-channel groups gi = k >> 3, [gi][pt][kq][16 lj][cb][s], n = 2*lj + cb: a lane's two
+    // accumulator blocks are ADJACENT channels, so the epilogue moves 8 bytes per lane and 128-byte lines per 16 lanes
+    dst = u + (size_t)(k >> 3) * 4096 + (kq * 16 + pair_lj(n)) * 4 + pair_cb(n) * 2 + (k & 1);
     for (int r = 0; r < 4; ++r) {
       const float u0 = t[r][0], u1 = 0.5f * (t[r][0] + t[r][1] + t[r][2]), u2 = 0.5f * (t[r][0] - t[r][1] + t[r][2]),
                   u3 = t[r][2];
@@ -93,7 +94,8 @@ __device__ __forceinline__ void wino_pack_one(const float* __restrict__ w, float
   if (wino_wide_ex(kc, nc, bf, (mode & 3) == 3)) {
     // wide: a workgroup owns 64 output channels, a wave 2 blocks of 16 (cb); 8-channel groups (k = 32*chunk + 8*G + 2*kq + s):
     // [nsp64][chunk][G 0..3][pt][kq][32 = 16*cp + lj][cb][s]
-    const int nsp = n >> 6, nl = ((n >> 5) & 1) * 16 + (n & 15), cb = (n >> 4) & 1, G = (k >> 3) & 3;
+    // (channel 32*ch + 2*lj + cb of the workgroup's 64: adjacent channels in a lane's two blocks, see the tall layout)
+    const int nsp = n >> 6, nl = ((n >> 5) & 1) * 16 + pair_lj(n), cb = pair_cb(n), G = (k >> 3) & 3;
     dst = u + (((size_t)nsp * nchunk + chunk) * 4 + G) * SU + (kq * 32 + nl) * 4 + cb * 2 + (k & 1);
   } else {
     const int nsp = n >> 5, nl = n & 31, G = (k >> 4) & 1, st = ((k >> 3) & 1) * 2 + (k & 1);
@@ -541,14 +543,15 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const WinoJobs jt, const f
       }
     }
     const int ry0 = (rrem / RPX) * 16, rx0 = (rrem % RPX) * 16;
+    // the lane's first channel: block cb adds 16 channels, or 1 with the paired mapping (wino_common.h pair_lj / pair_cb)
+    const int co = nsp * (32 * NB) + ch * (16 * NB) + ((NB == 2 && UGN_EPI_PAIR) ? 2 * lj : lj);
+    float y[NB][4][4];     // [block][tile r][output (a,b) row-major]
+    unsigned o[4][4];      // element offsets inside the image: the image base is wave-uniform and rides in SGPRs
 #pragma unroll
-    for (int cb = 0; cb < NB; ++cb) {
-      const int co = nsp * (32 * NB) + ch * (16 * NB) + cb * 16 + lj;
-      float y[4][4];     // [tile r][output (a,b) row-major]
-      unsigned o[4][4];   // element offsets inside the image: the image base is wave-uniform and rides in SGPRs
+    for (int r = 0; r < 4; ++r) {
+      const int ti = 4 * kq + r, tr = ti >> 3, tc = ti & 7;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int ti = 4 * kq + r, tr = ti >> 3, tc = ti & 7;
+      for (int cb = 0; cb < NB; ++cb) {
         float sm[2][4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -557,73 +560,20 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const WinoJobs jt, const f
         }
 #pragma unroll
         for (int a = 0; a < 2; ++a) {
-          y[r][a * 2 + 0] = sm[a][0] + sm[a][1] + sm[a][2];
-          y[r][a * 2 + 1] = sm[a][1] - sm[a][2] - sm[a][3];
-        }
-        const int oy = ry0 + 2 * (trow0 + TRSTEP * tr), ox = rx0 + 2 * tc;
-        if constexpr (EPI == EPI_LRELU_POOL) {
-          constexpr int HP = HW / 2;
-          o[r][0] = (unsigned)(((oy / 2) * HP + ox / 2) * NCF + co);
-        } else {
-#pragma unroll
-          for (int q = 0; q < 4; ++q) o[r][q] = (unsigned)(((oy + (q >> 1)) * HW + ox + (q & 1)) * NCF + co);
+          y[cb][r][a * 2 + 0] = sm[a][0] + sm[a][1] + sm[a][2];
+          y[cb][r][a * 2 + 1] = sm[a][1] - sm[a][2] - sm[a][3];
         }
       }
+      const int oy = ry0 + 2 * (trow0 + TRSTEP * tr), ox = rx0 + 2 * tc;
       if constexpr (EPI == EPI_LRELU_POOL) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float best = ugn_lrelu(y[r][0]);
-          int bi = 0;
-#pragma unroll
-          for (int q = 1; q < 4; ++q) {
-            const float v = ugn_lrelu(y[r][q]);
-            if (v > best) { best = v; bi = q; }
-          }
-          out[o[r][0]] = best;
-          out_idx[o[r][0]] = (uint8_t)bi;
-        }
-      } else if constexpr (EPI == EPI_LRELU) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-          for (int q = 0; q < 4; ++q) out[o[r][q]] = ugn_lrelu(y[r][q]);
+        constexpr int HP = HW / 2;
+        o[r][0] = (unsigned)(((oy / 2) * HP + ox / 2) * NCF + co);
       } else {
-        float av[4][4], dv[4][4];
-        if constexpr (EFLAGS & 1) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) av[r][q] = act[o[r][q]];
-        }
-        if constexpr (EFLAGS & 2) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) dv[r][q] = addend[o[r][q]];
-        }
-        float mv[4][4], gv[4][4];
-        if constexpr (EFLAGS & 8) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              mv[r][q] = sm_m[o[r][q]];
-              gv[r][q] = sm_g[o[r][q]];
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            float v = y[r][q];
-            if constexpr (EFLAGS & 2) v += dv[r][q];
-            if constexpr (EFLAGS & 8) v += av[r][q] == mv[r][q] ? gv[r][q] : 0.f;   // set-max gradient -> the frames holding the maximum
-            if constexpr (EFLAGS & 4) raw_out[o[r][q]] = v;
-            if constexpr (EFLAGS & 1) v *= ugn_lrelu_slope(av[r][q]);
-            out[o[r][q]] = v;
-          }
+        for (int q = 0; q < 4; ++q) o[r][q] = (unsigned)(((oy + (q >> 1)) * HW + ox + (q & 1)) * NCF + co);
       }
     }
+    wino_epilogue<NB, EPI, EFLAGS>(y, o, out, out_idx, act, addend, raw_out, sm_m, sm_g);
     jb = jn; lit = nlit;
   }
 }

@@ -349,14 +349,14 @@ __global__ __launch_bounds__(512, 2) void wino_tall_kernel(const WinoJobs jt, co
         }
       }
     }
+    const int co = UGN_EPI_PAIR ? 2 * lj : lj;      // the lane's first channel (wino_common.h pair_lj / pair_cb)
+    float y[2][4][4];      // [block][tile r][output (a,b) row-major]
+    unsigned o[4][4];      // element offsets inside the image: the image base is wave-uniform and rides in SGPRs
 #pragma unroll
-    for (int cb = 0; cb < 2; ++cb) {
-      const int co = cb * 16 + lj;
-      float y[4][4];     // [tile r][output (a,b) row-major]
-      unsigned o[4][4];   // element offsets inside the image: the image base is wave-uniform and rides in SGPRs
+    for (int r = 0; r < 4; ++r) {
+      const int ti = 4 * kq + r, tr = ti >> 3, tc = ti & 7;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int ti = 4 * kq + r, tr = ti >> 3, tc = ti & 7;
+      for (int cb = 0; cb < 2; ++cb) {
         float sm[2][4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -365,73 +365,20 @@ __global__ __launch_bounds__(512, 2) void wino_tall_kernel(const WinoJobs jt, co
         }
 #pragma unroll
         for (int a = 0; a < 2; ++a) {
-          y[r][a * 2 + 0] = sm[a][0] + sm[a][1] + sm[a][2];
-          y[r][a * 2 + 1] = sm[a][1] - sm[a][2] - sm[a][3];
-        }
-        const int oy = ry0 + 2 * (trow0 + 2 * tr), ox = rx0 + 2 * tc;
-        if constexpr (EPI == EPI_LRELU_POOL) {
-          constexpr int HP = HW / 2;
-          o[r][0] = (unsigned)(((oy / 2) * HP + ox / 2) * NCF + co);
-        } else {
-#pragma unroll
-          for (int q = 0; q < 4; ++q) o[r][q] = (unsigned)(((oy + (q >> 1)) * HW + ox + (q & 1)) * NCF + co);
+          y[cb][r][a * 2 + 0] = sm[a][0] + sm[a][1] + sm[a][2];
+          y[cb][r][a * 2 + 1] = sm[a][1] - sm[a][2] - sm[a][3];
         }
       }
+      const int oy = ry0 + 2 * (trow0 + 2 * tr), ox = rx0 + 2 * tc;
       if constexpr (EPI == EPI_LRELU_POOL) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float best = ugn_lrelu(y[r][0]);
-          int bi = 0;
-#pragma unroll
-          for (int q = 1; q < 4; ++q) {
-            const float v = ugn_lrelu(y[r][q]);
-            if (v > best) { best = v; bi = q; }
-          }
-          out[o[r][0]] = best;
-          out_idx[o[r][0]] = (uint8_t)bi;
-        }
-      } else if constexpr (EPI == EPI_LRELU) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-          for (int q = 0; q < 4; ++q) out[o[r][q]] = ugn_lrelu(y[r][q]);
+        constexpr int HP = HW / 2;
+        o[r][0] = (unsigned)(((oy / 2) * HP + ox / 2) * NCF + co);
       } else {
-        float av[4][4], dv[4][4];
-        if constexpr (EFLAGS & 1) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) av[r][q] = act[o[r][q]];
-        }
-        if constexpr (EFLAGS & 2) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) dv[r][q] = addend[o[r][q]];
-        }
-        float mv[4][4], gv[4][4];
-        if constexpr (EFLAGS & 8) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              mv[r][q] = sm_m[o[r][q]];
-              gv[r][q] = sm_g[o[r][q]];
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            float v = y[r][q];
-            if constexpr (EFLAGS & 2) v += dv[r][q];
-            if constexpr (EFLAGS & 8) v += av[r][q] == mv[r][q] ? gv[r][q] : 0.f;   // set-max gradient -> the frames holding the maximum
-            if constexpr (EFLAGS & 4) raw_out[o[r][q]] = v;
-            if constexpr (EFLAGS & 1) v *= ugn_lrelu_slope(av[r][q]);
-            out[o[r][q]] = v;
-          }
+        for (int q = 0; q < 4; ++q) o[r][q] = (unsigned)(((oy + (q >> 1)) * HW + ox + (q & 1)) * NCF + co);
       }
     }
+    wino_epilogue<2, EPI, EFLAGS>(y, o, out, out_idx, act, addend, raw_out, sm_m, sm_g);
     jb = jn; lit = nlit;
   }
 }

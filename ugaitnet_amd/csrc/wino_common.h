@@ -42,6 +42,14 @@ __device__ __forceinline__ int wino_job_of(const WinoJobs& jt, int it) {
   return jb;
 }
 
+// Output channel n (within 32) of a wave that owns two 16-column accumulator blocks <-> (block cb, MFMA column lj).
+// UGN_EPI_PAIR (default): n = 2*lj + cb -- the two values a lane holds for one pixel are adjacent channels.
+#ifndef UGN_EPI_PAIR
+#define UGN_EPI_PAIR 1
+#endif
+__host__ __device__ constexpr int pair_lj(int n) { return UGN_EPI_PAIR ? (n >> 1) & 15 : n & 15; }
+__host__ __device__ constexpr int pair_cb(int n) { return UGN_EPI_PAIR ? n & 1 : (n >> 4) & 1; }
+
 // filter layouts (decided from the GEMM dimensions alone, so that packer and kernels agree):
 //   tall  : 32 output channels            -> conv3x3_wino_tall.hip
 //   wide  : >= 64 output and K channels   -> wino_kernel, wide variant
@@ -49,11 +57,15 @@ __device__ __forceinline__ int wino_job_of(const WinoJobs& jt, int it) {
 __host__ __device__ constexpr bool wino_tall(int kc, int nc) { return nc == 32; }
 // (128 -> 64 channels at 16x16 stays narrow: wide would leave 600 frame-level items for 256 persistent workgroups, 2.34
 //  rounds of which the last is a third full; narrow makes 1200 items = 4.7 rounds, and 48 instead of 24 for the set-level twin)
-__host__ __device__ constexpr bool wino_wide(int kc, int nc) { return nc >= 64 && kc >= 64 && !(kc == 128 && nc == 64); }
+// Measured on merged 3-modality launches (tools/ab_ops.py, 1872 frames): 32 -> 64 forward wide 448 us against 473 narrow; the
+// 128 -> 64 data gradient wide 392 against 432 (1872 wide items over 256 workgroups quantise to 91 %, but an item is that
+// much cheaper; with one modality per launch -- 600 items, 2.34 rounds -- narrow was the better of the two).
+__host__ __device__ constexpr bool wino_wide(int kc, int nc) { return nc >= 64 && kc >= 32; }
 // bf16 operands: the data gradient of a POOLED 64 -> 64 layer (a4 / b2) runs narrow -- the wide pooled variant sits at 254
 // registers in fp32 and spills with the zero-padded operand pairs of the bf16 form
+// (bf16 operands also keep the two shapes narrow whose wide form spills with the zero-padded operand pairs)
 __host__ __device__ constexpr bool wino_wide_ex(int kc, int nc, bool bf, bool pooled_dgrad) {
-  return wino_wide(kc, nc) && !(bf && pooled_dgrad && kc == 64 && nc == 64);
+  return wino_wide(kc, nc) && !(bf && pooled_dgrad && kc == 64 && nc == 64) && !(bf && (kc == 32 || (kc == 128 && nc == 64)));
 }
 
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
@@ -101,6 +113,103 @@ __device__ __forceinline__ void dma4(const void* gsrc, unsigned lds_dst_uniform)
 
 // even pixel columns of a halo row first, then the odd ones (bank layout, see conv3x3_wino.hip)
 __device__ __forceinline__ constexpr int colpos(int col) { return (col & 1) ? 9 + (col >> 1) : (col >> 1); }
+
+// Epilogue shared by wino_kernel and wino_tall_kernel.  y[cb][r][q]: the lane's outputs -- block cb, tile r (of its 4),
+// position q (row-major in the 2x2 tile); o[r][q]: element offset (inside the image) of the lane's FIRST channel at that
+// pixel (pooled epilogue: o[r][0] = the pooled pixel).  With two blocks per lane and the paired channel mapping (pair_lj /
+// pair_cb) the lane's two channels are adjacent: every access moves 8 bytes per lane, i.e. whole 128-byte lines per 16 lanes
+// and half the memory instructions; otherwise block cb sits 16 channels further.
+template <int NB, int EPI, int EFLAGS>
+__device__ __forceinline__ void wino_epilogue(const float (&y)[NB][4][4], const unsigned (&o)[4][4], float* __restrict__ out,
+                                              uint8_t* __restrict__ out_idx, const float* __restrict__ act,
+                                              const float* __restrict__ addend, float* __restrict__ raw_out,
+                                              const float* __restrict__ sm_m, const float* __restrict__ sm_g) {
+  constexpr int W = (NB == 2 && UGN_EPI_PAIR) ? 2 : 1;      // channels per access
+  constexpr int NBLK = NB / W;
+  auto ld = [](const float* p, unsigned off, float (&v)[W]) {
+    if constexpr (W == 2) { const float2 t = *reinterpret_cast<const float2*>(p + off); v[0] = t.x; v[1] = t.y; }
+    else v[0] = p[off];
+  };
+  auto st = [](float* p, unsigned off, const float (&v)[W]) {
+    if constexpr (W == 2) *reinterpret_cast<float2*>(p + off) = make_float2(v[0], v[1]);
+    else p[off] = v[0];
+  };
+#pragma unroll
+  for (int blk = 0; blk < NBLK; ++blk) {
+    const unsigned cofs = W == 2 ? 0u : (unsigned)blk * 16u;
+    if constexpr (EPI == EPI_LRELU_POOL) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float best[W];
+        unsigned bi[W];
+#pragma unroll
+        for (int e = 0; e < W; ++e) {
+          best[e] = ugn_lrelu(y[blk * W + e][r][0]);
+          bi[e] = 0;
+#pragma unroll
+          for (int q = 1; q < 4; ++q) {
+            const float v = ugn_lrelu(y[blk * W + e][r][q]);
+            if (v > best[e]) { best[e] = v; bi[e] = q; }     // strict >: the FIRST maximum wins (TF MaxPoolGrad routing)
+          }
+        }
+        st(out, o[r][0] + cofs, best);
+        if constexpr (W == 2) *reinterpret_cast<uint16_t*>(out_idx + o[r][0]) = (uint16_t)(bi[0] | (bi[1] << 8));
+        else out_idx[o[r][0] + cofs] = (uint8_t)bi[0];
+      }
+    } else if constexpr (EPI == EPI_LRELU) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float v[W];
+#pragma unroll
+          for (int e = 0; e < W; ++e) v[e] = ugn_lrelu(y[blk * W + e][r][q]);
+          st(out, o[r][q] + cofs, v);
+        }
+    } else {
+      float av[4][4][W], dv[4][4][W], mv[4][4][W], gv[4][4][W];
+      if constexpr (EFLAGS & 1) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) ld(act, o[r][q] + cofs, av[r][q]);
+      }
+      if constexpr (EFLAGS & 2) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) ld(addend, o[r][q] + cofs, dv[r][q]);
+      }
+      if constexpr (EFLAGS & 8) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            ld(sm_m, o[r][q] + cofs, mv[r][q]);
+            ld(sm_g, o[r][q] + cofs, gv[r][q]);
+          }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float v[W];
+#pragma unroll
+          for (int e = 0; e < W; ++e) {
+            v[e] = y[blk * W + e][r][q];
+            if constexpr (EFLAGS & 2) v[e] += dv[r][q][e];
+            if constexpr (EFLAGS & 8) v[e] += av[r][q][e] == mv[r][q][e] ? gv[r][q][e] : 0.f;   // set-max gradient -> the frames holding the maximum
+          }
+          if constexpr (EFLAGS & 4) st(raw_out, o[r][q] + cofs, v);
+          if constexpr (EFLAGS & 1) {
+#pragma unroll
+            for (int e = 0; e < W; ++e) v[e] *= ugn_lrelu_slope(av[r][q][e]);
+          }
+          st(out, o[r][q] + cofs, v);
+        }
+    }
+  }
+}
 
 // 256 B of zeros in HBM: the LDS-DMA source for halo lanes outside the image (defined in conv3x3_wino.hip)
 const float* zero_block();

@@ -539,6 +539,10 @@ class GaitCore:
         # and receives exactly 0 gradient: skipping it changes no result, only the work done.
         self.skip_masked = bool(skip_masked)
         self._active = None
+        # frozen_branches: only the classification head trains (what build_or_load(freeze_all=True) leaves trainable on the
+        # gaitset path: every layer but the last, `classprob`, gets trainable = False; nets/mj_uwyhNets_ba.py:635-649).  The
+        # encoders' backward pass is then not run at all and Adam touches the head's slice of the flat buffer only.
+        self.frozen_branches = False
 
         named = []
         for mi, cin in enumerate(self.in_channels):
@@ -748,7 +752,12 @@ class GaitCore:
             if self.global_batch:   # every replica holds the head gradient of the whole batch; the all-reduce sums them
                 ops.scale_(self.store.g["head.wc"], 1.0 / self.world)
                 ops.scale_(self.store.g["head.bc"], 1.0 / self.world)
-            self._reduce_bucket(self.nmod)
+            if not self.frozen_branches:
+                self._reduce_bucket(self.nmod)
+        if self.frozen_branches:
+            if self.nclasses == 0:
+                raise ValueError("frozen branches without a classification head: nothing is trainable")
+            return
         bl, lo = self.last_b, self.row0
         own = (lambda t: t[:, lo:lo + bl].contiguous()) if self.global_batch else (lambda t: t)
         if self.multimodal:
@@ -825,6 +834,11 @@ class GaitCore:
         """Complete the step's gradient reduction; returns the factor Adam applies to the summed gradient."""
         if not self.dp_active:
             return 1.0
+        if self.frozen_branches:     # only the head's bucket carries a gradient
+            lo, hi = self._buckets[self.nmod]
+            scale = dp.allreduce_sum_(self.store.grad[lo:hi], self.pg, force=self.force)
+            self._ar_pending = None
+            return 1.0 if self.global_batch else scale
         if self._ar_pending is not None:
             for w in self._ar_pending:
                 w.wait()
@@ -841,8 +855,12 @@ class GaitCore:
         self.iterations += 1
         t = self.iterations
         lr_t = self.lr * math.sqrt(1.0 - self.beta_2 ** t) / (1.0 - self.beta_1 ** t)
-        ops.adam_step(self.store.flat, self.store.grad, self.store.m, self.store.v, lr_t, self.beta_1, self.beta_2,
-                      self.epsilon, scale)
+        st = self.store
+        if self.frozen_branches:
+            lo, hi = self._buckets[self.nmod]
+            ops.adam_step(st.flat[lo:hi], st.grad[lo:hi], st.m[lo:hi], st.v[lo:hi], lr_t, self.beta_1, self.beta_2, self.epsilon, scale)
+            return                      # (the convolution filters did not change: no repack)
+        ops.adam_step(st.flat, st.grad, st.m, st.v, lr_t, self.beta_1, self.beta_2, self.epsilon, scale)
         self.weights_changed()
 
     def train_step(self, xs, uses, labels, onehot):

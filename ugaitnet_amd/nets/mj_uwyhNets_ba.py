@@ -54,6 +54,21 @@ def _require_gaitset(gaitset, use3D, aux_losses, smoothlabels, init_branches, nd
         raise NotImplementedError("the extra dense 'code' layer is not on the gaitset path the mains run (ndense=0)")
 
 
+def _freeze_like_reference(model, build, initnet, freeze_convs, freeze_all, weights_filename):
+    """The gaitset arm of reference nets/mj_uwyhNets_ba.py:635-649 (and :1375-1389 for three modalities): with freeze_convs
+    or freeze_all a FRESH model is built and the `<initnet>_weights.hdf5` file loaded into it by name; freeze_all then sets
+    trainable = False on every layer but the last one (`classprob`) -- freeze_convs alone freezes nothing on this path."""
+    if not (freeze_convs or freeze_all):
+        return model
+    import os
+    model = build()
+    filewes = weights_filename(initnet)
+    model.load_weights(filewes if os.path.exists(filewes) else initnet, by_name=True, skip_mismatch=True)
+    if freeze_all:
+        model.core.frozen_branches = True
+    return model
+
+
 class UWYHSemiNet:
     """1- or 2-modality model (reference :581-999).  `input_shapes`: a tuple (L,60,60,C) for one modality, a list of two
     such tuples for two (first = optical flow, second = gray)."""
@@ -105,8 +120,8 @@ class UWYHSemiNet:
                       gaitset=False, seed=None):
         if gaitset:
             fActivation = 'leaky'
-        if freeze_convs or freeze_all or freeze_branches:
-            raise NotImplementedError("weight freezing is not implemented on the MI355X path")
+        if freeze_branches:
+            raise NotImplementedError("freeze_branches (with init_branches) is not implemented on the MI355X path")
         build = lambda: UWYHSemiNet.build(input_shapes, number_convolutional_layers, filters_size, filters_numbers,
                                           ndense_units, weight_decay, dropout, optimizer, margin, nclasses, loss_weights,
                                           use3D=use3D, smoothlabels=smoothlabels, postriplet=postriplet,
@@ -128,6 +143,7 @@ class UWYHSemiNet:
                 model.load_weights(initnet, by_name=True, skip_mismatch=True)   # load compatible weights
             else:
                 model = model_base
+            model = _freeze_like_reference(model, build, initnet, freeze_convs, freeze_all, UWYHSemiNet.get_weights_filename)
         print("Alright")
         return model
 
@@ -194,8 +210,8 @@ class UWYHSemiNet3Mods(UWYHSemiNet):
                       fActivation='relu', alpha=0.3, gaitset=False, seed=None):
         if gaitset:
             fActivation = 'leaky'
-        if freeze_convs or freeze_all or freeze_branches:
-            raise NotImplementedError("weight freezing is not implemented on the MI355X path")
+        if freeze_branches:
+            raise NotImplementedError("freeze_branches (with init_branches) is not implemented on the MI355X path")
         build = lambda: UWYHSemiNet3Mods.build(input_shapes, number_convolutional_layers, filters_size, filters_numbers,
                                                ndense_units, weight_decay, dropout, optimizer, margin, nclasses,
                                                loss_weights, use3D=use3D, smoothlabels=smoothlabels,
@@ -213,5 +229,6 @@ class UWYHSemiNet3Mods(UWYHSemiNet):
                 model.load_weights(initnet, by_name=True, skip_mismatch=True)
             else:
                 model = model_base
+            model = _freeze_like_reference(model, build, initnet, freeze_convs, freeze_all, UWYHSemiNet.get_weights_filename)
         print("Alright")
         return model
