@@ -72,7 +72,7 @@ int ugn_conv3x3_wgrad(const float* in, const float* dz, const uint8_t* dz_idx, f
  * pooled gradient + argmax of a MaxPool'ed layer: the kernels for the two cases consume different filter layouts).
  * Arguments otherwise as the direct versions; in the data gradient `addend` and `raw_out` require `act`. */
 int ugn_wino_pack(const float* w_hwio, float* u_packed, int cin, int cout, int dgrad, void* stream);
-/* Same for up to 32 (layer, direction) jobs in ONE launch; all five arrays are HOST arrays of length njobs. */
+/* Same for up to 64 (layer, direction) jobs in ONE launch (all branches of a 3-modality model: 54); HOST arrays of length njobs. */
 int ugn_wino_pack_multi(const float* const* w_hwio_host, float* const* u_packed_host, const int* cin_host,
                         const int* cout_host, const int* dgrad_host, int njobs, void* stream);
 int ugn_conv3x3_fwd_wino(const float* in, const float* u_packed, float* out, uint8_t* out_idx, int n, int hw, int cin,

@@ -77,6 +77,37 @@ def test_three_mod_build_fit_predict_save_load(dev, tmp_path):
     assert w.shape == (5, 5, 2, 32)
 
 
+def test_freeze_all_trains_the_classifier_only(dev, tmp_path):
+    """build_or_load(initnet=..., freeze_all=True) on the gaitset path (reference :635-649): a fresh model takes the weights of
+    `<initnet>_weights.hdf5` by name and every layer but `classprob` stops training; freeze_convs alone freezes nothing."""
+    from ugaitnet_amd.nets.mj_uwyhNets_ba import UWYHSemiNet, UWYHSemiNet3Mods, optimizers, sign_max
+    shapes = [(3, 60, 60, 2), (3, 60, 60, 1), (3, 60, 60, 1)]
+    kw = dict(optimizer=optimizers.Adam(lr=1e-2), nclasses=6, loss_weights=[1.0, 0.1], fMerge=sign_max, gaitset=True)
+    base = UWYHSemiNet3Mods.build_or_load(shapes, 4, [7, 5, 3, 2], [96, 192, 512, 4096], seed=1, **kw)
+    path = os.path.join(tmp_path, "model-state-0002.hdf5")
+    base.save(path)
+    base.save_weights(UWYHSemiNet.get_weights_filename(path))
+    gen = ToyGenerator(("of", "gray", "depth"), 4, 3, 6)
+    X, y = gen[0]
+    frozen = UWYHSemiNet3Mods.build_or_load(shapes, 4, [7, 5, 3, 2], [96, 192, 512, 4096], initnet=path, freeze_all=True, **kw)
+    before = frozen.core.store.flat.cpu().numpy().copy()
+    for _ in range(3):
+        frozen.train_on_batch(X, y)
+    after = frozen.core.store.flat.cpu().numpy()
+    lo, hi = frozen.core._buckets[3]                      # the head's slice of the flat parameter buffer
+    assert np.array_equal(before[:lo], after[:lo]) and not np.array_equal(before[lo:hi], after[lo:hi])
+    assert np.array_equal(frozen.predict(X)[0], base.predict(X)[0])      # signatures: the encoders are the loaded ones
+    # the head's update is the one the unfrozen model makes to its head on the first step
+    free = UWYHSemiNet3Mods.build_or_load(shapes, 4, [7, 5, 3, 2], [96, 192, 512, 4096], initnet=path, freeze_convs=True, **kw)
+    f0 = free.core.store.flat.cpu().numpy().copy()
+    free.train_on_batch(X, y)
+    f1 = free.core.store.flat.cpu().numpy()
+    assert not np.array_equal(f0[:lo], f1[:lo])            # freeze_convs alone: everything still trains on the gaitset path
+    again = UWYHSemiNet3Mods.build_or_load(shapes, 4, [7, 5, 3, 2], [96, 192, 512, 4096], initnet=path, freeze_all=True, **kw)
+    again.train_on_batch(X, y)
+    assert np.array_equal(again.core.store.flat.cpu().numpy()[lo:hi], f1[lo:hi])
+
+
 def test_single_and_two_modality_models_and_encode(dev):
     from ugaitnet_amd.nets.mj_uwyhNets_ba import Maximum, UWYHSemiNet, optimizers
     one = UWYHSemiNet.build_or_load((3, 60, 60, 1), 4, [7, 5, 3, 2], [96, 192, 512, 4096], optimizer=optimizers.Adam(lr=1e-4),

@@ -115,10 +115,11 @@ __global__ void wino_pack_kernel(const float* __restrict__ w, float* __restrict_
   wino_pack_one(w, u, cin, cout, dgrad, blockIdx.x * blockDim.x + threadIdx.x);
 }
 
-struct WinoPackTable {   // up to 32 (layer, direction) jobs in one launch; job = blockIdx.y
-  const float* w[32];
-  float* u[32];
-  int cin[32], cout[32], dgrad[32];
+constexpr int kPackJobs = 64;   // (3 modality branches x 9 layers x 2 directions = 54)
+struct WinoPackTable {   // up to kPackJobs (layer, direction) jobs in one launch; job = blockIdx.y
+  const float* w[kPackJobs];
+  float* u[kPackJobs];
+  int cin[kPackJobs], cout[kPackJobs], dgrad[kPackJobs];
 };
 
 __global__ void wino_pack_multi_kernel(WinoPackTable t) {
@@ -678,7 +679,7 @@ extern "C" int ugn_wino_pack(const float* w_hwio, float* u_packed, int cin, int 
 extern "C" int ugn_wino_pack_multi(const float* const* w_hwio_host, float* const* u_packed_host, const int* cin_host,
                                    const int* cout_host, const int* dgrad_host, int njobs, void* stream) {
   UGN_REQUIRE(w_hwio_host && u_packed_host && cin_host && cout_host && dgrad_host, "ugn_wino_pack_multi: null pointer");
-  UGN_REQUIRE(njobs >= 1 && njobs <= 32, "ugn_wino_pack_multi: njobs must be 1..32 (got %d)", njobs);
+  UGN_REQUIRE(njobs >= 1 && njobs <= kPackJobs, "ugn_wino_pack_multi: njobs must be 1..%d (got %d)", kPackJobs, njobs);
   WinoPackTable t = {};
   int maxe = 0;
   for (int j = 0; j < njobs; ++j) {

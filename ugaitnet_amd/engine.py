@@ -192,19 +192,23 @@ class Encoder:
     def G(self, name):
         return self.store.g[self.prefix + name]
 
+    def pack_jobs(self):
+        """(w, u_packed, dgrad, pooled) of every 3x3 layer and direction of this branch, for ops.wino_pack_multi."""
+        jobs = []
+        for name, k, _, _, _, pool in CONV_SPECS:
+            if k != 3:
+                continue
+            w = self.W(name)
+            for store, dgrad in ((self.uf, False), (self.ud, True)):
+                if name not in store:
+                    store[name] = torch.empty((16 * w.shape[2] * w.shape[3],), dtype=F32, device=w.device)
+                jobs.append((w, store[name], dgrad, pool))   # a pooled layer's dgrad takes dz at pooled resolution
+        return jobs
+
     def repack(self):
-        """Refresh the kernel-ready copies of the 3x3 weights (after every optimizer step): one launch per branch."""
+        """Refresh the kernel-ready copies of the 3x3 weights (after every optimizer step)."""
         if USE_WINOGRAD:
-            jobs = []
-            for name, k, _, _, _, pool in CONV_SPECS:
-                if k != 3:
-                    continue
-                w = self.W(name)
-                for store, dgrad in ((self.uf, False), (self.ud, True)):
-                    if name not in store:
-                        store[name] = torch.empty((16 * w.shape[2] * w.shape[3],), dtype=F32, device=w.device)
-                    jobs.append((w, store[name], dgrad, pool))   # a pooled layer's dgrad takes dz at pooled resolution
-            ops.wino_pack_multi(jobs, bf16=self.bf16)
+            ops.wino_pack_multi(self.pack_jobs(), bf16=self.bf16)
         else:
             for name, k, _, _, _, _ in CONV_SPECS:
                 if k == 3:
@@ -575,6 +579,10 @@ class GaitCore:
         self.weights_changed()
 
     def weights_changed(self):
+        if USE_WINOGRAD:     # one launch for the filters of all branches
+            jobs = [j for e in self.encoders for j in e.pack_jobs()]
+            ops.wino_pack_multi(jobs, bf16=self.encoders[0].bf16)
+            return
         for e in self.encoders:
             e.repack()
 

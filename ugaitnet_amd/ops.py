@@ -157,9 +157,9 @@ def wino_pack(w, dgrad, out=None, pooled_dz=False, bf16=False):
 
 
 def wino_pack_multi(jobs, bf16=False):
-    """jobs: list of (w HWIO tensor, u_packed tensor, dgrad flag, pooled_dz flag); one launch for up to 32 of them."""
-    for k in range(0, len(jobs), 32):
-        part = jobs[k:k + 32]
+    """jobs: list of (w HWIO tensor, u_packed tensor, dgrad flag, pooled_dz flag); one launch for up to 64 of them."""
+    for k in range(0, len(jobs), 64):
+        part = jobs[k:k + 64]
         n = len(part)
         ws = ptr_array([j[0] for j in part])
         us = ptr_array([j[1] for j in part])
