@@ -4,6 +4,7 @@ gradient) of C3 (of + gray + depth, 24 clips = 12 ids x 2, 150 classes) and C4 (
 torch-autograd statement that pins the numpy oracle, tests/test_oracle_crosscheck.py; the numpy oracle itself needs minutes at
 these sizes).
 
+C5 (configs[4]: C4's modalities, 16 clips per GPU, bf16 MFMA operands) runs the same comparison with the bf16 mode's bars.
 Bars: loss <= 1e-4, signature <= 1e-3 (north_star's tolerance; observed ~1e-5), active-triplet counts equal up to hinges that
 sit within fp32 rounding of zero (C3: exact; C4 has 744k hinges per step: at most 1 per bin, 3 in all), every parameter
 gradient <= 5e-3 relative L2 (an fp32-vs-fp64 near-tie can flip a MaxPool / set-max / HPP / sign_max routing decision)."""
@@ -20,6 +21,9 @@ pytestmark = pytest.mark.gpu
 CASES = {
     "C3": dict(kinds=("of", "gray", "depth"), b=24, ids=12, ncls=150),
     "C4": dict(kinds=("of", "gray", "sil"), b=40, ids=4, ncls=74),
+    # BASELINE.json configs[4] / SURVEY "C5": C4's modalities, 16 clips per GPU (128 per 8-GPU node, 8 ids x 16 -> 2 ids here),
+    # bf16 operands on the matrix cores with fp32 accumulate
+    "C5": dict(kinds=("of", "gray", "sil"), b=16, ids=2, ncls=74, precision="bf16"),
 }
 
 
@@ -29,7 +33,7 @@ def _rell2(a, b):
 
 
 @pytest.mark.timeout(1500)
-@pytest.mark.parametrize("name", ["C3", "C4"])
+@pytest.mark.parametrize("name", ["C3", "C4", "C5"])
 def test_whole_step_matches_the_fp64_oracle(dev, name):
     from ugaitnet_amd.engine import GaitCore
     c = CASES[name]
@@ -39,7 +43,9 @@ def test_whole_step_matches_the_fp64_oracle(dev, name):
     p64 = dict(branches=[O.init_branch_params(rng, 2 if k == "of" else 1, np.float64) for k in kinds],
                head=O.init_head_params(rng, ncls, np.float64))
     p64["head"]["bc"] = rng.normal(size=ncls) * 0.01
-    core = GaitCore([2, 1, 1], nclasses=ncls, fuse_mode="sign_max", margin=0.2, loss_weights=(1.0, 0.1), device=dev)
+    bf16 = c.get("precision") == "bf16"
+    core = GaitCore([2, 1, 1], nclasses=ncls, fuse_mode="sign_max", margin=0.2, loss_weights=(1.0, 0.1), device=dev,
+                    conv_precision="bf16" if bf16 else "f32")
     core.set_params_numpy(O.cast_params(p64, np.float32))
     core.forward_backward(xs, uses, labels, onehot)
     torch.cuda.synchronize()
@@ -53,21 +59,26 @@ def test_whole_step_matches_the_fp64_oracle(dev, name):
     res, g = T.loss_and_grads([torch.from_numpy(x.astype(np.float64)) for x in xs],
                               [torch.from_numpy(u.astype(np.float64)) for u in uses], torch.from_numpy(labels),
                               torch.from_numpy(onehot.astype(np.float64)), tp, margin=0.2, loss_weights=(1.0, 0.1))
-    assert abs(ls["loss"] - float(res["loss"])) <= 1e-4, (ls, float(res["loss"]))
-    assert abs(ls["triplet"] - float(res["triplet"])) <= 1e-4 and abs(ls["xent"] - float(res["xent"])) <= 1e-4
-    assert np.abs(sig - res["signature"].detach().numpy()).max() <= 1e-3
     dcount = np.abs(counts.astype(np.int64) - res["tri_counts"].numpy().astype(np.int64))
-    if name == "C3":
-        assert dcount.max() == 0, dcount
+    if bf16:    # bf16 operands (8 significant bits) in every 3x3 convolution: the bars of test_bf16_operand_mode_against_the_oracle
+        assert abs(ls["loss"] - float(res["loss"])) <= 5e-2, (ls, float(res["loss"]))
+        assert np.abs(sig - res["signature"].detach().numpy()).max() <= 2e-2
+        assert dcount.max() <= 0.02 * max(1.0, float(res["tri_counts"].max()))
     else:
-        assert dcount.max() <= 1 and dcount.sum() <= 3, dcount
+        assert abs(ls["loss"] - float(res["loss"])) <= 1e-4, (ls, float(res["loss"]))
+        assert abs(ls["triplet"] - float(res["triplet"])) <= 1e-4 and abs(ls["xent"] - float(res["xent"])) <= 1e-4
+        assert np.abs(sig - res["signature"].detach().numpy()).max() <= 1e-3
+        if name == "C3":
+            assert dcount.max() == 0, dcount
+        else:
+            assert dcount.max() <= 1 and dcount.sum() <= 3, dcount
     worst = {}
     for mi in range(3):
         for k, ref in g["branches"][mi].items():
             worst["m%d.%s" % (mi, k)] = _rell2(got["branches"][mi][k], ref.numpy())
     for k, ref in g["head"].items():
         worst["head." + k] = _rell2(got["head"][k], ref.numpy())
-    bad = {k: v for k, v in worst.items() if v > 5e-3}
+    bad = {k: v for k, v in worst.items() if v > (2e-1 if bf16 else 5e-3)}
     assert not bad, (bad, worst)
     print("%s: loss %.6f (oracle %.6f), max |sig - oracle| %.2e, worst gradient rel-L2 %.2e (%s)"
           % (name, ls["loss"], float(res["loss"]), np.abs(sig - res["signature"].detach().numpy()).max(),
