@@ -108,6 +108,24 @@ def test_freeze_all_trains_the_classifier_only(dev, tmp_path):
     assert np.array_equal(again.core.store.flat.cpu().numpy()[lo:hi], f1[lo:hi])
 
 
+def test_keras_surface_skips_masked_pairs_without_changing_results(dev):
+    """Models built through the reference's class API run each encoder only on the clips whose modality flag is 1."""
+    from ugaitnet_amd.nets.mj_uwyhNets_ba import UWYHSemiNet3Mods, optimizers, sign_max
+    shapes = [(3, 60, 60, 2), (3, 60, 60, 1), (3, 60, 60, 1)]
+    mk = lambda: UWYHSemiNet3Mods.build_or_load(shapes, 4, [7, 5, 3, 2], [96, 192, 512, 4096], optimizer=optimizers.Adam(lr=1e-3),
+                                                nclasses=6, loss_weights=[1.0, 0.1], fMerge=sign_max, gaitset=True, seed=4)
+    a, b = mk(), mk()
+    assert a.core.skip_masked
+    b.core.skip_masked = False
+    X, y = ToyGenerator(("of", "gray", "depth"), 8, 3, 6, n_batches=1)[0]      # 8 rows: every mask pattern at least once
+    pa, pb = a.predict(X), b.predict(X)
+    assert np.array_equal(pa[0], pb[0]) and np.array_equal(pa[1], pb[1])
+    la, lb = a.train_on_batch(X, y), b.train_on_batch(X, y)
+    assert abs(la["loss"] - lb["loss"]) <= 1e-6
+    wa, wb = a.core.store.flat.cpu().numpy(), b.core.store.flat.cpu().numpy()
+    assert np.abs(wa - wb).max() <= 2e-4        # (Adam's first step moves an element by up to lr = 1e-3; the two gradients differ by rounding)
+
+
 def test_single_and_two_modality_models_and_encode(dev):
     from ugaitnet_amd.nets.mj_uwyhNets_ba import Maximum, UWYHSemiNet, optimizers
     one = UWYHSemiNet.build_or_load((3, 60, 60, 1), 4, [7, 5, 3, 2], [96, 192, 512, 4096], optimizer=optimizers.Adam(lr=1e-4),

@@ -179,6 +179,10 @@ class GaitSetModel:
                              seed=seed, lr=optimizer.lr, beta_1=optimizer.beta_1, beta_2=optimizer.beta_2,
                              epsilon=optimizer.epsilon, world_size=world,
                              dp_mode=os.environ.get("UGN_DP_MODE", "replica"),
+                             # a masked (clip, modality) pair is multiplied by 0 in the gate (nets/mj_uwyhNets_ba.py:51-54): its
+                             # encoder work is skipped -- same outputs and gradients, 1.5x the clips/s on the 7-pattern masks
+                             # (bench.py's headline computes those pairs; `value_skip_masked` is this mode).  UGN_SKIP_MASKED=0: dense
+                             skip_masked=os.environ.get("UGN_SKIP_MASKED", "1") != "0",
                              conv_precision=os.environ.get("UGN_CONV_PRECISION", "f32"))
         if world > 1:  # replicas start from identical weights (MirroredStrategy semantics)
             torch.distributed.broadcast(self.core.store.flat, src=0)
