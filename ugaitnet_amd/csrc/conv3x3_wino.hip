@@ -28,6 +28,13 @@ using namespace ugn_wino;
 
 namespace {
 
+#ifndef UGN_STAMPS
+#define UGN_STAMPS 0     // diagnostic build only: s_memtime stamps around every group barrier of workgroup 0 (tools/stamps.py)
+#endif
+#if UGN_STAMPS
+__device__ unsigned long long ugn_stamp_buf[8 * 2048];
+#endif
+
 constexpr int TW = 16, PW = TW + 2, PH = 18, NPIX = PH * PW;   // 16x16 output region, 18x18 halo
 constexpr int CS = 36;                                         // halo pixel stride (floats) per 32-channel chunk
 constexpr int HSLOTS = NPIX * 9;                                // 16-byte slots of a halo tile (8 data + 1 pad per pixel)
@@ -231,8 +238,21 @@ __device__ __forceinline__ void read_pair_pooled_row(float2 (&dn)[16], const flo
 }
 
 // 32 KB filter slice (16 KB of bf16 elements): linear in both spaces, 4 (2) pieces of 1 KB per wave (8 waves)
+#ifndef UGN_ALT_PRIO
+#define UGN_ALT_PRIO 1
+#endif
+#ifndef UGN_PREF_POOLED
+#define UGN_PREF_POOLED 1     // touch the epilogue's act lines during the last group in the pooled data gradients too (-2.4 %)
+#endif
+// timing-only ablations (WRONG results): 1 no filter DMA, 2 no halo DMA, 4 no transform arithmetic, 8 no MFMA
+#ifndef UGN_ABLATE
+#define UGN_ABLATE 0
+#endif
 template <bool BF>
 __device__ __forceinline__ void dma_u_slice(const float* __restrict__ us, unsigned lds_byte_base, int tid, int wave) {
+#if UGN_ABLATE & 1
+  return;
+#endif
 #pragma unroll
   for (int q = 0; q < (BF ? 2 : 4); ++q) dma16(us + (q * 512 + tid) * 4, lds_byte_base + (unsigned)(q * 512 + wave * 64) * 16u);
 }
@@ -243,6 +263,7 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const WinoJobs jt, const f
   // WIDE (NCF >= 64): the workgroup owns 64 output channels, a wave 16 tiles x 2 channel blocks, and a group is 8 input
   // channels (2 k-steps): per MFMA half the transform work, patch reads and halo traffic of the narrow variant.
   constexpr bool WIDE = wino_wide_ex(KC, NCF, BF, IN_UNPOOL != 0);
+  constexpr bool ALT_PRIO = UGN_ALT_PRIO && EPI != EPI_DGRAD;
   constexpr int NB = WIDE ? 2 : 1;          // 16-channel output blocks per wave
   constexpr int NG = WIDE ? 4 : 2;          // channel groups per 32-channel chunk
   constexpr int GW = 32 / NG;               // input channels per group
@@ -303,6 +324,9 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const WinoJobs jt, const f
     else { V[pt][2 * h] = x; V[pt][2 * h + 1] = y; }
   };
   bool first = true;   // only the very first group of the workgroup transforms its patch un-pipelined
+#if UGN_STAMPS
+  int stamp_n = 0;
+#endif
 
   // Single-chunk narrow layers: the two filter slices of (job, nsp) stay RESIDENT in the two slots; every item of this
   // workgroup has the same nsp when the grid is a multiple of NSPLIT (each job's items are one).  res0 / res1 = the job whose
@@ -342,8 +366,14 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const WinoJobs jt, const f
       const float* sInNext = smem + (ibuf ^ 1) * SIN;
 #pragma unroll
       for (int G = 0; G < NG; ++G) {
+#if UGN_STAMPS
+        if (blockIdx.x == 0 && lane == 0 && stamp_n < 2046) ugn_stamp_buf[wave * 2048 + stamp_n++] = __builtin_amdgcn_s_memtime();
+#endif
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every DMA issued so far has landed (all are >= 1 group old)
         __syncthreads();                                    // ... and is visible; the other buffers have no readers left
+#if UGN_STAMPS
+        if (blockIdx.x == 0 && lane == 0 && stamp_n < 2046) ugn_stamp_buf[wave * 2048 + stamp_n++] = __builtin_amdgcn_s_memtime();
+#endif
         const float* sU = sU0 + ubuf * SU;
         // filter slice of the next group -> the other buffer, while this group computes
         // (single-chunk layers: the two slices of the workgroup's 32 output channels stay resident after the first item)
@@ -391,6 +421,7 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const WinoJobs jt, const f
         float2 dn[16], tn0s[16], tn1[16];
         float2 (&tn0)[16] = *(WIDE ? &dn : &tn0s);
         auto rowpass = [&](float2 (&tn)[16], int c) {
+          if (UGN_ABLATE & 4) { tn[0 + c] = dn[0 + c]; tn[4 + c] = dn[4 + c]; tn[8 + c] = dn[8 + c]; tn[12 + c] = dn[12 + c]; return; }
           const float2 d0 = dn[0 + c], d1 = dn[4 + c], d2 = dn[8 + c], d3 = dn[12 + c];
           tn[0 + c] = make_float2(d0.x - d2.x, d0.y - d2.y);
           tn[4 + c] = make_float2(d1.x + d2.x, d1.y + d2.y);
@@ -398,6 +429,10 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const WinoJobs jt, const f
           tn[12 + c] = make_float2(d1.x - d3.x, d1.y - d3.y);
         };
         auto colpass = [&](int r) {
+          if (UGN_ABLATE & 4) {
+            for (int j = 0; j < 4; ++j) { setV(r * 4 + j, 0, tn0[r * 4 + j].x, tn0[r * 4 + j].y); if constexpr (NH == 2) setV(r * 4 + j, 1, tn1[r * 4 + j].x, tn1[r * 4 + j].y); }
+            return;
+          }
           setV(r * 4 + 0, 0, tn0[r * 4 + 0].x - tn0[r * 4 + 2].x, tn0[r * 4 + 0].y - tn0[r * 4 + 2].y);
           setV(r * 4 + 1, 0, tn0[r * 4 + 1].x + tn0[r * 4 + 2].x, tn0[r * 4 + 1].y + tn0[r * 4 + 2].y);
           setV(r * 4 + 2, 0, tn0[r * 4 + 2].x - tn0[r * 4 + 1].x, tn0[r * 4 + 2].y - tn0[r * 4 + 1].y);
@@ -423,6 +458,14 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const WinoJobs jt, const f
 #pragma unroll
         for (int pp = 0; pp < 8; ++pp) {
           const int cu = pp & 1, nu = cu ^ 1;
+          // The two waves of a SIMD are not served alike: with equal priority the older one (waves 0-3) ends a group ~1300
+          // cycles before the younger and waits at the barrier (tools/stamps.py: 4600 / 5900 cycles inside an a6 forward
+          // group).  Taking turns pair by pair brings them to 5150 / 5650: -3...4 % on the forward kernels; the data
+          // gradients lose 0-4 % with it (their epilogue operands), so they keep equal priorities.
+          if constexpr (ALT_PRIO) {
+            if ((wave >= 4) == ((pp & 1) != 0)) __builtin_amdgcn_s_setprio(1);
+            else __builtin_amdgcn_s_setprio(0);
+          }
           if (pp < 7) {
             if constexpr (BF) {
               ub[nu][0] = *reinterpret_cast<const uint2*>(sU + ubase / 2 + (2 * pp + 2) * 256);
@@ -476,11 +519,11 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const WinoJobs jt, const f
           // halo of the next stage: all pieces of this wave during the FIRST group of the chunk, so that they are
           // a full group old at the next barrier and the next chunk's first transform can be pipelined as well
           if constexpr (IN_UNPOOL) {
-            if (G == 0 && pt >= 1 && pt <= 3)
+            if (!(UGN_ABLATE & 2) && G == 0 && pt >= 1 && pt <= 3)
               dma_pooled_piece<KC, HW>(in, in_idx, zeros, n_img, n_ry0, n_rx0, n_chunk, wave * 3 + (pt - 1), opaque(lane),
                                        sin_bytes + (unsigned)(ibuf ^ 1) * SIN * 4u);
           } else {
-            if (G == 0 && pt >= 1 && pt < 7)   // early in the group: the pieces must have landed by the group's end
+            if (!(UGN_ABLATE & 2) && G == 0 && pt >= 1 && pt < 7)   // early in the group: the pieces must have landed by the group's end
               dma_halo_piece<KC, HW>(in, zeros, n_img, n_ry0, n_rx0, n_chunk, wave * 6 + (pt - 1), halo_slot_geometry(wave * 6 + (pt - 1), opaque(lane)),
                                      sin_bytes + (unsigned)(ibuf ^ 1) * SIN * 4u);
           }
@@ -492,7 +535,7 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const WinoJobs jt, const f
             // The data-gradient epilogue reads act / addend at the item's output pixels; those loads are a dependent round
             // trip to HBM per item.  Touch one dword of every line they will read while the last group still computes
             // (LDS-DMA into a per-wave dump: no registers, nothing waits for it): the epilogue then hits L2.
-            if constexpr (EPI == EPI_DGRAD && (EFLAGS & 3) != 0 && !IN_UNPOOL) {   // (the pooled-input variants have no register to spare)
+            if constexpr (EPI == EPI_DGRAD && (EFLAGS & 3) != 0 && (!IN_UNPOOL || UGN_PREF_POOLED)) {
               if (pt == 9 && G == NG - 1 && last_chunk) {
                 const int p_region = lit / NSPLIT, p_nsp = lit % NSPLIT;
                 const int p_img = p_region / RPI, p_rrem = p_region % RPI;
@@ -513,6 +556,7 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const WinoJobs jt, const f
           }
           }
         }
+        if constexpr (ALT_PRIO) __builtin_amdgcn_s_setprio(0);
         ubuf ^= 1;
       }
       ibuf ^= 1;
@@ -654,6 +698,12 @@ int dispatch_dgrad(const WinoJob* jobs, const int* n, int njobs, int hw, int cin
 }
 
 }  // namespace
+
+#if UGN_STAMPS
+extern "C" int ugn_debug_stamps(unsigned long long* host_dst, int n) {
+  return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(ugn_stamp_buf), (size_t)n * sizeof(unsigned long long));
+}
+#endif
 
 // 256 B of zeros in HBM: the LDS-DMA source for halo lanes outside the image.  Allocated once per process, never written.
 const float* ugn_wino::zero_block() {

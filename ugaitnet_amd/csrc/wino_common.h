@@ -70,7 +70,12 @@ __host__ __device__ constexpr bool wino_wide_ex(int kc, int nc, bool bf, bool po
 
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
   // lane l: A[i = l&15][k = l>>4], B[k = l>>4][j = l&15]; D reg r of lane l = D[i = 4*(l>>4) + r][j = l&15]
+#if defined(UGN_ABLATE) && (UGN_ABLATE & 8)
+  c[0] += a * b;      // (timing-only ablation: one VALU keeps the operands alive)
+  return c;
+#else
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+#endif
 }
 
 // bf16-operand variant (template flag BF of the kernels; SURVEY 8(d) "C5": bf16 operands in the MFMA, fp32 accumulate, fp32
