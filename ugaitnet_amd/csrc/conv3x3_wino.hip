@@ -191,9 +191,19 @@ __device__ __forceinline__ void dma_pooled_piece(const float* __restrict__ dz, c
 // ((r+1)&1)*2 + ((c+1)&1) inside the 2x2 window, else 0 (MaxPool backward).  `ibytes`: the lane's argmax pair for h = 0.
 // (hipcc fuses pairs of these reads into ds_read2_b64, which banks mod 32 and is 2-way conflicted on this layout; keeping
 // them apart costs address registers that the 256-register budget of the multi-chunk variants does not have.)
-template <int IN_UNPOOL>
+template <int IN_UNPOOL, bool B64 = false>
 __device__ __forceinline__ void read_pair(float2 (&dn)[16], const float* base, const uint8_t* ibytes, int h) {
-  if constexpr (!IN_UNPOOL) {
+#if UGN_ABLATE & 16
+  for (int e = 0; e < 16; ++e) dn[e] = make_float2((float)h + e, 1.f);
+  return;
+#endif
+  if constexpr (!IN_UNPOOL && B64) {
+    const unsigned a0 = lds_addr(base) + (unsigned)(32 * h);      // (h: the second channel pair sits 8 floats further)
+#define UGN_RD(e_) dn[e_] = lds_read_b64<(((e_) >> 2) * PW + colpos((e_) & 3)) * CS * 4>(a0);
+    UGN_RD(0) UGN_RD(1) UGN_RD(2) UGN_RD(3) UGN_RD(4) UGN_RD(5) UGN_RD(6) UGN_RD(7)
+    UGN_RD(8) UGN_RD(9) UGN_RD(10) UGN_RD(11) UGN_RD(12) UGN_RD(13) UGN_RD(14) UGN_RD(15)
+#undef UGN_RD
+  } else if constexpr (!IN_UNPOOL) {
 #pragma unroll
     for (int e = 0; e < 16; ++e) dn[e] = *reinterpret_cast<const float2*>(base + ((e >> 2) * PW + colpos(e & 3)) * CS + 8 * h);
   } else {
@@ -244,7 +254,8 @@ __device__ __forceinline__ void read_pair_pooled_row(float2 (&dn)[16], const flo
 #ifndef UGN_PREF_POOLED
 #define UGN_PREF_POOLED 1     // touch the epilogue's act lines during the last group in the pooled data gradients too (-2.4 %)
 #endif
-// timing-only ablations (WRONG results): 1 no filter DMA, 2 no halo DMA, 4 no transform arithmetic, 8 no MFMA
+// timing-only ablations (WRONG results): 1 no filter DMA, 2 no halo DMA, 4 no transform arithmetic, 8 no MFMA, 16 no patch reads
+// from LDS, 32 no filter reads from LDS, 64 no group barrier
 #ifndef UGN_ABLATE
 #define UGN_ABLATE 0
 #endif
@@ -264,6 +275,9 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const WinoJobs jt, const f
   // channels (2 k-steps): per MFMA half the transform work, patch reads and halo traffic of the narrow variant.
   constexpr bool WIDE = wino_wide_ex(KC, NCF, BF, IN_UNPOOL != 0);
   constexpr bool ALT_PRIO = UGN_ALT_PRIO && EPI != EPI_DGRAD;
+  // unfused ds_read_b64 patch reads (wino_common.h lds_read_b64): -1.5...4 % where the extra register pressure does not spill
+  // into the loop: the forward kernels and the 128 -> 64 data gradient
+  constexpr bool B64 = UGN_B64ASM && !IN_UNPOOL && !BF && (EPI != EPI_DGRAD || (KC == 128 && NCF == 64));
   constexpr int NB = WIDE ? 2 : 1;          // 16-channel output blocks per wave
   constexpr int NG = WIDE ? 4 : 2;          // channel groups per 32-channel chunk
   constexpr int GW = 32 / NG;               // input channels per group
@@ -370,7 +384,9 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const WinoJobs jt, const f
         if (blockIdx.x == 0 && lane == 0 && stamp_n < 2046) ugn_stamp_buf[wave * 2048 + stamp_n++] = __builtin_amdgcn_s_memtime();
 #endif
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every DMA issued so far has landed (all are >= 1 group old)
+#if !(UGN_ABLATE & 64)
         __syncthreads();                                    // ... and is visible; the other buffers have no readers left
+#endif
 #if UGN_STAMPS
         if (blockIdx.x == 0 && lane == 0 && stamp_n < 2046) ugn_stamp_buf[wave * 2048 + stamp_n++] = __builtin_amdgcn_s_memtime();
 #endif
@@ -393,7 +409,8 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const WinoJobs jt, const f
 #pragma unroll
           for (int h = 0; h < NH; ++h) {
             float2 d[16], t[16];
-            read_pair<IN_UNPOOL>(d, sIn + pbase, reinterpret_cast<const uint8_t*>(sIn) + ibase, h);
+            read_pair<IN_UNPOOL, B64>(d, sIn + pbase, reinterpret_cast<const uint8_t*>(sIn) + ibase, h);
+            if constexpr (B64) patch_wait(d);
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
               t[0 + c] = make_float2(d[0 + c].x - d[8 + c].x, d[0 + c].y - d[8 + c].y);
@@ -454,6 +471,7 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const WinoJobs jt, const f
         } else {
           u[0][0] = *reinterpret_cast<const float4*>(sU + ubase);
           u[0][1] = *reinterpret_cast<const float4*>(sU + ubase + 512);
+          if (UGN_ABLATE & 32) { u[1][0] = u[0][0]; u[1][1] = u[0][1]; }
         }
 #pragma unroll
         for (int pp = 0; pp < 8; ++pp) {
@@ -466,7 +484,7 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const WinoJobs jt, const f
             if ((wave >= 4) == ((pp & 1) != 0)) __builtin_amdgcn_s_setprio(1);
             else __builtin_amdgcn_s_setprio(0);
           }
-          if (pp < 7) {
+          if (pp < 7 && !(UGN_ABLATE & 32)) {
             if constexpr (BF) {
               ub[nu][0] = *reinterpret_cast<const uint2*>(sU + ubase / 2 + (2 * pp + 2) * 256);
               ub[nu][1] = *reinterpret_cast<const uint2*>(sU + ubase / 2 + (2 * pp + 3) * 256);
@@ -514,7 +532,7 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const WinoJobs jt, const f
               if (pt == 7) read_pair_pooled_row<2>(dn, sNx + 8, sNi + 8);
             }
           } else {
-            if (tnext && (pt == 0 || (NH == 2 && pt == 3))) read_pair<IN_UNPOOL>(dn, sNx, sNi, pt == 0 ? 0 : 1);   // channels 2kq.. / 8+2kq..
+            if (tnext && (pt == 0 || (NH == 2 && pt == 3))) read_pair<IN_UNPOOL, B64>(dn, sNx, sNi, pt == 0 ? 0 : 1);   // channels 2kq.. / 8+2kq..
           }
           // halo of the next stage: all pieces of this wave during the FIRST group of the chunk, so that they are
           // a full group old at the next barrier and the next chunk's first transform can be pipelined as well
@@ -528,8 +546,12 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const WinoJobs jt, const f
                                      sin_bytes + (unsigned)(ibuf ^ 1) * SIN * 4u);
           }
           if (tnext) {
-            if (pt == (ROWWISE ? 3 : 1)) { rowpass(tn0, 0); rowpass(tn0, 1); }
-            if (pt == (ROWWISE ? 4 : 2)) { rowpass(tn0, 2); rowpass(tn0, 3); }   // pair 0 done before pair 1 is loaded at point 3
+            constexpr int RP0 = ROWWISE ? 3 : 1;
+            if constexpr (B64) {
+              if (pt == RP0 || (NH == 2 && pt == 4)) patch_wait(dn);
+            }
+            if (pt == RP0) { rowpass(tn0, 0); rowpass(tn0, 1); }
+            if (pt == RP0 + 1) { rowpass(tn0, 2); rowpass(tn0, 3); }   // pair 0 done before pair 1 is loaded at point 3
             if (NH == 2 && pt == (ROWWISE ? 8 : 4)) { rowpass(tn1, 0); rowpass(tn1, 1); }
             if (NH == 2 && pt == (ROWWISE ? 9 : 5)) { rowpass(tn1, 2); rowpass(tn1, 3); }
             // The data-gradient epilogue reads act / addend at the item's output pixels; those loads are a dependent round

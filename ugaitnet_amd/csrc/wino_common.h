@@ -116,6 +116,30 @@ __device__ __forceinline__ void dma4(const void* gsrc, unsigned lds_dst_uniform)
                : "memory");
 }
 
+// One ds_read_b64 that the compiler cannot fuse.  The halo tiles are laid out bank-exact for ds_read_b64 (64 banks, 32 lanes
+// per pass), but hipcc fuses neighbouring 8-byte reads into ds_read2_b64 / ds_read2st64_b64, which bank mod 32 at half rate and
+// hit this layout 2-way: 16 LDS cycles per pair of reads instead of 4, on the operand every transform waits for (removing the
+// patch reads altogether saves 15-20 % of a forward kernel, tools/stamps.py / UGN_ABLATE).  The asm form keeps them apart with
+// ONE address register and immediate offsets.  The compiler does not see the load: patch_wait() must come before the first use.
+#ifndef UGN_B64ASM
+#define UGN_B64ASM 1
+#endif
+template <int OFF_BYTES>
+__device__ __forceinline__ float2 lds_read_b64(unsigned lds_byte_addr) {
+  float2 r;
+  asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(r) : "v"(lds_byte_addr), "i"(OFF_BYTES));
+  return r;
+}
+// s_waitcnt lgkmcnt(0) that the 16 patch registers depend on (so that no use can be scheduled above it)
+__device__ __forceinline__ void patch_wait(float2 (&d)[16]) {
+  asm volatile("s_waitcnt lgkmcnt(0)"
+               : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]), "+v"(d[4]), "+v"(d[5]), "+v"(d[6]), "+v"(d[7]), "+v"(d[8]),
+                 "+v"(d[9]), "+v"(d[10]), "+v"(d[11]), "+v"(d[12]), "+v"(d[13]), "+v"(d[14]), "+v"(d[15]));
+}
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+  return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const void*)p;
+}
+
 // even pixel columns of a halo row first, then the odd ones (bank layout, see conv3x3_wino.hip)
 __device__ __forceinline__ constexpr int colpos(int col) { return (col & 1) ? 9 + (col >> 1) : (col >> 1); }
 
