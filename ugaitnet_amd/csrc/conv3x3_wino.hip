@@ -278,6 +278,10 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const WinoJobs jt, const f
   // unfused ds_read_b64 patch reads (wino_common.h lds_read_b64): -1.5...4 % where the extra register pressure does not spill
   // into the loop: the forward kernels and the 128 -> 64 data gradient
   constexpr bool B64 = UGN_B64ASM && !IN_UNPOOL && !BF && (EPI != EPI_DGRAD || (KC == 128 && NCF == 64));
+  // packed transform arithmetic (wino_common.h pk_add): -1...7 % except where the aligned register pairs it needs push the
+  // kernel into spilling inside the loop (the 128 -> 128 forward kernel; the bf16 variants stay as they were)
+  constexpr bool PK = UGN_PK && !BF && !(KC == 128 && NCF == 128 && EPI != EPI_DGRAD);
+  constexpr bool PKE = PK;
   constexpr int NB = WIDE ? 2 : 1;          // 16-channel output blocks per wave
   constexpr int NG = WIDE ? 4 : 2;          // channel groups per 32-channel chunk
   constexpr int GW = 32 / NG;               // input channels per group
@@ -440,25 +444,26 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const WinoJobs jt, const f
         auto rowpass = [&](float2 (&tn)[16], int c) {
           if (UGN_ABLATE & 4) { tn[0 + c] = dn[0 + c]; tn[4 + c] = dn[4 + c]; tn[8 + c] = dn[8 + c]; tn[12 + c] = dn[12 + c]; return; }
           const float2 d0 = dn[0 + c], d1 = dn[4 + c], d2 = dn[8 + c], d3 = dn[12 + c];
-          tn[0 + c] = make_float2(d0.x - d2.x, d0.y - d2.y);
-          tn[4 + c] = make_float2(d1.x + d2.x, d1.y + d2.y);
-          tn[8 + c] = make_float2(d2.x - d1.x, d2.y - d1.y);
-          tn[12 + c] = make_float2(d1.x - d3.x, d1.y - d3.y);
+          tn[0 + c] = pk_sub<PK>(d0, d2);
+          tn[4 + c] = pk_add<PK>(d1, d2);
+          tn[8 + c] = pk_sub<PK>(d2, d1);
+          tn[12 + c] = pk_sub<PK>(d1, d3);
         };
         auto colpass = [&](int r) {
           if (UGN_ABLATE & 4) {
             for (int j = 0; j < 4; ++j) { setV(r * 4 + j, 0, tn0[r * 4 + j].x, tn0[r * 4 + j].y); if constexpr (NH == 2) setV(r * 4 + j, 1, tn1[r * 4 + j].x, tn1[r * 4 + j].y); }
             return;
           }
-          setV(r * 4 + 0, 0, tn0[r * 4 + 0].x - tn0[r * 4 + 2].x, tn0[r * 4 + 0].y - tn0[r * 4 + 2].y);
-          setV(r * 4 + 1, 0, tn0[r * 4 + 1].x + tn0[r * 4 + 2].x, tn0[r * 4 + 1].y + tn0[r * 4 + 2].y);
-          setV(r * 4 + 2, 0, tn0[r * 4 + 2].x - tn0[r * 4 + 1].x, tn0[r * 4 + 2].y - tn0[r * 4 + 1].y);
-          setV(r * 4 + 3, 0, tn0[r * 4 + 1].x - tn0[r * 4 + 3].x, tn0[r * 4 + 1].y - tn0[r * 4 + 3].y);
+          auto put = [&](int pt, int h, float2 v) { setV(pt, h, v.x, v.y); };
+          put(r * 4 + 0, 0, pk_sub<PK>(tn0[r * 4 + 0], tn0[r * 4 + 2]));
+          put(r * 4 + 1, 0, pk_add<PK>(tn0[r * 4 + 1], tn0[r * 4 + 2]));
+          put(r * 4 + 2, 0, pk_sub<PK>(tn0[r * 4 + 2], tn0[r * 4 + 1]));
+          put(r * 4 + 3, 0, pk_sub<PK>(tn0[r * 4 + 1], tn0[r * 4 + 3]));
           if constexpr (NH == 2) {
-            setV(r * 4 + 0, 1, tn1[r * 4 + 0].x - tn1[r * 4 + 2].x, tn1[r * 4 + 0].y - tn1[r * 4 + 2].y);
-            setV(r * 4 + 1, 1, tn1[r * 4 + 1].x + tn1[r * 4 + 2].x, tn1[r * 4 + 1].y + tn1[r * 4 + 2].y);
-            setV(r * 4 + 2, 1, tn1[r * 4 + 2].x - tn1[r * 4 + 1].x, tn1[r * 4 + 2].y - tn1[r * 4 + 1].y);
-            setV(r * 4 + 3, 1, tn1[r * 4 + 1].x - tn1[r * 4 + 3].x, tn1[r * 4 + 1].y - tn1[r * 4 + 3].y);
+            put(r * 4 + 0, 1, pk_sub<PK>(tn1[r * 4 + 0], tn1[r * 4 + 2]));
+            put(r * 4 + 1, 1, pk_add<PK>(tn1[r * 4 + 1], tn1[r * 4 + 2]));
+            put(r * 4 + 2, 1, pk_sub<PK>(tn1[r * 4 + 2], tn1[r * 4 + 1]));
+            put(r * 4 + 3, 1, pk_sub<PK>(tn1[r * 4 + 1], tn1[r * 4 + 3]));
           }
         };
         // points are multiplied in PAIRS with their 4 k-steps interleaved (pt0 s0, pt1 s0, pt0 s1, ...): consecutive
@@ -614,23 +619,10 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const WinoJobs jt, const f
     const int co = nsp * (32 * NB) + ch * (16 * NB) + ((NB == 2 && UGN_EPI_PAIR) ? 2 * lj : lj);
     float y[NB][4][4];     // [block][tile r][output (a,b) row-major]
     unsigned o[4][4];      // element offsets inside the image: the image base is wave-uniform and rides in SGPRs
+    wino_out_transform<NB, PKE>(acc, y);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int ti = 4 * kq + r, tr = ti >> 3, tc = ti & 7;
-#pragma unroll
-      for (int cb = 0; cb < NB; ++cb) {
-        float sm[2][4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          sm[0][c] = acc[cb][0 * 4 + c][r] + acc[cb][1 * 4 + c][r] + acc[cb][2 * 4 + c][r];
-          sm[1][c] = acc[cb][1 * 4 + c][r] - acc[cb][2 * 4 + c][r] - acc[cb][3 * 4 + c][r];
-        }
-#pragma unroll
-        for (int a = 0; a < 2; ++a) {
-          y[cb][r][a * 2 + 0] = sm[a][0] + sm[a][1] + sm[a][2];
-          y[cb][r][a * 2 + 1] = sm[a][1] - sm[a][2] - sm[a][3];
-        }
-      }
       const int oy = ry0 + 2 * (trow0 + TRSTEP * tr), ox = rx0 + 2 * tc;
       if constexpr (EPI == EPI_LRELU_POOL) {
         constexpr int HP = HW / 2;

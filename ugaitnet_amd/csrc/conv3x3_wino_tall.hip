@@ -119,6 +119,7 @@ template <int KC, int HW, int IN_UNPOOL, int EPI, int EFLAGS, bool BF = false>
 __global__ __launch_bounds__(512, 2) void wino_tall_kernel(const WinoJobs jt, const float* __restrict__ zeros) {
   // unfused patch reads: -3.5 % on the 64 -> 32 data gradient (a3 | b1); the 32 -> 32 forward spills with them (+24 %)
   constexpr bool B64 = UGN_TALL_B64 && !IN_UNPOOL && !BF && KC == 64;
+  constexpr bool PK = UGN_PK && !BF;           // packed transform arithmetic (wino_common.h pk_add)
   constexpr int NST = KC / 16;                 // 16-channel stages per item
   constexpr int NGI = 2 * NST;                 // 8-channel groups per item
   constexpr int NCF = 32;
@@ -263,16 +264,17 @@ __global__ __launch_bounds__(512, 2) void wino_tall_kernel(const WinoJobs jt, co
         float2 dn[16];   // the row pass runs in place
         auto rowpass = [&](int c) {
           const float2 d0 = dn[0 + c], d1 = dn[4 + c], d2 = dn[8 + c], d3 = dn[12 + c];
-          dn[0 + c] = make_float2(d0.x - d2.x, d0.y - d2.y);
-          dn[4 + c] = make_float2(d1.x + d2.x, d1.y + d2.y);
-          dn[8 + c] = make_float2(d2.x - d1.x, d2.y - d1.y);
-          dn[12 + c] = make_float2(d1.x - d3.x, d1.y - d3.y);
+          dn[0 + c] = pk_sub<PK>(d0, d2);
+          dn[4 + c] = pk_add<PK>(d1, d2);
+          dn[8 + c] = pk_sub<PK>(d2, d1);
+          dn[12 + c] = pk_sub<PK>(d1, d3);
         };
         auto colpass = [&](int r) {
-          setV(r * 4 + 0, dn[r * 4 + 0].x - dn[r * 4 + 2].x, dn[r * 4 + 0].y - dn[r * 4 + 2].y);
-          setV(r * 4 + 1, dn[r * 4 + 1].x + dn[r * 4 + 2].x, dn[r * 4 + 1].y + dn[r * 4 + 2].y);
-          setV(r * 4 + 2, dn[r * 4 + 2].x - dn[r * 4 + 1].x, dn[r * 4 + 2].y - dn[r * 4 + 1].y);
-          setV(r * 4 + 3, dn[r * 4 + 1].x - dn[r * 4 + 3].x, dn[r * 4 + 1].y - dn[r * 4 + 3].y);
+          auto put = [&](int pt, float2 v) { setV(pt, v.x, v.y); };
+          put(r * 4 + 0, pk_sub<PK>(dn[r * 4 + 0], dn[r * 4 + 2]));
+          put(r * 4 + 1, pk_add<PK>(dn[r * 4 + 1], dn[r * 4 + 2]));
+          put(r * 4 + 2, pk_sub<PK>(dn[r * 4 + 2], dn[r * 4 + 1]));
+          put(r * 4 + 3, pk_sub<PK>(dn[r * 4 + 1], dn[r * 4 + 3]));
         };
         // points in PAIRS, their k-steps and channel blocks interleaved: no MFMA waits on its predecessor
         float4 u[2][2];   // {cb0 s0, cb0 s1, cb1 s0, cb1 s1}
@@ -370,23 +372,10 @@ __global__ __launch_bounds__(512, 2) void wino_tall_kernel(const WinoJobs jt, co
     const int co = UGN_EPI_PAIR ? 2 * lj : lj;      // the lane's first channel (wino_common.h pair_lj / pair_cb)
     float y[2][4][4];      // [block][tile r][output (a,b) row-major]
     unsigned o[4][4];      // element offsets inside the image: the image base is wave-uniform and rides in SGPRs
+    wino_out_transform<2, PK>(acc, y);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int ti = 4 * kq + r, tr = ti >> 3, tc = ti & 7;
-#pragma unroll
-      for (int cb = 0; cb < 2; ++cb) {
-        float sm[2][4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          sm[0][c] = acc[cb][0 * 4 + c][r] + acc[cb][1 * 4 + c][r] + acc[cb][2 * 4 + c][r];
-          sm[1][c] = acc[cb][1 * 4 + c][r] - acc[cb][2 * 4 + c][r] - acc[cb][3 * 4 + c][r];
-        }
-#pragma unroll
-        for (int a = 0; a < 2; ++a) {
-          y[cb][r][a * 2 + 0] = sm[a][0] + sm[a][1] + sm[a][2];
-          y[cb][r][a * 2 + 1] = sm[a][1] - sm[a][2] - sm[a][3];
-        }
-      }
       const int oy = ry0 + 2 * (trow0 + 2 * tr), ox = rx0 + 2 * tc;
       if constexpr (EPI == EPI_LRELU_POOL) {
         constexpr int HP = HW / 2;

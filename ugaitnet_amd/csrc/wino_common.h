@@ -116,6 +116,60 @@ __device__ __forceinline__ void dma4(const void* gsrc, unsigned lds_dst_uniform)
                : "memory");
 }
 
+// Packed fp32 arithmetic.  The Winograd transforms are sums and differences of register PAIRS (a lane owns two channels of
+// every patch element); written on a 2-vector type they become v_pk_add_f32 (both halves in one full-rate instruction, the
+// subtraction as a neg modifier) -- half the vector instructions of the transforms, whose issue time adds to the MFMA time.
+#ifndef UGN_PK
+#define UGN_PK 1
+#endif
+typedef float v2f __attribute__((ext_vector_type(2)));
+template <bool PK = (UGN_PK != 0)>
+__device__ __forceinline__ float2 pk_add(float2 a, float2 b) {
+  if constexpr (PK) {
+    const v2f r = v2f{a.x, a.y} + v2f{b.x, b.y};
+    return make_float2(r.x, r.y);
+  } else {
+    return make_float2(a.x + b.x, a.y + b.y);
+  }
+}
+template <bool PK = (UGN_PK != 0)>
+__device__ __forceinline__ float2 pk_sub(float2 a, float2 b) {
+  if constexpr (PK) {
+    const v2f r = v2f{a.x, a.y} - v2f{b.x, b.y};
+    return make_float2(r.x, r.y);
+  } else {
+    return make_float2(a.x - b.x, a.y - b.y);
+  }
+}
+
+// Output transform Y = A^T M A of the lane's accumulators: acc[cb][pt] holds point pt of the lane's 4 tiles (one register
+// each) for channel block cb -> y[cb][tile r][2x2 output, row-major].  The tiles r = 0..3 are the 4 registers of an
+// accumulator, so the packed form handles two tiles per instruction.
+template <int NB, bool PK>
+__device__ __forceinline__ void wino_out_transform(const f32x4 (&acc)[NB][16], float (&y)[NB][4][4]) {
+#pragma unroll
+  for (int rp = 0; rp < 2; ++rp)
+#pragma unroll
+    for (int cb = 0; cb < NB; ++cb) {
+      auto m = [&](int pt) { return make_float2(acc[cb][pt][2 * rp], acc[cb][pt][2 * rp + 1]); };
+      float2 sm[2][4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        sm[0][c] = pk_add<PK>(pk_add<PK>(m(0 * 4 + c), m(1 * 4 + c)), m(2 * 4 + c));
+        sm[1][c] = pk_sub<PK>(pk_sub<PK>(m(1 * 4 + c), m(2 * 4 + c)), m(3 * 4 + c));
+      }
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        const float2 y0 = pk_add<PK>(pk_add<PK>(sm[a][0], sm[a][1]), sm[a][2]);
+        const float2 y1 = pk_sub<PK>(pk_sub<PK>(sm[a][1], sm[a][2]), sm[a][3]);
+        y[cb][2 * rp][a * 2 + 0] = y0.x;
+        y[cb][2 * rp + 1][a * 2 + 0] = y0.y;
+        y[cb][2 * rp][a * 2 + 1] = y1.x;
+        y[cb][2 * rp + 1][a * 2 + 1] = y1.y;
+      }
+    }
+}
+
 // One ds_read_b64 that the compiler cannot fuse.  The halo tiles are laid out bank-exact for ds_read_b64 (64 banks, 32 lanes
 // per pass), but hipcc fuses neighbouring 8-byte reads into ds_read2_b64 / ds_read2st64_b64, which bank mod 32 at half rate and
 // hit this layout 2-way: 16 LDS cycles per pair of reads instead of 4, on the operand every transform waits for (removing the
