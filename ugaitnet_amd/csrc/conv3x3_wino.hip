@@ -38,14 +38,19 @@ __device__ unsigned long long ugn_stamp_buf[8 * 2048];
 constexpr int TW = 16, PW = TW + 2, PH = 18, NPIX = PH * PW;   // 16x16 output region, 18x18 halo
 constexpr int CS = 36;                                         // halo pixel stride (floats) per 32-channel chunk
 constexpr int HSLOTS = NPIX * 9;                                // 16-byte slots of a halo tile (8 data + 1 pad per pixel)
-constexpr int HPIECES = 46;                                     // 1 KB LDS-DMA pieces per halo tile (46 * 64 >= HSLOTS)
-constexpr int SIN = HPIECES * 256;                              // one halo buffer (floats) = 47,104 B
+// An LDS-DMA piece (64 lanes x 16 B) starts at a PIXEL boundary: 7 pixels = 63 slots, and lane 63 writes the first slot of
+// the next pixel (the same data the next piece puts there).  A lane's place inside its pixel group is then a constant of the
+// lane, and the per-piece address arithmetic is one multiply-shift for the halo row instead of divisions by 9 and 18.
+constexpr int HPX = 7, HPIECES = (NPIX + HPX - 1) / HPX;        // 47 pieces (8 waves x 6 = 48 issue slots)
+constexpr int SIN = ((HPIECES - 1) * HPX * 9 + 64) * 4;         // one halo buffer (floats) = 47,392 B incl. the last piece's overhang
 constexpr int SU = 16 * 4 * 32 * 4;                             // one filter slice: [16 pts][4 kq][32 out][4 ch] = 32 KB
 constexpr int LDS_BYTES = (2 * SIN + 2 * SU) * 4 + 8 * 256;     // 159,744 B + a 256-B dump per wave (of 163,840)
 // pooled-resolution input (data gradient of a MaxPool'ed layer): the LDS tile holds the 10x10 POOLED pixels under the halo,
 // 40 floats per pixel = 32 gradient values + 32 argmax bytes; the scatter through the argmax happens when a lane reads
 // its 4x4 patch (3x3 pooled pixels), so the 4x larger un-pooled gradient is never materialised anywhere.
-constexpr int UPW = 12, UCS = 44, UPIX = 10 * UPW, USLOTS = UPIX * 11, UPIECES = 21;   // 10 rows x (10 + 2 pad) positions
+constexpr int UPW = 12, UCS = 44, UPIX = 10 * UPW, USLOTS = UPIX * 11;   // 10 rows x (10 + 2 pad) positions
+constexpr int UPX = 5, UPIECES = UPIX / UPX;                    // pooled pieces: 5 positions = 55 slots (+ 9 of the next): 24 pieces
+static_assert(((UPIECES - 1) * UPX * 11 + 64) * 4 <= SIN, "pooled tile fits the halo buffer");
 // LDS bank layout.  A lane of an MFMA is (tile lj, channel slot kq) and reads its patch with ds_read_b64; the hardware
 // serves 32 lanes per pass, i.e. all 16 tiles x 2 channel slots.  Two choices make every pass touch each bank exactly twice
 // (ds_read_b64: 64 banks, 32 lanes per pass) -- the b64 optimum: (1) the halo tile stores the EVEN columns of a row first,
@@ -134,18 +139,19 @@ __global__ void wino_pack_multi_kernel(WinoPackTable t) {
   wino_pack_one(t.w[j], t.u[j], t.cin[j], t.cout[j], t.dgrad[j], blockIdx.x * blockDim.x + threadIdx.x);
 }
 
-// One 1 KB piece of the halo tile of (image, region origin, chunk): lane l fills 16-byte slot inst*64 + l; slot s =
-// pixel position s/9 (row-major, columns in colpos order), quarter-row s%9 (the 9th is the pad of the 36-float stride).
-// Geometry of halo slot (piece inst, lane): row, column and quarter-row, packed (yy << 16 | xx << 8 | c4).  It does not
-// depend on the item, so each lane computes its 6 values once per launch instead of dividing by 9 and 18 per piece.
-__device__ __forceinline__ int halo_slot_geometry(int inst, int lane) {
-  inst = inst < HPIECES ? inst : HPIECES - 1;      // 8 waves x 6 pieces = 48 >= 46: the surplus repeats the last piece
-  int slot = inst * 64 + lane;
-  slot = slot < HSLOTS ? slot : HSLOTS - 1;
-  const int p = slot / 9, c4 = slot - p * 9;
-  const int yy = p / PW, xp = p - yy * PW;
-  const int xx = xp < 9 ? 2 * xp : 2 * (xp - 9) + 1;   // even columns first (see colpos)
-  return (yy << 16) | (xx << 8) | c4;
+// Lane constants of the halo DMA: lane l of a piece fills slot 9 * (l / 9) + l % 9 of the piece's 7-pixel group, i.e.
+// quarter-row c4 = l % 9 of pixel j = l / 9 (lane 63: first slot of the following pixel).  The pad slot (c4 = 8) is never
+// read: it carries the pixel's last quarter-row again, so no lane needs a channel test.  Packed: j | (float offset << 8).
+__device__ __forceinline__ int halo_lane_geometry(int lane) {
+  const int j = (lane * 57) >> 9, c4 = lane - 9 * j;      // lane / 9, lane % 9
+  return j | ((c4 < 8 ? c4 : 7) * 4) << 8;
+}
+// pooled tile: slot 11 * (l / 11) + l % 11 of the piece's 5-position group -- part c = l % 11: 0..7 gradient values,
+// 8..9 argmax bytes, 10 pad (never read: carries part 9 again).  Packed: j | (byte offset inside the pixel << 8) | is_idx << 16.
+__device__ __forceinline__ int pooled_lane_geometry(int lane) {
+  const int j = (lane * 47) >> 9, c = lane - 11 * j;      // lane / 11, lane % 11
+  const int cc = c < 10 ? c : 9;
+  return j | (cc < 8 ? cc * 16 : (cc - 8) * 16) << 8 | (cc >= 8 ? 1 << 16 : 0);
 }
 
 // The compiler may not hoist what is derived from the result out of a loop: the per-lane slot geometry of a DMA piece is
@@ -156,33 +162,41 @@ __device__ __forceinline__ int opaque(int v) {
   return v;
 }
 
+// One piece of the halo tile of (image, region origin, chunk): pixels 7 * inst .. 7 * inst + 6 (row-major over the 18 x 18
+// halo, columns in colpos order) -> 63 + 1 slots at byte inst * 1008.  `lq` = halo_lane_geometry(lane).
 template <int KC, int HW>
 __device__ __forceinline__ void dma_halo_piece(const float* __restrict__ in, const float* __restrict__ zeros, int img, int ry0,
-                                               int rx0, int chunk, int inst, int geom, unsigned lds_byte_base) {
-  inst = inst < HPIECES ? inst : HPIECES - 1;
-  const int yy = geom >> 16, xx = (geom >> 8) & 0xff, c4 = geom & 0xff;
+                                               int rx0, int chunk, int inst, int lq, unsigned lds_byte_base) {
+  inst = inst < HPIECES ? inst : HPIECES - 1;       // 8 waves x 6 pieces = 48 >= 47: the surplus repeats the last piece
+  const int p = inst * HPX + (lq & 0xff);           // (the last piece's p runs to 329: halo "row 18", in the buffer's overhang)
+  const int yy = (p * 3641) >> 16, xp = p - yy * PW;          // p / 18 exactly for p < 400
+  const int xx = 2 * xp - (xp >= 9 ? 17 : 0);       // even columns first (see colpos)
   const int gy = ry0 - 1 + yy, gx = rx0 - 1 + xx;
-  const bool ok = c4 < 8 && (unsigned)gy < (unsigned)HW && (unsigned)gx < (unsigned)HW;
-  const float* src = ok ? in + (((size_t)img * HW + gy) * HW + gx) * KC + chunk * 32 + c4 * 4 : zeros;
-  dma16(src, lds_byte_base + (unsigned)inst * 1024u);   // all-scalar: base, inst are wave-uniform SGPR values
+  const bool ok = (unsigned)gy < (unsigned)HW && (unsigned)gx < (unsigned)HW;
+  const float* base = in + (size_t)img * HW * HW * KC + chunk * 32;        // wave-uniform
+  const float* src = ok ? base + (unsigned)((gy * HW + gx) * KC + (lq >> 8)) : zeros;
+  dma16(src, lds_byte_base + (unsigned)inst * (HPX * 9 * 16));
 }
 
-// One 1 KB piece of the POOLED input tile: slot s = pooled pixel s/11, part s%11 (0..7 values, 8..9 argmax bytes, 10 pad).
+// One piece of the POOLED input tile: positions 5 * inst .. 5 * inst + 4 of the 10 x 12 grid (positions 10, 11 of a row are
+// padding), 11 slots each (8 of values, 2 of argmax bytes, 1 pad).  `lq` = pooled_lane_geometry(lane).
 template <int KC, int HW>
 __device__ __forceinline__ void dma_pooled_piece(const float* __restrict__ dz, const uint8_t* __restrict__ idx,
                                                  const float* __restrict__ zeros, int img, int ry0, int rx0, int chunk,
-                                                 int inst, int lane, unsigned lds_byte_base) {
+                                                 int inst, int lq, unsigned lds_byte_base) {
   constexpr int HP = HW / 2;
-  inst = inst < UPIECES ? inst : UPIECES - 1;     // 8 waves x 3 pieces = 24 >= 18: the surplus repeats the last piece
-  int slot = inst * 64 + lane;
-  slot = slot < USLOTS ? slot : USLOTS - 1;
-  const int p = slot / 11, c = slot - p * 11;
-  const int pr = ry0 / 2 - 1 + p / UPW, pc = rx0 / 2 - 1 + p % UPW;
-  const bool ok = pr >= 0 && pr < HP && pc >= 0 && pc < HP && p % UPW < 10;   // positions 10, 11 of a row are padding
-  const size_t o = (((size_t)img * HP + pr) * HP + pc) * KC + chunk * 32;
-  const void* src = (!ok || c >= 10) ? (const void*)zeros
-                                     : (c < 8 ? (const void*)(dz + o + c * 4) : (const void*)(idx + o + (c - 8) * 16));
-  dma16(src, lds_byte_base + (unsigned)inst * 1024u);
+  inst = inst < UPIECES ? inst : UPIECES - 1;       // (8 waves x 3 pieces = 24 = UPIECES)
+  const int p = inst * UPX + (lq & 0xff);           // (the last piece's lanes 55.. see "row 10": harmless, inside the buffer)
+  const int prow = (p * 2731) >> 15, ppos = p - prow * UPW;   // p / 12 exactly for p < 200
+  const int pr = ry0 / 2 - 1 + prow, pc = rx0 / 2 - 1 + ppos;
+  const bool ok = (unsigned)pr < (unsigned)HP && (unsigned)pc < (unsigned)HP && ppos < 10;
+  const unsigned o = (unsigned)((pr * HP + pc) * KC);                       // element offset of the pooled pixel
+  const size_t pix = (size_t)img * HP * HP * KC + chunk * 32;               // wave-uniform
+  const bool is_idx = (lq >> 16) != 0;
+  const char* vsrc = reinterpret_cast<const char*>(dz + pix) + (size_t)(o * 4u + (unsigned)((lq >> 8) & 0xff));
+  const char* isrc = reinterpret_cast<const char*>(idx + pix) + (size_t)(o + (unsigned)((lq >> 8) & 0xff));
+  const void* src = !ok ? (const void*)zeros : (is_idx ? (const void*)isrc : (const void*)vsrc);
+  dma16(src, lds_byte_base + (unsigned)inst * (UPX * 11 * 16));
 }
 
 // The 4x4 patch of one channel pair (h = 0: channels 2kq, 2kq+1 of the group; h = 1: 8 + those).  Plain input: 16
@@ -308,11 +322,12 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const WinoJobs jt, const f
   const int ibase = ((a_trow * UPW + a_tc) * UCS + 32) * 4 + 2 * kq;           // BYTE offset of the argmax pair (pooled tile)
   const int ubase = (kq * 32 + ch * 16 + lj) * 4;
 
+  const int hlq = IN_UNPOOL ? pooled_lane_geometry(lane) : halo_lane_geometry(lane);   // the lane's place in a DMA piece
   int item = blockIdx.x;
   const int nitems = jt.start[kMaxJobs];
   if (item >= nitems) return;
-  // (the slot geometry of a DMA piece is recomputed where the piece is issued: ~10 VALU per piece, but six fewer live
-  //  registers in a kernel that sits at the 256-register limit)
+  // (what depends on the piece is recomputed where the piece is issued, see opaque(): ~15 VALU per piece, but no live
+  //  registers across the MFMA loop in a kernel that sits at the 256-register limit)
   // item -> job (wave-uniform: the table is read with scalar loads, once per item, at the item boundary)
   int jb = wino_job_of(jt, item), lit = item - jt.start[jb];   // job and job-local number of the current item
   auto u_slice = [&](const float* upk, int lit_, int chunk, int G) {
@@ -326,11 +341,11 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const WinoJobs jt, const f
     if constexpr (IN_UNPOOL) {
 #pragma unroll
       for (int j = 0; j < 3; ++j)
-        dma_pooled_piece<KC, HW>(in, in_idx, zeros, img, (rrem / RPX) * 16, (rrem % RPX) * 16, 0, wave * 3 + j, lane, sin_bytes);
+        dma_pooled_piece<KC, HW>(in, in_idx, zeros, img, (rrem / RPX) * 16, (rrem % RPX) * 16, 0, wave * 3 + j, hlq, sin_bytes);
     } else {
 #pragma unroll
       for (int j = 0; j < 6; ++j)
-        dma_halo_piece<KC, HW>(in, zeros, img, (rrem / RPX) * 16, (rrem % RPX) * 16, 0, wave * 6 + j, halo_slot_geometry(wave * 6 + j, lane), sin_bytes);
+        dma_halo_piece<KC, HW>(in, zeros, img, (rrem / RPX) * 16, (rrem % RPX) * 16, 0, wave * 6 + j, hlq, sin_bytes);
     }
     dma_u_slice<BF>(u_slice(jt.job[jb].upk, lit, 0, 0), su_bytes, tid, wave);
   }
@@ -543,11 +558,11 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const WinoJobs jt, const f
           // a full group old at the next barrier and the next chunk's first transform can be pipelined as well
           if constexpr (IN_UNPOOL) {
             if (!(UGN_ABLATE & 2) && G == 0 && pt >= 1 && pt <= 3)
-              dma_pooled_piece<KC, HW>(in, in_idx, zeros, n_img, n_ry0, n_rx0, n_chunk, wave * 3 + (pt - 1), opaque(lane),
+              dma_pooled_piece<KC, HW>(in, in_idx, zeros, n_img, n_ry0, n_rx0, n_chunk, wave * 3 + (pt - 1), opaque(hlq),
                                        sin_bytes + (unsigned)(ibuf ^ 1) * SIN * 4u);
           } else {
             if (!(UGN_ABLATE & 2) && G == 0 && pt >= 1 && pt < 7)   // early in the group: the pieces must have landed by the group's end
-              dma_halo_piece<KC, HW>(in, zeros, n_img, n_ry0, n_rx0, n_chunk, wave * 6 + (pt - 1), halo_slot_geometry(wave * 6 + (pt - 1), opaque(lane)),
+              dma_halo_piece<KC, HW>(in, zeros, n_img, n_ry0, n_rx0, n_chunk, wave * 6 + (pt - 1), opaque(hlq),
                                      sin_bytes + (unsigned)(ibuf ^ 1) * SIN * 4u);
           }
           if (tnext) {
