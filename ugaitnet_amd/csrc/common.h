@@ -29,7 +29,8 @@ void ugn_set_error(const char* fmt, ...);
     }                                                                               \
   } while (0)
 
-__device__ __forceinline__ float ugn_lrelu(float v) { return v > 0.f ? v : v * UGN_LRELU_ALPHA; }
+// (0 < alpha < 1: max(v, alpha * v) IS v > 0 ? v : alpha * v, signed zeros included -- two instructions instead of three)
+__device__ __forceinline__ float ugn_lrelu(float v) { return __builtin_fmaxf(v, v * UGN_LRELU_ALPHA); }
 __device__ __forceinline__ float ugn_lrelu_slope(float act) { return act > 0.f ? 1.f : UGN_LRELU_ALPHA; }
 
 // v_mfma_f32_32x32x2_f32: lane l supplies A[i = l&31][k = l>>5] and B[k = l>>5][j = l&31];

@@ -294,8 +294,8 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const WinoJobs jt, const f
   constexpr bool B64 = UGN_B64ASM && !IN_UNPOOL && !BF && (EPI != EPI_DGRAD || (KC == 128 && NCF == 64));
   // packed transform arithmetic (wino_common.h pk_add): -1...7 % except where the aligned register pairs it needs push the
   // kernel into spilling inside the loop (the 128 -> 128 forward kernel; the bf16 variants stay as they were)
-  constexpr bool PK = UGN_PK && !BF && !(KC == 128 && NCF == 128 && EPI != EPI_DGRAD);
-  constexpr bool PKE = PK;
+  constexpr int PK = (UGN_PK && !BF && !(KC == 128 && NCF == 128 && EPI != EPI_DGRAD)) ? 1 : 0;
+  constexpr int PKE = PK;
   constexpr int NB = WIDE ? 2 : 1;          // 16-channel output blocks per wave
   constexpr int NG = WIDE ? 4 : 2;          // channel groups per 32-channel chunk
   constexpr int GW = 32 / NG;               // input channels per group

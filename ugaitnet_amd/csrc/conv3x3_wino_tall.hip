@@ -119,7 +119,8 @@ template <int KC, int HW, int IN_UNPOOL, int EPI, int EFLAGS, bool BF = false>
 __global__ __launch_bounds__(512, 2) void wino_tall_kernel(const WinoJobs jt, const float* __restrict__ zeros) {
   // unfused patch reads: -3.5 % on the 64 -> 32 data gradient (a3 | b1); the 32 -> 32 forward spills with them (+24 %)
   constexpr bool B64 = UGN_TALL_B64 && !IN_UNPOOL && !BF && KC == 64;
-  constexpr bool PK = UGN_PK && !BF;           // packed transform arithmetic (wino_common.h pk_add)
+  constexpr int PK = (UGN_PK && !BF) ? 1 : 0;   // packed transform arithmetic (wino_common.h pk_add)
+  constexpr int PKE = PK;
   constexpr int NST = KC / 16;                 // 16-channel stages per item
   constexpr int NGI = 2 * NST;                 // 8-channel groups per item
   constexpr int NCF = 32;
@@ -372,7 +373,7 @@ __global__ __launch_bounds__(512, 2) void wino_tall_kernel(const WinoJobs jt, co
     const int co = UGN_EPI_PAIR ? 2 * lj : lj;      // the lane's first channel (wino_common.h pair_lj / pair_cb)
     float y[2][4][4];      // [block][tile r][output (a,b) row-major]
     unsigned o[4][4];      // element offsets inside the image: the image base is wave-uniform and rides in SGPRs
-    wino_out_transform<2, PK>(acc, y);
+    wino_out_transform<2, PKE>(acc, y);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int ti = 4 * kq + r, tr = ti >> 3, tc = ti & 7;

@@ -32,25 +32,16 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
-// Packed fp32 arithmetic for the operand transforms (v_pk_add_f32: two sums per full-rate instruction; the vector
-// instructions of the transforms issue in series with the MFMAs, so halving them is a direct gain).  A lane owns ONE channel
-// of its patch, so the pairs are neighbouring patch columns: the row pass B^T d combines whole pairs, the column pass
-// (t B) needs (t0 - t2, t1 + t2) and (t2 - t1, t1 - t3) from the pairs (t0, t1), (t2, t3) -- one instruction each with the
-// op_sel / neg modifiers of the packed encoding (the compiler builds the second form with two extra moves, hence the asm).
+// Packed fp32 arithmetic for the operand transforms (v_pk_add_f32: two sums per full-rate instruction).  A lane owns ONE
+// channel of its patch, so the pairs are neighbouring patch columns: the row pass B^T d combines whole pairs and packs, the
+// column pass (t B) mixes the halves of its pairs and stays scalar -- the op_sel forms the compiler builds for it measure
+// 2.5 % SLOWER than scalar code, and inline asm is not an option next to MFMAs (wino_common.h pk_add).  The gradient
+// transform A dY A^T packs over the lane's two channel blocks.  Worth 0.4 % here (the forward / data-gradient kernels, whose
+// lanes own channel pairs, gain 1-7 % from the same idea).
 #ifndef UGN_WG_PK
 #define UGN_WG_PK 1
 #endif
 typedef float wg_v2f __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ wg_v2f wg_col01(wg_v2f a, wg_v2f b) {   // (a.x - b.x, a.y + b.x)
-  wg_v2f r;
-  asm("v_pk_add_f32 %0, %1, %2 op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));
-  return r;
-}
-__device__ __forceinline__ wg_v2f wg_col23(wg_v2f a, wg_v2f b) {   // (b.x - a.y, a.y - b.y)
-  wg_v2f r;
-  asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[1,0]" : "=v"(r) : "v"(b), "v"(a));
-  return r;
-}
 
 // bf16 operands (template flag BF, shapes with 16 tiles per wave and region): the 4 k-steps of a region become the 4 k-slots
 // of ONE v_mfma_f32_16x16x16_bf16 per (point, channel block) -- slot j = the lane's tile of step j on both operands.
@@ -381,8 +372,10 @@ __global__ __launch_bounds__(512, 2) void wgrad_wino_kernel(const WgJobs jt, con
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const wg_v2f v01 = wg_col01(tp[r][0], tp[r][1]), v23 = wg_col23(tp[r][0], tp[r][1]);
-          V[r * 4 + 0] = v01.x; V[r * 4 + 1] = v01.y; V[r * 4 + 2] = v23.x; V[r * 4 + 3] = v23.y;
+          V[r * 4 + 0] = tp[r][0].x - tp[r][1].x;
+          V[r * 4 + 1] = tp[r][0].y + tp[r][1].x;
+          V[r * 4 + 2] = tp[r][1].x - tp[r][0].y;
+          V[r * 4 + 3] = tp[r][0].y - tp[r][1].y;
         }
       } else {
         float tt[16];

@@ -122,8 +122,12 @@ __device__ __forceinline__ void dma4(const void* gsrc, unsigned lds_dst_uniform)
 #ifndef UGN_PK
 #define UGN_PK 1
 #endif
+// (2-vector arithmetic that the compiler turns into the packed instruction; it splits part of it back into scalar
+// instructions in the tall kernel.  Forcing the instruction with inline asm is NOT an option next to MFMAs: the wait states
+// of the MFMA hazards -- a vector instruction reading a fresh MFMA result, or overwriting the accumulator input of an MFMA
+// in flight -- are inserted by the compiler for instructions it can see only; the asm form computed garbage.)
 typedef float v2f __attribute__((ext_vector_type(2)));
-template <bool PK = (UGN_PK != 0)>
+template <int PK = UGN_PK>
 __device__ __forceinline__ float2 pk_add(float2 a, float2 b) {
   if constexpr (PK) {
     const v2f r = v2f{a.x, a.y} + v2f{b.x, b.y};
@@ -132,7 +136,7 @@ __device__ __forceinline__ float2 pk_add(float2 a, float2 b) {
     return make_float2(a.x + b.x, a.y + b.y);
   }
 }
-template <bool PK = (UGN_PK != 0)>
+template <int PK = UGN_PK>
 __device__ __forceinline__ float2 pk_sub(float2 a, float2 b) {
   if constexpr (PK) {
     const v2f r = v2f{a.x, a.y} - v2f{b.x, b.y};
@@ -145,7 +149,7 @@ __device__ __forceinline__ float2 pk_sub(float2 a, float2 b) {
 // Output transform Y = A^T M A of the lane's accumulators: acc[cb][pt] holds point pt of the lane's 4 tiles (one register
 // each) for channel block cb -> y[cb][tile r][2x2 output, row-major].  The tiles r = 0..3 are the 4 registers of an
 // accumulator, so the packed form handles two tiles per instruction.
-template <int NB, bool PK>
+template <int NB, int PK>
 __device__ __forceinline__ void wino_out_transform(const f32x4 (&acc)[NB][16], float (&y)[NB][4][4]) {
 #pragma unroll
   for (int rp = 0; rp < 2; ++rp)
@@ -227,13 +231,17 @@ __device__ __forceinline__ void wino_epilogue(const float (&y)[NB][4][4], const 
         unsigned bi[W];
 #pragma unroll
         for (int e = 0; e < W; ++e) {
-          best[e] = ugn_lrelu(y[blk * W + e][r][0]);
+          // LeakyReLU is increasing, also after rounding: the window is pooled on the raw sums and the activation applied to
+          // the winner only (a quarter of the activation work).  Equal sums stay equal, so exact ties route as before; only two
+          // DIFFERENT negative sums whose products with 0.3 round to the same float now prefer the larger instead of the first.
+          best[e] = y[blk * W + e][r][0];
           bi[e] = 0;
 #pragma unroll
           for (int q = 1; q < 4; ++q) {
-            const float v = ugn_lrelu(y[blk * W + e][r][q]);
+            const float v = y[blk * W + e][r][q];
             if (v > best[e]) { best[e] = v; bi[e] = q; }     // strict >: the FIRST maximum wins (TF MaxPoolGrad routing)
           }
+          best[e] = ugn_lrelu(best[e]);
         }
         st(out, o[r][0] + cofs, best);
         if constexpr (W == 2) *reinterpret_cast<uint16_t*>(out_idx + o[r][0]) = (uint16_t)(bi[0] | (bi[1] << 8));
