@@ -262,6 +262,9 @@ __device__ __forceinline__ void read_pair_pooled_row(float2 (&dn)[16], const flo
 }
 
 // 32 KB filter slice (16 KB of bf16 elements): linear in both spaces, 4 (2) pieces of 1 KB per wave (8 waves)
+#ifndef UGN_B64_DGRAD
+#define UGN_B64_DGRAD 1
+#endif
 #ifndef UGN_ALT_PRIO
 #define UGN_ALT_PRIO 1
 #endif
@@ -291,7 +294,7 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const WinoJobs jt, const f
   constexpr bool ALT_PRIO = UGN_ALT_PRIO && EPI != EPI_DGRAD;
   // unfused ds_read_b64 patch reads (wino_common.h lds_read_b64): -1.5...4 % where the extra register pressure does not spill
   // into the loop: the forward kernels and the 128 -> 64 data gradient
-  constexpr bool B64 = UGN_B64ASM && !IN_UNPOOL && !BF && (EPI != EPI_DGRAD || (KC == 128 && NCF == 64));
+  constexpr bool B64 = UGN_B64ASM && !IN_UNPOOL && !BF && (UGN_B64_DGRAD || EPI != EPI_DGRAD || (KC == 128 && NCF == 64));
   // packed transform arithmetic (wino_common.h pk_add): -1...7 % except where the aligned register pairs it needs push the
   // kernel into spilling inside the loop (the 128 -> 128 forward kernel; the bf16 variants stay as they were)
   constexpr int PK = (UGN_PK && !BF && !(KC == 128 && NCF == 128 && EPI != EPI_DGRAD)) ? 1 : 0;

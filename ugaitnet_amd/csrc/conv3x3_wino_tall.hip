@@ -118,7 +118,7 @@ __device__ __forceinline__ void tall_dma_u(const float* __restrict__ us, unsigne
 template <int KC, int HW, int IN_UNPOOL, int EPI, int EFLAGS, bool BF = false>
 __global__ __launch_bounds__(512, 2) void wino_tall_kernel(const WinoJobs jt, const float* __restrict__ zeros) {
   // unfused patch reads: -3.5 % on the 64 -> 32 data gradient (a3 | b1); the 32 -> 32 forward spills with them (+24 %)
-  constexpr bool B64 = UGN_TALL_B64 && !IN_UNPOOL && !BF && KC == 64;
+  constexpr bool B64 = UGN_TALL_B64 && !IN_UNPOOL && !BF && (KC == 64 || UGN_TALL_B64 == 2);
   constexpr int PK = (UGN_PK && !BF) ? 1 : 0;   // packed transform arithmetic (wino_common.h pk_add)
   constexpr int PKE = PK;
   constexpr int NST = KC / 16;                 // 16-channel stages per item

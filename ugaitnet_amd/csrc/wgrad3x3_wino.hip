@@ -41,6 +41,11 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
 #ifndef UGN_WG_PK
 #define UGN_WG_PK 1
 #endif
+// timing-only ablations (WRONG results): 1 no input-transform arithmetic, 2 no gradient-transform arithmetic, 4 no operand
+// reads from LDS, 8 no MFMA, 16 no DMA
+#ifndef UGN_WG_ABLATE
+#define UGN_WG_ABLATE 0
+#endif
 typedef float wg_v2f __attribute__((ext_vector_type(2)));
 
 // bf16 operands (template flag BF, shapes with 16 tiles per wave and region): the 4 k-steps of a region become the 4 k-slots
@@ -149,6 +154,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_wino_kernel(const WgJobs jt, con
     dgeo[j] = (dp << 8) | (DZ_UNPOOL ? dq : (dq ^ swz(dp)));
   }
   auto issue_dma = [&](int job, int gregion, int buf) {   // (ONE table entry is read per call: scalar loads)
+    if constexpr ((UGN_WG_ABLATE & 16) != 0) return;
     const float* __restrict__ in = jt.job[job].in;
     const float* __restrict__ dz = jt.job[job].dz;
     const uint8_t* __restrict__ dz_idx = jt.job[job].dz_idx;
@@ -210,6 +216,11 @@ __global__ __launch_bounds__(512, 2) void wgrad_wino_kernel(const WgJobs jt, con
     float d[16], yv[2][4];
     unsigned ypos[2];
     auto load_raw = [&](int st) {
+      if constexpr ((UGN_WG_ABLATE & 4) != 0) {
+        for (int e = 0; e < 16; ++e) d[e] = (float)(st + e);
+        for (int cb = 0; cb < 2; ++cb) { for (int e = 0; e < 4; ++e) yv[cb][e] = (float)(cb + e); ypos[cb] = (unsigned)st; }
+        return;
+      }
       // this lane's tile of the step: t = ks*TPW + st*4 + kq, row t>>3 (0..3), col t&7.  Split into a lane part (kq, ks) and
       // a compile-time step part so that no address arithmetic is left inside the loop: the tile origin p0 = 2*(18*tr + tc)
       // has swizzle bit (18*tr + tc) & 1 = tc & 1 = kq & 1 -- a lane constant.
@@ -359,7 +370,10 @@ __global__ __launch_bounds__(512, 2) void wgrad_wino_kernel(const WgJobs jt, con
     for (int st = 0; st < STEPS; ++st) {
       // ---- A operand: V = B^T d B of (tile, input channel cib*16 + lj)
       float V[16], Q[2][16];
-      if constexpr (UGN_WG_PK && !DZ_UNPOOL) {   // (the pooled shapes measure 0.5-1.5 % slower with it)
+      if constexpr ((UGN_WG_ABLATE & 1) != 0) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) V[e] = d[e];
+      } else if constexpr (UGN_WG_PK && !DZ_UNPOOL) {   // (the pooled shapes measure 0.5-1.5 % slower with it)
         wg_v2f tp[4][2];   // [row of t][column pair]
 #pragma unroll
         for (int cp = 0; cp < 2; ++cp) {
@@ -395,7 +409,12 @@ __global__ __launch_bounds__(512, 2) void wgrad_wino_kernel(const WgJobs jt, con
         }
       }
       // ---- B operand: Q = A dY A^T of (tile, output channel cop*32 + cb*16 + lj)
-      if constexpr (!DZ_UNPOOL && UGN_WG_PK) {
+      if constexpr ((UGN_WG_ABLATE & 2) != 0) {
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) Q[cb][e] = yv[cb][DZ_UNPOOL ? 0 : (e & 3)];
+      } else if constexpr (!DZ_UNPOOL && UGN_WG_PK) {
         // (packed over the lane's two channel blocks; sign convention of rows / columns 3 as in the scalar form below)
         const wg_v2f y00 = {yv[0][0], yv[1][0]}, y01 = {yv[0][1], yv[1][1]}, y10 = {yv[0][2], yv[1][2]}, y11 = {yv[0][3], yv[1][3]};
         wg_v2f q[4][2];
@@ -450,8 +469,13 @@ __global__ __launch_bounds__(512, 2) void wgrad_wino_kernel(const WgJobs jt, con
       __builtin_amdgcn_s_setprio(1);   // keep the matrix pipe while the SIMD's other wave transforms its operands
 #pragma unroll
       for (int pt = 0; pt < 16; ++pt) {
-        acc[pt][0] = mfma16(V[pt], Q[0][pt], acc[pt][0]);
-        acc[pt][1] = mfma16(V[pt], Q[1][pt], acc[pt][1]);
+        if constexpr ((UGN_WG_ABLATE & 8) != 0) {
+          acc[pt][0][0] += V[pt] * Q[0][pt];
+          acc[pt][1][0] += V[pt] * Q[1][pt];
+        } else {
+          acc[pt][0] = mfma16(V[pt], Q[0][pt], acc[pt][0]);
+          acc[pt][1] = mfma16(V[pt], Q[1][pt], acc[pt][1]);
+        }
       }
       __builtin_amdgcn_s_setprio(0);
     }

@@ -179,6 +179,8 @@ __device__ __forceinline__ void wino_out_transform(const f32x4 (&acc)[NB][16], f
 // hit this layout 2-way: 16 LDS cycles per pair of reads instead of 4, on the operand every transform waits for (removing the
 // patch reads altogether saves 15-20 % of a forward kernel, tools/stamps.py / UGN_ABLATE).  The asm form keeps them apart with
 // ONE address register and immediate offsets.  The compiler does not see the load: patch_wait() must come before the first use.
+// (A volatile load keeps the reads apart as well, but pins all 16 in program order: 57-152 spilled registers in the tall kernel,
+// +8 % on the pooled data gradient.)
 #ifndef UGN_B64ASM
 #define UGN_B64ASM 1
 #endif
