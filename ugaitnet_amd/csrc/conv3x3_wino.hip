@@ -261,7 +261,37 @@ __device__ __forceinline__ void read_pair_pooled_row(float2 (&dn)[16], const flo
     }
 }
 
+// The same in two halves for the wide variant: the three value pairs of pooled row PROW are read with UNFUSED ds_read_b64
+// (lds_read_b64: the compiler would fuse them into ds_read2_b64, 2-way bank conflicted on this layout) one point ahead of
+// their use; pooled_row_select() waits for them and scatters them through the argmax bytes.
+template <int PROW>
+__device__ __forceinline__ void pooled_row_issue(float2 (&pv)[3], const float* base) {
+  const unsigned a0 = lds_addr(base);
+  pv[0] = lds_read_b64<(PROW * UPW + 0) * UCS * 4>(a0);
+  pv[1] = lds_read_b64<(PROW * UPW + 1) * UCS * 4>(a0);
+  pv[2] = lds_read_b64<(PROW * UPW + 2) * UCS * 4>(a0);
+}
+template <int PROW>
+__device__ __forceinline__ void pooled_row_select(float2 (&dn)[16], float2 (&pv)[3], const uint8_t* ibytes) {
+  unsigned iw[3];
+#pragma unroll
+  for (int qc = 0; qc < 3; ++qc) iw[qc] = *reinterpret_cast<const uint16_t*>(ibytes + (PROW * UPW + qc) * UCS * 4);
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(pv[0]), "+v"(pv[1]), "+v"(pv[2]), "+v"(iw[0]), "+v"(iw[1]), "+v"(iw[2]));
+#pragma unroll
+  for (int r = (PROW == 0 ? 0 : (PROW == 1 ? 1 : 3)); r <= (PROW == 0 ? 0 : (PROW == 1 ? 2 : 3)); ++r)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int qc = (c + 1) >> 1;
+      const unsigned pos = (((r + 1) & 1) << 1) | ((c + 1) & 1);
+      dn[r * 4 + c].x = (iw[qc] & 0xffu) == pos ? pv[qc].x : 0.f;
+      dn[r * 4 + c].y = (iw[qc] >> 8) == pos ? pv[qc].y : 0.f;
+    }
+}
+
 // 32 KB filter slice (16 KB of bf16 elements): linear in both spaces, 4 (2) pieces of 1 KB per wave (8 waves)
+#ifndef UGN_POOLED_B64
+#define UGN_POOLED_B64 1
+#endif
 #ifndef UGN_B64_DGRAD
 #define UGN_B64_DGRAD 1
 #endif
@@ -299,6 +329,7 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const WinoJobs jt, const f
   // kernel into spilling inside the loop (the 128 -> 128 forward kernel; the bf16 variants stay as they were)
   constexpr int PK = (UGN_PK && !BF && !(KC == 128 && NCF == 128 && EPI != EPI_DGRAD)) ? 1 : 0;
   constexpr int PKE = PK;
+  constexpr bool PB64 = UGN_POOLED_B64 && IN_UNPOOL && WIDE && !BF;   // unfused reads of the pooled tile (pooled_row_issue)
   constexpr int NB = WIDE ? 2 : 1;          // 16-channel output blocks per wave
   constexpr int NG = WIDE ? 4 : 2;          // channel groups per 32-channel chunk
   constexpr int GW = 32 / NG;               // input channels per group
@@ -458,6 +489,7 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const WinoJobs jt, const f
         // one V set plus the row-pass temporaries are live: the kernel must fit 256 arch VGPRs beside 128 accumulators.
         // (WIDE has a single channel pair per group: its row pass runs in place on dn, which frees 32 registers)
         float2 dn[16], tn0s[16], tn1[16];
+        float2 pvr[3];   // (PB64) raw value pairs of the pooled row in flight
         float2 (&tn0)[16] = *(WIDE ? &dn : &tn0s);
         auto rowpass = [&](float2 (&tn)[16], int c) {
           if (UGN_ABLATE & 4) { tn[0 + c] = dn[0 + c]; tn[4 + c] = dn[4 + c]; tn[8 + c] = dn[8 + c]; tn[12 + c] = dn[12 + c]; return; }
@@ -545,7 +577,12 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const WinoJobs jt, const f
           for (int half = 0; half < 2; ++half) {
           const int pt = 2 * pp + half;
           constexpr bool ROWWISE = IN_UNPOOL != 0;   // pooled tile: the patch arrives one pooled row per point
-          if constexpr (ROWWISE) {
+          if constexpr (ROWWISE && PB64) {
+            if (pt == 0) pooled_row_issue<0>(pvr, sNx);
+            if (pt == 1) { pooled_row_select<0>(dn, pvr, sNi); pooled_row_issue<1>(pvr, sNx); }
+            if (pt == 2) { pooled_row_select<1>(dn, pvr, sNi); pooled_row_issue<2>(pvr, sNx); }
+            if (pt == 3) pooled_row_select<2>(dn, pvr, sNi);
+          } else if constexpr (ROWWISE) {
             if (pt == 0) read_pair_pooled_row<0>(dn, sNx, sNi);
             if (pt == 1) read_pair_pooled_row<1>(dn, sNx, sNi);
             if (pt == 2) read_pair_pooled_row<2>(dn, sNx, sNi);
