@@ -119,6 +119,9 @@ def join_backward_streams(device):
 # single-GPU boxes this round ran on.
 AR_OVERLAP = os.environ.get("UGN_AR_OVERLAP", "0") == "1"
 
+# UGN_HEAD_SIDE=0: the classification head's forward on the main stream, behind the triplet kernel, instead of beside it.
+HEAD_SIDE = os.environ.get("UGN_HEAD_SIDE", "1") == "1"
+
 # UGN_ROUTED=1: form the set-max gradient inside the a3 / a5 data-gradient epilogues instead of materialising it with
 # setmax_bwd (bit-identical; measured 2.5 % SLOWER on MI355X: three operand loads per element make those epilogues spill).
 ROUTED = USE_WINOGRAD and os.environ.get("UGN_ROUTED", "0") == "1"
@@ -750,11 +753,17 @@ class GaitCore:
         b = sig.shape[1]
         self._ar_pending = [] if (self.dp_active and AR_OVERLAP and not BRANCH_STREAMS) else None
         w_tri, w_id = self.loss_weights
+        if self.nclasses > 0:
+            # the classification head's forward (two small kernels) runs on the side stream, beside the triplet kernel: both
+            # only read the signature; the head's backward ADDS to the triplet's signature gradient, so it waits for both
+            oh = self._dev(onehot, (b, self.nclasses))
+            with (_side(self.device) if HEAD_SIDE else contextlib.nullcontext()):
+                self.head = ops.head_fwd(sig, self.store.p["head.wc"], self.store.p["head.bc"], oh, w_id / b,
+                                         self._head_bufs(b))
         self.bin_loss, self.bin_num, dsig = self._triplet(sig, labels, w_tri)
         if self.nclasses > 0:
-            oh = self._dev(onehot, (b, self.nclasses))
-            self.head = ops.head_fwd(sig, self.store.p["head.wc"], self.store.p["head.bc"], oh, w_id / b,
-                                     self._head_bufs(b))
+            if WGRAD_STREAM and HEAD_SIDE:
+                torch.cuda.current_stream(self.device).wait_stream(_wgrad_stream(self.device))
             ops.head_bwd(sig, self.store.p["head.wc"], self.head["dlogits"], dsig, True, self.store.g["head.wc"],
                          self.store.g["head.bc"])
             if self.global_batch:   # every replica holds the head gradient of the whole batch; the all-reduce sums them
