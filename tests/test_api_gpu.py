@@ -202,3 +202,41 @@ def test_checkpoints_are_keras_hdf5_files(dev, tmp_path):
     e.load_weights(wpath)
     layers = [l for l in keras_h5.read_layers(wpath) if l[0] != "classprob"]
     assert len(layers) == 22
+
+
+def test_model_config_file_drives_loadnet_and_surgery(dev, tmp_path):
+    """`model-config.hdf5` beside a checkpoint (mains/mj_trainUWYHGaitNet_DataGen_CasiaB.py:474-489): the surgery route of
+    build_or_load rebuilds from it (reference :610-630) and loadnet falls back to it for a model file it cannot interpret
+    (:1008-1030), taking the arrays of `<net>_weights.hdf5` by name."""
+    from ugaitnet_amd import ddconfig, h5lite
+    from ugaitnet_amd.nets.mj_uwyhNets_ba import UWYHSemiNet, optimizers, sign_max
+    shapes = [(3, 60, 60, 2), (3, 60, 60, 1)]
+    a = UWYHSemiNet.build_or_load(shapes, 4, [7, 5, 3, 2], [96, 192, 512, 4096], nclasses=5, margin=0.25,
+                                  optimizer=optimizers.Adam(lr=1e-3), loss_weights=[1.0, 0.1], fMerge=sign_max, gaitset=True,
+                                  seed=3)
+    xs, uses, labels, onehot = make_batch(("of", "gray"), 4, 3, 5, ids=2, seed=9)
+    X = [xs[0], uses[0], xs[1], uses[1]]
+    sig = a.predict(X)[0]
+    net = os.path.join(tmp_path, "model-final.hdf5")
+    a.save_weights(UWYHSemiNet.get_weights_filename(net))
+    # what the main stores: names for optimizer and merge function, the shapes as a list of tuples
+    ddconfig.save(UWYHSemiNet.get_netconfig_filename(net),
+                  {"filters_size": [7, 5, 3, 2], "filters_numbers": [96, 192, 512, 4096], "input_shape": shapes,
+                   "ndense_units": 0, "weight_decay": 1e-4, "dropout": 0.4, "optimizer": "Adam", "margin": 0.25,
+                   "custom": "TripletSemiHardLoss", "nclasses": 5, "softlabel": 0, "use3D": False,
+                   "loss_weights": [1.0, 0.1], "fMerge": "sign_max"})
+    # (1) a model file of foreign make (here: a weights-only file under the model's name): loadnet rebuilds from the config
+    w = h5lite.Writer()
+    w.create_dataset("model_weights/placeholder", np.zeros(1, np.float32))
+    w.save(net)
+    b = UWYHSemiNet.loadnet(net)
+    assert b.get_layer("classprob").units == 5 and b.margin == 0.25 and b.fmerge_mode == "sign_max"
+    assert np.array_equal(b.predict(X)[0], sig)
+    # (2) surgery: the checkpoint has 5 classes, the caller wants 9 -> configuration + caller's settings, weights by name
+    a.save(net)
+    c = UWYHSemiNet.build_or_load([(9, 9, 9, 9)], 4, [7, 5, 3, 2], [96, 192, 512, 4096], nclasses=9, margin=0.3,
+                                  optimizer=optimizers.Adam(lr=2e-3), loss_weights=[1.0, 0.5], initnet=net, fMerge=sign_max,
+                                  gaitset=True)
+    assert c.get_layer("classprob").units == 9 and c.margin == 0.3 and c.loss_weights == [1.0, 0.5]
+    assert [tuple(s) for s in c.input_shapes] == shapes       # from the stored configuration, not from the (wrong) argument
+    assert np.array_equal(c.predict(X)[0], sig)

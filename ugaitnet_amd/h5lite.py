@@ -56,8 +56,13 @@ def _parse_datatype(buf, off=0):
         if (b0 & 15) != 1:
             raise H5Error("variable-length sequences (only variable-length strings are supported)")
         return _Type("vlen_str", None, 16, utf8=bool(b1 & 15))
-    if cls == 8:    # enumeration (h5py booleans): read as the base integer type
-        return _parse_datatype(buf, off + 8)
+    if cls == 4:    # bit field: read as the unsigned integer of its size
+        return _Type("num", np.dtype("%su%d" % (">" if b0 & 1 else "<", size)), size)
+    if cls == 8:    # enumeration: the base integer type; the two-member one-byte one (h5py / PyTables booleans) as bool
+        base = _parse_datatype(buf, off + 8)
+        if size == 1 and (b0 | (b1 << 8)) == 2:
+            return _Type("num", np.dtype(np.bool_), 1)
+        return base
     raise H5Error("datatype class %d (version %d)" % (cls, ver))
 
 
@@ -546,6 +551,9 @@ def _dtype_msg(dt):
         return struct.pack("<BBBBIHHBBBBI", 0x11, 0x20, sign, 0, dt.itemsize, 0, 8 * dt.itemsize, eloc, esz, mloc, msz, bias)
     if dt.kind == "S":
         return struct.pack("<BBBBI", 0x13, 0x01, 0, 0, max(dt.itemsize, 1))     # null-padded ASCII
+    if dt.kind == "b":   # the int8 enumeration FALSE = 0 / TRUE = 1 that h5py and PyTables store booleans as
+        base = struct.pack("<BBBBIHH", 0x10, 0x08, 0, 0, 1, 0, 8)
+        return struct.pack("<BBBBI", 0x18, 2, 0, 0, 1) + base + _pad8(b"FALSE\0") + _pad8(b"TRUE\0") + bytes([0, 1])
     raise H5Error("cannot write dtype %r" % (dt,))
 
 
@@ -555,8 +563,17 @@ def _space_msg(shape):
     return struct.pack("<BBBBI", 1, len(shape), 0, 0, 0) + struct.pack("<%dQ" % len(shape), *shape)
 
 
+class Bool:
+    """Marks a scalar to be written as an HDF5 boolean (enumeration) instead of the uint8 other booleans become."""
+
+    def __init__(self, v):
+        self.v = bool(v)
+
+
 def _as_array(v):
     """Attribute / dataset value -> numpy array of a writable dtype (str -> fixed-length bytes)."""
+    if isinstance(v, Bool):
+        return np.array(v.v, dtype=np.bool_)
     if isinstance(v, str):
         v = v.encode("utf-8")
     if isinstance(v, bytes):

@@ -69,6 +69,54 @@ def _freeze_like_reference(model, build, initnet, freeze_convs, freeze_all, weig
     return model
 
 
+def _resolve_config(netconfig):
+    """A configuration as stored in `model-config.hdf5` (ugaitnet_amd.ddconfig) names its optimizer and merge function
+    (`'optimizer': 'Adam'`, `'fMerge': 'Maximum'`: strings, mains/mj_trainUWYHGaitNet_DataGen_CasiaB.py:474-489); the
+    surgery route then overwrites both with live objects.  Either spelling is accepted."""
+    cfg = dict(netconfig)
+    opt = cfg.get("optimizer")
+    if isinstance(opt, str):
+        table = {"adam": Adam, "sgd": SGD}
+        if opt.lower() not in table:
+            raise ValueError("model configuration: unknown optimizer %r (Adam, SGD)" % opt)
+        cfg["optimizer"] = table[opt.lower()]()        # Keras' defaults, as compile(optimizer='Adam') takes them
+    fm = cfg.get("fMerge", Maximum)
+    if isinstance(fm, str):
+        table = {"Maximum": Maximum, "Average": Average, "sign_max": sign_max}
+        if fm not in table:
+            raise ValueError("model configuration: unknown fMerge %r (Maximum, Average, sign_max)" % fm)
+        fm = table[fm]
+    cfg["fMerge"] = fm
+    shp = cfg["input_shape"]
+    cfg["input_shape"] = [tuple(int(v) for v in t) for t in shp] if isinstance(shp[0], (list, tuple)) else tuple(int(v) for v in shp)
+    return cfg
+
+
+def _load_netconfig(modelpath):
+    """The dictionary of `<directory of modelpath>/model-config.hdf5`, or None when there is no such file."""
+    import os
+    from .. import ddconfig
+    fconfig = UWYHSemiNet.get_netconfig_filename(modelpath)
+    return ddconfig.load(fconfig) if os.path.exists(fconfig) else None
+
+
+def _surgery(cls, initnet, build, overrides):
+    """Reference :610-630 / :1331-1352: a checkpoint whose classification layer has another width is rebuilt from the stored
+    configuration (with the caller's loss / optimizer settings written over it) and takes the compatible weights of
+    `<initnet>_weights.hdf5` by name.  Without a configuration file the model is built from the caller's arguments."""
+    import os
+    netconfig = _load_netconfig(initnet)
+    if netconfig is None:
+        model = build()
+        model.load_weights(initnet, by_name=True, skip_mismatch=True)
+        return model
+    netconfig.update(overrides)
+    model = cls.build_by_config(netconfig)
+    filewes = UWYHSemiNet.get_weights_filename(initnet)
+    model.load_weights(filewes if os.path.exists(filewes) else initnet, by_name=True, skip_mismatch=True)
+    return model
+
+
 class UWYHSemiNet:
     """1- or 2-modality model (reference :581-999).  `input_shapes`: a tuple (L,60,60,C) for one modality, a list of two
     such tuples for two (first = optical flow, second = gray)."""
@@ -90,13 +138,15 @@ class UWYHSemiNet:
 
     @staticmethod
     def build_by_config(netconfig):
-        return UWYHSemiNet.build(netconfig["input_shape"], len(netconfig["filters_numbers"]), netconfig["filters_size"],
-                                 netconfig["filters_numbers"], netconfig["ndense_units"], netconfig["weight_decay"],
-                                 netconfig["dropout"], nclasses=netconfig.get("nclasses", 150),
-                                 loss_weights=netconfig.get("loss_weights", [1.0, 0.1]), optimizer=netconfig["optimizer"],
-                                 margin=netconfig["margin"], use3D=netconfig.get("use3D", False),
-                                 postriplet=netconfig.get("postriplet", 1), fMerge=netconfig.get("fMerge", Maximum),
-                                 fActivation=netconfig.get("fActivation", "relu"), gaitset=netconfig.get("gaitset", True))
+        """Reference :299-340 (`mj_buildnet_by_config`): the model a stored configuration describes.  A configuration of the
+        gaitset mains carries no `gaitset` key (it is a command-line switch there); this build has no other path."""
+        c = _resolve_config(netconfig)
+        return UWYHSemiNet.build(c["input_shape"], len(c["filters_numbers"]), c["filters_size"], c["filters_numbers"],
+                                 c["ndense_units"], c["weight_decay"], c["dropout"], nclasses=c.get("nclasses", 150),
+                                 loss_weights=c.get("loss_weights", [1.0, 0.1]), optimizer=c["optimizer"],
+                                 margin=float(c["margin"]), use3D=bool(c.get("use3D", False)),
+                                 postriplet=c.get("postriplet", 1), fMerge=c["fMerge"],
+                                 fActivation=c.get("fActivation", "relu"), gaitset=c.get("gaitset", True))
 
     @staticmethod
     def get_weights_filename(modelpath):
@@ -109,8 +159,23 @@ class UWYHSemiNet:
 
     @staticmethod
     def loadnet(netpath: str):
+        """Reference :553-577 (and the live fallback of :1008-1030): a model file this build wrote is loaded as such; one it
+        cannot interpret (a Keras-written model) is rebuilt from `model-config.hdf5` beside it, when that exists, and takes
+        the arrays of `<netpath>_weights.hdf5` by name."""
         print(netpath)
-        return load_model(netpath, compile=False)
+        try:
+            return load_model(netpath, compile=False)
+        except ValueError:
+            netconfig = _load_netconfig(netpath)
+            if netconfig is None:
+                raise
+            import os
+            shapes = netconfig["input_shape"]
+            cls = UWYHSemiNet3Mods if isinstance(shapes[0], (list, tuple)) and len(shapes) == 3 else UWYHSemiNet
+            model = cls.build_by_config(netconfig)
+            filewes = UWYHSemiNet.get_weights_filename(netpath)
+            model.load_weights(filewes if os.path.exists(filewes) else netpath, by_name=True)
+            return model
 
     @staticmethod
     def build_or_load(input_shapes, number_convolutional_layers, filters_size, filters_numbers, ndense_units=512,
@@ -139,8 +204,10 @@ class UWYHSemiNet:
                 units = nclasses
             if units != nclasses:
                 print("Surgery needed: {} vs {}".format(units, nclasses))
-                model = build()
-                model.load_weights(initnet, by_name=True, skip_mismatch=True)   # load compatible weights
+                model = _surgery(UWYHSemiNet, initnet, build,
+                                 dict(nclasses=nclasses, loss_weights=loss_weights, dropout=dropout, margin=margin,
+                                      optimizer=optimizer if optimizer is not None else optimizers.SGD(0.001, 0.9), use3D=use3D,
+                                      postriplet=postriplet, fMerge=fMerge, fActivation=fActivation, gaitset=gaitset))
             else:
                 model = model_base
             model = _freeze_like_reference(model, build, initnet, freeze_convs, freeze_all, UWYHSemiNet.get_weights_filename)
@@ -195,6 +262,17 @@ class UWYHSemiNet3Mods(UWYHSemiNet):
         return GaitSetModel(shapes, nclasses, loss_weights, margin, optimizer, fMerge, True, seed=seed)
 
     @staticmethod
+    def build_by_config(netconfig):
+        """Reference :299-340 with `UWYHSemiNet3Mods.build` (:1019-1023)."""
+        c = _resolve_config(netconfig)
+        return UWYHSemiNet3Mods.build(c["input_shape"], len(c["filters_numbers"]), c["filters_size"], c["filters_numbers"],
+                                      c["ndense_units"], c["weight_decay"], c["dropout"], nclasses=c.get("nclasses", 150),
+                                      loss_weights=c.get("loss_weights", [1.0, 0.1]), optimizer=c["optimizer"],
+                                      margin=float(c["margin"]), use3D=bool(c.get("use3D", False)),
+                                      postriplet=c.get("postriplet", 1), fMerge=c["fMerge"],
+                                      fActivation=c.get("fActivation", "relu"), gaitset=c.get("gaitset", True))
+
+    @staticmethod
     def compile_hard(model, optimizer, loss_weights, margin):
         """Reference :1301-1306: recompile with tfa.losses.TripletHardLoss(margin) in place of the batch-all loss."""
         from ..keras_compat import TripletHardLoss
@@ -225,8 +303,10 @@ class UWYHSemiNet3Mods(UWYHSemiNet):
             model_base = UWYHSemiNet3Mods.loadnet(initnet)
             if model_base.get_layer("classprob").units != nclasses:
                 print("Surgery needed: {} vs {}".format(model_base.get_layer("classprob").units, nclasses))
-                model = build()
-                model.load_weights(initnet, by_name=True, skip_mismatch=True)
+                model = _surgery(UWYHSemiNet3Mods, initnet, build,
+                                 dict(nclasses=nclasses, loss_weights=loss_weights, dropout=dropout, margin=margin,
+                                      optimizer=optimizer if optimizer is not None else optimizers.SGD(0.001, 0.9), use3D=use3D,
+                                      postriplet=postriplet, fMerge=fMerge, fActivation=fActivation, gaitset=gaitset))
             else:
                 model = model_base
             model = _freeze_like_reference(model, build, initnet, freeze_convs, freeze_all, UWYHSemiNet.get_weights_filename)
