@@ -42,7 +42,7 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
 #define UGN_WG_PK 1
 #endif
 // timing-only ablations (WRONG results): 1 no input-transform arithmetic, 2 no gradient-transform arithmetic, 4 no operand
-// reads from LDS, 8 no MFMA, 16 no DMA
+// reads from LDS, 8 no MFMA, 16 no DMA, 32 no operand reads in a region's FIRST step, 64 none in the other steps
 #ifndef UGN_WG_ABLATE
 #define UGN_WG_ABLATE 0
 #endif
@@ -216,7 +216,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_wino_kernel(const WgJobs jt, con
     float d[16], yv[2][4];
     unsigned ypos[2];
     auto load_raw = [&](int st) {
-      if constexpr ((UGN_WG_ABLATE & 4) != 0) {
+      if ((UGN_WG_ABLATE & 4) != 0 || ((UGN_WG_ABLATE & 32) != 0 && st == 0) || ((UGN_WG_ABLATE & 64) != 0 && st != 0)) {
         for (int e = 0; e < 16; ++e) d[e] = (float)(st + e);
         for (int cb = 0; cb < 2; ++cb) { for (int e = 0; e < 4; ++e) yv[cb][e] = (float)(cb + e); ypos[cb] = (unsigned)st; }
         return;
