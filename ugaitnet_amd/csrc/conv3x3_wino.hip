@@ -321,7 +321,7 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const WinoJobs jt, const f
   // WIDE (NCF >= 64): the workgroup owns 64 output channels, a wave 16 tiles x 2 channel blocks, and a group is 8 input
   // channels (2 k-steps): per MFMA half the transform work, patch reads and halo traffic of the narrow variant.
   constexpr bool WIDE = wino_wide_ex(KC, NCF, BF, IN_UNPOOL != 0);
-  constexpr bool ALT_PRIO = UGN_ALT_PRIO && EPI != EPI_DGRAD;
+  constexpr bool ALT_PRIO = UGN_ALT_PRIO == 2 || (UGN_ALT_PRIO && EPI != EPI_DGRAD);
   // unfused ds_read_b64 patch reads (wino_common.h lds_read_b64): -1.5...4 % where the extra register pressure does not spill
   // into the loop: the forward kernels and the 128 -> 64 data gradient
   constexpr bool B64 = UGN_B64ASM && !IN_UNPOOL && !BF && (UGN_B64_DGRAD || EPI != EPI_DGRAD || (KC == 128 && NCF == 64));
