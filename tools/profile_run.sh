@@ -25,3 +25,19 @@ pmc sq SQ_BUSY_CU_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAVE_CYCLES SQ_
 pmc fetch FETCH_SIZE
 pmc write WRITE_SIZE
 python3 $REPO/tools/pmc_summary.py $OUT/prof_$TAG $OUT/${TAG}_pmc_summary.csv > /dev/null && echo "pmc summary written"
+# LDS bank conflicts per kernel (profiles/<tag>_lds_conflicts.csv): conflict cycles / LDS active cycles, LDS active / CU busy
+pmc lds SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_BUSY_CU_CYCLES
+python3 - "$OUT/prof_$TAG/lds_counter_collection.csv" "$OUT/${TAG}_lds_conflicts.csv" <<'PY' && echo "lds summary written"
+import collections, csv, sys
+agg = collections.defaultdict(lambda: collections.defaultdict(list))
+for r in csv.DictReader(open(sys.argv[1])):
+    n = r["Kernel_Name"].replace("void ", "").replace("(anonymous namespace)::", "").replace("ugn_wino::", "").split("(")[0]
+    agg[n][r["Counter_Name"]].append(float(r["Counter_Value"]))
+m = lambda v: sum(v) / len(v) if v else 0.0
+rows = [(m(c["SQ_BUSY_CU_CYCLES"]), n, c) for n, c in agg.items() if m(c["SQ_LDS_IDX_ACTIVE"]) > 1e6]
+with open(sys.argv[2], "w") as f:
+    f.write("kernel,lds_bank_conflict_per_active_cycle,lds_active_per_cu_busy_cycle,lds_instructions_per_launch\n")
+    for _, n, c in sorted(rows, key=lambda t: -t[0]):
+        f.write('"%s",%.3f,%.3f,%.0f\n' % (n, m(c["SQ_LDS_BANK_CONFLICT"]) / m(c["SQ_LDS_IDX_ACTIVE"]),
+                                          m(c["SQ_LDS_IDX_ACTIVE"]) / m(c["SQ_BUSY_CU_CYCLES"]), m(c["SQ_INSTS_LDS"])))
+PY
