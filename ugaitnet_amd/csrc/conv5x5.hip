@@ -16,6 +16,13 @@ namespace {
 #ifndef UGN_C5_GRID
 #define UGN_C5_GRID 1024   // persistent workgroups of the forward kernel (256 CUs x 4 workgroups of 256 threads)
 #endif
+#ifndef UGN_C5_PITCH
+#define UGN_C5_PITCH 20  // pixels per patch row in the weight-gradient kernel's LDS tile: 26 would be bank-conflict free
+                         // for the five tap rows, but its extra LDS-DMA pieces cost more than the conflicts (+2-3 %)
+#endif
+#ifndef UGN_C5_DS
+#define UGN_C5_DS 32     // floats per pixel of the gradient tile in LDS (36 = padded, the earlier layout)
+#endif
 constexpr int T5 = 16;          // 16x16 output tile
 constexpr int P5 = T5 + 4;      // 20x20 input patch
 constexpr int RAW = 60, DOM = 64;
@@ -162,7 +169,8 @@ __device__ __forceinline__ void dma4_c5(const void* gsrc, unsigned lds_dst_unifo
 }
 
 // dw[k][co] = sum_pixels patch[pixel + tap_k][c_k] * dz1[pixel][co]; persistent workgroups, slabs [groups][25*CIN][32].
-// The gradient tile (16x16 pixels x 32 channels, 36-float pixel stride) and the input patch of the NEXT tile stream into
+// The gradient tile (16x16 pixels x 32 channels, unpadded: a lane pair reads pixels p, p + 1 = the two bank halves) and the
+// input patch of the NEXT tile stream into
 // the second LDS buffer by LDS-DMA (16-byte pieces for the gradient, dwords for the unaligned patch; lanes outside the image
 // or in the pad read a zero block) while the current tile is multiplied: the kernel runs at the rate dz1 can be read.
 template <int CIN, bool SIGN>
@@ -170,10 +178,12 @@ __global__ __launch_bounds__(256) void conv5x5_wgrad_kernel(const float* __restr
                                                             float* __restrict__ slab, const float* __restrict__ zeros,
                                                             const uint32_t* __restrict__ a1_sign, int tiles_total) {
   constexpr int K = 25 * CIN, MBK = (K + 31) / 32;
-  constexpr int DS = 36;
-  constexpr int SDF = T5 * T5 * DS;                       // floats per gradient buffer (36,864 B = 36 pieces of 1 KB)
-  constexpr int PE = P5 * P5 * CIN, PPIECES = (PE + 63) / 64, SPF = PPIECES * 64;   // patch dwords, 256-B pieces
-  constexpr int DPW = 9, PPW = (PPIECES + 3) / 4;         // pieces per wave
+  constexpr int DS = UGN_C5_DS;
+  constexpr int SDF = T5 * T5 * DS;                       // floats per gradient buffer (32 KB = 32 pieces of 1 KB)
+  // patch rows of WP pixels (UGN_C5_PITCH)
+  constexpr int WP = UGN_C5_PITCH;
+  constexpr int PE = P5 * WP * CIN, PPIECES = (PE + 63) / 64, SPF = PPIECES * 64;   // patch dwords, 256-B pieces
+  constexpr int DPW = DS / 4, PPW = (PPIECES + 3) / 4;    // pieces per wave
   extern __shared__ __attribute__((aligned(16))) float smem5[];
   float* sD0 = smem5;                 // [2][SDF]
   float* sP0 = smem5 + 2 * SDF;       // [2][SPF]
@@ -195,7 +205,7 @@ __global__ __launch_bounds__(256) void conv5x5_wgrad_kernel(const float* __restr
     int k = mb * 32 + li;
     if (k >= K) k = 0;  // padded rows: any valid address, result discarded
     const int tap = k / CIN, c = k % CIN;
-    abase[mb] = ((tap / 5) * P5 + (tap % 5)) * CIN + c + ((wave * 4) * P5 + lh) * CIN;  // wave owns tile rows 4w..4w+3
+    abase[mb] = ((tap / 5) * WP + (tap % 5)) * CIN + c + ((wave * 4) * WP + lh) * CIN;  // wave owns tile rows 4w..4w+3
   }
   const int bbase = (wave * 64 + lh) * DS + li;
 
@@ -203,8 +213,8 @@ __global__ __launch_bounds__(256) void conv5x5_wgrad_kernel(const float* __restr
   int dgeo[DPW], pgeo[PPW];
 #pragma unroll
   for (int j = 0; j < DPW; ++j) {
-    const int slot = (wave * DPW + j) * 64 + lane;       // 4 waves x 9 pieces = 36 = all slots
-    const int p = slot / 9, c4 = slot - p * 9;
+    const int slot = (wave * DPW + j) * 64 + lane;       // 4 waves x DPW pieces = all slots
+    const int p = slot / (DS / 4), c4 = slot - p * (DS / 4);
     dgeo[j] = c4 < 8 ? ((p >> 4) * DOM + (p & 15)) * 32 + c4 * 4 : -1;
   }
 #pragma unroll
@@ -213,7 +223,7 @@ __global__ __launch_bounds__(256) void conv5x5_wgrad_kernel(const float* __restr
     inst = inst < PPIECES ? inst : PPIECES - 1;
     const int e = inst * 64 + lane;
     const int pe = e / CIN, ch = e - pe * CIN;
-    pgeo[j] = e < PE ? ((pe / P5) << 16) | ((pe % P5) << 8) | ch : -1;
+    pgeo[j] = (e < PE && pe % WP < P5) ? ((pe / WP) << 16) | ((pe % WP) << 8) | ch : -1;
   }
   auto issue_dma = [&](int tile, int buf) {
     const int img = tile >> 4, trem = tile & 15;
@@ -246,7 +256,7 @@ __global__ __launch_bounds__(256) void conv5x5_wgrad_kernel(const float* __restr
     const float* sP = sP0 + buf * SPF;
 #pragma unroll
     for (int kp = 0; kp < 32; ++kp) {  // wave's 64 pixels: p = 2*kp + lh, row = p/16, col = p%16
-      const int po = ((2 * kp) / 16) * P5 + ((2 * kp) % 16);
+      const int po = ((2 * kp) / 16) * WP + ((2 * kp) % 16);
       float b = sD[bbase + 2 * kp * DS];
       if constexpr (SIGN) {   // dz1 arrives as dL/da1: the LeakyReLU' factor of a1 is applied here, from one bit per element
         const uint32_t wbits = sS0[buf * 256 + wave * 64 + 2 * kp + lh];
@@ -257,7 +267,7 @@ __global__ __launch_bounds__(256) void conv5x5_wgrad_kernel(const float* __restr
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  // cross-wave reduction through LDS (reuse sD: 4 waves x MBK x 16 x 64 floats <= 8192 floats < 9216)
+  // cross-wave reduction through LDS (reuse sD: 4 waves x MBK x 16 x 64 floats <= 8192 floats = one gradient buffer)
   __syncthreads();
 #pragma unroll
   for (int mb = 0; mb < MBK; ++mb)
@@ -337,7 +347,7 @@ extern "C" int ugn_conv5x5_in_wgrad(const float* x, const float* dz1, const uint
                 "ugn_conv5x5_in_wgrad: cannot allocate the zero block");
     zeros = p;
   }
-  const int lds = (2 * 256 * 36 + 2 * ((25 * 16 * cin + 63) / 64) * 64 + 2 * 256) * 4;
+  const int lds = (2 * 256 * UGN_C5_DS + 2 * ((20 * UGN_C5_PITCH * cin + 63) / 64) * 64 + 2 * 256) * 4;
   static bool attr_done[3] = {false, false, false};
   if (!attr_done[cin]) {
     const void* fns[4] = {(const void*)conv5x5_wgrad_kernel<1, false>, (const void*)conv5x5_wgrad_kernel<1, true>,
