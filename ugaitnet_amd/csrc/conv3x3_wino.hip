@@ -44,7 +44,7 @@ constexpr int HSLOTS = NPIX * 9;                                // 16-byte slots
 constexpr int HPX = 7, HPIECES = (NPIX + HPX - 1) / HPX;        // 47 pieces (8 waves x 6 = 48 issue slots)
 constexpr int SIN = ((HPIECES - 1) * HPX * 9 + 64) * 4;         // one halo buffer (floats) = 47,392 B incl. the last piece's overhang
 constexpr int SU = 16 * 4 * 32 * 4;                             // one filter slice: [16 pts][4 kq][32 out][4 ch] = 32 KB
-constexpr int LDS_BYTES = (2 * SIN + 2 * SU) * 4 + 8 * 256;     // 159,744 B + a 256-B dump per wave (of 163,840)
+constexpr int LDS_BYTES = (2 * SIN + 2 * SU) * 4 + 8 * 256;     // 160,320 B + a 256-B dump per wave = 162,368 (of 163,840)
 // pooled-resolution input (data gradient of a MaxPool'ed layer): the LDS tile holds the 10x10 POOLED pixels under the halo,
 // 40 floats per pixel = 32 gradient values + 32 argmax bytes; the scatter through the argmax happens when a lane reads
 // its 4x4 patch (3x3 pooled pixels), so the 4x larger un-pooled gradient is never materialised anywhere.
