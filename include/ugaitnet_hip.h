@@ -261,6 +261,40 @@ size_t ugn_knn_ws(int ngallery, int nprobe);
 int ugn_knn_predict(const float* gallery, const int32_t* gallery_labels, const float* probes, int ngallery, int nprobe,
                     int dim, int k, int32_t* pred, int32_t* neighbours, void* ws, size_t ws_bytes, void* stream);
 
+/* ---- "H2" tensors: the 3x3 layers on the f16 matrix pipe at fp32-class accuracy (round 3) ---------------------------
+ * Same reference call sites as the fp32 convolutions above (nets/mj_uwyhNets_ba.py:431-462); what changes is how the
+ * activations and gradients between those layers are HELD.  An H2 tensor [pixels][c] is stored as f16 bit patterns
+ * [pixels][2][c] -- plane 0 = H = f16(x * 2^e), plane 1 = L = f16(x * 2^e - H) -- with a ugn_h2meta {e, amax}:
+ * x = (H + L) * 2^-e (22 significant bits); 4 bytes per element like the fp32 tensor it replaces.  Products run as
+ * aH*bH + aH*bL + aL*bH on v_mfma_f32_32x32x16_f16 with fp32 accumulation: error <= that of an fp32 FMA chain
+ * (tools/probe_split.hip).  `e` is chosen by the producing kernel from a rigorous bound of its output, `amax` (bits of the
+ * largest |stored| value) is gathered by the producer with atomicMax and tells the consumer the true range.
+ * EVERY ugn_h2meta THAT A KERNEL WRITES MUST BE ZERO ON ENTRY (one hipMemsetAsync over the model's meta array per step). */
+typedef struct { int32_t e; uint32_t amax_bits; } ugn_h2meta;
+/* packed filter halves of a 3x3 layer: {block exponent, L1 bound}; filled by ugn_mm_pack_multi */
+typedef struct { int32_t e; float l1; } ugn_wmeta;
+/* meta <- {0, bits(max|x|)} of an fp32 tensor (meta zero on entry): what a kernel that turns fp32 into H2 needs first */
+int ugn_absmax(const float* x, size_t n, void* meta, void* stream);
+/* fp32 [npix][c] <-> H2 [npix][2][c] (tests, tools, the edges of the H2 part of the path); encode zeroes and fills meta */
+int ugn_h2_encode(const float* x, uint16_t* y, void* meta, size_t npix, int c, void* stream);
+int ugn_h2_decode(const uint16_t* y, const void* meta, float* x, size_t npix, int c, void* stream);
+/* Filters of up to 64 (layer, direction) jobs -> the order the kernels stream them (9*cin*cout halves x 2 planes =
+ * 36*cin*cout bytes per job) + their ugn_wmeta.  dgrad = 1 packs the flipped, transposed filter of the data gradient. */
+int ugn_mm_pack_multi(const float* const* w_hwio_host, uint16_t* const* wpk_host, void* const* wmeta_host,
+                      const int* cin_host, const int* cout_host, const int* dgrad_host, int njobs, void* stream);
+/* out = LeakyReLU(conv(in)) (+ MaxPool 2x2 + first-max argmax when pool), up to 6 jobs of one shape per launch; arrays are
+ * HOST arrays of device pointers.  in [n][hw][hw][2][cin], out [n][ho][ho][2][cout], out_idx uint8 [n][ho][ho][cout]. */
+int ugn_mm_conv3x3_fwd_multi(const uint16_t* const* in, const void* const* in_meta, const uint16_t* const* wpk,
+                             const void* const* wmeta, uint16_t* const* out, uint8_t* const* out_idx, void* const* out_meta,
+                             const int* n, int njobs, int hw, int cin, int cout, int pool, void* stream);
+/* Data gradient of the forward layer cin -> cout at hw x hw.  dz [n][hw][hw][2][cout], or with dz_idx the POOLED gradient
+ * [n][hw/2][hw/2][2][cout] + argmax bytes (MaxPool backward while staging).  act (optional, H2 [n][hw][hw][2][cin]):
+ * out = conv_transpose(dz, w) * LeakyReLU'(act), the sign taken from act's H plane.  wpk from ugn_mm_pack_multi(dgrad = 1). */
+int ugn_mm_conv3x3_dgrad_multi(const uint16_t* const* dz, const uint8_t* const* dz_idx, const void* const* dz_meta,
+                               const uint16_t* const* wpk, const void* const* wmeta, const uint16_t* const* act,
+                               uint16_t* const* out, void* const* out_meta, const int* n, int njobs, int hw, int cin, int cout,
+                               void* stream);
+
 #ifdef __cplusplus
 }
 #endif

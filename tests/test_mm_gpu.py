@@ -1,0 +1,167 @@
+"""Parity of the f16-matrix-pipe 3x3 kernels on H2 tensors (ugaitnet_amd/csrc/conv3x3_mm.hip, wgrad3x3_mm.hip) against the
+fp64 numpy oracle, at the SAME bars as the fp32 kernels they replace (tests/test_kernels_gpu.py): the split-fp16 products
+must be indistinguishable from fp32 arithmetic.  Reference call sites: nets/mj_uwyhNets_ba.py:431-462."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ugaitnet_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+CONV_CFGS = [  # (hw, cin, cout, pool)  == the five 3x3 shapes of the encoder
+    (64, 32, 32, True), (32, 32, 64, False), (32, 64, 64, True), (16, 64, 128, False), (16, 128, 128, False)]
+
+
+def T(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def close(got, ref, rtol, name=""):
+    got = got.detach().cpu().numpy() if isinstance(got, torch.Tensor) else np.asarray(got)
+    scale = float(np.abs(ref).max()) + 1e-300
+    err = float(np.abs(got.astype(np.float64) - ref.astype(np.float64)).max())
+    assert err <= rtol * scale, "%s: max abs err %.3e vs scale %.3e (rtol %.1e)" % (name, err, scale, rtol)
+
+
+def check_meta(t, name=""):
+    """The producer's bookkeeping: amax is the largest stored magnitude (taken before the value is split into halves, so equal
+    to 22 bits), and it stays below 2^15."""
+    e, bits = t.meta.cpu().numpy().tolist()
+    amax = float(np.array([bits], np.uint32).view(np.float32)[0])
+    d = t.data.cpu().numpy().view(np.float16).astype(np.float64)
+    stored = np.abs(d[:, :, :, 0, :] + d[:, :, :, 1, :]).max()
+    assert abs(amax - stored) <= 2.0 ** -20 * stored, "%s: meta amax %r vs stored max %r" % (name, amax, stored)
+    assert amax < 2.0 ** 15, "%s: stored max %r" % (name, amax)
+
+
+@pytest.mark.parametrize("scale", [1.0, 3e-7, 4e4])
+def test_h2_roundtrip(dev, scale):
+    from ugaitnet_amd import h2
+    rng = np.random.default_rng(5)
+    x = (rng.standard_normal((3, 16, 16, 32)) * scale).astype(np.float32)
+    x[0, 0, 0, :4] = [0.0, -0.0, scale * 1e-9, -scale * 3e-5]     # zeros and elements far below the tensor's scale
+    t = h2.encode(T(x, dev))
+    check_meta(t, "encode")
+    back = h2.decode(t).cpu().numpy()
+    # 22 significant bits per element down to 2^-18 of the tensor's maximum, absolute 2^-40 of it below
+    amax = np.abs(x).max()
+    tol = np.maximum(np.abs(x.astype(np.float64)) * 2.0 ** -21, amax * 2.0 ** -38)
+    assert np.all(np.abs(back.astype(np.float64) - x) <= tol), np.abs(back.astype(np.float64) - x).max() / amax
+    assert np.array_equal(t.numpy().astype(np.float32), back)
+    assert abs(t.true_amax() - amax) <= 1e-6 * amax
+
+
+@pytest.mark.parametrize("hw,cin,cout,pool", CONV_CFGS)
+@pytest.mark.parametrize("xscale", [1.0, 1e-5])
+def test_mm_fwd_and_dgrad(dev, hw, cin, cout, pool, xscale):
+    from ugaitnet_amd import h2
+    rng = np.random.default_rng(9000 + hw + cin + cout)
+    n = 9 if hw <= 32 else 5   # more items than one workgroup round for the small images: exercises the item pipeline
+    x = (rng.uniform(-1, 1, (n, hw, hw, cin)) * xscale).astype(np.float32)
+    w = rng.uniform(-0.2, 0.2, (3, 3, cin, cout)).astype(np.float32)
+    xt = h2.encode(T(x, dev))
+    x_h2 = xt.numpy()                      # what the kernel actually multiplies (x to 22 bits)
+    act = O.leaky(O.conv2d_same(x_h2, w.astype(np.float64)))
+    wf, mf = h2.mm_pack(T(w, dev), False)
+    ho = hw // 2 if pool else hw
+    out = h2.H2Tensor.empty((n, ho, ho, cout), dev)
+    if pool:
+        idx = torch.empty((n, ho, ho, cout), dtype=torch.uint8, device=dev)
+        h2.conv3x3_fwd_mm_multi([xt], [wf], [mf], cout, True, [out], [idx])
+        pref, iref = O.maxpool2x2(act)
+        close(out.numpy(), pref, 2e-6, "mm fwd+pool")
+        idx = idx.cpu().numpy()
+        win = act.reshape(n, hw // 2, 2, hw // 2, 2, cout).transpose(0, 1, 3, 2, 4, 5).reshape(n, hw // 2, hw // 2, 4, cout)
+        srt = np.sort(win, axis=3)
+        clear = (srt[:, :, :, 3, :] - srt[:, :, :, 2, :]) > 1e-4 * xscale
+        assert idx.max() <= 3 and np.array_equal(idx[clear], iref[clear])
+    else:
+        h2.conv3x3_fwd_mm_multi([xt], [wf], [mf], cout, False, [out])
+        close(out.numpy(), act, 2e-6, "mm fwd")
+    check_meta(out, "fwd out")
+    # data gradient, plain and with LeakyReLU'(act of the layer's input); pooled layers take the pooled gradient + argmax
+    gscale = 1e-4 * xscale               # gradients are small numbers: the block exponent has to carry them
+    act_prev = rng.normal(size=(n, hw, hw, cin)).astype(np.float32)
+    if pool:
+        dp = (rng.normal(size=(n, hw // 2, hw // 2, cout)) * gscale).astype(np.float32)
+        pidx = rng.integers(0, 4, size=dp.shape).astype(np.uint8)
+        dzt = h2.encode(T(dp, dev))
+        dz = O.maxpool2x2_bwd(pidx, dzt.numpy())
+        idx_t = [T(pidx, dev)]
+    else:
+        dzf = (rng.normal(size=(n, hw, hw, cout)) * gscale).astype(np.float32)
+        dzt = h2.encode(T(dzf, dev))
+        dz = dzt.numpy()
+        idx_t = None
+    _, dx_ref = O.conv2d_same_bwd(x_h2, w.astype(np.float64), dz)
+    wd, md = h2.mm_pack(T(w, dev), True)
+    dx = h2.H2Tensor.empty((n, hw, hw, cin), dev)
+    h2.conv3x3_dgrad_mm_multi([dzt], [wd], [md], hw, cin, cout, [dx], dz_idxs=idx_t)
+    close(dx.numpy(), dx_ref, 3e-6, "mm dgrad plain")
+    check_meta(dx, "dgrad out")
+    at = h2.encode(T(act_prev, dev))
+    dx2 = h2.H2Tensor.empty((n, hw, hw, cin), dev)
+    h2.conv3x3_dgrad_mm_multi([dzt], [wd], [md], hw, cin, cout, [dx2], dz_idxs=idx_t, acts=[at])
+    close(dx2.numpy(), np.where(at.numpy() > 0, dx_ref, 0.3 * dx_ref), 3e-6, "mm dgrad * LeakyReLU'")
+
+
+def test_mm_multi_job(dev):
+    """Six jobs of one shape in one launch (three modalities x frame-level + set-level), each with its own filters, sizes and
+    magnitudes: every job must equal its single-job launch bit for bit, and the oracle within the fp32 bar."""
+    from ugaitnet_amd import h2
+    rng = np.random.default_rng(77)
+    hw, cin, cout = 16, 64, 128
+    ns = [7, 5, 6, 2, 1, 3]
+    scales = [1.0, 0.01, 30.0, 1.0, 1e-3, 5.0]
+    xs, ws, outs, refs = [], [], [], []
+    for n, s in zip(ns, scales):
+        x = (rng.uniform(-1, 1, (n, hw, hw, cin)) * s).astype(np.float32)
+        w = rng.uniform(-0.1, 0.1, (3, 3, cin, cout)).astype(np.float32)
+        xs.append(h2.encode(T(x, dev)))
+        ws.append(h2.mm_pack(T(w, dev), False))
+        outs.append(h2.H2Tensor.empty((n, hw, hw, cout), dev))
+        refs.append(O.leaky(O.conv2d_same(xs[-1].numpy(), w.astype(np.float64))))
+    h2.conv3x3_fwd_mm_multi(xs, [w[0] for w in ws], [w[1] for w in ws], cout, False, outs)
+    for j, (o, r) in enumerate(zip(outs, refs)):
+        close(o.numpy(), r, 2e-6, "job %d" % j)
+        check_meta(o, "job %d" % j)
+        single = h2.H2Tensor.empty(o.shape, dev)
+        h2.conv3x3_fwd_mm_multi([xs[j]], [ws[j][0]], [ws[j][1]], cout, False, [single])
+        assert torch.equal(single.data, o.data) and torch.equal(single.meta, o.meta), "job %d differs from its own launch" % j
+
+
+@pytest.mark.parametrize("kind", ["flat", "diagonal"])
+def test_mm_pool_ties_route_to_the_first_maximum(dev, kind):
+    """Exact ties of a pooling window -- identical input patches under all four outputs -- must pick position 0 like TF's
+    MaxPoolGrad.  A direct convolution adds the same products in the same order for identical patches, so this holds for
+    axis-aligned flats AND for 45-degree edges (where the Winograd kernels route 1.7 % of the ties elsewhere)."""
+    from ugaitnet_amd import h2
+    rng = np.random.default_rng(3)
+    hw, cin, cout, n = 32, 64, 64, 4
+    if kind == "flat":
+        x = np.broadcast_to(rng.uniform(-1, 1, (n, 1, 1, cin)), (n, hw, hw, cin)).astype(np.float32)
+    else:   # value depends on y - x only: outputs (0,0) and (1,1) of every window see identical patches
+        yy, xx = np.meshgrid(np.arange(hw), np.arange(hw), indexing="ij")
+        prof = rng.uniform(-1, 1, (n, 2 * hw, cin)).astype(np.float32)
+        x = prof[:, (yy - xx) + hw, :]
+    w = rng.uniform(-0.2, 0.2, (3, 3, cin, cout)).astype(np.float32)
+    xt = h2.encode(T(np.ascontiguousarray(x), dev))
+    wf, mf = h2.mm_pack(T(w, dev), False)
+    out = h2.H2Tensor.empty((n, hw // 2, hw // 2, cout), dev)
+    idx = torch.empty((n, hw // 2, hw // 2, cout), dtype=torch.uint8, device=dev)
+    h2.conv3x3_fwd_mm_multi([xt], [wf], [mf], cout, True, [out], [idx])
+    act = O.leaky(O.conv2d_same(xt.numpy(), w.astype(np.float64)))
+    _, iref = O.maxpool2x2(act)
+    idx = idx.cpu().numpy()
+    inner = (slice(None), slice(1, hw // 2 - 1), slice(1, hw // 2 - 1))    # windows away from the zero padding
+    if kind == "flat":
+        assert np.all(idx[inner] == 0)
+    else:
+        win = act.reshape(n, hw // 2, 2, hw // 2, 2, cout).transpose(0, 1, 3, 2, 4, 5).reshape(n, hw // 2, hw // 2, 4, cout)
+        tied = np.abs(win[..., 0, :] - win[..., 3, :]) <= 1e-12 * np.abs(win).max()
+        top = np.maximum(win[..., 0, :], win[..., 3, :]) >= np.maximum(win[..., 1, :], win[..., 2, :]) + 1e-6
+        sel = np.zeros_like(tied)
+        sel[inner] = (tied & top)[inner]
+        assert sel.sum() > 1000
+        assert np.all(idx[sel] == 0), "%d of %d diagonal ties not routed to position 0" % ((idx[sel] != 0).sum(), sel.sum())

@@ -80,6 +80,13 @@ PROTOTYPES = {
     "ugn_knn_predict": (_i, [_p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _sz, _p]),
     "ugn_adam_step": (_i, [_p, _p, _p, _p, _sz, _f, _f, _f, _f, _f, _p]),
     "ugn_adam_step_dev": (_i, [_p, _p, _p, _p, _sz, _p, _f, _f, _f, _f, _p]),
+    # H2 tensors (split-fp16 halves + block exponent) and the f16-matrix-pipe 3x3 kernels
+    "ugn_absmax": (_i, [_p, _sz, _p, _p]),
+    "ugn_h2_encode": (_i, [_p, _p, _p, _sz, _i, _p]),
+    "ugn_h2_decode": (_i, [_p, _p, _p, _sz, _i, _p]),
+    "ugn_mm_pack_multi": (_i, [C.POINTER(_p)] * 3 + [C.POINTER(_i)] * 3 + [_i, _p]),
+    "ugn_mm_conv3x3_fwd_multi": (_i, [C.POINTER(_p)] * 7 + [C.POINTER(_i), _i, _i, _i, _i, _i, _p]),
+    "ugn_mm_conv3x3_dgrad_multi": (_i, [C.POINTER(_p)] * 8 + [C.POINTER(_i), _i, _i, _i, _i, _p]),
 }
 
 _lib = None

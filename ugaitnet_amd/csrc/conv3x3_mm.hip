@@ -1,0 +1,661 @@
+// Direct 3x3 convolution (forward / data gradient) of H2 tensors on v_mfma_f32_32x32x16_f16 -- see mm_common.h for the
+// format and why it exists.  Same operator contract as the Winograd kernels: replaces the implicit TF Conv2D /
+// Conv2DBackpropInput + LeakyRelu(Grad) + MaxPool(Grad) of reference nets/mj_uwyhNets_ba.py:431-462.
+//
+// Implicit GEMM: M = pixels, N = output channels, K = 9 taps x input channels.  A 512-thread workgroup (8 waves, two per
+// SIMD; 256 persistent workgroups stride over the items of all jobs) owns a 16x16-pixel region and ALL N channels (32, 64 or
+// 128); wave w owns pixel rows 2w, 2w+1 of the region = one 32-row MFMA block in POOL ORDER (row 4*window + position), so a
+// 2x2 pooling window is 4 consecutive accumulator registers of one lane and LeakyReLU + MaxPool + argmax are lane-local.
+//   * K runs in 32-channel chunks.  The chunk's 18x18 halo tile sits in LDS as one 128-byte record per pixel -- the H plane
+//     then the L plane of the 32 channels, i.e. exactly the bytes HBM holds -- fetched by LDS-DMA straight from the tensor;
+//     9 slots of 16 B per pixel (8 + 1 pad) and 168 slots per row (18 x 9 + 6 pad): every A fragment is ONE ds_read_b128 at
+//     lane base + immediate (tap, k-step, plane), and the 16-lane groups of ds_read_b128 hit 16 distinct slots for every tap.
+//   * Filters are packed once per step (mm_pack) in the order the kernel streams them, as f16 halves with a block exponent; a
+//     stage (1 tap x 128, or 3 taps x 32 / 64 output channels: 12-24 KB) is double-buffered in LDS by LDS-DMA, one barrier
+//     per stage.  A B fragment is one ds_read_b128 at lane * 16 + immediate.
+//   * Per (tap, 16-channel k-step, 32-channel block): acc += AH*BH + AH*BL + AL*BH -- three MFMAs, no VALU work at all.
+//   * Data gradient of a MaxPool'ed layer: the pooled gradient + argmax bytes are staged by LDS-DMA (10x10 pooled pixels) and
+//     scattered LDS -> LDS into the halo tile of the next chunk while the current one is multiplied.
+//   * Epilogue: block exponent, LeakyReLU (+ 2x2 MaxPool + argmax, first maximum wins) or LeakyReLU'(act), split into halves,
+//     4-byte stores of adjacent channel pairs; the stored maximum goes to the output's H2Meta with one atomicMax per wave.
+// MaxPool ties: identical input patches give bit-identical sums here (same operations in the same order), so EVERY exact tie
+// -- axis-aligned flats and diagonal edges alike -- routes to the first maximum like TF's MaxPoolGrad.
+#include <stdlib.h>
+#include "mm_common.h"
+
+using namespace ugn_mm;
+
+namespace {
+
+enum { EPI_LRELU = 0, EPI_LRELU_POOL = 1, EPI_DGRAD = 2, EPI_DGRAD_ACT = 3 };
+
+constexpr int HROW = 168;                       // 16-byte slots per halo row (18 pixels x 9 + 6 pad; = 8 mod 16)
+constexpr int HPIECES = 48;                     // 18 rows x 168 slots = 3024 -> 48 pieces of 64 slots (6 per wave)
+constexpr int HALO_BYTES = HPIECES * 1024;      // 49,152
+constexpr int W_OFF = 2 * HALO_BYTES;           // filter stages start here
+constexpr int STG_PIECES = 16;                  // pooled staging: 100 pooled pixels x 10 slots (H 4, L 4, argmax 2)
+constexpr int STG_BYTES = STG_PIECES * 1024;
+
+template <int NC>
+struct Geo {
+  static constexpr int NB = NC / 32;                     // 32-column MFMA blocks
+  static constexpr int TPS = NB == 4 ? 1 : 3;            // taps per filter stage
+  static constexpr int NSTG = 9 / TPS;                   // stages per 32-channel chunk
+  static constexpr int WSTAGE = TPS * NB * 4096;         // bytes: [tap][k-step 2][block][plane 2][1 KB]
+  static constexpr int WPIECES = WSTAGE / 1024;
+};
+template <int NC, int IN_POOLED>
+constexpr int lds_bytes() { return W_OFF + 2 * Geo<NC>::WSTAGE + (IN_POOLED ? STG_BYTES : 0); }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// filter statistics + packing
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int kPackJobs = 64;
+struct PackTable {
+  const float* w[kPackJobs];
+  uint16_t* pk[kPackJobs];
+  WMeta* meta[kPackJobs];
+  int cin[kPackJobs], cout[kPackJobs], dgrad[kPackJobs];
+};
+
+// one block per job: block exponent from max|w|, and the L1 bound of the direction
+__global__ __launch_bounds__(256) void mm_wstats_kernel(PackTable t) {
+  const int j = blockIdx.x, tid = threadIdx.x;
+  const float* w = t.w[j];
+  const int cin = t.cin[j], cout = t.cout[j], dgrad = t.dgrad[j];
+  float amax = 0.f;
+  for (int e = tid; e < 9 * cin * cout; e += 256) amax = fmaxf(amax, fabsf(w[e]));
+  // forward: an output channel sums over (tap, cin); data gradient: an input channel sums over (tap, cout)
+  float l1 = 0.f;
+  const int nout = dgrad ? cin : cout;
+  for (int o = tid; o < nout; o += 256) {
+    float s = 0.f;
+    if (!dgrad) {
+      for (int r = 0; r < 9 * cin; ++r) s += fabsf(w[(size_t)r * cout + o]);
+    } else {
+      for (int tap = 0; tap < 9; ++tap)
+        for (int co = 0; co < cout; ++co) s += fabsf(w[((size_t)tap * cin + o) * cout + co]);
+    }
+    l1 = fmaxf(l1, s);
+  }
+  __shared__ float sa[256], sl[256];
+  sa[tid] = amax;
+  sl[tid] = l1;
+  __syncthreads();
+  for (int o = 128; o >= 1; o >>= 1) {
+    if (tid < o) { sa[tid] = fmaxf(sa[tid], sa[tid + o]); sl[tid] = fmaxf(sl[tid], sl[tid + o]); }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    WMeta m;
+    m.e = h2_exp_for_bound(sa[0]) - 1;      // stored |w| < 2^14
+    m.l1 = sl[0] * 1.0001f;                 // (the sums above round; keep the bound a bound)
+    *t.meta[j] = m;
+  }
+}
+
+// element e of job j -> its two halves at [chunk][tap][k-step][block][plane][h][col][8]
+//   forward      : g[tap][k = cin][n = cout] = w[tap][cin][cout]
+//   data gradient: g[tap][k = cout][n = cin] = w[8 - tap][cin][cout]
+__global__ void mm_pack_kernel(PackTable t) {
+  const int j = blockIdx.y;
+  const int cin = t.cin[j], cout = t.cout[j], dgrad = t.dgrad[j];
+  const int kc = dgrad ? cout : cin, nc = dgrad ? cin : cout;
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= 9 * kc * nc) return;
+  const int tap = e / (kc * nc), rem = e - tap * (kc * nc);
+  // consecutive threads walk cout, the contiguous axis of the HWIO filter
+  const int k = dgrad ? rem % kc : rem / nc, n = dgrad ? rem / kc : rem % nc;
+  const float v = dgrad ? t.w[j][((size_t)(8 - tap) * cin + n) * cout + k] : t.w[j][((size_t)tap * cin + k) * cout + n];
+  _Float16 hi, lo;
+  h2_split(ldexpf(v, t.meta[j]->e), hi, lo);
+  const int nb_all = nc / 32;
+  const int chunk = k >> 5, s = (k >> 4) & 1, h = (k >> 3) & 1, ee = k & 7;
+  const int nb = mm_block_of(n, nc), col = mm_col_of(n, nc);
+  const size_t base = ((((size_t)chunk * 9 + tap) * 2 + s) * nb_all + nb) * 2;
+  uint16_t* pk = t.pk[j];
+  pk[(base + 0) * 512 + (h * 32 + col) * 8 + ee] = (uint16_t)h2_bits(hi);
+  pk[(base + 1) * 512 + (h * 32 + col) * 8 + ee] = (uint16_t)h2_bits(lo);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// LDS-DMA pieces
+// ---------------------------------------------------------------------------------------------------------------------
+// Piece `piece` (0..47) of the halo tile of (image base, region origin, chunk): slots 64 * piece .. + 63 of the 18 x 168
+// slot image.  Slot (row, 9 * px + c): c < 4 -> 16 bytes of the pixel's H plane, c < 8 -> of its L plane, c = 8 / the 6 slots
+// at the end of a row / rows >= 18: padding (never read; fetches the zero block).
+template <int KC, int HW>
+__device__ __forceinline__ void dma_halo_piece(const char* __restrict__ img_base, const void* __restrict__ zeros, int ry0,
+                                               int rx0, int chunk, int piece, int lane, unsigned lds_byte_base) {
+  const int g = piece * 64 + lane;
+  const int row = (g * 6242) >> 20;                 // g / 168 for g < 3072
+  const int rem = g - row * HROW;
+  const int px = (rem * 57) >> 9;                   // rem / 9 for rem < 168
+  const int c = rem - px * 9;
+  const int gy = ry0 - 1 + row, gx = rx0 - 1 + px;
+  const bool ok = rem < 162 && c < 8 && row < 18 && (unsigned)gy < (unsigned)HW && (unsigned)gx < (unsigned)HW;
+  const unsigned off = (unsigned)(gy * HW + gx) * (unsigned)(KC * 4) + (unsigned)(chunk * 64) +
+                       (c < 4 ? (unsigned)(c * 16) : (unsigned)(KC * 2 + (c - 4) * 16));
+  const void* src = ok ? (const void*)(img_base + off) : zeros;
+  dma16(src, lds_byte_base + (unsigned)piece * 1024u);
+}
+
+// Piece `piece` (0..15) of the pooled staging tile: 10 x 10 pooled pixels, 10 slots each: 4 of the H plane, 4 of the L plane,
+// 2 of argmax bytes (32 channels of the chunk).
+template <int KC, int HW>
+__device__ __forceinline__ void dma_pooled_piece(const char* __restrict__ dz_img, const char* __restrict__ idx_img,
+                                                 const void* __restrict__ zeros, int ry0, int rx0, int chunk, int piece,
+                                                 int lane, unsigned lds_byte_base) {
+  constexpr int HP = HW / 2;
+  const int g = piece * 64 + lane;
+  const int pp = (g * 205) >> 11;                   // g / 10 for g < 1024
+  const int part = g - pp * 10;
+  const int prow = (pp * 205) >> 11, pcol = pp - prow * 10;
+  const int pr = ry0 / 2 - 1 + prow, pc = rx0 / 2 - 1 + pcol;
+  const bool ok = pp < 100 && (unsigned)pr < (unsigned)HP && (unsigned)pc < (unsigned)HP;
+  const unsigned o = (unsigned)(pr * HP + pc);
+  const char* vsrc = dz_img + o * (unsigned)(KC * 4) + (unsigned)(chunk * 64) +
+                     (part < 4 ? (unsigned)(part * 16) : (unsigned)(KC * 2 + (part - 4) * 16));
+  const char* isrc = idx_img + o * (unsigned)KC + (unsigned)(chunk * 32) + (unsigned)((part - 8) * 16);
+  const void* src = !ok ? zeros : (part < 8 ? (const void*)vsrc : (const void*)isrc);
+  dma16(src, lds_byte_base + (unsigned)piece * 1024u);
+}
+
+// MaxPool backward while staging: pooled pixel pp (10 x 10), channel group cg (8 channels) -> its four positions of the
+// 18 x 18 halo tile receive the value where the argmax byte names the position, zero elsewhere.
+__device__ __forceinline__ void scatter_pooled(const char* stg, char* halo, int u) {
+  if (u >= 400) return;
+  const int pp = u >> 2, cg = u & 3;
+  const int prow = (pp * 205) >> 11, pcol = pp - prow * 10;
+  const uint4 hi = *reinterpret_cast<const uint4*>(stg + pp * 160 + cg * 16);
+  const uint4 lo = *reinterpret_cast<const uint4*>(stg + pp * 160 + 64 + cg * 16);
+  const uint2 ix = *reinterpret_cast<const uint2*>(stg + pp * 160 + 128 + cg * 8);
+  const unsigned hv[4] = {hi.x, hi.y, hi.z, hi.w}, lv[4] = {lo.x, lo.y, lo.z, lo.w};
+#pragma unroll
+  for (int pos = 0; pos < 4; ++pos) {
+    const int hy = 2 * prow - 1 + (pos >> 1), hx = 2 * pcol - 1 + (pos & 1);
+    if ((unsigned)hy >= 18u || (unsigned)hx >= 18u) continue;
+    unsigned m[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {            // dword d = channels 2d, 2d+1 of the group
+      const unsigned w = d < 2 ? ix.x : ix.y;
+      const unsigned b0 = (w >> (16 * (d & 1))) & 0xffu, b1 = (w >> (16 * (d & 1) + 8)) & 0xffu;
+      m[d] = (b0 == (unsigned)pos ? 0x0000ffffu : 0u) | (b1 == (unsigned)pos ? 0xffff0000u : 0u);
+    }
+    char* dst = halo + (hy * HROW + hx * 9) * 16 + cg * 16;
+    *reinterpret_cast<uint4*>(dst) = make_uint4(hv[0] & m[0], hv[1] & m[1], hv[2] & m[2], hv[3] & m[3]);
+    *reinterpret_cast<uint4*>(dst + 64) = make_uint4(lv[0] & m[0], lv[1] & m[1], lv[2] & m[2], lv[3] & m[3]);
+  }
+}
+
+__device__ __forceinline__ f32x16 mfma_h(const uint4& a, const uint4& b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, a), __builtin_bit_cast(h8, b), c, 0, 0, 0);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// the kernel
+// ---------------------------------------------------------------------------------------------------------------------
+// KC: GEMM K channels (input channels of the convolution being evaluated), NC: its output channels, HW: image size of the
+// OUTPUT of this kernel (= of the input, un-pooled).  IN_POOLED: `in` is a pooled gradient + argmax (MaxPool backward).
+template <int KC, int NC, int HW, int IN_POOLED, int EPI>
+__global__ __launch_bounds__(512, 2) void conv_mm_kernel(const MmJobs jt, const void* __restrict__ zeros) {
+  using G = Geo<NC>;
+  constexpr int NB = G::NB, TPS = G::TPS, NSTG = G::NSTG, WSTAGE = G::WSTAGE, WPIECES = G::WPIECES;
+  constexpr int NCHUNK = KC / 32;
+  constexpr int RPX = HW / 16, RPI = RPX * RPX;
+  static_assert(!IN_POOLED || NSTG >= 2, "the pooled scatter runs in the second stage of a chunk");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const unsigned sbase = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // A-side role of the lane: row r of the wave's 32-pixel block = window win (0..7), position q (0..3), k-half h
+  const int r = lane & 31, h = lane >> 5, win = r >> 2, q = r & 3;
+  const int a_lane = ((2 * wave + (q >> 1)) * HROW + (2 * win + (q & 1)) * 9) * 16 + h * 16;
+  const int b_lane = W_OFF + lane * 16;
+
+  int item = blockIdx.x;
+  const int nitems = jt.start[kMaxJobs];
+  if (item >= nitems) return;
+  int jb = mm_job_of(jt, item), lit = item - jt.start[jb];
+
+  auto img_in = [&](const MmJob& J, int img) {      // byte base of image `img` of the input tensor (+ its argmax map)
+    constexpr size_t IMG = IN_POOLED ? (size_t)(HW / 2) * (HW / 2) * KC : (size_t)HW * HW * KC;
+    return reinterpret_cast<const char*>(J.in) + (size_t)img * IMG * 4;
+  };
+  auto img_idx = [&](const MmJob& J, int img) {
+    return reinterpret_cast<const char*>(J.in_idx) + (size_t)img * (HW / 2) * (HW / 2) * KC;
+  };
+  // DMA roles.  Waves 4..7 fetch input tiles, waves 0..3 filter stages: vmcnt retires in order PER WAVE, so with separate
+  // queues an input tile can stay in flight for a whole chunk (HBM latency) while every filter stage (L2) is awaited.
+  const bool is_hw = wave >= 4;
+  const int rw = wave & 3;
+  constexpr int HSTG = NSTG == 3 ? 2 : 6;           // stages of a chunk that issue halo pieces (12 per wave)
+  constexpr int HPER = 12 / HSTG;
+  // halo pieces [first, first + count) of this wave for (item, chunk); pooled input: the staging tile instead (4 pieces, sg 0)
+  auto stage_in = [&](const MmJob& J, int lit_, int chunk, unsigned halo_dst, int first, int count) {
+    const int img = lit_ / RPI, rrem = lit_ % RPI;
+    const int ry0 = (rrem / RPX) * 16, rx0 = (rrem % RPX) * 16;
+    if constexpr (IN_POOLED) {
+      const char* vb = img_in(J, img);
+      const char* ib = img_idx(J, img);
+#pragma unroll
+      for (int j = 0; j < STG_PIECES / 4; ++j)
+        dma_pooled_piece<KC, HW>(vb, ib, zeros, ry0, rx0, chunk, rw * (STG_PIECES / 4) + j, lane, sbase + W_OFF + 2 * WSTAGE);
+    } else {
+      const char* vb = img_in(J, img);
+#pragma unroll
+      for (int j = 0; j < HPER; ++j)
+        if (j < count) dma_halo_piece<KC, HW>(vb, zeros, ry0, rx0, chunk, rw * 12 + first + j, lane, halo_dst);
+    }
+  };
+  auto stage_w = [&](const uint16_t* wpk, int st, unsigned dst) {     // filter stage `st` (chunk * NSTG + sg) of a job
+    const char* src = reinterpret_cast<const char*>(wpk) + (size_t)st * WSTAGE;
+#pragma unroll
+    for (int j = 0; j < WPIECES / 4; ++j) {
+      const int p = rw + 4 * j;
+      dma16(src + p * 1024 + lane * 16, dst + (unsigned)p * 1024u);
+    }
+  };
+
+  // ---- prologue: input tile of (item, chunk 0) -> halo buffer 0, filter stage 0 -> filter buffer 0
+  if (is_hw) {
+#pragma unroll
+    for (int k = 0; k < HSTG; ++k) stage_in(jt.job[jb], lit, 0, sbase, k * HPER, HPER);
+  } else {
+    stage_w(jt.job[jb].wpk, 0, sbase + W_OFF);
+  }
+  if constexpr (IN_POOLED) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    scatter_pooled(smem + W_OFF + 2 * WSTAGE, smem, tid);
+  }
+  int hbuf = 0, wbuf = 0;
+  bool first_item = true;
+  // per-job epilogue constants (block exponents) and the running maximum of what this wave stored for the job
+  int meta_jb = -1, e_out = 0;
+  float factor = 1.f, mx = 0.f;
+
+  for (; item < nitems; item += gridDim.x) {
+    const int next_item = item + gridDim.x;
+    const bool more = next_item < nitems;
+    const int jn = more ? mm_job_of(jt, next_item) : jb, nlit = more ? next_item - jt.start[jn] : lit;
+    if (jb != meta_jb) {          // (wave-uniform) first item of a job in this workgroup: its exponents, loaded under the MFMAs
+      if (meta_jb >= 0) h2_publish_amax(jt.job[meta_jb].out_meta, wave_max(mx), lane);
+      mx = 0.f;
+      const MmJob& Jm = jt.job[jb];
+      const int e_in = Jm.in_meta->e;
+      const float amax_in = h2_true_amax(e_in, Jm.in_meta->amax);
+      e_out = h2_exp_for_bound(amax_in * Jm.wmeta->l1);
+      factor = ldexpf(1.f, e_out - e_in - Jm.wmeta->e);
+      meta_jb = jb;
+    }
+    f32x16 acc[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[nb][i] = 0.f;
+
+#pragma unroll 1
+    for (int chunk = 0; chunk < NCHUNK; ++chunk) {
+      const bool last_chunk = chunk + 1 == NCHUNK;
+      const bool next_tile = !last_chunk || more;             // there is a (chunk, item) after this one
+      const bool to_next = last_chunk && more;
+      const int n_chunk = last_chunk ? 0 : chunk + 1;
+      const int nx_job = to_next ? jn : jb, n_lit = to_next ? nlit : lit;
+      const int a_addr = a_lane + hbuf * HALO_BYTES;
+#pragma unroll
+      for (int sg = 0; sg < NSTG; ++sg) {
+        // What this stage reads must have landed: the filter stage (issued a stage ago by waves 0..3), in the first stage of
+        // a chunk the input tile (issued a chunk ago by waves 4..7), before the pooled scatter the staging tile.  The first
+        // stage of every item but the first was awaited BEFORE the previous item's epilogue (see there).
+        if (!(sg == 0 && chunk == 0 && !first_item)) {
+          if (!is_hw || sg == 0 || (IN_POOLED && sg == NSTG - 1)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();                                     // ... and is visible; the other buffers have no readers left
+        if (!is_hw) {   // filter stage after this one -> the other filter buffer
+          if (sg + 1 < NSTG) {
+            stage_w(jt.job[jb].wpk, chunk * NSTG + sg + 1, sbase + W_OFF + (unsigned)(wbuf ^ 1) * WSTAGE);
+          } else if (next_tile) {
+            stage_w(jt.job[nx_job].wpk, n_chunk * NSTG, sbase + W_OFF + (unsigned)(wbuf ^ 1) * WSTAGE);
+          }
+        } else if (next_tile) {   // input tile of the next chunk / item -> the other halo buffer (pooled: the staging tile)
+          if (IN_POOLED ? sg == 0 : sg < HSTG)
+            stage_in(jt.job[nx_job], n_lit, n_chunk, sbase + (unsigned)(hbuf ^ 1) * HALO_BYTES, sg * HPER, HPER);
+        }
+        if constexpr (IN_POOLED) {   // MaxPool backward of the next tile, staging -> the other halo buffer
+          if (sg == NSTG - 1 && next_tile) scatter_pooled(smem + W_OFF + 2 * WSTAGE, smem + (hbuf ^ 1) * HALO_BYTES, tid);
+        }
+        const int b_addr = b_lane + wbuf * WSTAGE;
+#pragma unroll
+        for (int t = 0; t < TPS; ++t) {
+          const int tap = sg * TPS + t, dy = tap / 3, dx = tap % 3;
+#pragma unroll
+          for (int s = 0; s < 2; ++s) {
+            const int aoff = (dy * HROW + dx * 9) * 16 + s * 32;
+            const uint4 ah = *reinterpret_cast<const uint4*>(smem + a_addr + aoff);
+            const uint4 al = *reinterpret_cast<const uint4*>(smem + a_addr + aoff + 64);
+            uint4 bh[NB], bl[NB];
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+              bh[nb] = *reinterpret_cast<const uint4*>(smem + b_addr + (((t * 2 + s) * NB + nb) * 2 + 0) * 1024);
+              bl[nb] = *reinterpret_cast<const uint4*>(smem + b_addr + (((t * 2 + s) * NB + nb) * 2 + 1) * 1024);
+            }
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) acc[nb] = mfma_h(ah, bh[nb], acc[nb]);
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) acc[nb] = mfma_h(ah, bl[nb], acc[nb]);
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) acc[nb] = mfma_h(al, bh[nb], acc[nb]);
+          }
+        }
+        wbuf ^= 1;
+      }
+      hbuf ^= 1;
+    }
+    // The next item's first filter stage and input tile are awaited HERE, before this item's stores enter the queue: the
+    // first stage of the next item then needs no wait, and the stores have a whole stage to be acknowledged.
+    if (more) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    first_item = false;
+
+    // ---- epilogue.  acc[nb][4g + i] of lane (col c = lane & 31, half h): window 2g + h, position i of the wave's 8 windows,
+    // i.e. pixel (2 * wave + (i >> 1), 2 * (2g + h) + (i & 1)) of the region; channel: mm_block_of / mm_col_of.
+    const MmJob& J = jt.job[jb];
+    const int img = lit / RPI, rrem = lit % RPI;
+    const int ry0 = (rrem / RPX) * 16, rx0 = (rrem % RPX) * 16;
+    if (lit == 0 && tid == 0) J.out_meta->e = e_out;
+    constexpr bool POOL = EPI == EPI_LRELU_POOL;
+    constexpr int HO = POOL ? HW / 2 : HW;
+    char* out = reinterpret_cast<char*>(J.out) + (size_t)img * HO * HO * NC * 4;
+    const int c = lane & 31;
+    if constexpr (NB >= 2) {
+#pragma unroll
+      for (int m = 0; m < NB / 2; ++m) {
+        const unsigned chb = (unsigned)(64 * m + 2 * c) * 2u;       // byte offset of the lane's channel pair in a plane
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int wx = 2 * g + h;
+          if constexpr (POOL) {
+            float best[2];
+            unsigned bi[2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+              best[e] = acc[2 * m + e][4 * g];
+              bi[e] = 0;
+#pragma unroll
+              for (int i = 1; i < 4; ++i) {
+                const float v = acc[2 * m + e][4 * g + i];
+                if (v > best[e]) { best[e] = v; bi[e] = i; }     // strict >: the FIRST maximum wins (TF MaxPoolGrad)
+              }
+              best[e] = ugn_lrelu(best[e] * factor);
+              mx = fmaxf(mx, fabsf(best[e]));
+            }
+            const unsigned pix = (unsigned)((ry0 / 2 + wave) * HO + rx0 / 2 + wx);
+            _Float16 h0, l0, h1, l1;
+            h2_split(best[0], h0, l0);
+            h2_split(best[1], h1, l1);
+            *reinterpret_cast<unsigned*>(out + pix * (unsigned)(NC * 4) + chb) = h2_pack(h0, h1);
+            *reinterpret_cast<unsigned*>(out + pix * (unsigned)(NC * 4) + (unsigned)(NC * 2) + chb) = h2_pack(l0, l1);
+            uint8_t* oi = J.out_idx + (size_t)img * HO * HO * NC;
+            *reinterpret_cast<uint16_t*>(oi + pix * (unsigned)NC + (unsigned)(64 * m + 2 * c)) = (uint16_t)(bi[0] | (bi[1] << 8));
+          } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const unsigned pix = (unsigned)((ry0 + 2 * wave + (i >> 1)) * HW + rx0 + 2 * wx + (i & 1));
+              float v0 = acc[2 * m][4 * g + i] * factor, v1 = acc[2 * m + 1][4 * g + i] * factor;
+              if constexpr (EPI == EPI_LRELU) {
+                v0 = ugn_lrelu(v0);
+                v1 = ugn_lrelu(v1);
+              } else if constexpr (EPI == EPI_DGRAD_ACT) {
+                const char* act = reinterpret_cast<const char*>(J.act) + (size_t)img * HW * HW * NC * 4;
+                const unsigned ah2 = *reinterpret_cast<const unsigned*>(act + pix * (unsigned)(NC * 4) + chb);
+                v0 *= (short)(ah2 & 0xffffu) > 0 ? 1.f : UGN_LRELU_ALPHA;      // LeakyReLU' from the sign of the H half
+                v1 *= (short)(ah2 >> 16) > 0 ? 1.f : UGN_LRELU_ALPHA;
+              }
+              mx = fmaxf(mx, fmaxf(fabsf(v0), fabsf(v1)));
+              _Float16 h0, l0, h1, l1;
+              h2_split(v0, h0, l0);
+              h2_split(v1, h1, l1);
+              *reinterpret_cast<unsigned*>(out + pix * (unsigned)(NC * 4) + chb) = h2_pack(h0, h1);
+              *reinterpret_cast<unsigned*>(out + pix * (unsigned)(NC * 4) + (unsigned)(NC * 2) + chb) = h2_pack(l0, l1);
+            }
+          }
+        }
+      }
+    } else {
+      // one block: lane c owns channel c; neighbouring lanes (c, c^1) exchange their halves so that the even lane stores the H
+      // pair and the odd lane the L pair -- 32 lanes x 4 bytes = the pixel's 128-byte record
+      const unsigned sel = (c & 1) ? 0x03020706u : 0x05040100u;
+      const unsigned chb = (c & 1) ? (unsigned)(NC * 2 + (c - 1) * 2) : (unsigned)(c * 2);
+      auto store1 = [&](unsigned pix, float v) {
+        _Float16 hi, lo;
+        h2_split(v, hi, lo);
+        const unsigned own = h2_pack(hi, lo);
+        const unsigned oth = (unsigned)__builtin_amdgcn_update_dpp(0, (int)own, 0xB1, 0xf, 0xf, false);   // quad_perm [1,0,3,2]
+        *reinterpret_cast<unsigned*>(out + pix * (unsigned)(NC * 4) + chb) = __builtin_amdgcn_perm(oth, own, sel);
+      };
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int wx = 2 * g + h;
+        if constexpr (POOL) {
+          float best = acc[0][4 * g];
+          unsigned bi = 0;
+#pragma unroll
+          for (int i = 1; i < 4; ++i) {
+            const float v = acc[0][4 * g + i];
+            if (v > best) { best = v; bi = i; }
+          }
+          best = ugn_lrelu(best * factor);
+          mx = fmaxf(mx, fabsf(best));
+          const unsigned pix = (unsigned)((ry0 / 2 + wave) * HO + rx0 / 2 + wx);
+          store1(pix, best);
+          uint8_t* oi = J.out_idx + (size_t)img * HO * HO * NC;
+          oi[pix * (unsigned)NC + (unsigned)c] = (uint8_t)bi;
+        } else {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const unsigned pix = (unsigned)((ry0 + 2 * wave + (i >> 1)) * HW + rx0 + 2 * wx + (i & 1));
+            float v = acc[0][4 * g + i] * factor;
+            if constexpr (EPI == EPI_LRELU) {
+              v = ugn_lrelu(v);
+            } else if constexpr (EPI == EPI_DGRAD_ACT) {
+              const char* act = reinterpret_cast<const char*>(J.act) + (size_t)img * HW * HW * NC * 4;
+              const unsigned short ah = *reinterpret_cast<const unsigned short*>(act + pix * (unsigned)(NC * 4) + (unsigned)(c * 2));
+              v *= (short)ah > 0 ? 1.f : UGN_LRELU_ALPHA;
+            }
+            mx = fmaxf(mx, fabsf(v));
+            store1(pix, v);
+          }
+        }
+      }
+    }
+    jb = jn;
+    lit = nlit;
+  }
+  // one atomicMax per wave and job (not per item: 230 k contended atomics on one address cost a 64x64 layer a millisecond)
+  h2_publish_amax(jt.job[meta_jb].out_meta, wave_max(mx), lane);
+}
+
+template <int KC, int NC, int HW, int IN_POOLED, int EPI>
+int launch_mm(const MmJob* jobs, const int* n, int njobs, hipStream_t st) {
+  auto kern = conv_mm_kernel<KC, NC, HW, IN_POOLED, EPI>;
+  constexpr int LDS = lds_bytes<NC, IN_POOLED>();
+  static_assert(LDS <= 163840, "LDS budget");
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    if (e != hipSuccess) { ugn_set_error("conv_mm: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
+    attr_done = true;
+  }
+  const void* zeros = zero_block();
+  if (!zeros) { ugn_set_error("conv_mm: cannot allocate the zero block"); return UGN_EINVAL; }
+  MmJobs jt;
+  const int nitems = make_mm_table(jt, jobs, n, njobs, (HW / 16) * (HW / 16));
+  const int grid = nitems < kGrid ? nitems : kGrid;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), LDS, st, jt, zeros);
+  UGN_CHECK_LAUNCH("conv_mm");
+  return 0;
+}
+
+int dispatch_fwd(const MmJob* jobs, const int* n, int njobs, int hw, int cin, int cout, int pool, hipStream_t st) {
+#define MF(KC_, NC_, HW_, P_)                                              \
+  if (cin == KC_ && cout == NC_ && hw == HW_ && (pool != 0) == (P_ != 0))  \
+    return launch_mm<KC_, NC_, HW_, 0, P_ ? EPI_LRELU_POOL : EPI_LRELU>(jobs, n, njobs, st);
+  MF(32, 32, 64, 1) MF(32, 64, 32, 0) MF(64, 64, 32, 1) MF(64, 128, 16, 0) MF(128, 128, 16, 0)
+#undef MF
+  ugn_set_error("ugn_mm_conv3x3_fwd: unsupported shape cin=%d cout=%d hw=%d pool=%d", cin, cout, hw, pool);
+  return UGN_EINVAL;
+}
+
+// data gradient of the forward layer cin -> cout at hw x hw: K = cout, N = cin
+int dispatch_dgrad(const MmJob* jobs, const int* n, int njobs, int hw, int cin, int cout, int unpool, bool act, hipStream_t st) {
+#define MD(CI_, CO_, HW_, U_)                                                                     \
+  if (cin == CI_ && cout == CO_ && hw == HW_ && unpool == U_)                                     \
+    return act ? launch_mm<CO_, CI_, HW_, U_, EPI_DGRAD_ACT>(jobs, n, njobs, st)                  \
+               : launch_mm<CO_, CI_, HW_, U_, EPI_DGRAD>(jobs, n, njobs, st);
+  MD(32, 32, 64, 1) MD(32, 64, 32, 0) MD(64, 64, 32, 1) MD(64, 128, 16, 0) MD(128, 128, 16, 0)
+#undef MD
+  ugn_set_error("ugn_mm_conv3x3_dgrad: unsupported shape cin=%d cout=%d hw=%d unpool=%d", cin, cout, hw, unpool);
+  return UGN_EINVAL;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// fp32 <-> H2 (tests, tools and the boundary of the H2 part of the path)
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ void absmax_kernel(const float* __restrict__ x, size_t n, H2Meta* meta) {
+  float m = 0.f;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) m = fmaxf(m, fabsf(x[i]));
+  h2_publish_amax(meta, wave_max(m), threadIdx.x & 63);
+}
+// x [npix][c] fp32 (meta: e = 0, amax = max|x|) -> y [npix][2][c]; the new exponent goes to meta_out (which may be meta_in:
+// it is written by a separate one-thread kernel afterwards)
+__global__ void h2_encode_kernel(const float* __restrict__ x, uint16_t* __restrict__ y, const H2Meta* meta_in, size_t npix, int c) {
+  const int e = h2_exp_for_bound(h2_true_amax(meta_in->e, meta_in->amax));
+  const size_t total = npix * (size_t)c;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t p = i / c;
+    const int ch = (int)(i - p * c);
+    _Float16 hi, lo;
+    h2_split(ldexpf(x[i], e), hi, lo);
+    y[(p * 2 + 0) * c + ch] = (uint16_t)h2_bits(hi);
+    y[(p * 2 + 1) * c + ch] = (uint16_t)h2_bits(lo);
+  }
+}
+__global__ void h2_rescale_meta_kernel(H2Meta* meta) {
+  const int e = h2_exp_for_bound(h2_true_amax(meta->e, meta->amax));
+  const float a = ldexpf(__uint_as_float(meta->amax), e - meta->e);
+  meta->e = e;
+  meta->amax = __float_as_uint(a);
+}
+__global__ void h2_decode_kernel(const uint16_t* __restrict__ y, const H2Meta* meta, float* __restrict__ x, size_t npix, int c) {
+  const int e = meta->e;
+  const size_t total = npix * (size_t)c;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t p = i / c;
+    const int ch = (int)(i - p * c);
+    x[i] = ldexpf(h2_half(y[(p * 2 + 0) * c + ch]) + h2_half(y[(p * 2 + 1) * c + ch]), -e);
+  }
+}
+
+}  // namespace
+
+const void* ugn_mm::zero_block() {
+  static void* z = nullptr;
+  if (!z) {
+    void* p = nullptr;
+    if (hipMalloc(&p, 256) != hipSuccess || hipMemset(p, 0, 256) != hipSuccess) return nullptr;
+    z = p;
+  }
+  return z;
+}
+
+extern "C" int ugn_mm_pack_multi(const float* const* w_hwio_host, uint16_t* const* wpk_host, void* const* wmeta_host,
+                                 const int* cin_host, const int* cout_host, const int* dgrad_host, int njobs, void* stream) {
+  UGN_REQUIRE(w_hwio_host && wpk_host && wmeta_host && cin_host && cout_host && dgrad_host, "ugn_mm_pack_multi: null pointer");
+  UGN_REQUIRE(njobs >= 1 && njobs <= kPackJobs, "ugn_mm_pack_multi: njobs must be 1..%d (got %d)", kPackJobs, njobs);
+  PackTable t = {};
+  int maxe = 0;
+  for (int j = 0; j < njobs; ++j) {
+    const int ci = cin_host[j], co = cout_host[j];
+    UGN_REQUIRE(w_hwio_host[j] && wpk_host[j] && wmeta_host[j], "ugn_mm_pack_multi: null pointer in job %d", j);
+    UGN_REQUIRE(ci > 0 && co > 0 && ci % 32 == 0 && co % 32 == 0, "ugn_mm_pack_multi: channels must be multiples of 32 (job %d)", j);
+    const int nc = dgrad_host[j] ? ci : co;
+    UGN_REQUIRE(nc == 32 || nc == 64 || nc == 128, "ugn_mm_pack_multi: %d output channels of the GEMM (32, 64 or 128; job %d)", nc, j);
+    t.w[j] = w_hwio_host[j]; t.pk[j] = wpk_host[j]; t.meta[j] = (WMeta*)wmeta_host[j];
+    t.cin[j] = ci; t.cout[j] = co; t.dgrad[j] = dgrad_host[j] ? 1 : 0;
+    if (9 * ci * co > maxe) maxe = 9 * ci * co;
+  }
+  hipLaunchKernelGGL(mm_wstats_kernel, dim3(njobs), dim3(256), 0, (hipStream_t)stream, t);
+  UGN_CHECK_LAUNCH("mm_wstats");
+  hipLaunchKernelGGL(mm_pack_kernel, dim3((maxe + 255) / 256, njobs), dim3(256), 0, (hipStream_t)stream, t);
+  UGN_CHECK_LAUNCH("mm_pack");
+  return 0;
+}
+
+extern "C" int ugn_mm_conv3x3_fwd_multi(const uint16_t* const* in, const void* const* in_meta, const uint16_t* const* wpk,
+                                        const void* const* wmeta, uint16_t* const* out, uint8_t* const* out_idx,
+                                        void* const* out_meta, const int* n, int njobs, int hw, int cin, int cout, int pool,
+                                        void* stream) {
+  UGN_REQUIRE(in && in_meta && wpk && wmeta && out && out_meta && n, "ugn_mm_conv3x3_fwd_multi: null array");
+  UGN_REQUIRE(njobs >= 1 && njobs <= kMaxJobs, "ugn_mm_conv3x3_fwd_multi: njobs must be 1..%d (got %d)", kMaxJobs, njobs);
+  MmJob jobs[kMaxJobs];
+  for (int j = 0; j < njobs; ++j) {
+    UGN_REQUIRE(in[j] && in_meta[j] && wpk[j] && wmeta[j] && out[j] && out_meta[j] && n[j] > 0,
+                "ugn_mm_conv3x3_fwd_multi: null pointer or n <= 0 in job %d", j);
+    UGN_REQUIRE(!pool || (out_idx && out_idx[j]), "ugn_mm_conv3x3_fwd_multi: pool needs out_idx");
+    jobs[j] = {in[j], nullptr, (const H2Meta*)in_meta[j], wpk[j], (const WMeta*)wmeta[j], out[j], pool ? out_idx[j] : nullptr,
+               (H2Meta*)out_meta[j], nullptr};
+  }
+  return dispatch_fwd(jobs, n, njobs, hw, cin, cout, pool, (hipStream_t)stream);
+}
+
+extern "C" int ugn_mm_conv3x3_dgrad_multi(const uint16_t* const* dz, const uint8_t* const* dz_idx, const void* const* dz_meta,
+                                          const uint16_t* const* wpk, const void* const* wmeta, const uint16_t* const* act,
+                                          uint16_t* const* out, void* const* out_meta, const int* n, int njobs, int hw, int cin,
+                                          int cout, void* stream) {
+  UGN_REQUIRE(dz && dz_meta && wpk && wmeta && out && out_meta && n, "ugn_mm_conv3x3_dgrad_multi: null array");
+  UGN_REQUIRE(njobs >= 1 && njobs <= kMaxJobs, "ugn_mm_conv3x3_dgrad_multi: njobs must be 1..%d (got %d)", kMaxJobs, njobs);
+  MmJob jobs[kMaxJobs];
+  for (int j = 0; j < njobs; ++j) {
+    UGN_REQUIRE(dz[j] && dz_meta[j] && wpk[j] && wmeta[j] && out[j] && out_meta[j] && n[j] > 0,
+                "ugn_mm_conv3x3_dgrad_multi: null pointer or n <= 0 in job %d", j);
+    jobs[j] = {dz[j], dz_idx ? dz_idx[j] : nullptr, (const H2Meta*)dz_meta[j], wpk[j], (const WMeta*)wmeta[j], out[j], nullptr,
+               (H2Meta*)out_meta[j], act ? act[j] : nullptr};
+    UGN_REQUIRE((jobs[0].in_idx != nullptr) == (jobs[j].in_idx != nullptr), "ugn_mm_conv3x3_dgrad_multi: dz_idx for all jobs or none");
+    UGN_REQUIRE((jobs[0].act != nullptr) == (jobs[j].act != nullptr), "ugn_mm_conv3x3_dgrad_multi: act for all jobs or none");
+  }
+  return dispatch_dgrad(jobs, n, njobs, hw, cin, cout, jobs[0].in_idx != nullptr, jobs[0].act != nullptr, (hipStream_t)stream);
+}
+
+// meta <- {e = 0, amax = max|x|} of an fp32 tensor (meta must be zero on entry, like every H2Meta)
+extern "C" int ugn_absmax(const float* x, size_t n, void* meta, void* stream) {
+  UGN_REQUIRE(x && meta && n > 0, "ugn_absmax: null pointer or n == 0");
+  const size_t blocks = (n + 256 * 8 - 1) / (256 * 8);
+  hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, (hipStream_t)stream, x, n, (H2Meta*)meta);
+  UGN_CHECK_LAUNCH("absmax");
+  return 0;
+}
+
+extern "C" int ugn_h2_encode(const float* x, uint16_t* y, void* meta, size_t npix, int c, void* stream) {
+  UGN_REQUIRE(x && y && meta && npix > 0 && c > 0, "ugn_h2_encode: null pointer or empty tensor");
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(meta, 0, sizeof(H2Meta), st);
+  if (e != hipSuccess) { ugn_set_error("ugn_h2_encode: memset: %s", hipGetErrorString(e)); return (int)e; }
+  const size_t n = npix * (size_t)c;
+  const size_t blocks = (n + 256 * 8 - 1) / (256 * 8);
+  const unsigned grid = (unsigned)(blocks < 2048 ? blocks : 2048);
+  hipLaunchKernelGGL(absmax_kernel, dim3(grid), dim3(256), 0, st, x, n, (H2Meta*)meta);
+  hipLaunchKernelGGL(h2_encode_kernel, dim3(grid), dim3(256), 0, st, x, y, (const H2Meta*)meta, npix, c);
+  hipLaunchKernelGGL(h2_rescale_meta_kernel, dim3(1), dim3(1), 0, st, (H2Meta*)meta);
+  UGN_CHECK_LAUNCH("h2_encode");
+  return 0;
+}
+
+extern "C" int ugn_h2_decode(const uint16_t* y, const void* meta, float* x, size_t npix, int c, void* stream) {
+  UGN_REQUIRE(x && y && meta && npix > 0 && c > 0, "ugn_h2_decode: null pointer or empty tensor");
+  const size_t n = npix * (size_t)c;
+  const size_t blocks = (n + 256 * 8 - 1) / (256 * 8);
+  hipLaunchKernelGGL(h2_decode_kernel, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, (hipStream_t)stream, y,
+                     (const H2Meta*)meta, x, npix, c);
+  UGN_CHECK_LAUNCH("h2_decode");
+  return 0;
+}

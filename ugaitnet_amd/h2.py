@@ -1,0 +1,167 @@
+"""H2 tensors (split-fp16 halves + block exponent) and the host wrappers of the kernels that consume them.
+
+Format and rationale: ugaitnet_amd/csrc/mm_common.h.  An H2 tensor replaces an fp32 NHWC activation / gradient between the
+3x3 layers of the encoder (reference nets/mj_uwyhNets_ba.py:431-462): same bytes, but the halves feed
+v_mfma_f32_32x32x16_f16 directly.  torch holds the buffers; every arithmetic op is a C-ABI call.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from ._lib import call, ptr, ptr_array
+
+I16 = torch.int16
+I32 = torch.int32
+U8 = torch.uint8
+F32 = torch.float32
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class MetaPool:
+    """All ugn_h2meta / ugn_wmeta records of a model in ONE int32 buffer: the per-step reset is a single memset.
+    Slots are handed out by name and live as long as the pool."""
+
+    def __init__(self, device, capacity=1024):
+        self.buf = torch.zeros((capacity, 2), dtype=I32, device=device)
+        self.slots = {}
+
+    def slot(self, name):
+        i = self.slots.get(name)
+        if i is None:
+            i = self.slots[name] = len(self.slots)
+            if i >= self.buf.shape[0]:
+                raise RuntimeError("MetaPool: out of slots")
+        return self.buf[i]
+
+    def reset(self, keep=()):
+        """Zero every record (amax gathers by atomicMax) except the named ones (filter metas survive the step)."""
+        if not keep:
+            self.buf.zero_()
+            return
+        saved = [(self.slots[k], self.buf[self.slots[k]].clone()) for k in keep if k in self.slots]
+        self.buf.zero_()
+        for i, v in saved:
+            self.buf[i].copy_(v)
+
+
+class H2Tensor:
+    """data: int16 [n, h, w, 2, c] (f16 bit patterns, plane 0 = H, plane 1 = L); meta: int32 [2] = {e, bits(amax)}."""
+
+    __slots__ = ("data", "meta")
+
+    def __init__(self, data, meta):
+        assert data.dtype == I16 and data.is_contiguous() and data.dim() == 5 and data.shape[3] == 2, (data.dtype, data.shape)
+        assert meta.dtype == I32 and meta.numel() == 2
+        self.data, self.meta = data, meta
+
+    @property
+    def shape(self):          # logical NHWC shape
+        n, h, w, _, c = self.data.shape
+        return (n, h, w, c)
+
+    @property
+    def device(self):
+        return self.data.device
+
+    @staticmethod
+    def empty(shape, device, meta=None):
+        n, h, w, c = shape
+        meta = torch.zeros(2, dtype=I32, device=device) if meta is None else meta
+        return H2Tensor(torch.empty((n, h, w, 2, c), dtype=I16, device=device), meta)
+
+    def numpy(self):
+        """Decode on the HOST (tests): float64 array of the true values."""
+        e, amax = self.meta.cpu().numpy().tolist()
+        d = self.data.cpu().numpy().view(np.float16).astype(np.float64)
+        return (d[:, :, :, 0, :] + d[:, :, :, 1, :]) * 2.0 ** (-e)
+
+    def true_amax(self):
+        e, bits = self.meta.cpu().numpy().tolist()
+        return float(np.array([bits], np.uint32).view(np.float32)[0]) * 2.0 ** (-e)
+
+
+def encode(x, out=None):
+    """fp32 NHWC tensor -> H2Tensor (three small kernels: max |x|, split, meta)."""
+    assert x.is_cuda and x.dtype == F32 and x.is_contiguous() and x.dim() == 4
+    n, h, w, c = x.shape
+    out = H2Tensor.empty((n, h, w, c), x.device) if out is None else out
+    call("ugn_h2_encode", ptr(x), ptr(out.data), ptr(out.meta), n * h * w, c, _stream())
+    return out
+
+
+def decode(t, out=None):
+    n, h, w, c = t.shape
+    out = torch.empty((n, h, w, c), dtype=F32, device=t.device) if out is None else out
+    call("ugn_h2_decode", ptr(t.data), ptr(t.meta), ptr(out), n * h * w, c, _stream())
+    return out
+
+
+def absmax(x, meta):
+    """meta <- {0, bits(max|x|)} (meta zero on entry)."""
+    call("ugn_absmax", ptr(x), x.numel(), ptr(meta), _stream())
+    return meta
+
+
+def mm_pack_multi(jobs):
+    """jobs: list of (w HWIO fp32 tensor, packed int16 tensor of 18*cin*cout elements, wmeta int32[2], dgrad flag)."""
+    for k in range(0, len(jobs), 64):
+        part = jobs[k:k + 64]
+        n = len(part)
+        call("ugn_mm_pack_multi", ptr_array([j[0] for j in part]), ptr_array([j[1] for j in part]), ptr_array([j[2] for j in part]),
+             (C.c_int * n)(*[j[0].shape[2] for j in part]), (C.c_int * n)(*[j[0].shape[3] for j in part]),
+             (C.c_int * n)(*[int(bool(j[3])) for j in part]), n, _stream())
+
+
+def mm_pack(w, dgrad, pk=None, wmeta=None):
+    cin, cout = w.shape[2], w.shape[3]
+    pk = torch.empty((18 * cin * cout,), dtype=I16, device=w.device) if pk is None else pk
+    wmeta = torch.zeros(2, dtype=I32, device=w.device) if wmeta is None else wmeta
+    mm_pack_multi([(w, pk, wmeta, dgrad)])
+    return pk, wmeta
+
+
+def _mm_work(kind, hw, cin, cout, pooled, ns, act=False):
+    n = int(sum(ns))
+    flops = 2.0 * 9 * cin * cout * hw * hw * n
+    if kind == "fwd":
+        kern = "conv_mm_kernel<%d, %d, %d, 0, %d>" % (cin, cout, hw, 1 if pooled else 0)
+    else:
+        kern = "conv_mm_kernel<%d, %d, %d, %d, %d>" % (cout, cin, hw, int(pooled), 3 if act else 2)
+    label = "conv3x3_%s[%d->%d @%dx%d%s h2] %s" % (kind, cin, cout, hw, hw, " pooled" if pooled else "", kern)
+    # three f16 MFMAs per fp32-equivalent product: the matrix pipe executes 3x the algorithmic FLOPs
+    return label, dict(flops=flops, mfma_flops=3.0 * flops, bytes=None, kernel=kern, bound="mfma", images=n, dtype="f16x2")
+
+
+def conv3x3_fwd_mm_multi(xs, wpks, wmetas, cout, pool, outs, idxs=None):
+    """LeakyReLU(conv3x3(x)) (+ MaxPool + argmax) for up to 6 jobs of one shape in one launch.  xs / outs: H2Tensors."""
+    n_, hw, _, cin = xs[0].shape
+    ns = (C.c_int * len(xs))(*[x.shape[0] for x in xs])
+    ho = hw // 2 if pool else hw
+    for x, o in zip(xs, outs):
+        assert x.shape[1:] == (hw, hw, cin) and o.shape == (x.shape[0], ho, ho, cout), (x.shape, o.shape)
+    label, work = _mm_work("fwd", hw, cin, cout, pool, [x.shape[0] for x in xs])
+    call("ugn_mm_conv3x3_fwd_multi", ptr_array([x.data for x in xs]), ptr_array([x.meta for x in xs]), ptr_array(wpks),
+         ptr_array(wmetas), ptr_array([o.data for o in outs]), ptr_array(idxs) if pool else None,
+         ptr_array([o.meta for o in outs]), ns, len(xs), hw, cin, cout, int(bool(pool)), _stream(), label=label, work=work)
+    return (outs, idxs) if pool else outs
+
+
+def conv3x3_dgrad_mm_multi(dzs, wpks, wmetas, hw, cin, cout, outs, dz_idxs=None, acts=None):
+    """Data gradient of the layer cin -> cout at hw x hw for up to 6 jobs.  dzs: H2 gradients w.r.t. the layer's
+    pre-activation ([n,hw,hw,cout]; with dz_idxs: pooled [n,hw/2,hw/2,cout] + argmax bytes).  acts: H2 inputs of the layer
+    (out *= LeakyReLU'(act))."""
+    ns = (C.c_int * len(dzs))(*[d.shape[0] for d in dzs])
+    for d, o in zip(dzs, outs):
+        assert o.shape == (d.shape[0], hw, hw, cin), (d.shape, o.shape)
+    label, work = _mm_work("dgrad", hw, cin, cout, dz_idxs is not None, [d.shape[0] for d in dzs], act=acts is not None)
+    call("ugn_mm_conv3x3_dgrad_multi", ptr_array([d.data for d in dzs]), ptr_array(dz_idxs) if dz_idxs is not None else None,
+         ptr_array([d.meta for d in dzs]), ptr_array(wpks), ptr_array(wmetas),
+         ptr_array([a.data for a in acts]) if acts is not None else None, ptr_array([o.data for o in outs]),
+         ptr_array([o.meta for o in outs]), ns, len(dzs), hw, cin, cout, _stream(), label=label, work=work)
+    return outs
