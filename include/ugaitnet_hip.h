@@ -295,6 +295,14 @@ int ugn_mm_conv3x3_dgrad_multi(const uint16_t* const* dz, const uint8_t* const* 
                                uint16_t* const* out, void* const* out_meta, const int* n, int njobs, int hw, int cin, int cout,
                                void* stream);
 
+/* Weight gradient dw HWIO [3,3,cin,cout] (fp32) = sum in (x) dz over images and pixels; in H2 [n][hw][hw][2][cin], dz as in
+ * the data gradient (pooled + argmax bytes when dz_idx is given).  ws: >= ugn_mm_conv3x3_wgrad_ws(hw, cin, cout) bytes of
+ * scratch for the partial-sum slabs (fixed-order reduction, no atomics: bitwise reproducible). */
+size_t ugn_mm_conv3x3_wgrad_ws(int hw, int cin, int cout);
+int ugn_mm_conv3x3_wgrad_multi(const uint16_t* const* in, const void* const* in_meta, const uint16_t* const* dz,
+                               const uint8_t* const* dz_idx, const void* const* dz_meta, float* const* dw, const int* n,
+                               int njobs, int hw, int cin, int cout, void* ws, size_t ws_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

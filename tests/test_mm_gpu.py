@@ -165,3 +165,55 @@ def test_mm_pool_ties_route_to_the_first_maximum(dev, kind):
         sel[inner] = (tied & top)[inner]
         assert sel.sum() > 1000
         assert np.all(idx[sel] == 0), "%d of %d diagonal ties not routed to position 0" % ((idx[sel] != 0).sum(), sel.sum())
+
+
+@pytest.mark.parametrize("hw,cin,cout,pool", CONV_CFGS)
+def test_mm_wgrad(dev, hw, cin, cout, pool):
+    """dW = sum in (x) dz on the f16 pipe (transposed LDS reads, K = pixels) against the fp64 oracle at the fp32 kernels' bar;
+    pooled layers take the pooled gradient + argmax.  Two launches must agree bit for bit (fixed-order slab reduction)."""
+    from ugaitnet_amd import h2
+    rng = np.random.default_rng(4000 + hw + cin + cout)
+    n = 7 if hw <= 32 else 3
+    x = rng.uniform(-1, 1, (n, hw, hw, cin)).astype(np.float32)
+    xt = h2.encode(T(x, dev))
+    ho = hw // 2 if pool else hw
+    g = (rng.normal(size=(n, ho, ho, cout)) * 1e-5).astype(np.float32)
+    gt = h2.encode(T(g, dev))
+    if pool:
+        pidx = rng.integers(0, 4, size=g.shape).astype(np.uint8)
+        dz = O.maxpool2x2_bwd(pidx, gt.numpy())
+        idx_t = [T(pidx, dev)]
+    else:
+        dz = gt.numpy()
+        idx_t = None
+    w0 = np.zeros((3, 3, cin, cout))
+    dw_ref, _ = O.conv2d_same_bwd(xt.numpy(), w0, dz, need_dx=False)
+    dw = torch.empty((3, 3, cin, cout), device=dev)
+    h2.conv3x3_wgrad_mm_multi([xt], [gt], cout, [dw], dz_idxs=idx_t)
+    close(dw, dw_ref, 5e-6, "mm wgrad")
+    dw2 = torch.empty_like(dw)
+    h2.conv3x3_wgrad_mm_multi([xt], [gt], cout, [dw2], dz_idxs=idx_t)
+    assert torch.equal(dw, dw2)
+
+
+def test_mm_wgrad_multi_job(dev):
+    """Jobs of very different sizes in one launch (frame-level + set-level of three modalities, down to ONE image): shares cross
+    job boundaries, some groups get no strip at all; every job must equal its own single-job launch within rounding of the
+    slab order and the oracle within the bar."""
+    from ugaitnet_amd import h2
+    rng = np.random.default_rng(11)
+    hw, cin, cout = 16, 64, 128
+    ns = [9, 5, 7, 1, 2, 1]
+    xs, gs, refs = [], [], []
+    for n in ns:
+        xs.append(h2.encode(T(rng.uniform(-1, 1, (n, hw, hw, cin)).astype(np.float32), dev)))
+        gs.append(h2.encode(T((rng.normal(size=(n, hw, hw, cout)) * rng.choice([1e-6, 1e-2, 3.0])).astype(np.float32), dev)))
+        refs.append(O.conv2d_same_bwd(xs[-1].numpy(), np.zeros((3, 3, cin, cout)), gs[-1].numpy(), need_dx=False)[0])
+    dws = [torch.empty((3, 3, cin, cout), device=dev) for _ in ns]
+    h2.conv3x3_wgrad_mm_multi(xs, gs, cout, dws)
+    for j, (d, r) in enumerate(zip(dws, refs)):
+        close(d, r, 5e-6, "wgrad job %d" % j)
+    # a launch with fewer strips than groups (one image of two strips): the unwritten slabs must count as zero
+    one = torch.empty((3, 3, cin, cout), device=dev)
+    h2.conv3x3_wgrad_mm_multi([xs[3]], [gs[3]], cout, [one])
+    close(one, refs[3], 5e-6, "wgrad single image")

@@ -87,6 +87,8 @@ PROTOTYPES = {
     "ugn_mm_pack_multi": (_i, [C.POINTER(_p)] * 3 + [C.POINTER(_i)] * 3 + [_i, _p]),
     "ugn_mm_conv3x3_fwd_multi": (_i, [C.POINTER(_p)] * 7 + [C.POINTER(_i), _i, _i, _i, _i, _i, _p]),
     "ugn_mm_conv3x3_dgrad_multi": (_i, [C.POINTER(_p)] * 8 + [C.POINTER(_i), _i, _i, _i, _i, _p]),
+    "ugn_mm_conv3x3_wgrad_ws": (_sz, [_i, _i, _i]),
+    "ugn_mm_conv3x3_wgrad_multi": (_i, [C.POINTER(_p)] * 6 + [C.POINTER(_i), _i, _i, _i, _i, _p, _sz, _p]),
 }
 
 _lib = None

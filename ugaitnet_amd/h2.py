@@ -11,6 +11,7 @@ import ctypes as C
 import numpy as np
 import torch
 
+from . import _lib
 from ._lib import call, ptr, ptr_array
 
 I16 = torch.int16
@@ -165,3 +166,35 @@ def conv3x3_dgrad_mm_multi(dzs, wpks, wmetas, hw, cin, cout, outs, dz_idxs=None,
          ptr_array([a.data for a in acts]) if acts is not None else None, ptr_array([o.data for o in outs]),
          ptr_array([o.meta for o in outs]), ns, len(dzs), hw, cin, cout, _stream(), label=label, work=work)
     return outs
+
+
+_WS = {}
+
+
+def _workspace(nbytes, device):
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    buf = _WS.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = _WS[key] = torch.empty(max(int(nbytes), 1), dtype=U8, device=device)
+    return buf
+
+
+def conv3x3_wgrad_mm_multi(xs, dzs, cout, dws, dz_idxs=None):
+    """Weight gradients (fp32 HWIO, written to dws) of up to 6 jobs of one shape in one launch.  xs: H2 layer inputs
+    [n,hw,hw,cin]; dzs: H2 gradients w.r.t. the pre-activation ([n,hw,hw,cout], or pooled + dz_idxs argmax bytes)."""
+    n_, hw, _, cin = xs[0].shape
+    ns = (C.c_int * len(xs))(*[x.shape[0] for x in xs])
+    nbytes = _lib.load().ugn_mm_conv3x3_wgrad_ws(hw, cin, cout)
+    if nbytes == 0:
+        raise ValueError("conv3x3_wgrad_mm_multi: unsupported shape hw=%d cin=%d cout=%d" % (hw, cin, cout))
+    ws = _workspace(nbytes, xs[0].device)
+    pooled = dz_idxs is not None
+    flops = 2.0 * 9 * cin * cout * hw * hw * sum(x.shape[0] for x in xs)
+    kern = "wgrad_mm_kernel<%d, %d, %d, %d>" % (cin, cout, hw, int(pooled))
+    label = "conv3x3_wgrad[%d->%d @%dx%d%s h2] %s" % (cin, cout, hw, hw, " pooled" if pooled else "", kern)
+    call("ugn_mm_conv3x3_wgrad_multi", ptr_array([x.data for x in xs]), ptr_array([x.meta for x in xs]),
+         ptr_array([d.data for d in dzs]), ptr_array(dz_idxs) if pooled else None, ptr_array([d.meta for d in dzs]),
+         ptr_array(dws), ns, len(xs), hw, cin, cout, ptr(ws), ws.numel(), _stream(), label=label,
+         work=dict(flops=flops, mfma_flops=3.0 * flops, bytes=None, kernel=kern, bound="mfma", images=int(sum(x.shape[0] for x in xs)),
+                   dtype="f16x2"))
+    return dws
