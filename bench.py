@@ -34,6 +34,11 @@ sys.path.insert(0, ROOT)
 L = 25
 # secondary workloads (never the headline line): --workload c4 = SURVEY 8(d) "C4", the CASIA-B shape
 WORKLOADS = {
+    # C2 = BASELINE.json configs[1]: BL-single gray, the single-modality graph (no gate, no normalisation:
+    # nets/mj_uwyhNets_ba.py:893-903), 24 clips = 12 ids x 2, 150 classes
+    "c2": dict(kinds=("gray",), clips=24, ncls=150, ids_per=2, multimodal=False,
+               text="C2: BL-single gray (single-modality graph), 25x60x60, %d clips/GPU, %d ids x %d, 150 classes, "
+                    "triplet(0.2)+0.1*xent, Adam 1e-4"),
     "c3": dict(kinds=("of", "gray", "depth"), clips=24, ncls=150, ids_per=2,
                text="C3: 3 modalities (of 2ch + gray + depth), 25x60x60, %d clips/GPU, %d ids x %d, 150 classes, sign_max, "
                     "7-pattern masks, triplet(0.2)+0.1*xent, Adam 1e-4"),
@@ -49,12 +54,25 @@ WORKLOADS = {
 F_FWD = {1: 7.944e9, 2: 8.108e9}
 F_FIRST = {1: 0.164e9, 2: 0.328e9}
 FLOP_PER_CLIP = sum(3 * F_FWD[c] - F_FIRST[c] for c in (2, 1, 1))   # fwd + dgrad + wgrad, no dgrad for layer 1
+
+
+def flop_per_clip(kinds):
+    return sum(3 * F_FWD[2 if k == "of" else 1] - F_FIRST[2 if k == "of" else 1] for k in kinds)
+
+
+DTYPE_TEXT = {
+    "f32": "f32",
+    "bf16": "bf16 MFMA operands in the 3x3 fwd/dgrad/wgrad (f32 accumulate)",
+    "h2": "f16x2: fp32-class values held as two f16 halves + a block exponent (22 significant bits); 3x3 layers = three "
+          "v_mfma_f32_32x32x16_f16 per product (hi*hi + hi*lo + lo*hi), f32 accumulate; everything else f32",
+}
 PEAK_F32_MFMA = 157.3e12   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 / 16x16x4_f32 dense peak
 PEAK_BF16_MFMA = 16 * PEAK_F32_MFMA   # same guide: the f32 MFMA rate is 1/16 of the dense bf16 rate (~2.5 PFLOP/s)
 PEAK_HBM = 8.0e12          # same guide: HBM3E spec peak (6.3 TB/s is what a float4 copy achieves)
+DEFAULT_DTYPE = os.environ.get("UGN_BENCH_DTYPE", "f32")
 
 
-def cpu_baseline(kinds, ncls, clips, n_ids, seconds_budget=30.0):
+def cpu_baseline(kinds, ncls, clips, n_ids, seconds_budget=30.0, multimodal=True):
     """The CPU restatement (torch CPU ops, oneDNN) timed on this host on a bounded sample of the same workload: the SAME
     batch shape (all clips of one step), one warm-up on a small batch (pages in oneDNN's kernels), then whole steps until the
     budget is spent (at least one)."""
@@ -65,12 +83,12 @@ def cpu_baseline(kinds, ncls, clips, n_ids, seconds_budget=30.0):
     rng = np.random.default_rng(0)
     params = dict(branches=[O.init_branch_params(rng, 2 if k == "of" else 1) for k in kinds],
                   head=O.init_head_params(rng, ncls))
-    tr = T.TorchTrainer(T.params_from_numpy(params), lr=1e-4, margin=0.2, loss_weights=(1.0, 0.1))
+    tr = T.TorchTrainer(T.params_from_numpy(params), lr=1e-4, margin=0.2, loss_weights=(1.0, 0.1), multimodal=multimodal)
 
     def tensors(b, ids):
         xs, uses, labels, onehot = make_batch(kinds, b, L, ncls, ids=ids, seed=232323)
-        return ([torch.from_numpy(x) for x in xs], [torch.from_numpy(u) for u in uses], torch.from_numpy(labels),
-                torch.from_numpy(onehot))
+        return ([torch.from_numpy(x) for x in xs], [torch.from_numpy(u) for u in uses] if multimodal else None,
+                torch.from_numpy(labels), torch.from_numpy(onehot))
     tr.step(*tensors(4, 2))  # warm-up
     batch = tensors(clips, n_ids)
     times = []
@@ -81,9 +99,9 @@ def cpu_baseline(kinds, ncls, clips, n_ids, seconds_budget=30.0):
         times.append(time.perf_counter() - t0)
     med = float(np.median(times))
     return dict(value=clips / med, unit="clips/s", cores=int(torch.get_num_threads()), kind="port",
-                sample="%d whole step(s) of the same %d-clip batch (3 modalities, masks, L=25) after a 4-clip warm-up, median; "
+                sample="%d whole step(s) of the same %d-clip batch (%d modalit%s, L=25) after a 4-clip warm-up, median; "
                        "torch-CPU (oneDNN) restatement oracle/torch_ref.py, fwd+bwd+Adam; the TF-2.3 reference cannot run here"
-                       % (len(times), clips))
+                       % (len(times), clips, len(kinds), "ies, masks" if multimodal else "y"))
 
 
 def build_parser():
@@ -100,8 +118,10 @@ def build_parser():
                     help="N > 1: 'replica' = the reference's MirroredStrategy (losses per replica slice, one gradient "
                          "all-reduce; default for weak scaling); 'global' = all-gather the fused features so the losses see the "
                          "whole batch (default for --scaling strong: N GPUs then compute the one-GPU step)")
-    ap.add_argument("--dtype", choices=("f32", "bf16"), default="f32",
-                    help="bf16 = BASELINE configs[4] / SURVEY C5 arithmetic; never the headline")
+    ap.add_argument("--dtype", choices=("f32", "bf16", "h2"), default=DEFAULT_DTYPE,
+                    help="f32 = Winograd fp32-MFMA kernels; h2 = fp32-class values as two f16 halves, 3x3 layers on the f16 matrix "
+                         "pipe (the default when it holds every fp32 parity bar); bf16 = BASELINE configs[4] arithmetic, never the "
+                         "headline")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c3", help="c3 is the headline workload")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
                     help="strong: the workload's batch is split over the ranks (c4: 40 / N clips per GPU)")
@@ -175,7 +195,7 @@ def roofline_pass(core, batch, steps, dtype, table_path=""):
         w = work.get(label)
         d = dict(kernel=label, launches_per_step=n // steps, avg_us=round(avg, 1), share_of_step=round(tot / total, 4))
         if w and w["bound"] == "mfma":
-            peak = PEAK_BF16_MFMA if w["dtype"] == "bf16" else PEAK_F32_MFMA
+            peak = PEAK_BF16_MFMA if w["dtype"] in ("bf16", "f16x2") else PEAK_F32_MFMA   # (f16 MFMAs run at the bf16 rate)
             d.update(bound="mfma", unit="TFLOP/s", peak=round(peak / 1e12, 1), achieved=round(w["mfma_flops"] / avg / 1e6, 2),
                      frac=round(w["mfma_flops"] / (avg * 1e-6) / peak, 4), algorithmic_tflops=round(w["flops"] / avg / 1e6, 2),
                      rocprof_kernel=w["kernel"], images_per_launch=w["images"])
@@ -196,14 +216,21 @@ def roofline_pass(core, batch, steps, dtype, table_path=""):
                 frac=top.get("frac"), traffic=None)
     roof.update({k: v for k, v in top.items() if k not in roof})
     roof["how"] = ("dominant kernel = largest total duration in a serialised pass of %d steps after the timed region (every "
-                   "launch on one stream, HIP-event pairs on that stream); achieved = FLOPs executed on the matrix pipe "
-                   "(Winograd F(2x2,3x3): 16/36 of the direct-convolution count, which is `algorithmic_tflops`) / avg duration"
-                   % steps)
-    tfile = os.path.join(ROOT, "profiles", "roofline_traffic.json")
-    if os.path.exists(tfile) and dtype == "f32":
+                   "launch on one stream, HIP-event pairs on that stream); achieved = FLOPs EXECUTED on the matrix pipe / avg "
+                   "duration, against the peak of the instruction that executes them: f16x2 kernels run three f16 MFMAs per "
+                   "fp32-class product (3x the direct-convolution count `algorithmic_tflops`, dense f16/bf16 peak); Winograd "
+                   "F(2x2,3x3) fp32 kernels 16/36 of it (fp32-MFMA peak)" % steps)
+    # `traffic` is NOT measured in this run: it is the PMC figure (FETCH_SIZE x2-corrected + WRITE_SIZE, separate --pmc passes) of
+    # the same kernel and launch size recorded by tools/profile_run.sh; absent (null) when no record matches
+    for tname in ("roofline_traffic_%s.json" % dtype, "roofline_traffic.json"):
+        tfile = os.path.join(ROOT, "profiles", tname)
+        if not os.path.exists(tfile):
+            continue
         t = json.load(open(tfile))
         if t.get("rocprof_kernel") == top.get("rocprof_kernel") and t.get("images_per_launch") == top.get("images_per_launch"):
             roof["traffic"] = t.get("hbm_bytes_per_launch")
+            roof["traffic_source"] = "profiles/" + tname + " (rocprofv3 --pmc passes of this kernel at this launch size; not this run)"
+            break
     roof["serial_step_us"] = round(total / steps, 1)
     roof["other_kernels"] = [describe(r) for r in rows[1:10]]
     return roof
@@ -214,6 +241,7 @@ def run(args):
     if args.workload == "c5":
         args.dtype = "bf16"
     kinds, ncls = wl["kinds"], wl["ncls"]
+    multimodal = wl.get("multimodal", True)
 
     import torch
     import torch.distributed as dist
@@ -276,15 +304,16 @@ def run(args):
         xs, uses, labels, onehot = make_batch(kinds, b_gpu, L, ncls, ids=n_ids, seed=232323 + rank)
 
     def make_core(skip):
-        return GaitCore([2, 1, 1], nclasses=ncls, fuse_mode="sign_max", margin=0.2, loss_weights=(1.0, 0.1), device=dev,
-                        seed=232323, lr=1e-4, world_size=world, skip_masked=skip, dp_mode=dp_mode, conv_precision=args.dtype,
-                        force_collectives=args.force_dist)
+        return GaitCore([2 if k == "of" else 1 for k in kinds], nclasses=ncls, multimodal=multimodal, fuse_mode="sign_max", margin=0.2,
+                        loss_weights=(1.0, 0.1), device=dev, seed=232323, lr=1e-4, world_size=world, skip_masked=skip and multimodal,
+                        dp_mode=dp_mode, conv_precision=args.dtype, force_collectives=args.force_dist)
 
     core = make_core(args.skip_masked)
     dxs = [torch.from_numpy(np.ascontiguousarray(x)).to(dev) for x in xs]
-    dus_dev = [torch.from_numpy(np.ascontiguousarray(u)).to(dev) for u in uses]
+    dus_dev = [torch.from_numpy(np.ascontiguousarray(u)).to(dev) for u in uses] if multimodal else None
     doh = torch.from_numpy(np.ascontiguousarray(onehot)).to(dev)
-    batch = (dxs, uses if args.skip_masked else dus_dev, labels, doh)   # flags: host copies when they steer the launch
+    # flags: host copies when they steer the launch
+    batch = (dxs, (uses if args.skip_masked else dus_dev) if multimodal else None, labels, doh)
 
     def sync_all():
         if world > 1:
@@ -321,7 +350,7 @@ def run(args):
     # secondary figure, same workload: encoders run only on the clips whose modality flag is 1 (the gate multiplies the
     # rest by 0, so every result is unchanged; tests/test_fullsize_gpu.py).  Never reported as `value`.
     skip_rate = None
-    if not args.skip_masked and not args.dense_only and not args.serial:
+    if not args.skip_masked and not args.dense_only and not args.serial and multimodal:
         del core
         torch.cuda.empty_cache()
         core2 = make_core(True)
@@ -334,26 +363,35 @@ def run(args):
         if use_dist:
             dist_info = dict(backend=dist.get_backend(), world_size=dist.get_world_size(),
                              allreduce="bucketed, overlapped with backward" if engine.AR_OVERLAP else "one call after backward")
-        out = dict(metric="clips/sec (3-mod, L=25, 60x60) fwd+bwd+Adam", value=round(value, 2), unit="clips/s",
+        fpc = flop_per_clip(kinds)
+        exec_factor = {"f32": 16.0 / 36.0, "bf16": 16.0 / 36.0, "h2": 3.0}[args.dtype]
+        exec_peak = PEAK_F32_MFMA if args.dtype == "f32" else PEAK_BF16_MFMA
+        out = dict(metric="clips/sec (%s, L=25, 60x60) fwd+bwd+Adam" % ("3-mod" if len(kinds) == 3 else "%d-mod" % len(kinds)),
+                   value=round(value, 2), unit="clips/s",
                    n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(dt / args.steps * 1e3, 3),
                    higher_is_better=True, scaling=args.scaling, vs_baseline=None,
-                   dtype="f32" if args.dtype == "f32" else "bf16 MFMA operands in the 3x3 fwd/dgrad/wgrad (f32 accumulate)",
+                   dtype=DTYPE_TEXT[args.dtype],
                    data="synthetic",
                    config=dict(workload=wl["text"] % (b_gpu, n_ids, max(1, b_gpu // n_ids) if args.scaling == "weak" else wl["ids_per"]),
                                clips_per_gpu=b_gpu, global_batch=world * b_gpu, parallelism="dp%d" % world, dp_mode=dp_mode,
                                masked_pairs_skipped=bool(args.skip_masked), distributed=dist_info,
                                launch_schedule="serial (one stream)" if args.serial else
-                               "fwd chains on %d side streams, wgrad beside dgrad" % engine.FWD_STREAMS),
-                   whole_step_tflops=round(value * FLOP_PER_CLIP / 1e12, 2),
-                   whole_step_frac_of_f32_mfma_peak=round(value * FLOP_PER_CLIP * (16.0 / 36.0) / world / PEAK_F32_MFMA, 4),
+                               ("one launch per layer for all modalities (frame-level layer + set-level twin as jobs of one "
+                                "launch): forward = one chain on the main stream; weight gradients on a second stream beside the "
+                                "data gradients; head forward beside the triplet kernel")),
+                   whole_step_tflops=round(value * fpc / 1e12, 2),
+                   whole_step_frac_of_matrix_peak=round(value * fpc * exec_factor / world / exec_peak, 4),
                    loss=round(losses["loss"], 5), roofline=roof)
-        out["whole_step_note"] = ("whole_step_tflops prices the step with SURVEY 8(d)'s 71.3 algorithmic GFLOP per 3-modality "
-                                  "clip; the fraction beside it counts 16/36 of them (what Winograd executes) against the f32 peak")
+        out["whole_step_note"] = ("whole_step_tflops prices the step with SURVEY 8(d)'s algorithmic FLOPs per clip (71.3 G for 3 "
+                                  "modalities); the fraction beside it counts the FLOPs the matrix pipe executes for them (f32 / "
+                                  "bf16-operand Winograd: 16/36 against the fp32-MFMA / bf16 peak; f16x2: 3x against the dense "
+                                  "f16 peak of 2.5 PFLOP/s)")
         if skip_rate is not None:
             out["value_skip_masked"] = round(skip_rate, 2)   # 29 of the 72 (clip, modality) pairs of the C3 batch are masked
         if not args.no_cpu_baseline and world == 1:
             big = b_gpu > 40      # (the generator-expanded batches: time the workload's own batch on the CPU)
-            out["cpu_baseline"] = cpu_baseline(kinds, ncls, wl["clips"] if big else b_gpu, wl["clips"] // wl["ids_per"] if big else n_ids)
+            out["cpu_baseline"] = cpu_baseline(kinds, ncls, wl["clips"] if big else b_gpu, wl["clips"] // wl["ids_per"] if big else n_ids,
+                                               multimodal=multimodal)
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.destroy_process_group()

@@ -303,6 +303,41 @@ int ugn_mm_conv3x3_wgrad_multi(const uint16_t* const* in, const void* const* in_
                                const uint8_t* const* dz_idx, const void* const* dz_meta, float* const* dw, const int* n,
                                int njobs, int hw, int cin, int cout, void* ws, size_t ws_bytes, void* stream);
 
+/* ---- the steps around the 3x3 layers on H2 tensors (same reference lines as their fp32 versions above) ------------------
+ * first layer (nets/mj_uwyhNets_ba.py:428-430) with a1 written as H2 [n][64][64][2][32]; x_meta = {0, bits(max|x|)} */
+int ugn_conv5x5_in_fwd_h2(const float* x, const void* x_meta, const float* w, uint16_t* a1, void* a1_meta, uint32_t* a1_sign,
+                          int n, int cin, void* stream);
+/* its weight gradient with dz1 given as H2 [n][64][64][2][32] */
+int ugn_conv5x5_in_wgrad_h2(const float* x, const uint16_t* dz1, const void* dz1_meta, const uint32_t* a1_sign, float* dw, int n,
+                            int cin, void* ws, size_t ws_bytes, void* stream);
+/* meta[j] <- {0, bits(max|x[j]|)} for up to 6 fp32 tensors (metas zero on entry) */
+int ugn_absmax_multi(const float* const* x, const size_t* n, void* const* meta, int njobs, void* stream);
+/* fp32 [npix][c] -> H2 for up to 6 tensors; amax_meta[j] from ugn_absmax_multi, meta[j] (another record) is filled */
+int ugn_h2_encode_multi(const float* const* x, const void* const* amax_meta, uint16_t* const* y, void* const* meta,
+                        const size_t* npix, int njobs, int c, void* stream);
+/* set pooling over the l frames of each clip, tf.math.reduce_max(axis=1) (+ Add of the set-level addend), :435,451-452,463-465.
+ * p H2 [b*l][npix][2][c]; addend H2 [b][npix][2][c] (optional); m (optional) = maxima, sum = m + addend, both H2. */
+int ugn_h2_setmax_fwd_multi(const uint16_t* const* p, const void* const* p_meta, const uint16_t* const* addend,
+                            const void* const* addend_meta, uint16_t* const* m, void* const* m_meta, uint16_t* const* sum,
+                            void* const* sum_meta, const int* b, int njobs, int l, int npix, int c, void* stream);
+/* the same with fp32 outputs [b][npix][c]: the last set pooling feeds HPP */
+int ugn_h2_setmax_fwd_f32_multi(const uint16_t* const* p, const void* const* p_meta, const uint16_t* const* addend,
+                                const void* const* addend_meta, float* const* m, float* const* sum, const int* b, int njobs,
+                                int l, int npix, int c, void* stream);
+/* its gradient: out = ((p == max ? dm / #maxima : 0) + addend) * (apply_lrelu ? LeakyReLU'(p) : 1).  dm: H2 [b][npix][2][c], or
+ * (dm_is_f32) fp32 [b][npix][c] with dm_meta = {0, bits(max|dm|)}.  addend (optional) H2 [b*l][npix][2][c]; out may alias its
+ * data, out_meta must be another record than addend_meta. */
+int ugn_h2_setmax_bwd_multi(const uint16_t* const* p, const void* const* p_meta, const void* const* dm,
+                            const void* const* dm_meta, int dm_is_f32, const uint16_t* const* addend,
+                            const void* const* addend_meta, uint16_t* const* out, void* const* out_meta, const int* b, int njobs,
+                            int l, int npix, int c, int apply_lrelu, void* stream);
+/* out = g * LeakyReLU'(act), all H2 [npix][2][c] */
+int ugn_h2_lrelu_bwd_multi(const uint16_t* const* g, const void* const* g_meta, const uint16_t* const* act,
+                           uint16_t* const* out, void* const* out_meta, const size_t* npix, int njobs, int c, void* stream);
+/* HPP backward (nets/mj_uwyhNets_ba.py:468-481) with b4 held as H2 [b][16][16][2][128]: only its sign is used */
+int ugn_hpp_bwd_b4h2_multi(const float* const* a, const float* const* s3, const uint16_t* const* b4, const float* const* dfeat,
+                           float* const* dm3, float* const* dzb4, const int* b, int njobs, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -34,12 +34,18 @@ def oracle_params(kinds, nclasses, seed=5):
     return p
 
 
+# "f32": the Winograd fp32-MFMA kernels; "h2": activations / gradients as split-fp16 halves, 3x3 layers on the f16 matrix pipe
+# (ugaitnet_amd/engine_h2.py).  Both are held to the SAME bars: the H2 path claims fp32-class arithmetic.
+PRECISIONS = ["f32", "h2"]
+
+
+@pytest.mark.parametrize("prec", PRECISIONS)
 @pytest.mark.parametrize("mode", ["sign_max", "max", "avg"])
-def test_three_modalities_forward_backward(dev, mode):
+def test_three_modalities_forward_backward(dev, mode, prec):
     kinds, b, l, ncls = ('of', 'gray', 'depth'), 8, 4, 10
     xs, uses, labels, onehot = make_batch(kinds, b, l, ncls, ids=4, seed=1)
     p64 = oracle_params(kinds, ncls)
-    core = build(kinds, ncls, mode, p64)
+    core = build(kinds, ncls, mode, p64, conv_precision=prec)
     r, g = O.model_loss_and_grads([x.astype(np.float64) for x in xs], [u.astype(np.float64) for u in uses], labels,
                                   onehot.astype(np.float64), p64, margin=0.2, loss_weights=(1.0, 0.1), mode=mode)
     core.forward_backward(xs, uses, labels, onehot)
@@ -72,14 +78,15 @@ def test_three_modalities_forward_backward(dev, mode):
     assert not bad, bad
 
 
+@pytest.mark.parametrize("prec", PRECISIONS)
 @pytest.mark.parametrize("b,l,ids", [(2, 1, 1), (3, 5, 3), (6, 7, 2)])
-def test_ragged_batches_and_set_lengths(dev, b, l, ids):
+def test_ragged_batches_and_set_lengths(dev, b, l, ids, prec):
     """Edge shapes: a single frame per clip (set-max over one element), odd clip counts and set lengths, a batch that
     fills only a few of the persistent workgroups, identities with a single sample (no positive pair besides itself)."""
     kinds, ncls = ('of', 'gray', 'depth'), 5
     xs, uses, labels, onehot = make_batch(kinds, b, l, ncls, ids=ids, seed=40 + b)
     p64 = oracle_params(kinds, ncls)
-    core = build(kinds, ncls, "sign_max", p64)
+    core = build(kinds, ncls, "sign_max", p64, conv_precision=prec)
     r, g = O.model_loss_and_grads([x.astype(np.float64) for x in xs], [u.astype(np.float64) for u in uses], labels,
                                   onehot.astype(np.float64), p64, margin=0.2, loss_weights=(1.0, 0.1), mode="sign_max")
     core.forward_backward(xs, uses, labels, onehot)
@@ -120,12 +127,13 @@ def test_batch_hard_mode_end_to_end(dev):
     assert not bad, bad
 
 
-def test_single_modality_graph(dev):
+@pytest.mark.parametrize("prec", PRECISIONS)
+def test_single_modality_graph(dev, prec):
     """BL-single gray: no gate, no normalisation, raw [62,B,256] to both heads (nets/mj_uwyhNets_ba.py:893-903)."""
     kinds, b, l, ncls = ('gray',), 6, 5, 12
     xs, uses, labels, onehot = make_batch(kinds, b, l, ncls, ids=3, seed=2)
     p64 = oracle_params(kinds, ncls)
-    core = build(kinds, ncls, 'sign_max', p64, multimodal=False)
+    core = build(kinds, ncls, 'sign_max', p64, multimodal=False, conv_precision=prec)
     r, g = O.model_loss_and_grads([xs[0].astype(np.float64)], None, labels, onehot.astype(np.float64), p64, margin=0.2,
                                   loss_weights=(1.0, 0.1), multimodal=False)
     core.forward_backward(xs, None, labels, onehot)
@@ -137,7 +145,8 @@ def test_single_modality_graph(dev):
     assert max(bad.values()) <= 5e-3, bad
 
 
-def test_two_modalities_train_steps_track_oracle(dev):
+@pytest.mark.parametrize("prec", PRECISIONS)
+def test_two_modalities_train_steps_track_oracle(dev, prec):
     """keras Adam (eps 1e-7) on the flat parameter buffer: the first update equals the oracle's wherever the gradient is
     not at rounding level (Adam's first step is lr*sign(g), so a sign flip of a ~0 gradient moves a weight by 2*lr),
     and three steps keep the loss on the oracle's trajectory."""
@@ -145,7 +154,7 @@ def test_two_modalities_train_steps_track_oracle(dev):
     xs, uses, labels, onehot = make_batch(kinds, b, l, ncls, ids=3, seed=3)
     p64 = oracle_params(kinds, ncls)
     p0 = oracle_params(kinds, ncls)
-    core = build(kinds, ncls, 'sign_max', p64, lr=1e-3)
+    core = build(kinds, ncls, 'sign_max', p64, lr=1e-3, conv_precision=prec)
     keys = [('branches', mi, k) for mi in range(2) for k in sorted(p64['branches'][mi])] + [('head', None, k) for k in ('bc', 'wc')]
     get = lambda p, key: p['head'][key[2]] if key[0] == 'head' else p['branches'][key[1]][key[2]]
     ms = {key: np.zeros_like(get(p64, key)) for key in keys}
@@ -209,3 +218,27 @@ def test_bf16_operand_mode_against_the_oracle(dev):
         assert (np.abs(core.sig.cpu().numpy() - r['signature']) > 5e-2).mean() < 0.05
     with pytest.raises(ValueError):
         build(kinds, ncls, 'sign_max', p64, conv_precision='fp8')
+
+
+def test_h2_path_properties(dev):
+    """The H2 path on a batch with masked modalities: skipping the masked (clip, modality) pairs changes nothing (their gate is
+    0), two runs agree bit for bit (no atomics besides an order-independent max), and the path is not the fp32 one."""
+    kinds, b, l, ncls = ('of', 'gray', 'depth'), 9, 3, 5
+    xs, uses, labels, onehot = make_batch(kinds, b, l, ncls, ids=3, seed=9)
+    p64 = oracle_params(kinds, ncls)
+    dense = build(kinds, ncls, 'sign_max', p64, conv_precision='h2')
+    skip = build(kinds, ncls, 'sign_max', p64, conv_precision='h2', skip_masked=True)
+    f32 = build(kinds, ncls, 'sign_max', p64)
+    for c in (dense, skip, f32):
+        c.forward_backward(xs, uses, labels, onehot)
+    torch.cuda.synchronize()
+    assert np.array_equal(np.abs(dense.sig.cpu().numpy()), np.abs(skip.sig.cpu().numpy()))
+    g1 = dense.store.grad.clone()
+    dense.forward_backward(xs, uses, labels, onehot)
+    assert torch.equal(g1, dense.store.grad), "run-to-run determinism"
+    gd, gs = dense.get_grads_numpy(), skip.get_grads_numpy()
+    for mi in range(3):
+        for k in gd['branches'][mi]:
+            assert rell2(gs['branches'][mi][k], gd['branches'][mi][k].astype(np.float64)) <= 1e-6, (mi, k)
+    assert not torch.equal(dense.store.grad, f32.store.grad)
+    assert rell2(dense.store.grad.cpu().numpy(), f32.store.grad.cpu().numpy().astype(np.float64)) <= 1e-3

@@ -87,6 +87,15 @@ PROTOTYPES = {
     "ugn_mm_pack_multi": (_i, [C.POINTER(_p)] * 3 + [C.POINTER(_i)] * 3 + [_i, _p]),
     "ugn_mm_conv3x3_fwd_multi": (_i, [C.POINTER(_p)] * 7 + [C.POINTER(_i), _i, _i, _i, _i, _i, _p]),
     "ugn_mm_conv3x3_dgrad_multi": (_i, [C.POINTER(_p)] * 8 + [C.POINTER(_i), _i, _i, _i, _i, _p]),
+    "ugn_conv5x5_in_fwd_h2": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _p]),
+    "ugn_conv5x5_in_wgrad_h2": (_i, [_p, _p, _p, _p, _p, _i, _i, _p, _sz, _p]),
+    "ugn_absmax_multi": (_i, [C.POINTER(_p), C.POINTER(_sz), C.POINTER(_p), _i, _p]),
+    "ugn_h2_encode_multi": (_i, [C.POINTER(_p)] * 4 + [C.POINTER(_sz), _i, _i, _p]),
+    "ugn_h2_setmax_fwd_multi": (_i, [C.POINTER(_p)] * 8 + [C.POINTER(_i), _i, _i, _i, _i, _p]),
+    "ugn_h2_setmax_fwd_f32_multi": (_i, [C.POINTER(_p)] * 6 + [C.POINTER(_i), _i, _i, _i, _i, _p]),
+    "ugn_h2_setmax_bwd_multi": (_i, [C.POINTER(_p)] * 4 + [_i] + [C.POINTER(_p)] * 4 + [C.POINTER(_i), _i, _i, _i, _i, _i, _p]),
+    "ugn_h2_lrelu_bwd_multi": (_i, [C.POINTER(_p)] * 5 + [C.POINTER(_sz), _i, _i, _p]),
+    "ugn_hpp_bwd_b4h2_multi": (_i, [C.POINTER(_p)] * 6 + [C.POINTER(_i), _i, _p]),
     "ugn_mm_conv3x3_wgrad_ws": (_sz, [_i, _i, _i]),
     "ugn_mm_conv3x3_wgrad_multi": (_i, [C.POINTER(_p)] * 6 + [C.POINTER(_i), _i, _i, _i, _i, _p, _sz, _p]),
 }

@@ -6,9 +6,11 @@
 //
 // Domain: the explicit 2-pixel zero ring makes the conv domain 64x64; input pixel (u,v) of that domain is raw pixel
 // (u-2,v-2) or 0.  The 5x5 SAME conv then reads (y+dy-2, x+dx-2), dy,dx in 0..4.
-#include "common.h"
+#include "mm_common.h"
 
 namespace {
+
+using ugn_mm::H2Meta;
 
 #ifndef UGN_C5_WAVES
 #define UGN_C5_WAVES 4     // waves per SIMD the forward kernel is compiled for (measured: 4 and 6 equal, 8 spills)
@@ -48,10 +50,14 @@ __device__ __forceinline__ void stage_patch(float* sP, const float* __restrict__
 // Persistent form: gridDim.x workgroups stride over the n * 16 tiles.  The filter is staged once per workgroup; the raw patch
 // of the NEXT tile is fetched into registers before the current tile is multiplied and written to LDS after it, so the
 // global-load latency of the staging hides behind the MFMAs and the stores of the tile before.
-template <int CIN, bool SIGN>
+// H2OUT: a1 leaves as an H2 tensor (mm_common.h: f16 halves [pixel][2][32] + block exponent) for the f16-matrix-pipe 3x3
+// kernels.  x_meta = {0, bits(max|x|)} (ugn_absmax_multi); the exponent comes from the bound max|x| * max_co sum_k |w[k][co]|,
+// which every workgroup forms from the filter it has just staged; the stored maximum is gathered per workgroup.
+template <int CIN, bool SIGN, bool H2OUT = false>
 __global__ __launch_bounds__(256, UGN_C5_WAVES) void conv5x5_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                                         float* __restrict__ a1, uint32_t* __restrict__ sign_out,
-                                                                        int ntiles) {
+                                                                        int ntiles, const H2Meta* __restrict__ x_meta = nullptr,
+                                                                        H2Meta* __restrict__ out_meta = nullptr) {
   constexpr int K = 25 * CIN, KP = (K + 1) / 2;  // k-pairs
   constexpr int PE = P5 * P5;                     // patch pixels
   constexpr int PPT = (PE + 255) / 256;           // patch pixels per thread (2)
@@ -61,6 +67,16 @@ __global__ __launch_bounds__(256, UGN_C5_WAVES) void conv5x5_fwd_kernel(const fl
   const int li = lane & 31, lh = lane >> 5;
 
   for (int e = tid; e < 2 * KP * 32; e += 256) sW[e] = e < K * 32 ? w[e] : 0.f;
+  float h2_factor = 1.f, h2_mx = 0.f;
+  if constexpr (H2OUT) {
+    __syncthreads();
+    float l1 = 0.f;
+    for (int k = 0; k < K; ++k) l1 += fabsf(sW[k * 32 + li]);      // lane li = output channel (both lane halves alike)
+    l1 = ugn_mm::wave_max(l1) * 1.0001f;
+    const int e_out = ugn_mm::h2_exp_for_bound(ugn_mm::h2_true_amax(x_meta->e, x_meta->amax) * l1);
+    h2_factor = ldexpf(1.f, e_out);
+    if (blockIdx.x == 0 && tid == 0) out_meta->e = e_out;
+  }
   // patch pixel e = tid + 256 * j of tile t: (yy, xx) = (e / 20, e % 20) -> raw pixel (ty0 - 4 + yy, tx0 - 4 + xx)
   int pyy[PPT], pxx[PPT];
 #pragma unroll
@@ -132,10 +148,25 @@ __global__ __launch_bounds__(256, UGN_C5_WAVES) void conv5x5_fwd_kernel(const fl
       const int mbi = wave * 2 + m;
       uint32_t myword = 0;   // SIGN: lane li < 16 of each half collects the word of register r = li
       float* __restrict__ orow = a1 + (((size_t)img * DOM + ty0 + 2 * mbi) * DOM + tx0 + 2 * lh) * 32 + li;
+      // H2: the pixel's 128-byte record = 32 H halves + 32 L halves; lanes (li, li ^ 1) exchange halves so that the even lane
+      // stores the H pair and the odd lane the L pair (as the one-block epilogue of conv3x3_mm.hip)
+      char* __restrict__ hrow = reinterpret_cast<char*>(a1) + (((size_t)img * DOM + ty0 + 2 * mbi) * DOM + tx0 + 2 * lh) * 128 +
+                                ((li & 1) ? 64 + (li - 1) * 2 : li * 2);
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         // pixel (2 * mbi + ((r >> 1) & 1), 2 * (lh + 2 * (r >> 2)) + (r & 1)) of the tile: compile-time offset from orow
-        orow[(((r >> 1) & 1) * DOM + 4 * (r >> 2) + (r & 1)) * 32] = ugn_lrelu(acc[m][r]);
+        if constexpr (H2OUT) {
+          const float v = ugn_lrelu(acc[m][r]) * h2_factor;
+          h2_mx = fmaxf(h2_mx, fabsf(v));
+          _Float16 hi, lo;
+          ugn_mm::h2_split(v, hi, lo);
+          const unsigned own = ugn_mm::h2_pack(hi, lo);
+          const unsigned oth = (unsigned)__builtin_amdgcn_update_dpp(0, (int)own, 0xB1, 0xf, 0xf, false);   // quad_perm [1,0,3,2]
+          *reinterpret_cast<unsigned*>(hrow + (((r >> 1) & 1) * DOM + 4 * (r >> 2) + (r & 1)) * 128) =
+              __builtin_amdgcn_perm(oth, own, (li & 1) ? 0x03020706u : 0x05040100u);
+        } else {
+          orow[(((r >> 1) & 1) * DOM + 4 * (r >> 2) + (r & 1)) * 32] = ugn_lrelu(acc[m][r]);
+        }
         if constexpr (SIGN) {   // bit c of a pixel's word = (a1 > 0): all the layer's backward needs of a1 besides its values
           const unsigned long long bal = __ballot(acc[m][r] > 0.f);   // lanes 0..31: pixel of lh = 0, 32..63: lh = 1
           if (li == r) myword = (uint32_t)(bal >> (32 * lh));
@@ -150,6 +181,7 @@ __global__ __launch_bounds__(256, UGN_C5_WAVES) void conv5x5_fwd_kernel(const fl
       }
     }
   }
+  if constexpr (H2OUT) ugn_mm::h2_publish_amax(out_meta, ugn_mm::wave_max(h2_mx), lane);
 }
 
 // global -> LDS without a VGPR destination (LDS address = M0 + lane * 16 or + lane * 4); see conv3x3_wino.hip for why asm
@@ -173,7 +205,9 @@ __device__ __forceinline__ void dma4_c5(const void* gsrc, unsigned lds_dst_unifo
 // input patch of the NEXT tile stream into
 // the second LDS buffer by LDS-DMA (16-byte pieces for the gradient, dwords for the unaligned patch; lanes outside the image
 // or in the pad read a zero block) while the current tile is multiplied: the kernel runs at the rate dz1 can be read.
-template <int CIN, bool SIGN>
+// H2DZ: dz1 is an H2 tensor ([pixel][2][32] halves: the same 128 bytes per pixel, so the LDS-DMA staging is unchanged); a
+// gradient value is re-assembled from its two halves when it is read, the block exponent is undone by reduce5_kernel.
+template <int CIN, bool SIGN, bool H2DZ = false>
 __global__ __launch_bounds__(256) void conv5x5_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dz1,
                                                             float* __restrict__ slab, const float* __restrict__ zeros,
                                                             const uint32_t* __restrict__ a1_sign, int tiles_total) {
@@ -257,7 +291,13 @@ __global__ __launch_bounds__(256) void conv5x5_wgrad_kernel(const float* __restr
 #pragma unroll
     for (int kp = 0; kp < 32; ++kp) {  // wave's 64 pixels: p = 2*kp + lh, row = p/16, col = p%16
       const int po = ((2 * kp) / 16) * WP + ((2 * kp) % 16);
-      float b = sD[bbase + 2 * kp * DS];
+      float b;
+      if constexpr (H2DZ) {
+        const uint16_t* rec = reinterpret_cast<const uint16_t*>(sD) + (size_t)(wave * 64 + lh + 2 * kp) * 64;
+        b = ugn_mm::h2_half(rec[li]) + ugn_mm::h2_half(rec[32 + li]);
+      } else {
+        b = sD[bbase + 2 * kp * DS];
+      }
       if constexpr (SIGN) {   // dz1 arrives as dL/da1: the LeakyReLU' factor of a1 is applied here, from one bit per element
         const uint32_t wbits = sS0[buf * 256 + wave * 64 + 2 * kp + lh];
         b *= ((wbits >> li) & 1u) ? 1.f : UGN_LRELU_ALPHA;
@@ -288,7 +328,7 @@ __global__ __launch_bounds__(256) void conv5x5_wgrad_kernel(const float* __restr
 // dst[e] = sum_g src[g][e]: 256 threads = 8 elements x 32 slab lanes (lane ly sums slabs ly, ly+32, ...), combined in a fixed
 // order through LDS -> bitwise reproducible.  (800 / 1600 elements only: 32 lanes per element keep 100 / 200 workgroups busy.)
 __global__ __launch_bounds__(256) void reduce5_kernel(const float* __restrict__ src, float* __restrict__ dst, int nelem,
-                                                      int nin) {
+                                                      int nin, const H2Meta* __restrict__ dz_meta = nullptr) {
   __shared__ float sR[32][9];
   const int le = threadIdx.x & 7, ly = threadIdx.x >> 3;
   const int e = blockIdx.x * 8 + le;
@@ -300,7 +340,7 @@ __global__ __launch_bounds__(256) void reduce5_kernel(const float* __restrict__ 
   if (ly == 0 && e < nelem) {
 #pragma unroll
     for (int k = 1; k < 32; ++k) s += sR[k][le];
-    dst[e] = s;
+    dst[e] = dz_meta ? ldexpf(s, -dz_meta->e) : s;
   }
 }
 
@@ -325,6 +365,27 @@ extern "C" int ugn_conv5x5_in_fwd(const float* x, const float* w, float* a1, uin
   return 0;
 }
 
+/* the same layer with a1 as an H2 tensor [n][64][64][2][32] (+ its ugn_h2meta, zero on entry); x_meta = {0, bits(max|x|)} */
+extern "C" int ugn_conv5x5_in_fwd_h2(const float* x, const void* x_meta, const float* w, uint16_t* a1, void* a1_meta,
+                                     uint32_t* a1_sign, int n, int cin, void* stream) {
+  UGN_REQUIRE(x && x_meta && w && a1 && a1_meta && n > 0, "ugn_conv5x5_in_fwd_h2: null pointer or n <= 0");
+  UGN_REQUIRE(cin == 1 || cin == 2, "ugn_conv5x5_in_fwd_h2: cin must be 1 or 2 (got %d)", cin);
+  UGN_REQUIRE(UGN_C5_DS == 32, "ugn_conv5x5_in_fwd_h2: built with a padded gradient tile");
+  hipStream_t st = (hipStream_t)stream;
+  const int ntiles = n * 16;
+  const int grid = ntiles < UGN_C5_GRID ? ntiles : UGN_C5_GRID;
+#define UGN_C5F(C_, S_) hipLaunchKernelGGL((conv5x5_fwd_kernel<C_, S_, true>), dim3(grid), dim3(256), 0, st, x, w, (float*)a1, a1_sign, \
+                                           ntiles, (const H2Meta*)x_meta, (H2Meta*)a1_meta)
+  if (cin == 1) {
+    if (a1_sign) UGN_C5F(1, true); else UGN_C5F(1, false);
+  } else {
+    if (a1_sign) UGN_C5F(2, true); else UGN_C5F(2, false);
+  }
+#undef UGN_C5F
+  UGN_CHECK_LAUNCH("conv5x5_fwd_h2");
+  return 0;
+}
+
 extern "C" size_t ugn_conv5x5_in_wgrad_ws(int n, int cin) {
   if (n <= 0 || (cin != 1 && cin != 2)) return 0;
   const long tiles = (long)n * 16;
@@ -332,8 +393,20 @@ extern "C" size_t ugn_conv5x5_in_wgrad_ws(int n, int cin) {
   return (size_t)groups * 25 * cin * 32 * sizeof(float);
 }
 
+static int conv5x5_wgrad_any(const float* x, const float* dz1, const H2Meta* dz_meta, const uint32_t* a1_sign, float* dw, int n,
+                             int cin, void* ws, size_t ws_bytes, void* stream);
 extern "C" int ugn_conv5x5_in_wgrad(const float* x, const float* dz1, const uint32_t* a1_sign, float* dw, int n, int cin,
                                     void* ws, size_t ws_bytes, void* stream) {
+  return conv5x5_wgrad_any(x, dz1, nullptr, a1_sign, dw, n, cin, ws, ws_bytes, stream);
+}
+/* dz1 as an H2 tensor [n][64][64][2][32] with its ugn_h2meta */
+extern "C" int ugn_conv5x5_in_wgrad_h2(const float* x, const uint16_t* dz1, const void* dz1_meta, const uint32_t* a1_sign, float* dw,
+                                       int n, int cin, void* ws, size_t ws_bytes, void* stream) {
+  UGN_REQUIRE(dz1_meta, "ugn_conv5x5_in_wgrad_h2: null meta");
+  return conv5x5_wgrad_any(x, reinterpret_cast<const float*>(dz1), (const H2Meta*)dz1_meta, a1_sign, dw, n, cin, ws, ws_bytes, stream);
+}
+static int conv5x5_wgrad_any(const float* x, const float* dz1, const H2Meta* dz_meta, const uint32_t* a1_sign, float* dw, int n,
+                             int cin, void* ws, size_t ws_bytes, void* stream) {
   UGN_REQUIRE(x && dz1 && dw && ws && n > 0, "ugn_conv5x5_in_wgrad: null pointer or n <= 0");
   UGN_REQUIRE(cin == 1 || cin == 2, "ugn_conv5x5_in_wgrad: cin must be 1 or 2 (got %d)", cin);
   UGN_REQUIRE(ws_bytes >= ugn_conv5x5_in_wgrad_ws(n, cin), "ugn_conv5x5_in_wgrad: workspace too small");
@@ -350,17 +423,26 @@ extern "C" int ugn_conv5x5_in_wgrad(const float* x, const float* dz1, const uint
   const int lds = (2 * 256 * UGN_C5_DS + 2 * ((20 * UGN_C5_PITCH * cin + 63) / 64) * 64 + 2 * 256) * 4;
   static bool attr_done[3] = {false, false, false};
   if (!attr_done[cin]) {
-    const void* fns[4] = {(const void*)conv5x5_wgrad_kernel<1, false>, (const void*)conv5x5_wgrad_kernel<1, true>,
-                          (const void*)conv5x5_wgrad_kernel<2, false>, (const void*)conv5x5_wgrad_kernel<2, true>};
-    for (int v = 0; v < 2; ++v) {
-      hipError_t e = hipFuncSetAttribute(fns[(cin - 1) * 2 + v], hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    const void* fns[8] = {(const void*)conv5x5_wgrad_kernel<1, false>, (const void*)conv5x5_wgrad_kernel<1, true>,
+                          (const void*)conv5x5_wgrad_kernel<1, false, true>, (const void*)conv5x5_wgrad_kernel<1, true, true>,
+                          (const void*)conv5x5_wgrad_kernel<2, false>, (const void*)conv5x5_wgrad_kernel<2, true>,
+                          (const void*)conv5x5_wgrad_kernel<2, false, true>, (const void*)conv5x5_wgrad_kernel<2, true, true>};
+    for (int v = 0; v < 4; ++v) {
+      hipError_t e = hipFuncSetAttribute(fns[(cin - 1) * 4 + v], hipFuncAttributeMaxDynamicSharedMemorySize, lds);
       UGN_REQUIRE(e == hipSuccess, "ugn_conv5x5_in_wgrad: hipFuncSetAttribute: %s", hipGetErrorString(e));
     }
     attr_done[cin] = true;
   }
-#define UGN_C5W(C_, S_)                                                                                                     \
-  hipLaunchKernelGGL((conv5x5_wgrad_kernel<C_, S_>), dim3(groups), dim3(256), lds, st, x, dz1, (float*)ws, (const float*)zeros, \
-                     a1_sign, tiles)
+#define UGN_C5W(C_, S_)                                                                                                      \
+  do {                                                                                                                        \
+    if (dz_meta)                                                                                                              \
+      hipLaunchKernelGGL((conv5x5_wgrad_kernel<C_, S_, true>), dim3(groups), dim3(256), lds, st, x, dz1, (float*)ws,          \
+                         (const float*)zeros, a1_sign, tiles);                                                                \
+    else                                                                                                                      \
+      hipLaunchKernelGGL((conv5x5_wgrad_kernel<C_, S_>), dim3(groups), dim3(256), lds, st, x, dz1, (float*)ws,                \
+                         (const float*)zeros, a1_sign, tiles);                                                                \
+  } while (0)
+  UGN_REQUIRE(!dz_meta || UGN_C5_DS == 32, "ugn_conv5x5_in_wgrad_h2: built with a padded gradient tile");
   if (cin == 1) {
     if (a1_sign) UGN_C5W(1, true); else UGN_C5W(1, false);
   } else {
@@ -369,7 +451,7 @@ extern "C" int ugn_conv5x5_in_wgrad(const float* x, const float* dz1, const uint
 #undef UGN_C5W
   UGN_CHECK_LAUNCH("conv5x5_wgrad");
   const int nelem = 25 * cin * 32;
-  hipLaunchKernelGGL(reduce5_kernel, dim3((nelem + 7) / 8), dim3(256), 0, st, (const float*)ws, dw, nelem, groups);
+  hipLaunchKernelGGL(reduce5_kernel, dim3((nelem + 7) / 8), dim3(256), 0, st, (const float*)ws, dw, nelem, groups, dz_meta);
   UGN_CHECK_LAUNCH("conv5x5_wgrad reduce");
   return 0;
 }

@@ -206,6 +206,7 @@ __global__ void hpp_fwd_kernel(const HppJobs jt) {
 // owns the 16 positions of one finest strip for BOTH tensors (a and s3), so dm3 = dL/da + dL/ds3 needs no exchange.
 // Level l (0..4) has 2^l strips of 256 / 2^l positions; strip maxima and tie counts of the coarser levels are combined
 // through LDS.  mean: g / n ; max: g / (#maxima) to every maximum (TF reduce_max gradient).
+template <bool B4H2>
 __global__ __launch_bounds__(512) void hpp_bwd_kernel(const HppJobs jt) {
   __shared__ float sMx[2][16][32];
   __shared__ float sCnt[2][5][16][32];
@@ -270,7 +271,12 @@ __global__ __launch_bounds__(512) void hpp_bwd_kernel(const HppJobs jt) {
   for (int q = 0; q < 16; ++q) {
     const size_t o = base + (size_t)q * 128;
     dm3[o] = g[0][q] + g[1][q];
-    dzb4[o] = g[1][q] * ugn_lrelu_slope(b4[o]);
+    if constexpr (B4H2) {   // b4 is an H2 tensor [b][256][2][128] (ugaitnet_amd/csrc/mm_common.h): the sign of its H half is b4's sign
+      const short hb = reinterpret_cast<const short*>(b4)[(((size_t)b * 256 + st * 16 + q) * 2) * 128 + c];
+      dzb4[o] = g[1][q] * (hb > 0 ? 1.f : UGN_LRELU_ALPHA);
+    } else {
+      dzb4[o] = g[1][q] * ugn_lrelu_slope(b4[o]);
+    }
   }
 }
 
@@ -403,8 +409,27 @@ extern "C" int ugn_hpp_bwd_multi(const float* const* a, const float* const* s3, 
     jt.b[j] = b[j];
     if (b[j] > bmax) bmax = b[j];
   }
-  hipLaunchKernelGGL(hpp_bwd_kernel, dim3(bmax * 4, njobs), dim3(512), 0, (hipStream_t)stream, jt);
+  hipLaunchKernelGGL(hpp_bwd_kernel<false>, dim3(bmax * 4, njobs), dim3(512), 0, (hipStream_t)stream, jt);
   UGN_CHECK_LAUNCH("hpp_bwd");
+  return 0;
+}
+
+/* the same with b4 held as an H2 tensor [b][16][16][2][128] (only its sign is used); dm3 / dzb4 stay fp32 */
+extern "C" int ugn_hpp_bwd_b4h2_multi(const float* const* a, const float* const* s3, const uint16_t* const* b4,
+                                      const float* const* dfeat, float* const* dm3, float* const* dzb4, const int* b, int njobs,
+                                      void* stream) {
+  UGN_REQUIRE(a && s3 && b4 && dfeat && dm3 && dzb4 && b && njobs >= 1 && njobs <= kPoolJobs,
+              "ugn_hpp_bwd_b4h2_multi: bad arguments (1..%d jobs)", kPoolJobs);
+  HppJobs jt = {};
+  int bmax = 0;
+  for (int j = 0; j < njobs; ++j) {
+    UGN_REQUIRE(a[j] && s3[j] && b4[j] && dfeat[j] && dm3[j] && dzb4[j] && b[j] > 0, "ugn_hpp_bwd_b4h2_multi: bad job %d", j);
+    jt.a[j] = a[j]; jt.s3[j] = s3[j]; jt.b4[j] = reinterpret_cast<const float*>(b4[j]); jt.dfeat[j] = dfeat[j];
+    jt.dm3[j] = dm3[j]; jt.dzb4[j] = dzb4[j]; jt.b[j] = b[j];
+    if (b[j] > bmax) bmax = b[j];
+  }
+  hipLaunchKernelGGL(hpp_bwd_kernel<true>, dim3(bmax * 4, njobs), dim3(512), 0, (hipStream_t)stream, jt);
+  UGN_CHECK_LAUNCH("hpp_bwd_b4h2");
   return 0;
 }
 

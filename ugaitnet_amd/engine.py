@@ -18,7 +18,8 @@ import torch
 import contextlib
 import os
 
-from . import _lib, dp, ops
+from . import _lib, dp, h2, ops
+from .engine_h2 import H2State, backward_h2, forward_h2
 
 F32 = torch.float32
 
@@ -557,11 +558,19 @@ class GaitCore:
         if self.nclasses > 0:
             named += [("head.wc", (NBINS * HIDDEN, self.nclasses)), ("head.bc", (self.nclasses,))]
         self.store = ParamStore(named, self.device)
-        if conv_precision not in ("f32", "bf16"):
-            raise ValueError("conv_precision must be 'f32' or 'bf16', got %r" % (conv_precision,))
+        # "f32": Winograd fp32 MFMA kernels; "bf16": the same with bf16-rounded MFMA operands; "h2": activations / gradients
+        # between the 3x3 layers held as split-fp16 halves + block exponent, 3x3 layers on the f16 matrix pipe at fp32-class
+        # accuracy (engine_h2.py, csrc/mm_common.h)
+        if conv_precision not in ("f32", "bf16", "h2"):
+            raise ValueError("conv_precision must be 'f32', 'bf16' or 'h2', got %r" % (conv_precision,))
         self.conv_precision = conv_precision
+        self.h2 = conv_precision == "h2"
         self.encoders = [Encoder(self.store, "m%d." % mi, cin, bf16=conv_precision == "bf16")
                          for mi, cin in enumerate(self.in_channels)]
+        if self.h2:
+            self.meta_pool = h2.MetaPool(self.device, 64 * self.nmod)
+            for enc in self.encoders:
+                enc.h2 = H2State(enc, self.meta_pool)
         self.scratch = {}
         self.bufs = {}
         self._tri_cache = {}
@@ -582,6 +591,9 @@ class GaitCore:
         self.weights_changed()
 
     def weights_changed(self):
+        if self.h2:          # f16 halves + block exponent + L1 bound of every 3x3 filter, both directions: two launches
+            h2.mm_pack_multi([j for e in self.encoders for j in e.h2.pack_jobs()])
+            return
         if USE_WINOGRAD:     # one launch for the filters of all branches
             jobs = [j for e in self.encoders for j in e.pack_jobs()]
             ops.wino_pack_multi(jobs, bf16=self.encoders[0].bf16)
@@ -661,7 +673,10 @@ class GaitCore:
         xs = [self._dev(x) for x in xs]
         b = xs[0].shape[0]
         self._active = None
-        merged = _merged_ok() and len(self.encoders) > 1
+        merged = (_merged_ok() and len(self.encoders) > 1) or self.h2
+        if self.h2:
+            self.meta_pool.reset()      # every H2 meta of the step gathers its maximum from zero: one memset
+        fwd_many = forward_h2 if self.h2 else forward_merged
         if self.multimodal and self.skip_masked:
             outs, self._active = [None] * self.nmod, []
             sub = []      # (modality, rows tensor or None, input of the active clips)
@@ -679,8 +694,8 @@ class GaitCore:
                 outs[mi].zero_()
                 if len(rows):
                     sub.append((mi, idx, x.index_select(0, idx).contiguous()))
-            if merged and len(sub) > 1:
-                res = forward_merged([self.encoders[mi] for mi, _, _ in sub], [x for _, _, x in sub])
+            if merged and (len(sub) > 1 or (self.h2 and sub)):
+                res = fwd_many([self.encoders[mi] for mi, _, _ in sub], [x for _, _, x in sub])
             else:
                 res = [self.encoders[mi].forward(x) for mi, _, x in sub]
             for (mi, idx, _), o in zip(sub, res):
@@ -689,7 +704,7 @@ class GaitCore:
                 else:
                     outs[mi].index_copy_(1, idx, o)
         elif merged:
-            outs = forward_merged(self.encoders, xs)
+            outs = fwd_many(self.encoders, xs)
         elif FWD_STREAMS and len(self.encoders) > 1:
             main = torch.cuda.current_stream(self.device)
             outs = [None] * len(self.encoders)
@@ -783,7 +798,7 @@ class GaitCore:
                                       [self._buf("dout%d" % m, (NBINS, bl, HIDDEN)) for m in range(self.nmod)])
         else:
             douts = [own(dsig)]
-        if _merged_ok() and self.nmod > 1 and not BRANCH_STREAMS:
+        if self.h2 or (_merged_ok() and self.nmod > 1 and not BRANCH_STREAMS):
             encs, ds = [], []
             for mi, (enc, d) in enumerate(zip(self.encoders, douts)):
                 idx = self._active[mi] if self._active is not None else None
@@ -796,7 +811,10 @@ class GaitCore:
                 else:
                     encs.append(enc)
                     ds.append(d.index_select(1, idx).contiguous())
-            if len(encs) > 1:
+            if self.h2:
+                if encs:
+                    backward_h2(encs, ds, _side)
+            elif len(encs) > 1:
                 backward_merged(encs, ds, [self.scratch.setdefault(self.encoders.index(e), {}) for e in encs])
             elif encs:
                 encs[0].backward(ds[0], self.scratch.setdefault(self.encoders.index(encs[0]), {}))

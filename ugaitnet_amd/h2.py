@@ -198,3 +198,109 @@ def conv3x3_wgrad_mm_multi(xs, dzs, cout, dws, dz_idxs=None):
          work=dict(flops=flops, mfma_flops=3.0 * flops, bytes=None, kernel=kern, bound="mfma", images=int(sum(x.shape[0] for x in xs)),
                    dtype="f16x2"))
     return dws
+
+
+# ---- the steps around the 3x3 layers -----------------------------------------------------------------------------------
+def _ints(v):
+    return (C.c_int * len(v))(*[int(x) for x in v])
+
+
+def _sizes(v):
+    return (C.c_size_t * len(v))(*[int(x) for x in v])
+
+
+def _opt(ts, attr=None):
+    if ts is None:
+        return None
+    return ptr_array([None if t is None else (getattr(t, attr) if attr else t) for t in ts])
+
+
+def _hbm(kernel, nbytes):
+    return dict(flops=None, mfma_flops=None, bytes=float(nbytes), kernel=kernel, bound="hbm")
+
+
+def absmax_multi(xs, metas):
+    call("ugn_absmax_multi", ptr_array(xs), _sizes([x.numel() for x in xs]), ptr_array(metas), len(xs), _stream(),
+         label="absmax", work=_hbm("absmax_multi_kernel", sum(x.numel() for x in xs) * 4.0))
+    return metas
+
+
+def encode_multi(xs, amax_metas, outs):
+    """fp32 NHWC tensors -> H2 (outs), given metas that already hold max|x| (absmax_multi)."""
+    c = xs[0].shape[-1]
+    call("ugn_h2_encode_multi", ptr_array(xs), ptr_array(amax_metas), ptr_array([o.data for o in outs]),
+         ptr_array([o.meta for o in outs]), _sizes([x.numel() // c for x in xs]), len(xs), c, _stream(),
+         label="h2_encode", work=_hbm("encode_multi_kernel", sum(x.numel() for x in xs) * 8.0))
+    return outs
+
+
+def conv5x5_in_fwd_h2(x, x_meta, w, out, sign=None):
+    """First layer with a1 written as H2 (out: H2Tensor [n,64,64,32]); x_meta = {0, bits(max|x|)}."""
+    n, cin = x.shape[0], x.shape[3]
+    call("ugn_conv5x5_in_fwd_h2", ptr(x), ptr(x_meta), ptr(w), ptr(out.data), ptr(out.meta), ptr(sign), n, cin, _stream(),
+         label="conv5x5_fwd[cin=%d h2]" % cin,
+         work=_hbm("conv5x5_fwd_kernel<%d, %s, true>" % (cin, "true" if sign is not None else "false"),
+                   n * (3600.0 * cin * 4 + 4096 * 32 * 4 + (4096 * 4 if sign is not None else 0))))
+    return out
+
+
+def conv5x5_in_wgrad_h2(x, dz1, dw, sign=None):
+    n, cin = x.shape[0], x.shape[3]
+    nbytes = _lib.load().ugn_conv5x5_in_wgrad_ws(n, cin)
+    ws = _workspace(nbytes, x.device)
+    call("ugn_conv5x5_in_wgrad_h2", ptr(x), ptr(dz1.data), ptr(dz1.meta), ptr(sign), ptr(dw), n, cin, ptr(ws), ws.numel(), _stream(),
+         label="conv5x5_wgrad[cin=%d h2]" % cin,
+         work=_hbm("conv5x5_wgrad_kernel<%d, %s, true>" % (cin, "true" if sign is not None else "false"),
+                   n * (3600.0 * cin * 4 + 4096 * 32 * 4 + (4096 * 4 if sign is not None else 0))))
+    return dw
+
+
+def setmax_fwd_h2_multi(ps, bs, l, ms=None, addends=None, sums=None):
+    """H2 set pooling: ms[j] (optional) = max over the l frames, sums[j] = ms[j] + addends[j] (H2 outputs)."""
+    n, h, w, c = ps[0].shape
+    call("ugn_h2_setmax_fwd_multi", ptr_array([p.data for p in ps]), ptr_array([p.meta for p in ps]), _opt(addends, "data"),
+         _opt(addends, "meta"), _opt(ms, "data"), _opt(ms, "meta"), _opt(sums, "data"), _opt(sums, "meta"), _ints(bs), len(ps), l,
+         h * w, c, _stream(), label="setmax_fwd[%dx%dx%d h2]" % (h, w, c),
+         work=_hbm("setmax_fwd_h2_kernel<false>", sum(bs) * (l + 1.0) * h * w * c * 4))
+    return ms, sums
+
+
+def setmax_fwd_h2_f32_multi(ps, bs, l, ms, addends, sums):
+    """H2 frames (+ H2 set-level addend) -> fp32 maxima ms and sums (the inputs of HPP)."""
+    n, h, w, c = ps[0].shape
+    call("ugn_h2_setmax_fwd_f32_multi", ptr_array([p.data for p in ps]), ptr_array([p.meta for p in ps]), _opt(addends, "data"),
+         _opt(addends, "meta"), _opt(ms), _opt(sums), _ints(bs), len(ps), l, h * w, c, _stream(),
+         label="setmax_fwd[%dx%dx%d h2->f32]" % (h, w, c),
+         work=_hbm("setmax_fwd_h2_kernel<true>", sum(bs) * (l + 1.0) * h * w * c * 4))
+    return ms, sums
+
+
+def setmax_bwd_h2_multi(ps, dms, dm_metas, bs, l, lrelu, outs, addends=None, dm_is_f32=False):
+    """outs[j] (H2Tensor; its data may be addends[j].data) = ((p == max ? dm / #maxima : 0) + addend) * LeakyReLU'(p).
+    dms: H2Tensors, or with dm_is_f32 fp32 tensors whose dm_metas hold {0, bits(max|dm|)}."""
+    n, h, w, c = ps[0].shape
+    dm_ptrs = ptr_array(dms) if dm_is_f32 else ptr_array([d.data for d in dms])
+    call("ugn_h2_setmax_bwd_multi", ptr_array([p.data for p in ps]), ptr_array([p.meta for p in ps]), dm_ptrs, ptr_array(dm_metas),
+         int(bool(dm_is_f32)), _opt(addends, "data"), _opt(addends, "meta"), ptr_array([o.data for o in outs]),
+         ptr_array([o.meta for o in outs]), _ints(bs), len(ps), l, h * w, c, int(bool(lrelu)), _stream(),
+         label="setmax_bwd[%dx%dx%d h2%s]" % (h, w, c, " +addend" if addends is not None else ""),
+         work=_hbm("setmax_bwd_h2_kernel<%s>" % ("true" if dm_is_f32 else "false"),
+                   sum(bs) * l * h * w * c * 4.0 * (3 if addends is not None else 2)))
+    return outs
+
+
+def lrelu_bwd_h2_multi(gs, acts, outs):
+    n, h, w, c = gs[0].shape
+    call("ugn_h2_lrelu_bwd_multi", ptr_array([g.data for g in gs]), ptr_array([g.meta for g in gs]), ptr_array([a.data for a in acts]),
+         ptr_array([o.data for o in outs]), ptr_array([o.meta for o in outs]), _sizes([g.shape[0] * h * w for g in gs]), len(gs), c,
+         _stream(), label="lrelu_bwd[h2]", work=_hbm("lrelu_bwd_h2_kernel", sum(g.data.numel() for g in gs) * 2.0 * 3))
+    return outs
+
+
+def hpp_bwd_b4h2_multi(as_, s3s, b4s, dfeats, dm3s, dzb4s):
+    """HPP backward with b4 as H2Tensors (sign only); dm3s / dzb4s fp32 outputs."""
+    bs = [a.shape[0] for a in as_]
+    call("ugn_hpp_bwd_b4h2_multi", ptr_array(as_), ptr_array(s3s), ptr_array([b.data for b in b4s]), ptr_array(dfeats), ptr_array(dm3s),
+         ptr_array(dzb4s), _ints(bs), len(as_), _stream(), label="hpp_bwd[h2]",
+         work=_hbm("hpp_bwd_kernel<true>", sum(bs) * 256 * 128 * 4.0 * 5))
+    return dm3s, dzb4s
