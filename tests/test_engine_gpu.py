@@ -239,6 +239,6 @@ def test_h2_path_properties(dev):
     gd, gs = dense.get_grads_numpy(), skip.get_grads_numpy()
     for mi in range(3):
         for k in gd['branches'][mi]:
-            assert rell2(gs['branches'][mi][k], gd['branches'][mi][k].astype(np.float64)) <= 1e-6, (mi, k)
+            assert rell2(gs['branches'][mi][k], gd['branches'][mi][k].astype(np.float64)) <= 5e-6, (mi, k)   # (slab order differs)
     assert not torch.equal(dense.store.grad, f32.store.grad)
     assert rell2(dense.store.grad.cpu().numpy(), f32.store.grad.cpu().numpy().astype(np.float64)) <= 1e-3

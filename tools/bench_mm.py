@@ -28,12 +28,17 @@ def main():
     dev = torch.device("cuda")
     res = {}
 
+    cold = "--cold" in argv      # evict the Infinity Cache (256 MB) before every timed launch: in the training step a kernel's
+    junk = torch.empty(1 << 28, dtype=torch.float32, device=dev) if cold else None   # inputs come from HBM, not from a replay
+
     def timeit(fn):
         for _ in range(2):
             fn()
         torch.cuda.synchronize()
         ts = []
         for _ in range(reps):
+            if cold:
+                junk.add_(1.0)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             fn()
@@ -47,6 +52,9 @@ def main():
         ns = [frames] * nmod + ([24] * nmod if layer != "a2" else [])
         ho = hw // 2 if pool else hw
         xs = [torch.randn(n, hw, hw, cin, device=dev) for n in ns]
+        if "--masked" in argv:      # 40 % of the images carry the tiny activations of a masked modality (input = constant 1e-9)
+            for x in xs:
+                x[torch.rand(x.shape[0], device=dev) < 0.4] = 1e-9
         ws = [torch.randn(3, 3, cin, cout, device=dev) * 0.05 for _ in ns]
         dzs = [torch.randn(n, ho, ho, cout, device=dev) * 1e-4 for n in ns]
         idxs = [torch.randint(0, 4, (n, ho, ho, cout), device=dev, dtype=torch.uint8) for n in ns] if pool else None
@@ -56,7 +64,8 @@ def main():
             ufs = [ops.wino_pack(w, False) for w in ws]
             outs = [torch.empty(n, ho, ho, cout, device=dev) for n in ns]
             oidx = [torch.empty(n, ho, ho, cout, device=dev, dtype=torch.uint8) for n in ns] if pool else None
-            fns["fwd wino"] = lambda: ops.conv3x3_fwd_wino_multi(xs, ufs, cout, pool, outs, oidx)
+            if "--only-mm" not in argv:
+                fns["fwd wino"] = lambda: ops.conv3x3_fwd_wino_multi(xs, ufs, cout, pool, outs, oidx)
             hx = [h2.encode(x) for x in xs]
             pk = [h2.mm_pack(w, False) for w in ws]
             ho_ = [h2.H2Tensor.empty((n, ho, ho, cout), dev) for n in ns]
@@ -66,7 +75,8 @@ def main():
             douts = [torch.empty(n, hw, hw, cin, device=dev) for n in ns]
             use_act = layer in ("a4", "a6")
             acts = xs if use_act else None
-            fns["dgrad wino"] = lambda: ops.conv3x3_dgrad_wino_multi(dzs, uds, hw, cin, cout, douts, dz_idxs=idxs, acts=acts)
+            if "--only-mm" not in argv:
+                fns["dgrad wino"] = lambda: ops.conv3x3_dgrad_wino_multi(dzs, uds, hw, cin, cout, douts, dz_idxs=idxs, acts=acts)
             hdz = [h2.encode(d) for d in dzs]
             pkd = [h2.mm_pack(w, True) for w in ws]
             hdo = [h2.H2Tensor.empty((n, hw, hw, cin), dev) for n in ns]
@@ -75,7 +85,8 @@ def main():
                                                                                  dz_idxs=idxs, acts=hact)
         if "wgrad" in kinds:
             dws = [torch.empty(3, 3, cin, cout, device=dev) for _ in ns]
-            fns["wgrad wino"] = lambda: ops.conv3x3_wgrad_wino_multi(xs, dzs, cout, dws, dz_idxs=idxs)
+            if "--only-mm" not in argv:
+                fns["wgrad wino"] = lambda: ops.conv3x3_wgrad_wino_multi(xs, dzs, cout, dws, dz_idxs=idxs)
             if hasattr(h2, "conv3x3_wgrad_mm_multi"):
                 hx2 = [h2.encode(x) for x in xs]
                 hdz2 = [h2.encode(d) for d in dzs]

@@ -29,6 +29,17 @@ namespace {
 
 enum { EPI_LRELU = 0, EPI_LRELU_POOL = 1, EPI_DGRAD = 2, EPI_DGRAD_ACT = 3 };
 
+// timing-only ablations (WRONG results; tools/bench_mm.py --variants): 1 no filter DMA after the prologue, 2 no input-tile DMA
+// after the prologue, 4 no epilogue stores, 8 no MFMA, 16 no per-stage wait for the filter DMA
+#ifndef UGN_MM_ABLATE
+#define UGN_MM_ABLATE 0
+#endif
+#if UGN_MM_ABLATE & 4
+#define UGN_ST(T_, ptr_, val_) do { unsigned v__ = (unsigned)(val_); asm volatile("" :: "v"(v__)); (void)(ptr_); } while (0)
+#else
+#define UGN_ST(T_, ptr_, val_) *reinterpret_cast<T_*>(ptr_) = (T_)(val_)
+#endif
+
 constexpr int HROW = 168;                       // 16-byte slots per halo row (18 pixels x 9 + 6 pad; = 8 mod 16)
 constexpr int HPIECES = 48;                     // 18 rows x 168 slots = 3024 -> 48 pieces of 64 slots (6 per wave)
 constexpr int HALO_BYTES = HPIECES * 1024;      // 49,152
@@ -189,7 +200,12 @@ __device__ __forceinline__ void scatter_pooled(const char* stg, char* halo, int 
 }
 
 __device__ __forceinline__ f32x16 mfma_h(const uint4& a, const uint4& b, f32x16 c) {
+#if UGN_MM_ABLATE & 8
+  c[0] += __uint_as_float(a.x ^ b.y);     // (keeps the operands alive)
+  return c;
+#else
   return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, a), __builtin_bit_cast(h8, b), c, 0, 0, 0);
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -280,7 +296,7 @@ __global__ __launch_bounds__(512, 2) void conv_mm_kernel(const MmJobs jt, const 
     const bool more = next_item < nitems;
     const int jn = more ? mm_job_of(jt, next_item) : jb, nlit = more ? next_item - jt.start[jn] : lit;
     if (jb != meta_jb) {          // (wave-uniform) first item of a job in this workgroup: its exponents, loaded under the MFMAs
-      if (meta_jb >= 0) h2_publish_amax(jt.job[meta_jb].out_meta, wave_max(mx), lane);
+      if (meta_jb >= 0) h2_publish_amax(jt.job[meta_jb].out_meta, wave_max(mx), lane);   // (a job change: at most 5 per workgroup)
       mx = 0.f;
       const MmJob& Jm = jt.job[jb];
       const int e_in = Jm.in_meta->e;
@@ -294,6 +310,12 @@ __global__ __launch_bounds__(512, 2) void conv_mm_kernel(const MmJobs jt, const 
     for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[nb][i] = 0.f;
+    const int img = lit / RPI, rrem = lit % RPI;
+    const int ry0 = (rrem / RPX) * 16, rx0 = (rrem % RPX) * 16;
+    // LeakyReLU' epilogue: the H halves of the layer's input at the lane's 16 pixels x channel pairs are fetched during the last
+    // stage (as epilogue loads between its stores they were 32 dependent round trips to HBM: +0.2 ms on the 128 -> 128 layer)
+    constexpr bool ACTPF = EPI == EPI_DGRAD_ACT && NB >= 2;
+    unsigned actv[ACTPF ? NB / 2 : 1][16];
 
 #pragma unroll 1
     for (int chunk = 0; chunk < NCHUNK; ++chunk) {
@@ -309,16 +331,29 @@ __global__ __launch_bounds__(512, 2) void conv_mm_kernel(const MmJobs jt, const 
         // a chunk the input tile (issued a chunk ago by waves 4..7), before the pooled scatter the staging tile.  The first
         // stage of every item but the first was awaited BEFORE the previous item's epilogue (see there).
         if (!(sg == 0 && chunk == 0 && !first_item)) {
-          if (!is_hw || sg == 0 || (IN_POOLED && sg == NSTG - 1)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          if ((!is_hw && !(UGN_MM_ABLATE & 16)) || sg == 0 || (IN_POOLED && sg == NSTG - 1)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __syncthreads();                                     // ... and is visible; the other buffers have no readers left
-        if (!is_hw) {   // filter stage after this one -> the other filter buffer
+        if constexpr (ACTPF) {
+          if (sg == NSTG - 1 && last_chunk) {
+            const char* act = reinterpret_cast<const char*>(jt.job[jb].act) + (size_t)img * HW * HW * NC * 4;
+#pragma unroll
+            for (int m = 0; m < NB / 2; ++m)
+#pragma unroll
+              for (int r = 0; r < 16; ++r) {
+                const int g = r >> 2, i = r & 3;
+                const unsigned pix = (unsigned)((ry0 + 2 * wave + (i >> 1)) * HW + rx0 + 2 * (2 * g + h) + (i & 1));
+                actv[m][r] = *reinterpret_cast<const unsigned*>(act + pix * (unsigned)(NC * 4) + (unsigned)(64 * m + 2 * (lane & 31)) * 2u);
+              }
+          }
+        }
+        if (!is_hw && !(UGN_MM_ABLATE & 1)) {   // filter stage after this one -> the other filter buffer
           if (sg + 1 < NSTG) {
             stage_w(jt.job[jb].wpk, chunk * NSTG + sg + 1, sbase + W_OFF + (unsigned)(wbuf ^ 1) * WSTAGE);
           } else if (next_tile) {
             stage_w(jt.job[nx_job].wpk, n_chunk * NSTG, sbase + W_OFF + (unsigned)(wbuf ^ 1) * WSTAGE);
           }
-        } else if (next_tile) {   // input tile of the next chunk / item -> the other halo buffer (pooled: the staging tile)
+        } else if (is_hw && next_tile && !(UGN_MM_ABLATE & 2)) {   // input tile of the next chunk / item -> the other halo buffer (pooled: the staging tile)
           if (IN_POOLED ? sg == 0 : sg < HSTG)
             stage_in(jt.job[nx_job], n_lit, n_chunk, sbase + (unsigned)(hbuf ^ 1) * HALO_BYTES, sg * HPER, HPER);
         }
@@ -360,8 +395,6 @@ __global__ __launch_bounds__(512, 2) void conv_mm_kernel(const MmJobs jt, const 
     // ---- epilogue.  acc[nb][4g + i] of lane (col c = lane & 31, half h): window 2g + h, position i of the wave's 8 windows,
     // i.e. pixel (2 * wave + (i >> 1), 2 * (2g + h) + (i & 1)) of the region; channel: mm_block_of / mm_col_of.
     const MmJob& J = jt.job[jb];
-    const int img = lit / RPI, rrem = lit % RPI;
-    const int ry0 = (rrem / RPX) * 16, rx0 = (rrem % RPX) * 16;
     if (lit == 0 && tid == 0) J.out_meta->e = e_out;
     constexpr bool POOL = EPI == EPI_LRELU_POOL;
     constexpr int HO = POOL ? HW / 2 : HW;
@@ -393,10 +426,10 @@ __global__ __launch_bounds__(512, 2) void conv_mm_kernel(const MmJobs jt, const 
             _Float16 h0, l0, h1, l1;
             h2_split(best[0], h0, l0);
             h2_split(best[1], h1, l1);
-            *reinterpret_cast<unsigned*>(out + pix * (unsigned)(NC * 4) + chb) = h2_pack(h0, h1);
-            *reinterpret_cast<unsigned*>(out + pix * (unsigned)(NC * 4) + (unsigned)(NC * 2) + chb) = h2_pack(l0, l1);
+            UGN_ST(unsigned, out + pix * (unsigned)(NC * 4) + chb, h2_pack(h0, h1));
+            UGN_ST(unsigned, out + pix * (unsigned)(NC * 4) + (unsigned)(NC * 2) + chb, h2_pack(l0, l1));
             uint8_t* oi = J.out_idx + (size_t)img * HO * HO * NC;
-            *reinterpret_cast<uint16_t*>(oi + pix * (unsigned)NC + (unsigned)(64 * m + 2 * c)) = (uint16_t)(bi[0] | (bi[1] << 8));
+            UGN_ST(uint16_t, oi + pix * (unsigned)NC + (unsigned)(64 * m + 2 * c), bi[0] | (bi[1] << 8));
           } else {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -406,8 +439,7 @@ __global__ __launch_bounds__(512, 2) void conv_mm_kernel(const MmJobs jt, const 
                 v0 = ugn_lrelu(v0);
                 v1 = ugn_lrelu(v1);
               } else if constexpr (EPI == EPI_DGRAD_ACT) {
-                const char* act = reinterpret_cast<const char*>(J.act) + (size_t)img * HW * HW * NC * 4;
-                const unsigned ah2 = *reinterpret_cast<const unsigned*>(act + pix * (unsigned)(NC * 4) + chb);
+                const unsigned ah2 = actv[m][4 * g + i];
                 v0 *= (short)(ah2 & 0xffffu) > 0 ? 1.f : UGN_LRELU_ALPHA;      // LeakyReLU' from the sign of the H half
                 v1 *= (short)(ah2 >> 16) > 0 ? 1.f : UGN_LRELU_ALPHA;
               }
@@ -415,8 +447,8 @@ __global__ __launch_bounds__(512, 2) void conv_mm_kernel(const MmJobs jt, const 
               _Float16 h0, l0, h1, l1;
               h2_split(v0, h0, l0);
               h2_split(v1, h1, l1);
-              *reinterpret_cast<unsigned*>(out + pix * (unsigned)(NC * 4) + chb) = h2_pack(h0, h1);
-              *reinterpret_cast<unsigned*>(out + pix * (unsigned)(NC * 4) + (unsigned)(NC * 2) + chb) = h2_pack(l0, l1);
+              UGN_ST(unsigned, out + pix * (unsigned)(NC * 4) + chb, h2_pack(h0, h1));
+              UGN_ST(unsigned, out + pix * (unsigned)(NC * 4) + (unsigned)(NC * 2) + chb, h2_pack(l0, l1));
             }
           }
         }
@@ -431,7 +463,7 @@ __global__ __launch_bounds__(512, 2) void conv_mm_kernel(const MmJobs jt, const 
         h2_split(v, hi, lo);
         const unsigned own = h2_pack(hi, lo);
         const unsigned oth = (unsigned)__builtin_amdgcn_update_dpp(0, (int)own, 0xB1, 0xf, 0xf, false);   // quad_perm [1,0,3,2]
-        *reinterpret_cast<unsigned*>(out + pix * (unsigned)(NC * 4) + chb) = __builtin_amdgcn_perm(oth, own, sel);
+        UGN_ST(unsigned, out + pix * (unsigned)(NC * 4) + chb, __builtin_amdgcn_perm(oth, own, sel));
       };
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
@@ -449,7 +481,7 @@ __global__ __launch_bounds__(512, 2) void conv_mm_kernel(const MmJobs jt, const 
           const unsigned pix = (unsigned)((ry0 / 2 + wave) * HO + rx0 / 2 + wx);
           store1(pix, best);
           uint8_t* oi = J.out_idx + (size_t)img * HO * HO * NC;
-          oi[pix * (unsigned)NC + (unsigned)c] = (uint8_t)bi;
+          UGN_ST(uint8_t, oi + pix * (unsigned)NC + (unsigned)c, bi);
         } else {
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
@@ -471,8 +503,9 @@ __global__ __launch_bounds__(512, 2) void conv_mm_kernel(const MmJobs jt, const 
     jb = jn;
     lit = nlit;
   }
-  // one atomicMax per wave and job (not per item: 230 k contended atomics on one address cost a 64x64 layer a millisecond)
-  h2_publish_amax(jt.job[meta_jb].out_meta, wave_max(mx), lane);
+  // one atomicMax per WORKGROUP for the job it ends with (not per item or wave: atomics on one address serialise at ~10 ns
+  // each; 230 k of them cost a 64x64 layer a millisecond).  No DMA is in flight any more: any LDS serves as scratch.
+  h2_publish_amax_block(jt.job[meta_jb].out_meta, mx, reinterpret_cast<float*>(smem), tid, 8);
 }
 
 template <int KC, int NC, int HW, int IN_POOLED, int EPI>
@@ -522,9 +555,10 @@ int dispatch_dgrad(const MmJob* jobs, const int* n, int njobs, int hw, int cin, 
 // fp32 <-> H2 (tests, tools and the boundary of the H2 part of the path)
 // ---------------------------------------------------------------------------------------------------------------------
 __global__ void absmax_kernel(const float* __restrict__ x, size_t n, H2Meta* meta) {
+  __shared__ float red[4];
   float m = 0.f;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) m = fmaxf(m, fabsf(x[i]));
-  h2_publish_amax(meta, wave_max(m), threadIdx.x & 63);
+  h2_publish_amax_block(meta, m, red, threadIdx.x, 4);
 }
 // x [npix][c] fp32 (meta: e = 0, amax = max|x|) -> y [npix][2][c]; the new exponent goes to meta_out (which may be meta_in:
 // it is written by a separate one-thread kernel afterwards)
@@ -630,7 +664,7 @@ extern "C" int ugn_mm_conv3x3_dgrad_multi(const uint16_t* const* dz, const uint8
 extern "C" int ugn_absmax(const float* x, size_t n, void* meta, void* stream) {
   UGN_REQUIRE(x && meta && n > 0, "ugn_absmax: null pointer or n == 0");
   const size_t blocks = (n + 256 * 8 - 1) / (256 * 8);
-  hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, (hipStream_t)stream, x, n, (H2Meta*)meta);
+  hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)(blocks < 256 ? blocks : 256)), dim3(256), 0, (hipStream_t)stream, x, n, (H2Meta*)meta);
   UGN_CHECK_LAUNCH("absmax");
   return 0;
 }
@@ -643,7 +677,7 @@ extern "C" int ugn_h2_encode(const float* x, uint16_t* y, void* meta, size_t npi
   const size_t n = npix * (size_t)c;
   const size_t blocks = (n + 256 * 8 - 1) / (256 * 8);
   const unsigned grid = (unsigned)(blocks < 2048 ? blocks : 2048);
-  hipLaunchKernelGGL(absmax_kernel, dim3(grid), dim3(256), 0, st, x, n, (H2Meta*)meta);
+  hipLaunchKernelGGL(absmax_kernel, dim3(grid < 256 ? grid : 256), dim3(256), 0, st, x, n, (H2Meta*)meta);
   hipLaunchKernelGGL(h2_encode_kernel, dim3(grid), dim3(256), 0, st, x, y, (const H2Meta*)meta, npix, c);
   hipLaunchKernelGGL(h2_rescale_meta_kernel, dim3(1), dim3(1), 0, st, (H2Meta*)meta);
   UGN_CHECK_LAUNCH("h2_encode");

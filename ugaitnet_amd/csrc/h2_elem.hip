@@ -187,9 +187,16 @@ struct CvtJobs {
 __global__ void absmax_multi_kernel(const CvtJobs jt) {
   const int j = blockIdx.y;
   const float* x = jt.x[j];
+  __shared__ float red[4];
   float m = 0.f;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < jt.n[j]; i += (size_t)gridDim.x * blockDim.x) m = fmaxf(m, fabsf(x[i]));
-  h2_publish_amax(jt.scratch[j], wave_max(m), threadIdx.x & 63);
+  const size_t n4 = jt.n[j] / 4;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    const float4 v = reinterpret_cast<const float4*>(x)[i];
+    m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+  }
+  if (blockIdx.x == 0)
+    for (size_t i = n4 * 4 + threadIdx.x; i < jt.n[j]; i += blockDim.x) m = fmaxf(m, fabsf(x[i]));
+  h2_publish_amax_block(jt.scratch[j], m, red, threadIdx.x, 4);
 }
 __global__ void encode_multi_kernel(const CvtJobs jt, int c) {
   const int j = blockIdx.y;
@@ -320,8 +327,8 @@ extern "C" int ugn_absmax_multi(const float* const* x, const size_t* n, void* co
     jt.x[j] = x[j]; jt.scratch[j] = (H2Meta*)meta[j]; jt.n[j] = n[j];
     if (n[j] > nmax) nmax = n[j];
   }
-  const size_t blocks = (nmax + 256 * 8 - 1) / (256 * 8);
-  hipLaunchKernelGGL(absmax_multi_kernel, dim3((unsigned)(blocks < 1024 ? blocks : 1024), njobs), dim3(256), 0, (hipStream_t)stream, jt);
+  const size_t blocks = (nmax + 256 * 16 - 1) / (256 * 16);
+  hipLaunchKernelGGL(absmax_multi_kernel, dim3((unsigned)(blocks < 256 ? blocks : 256), njobs), dim3(256), 0, (hipStream_t)stream, jt);
   UGN_CHECK_LAUNCH("absmax_multi");
   return 0;
 }

@@ -67,6 +67,19 @@ __device__ __forceinline__ float wave_max(float v) {
 __device__ __forceinline__ void h2_publish_amax(H2Meta* m, float wave_amax, int lane) {
   if (lane == 0 && wave_amax > 0.f) atomicMax(&m->amax, __float_as_uint(wave_amax));
 }
+// the same for a whole workgroup through `scratch` (one float per wave, in LDS): ONE atomic per workgroup -- atomics on one
+// address serialise at ~10 ns each, so 12 k of them (a wave each, 6 jobs) are 0.1 ms at the tail of a launch
+__device__ __forceinline__ void h2_publish_amax_block(H2Meta* m, float v, float* scratch, int tid, int nwaves) {
+  const float w = wave_max(v);
+  __syncthreads();
+  if ((tid & 63) == 0) scratch[tid >> 6] = w;
+  __syncthreads();
+  if (tid == 0) {
+    float a = scratch[0];
+    for (int k = 1; k < nwaves; ++k) a = fmaxf(a, scratch[k]);
+    if (a > 0.f) atomicMax(&m->amax, __float_as_uint(a));
+  }
+}
 
 // global -> LDS, 16 B per lane (LDS address = M0 + lane * 16); see wino_common.h dma16 for why this is inline asm
 __device__ __forceinline__ void dma16(const void* gsrc, unsigned lds_dst_uniform) {

@@ -25,11 +25,17 @@ def _stream():
 
 
 class MetaPool:
-    """All ugn_h2meta / ugn_wmeta records of a model in ONE int32 buffer: the per-step reset is a single memset.
-    Slots are handed out by name and live as long as the pool."""
+    """All ugn_h2meta records of a model in ONE int32 buffer: the per-step reset is a single memset.
+    Slots are handed out by name and live as long as the pool.
+
+    ONE RECORD PER 256 BYTES.  A producer gathers `amax` with atomicMax (thousands per launch, all on one address, ~0.1 us
+    each at the L2); a consumer -- or the same kernel, for its INPUT's record -- loads the neighbouring record.  Side by side
+    in one cache line those loads queue behind the atomics: measured on MI355X, the 32 -> 64 forward launch of the C3 step took
+    447 us with input and output records adjacent and 247 us with either of them moved away (tools/bench_step_kernels.py)."""
+    STRIDE = 64      # int32 per record (the record itself is the first two)
 
     def __init__(self, device, capacity=1024):
-        self.buf = torch.zeros((capacity, 2), dtype=I32, device=device)
+        self.buf = torch.zeros((capacity, self.STRIDE), dtype=I32, device=device)
         self.slots = {}
 
     def slot(self, name):
@@ -38,7 +44,7 @@ class MetaPool:
             i = self.slots[name] = len(self.slots)
             if i >= self.buf.shape[0]:
                 raise RuntimeError("MetaPool: out of slots")
-        return self.buf[i]
+        return self.buf[i, :2]
 
     def reset(self, keep=()):
         """Zero every record (amax gathers by atomicMax) except the named ones (filter metas survive the step)."""
