@@ -69,7 +69,7 @@ DTYPE_TEXT = {
 PEAK_F32_MFMA = 157.3e12   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 / 16x16x4_f32 dense peak
 PEAK_BF16_MFMA = 16 * PEAK_F32_MFMA   # same guide: the f32 MFMA rate is 1/16 of the dense bf16 rate (~2.5 PFLOP/s)
 PEAK_HBM = 8.0e12          # same guide: HBM3E spec peak (6.3 TB/s is what a float4 copy achieves)
-DEFAULT_DTYPE = os.environ.get("UGN_BENCH_DTYPE", "f32")
+DEFAULT_DTYPE = os.environ.get("UGN_BENCH_DTYPE", "h2")     # the product's default arithmetic (engine.DEFAULT_PRECISION)
 
 
 def cpu_baseline(kinds, ncls, clips, n_ids, seconds_budget=30.0, multimodal=True):

@@ -271,8 +271,9 @@ int ugn_knn_predict(const float* gallery, const int32_t* gallery_labels, const f
  * largest |stored| value) is gathered by the producer with atomicMax and tells the consumer the true range.
  * EVERY ugn_h2meta THAT A KERNEL WRITES MUST BE ZERO ON ENTRY (one hipMemsetAsync over the model's meta array per step). */
 typedef struct { int32_t e; uint32_t amax_bits; } ugn_h2meta;
-/* packed filter halves of a 3x3 layer: {block exponent, L1 bound}; filled by ugn_mm_pack_multi */
-typedef struct { int32_t e; float l1; } ugn_wmeta;
+/* packed filter halves of a 3x3 layer: {block exponent, L1 bound, bits of max|w|, unused}; filled by ugn_mm_pack_multi (the
+ * kernels read the first two words) */
+typedef struct { int32_t e; float l1; uint32_t amax_bits; uint32_t reserved; } ugn_wmeta;
 /* meta <- {0, bits(max|x|)} of an fp32 tensor (meta zero on entry): what a kernel that turns fp32 into H2 needs first */
 int ugn_absmax(const float* x, size_t n, void* meta, void* stream);
 /* fp32 [npix][c] <-> H2 [npix][2][c] (tests, tools, the edges of the H2 part of the path); encode zeroes and fills meta */

@@ -13,7 +13,7 @@ def _core(seed=3, **kw):
     return GaitCore([2, 1, 1], nclasses=6, fuse_mode="sign_max", margin=0.2, loss_weights=(1.0, 0.1), seed=seed, lr=1e-3, **kw)
 
 
-@pytest.mark.parametrize("prec", ["f32", "bf16"])
+@pytest.mark.parametrize("prec", ["f32", "bf16", "h2"])
 def test_graphed_step_equals_eager_step(dev, prec):
     from ugaitnet_amd.engine import GraphedTrainStep
     kinds = ("of", "gray", "depth")

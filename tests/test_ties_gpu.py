@@ -1,4 +1,5 @@
-"""MaxPool tie-breaking on the DEFAULT path (Winograd F(2x2,3x3) convolutions) and on the direct kernels (UGN_WINO=0).
+"""MaxPool tie-breaking on the Winograd fp32 path (conv_precision="f32"), on the fp32 direct kernels (UGN_WINO=0) and on the H2
+path (conv_precision="h2", the default: direct convolutions on the f16 matrix pipe, exact on every tie).
 
 Reference rule: TF's MaxPoolGrad routes the gradient to the FIRST maximum of a 2x2 window in row-major order
 (nets/mj_uwyhNets_ba.py:433,449).  Exact ties are the normal case on silhouettes and constant inputs: wherever the 3x3 input
@@ -76,10 +77,10 @@ def _diag_batch(b=6, l=3, seed=4):
     return xs, uses, labels, onehot
 
 
-def _run(dev, batch, direct=False):
+def _run(dev, batch, direct=False, precision="f32"):
     from ugaitnet_amd import engine
     from ugaitnet_amd.engine import GaitCore
-    assert engine.USE_WINOGRAD, "the default path is the Winograd one"
+    assert engine.USE_WINOGRAD, "conv_precision='f32' means the Winograd kernels unless UGN_WINO=0"
     xs, uses, labels, onehot = batch
     rng = np.random.default_rng(21)
     p64 = dict(branches=[O.init_branch_params(rng, c, np.float64) for c in (2, 1, 1)], head=O.init_head_params(rng, 4, np.float64))
@@ -88,7 +89,8 @@ def _run(dev, batch, direct=False):
         from ugaitnet_amd import ops
         engine.USE_WINOGRAD, engine._wgrad3x3 = False, ops.conv3x3_wgrad
     try:
-        core = GaitCore([2, 1, 1], nclasses=4, fuse_mode="sign_max", margin=0.2, loss_weights=(1.0, 0.1), device=dev)
+        core = GaitCore([2, 1, 1], nclasses=4, fuse_mode="sign_max", margin=0.2, loss_weights=(1.0, 0.1), device=dev,
+                        conv_precision=precision)
         core.set_params_numpy(O.cast_params(p64, np.float32))
         core.forward_backward(xs, uses, labels, onehot)
         torch.cuda.synchronize()
@@ -128,7 +130,7 @@ def _tie_report(core, r):
     for mi, enc in enumerate(core.encoders):
         c = r["branch"][mi]
         for pre, ref_idx, key in ((c["a2"], c["i2"], "i2"), (c["a4"], c["i4"], "i4"), (c["b2"], c["j2"], "j2")):
-            got_idx = enc.act[key].cpu().numpy()
+            got_idx = (enc.h2.bufs[key] if core.h2 else enc.act[key]).cpu().numpy()
             ties, first = _tie_windows(pre)
             t, m, o = rep.get(key, (0, 0, 0))
             rep[key] = (t + int(ties.sum()), m + int((got_idx[ties] != first[ties]).sum()),
@@ -182,3 +184,18 @@ def test_diagonal_edges_direct_kernels_are_exact(dev):
     rep = _tie_report(core, r)
     assert all(v[1] == 0 and v[2] <= 20 for v in rep.values()), rep
     _check_forward_and_grads(core, r, g, 1e-2)
+
+
+@pytest.mark.parametrize("batch", ["flat", "diagonal"])
+def test_h2_path_routes_every_tie_to_the_first_maximum(dev, batch):
+    """conv_precision="h2" (direct convolutions on the f16 matrix pipe, ugaitnet_amd/csrc/conv3x3_mm.hip): identical input
+    patches give bit-identical sums, so EVERY exact tie of the reference -- axis-aligned flats and 45-degree edges, in all three
+    pooled layers -- routes to the first maximum, as TF's MaxPoolGrad does."""
+    core, r, g = _run(dev, _flat_batch() if batch == "flat" else _diag_batch(), precision="h2")
+    rep = _tie_report(core, r)
+    ties = sum(v[0] for v in rep.values())
+    print("%s batch, H2 path: (ties, moved, other mismatches) per pooled layer: %r" % (batch, rep))
+    assert ties > 100000
+    assert all(v[1] == 0 for v in rep.values()), rep
+    assert all(v[2] <= 20 for v in rep.values()), rep               # elsewhere: only fp32-vs-fp64 near-ties may differ
+    _check_forward_and_grads(core, r, g, 1e-3)

@@ -66,42 +66,52 @@ struct PackTable {
   const float* w[kPackJobs];
   uint16_t* pk[kPackJobs];
   WMeta* meta[kPackJobs];
+  unsigned* amax[kPackJobs];     // bits of max|w| (the third word of the filter's ugn_wmeta record)
   int cin[kPackJobs], cout[kPackJobs], dgrad[kPackJobs];
 };
 
-// one block per job: block exponent from max|w|, and the L1 bound of the direction
+// Filter statistics, 16 blocks per job: block exponent from max|w| and the L1 bound of the direction
+//   forward: an output channel sums over (tap, cin); data gradient: an input channel sums over (tap, cout).
+// Block s of a job owns a 1/16 slice of the outputs; its 256 threads = (output of the slice) x (part of the sum), the parts
+// are added through LDS in a fixed order.  Maxima leave by atomicMax on the bits of non-negative floats (order-independent).
+constexpr int kStatSlices = 16;
+__global__ __launch_bounds__(256) void mm_wstats_zero_kernel(PackTable t, int njobs) {
+  if ((int)threadIdx.x < njobs) { t.meta[threadIdx.x]->l1 = 0.f; t.amax[threadIdx.x][0] = 0u; }
+}
 __global__ __launch_bounds__(256) void mm_wstats_kernel(PackTable t) {
-  const int j = blockIdx.x, tid = threadIdx.x;
+  const int j = blockIdx.y, sl = blockIdx.x, tid = threadIdx.x;
   const float* w = t.w[j];
   const int cin = t.cin[j], cout = t.cout[j], dgrad = t.dgrad[j];
+  __shared__ float sp[256];
   float amax = 0.f;
-  for (int e = tid; e < 9 * cin * cout; e += 256) amax = fmaxf(amax, fabsf(w[e]));
-  // forward: an output channel sums over (tap, cin); data gradient: an input channel sums over (tap, cout)
-  float l1 = 0.f;
-  const int nout = dgrad ? cin : cout;
-  for (int o = tid; o < nout; o += 256) {
-    float s = 0.f;
-    if (!dgrad) {
-      for (int r = 0; r < 9 * cin; ++r) s += fabsf(w[(size_t)r * cout + o]);
-    } else {
-      for (int tap = 0; tap < 9; ++tap)
-        for (int co = 0; co < cout; ++co) s += fabsf(w[((size_t)tap * cin + o) * cout + co]);
-    }
-    l1 = fmaxf(l1, s);
+  const int total = 9 * cin * cout, per = (total + kStatSlices - 1) / kStatSlices;
+  for (int e = sl * per + tid; e < min(total, (sl + 1) * per); e += 256) amax = fmaxf(amax, fabsf(w[e]));
+  const int nout = dgrad ? cin : cout, os = nout / kStatSlices;     // outputs of this block (2 ... 8)
+  const int parts = 256 / os, o = sl * os + tid / parts, part = tid % parts;
+  float s = 0.f;
+  if (!dgrad) {       // terms r = (tap, ci): rows of the [9*cin][cout] matrix
+    for (int r = part; r < 9 * cin; r += parts) s += fabsf(w[(size_t)r * cout + o]);
+  } else {            // terms (tap, co) of row (tap, ci = o)
+    for (int q = part; q < 9 * cout; q += parts) s += fabsf(w[((size_t)(q / cout) * cin + o) * cout + (q % cout)]);
   }
-  __shared__ float sa[256], sl[256];
-  sa[tid] = amax;
-  sl[tid] = l1;
+  sp[tid] = s;
   __syncthreads();
-  for (int o = 128; o >= 1; o >>= 1) {
-    if (tid < o) { sa[tid] = fmaxf(sa[tid], sa[tid + o]); sl[tid] = fmaxf(sl[tid], sl[tid + o]); }
+  float l1 = 0.f;
+  if (part == 0) {
+    for (int k = 0; k < parts; ++k) l1 += sp[tid + k];
+  }
+  __syncthreads();
+  sp[tid] = part == 0 ? l1 : 0.f;
+  __shared__ float sa[256];
+  sa[tid] = amax;
+  __syncthreads();
+  for (int k = 128; k >= 1; k >>= 1) {
+    if (tid < k) { sa[tid] = fmaxf(sa[tid], sa[tid + k]); sp[tid] = fmaxf(sp[tid], sp[tid + k]); }
     __syncthreads();
   }
   if (tid == 0) {
-    WMeta m;
-    m.e = h2_exp_for_bound(sa[0]) - 1;      // stored |w| < 2^14
-    m.l1 = sl[0] * 1.0001f;                 // (the sums above round; keep the bound a bound)
-    *t.meta[j] = m;
+    atomicMax(t.amax[j], __float_as_uint(sa[0]));
+    atomicMax(reinterpret_cast<unsigned*>(&t.meta[j]->l1), __float_as_uint(sp[0] * 1.0001f));   // (the sums round; keep the bound a bound)
   }
 }
 
@@ -118,8 +128,10 @@ __global__ void mm_pack_kernel(PackTable t) {
   // consecutive threads walk cout, the contiguous axis of the HWIO filter
   const int k = dgrad ? rem % kc : rem / nc, n = dgrad ? rem / kc : rem % nc;
   const float v = dgrad ? t.w[j][((size_t)(8 - tap) * cin + n) * cout + k] : t.w[j][((size_t)tap * cin + k) * cout + n];
+  const int ew = h2_exp_for_bound(__uint_as_float(t.amax[j][0])) - 1;      // stored |w| < 2^14
+  if (e == 0) t.meta[j]->e = ew;
   _Float16 hi, lo;
-  h2_split(ldexpf(v, t.meta[j]->e), hi, lo);
+  h2_split(ldexpf(v, ew), hi, lo);
   const int nb_all = nc / 32;
   const int chunk = k >> 5, s = (k >> 4) & 1, h = (k >> 3) & 1, ee = k & 7;
   const int nb = mm_block_of(n, nc), col = mm_col_of(n, nc);
@@ -615,10 +627,12 @@ extern "C" int ugn_mm_pack_multi(const float* const* w_hwio_host, uint16_t* cons
     const int nc = dgrad_host[j] ? ci : co;
     UGN_REQUIRE(nc == 32 || nc == 64 || nc == 128, "ugn_mm_pack_multi: %d output channels of the GEMM (32, 64 or 128; job %d)", nc, j);
     t.w[j] = w_hwio_host[j]; t.pk[j] = wpk_host[j]; t.meta[j] = (WMeta*)wmeta_host[j];
+    t.amax[j] = reinterpret_cast<unsigned*>(wmeta_host[j]) + 2;
     t.cin[j] = ci; t.cout[j] = co; t.dgrad[j] = dgrad_host[j] ? 1 : 0;
     if (9 * ci * co > maxe) maxe = 9 * ci * co;
   }
-  hipLaunchKernelGGL(mm_wstats_kernel, dim3(njobs), dim3(256), 0, (hipStream_t)stream, t);
+  hipLaunchKernelGGL(mm_wstats_zero_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, t, njobs);
+  hipLaunchKernelGGL(mm_wstats_kernel, dim3(kStatSlices, njobs), dim3(256), 0, (hipStream_t)stream, t);
   UGN_CHECK_LAUNCH("mm_wstats");
   hipLaunchKernelGGL(mm_pack_kernel, dim3((maxe + 255) / 256, njobs), dim3(256), 0, (hipStream_t)stream, t);
   UGN_CHECK_LAUNCH("mm_pack");

@@ -34,6 +34,12 @@ CONV_SPECS = (
 )
 NBINS, FEAT, HIDDEN = 62, 128, 256
 
+# Arithmetic of the 3x3 layers when a model does not name one (GaitCore(conv_precision=...), UGN_CONV_PRECISION):
+#   "h2"  (default) activations / gradients between the 3x3 layers as split-fp16 halves + block exponent (22 significant bits),
+#         3x3 layers as direct convolutions on the f16 matrix pipe: holds every fp32 parity bar of tests/ and is 1.4x faster
+#   "f32" Winograd F(2x2,3x3) on the fp32 MFMA;  "bf16" the same with bf16-rounded MFMA operands
+DEFAULT_PRECISION = os.environ.get("UGN_CONV_PRECISION", "h2")
+
 # Winograd F(2x2,3x3) kernels for the 3x3 forward convolutions and data gradients (UGN_WINO=0 selects the direct
 # implicit-GEMM kernels, whose MaxPool tie-breaking on exactly equal activations follows the reference's first-max rule).
 USE_WINOGRAD = os.environ.get("UGN_WINO", "1") != "0"
@@ -511,7 +517,7 @@ class GaitCore:
 
     def __init__(self, in_channels, nclasses=0, multimodal=None, fuse_mode="sign_max", margin=0.2,
                  loss_weights=(1.0, 1.0), device=None, seed=None, lr=1e-4, beta_1=0.9, beta_2=0.999, epsilon=1e-7,
-                 process_group=None, world_size=1, skip_masked=False, dp_mode="replica", conv_precision="f32",
+                 process_group=None, world_size=1, skip_masked=False, dp_mode="replica", conv_precision=None,
                  force_collectives=False, triplet_mode="all"):
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         self.in_channels = tuple(int(c) for c in in_channels)
@@ -561,6 +567,7 @@ class GaitCore:
         # "f32": Winograd fp32 MFMA kernels; "bf16": the same with bf16-rounded MFMA operands; "h2": activations / gradients
         # between the 3x3 layers held as split-fp16 halves + block exponent, 3x3 layers on the f16 matrix pipe at fp32-class
         # accuracy (engine_h2.py, csrc/mm_common.h)
+        conv_precision = DEFAULT_PRECISION if conv_precision is None else conv_precision
         if conv_precision not in ("f32", "bf16", "h2"):
             raise ValueError("conv_precision must be 'f32', 'bf16' or 'h2', got %r" % (conv_precision,))
         self.conv_precision = conv_precision

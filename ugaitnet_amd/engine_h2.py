@@ -30,7 +30,7 @@ class H2State:
     def __init__(self, enc, pool):
         self.enc, self.pool = enc, pool
         dev = enc.store.device
-        self.wmeta = torch.zeros((len(LAYERS3), 2, 2), dtype=I32, device=dev)     # [layer][direction] {e, l1}: NOT reset per step
+        self.wmeta = torch.zeros((len(LAYERS3), 2, 4), dtype=I32, device=dev)     # [layer][direction] ugn_wmeta: NOT reset per step
         self.pk = {}
         for k, (name, cin, cout, _, _) in enumerate(LAYERS3):
             self.pk[name] = tuple((torch.empty((18 * cin * cout,), dtype=I16, device=dev), self.wmeta[k, d]) for d in (0, 1))

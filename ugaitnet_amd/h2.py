@@ -116,7 +116,7 @@ def absmax(x, meta):
 
 
 def mm_pack_multi(jobs):
-    """jobs: list of (w HWIO fp32 tensor, packed int16 tensor of 18*cin*cout elements, wmeta int32[2], dgrad flag)."""
+    """jobs: list of (w HWIO fp32 tensor, packed int16 tensor of 18*cin*cout elements, wmeta int32[4], dgrad flag)."""
     for k in range(0, len(jobs), 64):
         part = jobs[k:k + 64]
         n = len(part)
@@ -128,7 +128,7 @@ def mm_pack_multi(jobs):
 def mm_pack(w, dgrad, pk=None, wmeta=None):
     cin, cout = w.shape[2], w.shape[3]
     pk = torch.empty((18 * cin * cout,), dtype=I16, device=w.device) if pk is None else pk
-    wmeta = torch.zeros(2, dtype=I32, device=w.device) if wmeta is None else wmeta
+    wmeta = torch.zeros(4, dtype=I32, device=w.device) if wmeta is None else wmeta      # ugn_wmeta: 16 bytes
     mm_pack_multi([(w, pk, wmeta, dgrad)])
     return pk, wmeta
 
