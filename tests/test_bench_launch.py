@@ -78,19 +78,25 @@ def test_rccl_path_with_one_rank(dev):
 
 @pytest.mark.gpu
 @pytest.mark.timeout(900)
-def test_roofline_object_of_the_default_command(dev, tmp_path):
+@pytest.mark.parametrize("dtype", ["h2", "f32"])
+def test_roofline_object_of_the_default_command(dev, tmp_path, dtype):
     """The bench line's roofline: dominant kernel by total duration of the serialised pass, fraction of peak on EXECUTED matrix
-    FLOPs (<= 1), the algorithmic rate beside it, HBM-bound rows priced in bytes; --kernel-table writes every row."""
+    FLOPs (<= 1) against the peak of the instruction that executes them, the algorithmic rate beside it, HBM-bound rows priced in
+    bytes; --kernel-table writes every row.  h2 is what the bare command runs (dtype f16x2); f32 is the Winograd line."""
     table = str(tmp_path / "ktable.csv")
     r = subprocess.run([sys.executable, BENCH, "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--dense-only", "--clips-per-gpu",
-                        "8", "--kernel-table", table], env=_env(), capture_output=True, text=True, timeout=800)
+                        "8", "--kernel-table", table] + ([] if dtype == "h2" else ["--dtype", dtype]),
+                       env=_env(), capture_output=True, text=True, timeout=800)
     assert r.returncode == 0, r.stderr[-3000:]
     d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
     roof = d["roofline"]
-    assert roof["bound"] == "mfma" and roof["unit"] == "TFLOP/s" and roof["peak"] == 157.3
+    assert d["dtype"].startswith("f16x2" if dtype == "h2" else "f32")
+    assert roof["bound"] == "mfma" and roof["unit"] == "TFLOP/s" and roof["peak"] == (2516.8 if dtype == "h2" else 157.3)
     assert 0.05 < roof["frac"] <= 1.0 and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3
-    assert abs(roof["algorithmic_tflops"] / roof["achieved"] - 36.0 / 16.0) < 0.01       # Winograd executes 16/36 of the direct count
-    assert roof["kernel"].startswith("conv3x3_") and "wino" in roof["rocprof_kernel"] and roof["launches_per_step"] >= 1
+    # executed / algorithmic FLOPs: three f16 MFMAs per product on the H2 path, 16/36 of the direct count for Winograd
+    assert abs(roof["achieved"] / roof["algorithmic_tflops"] - (3.0 if dtype == "h2" else 16.0 / 36.0)) < 0.01
+    assert roof["kernel"].startswith("conv3x3_") and ("_mm_kernel" if dtype == "h2" else "wino") in roof["rocprof_kernel"]
+    assert roof["launches_per_step"] >= 1
     assert roof["avg_us"] > 0 and 0 < roof["share_of_step"] < 0.5 and roof["serial_step_us"] > 0
     kinds = {k.get("bound") for k in roof["other_kernels"]}
     assert "mfma" in kinds and all(k.get("frac", 0) <= 1.0 for k in roof["other_kernels"] if k.get("bound") == "mfma")

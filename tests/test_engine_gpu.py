@@ -228,7 +228,7 @@ def test_h2_path_properties(dev):
     p64 = oracle_params(kinds, ncls)
     dense = build(kinds, ncls, 'sign_max', p64, conv_precision='h2')
     skip = build(kinds, ncls, 'sign_max', p64, conv_precision='h2', skip_masked=True)
-    f32 = build(kinds, ncls, 'sign_max', p64)
+    f32 = build(kinds, ncls, 'sign_max', p64, conv_precision='f32')
     for c in (dense, skip, f32):
         c.forward_backward(xs, uses, labels, onehot)
     torch.cuda.synchronize()
