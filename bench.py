@@ -62,7 +62,8 @@ def flop_per_clip(kinds):
 
 DTYPE_TEXT = {
     "f32": "f32",
-    "bf16": "bf16 MFMA operands in the 3x3 fwd/dgrad/wgrad (f32 accumulate)",
+    "bf16": "bf16: activations, gradients and saved tensors bf16 in HBM, 3x3 layers on v_mfma_f32_32x32x16_bf16 with f32 accumulate, "
+            "f32 weight gradients / master weights / Adam (BASELINE configs[4])",
     "h2": "f16x2: fp32-class values held as two f16 halves + a block exponent (22 significant bits); 3x3 layers = three "
           "v_mfma_f32_32x32x16_f16 per product (hi*hi + hi*lo + lo*hi), f32 accumulate; everything else f32",
 }
@@ -338,7 +339,14 @@ def run(args):
     ctx = engine.serial_launches() if args.serial else None
     if ctx:
         ctx.__enter__()
+    if use_dist:      # per-collective event pairs during the timed steps (warm-up included: divided by all steps run)
+        from ugaitnet_amd import dp as _dp
+        _dp.TIMING = {}
     dt = timed(core, batch)
+    coll_ms = None
+    if use_dist:
+        coll_ms = _dp.timing_summary(args.steps + args.warmup)
+        _dp.TIMING = None
     if ctx:
         ctx.__exit__(None, None, None)
     losses = core.losses()
@@ -361,10 +369,15 @@ def run(args):
         value = world * b_gpu * args.steps / dt
         dist_info = None
         if use_dist:
-            dist_info = dict(backend=dist.get_backend(), world_size=dist.get_world_size(),
-                             allreduce="bucketed, overlapped with backward" if engine.AR_OVERLAP else "one call after backward")
+            try:
+                rccl = ".".join(str(v) for v in torch.cuda.nccl.version())
+            except Exception:
+                rccl = None
+            dist_info = dict(backend=dist.get_backend(), world_size=dist.get_world_size(), rccl_version=rccl,
+                             allreduce="bucketed, overlapped with backward" if engine.AR_OVERLAP else "one call after backward",
+                             gradient_bytes=int(core.store.numel * 4), collectives_ms_per_step=coll_ms)
         fpc = flop_per_clip(kinds)
-        exec_factor = {"f32": 16.0 / 36.0, "bf16": 16.0 / 36.0, "h2": 3.0}[args.dtype]
+        exec_factor = {"f32": 16.0 / 36.0, "bf16": 1.0, "h2": 3.0}[args.dtype]
         exec_peak = PEAK_F32_MFMA if args.dtype == "f32" else PEAK_BF16_MFMA
         out = dict(metric="clips/sec (%s, L=25, 60x60) fwd+bwd+Adam" % ("3-mod" if len(kinds) == 3 else "%d-mod" % len(kinds)),
                    value=round(value, 2), unit="clips/s",

@@ -296,6 +296,10 @@ int ugn_mm_conv3x3_dgrad_multi(const uint16_t* const* dz, const uint8_t* const* 
                                uint16_t* const* out, void* const* out_meta, const int* n, int njobs, int hw, int cin, int cout,
                                void* stream);
 
+/* Persistent workgroups of the ugn_mm_conv3x3_{fwd,dgrad}_multi launches: 8..256, 0 = default (256 = one per CU).  A process-wide
+ * setting (the one piece of mutable state besides the error message): under data parallelism a value below 256 leaves CUs to RCCL's
+ * channels while the backward pass runs.  Results do not depend on it. */
+int ugn_set_persistent_wgs(int n);
 /* Weight gradient dw HWIO [3,3,cin,cout] (fp32) = sum in (x) dz over images and pixels; in H2 [n][hw][hw][2][cin], dz as in
  * the data gradient (pooled + argmax bytes when dz_idx is given).  ws: >= ugn_mm_conv3x3_wgrad_ws(hw, cin, cout) bytes of
  * scratch for the partial-sum slabs (fixed-order reduction, no atomics: bitwise reproducible). */
@@ -337,6 +341,36 @@ int ugn_h2_lrelu_bwd_multi(const uint16_t* const* g, const void* const* g_meta, 
                            uint16_t* const* out, void* const* out_meta, const size_t* npix, int njobs, int c, void* stream);
 /* HPP backward (nets/mj_uwyhNets_ba.py:468-481) with b4 held as H2 [b][16][16][2][128]: only its sign is used */
 int ugn_hpp_bwd_b4h2_multi(const float* const* a, const float* const* s3, const uint16_t* const* b4, const float* const* dfeat,
+                           float* const* dm3, float* const* dzb4, const int* b, int njobs, void* stream);
+
+/* ---- bf16 path: BASELINE.json configs[4] ("MFMA bf16 conv tiles + fp32 accumulate"), SURVEY 8(d) C5 ----------------------------
+ * bf16 activations, gradients and saved tensors in HBM ([pixel][c] bf16, half the bytes of fp32), one v_mfma_f32_32x32x16_bf16 per
+ * product, fp32 accumulate; weight gradients, master weights and Adam fp32.  Same reference lines as the fp32 / H2 entry points with
+ * the same names (nets/mj_uwyhNets_ba.py:428-481); `GaitCore(conv_precision="bf16")`.
+ * pooled_host[j] (data-gradient jobs): the layer is MaxPool'ed, i.e. its data gradient reads a pooled dz (32-channel chunks). */
+int ugn_bf_pack_multi(const float* const* w_hwio_host, uint16_t* const* wpk_host, const int* cin_host, const int* cout_host,
+                      const int* dgrad_host, const int* pooled_host, int njobs, void* stream);
+int ugn_bf_conv3x3_fwd_multi(const uint16_t* const* in, const uint16_t* const* wpk, uint16_t* const* out, uint8_t* const* out_idx,
+                             const int* n, int njobs, int hw, int cin, int cout, int pool, void* stream);
+int ugn_bf_conv3x3_dgrad_multi(const uint16_t* const* dz, const uint8_t* const* dz_idx, const uint16_t* const* wpk,
+                               const uint16_t* const* act, uint16_t* const* out, const int* n, int njobs, int hw, int cin, int cout,
+                               void* stream);
+size_t ugn_bf_conv3x3_wgrad_ws(int hw, int cin, int cout);
+int ugn_bf_conv3x3_wgrad_multi(const uint16_t* const* in, const uint16_t* const* dz, const uint8_t* const* dz_idx, float* const* dw,
+                               const int* n, int njobs, int hw, int cin, int cout, void* ws, size_t ws_bytes, void* stream);
+int ugn_conv5x5_in_fwd_bf(const float* x, const float* w, uint16_t* a1, uint32_t* a1_sign, int n, int cin, void* stream);
+int ugn_conv5x5_in_wgrad_bf(const float* x, const uint16_t* dz1, const uint32_t* a1_sign, float* dw, int n, int cin, void* ws,
+                            size_t ws_bytes, void* stream);
+int ugn_bf_setmax_fwd_multi(const uint16_t* const* p, const uint16_t* const* addend, uint16_t* const* m, uint16_t* const* sum,
+                            const int* b, int njobs, int l, int npix, int c, void* stream);
+int ugn_bf_setmax_fwd_f32_multi(const uint16_t* const* p, const uint16_t* const* addend, float* const* m, float* const* sum,
+                                const int* b, int njobs, int l, int npix, int c, void* stream);
+int ugn_bf_setmax_bwd_multi(const uint16_t* const* p, const void* const* dm, int dm_is_f32, const uint16_t* const* addend,
+                            uint16_t* const* out, const int* b, int njobs, int l, int npix, int c, int apply_lrelu, void* stream);
+int ugn_bf_lrelu_bwd_multi(const uint16_t* const* g, const uint16_t* const* act, uint16_t* const* out, const size_t* npix, int njobs,
+                           int c, void* stream);
+int ugn_bf_convert_multi(const float* const* x, uint16_t* const* y, const size_t* n, int njobs, void* stream);
+int ugn_hpp_bwd_b4bf_multi(const float* const* a, const float* const* s3, const uint16_t* const* b4, const float* const* dfeat,
                            float* const* dm3, float* const* dzb4, const int* b, int njobs, void* stream);
 
 #ifdef __cplusplus

@@ -74,6 +74,10 @@ def test_rccl_path_with_one_rank(dev):
         d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
         assert d["config"]["distributed"]["backend"] == "nccl" and d["config"]["distributed"]["world_size"] == 1
         assert d["value"] > 0 and d["loss"] == d["loss"]
+        # a SCALE record must be diagnosable: milliseconds per step per collective, payload, library version
+        cm = d["config"]["distributed"]["collectives_ms_per_step"]
+        assert cm and all(v >= 0 for v in cm.values()) and d["config"]["distributed"]["gradient_bytes"] > 30e6
+        assert ("allreduce_exposed_wait_ms" if overlap == "1" else "allreduce_grad_ms") in cm, cm
 
 
 @pytest.mark.gpu

@@ -177,9 +177,10 @@ def test_two_modalities_train_steps_track_oracle(dev, prec):
                 assert np.abs(d_got - d_ref).max() <= 5e-5, (key, np.abs(d_got - d_ref).max())   # |update| ~ 1e-3
 
 
-def test_bf16_operand_mode_against_the_oracle(dev):
-    """BASELINE configs[4] arithmetic (bf16 MFMA operands in the 3x3 forward convolutions and data gradients, fp32
-    accumulate): same graph, same oracle, tolerances of an 8-bit significand -- encoder outputs and signatures 2e-2 of their
+@pytest.mark.parametrize("bfmode", ["bf16", "bf16w"])
+def test_bf16_operand_mode_against_the_oracle(dev, bfmode):
+    """BASELINE configs[4] arithmetic -- "bf16": bf16 tensors in HBM + bf16 MFMA + fp32 accumulate (engine_bf.py); "bf16w": the
+    round 1-2 form (fp32 tensors, Winograd with bf16-rounded operands): same graph, same oracle, tolerances of an 8-bit significand -- encoder outputs and signatures 2e-2 of their
     scale, losses 5e-2 relative, gradients 2e-1 relative L2 (argmax flips of the pooling layers move whole routing decisions
     at this precision) -- and demonstrably NOT the fp32 path.  The element-wise comparison uses the smooth 'avg' fusion;
     under sign_max a near-tie between two modalities flips the selected one (and possibly the sign), so there only the
@@ -188,16 +189,19 @@ def test_bf16_operand_mode_against_the_oracle(dev):
     xs, uses, labels, onehot = make_batch(kinds, b, l, ncls, ids=4, seed=1)
     p64 = oracle_params(kinds, ncls)
     x64, u64 = [x.astype(np.float64) for x in xs], [u.astype(np.float64) for u in uses]
-    core = build(kinds, ncls, 'avg', p64, conv_precision='bf16')
-    ref32 = build(kinds, ncls, 'avg', p64)
+    core = build(kinds, ncls, 'avg', p64, conv_precision=bfmode)
+    ref32 = build(kinds, ncls, 'avg', p64, conv_precision='f32')
     r, g = O.model_loss_and_grads(x64, u64, labels, onehot.astype(np.float64), p64, margin=0.2, loss_weights=(1.0, 0.1), mode='avg')
     core.forward_backward(xs, uses, labels, onehot)
     ref32.forward_backward(xs, uses, labels, onehot)
     torch.cuda.synchronize()
     errs = [relmax(enc.act['out'].cpu().numpy(), ref) for enc, ref in zip(core.encoders, r['outs'])]
-    assert all(1e-4 < e <= 2e-2 for e in errs), errs
     sig_err = np.abs(core.sig.cpu().numpy() - r['signature'])
-    assert sig_err.max() <= 5e-2 and np.median(sig_err) <= 5e-3, (sig_err.max(), np.median(sig_err))
+    print("%s: encoder outputs rel-max %r; signature max %.3e / 99.9th percentile %.3e / median %.3e" %
+          (bfmode, [round(e, 5) for e in errs], sig_err.max(), np.quantile(sig_err, 0.999), np.median(sig_err)))
+    assert all(1e-4 < e <= 2e-2 for e in errs), errs
+    # (the batch-axis normalisation divides by a column norm over 8 clips: a few columns amplify the 8-bit rounding)
+    assert sig_err.max() <= 1e-1 and np.quantile(sig_err, 0.999) <= 3e-2 and np.median(sig_err) <= 5e-3, (sig_err.max(), np.median(sig_err))
     ls = core.losses()
     assert abs(ls['loss'] - float(r['loss'])) <= 5e-2 * abs(float(r['loss'])), (ls['loss'], float(r['loss']))
     got, got32 = core.get_grads_numpy(), ref32.get_grads_numpy()
@@ -207,10 +211,12 @@ def test_bf16_operand_mode_against_the_oracle(dev):
             worst['m%d.%s' % (mi, k)] = rell2(got['branches'][mi][k], ref)
     for k, ref in g['head'].items():
         worst['head.' + k] = rell2(got['head'][k], ref)
+    print("%s: loss %.5f (oracle %.5f), worst gradient rel-L2 %.3e (%s)" % (bfmode, ls['loss'], float(r['loss']), max(worst.values()),
+                                                                             max(worst, key=worst.get)))
     assert max(worst.values()) <= 2e-1, worst
     assert rell2(got['branches'][1]['a3'], got32['branches'][1]['a3'].astype(np.float64)) > 1e-4
     # sign_max: few selections flip, everything stays finite, a training step runs (bf16 repack, Adam on fp32 master weights)
-    core = build(kinds, ncls, 'sign_max', p64, conv_precision='bf16')
+    core = build(kinds, ncls, 'sign_max', p64, conv_precision=bfmode)
     r = O.model_forward(x64, u64, p64, mode='sign_max') if hasattr(O, 'model_forward') else None
     core.train_step(xs, uses, labels, onehot)
     assert np.isfinite(core.losses()['loss'])

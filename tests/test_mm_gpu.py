@@ -217,3 +217,29 @@ def test_mm_wgrad_multi_job(dev):
     one = torch.empty((3, 3, cin, cout), device=dev)
     h2.conv3x3_wgrad_mm_multi([xs[3]], [gs[3]], cout, [one])
     close(one, refs[3], 5e-6, "wgrad single image")
+
+
+def test_mm_results_do_not_depend_on_the_persistent_grid(dev):
+    """ugn_set_persistent_wgs(n < 256) leaves CUs free for RCCL's channels under data parallelism; forward and data gradient are
+    bit-identical whatever the number of persistent workgroups."""
+    from ugaitnet_amd import h2
+    rng = np.random.default_rng(2)
+    hw, cin, cout = 32, 64, 64
+    ns = [11, 3]
+    xs = [h2.encode(T(rng.uniform(-1, 1, (n, hw, hw, cin)).astype(np.float32), dev)) for n in ns]
+    ws = [h2.mm_pack(T(rng.uniform(-0.1, 0.1, (3, 3, cin, cout)).astype(np.float32), dev), False) for _ in ns]
+    res = {}
+    try:
+        for wgs in (0, 200, 24):
+            h2.set_persistent_wgs(wgs)
+            outs = [h2.H2Tensor.empty((n, hw // 2, hw // 2, cout), dev) for n in ns]
+            idxs = [torch.empty((n, hw // 2, hw // 2, cout), dtype=torch.uint8, device=dev) for n in ns]
+            h2.conv3x3_fwd_mm_multi(xs, [w[0] for w in ws], [w[1] for w in ws], cout, True, outs, idxs)
+            res[wgs] = [(o.data.clone(), o.meta.clone(), i.clone()) for o, i in zip(outs, idxs)]
+    finally:
+        h2.set_persistent_wgs(0)
+    for wgs in (200, 24):
+        for a, b in zip(res[0], res[wgs]):
+            assert all(torch.equal(x, y) for x, y in zip(a, b)), wgs
+    with pytest.raises(ValueError):
+        h2.set_persistent_wgs(300)

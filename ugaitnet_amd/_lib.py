@@ -96,6 +96,21 @@ PROTOTYPES = {
     "ugn_h2_setmax_bwd_multi": (_i, [C.POINTER(_p)] * 4 + [_i] + [C.POINTER(_p)] * 4 + [C.POINTER(_i), _i, _i, _i, _i, _i, _p]),
     "ugn_h2_lrelu_bwd_multi": (_i, [C.POINTER(_p)] * 5 + [C.POINTER(_sz), _i, _i, _p]),
     "ugn_hpp_bwd_b4h2_multi": (_i, [C.POINTER(_p)] * 6 + [C.POINTER(_i), _i, _p]),
+    "ugn_set_persistent_wgs": (_i, [_i]),
+    # bf16 tensors in HBM (configs[4])
+    "ugn_bf_pack_multi": (_i, [C.POINTER(_p)] * 2 + [C.POINTER(_i)] * 4 + [_i, _p]),
+    "ugn_bf_conv3x3_fwd_multi": (_i, [C.POINTER(_p)] * 4 + [C.POINTER(_i), _i, _i, _i, _i, _i, _p]),
+    "ugn_bf_conv3x3_dgrad_multi": (_i, [C.POINTER(_p)] * 5 + [C.POINTER(_i), _i, _i, _i, _i, _p]),
+    "ugn_bf_conv3x3_wgrad_ws": (_sz, [_i, _i, _i]),
+    "ugn_bf_conv3x3_wgrad_multi": (_i, [C.POINTER(_p)] * 4 + [C.POINTER(_i), _i, _i, _i, _i, _p, _sz, _p]),
+    "ugn_conv5x5_in_fwd_bf": (_i, [_p, _p, _p, _p, _i, _i, _p]),
+    "ugn_conv5x5_in_wgrad_bf": (_i, [_p, _p, _p, _p, _i, _i, _p, _sz, _p]),
+    "ugn_bf_setmax_fwd_multi": (_i, [C.POINTER(_p)] * 4 + [C.POINTER(_i), _i, _i, _i, _i, _p]),
+    "ugn_bf_setmax_fwd_f32_multi": (_i, [C.POINTER(_p)] * 4 + [C.POINTER(_i), _i, _i, _i, _i, _p]),
+    "ugn_bf_setmax_bwd_multi": (_i, [C.POINTER(_p)] * 2 + [_i] + [C.POINTER(_p)] * 2 + [C.POINTER(_i), _i, _i, _i, _i, _i, _p]),
+    "ugn_bf_lrelu_bwd_multi": (_i, [C.POINTER(_p)] * 3 + [C.POINTER(_sz), _i, _i, _p]),
+    "ugn_bf_convert_multi": (_i, [C.POINTER(_p)] * 2 + [C.POINTER(_sz), _i, _p]),
+    "ugn_hpp_bwd_b4bf_multi": (_i, [C.POINTER(_p)] * 6 + [C.POINTER(_i), _i, _p]),
     "ugn_mm_conv3x3_wgrad_ws": (_sz, [_i, _i, _i]),
     "ugn_mm_conv3x3_wgrad_multi": (_i, [C.POINTER(_p)] * 6 + [C.POINTER(_i), _i, _i, _i, _i, _p, _sz, _p]),
 }

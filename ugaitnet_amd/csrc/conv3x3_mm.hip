@@ -520,6 +520,11 @@ __global__ __launch_bounds__(512, 2) void conv_mm_kernel(const MmJobs jt, const 
   h2_publish_amax_block(jt.job[meta_jb].out_meta, mx, reinterpret_cast<float*>(smem), tid, 8);
 }
 
+// Persistent workgroups of the forward / data-gradient launches (one per CU by default).  Under data parallelism RCCL's channels
+// need CUs of their own while the backward pass still runs: ugn_set_persistent_wgs(n < 256) leaves 256 - n of them free.  Results
+// do not depend on it (an item's arithmetic is the same whichever workgroup runs it).
+int g_persistent_wgs = kGrid;
+
 template <int KC, int NC, int HW, int IN_POOLED, int EPI>
 int launch_mm(const MmJob* jobs, const int* n, int njobs, hipStream_t st) {
   auto kern = conv_mm_kernel<KC, NC, HW, IN_POOLED, EPI>;
@@ -535,7 +540,7 @@ int launch_mm(const MmJob* jobs, const int* n, int njobs, hipStream_t st) {
   if (!zeros) { ugn_set_error("conv_mm: cannot allocate the zero block"); return UGN_EINVAL; }
   MmJobs jt;
   const int nitems = make_mm_table(jt, jobs, n, njobs, (HW / 16) * (HW / 16));
-  const int grid = nitems < kGrid ? nitems : kGrid;
+  const int grid = nitems < g_persistent_wgs ? nitems : g_persistent_wgs;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), LDS, st, jt, zeros);
   UGN_CHECK_LAUNCH("conv_mm");
   return 0;
@@ -612,6 +617,12 @@ const void* ugn_mm::zero_block() {
     z = p;
   }
   return z;
+}
+
+extern "C" int ugn_set_persistent_wgs(int n) {
+  UGN_REQUIRE(n == 0 || (n >= 8 && n <= kGrid), "ugn_set_persistent_wgs: 8..%d workgroups, or 0 for the default (got %d)", kGrid, n);
+  g_persistent_wgs = n == 0 ? kGrid : n;
+  return 0;
 }
 
 extern "C" int ugn_mm_pack_multi(const float* const* w_hwio_host, uint16_t* const* wpk_host, void* const* wmeta_host,

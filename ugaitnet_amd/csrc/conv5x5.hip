@@ -53,7 +53,8 @@ __device__ __forceinline__ void stage_patch(float* sP, const float* __restrict__
 // H2OUT: a1 leaves as an H2 tensor (mm_common.h: f16 halves [pixel][2][32] + block exponent) for the f16-matrix-pipe 3x3
 // kernels.  x_meta = {0, bits(max|x|)} (ugn_absmax_multi); the exponent comes from the bound max|x| * max_co sum_k |w[k][co]|,
 // which every workgroup forms from the filter it has just staged; the stored maximum is gathered per workgroup.
-template <int CIN, bool SIGN, bool H2OUT = false>
+// OFMT: 0 fp32 a1, 1 H2 (above), 2 bf16 (configs[4]: [pixel][32] bf16, no exponent)
+template <int CIN, bool SIGN, int OFMT = 0>
 __global__ __launch_bounds__(256, UGN_C5_WAVES) void conv5x5_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                                         float* __restrict__ a1, uint32_t* __restrict__ sign_out,
                                                                         int ntiles, const H2Meta* __restrict__ x_meta = nullptr,
@@ -67,6 +68,7 @@ __global__ __launch_bounds__(256, UGN_C5_WAVES) void conv5x5_fwd_kernel(const fl
   const int li = lane & 31, lh = lane >> 5;
 
   for (int e = tid; e < 2 * KP * 32; e += 256) sW[e] = e < K * 32 ? w[e] : 0.f;
+  constexpr bool H2OUT = OFMT == 1;
   float h2_factor = 1.f, h2_mx = 0.f;
   if constexpr (H2OUT) {
     __syncthreads();
@@ -164,6 +166,11 @@ __global__ __launch_bounds__(256, UGN_C5_WAVES) void conv5x5_fwd_kernel(const fl
           const unsigned oth = (unsigned)__builtin_amdgcn_update_dpp(0, (int)own, 0xB1, 0xf, 0xf, false);   // quad_perm [1,0,3,2]
           *reinterpret_cast<unsigned*>(hrow + (((r >> 1) & 1) * DOM + 4 * (r >> 2) + (r & 1)) * 128) =
               __builtin_amdgcn_perm(oth, own, (li & 1) ? 0x03020706u : 0x05040100u);
+        } else if constexpr (OFMT == 2) {     // bf16: lanes (li, li ^ 1) pair up, the even lane stores both channels
+          const unsigned own = (unsigned)__builtin_bit_cast(unsigned short, (__bf16)ugn_lrelu(acc[m][r]));
+          const unsigned oth = (unsigned)__builtin_amdgcn_update_dpp(0, (int)own, 0xB1, 0xf, 0xf, false);
+          char* brow = reinterpret_cast<char*>(a1) + (((size_t)img * DOM + ty0 + 2 * mbi) * DOM + tx0 + 2 * lh) * 64 + li * 2;
+          if (!(li & 1)) *reinterpret_cast<unsigned*>(brow + (((r >> 1) & 1) * DOM + 4 * (r >> 2) + (r & 1)) * 64) = own | (oth << 16);
         } else {
           orow[(((r >> 1) & 1) * DOM + 4 * (r >> 2) + (r & 1)) * 32] = ugn_lrelu(acc[m][r]);
         }
@@ -207,7 +214,8 @@ __device__ __forceinline__ void dma4_c5(const void* gsrc, unsigned lds_dst_unifo
 // or in the pad read a zero block) while the current tile is multiplied: the kernel runs at the rate dz1 can be read.
 // H2DZ: dz1 is an H2 tensor ([pixel][2][32] halves: the same 128 bytes per pixel, so the LDS-DMA staging is unchanged); a
 // gradient value is re-assembled from its two halves when it is read, the block exponent is undone by reduce5_kernel.
-template <int CIN, bool SIGN, bool H2DZ = false>
+// DZFMT: 0 fp32 dz1, 1 H2, 2 bf16 ([pixel][32] bf16: 64-byte records, half the gradient tile)
+template <int CIN, bool SIGN, int DZFMT = 0>
 __global__ __launch_bounds__(256) void conv5x5_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dz1,
                                                             float* __restrict__ slab, const float* __restrict__ zeros,
                                                             const uint32_t* __restrict__ a1_sign, int tiles_total) {
@@ -217,7 +225,8 @@ __global__ __launch_bounds__(256) void conv5x5_wgrad_kernel(const float* __restr
   // patch rows of WP pixels (UGN_C5_PITCH)
   constexpr int WP = UGN_C5_PITCH;
   constexpr int PE = P5 * WP * CIN, PPIECES = (PE + 63) / 64, SPF = PPIECES * 64;   // patch dwords, 256-B pieces
-  constexpr int DPW = DS / 4, PPW = (PPIECES + 3) / 4;    // pieces per wave
+  constexpr bool H2DZ = DZFMT == 1, BFDZ = DZFMT == 2;
+  constexpr int DPW = BFDZ ? 4 : DS / 4, PPW = (PPIECES + 3) / 4;    // pieces per wave
   extern __shared__ __attribute__((aligned(16))) float smem5[];
   float* sD0 = smem5;                 // [2][SDF]
   float* sP0 = smem5 + 2 * SDF;       // [2][SPF]
@@ -248,8 +257,13 @@ __global__ __launch_bounds__(256) void conv5x5_wgrad_kernel(const float* __restr
 #pragma unroll
   for (int j = 0; j < DPW; ++j) {
     const int slot = (wave * DPW + j) * 64 + lane;       // 4 waves x DPW pieces = all slots
-    const int p = slot / (DS / 4), c4 = slot - p * (DS / 4);
-    dgeo[j] = c4 < 8 ? ((p >> 4) * DOM + (p & 15)) * 32 + c4 * 4 : -1;
+    if constexpr (BFDZ) {                                // 4 slots of 16 bytes per pixel; dgeo in FLOAT units of the 64-byte records
+      const int p = slot >> 2, c4 = slot & 3;
+      dgeo[j] = ((p >> 4) * DOM + (p & 15)) * 16 + c4 * 4;
+    } else {
+      const int p = slot / (DS / 4), c4 = slot - p * (DS / 4);
+      dgeo[j] = c4 < 8 ? ((p >> 4) * DOM + (p & 15)) * 32 + c4 * 4 : -1;
+    }
   }
 #pragma unroll
   for (int j = 0; j < PPW; ++j) {
@@ -262,7 +276,7 @@ __global__ __launch_bounds__(256) void conv5x5_wgrad_kernel(const float* __restr
   auto issue_dma = [&](int tile, int buf) {
     const int img = tile >> 4, trem = tile & 15;
     const int ty0 = (trem >> 2) * T5, tx0 = (trem & 3) * T5;
-    const float* dzt = dz1 + (((size_t)img * DOM + ty0) * DOM + tx0) * 32;
+    const float* dzt = dz1 + (((size_t)img * DOM + ty0) * DOM + tx0) * (BFDZ ? 16 : 32);
 #pragma unroll
     for (int j = 0; j < DPW; ++j)
       dma16_c5(dgeo[j] >= 0 ? dzt + dgeo[j] : zeros, sd_bytes + (unsigned)buf * SDF * 4u + (unsigned)(wave * DPW + j) * 1024u);
@@ -295,6 +309,8 @@ __global__ __launch_bounds__(256) void conv5x5_wgrad_kernel(const float* __restr
       if constexpr (H2DZ) {
         const uint16_t* rec = reinterpret_cast<const uint16_t*>(sD) + (size_t)(wave * 64 + lh + 2 * kp) * 64;
         b = ugn_mm::h2_half(rec[li]) + ugn_mm::h2_half(rec[32 + li]);
+      } else if constexpr (BFDZ) {
+        b = __uint_as_float((unsigned)reinterpret_cast<const uint16_t*>(sD)[(size_t)(wave * 64 + lh + 2 * kp) * 32 + li] << 16);
       } else {
         b = sD[bbase + 2 * kp * DS];
       }
@@ -374,7 +390,7 @@ extern "C" int ugn_conv5x5_in_fwd_h2(const float* x, const void* x_meta, const f
   hipStream_t st = (hipStream_t)stream;
   const int ntiles = n * 16;
   const int grid = ntiles < UGN_C5_GRID ? ntiles : UGN_C5_GRID;
-#define UGN_C5F(C_, S_) hipLaunchKernelGGL((conv5x5_fwd_kernel<C_, S_, true>), dim3(grid), dim3(256), 0, st, x, w, (float*)a1, a1_sign, \
+#define UGN_C5F(C_, S_) hipLaunchKernelGGL((conv5x5_fwd_kernel<C_, S_, 1>), dim3(grid), dim3(256), 0, st, x, w, (float*)a1, a1_sign, \
                                            ntiles, (const H2Meta*)x_meta, (H2Meta*)a1_meta)
   if (cin == 1) {
     if (a1_sign) UGN_C5F(1, true); else UGN_C5F(1, false);
@@ -394,7 +410,7 @@ extern "C" size_t ugn_conv5x5_in_wgrad_ws(int n, int cin) {
 }
 
 static int conv5x5_wgrad_any(const float* x, const float* dz1, const H2Meta* dz_meta, const uint32_t* a1_sign, float* dw, int n,
-                             int cin, void* ws, size_t ws_bytes, void* stream);
+                             int cin, void* ws, size_t ws_bytes, void* stream, bool bf = false);
 extern "C" int ugn_conv5x5_in_wgrad(const float* x, const float* dz1, const uint32_t* a1_sign, float* dw, int n, int cin,
                                     void* ws, size_t ws_bytes, void* stream) {
   return conv5x5_wgrad_any(x, dz1, nullptr, a1_sign, dw, n, cin, ws, ws_bytes, stream);
@@ -405,8 +421,30 @@ extern "C" int ugn_conv5x5_in_wgrad_h2(const float* x, const uint16_t* dz1, cons
   UGN_REQUIRE(dz1_meta, "ugn_conv5x5_in_wgrad_h2: null meta");
   return conv5x5_wgrad_any(x, reinterpret_cast<const float*>(dz1), (const H2Meta*)dz1_meta, a1_sign, dw, n, cin, ws, ws_bytes, stream);
 }
+/* dz1 as a bf16 tensor [n][64][64][32] (configs[4]) */
+extern "C" int ugn_conv5x5_in_wgrad_bf(const float* x, const uint16_t* dz1, const uint32_t* a1_sign, float* dw, int n, int cin, void* ws,
+                                       size_t ws_bytes, void* stream) {
+  return conv5x5_wgrad_any(x, reinterpret_cast<const float*>(dz1), nullptr, a1_sign, dw, n, cin, ws, ws_bytes, stream, true);
+}
+/* first layer with a1 written as bf16 [n][64][64][32] */
+extern "C" int ugn_conv5x5_in_fwd_bf(const float* x, const float* w, uint16_t* a1, uint32_t* a1_sign, int n, int cin, void* stream) {
+  UGN_REQUIRE(x && w && a1 && n > 0, "ugn_conv5x5_in_fwd_bf: null pointer or n <= 0");
+  UGN_REQUIRE(cin == 1 || cin == 2, "ugn_conv5x5_in_fwd_bf: cin must be 1 or 2 (got %d)", cin);
+  hipStream_t st = (hipStream_t)stream;
+  const int ntiles = n * 16;
+  const int grid = ntiles < UGN_C5_GRID ? ntiles : UGN_C5_GRID;
+#define UGN_C5F(C_, S_) hipLaunchKernelGGL((conv5x5_fwd_kernel<C_, S_, 2>), dim3(grid), dim3(256), 0, st, x, w, (float*)a1, a1_sign, ntiles)
+  if (cin == 1) {
+    if (a1_sign) UGN_C5F(1, true); else UGN_C5F(1, false);
+  } else {
+    if (a1_sign) UGN_C5F(2, true); else UGN_C5F(2, false);
+  }
+#undef UGN_C5F
+  UGN_CHECK_LAUNCH("conv5x5_fwd_bf");
+  return 0;
+}
 static int conv5x5_wgrad_any(const float* x, const float* dz1, const H2Meta* dz_meta, const uint32_t* a1_sign, float* dw, int n,
-                             int cin, void* ws, size_t ws_bytes, void* stream) {
+                             int cin, void* ws, size_t ws_bytes, void* stream, bool bf) {
   UGN_REQUIRE(x && dz1 && dw && ws && n > 0, "ugn_conv5x5_in_wgrad: null pointer or n <= 0");
   UGN_REQUIRE(cin == 1 || cin == 2, "ugn_conv5x5_in_wgrad: cin must be 1 or 2 (got %d)", cin);
   UGN_REQUIRE(ws_bytes >= ugn_conv5x5_in_wgrad_ws(n, cin), "ugn_conv5x5_in_wgrad: workspace too small");
@@ -423,20 +461,25 @@ static int conv5x5_wgrad_any(const float* x, const float* dz1, const H2Meta* dz_
   const int lds = (2 * 256 * UGN_C5_DS + 2 * ((20 * UGN_C5_PITCH * cin + 63) / 64) * 64 + 2 * 256) * 4;
   static bool attr_done[3] = {false, false, false};
   if (!attr_done[cin]) {
-    const void* fns[8] = {(const void*)conv5x5_wgrad_kernel<1, false>, (const void*)conv5x5_wgrad_kernel<1, true>,
-                          (const void*)conv5x5_wgrad_kernel<1, false, true>, (const void*)conv5x5_wgrad_kernel<1, true, true>,
-                          (const void*)conv5x5_wgrad_kernel<2, false>, (const void*)conv5x5_wgrad_kernel<2, true>,
-                          (const void*)conv5x5_wgrad_kernel<2, false, true>, (const void*)conv5x5_wgrad_kernel<2, true, true>};
-    for (int v = 0; v < 4; ++v) {
-      hipError_t e = hipFuncSetAttribute(fns[(cin - 1) * 4 + v], hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    const void* fns[12] = {(const void*)conv5x5_wgrad_kernel<1, false>, (const void*)conv5x5_wgrad_kernel<1, true>,
+                           (const void*)conv5x5_wgrad_kernel<1, false, 1>, (const void*)conv5x5_wgrad_kernel<1, true, 1>,
+                           (const void*)conv5x5_wgrad_kernel<1, false, 2>, (const void*)conv5x5_wgrad_kernel<1, true, 2>,
+                           (const void*)conv5x5_wgrad_kernel<2, false>, (const void*)conv5x5_wgrad_kernel<2, true>,
+                           (const void*)conv5x5_wgrad_kernel<2, false, 1>, (const void*)conv5x5_wgrad_kernel<2, true, 1>,
+                           (const void*)conv5x5_wgrad_kernel<2, false, 2>, (const void*)conv5x5_wgrad_kernel<2, true, 2>};
+    for (int v = 0; v < 6; ++v) {
+      hipError_t e = hipFuncSetAttribute(fns[(cin - 1) * 6 + v], hipFuncAttributeMaxDynamicSharedMemorySize, lds);
       UGN_REQUIRE(e == hipSuccess, "ugn_conv5x5_in_wgrad: hipFuncSetAttribute: %s", hipGetErrorString(e));
     }
     attr_done[cin] = true;
   }
 #define UGN_C5W(C_, S_)                                                                                                      \
   do {                                                                                                                        \
-    if (dz_meta)                                                                                                              \
-      hipLaunchKernelGGL((conv5x5_wgrad_kernel<C_, S_, true>), dim3(groups), dim3(256), lds, st, x, dz1, (float*)ws,          \
+    if (bf)                                                                                                                   \
+      hipLaunchKernelGGL((conv5x5_wgrad_kernel<C_, S_, 2>), dim3(groups), dim3(256), lds, st, x, dz1, (float*)ws,             \
+                         (const float*)zeros, a1_sign, tiles);                                                                \
+    else if (dz_meta)                                                                                                         \
+      hipLaunchKernelGGL((conv5x5_wgrad_kernel<C_, S_, 1>), dim3(groups), dim3(256), lds, st, x, dz1, (float*)ws,             \
                          (const float*)zeros, a1_sign, tiles);                                                                \
     else                                                                                                                      \
       hipLaunchKernelGGL((conv5x5_wgrad_kernel<C_, S_>), dim3(groups), dim3(256), lds, st, x, dz1, (float*)ws,                \

@@ -84,9 +84,12 @@ __device__ __forceinline__ void h2_publish_amax_block(H2Meta* m, float v, float*
 // global -> LDS, 16 B per lane (LDS address = M0 + lane * 16); see wino_common.h dma16 for why this is inline asm
 __device__ __forceinline__ void dma16(const void* gsrc, unsigned lds_dst_uniform) {
   unsigned keep;
+  // (the destination is wave-uniform by construction; readfirstlane makes that provable where the compiler's divergence analysis
+  //  gives up -- it folds away when the value already lives in an SGPR)
+  const unsigned dst = __builtin_amdgcn_readfirstlane(lds_dst_uniform);
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                : "=&s"(keep)
-               : "v"(gsrc), "s"(lds_dst_uniform)
+               : "v"(gsrc), "s"(dst)
                : "memory");
 }
 

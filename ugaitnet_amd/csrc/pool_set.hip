@@ -206,7 +206,8 @@ __global__ void hpp_fwd_kernel(const HppJobs jt) {
 // owns the 16 positions of one finest strip for BOTH tensors (a and s3), so dm3 = dL/da + dL/ds3 needs no exchange.
 // Level l (0..4) has 2^l strips of 256 / 2^l positions; strip maxima and tie counts of the coarser levels are combined
 // through LDS.  mean: g / n ; max: g / (#maxima) to every maximum (TF reduce_max gradient).
-template <bool B4H2>
+// B4FMT: 0 fp32 b4, 1 H2 b4 (sign of its H half), 2 bf16 b4
+template <int B4FMT>
 __global__ __launch_bounds__(512) void hpp_bwd_kernel(const HppJobs jt) {
   __shared__ float sMx[2][16][32];
   __shared__ float sCnt[2][5][16][32];
@@ -271,7 +272,10 @@ __global__ __launch_bounds__(512) void hpp_bwd_kernel(const HppJobs jt) {
   for (int q = 0; q < 16; ++q) {
     const size_t o = base + (size_t)q * 128;
     dm3[o] = g[0][q] + g[1][q];
-    if constexpr (B4H2) {   // b4 is an H2 tensor [b][256][2][128] (ugaitnet_amd/csrc/mm_common.h): the sign of its H half is b4's sign
+    if constexpr (B4FMT == 2) {
+      const short hb = reinterpret_cast<const short*>(b4)[((size_t)b * 256 + st * 16 + q) * 128 + c];
+      dzb4[o] = g[1][q] * (hb > 0 ? 1.f : UGN_LRELU_ALPHA);
+    } else if constexpr (B4FMT == 1) {   // b4 is an H2 tensor [b][256][2][128] (ugaitnet_amd/csrc/mm_common.h): the sign of its H half is b4's sign
       const short hb = reinterpret_cast<const short*>(b4)[(((size_t)b * 256 + st * 16 + q) * 2) * 128 + c];
       dzb4[o] = g[1][q] * (hb > 0 ? 1.f : UGN_LRELU_ALPHA);
     } else {
@@ -409,15 +413,27 @@ extern "C" int ugn_hpp_bwd_multi(const float* const* a, const float* const* s3, 
     jt.b[j] = b[j];
     if (b[j] > bmax) bmax = b[j];
   }
-  hipLaunchKernelGGL(hpp_bwd_kernel<false>, dim3(bmax * 4, njobs), dim3(512), 0, (hipStream_t)stream, jt);
+  hipLaunchKernelGGL(hpp_bwd_kernel<0>, dim3(bmax * 4, njobs), dim3(512), 0, (hipStream_t)stream, jt);
   UGN_CHECK_LAUNCH("hpp_bwd");
   return 0;
 }
 
 /* the same with b4 held as an H2 tensor [b][16][16][2][128] (only its sign is used); dm3 / dzb4 stay fp32 */
+static int hpp_bwd_b4fmt(const float* const* a, const float* const* s3, const uint16_t* const* b4, const float* const* dfeat,
+                         float* const* dm3, float* const* dzb4, const int* b, int njobs, void* stream, bool bf);
 extern "C" int ugn_hpp_bwd_b4h2_multi(const float* const* a, const float* const* s3, const uint16_t* const* b4,
                                       const float* const* dfeat, float* const* dm3, float* const* dzb4, const int* b, int njobs,
                                       void* stream) {
+  return hpp_bwd_b4fmt(a, s3, b4, dfeat, dm3, dzb4, b, njobs, stream, false);
+}
+/* the same with b4 as a bf16 tensor [b][16][16][128] */
+extern "C" int ugn_hpp_bwd_b4bf_multi(const float* const* a, const float* const* s3, const uint16_t* const* b4,
+                                      const float* const* dfeat, float* const* dm3, float* const* dzb4, const int* b, int njobs,
+                                      void* stream) {
+  return hpp_bwd_b4fmt(a, s3, b4, dfeat, dm3, dzb4, b, njobs, stream, true);
+}
+static int hpp_bwd_b4fmt(const float* const* a, const float* const* s3, const uint16_t* const* b4, const float* const* dfeat,
+                         float* const* dm3, float* const* dzb4, const int* b, int njobs, void* stream, bool bf) {
   UGN_REQUIRE(a && s3 && b4 && dfeat && dm3 && dzb4 && b && njobs >= 1 && njobs <= kPoolJobs,
               "ugn_hpp_bwd_b4h2_multi: bad arguments (1..%d jobs)", kPoolJobs);
   HppJobs jt = {};
@@ -428,7 +444,8 @@ extern "C" int ugn_hpp_bwd_b4h2_multi(const float* const* a, const float* const*
     jt.dm3[j] = dm3[j]; jt.dzb4[j] = dzb4[j]; jt.b[j] = b[j];
     if (b[j] > bmax) bmax = b[j];
   }
-  hipLaunchKernelGGL(hpp_bwd_kernel<true>, dim3(bmax * 4, njobs), dim3(512), 0, (hipStream_t)stream, jt);
+  if (bf) hipLaunchKernelGGL(hpp_bwd_kernel<2>, dim3(bmax * 4, njobs), dim3(512), 0, (hipStream_t)stream, jt);
+  else hipLaunchKernelGGL(hpp_bwd_kernel<1>, dim3(bmax * 4, njobs), dim3(512), 0, (hipStream_t)stream, jt);
   UGN_CHECK_LAUNCH("hpp_bwd_b4h2");
   return 0;
 }

@@ -1,0 +1,344 @@
+// Weight gradient of the 3x3 layers on bf16 tensors (v_mfma_f32_32x32x16_bf16, fp32 accumulate, fp32 result): the configs[4]
+// counterpart of wgrad3x3_mm.hip -- read its header; same structure (K = pixels, both operands by ds_read_b64_tr_b16 from planar
+// 64-byte-row tiles, strips of 8 x 16 pixels, K-split waves added through LDS, slabs, fixed-order finish), with ONE plane per
+// tile and ONE MFMA per tap.  Replaces Conv2DBackpropFilter (+ MaxPoolGrad) of reference nets/mj_uwyhNets_ba.py:431-462.
+#include "mm_common.h"
+
+using namespace ugn_mm;
+
+namespace {
+
+typedef short s4 __attribute__((ext_vector_type(4)));
+typedef short s8 __attribute__((ext_vector_type(8)));
+#define LDS_PTR(T) __attribute__((address_space(3))) T*
+
+constexpr int kWgMaxJobs = 6;
+constexpr int IN_PIX = 10 * 18;
+constexpr int IN_PIECES = 12;                  // 180 pixels x 4 slots = 720 slots -> 11.25 pieces
+constexpr int IN_BYTES = IN_PIECES * 1024;
+
+struct WgJob {
+  const uint16_t* in;        // bf16 [n][hw][hw][ci]
+  const uint16_t* dz;        // bf16 [n][hw][hw][co]   (pooled: [n][hw/2][hw/2][co])
+  const uint8_t* dz_idx;     // pooled: argmax bytes
+  float* slab;               // [combo][ng][9][32][COW]
+  int g0, ng;                // the groups (of every combination) that touch this job
+};
+struct WgJobs {
+  WgJob job[kWgMaxJobs];
+  int start[kWgMaxJobs + 1]; // first strip of job j; [njobs..] = total
+  int ngroups;               // groups per block combination (a multiple of 8)
+};
+
+template <int CO>
+struct WGeo {
+  static constexpr int COW = CO >= 64 ? 64 : 32;     // output channels of a workgroup
+  static constexpr int PW = COW / 32;                // 32x32 block pairs
+  static constexpr int KS = 8 / PW;                  // waves sharing a pair (K split)
+  static constexpr int RPW = 8 / KS;                 // pixel rows of a strip per wave
+  static constexpr int DZ_BYTES = PW * 8192;         // [block][128 pixels][64 B]
+  static constexpr int SET = IN_BYTES + DZ_BYTES;
+  static constexpr int STG_SLOTS_PP = 3 * COW / 16;  // staging slots per pooled pixel: values (COW/8), argmax (COW/16)
+  static constexpr int STG_PIECES = 32 * STG_SLOTS_PP / 64;
+  static constexpr int STG_BYTES = STG_PIECES * 1024;
+};
+// (+ 32 KB of scratch for the K-split combine: a bf16 buffer set -- 20 / 28 KB -- is smaller than the 8 waves x 4 KB it needs)
+template <int CO, int POOLED>
+constexpr int wg_scr_off() { return 2 * WGeo<CO>::SET + (POOLED ? WGeo<CO>::STG_BYTES : 0); }
+template <int CO, int POOLED>
+constexpr int wg_lds_bytes() { return wg_scr_off<CO, POOLED>() + 32768; }
+
+__device__ __forceinline__ h8 tr_pair(const LDS_PTR(char) base, int off0, int off1) {
+  const s4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s4))(base + off0));
+  const s4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s4))(base + off1));
+  const s8 v = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_bit_cast(h8, v);
+}
+typedef __bf16 b8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ f32x16 mfma_b8(h8 a, h8 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(b8, a), __builtin_bit_cast(b8, b), c, 0, 0, 0);
+}
+
+template <int CI, int CO, int HW, int POOLED>
+__global__ __launch_bounds__(512, 2) void wgrad_bf_kernel(const WgJobs jt, const void* __restrict__ zeros) {
+  using G = WGeo<CO>;
+  constexpr int COW = G::COW, PW = G::PW, KS = G::KS, RPW = G::RPW, SET = G::SET;
+  constexpr int NCOC = CO / COW, NCOMBO = (CI / 32) * NCOC;
+  constexpr int SPX = HW / 16, SPI = (HW / 8) * SPX;        // strips per image row / per image
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const LDS_PTR(char) lds = (LDS_PTR(char))smem;
+  const unsigned sbase = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)lds);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // workgroup -> (combination, group): all combinations of a group sit on ONE XCD (blockIdx % 8), so the strip both read
+  // comes from HBM once per XCD and from that XCD's L2 afterwards
+  const int bid = blockIdx.x, xcd = bid & 7, rest = bid >> 3;
+  const int combo = rest % NCOMBO, grp = (rest / NCOMBO) * 8 + xcd;
+  const int cic = combo / NCOC, coc = combo % NCOC;
+  const int total = jt.start[kWgMaxJobs];
+  const int s0 = (int)((long long)grp * total / jt.ngroups), s1 = (int)((long long)(grp + 1) * total / jt.ngroups);
+  if (s0 >= s1) return;
+  const int pair = wave % PW, ks = wave / PW;
+  // transposed-read role of the lane: 16-lane group (channel half gh, k half h), row q of the 4-pixel block, columns 4p..
+  const int h = lane >> 5, gh = (lane >> 4) & 1, q = (lane >> 2) & 3, p = lane & 3;
+  const int lane_off = (8 * h + q) * 64 + (16 * gh + 4 * p) * 2;
+
+  auto job_of = [&](int s) {
+    int jb = 0;
+#pragma unroll
+    for (int j = 1; j < kWgMaxJobs; ++j) jb += s >= jt.start[j] ? 1 : 0;
+    return jb;
+  };
+  // tiles of strip s -> buffer set b (pooled: the gradient goes to the staging tile instead)
+  auto stage = [&](int s, int b) {
+    const int jb = job_of(s), ls = s - jt.start[jb];
+    const int img = ls / SPI, r = ls % SPI;
+    const int sy0 = (r / SPX) * 8, sx0 = (r % SPX) * 16;
+    const char* in_img = reinterpret_cast<const char*>(jt.job[jb].in) + (size_t)img * HW * HW * CI * 2 + cic * 64;
+    constexpr int NPIECE = IN_PIECES + (POOLED ? G::STG_PIECES : PW * 8);
+#pragma unroll
+    for (int j = 0; j < (NPIECE + 7) / 8; ++j) {
+      const int pi = wave + 8 * j;
+      if (pi >= NPIECE) break;
+      if (pi < IN_PIECES) {
+        const int sg = pi * 64 + lane;                         // slot: [pixel 0..179][quarter]
+        const int pix = sg >> 2, c4 = sg & 3;
+        const int row = (pix * 3641) >> 16, px = pix - row * 18;         // pix / 18 for pix < 400
+        const int gy = sy0 - 1 + row, gx = sx0 - 1 + px;
+        const bool ok = sg < 720 && (unsigned)gy < (unsigned)HW && (unsigned)gx < (unsigned)HW;
+        const void* src = ok ? (const void*)(in_img + (unsigned)(gy * HW + gx) * (unsigned)(CI * 2) + (unsigned)(c4 * 16)) : zeros;
+        dma16(src, sbase + (unsigned)(b * SET) + (unsigned)pi * 1024u);
+      } else if constexpr (!POOLED) {
+        const int pd = pi - IN_PIECES;
+        const int sg = pd * 64 + lane;                         // slot: [block][pixel 0..127][quarter]
+        const int nb = sg >> 9, rem2 = sg & 511;
+        const int pix = rem2 >> 2, c4 = rem2 & 3;
+        const int gy = sy0 + (pix >> 4), gx = sx0 + (pix & 15);
+        const char* dz_img = reinterpret_cast<const char*>(jt.job[jb].dz) + (size_t)img * HW * HW * CO * 2;
+        const void* src = dz_img + (unsigned)(gy * HW + gx) * (unsigned)(CO * 2) + (unsigned)((coc * COW + nb * 32) * 2 + c4 * 16);
+        dma16(src, sbase + (unsigned)(b * SET + IN_BYTES) + (unsigned)pd * 1024u);
+      } else {
+        constexpr int HP = HW / 2, SL = G::STG_SLOTS_PP;
+        const int pd = pi - IN_PIECES;
+        const int sg = pd * 64 + lane;                         // slot: [pooled pixel 0..31][values COW/8 | argmax COW/16]
+        const int pp = sg / SL, part = sg - pp * SL;
+        const int py = sy0 / 2 + (pp >> 3), pxx = sx0 / 2 + (pp & 7);
+        const unsigned o = (unsigned)(py * HP + pxx);
+        const char* dz_img = reinterpret_cast<const char*>(jt.job[jb].dz) + (size_t)img * HP * HP * CO * 2;
+        const char* ix_img = reinterpret_cast<const char*>(jt.job[jb].dz_idx) + (size_t)img * HP * HP * CO;
+        const void* src;
+        if (part < COW / 8) src = dz_img + o * (unsigned)(CO * 2) + (unsigned)(coc * COW * 2 + part * 16);
+        else src = ix_img + o * (unsigned)CO + (unsigned)(coc * COW + (part - COW / 8) * 16);
+        dma16(src, sbase + (unsigned)(2 * SET) + (unsigned)pd * 1024u);
+      }
+    }
+  };
+  // MaxPool backward of the staged strip: pooled pixel pp (4 x 8), channel group cg (8 channels) -> 4 positions of the tile
+  auto scatter = [&](int b) {
+    constexpr int NCG = COW / 8;
+    if (tid >= 32 * NCG) return;
+    const int pp = tid / NCG, cg = tid - pp * NCG;
+    const char* rec = smem + 2 * SET + pp * (3 * COW);
+    const uint4 hi = *reinterpret_cast<const uint4*>(rec + cg * 16);
+    const uint2 ix = *reinterpret_cast<const uint2*>(rec + COW * 2 + cg * 8);
+    const unsigned hv[4] = {hi.x, hi.y, hi.z, hi.w};
+    const int nb = cg >> 2, c4 = cg & 3;
+#pragma unroll
+    for (int pos = 0; pos < 4; ++pos) {
+      unsigned m[4];
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        const unsigned w = d < 2 ? ix.x : ix.y;
+        const unsigned b0 = (w >> (16 * (d & 1))) & 0xffu, b1 = (w >> (16 * (d & 1) + 8)) & 0xffu;
+        m[d] = (b0 == (unsigned)pos ? 0x0000ffffu : 0u) | (b1 == (unsigned)pos ? 0xffff0000u : 0u);
+      }
+      const int y = 2 * (pp >> 3) + (pos >> 1), x = 2 * (pp & 7) + (pos & 1);
+      char* dst = smem + b * SET + IN_BYTES + (nb * 128 + y * 16 + x) * 64 + c4 * 16;
+      *reinterpret_cast<uint4*>(dst) = make_uint4(hv[0] & m[0], hv[1] & m[1], hv[2] & m[2], hv[3] & m[3]);
+    }
+  };
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+
+  stage(s0, 0);
+  int b = 0;
+  int jb = job_of(s0);
+  for (int s = s0; s < s1; ++s) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                   // strip s has landed; nobody reads the other buffer set any more
+    if constexpr (POOLED) {
+      scatter(b);
+      __syncthreads();
+    }
+    if (s + 1 < s1) stage(s + 1, b ^ 1);
+    const LDS_PTR(char) in_b = lds + b * SET + ks * RPW * (18 * 64) + lane_off;
+    const LDS_PTR(char) dz_b = lds + b * SET + IN_BYTES + pair * 8192 + ks * RPW * (16 * 64) + lane_off;
+#pragma unroll
+    for (int rr = 0; rr < RPW; ++rr) {
+      // k-step = pixel row rr of the wave: lane half h covers pixels 8h .. 8h+7 (two 4-pixel blocks)
+      const h8 bh = tr_pair(dz_b, (rr * 16) * 64, (rr * 16 + 4) * 64);
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const int dy = t / 3, dx = t % 3;
+        const int o = ((rr + dy) * 18 + dx) * 64;
+        const h8 ah = tr_pair(in_b, o, o + 4 * 64);
+        acc[t] = mfma_b8(ah, bh, acc[t]);
+      }
+    }
+    const int jn = s + 1 < s1 ? job_of(s + 1) : -1;
+    if (jn != jb) {
+      // ---- job (or share) finished: add the K-split waves of a pair through LDS in a fixed order, write the slab.  The
+      // scratch is the buffer set just multiplied (the next strip streams into the other one).
+      float* slab = jt.job[jb].slab + ((size_t)combo * jt.job[jb].ng + (grp - jt.job[jb].g0)) * (9 * 32 * COW);
+      float* scr = reinterpret_cast<float*>(smem + wg_scr_off<CO, POOLED>());
+#pragma unroll 1
+      for (int t = 0; t < 9; ++t) {
+        __syncthreads();
+        f32x16 a = acc[0];
+#pragma unroll
+        for (int u = 1; u < 9; ++u) if (t == u) a = acc[u];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) scr[wave * 1024 + i * 64 + lane] = a[i];
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 2 * PW; ++k) {
+          const int e = tid + 512 * k, pr = e >> 10, idx = e & 1023;
+          float sum = 0.f;
+#pragma unroll
+          for (int w = 0; w < KS; ++w) sum += scr[(w * PW + pr) * 1024 + idx];
+          const int reg = idx >> 6, ln = idx & 63;
+          const int ci = (reg & 3) + 8 * (reg >> 2) + 4 * (ln >> 5), co = pr * 32 + (ln & 31);
+          slab[(t * 32 + ci) * COW + co] = sum;
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+      jb = jn;
+    }
+    b ^= 1;
+  }
+}
+
+struct WgFinish {
+  const float* slab[kWgMaxJobs];
+  float* dw[kWgMaxJobs];
+  int ng[kWgMaxJobs];
+};
+// dW[tap][ci][co] (HWIO) = 2^-(e_in + e_dz) * sum over the job's groups, in order.  One thread per element; blockIdx.y = job.
+__global__ __launch_bounds__(256) void wgrad_bf_finish(const WgFinish ft, int CI, int CO, int COW) {
+  const int j = blockIdx.y;
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= 9 * CI * CO) return;
+  const int co = e % CO, ci = (e / CO) % CI, tap = e / (CO * CI);
+  const int ncoc = CO / COW, combo = (ci >> 5) * ncoc + co / COW;
+  const int ng = ft.ng[j];
+  const float* sl = ft.slab[j] + (size_t)combo * ng * (9 * 32 * COW) + (tap * 32 + (ci & 31)) * COW + (co % COW);
+  float sum = 0.f;
+  for (int g = 0; g < ng; ++g) sum += sl[(size_t)g * (9 * 32 * COW)];
+  ft.dw[j][e] = sum;
+}
+
+template <int CI, int CO>
+constexpr int wg_ngroups() { return 256 / ((CI / 32) * (CO / WGeo<CO>::COW)); }
+
+template <int CI, int CO, int HW, int POOLED>
+int launch_wgrad(const uint16_t* const* in, const uint16_t* const* dz, const uint8_t* const* dz_idx, float* const* dw, const int* n,
+                 int njobs, float* ws, size_t ws_floats, hipStream_t st) {
+  using G = WGeo<CO>;
+  constexpr int NCOMBO = (CI / 32) * (CO / G::COW), NG = wg_ngroups<CI, CO>();
+  constexpr int SPI = (HW / 8) * (HW / 16);
+  constexpr int LDS = wg_lds_bytes<CO, POOLED>();
+  static_assert(LDS <= 163840 && NG % 8 == 0, "geometry");
+  auto kern = wgrad_bf_kernel<CI, CO, HW, POOLED>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    if (e != hipSuccess) { ugn_set_error("wgrad_bf: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
+    attr_done = true;
+  }
+  const void* zeros = zero_block();
+  if (!zeros) { ugn_set_error("wgrad_bf: cannot allocate the zero block"); return UGN_EINVAL; }
+  WgJobs jt = {};
+  WgFinish ft = {};
+  int total = 0;
+  for (int j = 0; j < kWgMaxJobs; ++j) {
+    jt.start[j] = total;
+    if (j < njobs) total += n[j] * SPI;
+  }
+  jt.start[kWgMaxJobs] = total;
+  jt.ngroups = NG;
+  const size_t slab_floats = (size_t)9 * 32 * G::COW;
+  size_t used = 0;
+  for (int j = 0; j < kWgMaxJobs; ++j) {
+    const int jj = j < njobs ? j : njobs - 1;
+    jt.job[j].in = in[jj]; jt.job[j].dz = dz[jj]; jt.job[j].dz_idx = POOLED ? dz_idx[jj] : nullptr;
+    if (j >= njobs) { jt.job[j].slab = jt.job[jj].slab; jt.job[j].g0 = jt.job[jj].g0; jt.job[j].ng = jt.job[jj].ng; continue; }
+    // groups whose share [g*T/NG, (g+1)*T/NG) meets the job's strips [a, b)
+    const long long a = jt.start[j], bnd = (long long)jt.start[j] + (long long)n[j] * SPI;
+    int g0 = (int)(a * NG / total);
+    while ((long long)(g0 + 1) * total / NG <= a) ++g0;            // first group whose share ends after a
+    while (g0 > 0 && (long long)g0 * total / NG > a) --g0;
+    int g1 = g0;
+    while (g1 + 1 < NG && (long long)(g1 + 1) * total / NG < bnd) ++g1;
+    jt.job[j].g0 = g0; jt.job[j].ng = g1 - g0 + 1;
+    jt.job[j].slab = ws + used;
+    used += (size_t)NCOMBO * jt.job[j].ng * slab_floats;
+    ft.slab[j] = jt.job[j].slab; ft.dw[j] = dw[j]; ft.ng[j] = jt.job[j].ng;
+  }
+  if (used > ws_floats) { ugn_set_error("wgrad_bf: workspace too small (%zu floats needed, %zu given)", used, ws_floats); return UGN_EINVAL; }
+  // a group with an EMPTY share writes nothing, but may lie between two groups of a job's slab list: such a slab must add 0
+  // (only possible when there are fewer strips than groups)
+  if (total < NG) {
+    hipError_t me = hipMemsetAsync(ws, 0, used * sizeof(float), st);
+    if (me != hipSuccess) { ugn_set_error("wgrad_bf: memset: %s", hipGetErrorString(me)); return (int)me; }
+  }
+  hipLaunchKernelGGL(kern, dim3(NG * NCOMBO), dim3(512), LDS, st, jt, zeros);
+  UGN_CHECK_LAUNCH("wgrad_bf");
+  hipLaunchKernelGGL(wgrad_bf_finish, dim3((9 * CI * CO + 255) / 256, njobs), dim3(256), 0, st, ft, CI, CO, G::COW);
+  UGN_CHECK_LAUNCH("wgrad_bf finish");
+  return 0;
+}
+
+template <int CI, int CO>
+size_t ws_floats_for(int njobs) {
+  using G = WGeo<CO>;
+  constexpr int NCOMBO = (CI / 32) * (CO / G::COW), NG = wg_ngroups<CI, CO>();
+  return (size_t)NCOMBO * (NG + njobs) * 9 * 32 * G::COW;
+}
+
+}  // namespace
+
+extern "C" size_t ugn_bf_conv3x3_wgrad_ws(int hw, int cin, int cout) {
+#define WS(CI_, CO_, HW_) if (cin == CI_ && cout == CO_ && hw == HW_) return ws_floats_for<CI_, CO_>(kWgMaxJobs) * sizeof(float);
+  WS(32, 32, 64) WS(32, 64, 32) WS(64, 64, 32) WS(64, 128, 16) WS(128, 128, 16)
+#undef WS
+  return 0;
+}
+
+extern "C" int ugn_bf_conv3x3_wgrad_multi(const uint16_t* const* in, const uint16_t* const* dz, const uint8_t* const* dz_idx,
+                                          float* const* dw, const int* n, int njobs, int hw, int cin, int cout, void* ws,
+                                          size_t ws_bytes, void* stream) {
+  UGN_REQUIRE(in && dz && dw && n && ws, "ugn_bf_conv3x3_wgrad_multi: null array");
+  UGN_REQUIRE(njobs >= 1 && njobs <= kWgMaxJobs, "ugn_bf_conv3x3_wgrad_multi: njobs must be 1..%d (got %d)", kWgMaxJobs, njobs);
+  const bool pooled = dz_idx != nullptr && dz_idx[0] != nullptr;
+  for (int j = 0; j < njobs; ++j) {
+    UGN_REQUIRE(in[j] && dz[j] && dw[j] && n[j] > 0, "ugn_bf_conv3x3_wgrad_multi: null pointer or n <= 0 in job %d", j);
+    UGN_REQUIRE(pooled == (dz_idx != nullptr && dz_idx[j] != nullptr), "ugn_bf_conv3x3_wgrad_multi: dz_idx for all jobs or none");
+  }
+  hipStream_t st = (hipStream_t)stream;
+  float* wsf = (float*)ws;
+  const size_t wfl = ws_bytes / sizeof(float);
+#define WG(CI_, CO_, HW_, P_)                                        \
+  if (cin == CI_ && cout == CO_ && hw == HW_ && pooled == (P_ != 0)) \
+    return launch_wgrad<CI_, CO_, HW_, P_>(in, dz, dz_idx, dw, n, njobs, wsf, wfl, st);
+  WG(32, 32, 64, 1) WG(32, 64, 32, 0) WG(64, 64, 32, 1) WG(64, 128, 16, 0) WG(128, 128, 16, 0)
+#undef WG
+  ugn_set_error("ugn_bf_conv3x3_wgrad_multi: unsupported shape cin=%d cout=%d hw=%d pooled=%d", cin, cout, hw, (int)pooled);
+  return UGN_EINVAL;
+}

@@ -22,6 +22,32 @@ import os
 import numpy as np
 
 
+# bench.py sets TIMING = {} when ranks > 1 (or --force-dist): every collective of the path is then bracketed by an event pair on
+# the stream it is issued on, and the JSON line reports milliseconds per step per collective kind.
+TIMING = None
+
+
+def _timed(name, fn):
+    if TIMING is None:
+        return fn()
+    import torch
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    r = fn()
+    e1.record()
+    TIMING.setdefault(name, []).append((e0, e1))
+    return r
+
+
+def timing_summary(steps):
+    """{collective: ms per step} from the recorded event pairs (synchronises)."""
+    import torch
+    if not TIMING:
+        return {}
+    torch.cuda.synchronize()
+    return {k: round(sum(a.elapsed_time(b) for a, b in v) / max(1, steps), 4) for k, v in TIMING.items()}
+
+
 def env_rank_world():
     return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
 
@@ -67,7 +93,7 @@ def allreduce_sum_(flat, group=None, force=False):
     world = dist.get_world_size(group)
     if world == 1 and not force:
         return 1.0
-    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    _timed("allreduce_grad_ms", lambda: dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group))
     return 1.0 / world
 
 
@@ -88,7 +114,7 @@ def gather_batch_axis(t, axis, group=None, check=True, force=False):
         if any(not torch.equal(s, shape) for s in shapes):
             raise ValueError("global-batch mode needs equal per-replica shapes, got %r" % ([s.tolist() for s in shapes],))
     parts = [torch.empty_like(t) for _ in range(world)]
-    dist.all_gather(parts, t.contiguous(), group=group)
+    _timed("allgather_ms", lambda: dist.all_gather(parts, t.contiguous(), group=group))
     return torch.cat(parts, dim=axis)
 
 

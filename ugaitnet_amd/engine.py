@@ -19,6 +19,7 @@ import contextlib
 import os
 
 from . import _lib, dp, h2, ops
+from .engine_bf import BFState, backward_bf, forward_bf
 from .engine_h2 import H2State, backward_h2, forward_h2
 
 F32 = torch.float32
@@ -37,7 +38,10 @@ NBINS, FEAT, HIDDEN = 62, 128, 256
 # Arithmetic of the 3x3 layers when a model does not name one (GaitCore(conv_precision=...), UGN_CONV_PRECISION):
 #   "h2"  (default) activations / gradients between the 3x3 layers as split-fp16 halves + block exponent (22 significant bits),
 #         3x3 layers as direct convolutions on the f16 matrix pipe: holds every fp32 parity bar of tests/ and is 1.4x faster
-#   "f32" Winograd F(2x2,3x3) on the fp32 MFMA;  "bf16" the same with bf16-rounded MFMA operands
+#   "f32" Winograd F(2x2,3x3) on the fp32 MFMA
+#   "bf16" BASELINE configs[4]: bf16 activations / gradients / saved tensors in HBM, direct convolutions on the bf16 matrix pipe,
+#         fp32 accumulate, fp32 master weights and Adam (engine_bf.py)
+#   "bf16w" (round 1-2) fp32 tensors, Winograd with bf16-rounded MFMA operands
 DEFAULT_PRECISION = os.environ.get("UGN_CONV_PRECISION", "h2")
 
 # Winograd F(2x2,3x3) kernels for the 3x3 forward convolutions and data gradients (UGN_WINO=0 selects the direct
@@ -568,13 +572,22 @@ class GaitCore:
         # between the 3x3 layers held as split-fp16 halves + block exponent, 3x3 layers on the f16 matrix pipe at fp32-class
         # accuracy (engine_h2.py, csrc/mm_common.h)
         conv_precision = DEFAULT_PRECISION if conv_precision is None else conv_precision
-        if conv_precision not in ("f32", "bf16", "h2"):
-            raise ValueError("conv_precision must be 'f32', 'bf16' or 'h2', got %r" % (conv_precision,))
+        if conv_precision not in ("f32", "bf16", "bf16w", "h2"):
+            raise ValueError("conv_precision must be 'h2', 'f32', 'bf16' or 'bf16w', got %r" % (conv_precision,))
         self.conv_precision = conv_precision
         self.h2 = conv_precision == "h2"
-        self.encoders = [Encoder(self.store, "m%d." % mi, cin, bf16=conv_precision == "bf16")
+        self.bf = conv_precision == "bf16"
+        self.encoders = [Encoder(self.store, "m%d." % mi, cin, bf16=conv_precision == "bf16w")
                          for mi, cin in enumerate(self.in_channels)]
+        if self.bf:
+            for enc in self.encoders:
+                enc.bf = BFState(enc)
         if self.h2:
+            # UGN_PERSISTENT_WGS=n (< 256): the persistent convolution launches leave 256 - n CUs free -- room for RCCL's channels
+            # when the bucketed all-reduce (UGN_AR_OVERLAP=1) overlaps the backward pass.  Results do not depend on it
+            # (tests/test_mm_gpu.py); unmeasured on multi-GPU hardware, hence not a default.
+            if os.environ.get("UGN_PERSISTENT_WGS"):
+                h2.set_persistent_wgs(int(os.environ["UGN_PERSISTENT_WGS"]))
             self.meta_pool = h2.MetaPool(self.device, 64 * self.nmod)
             for enc in self.encoders:
                 enc.h2 = H2State(enc, self.meta_pool)
@@ -600,6 +613,10 @@ class GaitCore:
     def weights_changed(self):
         if self.h2:          # f16 halves + block exponent + L1 bound of every 3x3 filter, both directions: two launches
             h2.mm_pack_multi([j for e in self.encoders for j in e.h2.pack_jobs()])
+            return
+        if self.bf:          # bf16 copies of the fp32 master filters in the order the kernels stream them: one launch
+            from . import bf16
+            bf16.pack_multi([j for e in self.encoders for j in e.bf.pack_jobs()])
             return
         if USE_WINOGRAD:     # one launch for the filters of all branches
             jobs = [j for e in self.encoders for j in e.pack_jobs()]
@@ -680,10 +697,10 @@ class GaitCore:
         xs = [self._dev(x) for x in xs]
         b = xs[0].shape[0]
         self._active = None
-        merged = (_merged_ok() and len(self.encoders) > 1) or self.h2
+        merged = (_merged_ok() and len(self.encoders) > 1) or self.h2 or self.bf
         if self.h2:
             self.meta_pool.reset()      # every H2 meta of the step gathers its maximum from zero: one memset
-        fwd_many = forward_h2 if self.h2 else forward_merged
+        fwd_many = forward_h2 if self.h2 else (forward_bf if self.bf else forward_merged)
         if self.multimodal and self.skip_masked:
             outs, self._active = [None] * self.nmod, []
             sub = []      # (modality, rows tensor or None, input of the active clips)
@@ -701,7 +718,7 @@ class GaitCore:
                 outs[mi].zero_()
                 if len(rows):
                     sub.append((mi, idx, x.index_select(0, idx).contiguous()))
-            if merged and (len(sub) > 1 or (self.h2 and sub)):
+            if merged and (len(sub) > 1 or ((self.h2 or self.bf) and sub)):
                 res = fwd_many([self.encoders[mi] for mi, _, _ in sub], [x for _, _, x in sub])
             else:
                 res = [self.encoders[mi].forward(x) for mi, _, x in sub]
@@ -805,7 +822,7 @@ class GaitCore:
                                       [self._buf("dout%d" % m, (NBINS, bl, HIDDEN)) for m in range(self.nmod)])
         else:
             douts = [own(dsig)]
-        if self.h2 or (_merged_ok() and self.nmod > 1 and not BRANCH_STREAMS):
+        if self.h2 or self.bf or (_merged_ok() and self.nmod > 1 and not BRANCH_STREAMS):
             encs, ds = [], []
             for mi, (enc, d) in enumerate(zip(self.encoders, douts)):
                 idx = self._active[mi] if self._active is not None else None
@@ -818,9 +835,9 @@ class GaitCore:
                 else:
                     encs.append(enc)
                     ds.append(d.index_select(1, idx).contiguous())
-            if self.h2:
+            if self.h2 or self.bf:
                 if encs:
-                    backward_h2(encs, ds, _side)
+                    (backward_h2 if self.h2 else backward_bf)(encs, ds, _side)
             elif len(encs) > 1:
                 backward_merged(encs, ds, [self.scratch.setdefault(self.encoders.index(e), {}) for e in encs])
             elif encs:
@@ -882,8 +899,8 @@ class GaitCore:
             self._ar_pending = None
             return 1.0 if self.global_batch else scale
         if self._ar_pending is not None:
-            for w in self._ar_pending:
-                w.wait()
+            pending = self._ar_pending
+            dp._timed("allreduce_exposed_wait_ms", lambda: [w.wait() for w in pending])   # (what the buckets did not hide)
             self._ar_pending = None
             scale = 1.0 / self.world
         else:

@@ -109,6 +109,11 @@ def decode(t, out=None):
     return out
 
 
+def set_persistent_wgs(n):
+    """Workgroups of the persistent forward / data-gradient launches (0 = default, one per CU): see include/ugaitnet_hip.h."""
+    _lib.check(_lib.load().ugn_set_persistent_wgs(int(n)), "ugn_set_persistent_wgs")
+
+
 def absmax(x, meta):
     """meta <- {0, bits(max|x|)} (meta zero on entry)."""
     call("ugn_absmax", ptr(x), x.numel(), ptr(meta), _stream())
