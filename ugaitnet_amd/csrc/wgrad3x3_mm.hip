@@ -52,13 +52,17 @@ struct WGeo {
   static constexpr int KS = 8 / PW;                  // waves sharing a pair (K split)
   static constexpr int RPW = 8 / KS;                 // pixel rows of a strip per wave
   static constexpr int DZ_BYTES = PW * 16384;        // [plane][block][128 pixels][64 B]
-  static constexpr int SET = IN_BYTES + DZ_BYTES;
-  static constexpr int STG_SLOTS_PP = 5 * COW / 16;  // staging slots per pooled pixel: H, L (COW/8 each), argmax (COW/16)
-  static constexpr int STG_PIECES = 32 * STG_SLOTS_PP / 64;
-  static constexpr int STG_BYTES = STG_PIECES * 1024;
+  // pooled layers: the gradient tile is the POOLED one, [plane][block][32 pooled pixels][64 B], + [32 pooled pixels][COW] argmax bytes
+  static constexpr int PZ_VAL = PW * 4096;
+  static constexpr int PZ_PIECES = PW * 5;           // 4 of values + 1 of argmax bytes per block
+  static constexpr int PZ_BYTES = PZ_PIECES * 1024;
 };
+// buffer set = input halo + gradient tile (pooled: the pooled gradient tile); + 32 KB of scratch for the K-split combine where a
+// set is smaller than that
 template <int CO, int POOLED>
-constexpr int wg_lds_bytes() { return 2 * WGeo<CO>::SET + (POOLED ? WGeo<CO>::STG_BYTES : 0); }
+constexpr int wg_set_bytes() { return IN_BYTES + (POOLED ? WGeo<CO>::PZ_BYTES : WGeo<CO>::DZ_BYTES); }
+template <int CO, int POOLED>
+constexpr int wg_lds_bytes() { return 2 * wg_set_bytes<CO, POOLED>() + (wg_set_bytes<CO, POOLED>() < 32768 ? 32768 : 0); }
 
 __device__ __forceinline__ h8 tr_pair(const LDS_PTR(char) base, int off0, int off1) {
   const s4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s4))(base + off0));
@@ -68,10 +72,15 @@ __device__ __forceinline__ h8 tr_pair(const LDS_PTR(char) base, int off0, int of
 }
 __device__ __forceinline__ f32x16 mfma_h8(h8 a, h8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
 
+#ifdef UGN_WG_STAMP
+__device__ unsigned long long* g_wg_stamp = nullptr;
+constexpr int kWgStampPerWave = 4 + 6 * 60;
+#endif
+
 template <int CI, int CO, int HW, int POOLED>
 __global__ __launch_bounds__(512, 2) void wgrad_mm_kernel(const WgJobs jt, const void* __restrict__ zeros) {
   using G = WGeo<CO>;
-  constexpr int COW = G::COW, PW = G::PW, KS = G::KS, RPW = G::RPW, SET = G::SET;
+  constexpr int COW = G::COW, PW = G::PW, KS = G::KS, RPW = G::RPW, SET = wg_set_bytes<CO, POOLED>();
   constexpr int NCOC = CO / COW, NCOMBO = (CI / 32) * NCOC;
   constexpr int SPX = HW / 16, SPI = (HW / 8) * SPX;        // strips per image row / per image
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -98,78 +107,117 @@ __global__ __launch_bounds__(512, 2) void wgrad_mm_kernel(const WgJobs jt, const
     for (int j = 1; j < kWgMaxJobs; ++j) jb += s >= jt.start[j] ? 1 : 0;
     return jb;
   };
-  // tiles of strip s -> buffer set b (pooled: the gradient goes to the staging tile instead)
-  auto stage = [&](int s, int b) {
-    const int jb = job_of(s), ls = s - jt.start[jb];
-    const int img = ls / SPI, r = ls % SPI;
-    const int sy0 = (r / SPX) * 8, sx0 = (r % SPX) * 16;
-    const char* in_img = reinterpret_cast<const char*>(jt.job[jb].in) + (size_t)img * HW * HW * CI * 4 + cic * 64;
-    constexpr int NPIECE = IN_PIECES + (POOLED ? G::STG_PIECES : PW * 16);
+  // ---- LDS-DMA pieces of this wave (piece pi = wave + 8 j of a strip's tiles).  What depends only on the lane is computed
+  // once: the byte offset of the lane's 16-byte slot relative to the strip's first pixel and, for the input halo, the slot's
+  // (row, column) for the image-border test -- packed off << 12 | row << 5 | column (pad slots: row 127, never inside an
+  // image); for the pooled staging tile bit 0 says "argmax bytes" (a base of their own).  Per strip a piece then costs a dozen
+  // instructions, and the pieces are issued BETWEEN the taps of the MFMA loop (they were a phase of 1,200-3,700 cycles per
+  // strip in which no wave multiplied; in-kernel stamps, tools/stamp_wgrad.py).
+  constexpr int NPIECE = IN_PIECES + (POOLED ? G::PZ_PIECES : PW * 16);
+  constexpr int NJ = (NPIECE + 7) / 8;
+  int pk[NJ];
 #pragma unroll
-    for (int j = 0; j < (NPIECE + 7) / 8; ++j) {
-      const int pi = wave + 8 * j;
-      if (pi >= NPIECE) break;
-      if (pi < IN_PIECES) {
-        const int sg = pi * 64 + lane;                         // slot: [plane][pixel 0..179][quarter]
-        const int plane = sg >= 720 ? 1 : 0, rem = sg - 720 * plane;
-        const int pix = rem >> 2, c4 = rem & 3;
-        const int row = (pix * 3641) >> 16, px = pix - row * 18;         // pix / 18 for pix < 400
-        const int gy = sy0 - 1 + row, gx = sx0 - 1 + px;
-        const bool ok = sg < 1440 && (unsigned)gy < (unsigned)HW && (unsigned)gx < (unsigned)HW;
-        const void* src = ok ? (const void*)(in_img + (unsigned)(gy * HW + gx) * (unsigned)(CI * 4) + (unsigned)(plane * CI * 2 + c4 * 16)) : zeros;
-        dma16(src, sbase + (unsigned)(b * SET) + (unsigned)pi * 1024u);
-      } else if constexpr (!POOLED) {
-        const int pd = pi - IN_PIECES;
-        const int sg = pd * 64 + lane;                         // slot: [plane][block][pixel 0..127][quarter]
+  for (int j = 0; j < NJ; ++j) {
+    const int pi = wave + 8 * j;
+    pk[j] = 127 << 5;
+    if (pi < IN_PIECES) {
+      const int sg = pi * 64 + lane;                         // slot: [plane][pixel 0..179][quarter]
+      const int plane = sg >= 720 ? 1 : 0, rem = sg - 720 * plane;
+      const int pix = rem >> 2, c4 = rem & 3;
+      const int row = (pix * 3641) >> 16, px = pix - row * 18;         // pix / 18 for pix < 400
+      const int off = ((row - 1) * HW + (px - 1)) * (CI * 4) + plane * CI * 2 + c4 * 16;
+      if (sg < 1440) pk[j] = (int)(((unsigned)off << 12) | (unsigned)(row << 5) | (unsigned)px);
+    } else if (pi < NPIECE) {
+      const int pd = pi - IN_PIECES;
+      const int sg = pd * 64 + lane;
+      if constexpr (!POOLED) {                               // slot: [plane][block][pixel 0..127][quarter]
         const int plane = sg / (PW * 512), rem = sg - plane * (PW * 512);
         const int nb = rem >> 9, rem2 = rem & 511;
         const int pix = rem2 >> 2, c4 = rem2 & 3;
-        const int gy = sy0 + (pix >> 4), gx = sx0 + (pix & 15);
-        const char* dz_img = reinterpret_cast<const char*>(jt.job[jb].dz) + (size_t)img * HW * HW * CO * 4;
-        const void* src = dz_img + (unsigned)(gy * HW + gx) * (unsigned)(CO * 4) + (unsigned)(plane * CO * 2 + (coc * COW + nb * 32) * 2 + c4 * 16);
-        dma16(src, sbase + (unsigned)(b * SET + IN_BYTES) + (unsigned)pd * 1024u);
+        pk[j] = ((pix >> 4) * HW + (pix & 15)) * (CO * 4) + plane * CO * 2 + (coc * COW + nb * 32) * 2 + c4 * 16;
+      } else {                     // slots: [plane][block][pooled pixel 0..31][quarter], then [pooled pixel][COW / 16] of argmax bytes
+        constexpr int HP = HW / 2;
+        if (sg < PW * 256) {
+          const int plane = sg / (PW * 128), rem = sg - plane * (PW * 128);
+          const int nb = rem >> 7, rem2 = rem & 127;
+          const int pp = rem2 >> 2, c4 = rem2 & 3;
+          pk[j] = (((pp >> 3) * HP + (pp & 7)) * (CO * 4) + plane * CO * 2 + (coc * COW + nb * 32) * 2 + c4 * 16) << 1;
+        } else {
+          const int si = sg - PW * 256;
+          const int pp = si / (COW / 16), part = si - pp * (COW / 16);
+          pk[j] = pp < 32 ? ((((pp >> 3) * HP + (pp & 7)) * CO + coc * COW + part * 16) << 1) | 1 : -2;     // (-2: pad slot)
+        }
+      }
+    }
+  }
+  // per-strip bases (wave-uniform)
+  struct StripSrc { const char* in; const char* dz; const char* ix; int sy0, sx0; };
+  auto strip_src = [&](int s) {
+    const int jb = job_of(s), ls = s - jt.start[jb];
+    const int img = ls / SPI, r = ls % SPI;
+    StripSrc S;
+    S.sy0 = (r / SPX) * 8;
+    S.sx0 = (r % SPX) * 16;
+    S.in = reinterpret_cast<const char*>(jt.job[jb].in) + (size_t)img * HW * HW * CI * 4 + cic * 64 +
+           (size_t)(S.sy0 * HW + S.sx0) * (CI * 4);
+    if constexpr (POOLED) {
+      constexpr int HP = HW / 2;
+      const size_t o = (size_t)img * HP * HP + (size_t)((S.sy0 / 2) * HP + S.sx0 / 2);
+      S.dz = reinterpret_cast<const char*>(jt.job[jb].dz) + o * (CO * 4);
+      S.ix = reinterpret_cast<const char*>(jt.job[jb].dz_idx) + o * CO;
+    } else {
+      S.dz = reinterpret_cast<const char*>(jt.job[jb].dz) + ((size_t)img * HW * HW + (size_t)(S.sy0 * HW + S.sx0)) * (CO * 4);
+      S.ix = nullptr;
+    }
+    return S;
+  };
+  // piece j of this wave: input halo and gradient tile (pooled: pooled gradient + argmax bytes) of strip `Sin` -> buffer set b
+  auto issue = [&](int j, const StripSrc& Sin, int b) {
+    const int pi = wave + 8 * j;
+    if (pi < IN_PIECES) {
+      const int v = pk[j];
+      const int gy = Sin.sy0 - 1 + ((v >> 5) & 127), gx = Sin.sx0 - 1 + (v & 31);
+      const bool ok = (unsigned)gy < (unsigned)HW && (unsigned)gx < (unsigned)HW;
+      const void* src = ok ? (const void*)(Sin.in + (ptrdiff_t)(v >> 12)) : zeros;
+      dma16(src, sbase + (unsigned)(b * SET) + (unsigned)pi * 1024u);
+    } else if (pi < NPIECE) {
+      const int pd = pi - IN_PIECES;
+      if constexpr (!POOLED) {
+        dma16(Sin.dz + pk[j], sbase + (unsigned)(b * SET + IN_BYTES) + (unsigned)pd * 1024u);
       } else {
-        constexpr int HP = HW / 2, SL = G::STG_SLOTS_PP;
-        const int pd = pi - IN_PIECES;
-        const int sg = pd * 64 + lane;                         // slot: [pooled pixel 0..31][H COW/8 | L COW/8 | argmax COW/16]
-        const int pp = sg / SL, part = sg - pp * SL;
-        const int py = sy0 / 2 + (pp >> 3), pxx = sx0 / 2 + (pp & 7);
-        const unsigned o = (unsigned)(py * HP + pxx);
-        const char* dz_img = reinterpret_cast<const char*>(jt.job[jb].dz) + (size_t)img * HP * HP * CO * 4;
-        const char* ix_img = reinterpret_cast<const char*>(jt.job[jb].dz_idx) + (size_t)img * HP * HP * CO;
-        const void* src;
-        if (part < COW / 8) src = dz_img + o * (unsigned)(CO * 4) + (unsigned)(coc * COW * 2 + part * 16);
-        else if (part < COW / 4) src = dz_img + o * (unsigned)(CO * 4) + (unsigned)(CO * 2 + coc * COW * 2 + (part - COW / 8) * 16);
-        else src = ix_img + o * (unsigned)CO + (unsigned)(coc * COW + (part - COW / 4) * 16);
-        dma16(src, sbase + (unsigned)(2 * SET) + (unsigned)pd * 1024u);
+        const int v = pk[j];
+        const char* base = (v & 1) ? Sin.ix : Sin.dz;
+        const void* src = v == -2 ? zeros : (const void*)(base + (v >> 1));
+        dma16(src, sbase + (unsigned)(b * SET + IN_BYTES) + (unsigned)pd * 1024u);
       }
     }
   };
-  // MaxPool backward of the staged strip: pooled pixel pp (4 x 8), channel group cg (8 channels) -> 4 positions of the tile
-  auto scatter = [&](int b) {
-    constexpr int NCG = COW / 8;
-    if (tid >= 32 * NCG) return;
-    const int pp = tid / NCG, cg = tid - pp * NCG;
-    const char* rec = smem + 2 * SET + pp * (5 * COW);
-    const uint4 hi = *reinterpret_cast<const uint4*>(rec + cg * 16);
-    const uint4 lo = *reinterpret_cast<const uint4*>(rec + COW * 2 + cg * 16);
-    const uint2 ix = *reinterpret_cast<const uint2*>(rec + COW * 4 + cg * 8);
-    const unsigned hv[4] = {hi.x, hi.y, hi.z, hi.w}, lv[4] = {lo.x, lo.y, lo.z, lo.w};
-    const int nb = cg >> 2, c4 = cg & 3;
+  // MaxPool backward is part of the fragment build (pooled layers).  The B fragment of a k-step -- pixel row y of the strip, lane
+  // (channel c, k half h) = pixels 8h .. 8h+7 -- holds, per pixel, the pooled gradient of its window where the window's argmax
+  // byte names the pixel's position, else zero: ONE transposed read per plane (pooled pixels 4h .. 4h+3 of pooled row y / 2), the
+  // four argmax bytes, and a dozen selects.  (The first version scattered the staged tile LDS -> LDS into a full-resolution
+  // gradient tile: 950-1,450 cycles per strip and a second barrier, tools/stamp_wgrad.py.)
+  const int lane_off_p = (4 * h + q) * 64 + (16 * gh + 4 * p) * 2;
+  auto pooled_frag = [&](int b, int y, h8& bh, h8& bl) {
+    const LDS_PTR(char) pv = lds + b * SET + IN_BYTES + pair * 2048 + (y >> 1) * 512 + lane_off_p;
+    const s4 ph = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s4))pv);
+    const s4 pl = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s4))(pv + PW * 2048));
+    const unsigned char* pi8 = reinterpret_cast<const unsigned char*>(smem) + b * SET + IN_BYTES + G::PZ_VAL +
+                               ((y >> 1) * 8 + 4 * h) * COW + pair * 32 + (lane & 31);
+    const unsigned posa = 2u * (unsigned)(y & 1);
+    const uint2 hv = __builtin_bit_cast(uint2, ph), lv = __builtin_bit_cast(uint2, pl);
+    unsigned fh[4], fl[4];
 #pragma unroll
-    for (int pos = 0; pos < 4; ++pos) {
-      unsigned m[4];
-#pragma unroll
-      for (int d = 0; d < 4; ++d) {
-        const unsigned w = d < 2 ? ix.x : ix.y;
-        const unsigned b0 = (w >> (16 * (d & 1))) & 0xffu, b1 = (w >> (16 * (d & 1) + 8)) & 0xffu;
-        m[d] = (b0 == (unsigned)pos ? 0x0000ffffu : 0u) | (b1 == (unsigned)pos ? 0xffff0000u : 0u);
-      }
-      const int y = 2 * (pp >> 3) + (pos >> 1), x = 2 * (pp & 7) + (pos & 1);
-      char* dst = smem + b * SET + IN_BYTES + (nb * 128 + y * 16 + x) * 64 + c4 * 16;
-      *reinterpret_cast<uint4*>(dst) = make_uint4(hv[0] & m[0], hv[1] & m[1], hv[2] & m[2], hv[3] & m[3]);
-      *reinterpret_cast<uint4*>(dst + PW * 8192) = make_uint4(lv[0] & m[0], lv[1] & m[1], lv[2] & m[2], lv[3] & m[3]);
+    for (int j = 0; j < 4; ++j) {
+      const unsigned ix = pi8[j * COW];
+      const unsigned m = (ix == posa ? 0x0000ffffu : 0u) | (ix == posa + 1u ? 0xffff0000u : 0u);
+      const unsigned h2w = j < 2 ? hv.x : hv.y, l2w = j < 2 ? lv.x : lv.y;
+      const unsigned hs = (j & 1) ? (h2w >> 16) : (h2w & 0xffffu), ls = (j & 1) ? (l2w >> 16) : (l2w & 0xffffu);
+      fh[j] = (hs | (hs << 16)) & m;
+      fl[j] = (ls | (ls << 16)) & m;
     }
+    bh = __builtin_bit_cast(h8, make_uint4(fh[0], fh[1], fh[2], fh[3]));
+    bl = __builtin_bit_cast(h8, make_uint4(fl[0], fl[1], fl[2], fl[3]));
   };
 
   f32x16 acc[9];
@@ -178,24 +226,45 @@ __global__ __launch_bounds__(512, 2) void wgrad_mm_kernel(const WgJobs jt, const
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
 
-  stage(s0, 0);
+#ifdef UGN_WG_STAMP
+  unsigned long long* stamp = g_wg_stamp ? g_wg_stamp + ((size_t)blockIdx.x * 8 + wave) * kWgStampPerWave : nullptr;
+  int nstamp = 0;
+  if (stamp && lane == 0) { stamp[0] = __builtin_amdgcn_s_memtime(); stamp[1] = __builtin_amdgcn_s_memrealtime(); }
+#define WG_STAMP(k_) do { if (stamp && lane == 0 && nstamp < 60) stamp[4 + 6 * nstamp + (k_)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define WG_STAMP(k_) do { } while (0)
+#endif
+  // ---- prologue: tiles of strip s0 -> set 0
+  {
+    const StripSrc S0 = strip_src(s0);
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) issue(j, S0, 0);
+  }
   int b = 0;
   int jb = job_of(s0);
   for (int s = s0; s < s1; ++s) {
+    WG_STAMP(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();                                   // strip s has landed; nobody reads the other buffer set any more
-    if constexpr (POOLED) {
-      scatter(b);
-      __syncthreads();
-    }
-    if (s + 1 < s1) stage(s + 1, b ^ 1);
+    WG_STAMP(1);
+    __syncthreads();      // strip s is in set b; nobody reads the other set any more
+    WG_STAMP(2);
+    // the tiles of strip s + 1 -> the other set, issued between the taps below
+    const bool have_in = s + 1 < s1;
+    const StripSrc Sin = strip_src(have_in ? s + 1 : s);
+    WG_STAMP(3);
+    WG_STAMP(4);
     const LDS_PTR(char) in_b = lds + b * SET + ks * RPW * (18 * 64) + lane_off;
     const LDS_PTR(char) dz_b = lds + b * SET + IN_BYTES + pair * 8192 + ks * RPW * (16 * 64) + lane_off;
 #pragma unroll
     for (int rr = 0; rr < RPW; ++rr) {
       // k-step = pixel row rr of the wave: lane half h covers pixels 8h .. 8h+7 (two 4-pixel blocks)
-      const h8 bh = tr_pair(dz_b, (rr * 16) * 64, (rr * 16 + 4) * 64);
-      const h8 bl = tr_pair(dz_b, PW * 8192 + (rr * 16) * 64, PW * 8192 + (rr * 16 + 4) * 64);
+      h8 bh, bl;
+      if constexpr (POOLED) {
+        pooled_frag(b, ks * RPW + rr, bh, bl);
+      } else {
+        bh = tr_pair(dz_b, (rr * 16) * 64, (rr * 16 + 4) * 64);
+        bl = tr_pair(dz_b, PW * 8192 + (rr * 16) * 64, PW * 8192 + (rr * 16 + 4) * 64);
+      }
 #pragma unroll
       for (int t = 0; t < 9; ++t) {
         const int dy = t / 3, dx = t % 3;
@@ -205,14 +274,26 @@ __global__ __launch_bounds__(512, 2) void wgrad_mm_kernel(const WgJobs jt, const
         acc[t] = mfma_h8(ah, bh, acc[t]);
         acc[t] = mfma_h8(ah, bl, acc[t]);
         acc[t] = mfma_h8(al, bh, acc[t]);
+        // one LDS-DMA piece after every tap (every second tap where there are two k-steps) until the wave's pieces are out
+        constexpr int EVERY = RPW == 1 ? 1 : 2;
+        const int slot = rr * 9 + t;
+        if (slot % EVERY == 0 && slot / EVERY < NJ && have_in) {
+          __builtin_amdgcn_sched_barrier(0);
+          issue(slot / EVERY, Sin, b ^ 1);
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
     }
+    WG_STAMP(5);
+#ifdef UGN_WG_STAMP
+    ++nstamp;
+#endif
     const int jn = s + 1 < s1 ? job_of(s + 1) : -1;
     if (jn != jb) {
       // ---- job (or share) finished: add the K-split waves of a pair through LDS in a fixed order, write the slab.  The
       // scratch is the buffer set just multiplied (the next strip streams into the other one).
       float* slab = jt.job[jb].slab + ((size_t)combo * jt.job[jb].ng + (grp - jt.job[jb].g0)) * (9 * 32 * COW);
-      float* scr = reinterpret_cast<float*>(smem + b * SET);
+      float* scr = reinterpret_cast<float*>(smem + (SET < 32768 ? 2 * SET : b * SET));
 #pragma unroll 1
       for (int t = 0; t < 9; ++t) {
         __syncthreads();
@@ -241,6 +322,9 @@ __global__ __launch_bounds__(512, 2) void wgrad_mm_kernel(const WgJobs jt, const
     }
     b ^= 1;
   }
+#ifdef UGN_WG_STAMP
+  if (stamp && lane == 0) { stamp[2] = __builtin_amdgcn_s_memtime(); stamp[3] = __builtin_amdgcn_s_memrealtime(); }
+#endif
 }
 
 struct WgFinish {
@@ -334,6 +418,13 @@ size_t ws_floats_for(int njobs) {
 }
 
 }  // namespace
+
+#ifdef UGN_WG_STAMP
+extern "C" int ugn_wg_debug_stamps(void* buf) {
+  unsigned long long* p = (unsigned long long*)buf;
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_wg_stamp), &p, sizeof(p));
+}
+#endif
 
 extern "C" size_t ugn_mm_conv3x3_wgrad_ws(int hw, int cin, int cout) {
 #define WS(CI_, CO_, HW_) if (cin == CI_ && cout == CO_ && hw == HW_) return ws_floats_for<CI_, CO_>(kWgMaxJobs) * sizeof(float);
