@@ -37,14 +37,17 @@ struct WGeo {
   static constexpr int KS = 8 / PW;                  // waves sharing a pair (K split)
   static constexpr int RPW = 8 / KS;                 // pixel rows of a strip per wave
   static constexpr int DZ_BYTES = PW * 8192;         // [block][128 pixels][64 B]
-  static constexpr int SET = IN_BYTES + DZ_BYTES;
-  static constexpr int STG_SLOTS_PP = 3 * COW / 16;  // staging slots per pooled pixel: values (COW/8), argmax (COW/16)
-  static constexpr int STG_PIECES = 32 * STG_SLOTS_PP / 64;
-  static constexpr int STG_BYTES = STG_PIECES * 1024;
+  // pooled layers: the gradient tile is the POOLED one, [block][32 pooled pixels][64 B], + [32 pooled pixels][COW] argmax bytes
+  static constexpr int PZ_VAL = PW * 2048;
+  static constexpr int PZ_PIECES = PW * 3;           // 2 of values + 1 of argmax bytes per block
+  static constexpr int PZ_BYTES = PZ_PIECES * 1024;
 };
-// (+ 32 KB of scratch for the K-split combine: a bf16 buffer set -- 20 / 28 KB -- is smaller than the 8 waves x 4 KB it needs)
+// buffer set = input halo + gradient tile (pooled: the pooled gradient tile); + 32 KB of scratch for the K-split combine (a
+// bf16 set -- 15 ... 28 KB -- is smaller than the 8 waves x 4 KB it needs)
 template <int CO, int POOLED>
-constexpr int wg_scr_off() { return 2 * WGeo<CO>::SET + (POOLED ? WGeo<CO>::STG_BYTES : 0); }
+constexpr int wg_set_bytes() { return IN_BYTES + (POOLED ? WGeo<CO>::PZ_BYTES : WGeo<CO>::DZ_BYTES); }
+template <int CO, int POOLED>
+constexpr int wg_scr_off() { return 2 * wg_set_bytes<CO, POOLED>(); }
 template <int CO, int POOLED>
 constexpr int wg_lds_bytes() { return wg_scr_off<CO, POOLED>() + 32768; }
 
@@ -62,7 +65,7 @@ __device__ __forceinline__ f32x16 mfma_b8(h8 a, h8 b, f32x16 c) {
 template <int CI, int CO, int HW, int POOLED>
 __global__ __launch_bounds__(512, 2) void wgrad_bf_kernel(const WgJobs jt, const void* __restrict__ zeros) {
   using G = WGeo<CO>;
-  constexpr int COW = G::COW, PW = G::PW, KS = G::KS, RPW = G::RPW, SET = G::SET;
+  constexpr int COW = G::COW, PW = G::PW, KS = G::KS, RPW = G::RPW, SET = wg_set_bytes<CO, POOLED>();
   constexpr int NCOC = CO / COW, NCOMBO = (CI / 32) * NCOC;
   constexpr int SPX = HW / 16, SPI = (HW / 8) * SPX;        // strips per image row / per image
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -89,73 +92,108 @@ __global__ __launch_bounds__(512, 2) void wgrad_bf_kernel(const WgJobs jt, const
     for (int j = 1; j < kWgMaxJobs; ++j) jb += s >= jt.start[j] ? 1 : 0;
     return jb;
   };
-  // tiles of strip s -> buffer set b (pooled: the gradient goes to the staging tile instead)
-  auto stage = [&](int s, int b) {
-    const int jb = job_of(s), ls = s - jt.start[jb];
-    const int img = ls / SPI, r = ls % SPI;
-    const int sy0 = (r / SPX) * 8, sx0 = (r % SPX) * 16;
-    const char* in_img = reinterpret_cast<const char*>(jt.job[jb].in) + (size_t)img * HW * HW * CI * 2 + cic * 64;
-    constexpr int NPIECE = IN_PIECES + (POOLED ? G::STG_PIECES : PW * 8);
+  // ---- LDS-DMA pieces of this wave (piece pi = wave + 8 j of a strip's tiles).  What depends only on the lane is computed
+  // once: the byte offset of the lane's 16-byte slot relative to the strip's first pixel and, for the input halo, the slot's
+  // (row, column) for the image-border test -- packed off << 12 | row << 5 | column (pad slots: row 127, never inside an
+  // image); for the pooled staging tile bit 0 says "argmax bytes" (a base of their own).  Per strip a piece then costs a dozen
+  // instructions, and the pieces are issued BETWEEN the taps of the MFMA loop (they were a phase of 1,200-3,700 cycles per
+  // strip in which no wave multiplied; in-kernel stamps, tools/stamp_wgrad.py).
+  constexpr int NPIECE = IN_PIECES + (POOLED ? G::PZ_PIECES : PW * 8);
+  constexpr int NJ = (NPIECE + 7) / 8;
+  int pk[NJ];
 #pragma unroll
-    for (int j = 0; j < (NPIECE + 7) / 8; ++j) {
-      const int pi = wave + 8 * j;
-      if (pi >= NPIECE) break;
-      if (pi < IN_PIECES) {
-        const int sg = pi * 64 + lane;                         // slot: [pixel 0..179][quarter]
-        const int pix = sg >> 2, c4 = sg & 3;
-        const int row = (pix * 3641) >> 16, px = pix - row * 18;         // pix / 18 for pix < 400
-        const int gy = sy0 - 1 + row, gx = sx0 - 1 + px;
-        const bool ok = sg < 720 && (unsigned)gy < (unsigned)HW && (unsigned)gx < (unsigned)HW;
-        const void* src = ok ? (const void*)(in_img + (unsigned)(gy * HW + gx) * (unsigned)(CI * 2) + (unsigned)(c4 * 16)) : zeros;
-        dma16(src, sbase + (unsigned)(b * SET) + (unsigned)pi * 1024u);
-      } else if constexpr (!POOLED) {
-        const int pd = pi - IN_PIECES;
-        const int sg = pd * 64 + lane;                         // slot: [block][pixel 0..127][quarter]
+  for (int j = 0; j < NJ; ++j) {
+    const int pi = wave + 8 * j;
+    pk[j] = 127 << 5;
+    if (pi < IN_PIECES) {
+      const int sg = pi * 64 + lane;                         // slot: [pixel 0..179][quarter]
+      const int pix = sg >> 2, c4 = sg & 3;
+      const int row = (pix * 3641) >> 16, px = pix - row * 18;         // pix / 18 for pix < 400
+      const int off = ((row - 1) * HW + (px - 1)) * (CI * 2) + c4 * 16;
+      if (sg < 720) pk[j] = (int)(((unsigned)off << 12) | (unsigned)(row << 5) | (unsigned)px);
+    } else if (pi < NPIECE) {
+      const int pd = pi - IN_PIECES;
+      const int sg = pd * 64 + lane;
+      if constexpr (!POOLED) {                               // slot: [block][pixel 0..127][quarter]
         const int nb = sg >> 9, rem2 = sg & 511;
         const int pix = rem2 >> 2, c4 = rem2 & 3;
-        const int gy = sy0 + (pix >> 4), gx = sx0 + (pix & 15);
-        const char* dz_img = reinterpret_cast<const char*>(jt.job[jb].dz) + (size_t)img * HW * HW * CO * 2;
-        const void* src = dz_img + (unsigned)(gy * HW + gx) * (unsigned)(CO * 2) + (unsigned)((coc * COW + nb * 32) * 2 + c4 * 16);
-        dma16(src, sbase + (unsigned)(b * SET + IN_BYTES) + (unsigned)pd * 1024u);
+        pk[j] = ((pix >> 4) * HW + (pix & 15)) * (CO * 2) + (coc * COW + nb * 32) * 2 + c4 * 16;
+      } else {                     // slots: [block][pooled pixel 0..31][quarter], then [pooled pixel][COW / 16] of argmax bytes
+        constexpr int HP = HW / 2;
+        if (sg < PW * 128) {
+          const int nb = sg >> 7, rem2 = sg & 127;
+          const int pp = rem2 >> 2, c4 = rem2 & 3;
+          pk[j] = (((pp >> 3) * HP + (pp & 7)) * (CO * 2) + (coc * COW + nb * 32) * 2 + c4 * 16) << 1;
+        } else {
+          const int si = sg - PW * 128;
+          const int pp = si / (COW / 16), part = si - pp * (COW / 16);
+          pk[j] = pp < 32 ? ((((pp >> 3) * HP + (pp & 7)) * CO + coc * COW + part * 16) << 1) | 1 : -2;     // (-2: pad slot)
+        }
+      }
+    }
+  }
+  // per-strip bases (wave-uniform)
+  struct StripSrc { const char* in; const char* dz; const char* ix; int sy0, sx0; };
+  auto strip_src = [&](int s) {
+    const int jb = job_of(s), ls = s - jt.start[jb];
+    const int img = ls / SPI, r = ls % SPI;
+    StripSrc S;
+    S.sy0 = (r / SPX) * 8;
+    S.sx0 = (r % SPX) * 16;
+    S.in = reinterpret_cast<const char*>(jt.job[jb].in) + (size_t)img * HW * HW * CI * 2 + cic * 64 +
+           (size_t)(S.sy0 * HW + S.sx0) * (CI * 2);
+    if constexpr (POOLED) {
+      constexpr int HP = HW / 2;
+      const size_t o = (size_t)img * HP * HP + (size_t)((S.sy0 / 2) * HP + S.sx0 / 2);
+      S.dz = reinterpret_cast<const char*>(jt.job[jb].dz) + o * (CO * 2);
+      S.ix = reinterpret_cast<const char*>(jt.job[jb].dz_idx) + o * CO;
+    } else {
+      S.dz = reinterpret_cast<const char*>(jt.job[jb].dz) + ((size_t)img * HW * HW + (size_t)(S.sy0 * HW + S.sx0)) * (CO * 2);
+      S.ix = nullptr;
+    }
+    return S;
+  };
+  // piece j of this wave: input halo and gradient tile (pooled: pooled gradient + argmax bytes) of strip `Sin` -> buffer set b
+  auto issue = [&](int j, const StripSrc& Sin, int b) {
+    const int pi = wave + 8 * j;
+    if (pi < IN_PIECES) {
+      const int v = pk[j];
+      const int gy = Sin.sy0 - 1 + ((v >> 5) & 127), gx = Sin.sx0 - 1 + (v & 31);
+      const bool ok = (unsigned)gy < (unsigned)HW && (unsigned)gx < (unsigned)HW;
+      const void* src = ok ? (const void*)(Sin.in + (ptrdiff_t)(v >> 12)) : zeros;
+      dma16(src, sbase + (unsigned)(b * SET) + (unsigned)pi * 1024u);
+    } else if (pi < NPIECE) {
+      const int pd = pi - IN_PIECES;
+      if constexpr (!POOLED) {
+        dma16(Sin.dz + pk[j], sbase + (unsigned)(b * SET + IN_BYTES) + (unsigned)pd * 1024u);
       } else {
-        constexpr int HP = HW / 2, SL = G::STG_SLOTS_PP;
-        const int pd = pi - IN_PIECES;
-        const int sg = pd * 64 + lane;                         // slot: [pooled pixel 0..31][values COW/8 | argmax COW/16]
-        const int pp = sg / SL, part = sg - pp * SL;
-        const int py = sy0 / 2 + (pp >> 3), pxx = sx0 / 2 + (pp & 7);
-        const unsigned o = (unsigned)(py * HP + pxx);
-        const char* dz_img = reinterpret_cast<const char*>(jt.job[jb].dz) + (size_t)img * HP * HP * CO * 2;
-        const char* ix_img = reinterpret_cast<const char*>(jt.job[jb].dz_idx) + (size_t)img * HP * HP * CO;
-        const void* src;
-        if (part < COW / 8) src = dz_img + o * (unsigned)(CO * 2) + (unsigned)(coc * COW * 2 + part * 16);
-        else src = ix_img + o * (unsigned)CO + (unsigned)(coc * COW + (part - COW / 8) * 16);
-        dma16(src, sbase + (unsigned)(2 * SET) + (unsigned)pd * 1024u);
+        const int v = pk[j];
+        const char* base = (v & 1) ? Sin.ix : Sin.dz;
+        const void* src = v == -2 ? zeros : (const void*)(base + (v >> 1));
+        dma16(src, sbase + (unsigned)(b * SET + IN_BYTES) + (unsigned)pd * 1024u);
       }
     }
   };
-  // MaxPool backward of the staged strip: pooled pixel pp (4 x 8), channel group cg (8 channels) -> 4 positions of the tile
-  auto scatter = [&](int b) {
-    constexpr int NCG = COW / 8;
-    if (tid >= 32 * NCG) return;
-    const int pp = tid / NCG, cg = tid - pp * NCG;
-    const char* rec = smem + 2 * SET + pp * (3 * COW);
-    const uint4 hi = *reinterpret_cast<const uint4*>(rec + cg * 16);
-    const uint2 ix = *reinterpret_cast<const uint2*>(rec + COW * 2 + cg * 8);
-    const unsigned hv[4] = {hi.x, hi.y, hi.z, hi.w};
-    const int nb = cg >> 2, c4 = cg & 3;
+  // MaxPool backward is part of the fragment build (pooled layers): see wgrad3x3_mm.hip.  One transposed read (pooled pixels
+  // 4h .. 4h+3 of pooled row y / 2), the four argmax bytes, and the selects.
+  const int lane_off_p = (4 * h + q) * 64 + (16 * gh + 4 * p) * 2;
+  auto pooled_frag = [&](int b, int y, h8& bh) {
+    const LDS_PTR(char) pv = lds + b * SET + IN_BYTES + pair * 2048 + (y >> 1) * 512 + lane_off_p;
+    const s4 ph = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s4))pv);
+    const unsigned char* pi8 = reinterpret_cast<const unsigned char*>(smem) + b * SET + IN_BYTES + G::PZ_VAL +
+                               ((y >> 1) * 8 + 4 * h) * COW + pair * 32 + (lane & 31);
+    const unsigned posa = 2u * (unsigned)(y & 1);
+    const uint2 hv = __builtin_bit_cast(uint2, ph);
+    unsigned fh[4];
 #pragma unroll
-    for (int pos = 0; pos < 4; ++pos) {
-      unsigned m[4];
-#pragma unroll
-      for (int d = 0; d < 4; ++d) {
-        const unsigned w = d < 2 ? ix.x : ix.y;
-        const unsigned b0 = (w >> (16 * (d & 1))) & 0xffu, b1 = (w >> (16 * (d & 1) + 8)) & 0xffu;
-        m[d] = (b0 == (unsigned)pos ? 0x0000ffffu : 0u) | (b1 == (unsigned)pos ? 0xffff0000u : 0u);
-      }
-      const int y = 2 * (pp >> 3) + (pos >> 1), x = 2 * (pp & 7) + (pos & 1);
-      char* dst = smem + b * SET + IN_BYTES + (nb * 128 + y * 16 + x) * 64 + c4 * 16;
-      *reinterpret_cast<uint4*>(dst) = make_uint4(hv[0] & m[0], hv[1] & m[1], hv[2] & m[2], hv[3] & m[3]);
+    for (int j = 0; j < 4; ++j) {
+      const unsigned ix = pi8[j * COW];
+      const unsigned m = (ix == posa ? 0x0000ffffu : 0u) | (ix == posa + 1u ? 0xffff0000u : 0u);
+      const unsigned h2w = j < 2 ? hv.x : hv.y;
+      const unsigned hs = (j & 1) ? (h2w >> 16) : (h2w & 0xffffu);
+      fh[j] = (hs | (hs << 16)) & m;
     }
+    bh = __builtin_bit_cast(h8, make_uint4(fh[0], fh[1], fh[2], fh[3]));
   };
 
   f32x16 acc[9];
@@ -164,29 +202,45 @@ __global__ __launch_bounds__(512, 2) void wgrad_bf_kernel(const WgJobs jt, const
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
 
-  stage(s0, 0);
+  // ---- prologue: tiles of strip s0 -> set 0
+  {
+    const StripSrc S0 = strip_src(s0);
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) issue(j, S0, 0);
+  }
   int b = 0;
   int jb = job_of(s0);
   for (int s = s0; s < s1; ++s) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();                                   // strip s has landed; nobody reads the other buffer set any more
-    if constexpr (POOLED) {
-      scatter(b);
-      __syncthreads();
-    }
-    if (s + 1 < s1) stage(s + 1, b ^ 1);
+    __syncthreads();      // strip s is in set b; nobody reads the other set any more
+    // the tiles of strip s + 1 -> the other set, issued between the taps below
+    const bool have_in = s + 1 < s1;
+    const StripSrc Sin = strip_src(have_in ? s + 1 : s);
     const LDS_PTR(char) in_b = lds + b * SET + ks * RPW * (18 * 64) + lane_off;
     const LDS_PTR(char) dz_b = lds + b * SET + IN_BYTES + pair * 8192 + ks * RPW * (16 * 64) + lane_off;
 #pragma unroll
     for (int rr = 0; rr < RPW; ++rr) {
       // k-step = pixel row rr of the wave: lane half h covers pixels 8h .. 8h+7 (two 4-pixel blocks)
-      const h8 bh = tr_pair(dz_b, (rr * 16) * 64, (rr * 16 + 4) * 64);
+      h8 bh;
+      if constexpr (POOLED) {
+        pooled_frag(b, ks * RPW + rr, bh);
+      } else {
+        bh = tr_pair(dz_b, (rr * 16) * 64, (rr * 16 + 4) * 64);
+      }
 #pragma unroll
       for (int t = 0; t < 9; ++t) {
         const int dy = t / 3, dx = t % 3;
         const int o = ((rr + dy) * 18 + dx) * 64;
         const h8 ah = tr_pair(in_b, o, o + 4 * 64);
         acc[t] = mfma_b8(ah, bh, acc[t]);
+        // one LDS-DMA piece after every tap (every second tap where there are two k-steps) until the wave's pieces are out
+        constexpr int EVERY = RPW == 1 ? 1 : 2;
+        const int slot = rr * 9 + t;
+        if (slot % EVERY == 0 && slot / EVERY < NJ && have_in) {
+          __builtin_amdgcn_sched_barrier(0);
+          issue(slot / EVERY, Sin, b ^ 1);
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
     }
     const int jn = s + 1 < s1 ? job_of(s + 1) : -1;
