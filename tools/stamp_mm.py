@@ -2,8 +2,9 @@
 """In-kernel clock stamps of the f16-pipe convolution kernel (diagnostic build: python -m ugaitnet_amd.build --variant stamp
 -DUGN_MM_STAMP; UGN_LIB=.../libugaitnet_hip_stamp.so python tools/stamp_mm.py [--layer a6] [--op fwd]).
 
-Reports the clock the kernel ran at (s_memtime / s_memrealtime per workgroup) and, for a few workgroups, how long the
-multiplying wave 0 and the loader waves 8 / 9 waited at each stage barrier.
+Reports the clock the kernel ran at (s_memtime / s_memrealtime per workgroup) and, for two workgroups, the mean cycles every
+wave spends in the phases of a stage (wait for the LDS-DMA, barrier, issue of the next DMA pieces, LDS reads + MFMAs) and in the
+epilogue of an item.
 """
 import ctypes as C
 import os
@@ -17,7 +18,8 @@ import torch
 from ugaitnet_amd import _lib, h2
 
 CFGS = {"a2": (64, 32, 32, True), "a3": (32, 32, 64, False), "a4": (32, 64, 64, True), "a5": (16, 64, 128, False), "a6": (16, 128, 128, False)}
-PER_WAVE = 4 + 4 * 100
+NST, NIT = 60, 20
+PER_WAVE = 4 + 5 * NST + 2 * NIT
 
 
 def main():
@@ -33,7 +35,7 @@ def main():
     lib = _lib.load()
     lib.ugn_mm_debug_stamps.argtypes = [C.c_void_p]
     lib.ugn_mm_debug_stamps.restype = C.c_int
-    buf = torch.zeros(256 * 12 * PER_WAVE, dtype=torch.int64, device=dev)
+    buf = torch.zeros(256 * 8 * PER_WAVE, dtype=torch.int64, device=dev)
     if op == "fwd":
         hx = [h2.encode(x) for x in xs]
         pk = [h2.mm_pack(w, False) for w in ws]
@@ -55,35 +57,27 @@ def main():
     fn()
     torch.cuda.synchronize()
     lib.ugn_mm_debug_stamps(C.c_void_p(0))
-    st = buf.cpu().numpy().reshape(256, 12, PER_WAVE)
+    st = buf.cpu().numpy().reshape(256, 8, PER_WAVE).astype(np.float64)
     t0, r0, t1, r1 = st[:, 0, 0], st[:, 0, 1], st[:, 0, 2], st[:, 0, 3]
     ok = t1 > 0
-    cyc, real = (t1 - t0)[ok].astype(np.float64), (r1 - r0)[ok].astype(np.float64)
+    cyc, real = (t1 - t0)[ok], (r1 - r0)[ok]
     print("%s %s: workgroups %d; kernel time per workgroup median %.1f us (max %.1f); in-kernel clock median %.3f GHz"
           % (layer, op, ok.sum(), np.median(real) / 100.0, real.max() / 100.0, np.median(cyc / real) * 0.1))
+    names = ["DMA wait", "barrier", "DMA issue (+scatter)", "reads + MFMA", "to next stage"]
     for wg in (0, 100):
-        print("workgroup %d, per stage: period | multiplier wave 0: barrier wait, body | filter loader 8: vmcnt wait, barrier wait, "
-              "issue | tile loader 10: vmcnt wait, barrier wait, issue   (cycles)" % wg)
-        q = lambda w: st[wg, w, 4:].reshape(-1, 4).astype(np.float64)
-        m, fl, tl = q(0), q(8), q(10)
-        n = int((m[:, 2] > 0).sum())
-        rows = []
-        for s in range(1, min(n, 100)):
-            rows.append((m[s, 2] - m[s - 1, 2], m[s, 2] - m[s, 1], m[s, 3] - m[s, 2],
-                         fl[s, 1] - fl[s, 0], fl[s, 2] - fl[s, 1], fl[s, 3] - fl[s, 2],
-                         tl[s, 1] - tl[s, 0], tl[s, 2] - tl[s, 1], tl[s, 3] - tl[s, 2]))
-        rows = np.array(rows)
-        for s in range(min(len(rows), 45)):
-            print("  stage %3d: %6d | %6d %6d | %6d %6d %6d | %6d %6d %6d" % (s + 1, *rows[s]))
-        print("  mean over %d stages: %s" % (len(rows), " ".join("%.0f" % v for v in rows.mean(axis=0))))
-        allw = st[wg, :, 4:].reshape(12, -1, 4).astype(np.float64)
-        bw = allw[:, 1:n, 2] - allw[:, 1:n, 1]          # barrier wait of every wave
-        body = allw[:, 1:n, 3] - allw[:, 1:n, 2]
-        arrive = allw[:, 1:n, 1] - allw[0:1, 1:n, 2] + bw[0:1]     # arrival relative to the release seen by wave 0
-        print("  mean barrier wait per wave: " + " ".join("%.0f" % v for v in bw.mean(axis=1)))
-        print("  mean body per wave:         " + " ".join("%.0f" % v for v in body.mean(axis=1)))
-        last = bw.argmin(axis=0)
-        print("  last arriver histogram:     " + " ".join("%d" % (last == w).sum() for w in range(12)))
+        q = st[wg, :, 4:4 + 5 * NST].reshape(8, NST, 5)
+        it = st[wg, :, 4 + 5 * NST:].reshape(8, NIT, 2)
+        n = int((q[0, :, 4] > 0).sum()) - 1
+        seg = np.stack([q[:, 1:n, 1] - q[:, 1:n, 0], q[:, 1:n, 2] - q[:, 1:n, 1], q[:, 1:n, 3] - q[:, 1:n, 2], q[:, 1:n, 4] - q[:, 1:n, 3],
+                        q[:, 2:n + 1, 0] - q[:, 1:n, 4]], axis=-1)
+        period = (q[0, 2:n + 1, 2] - q[0, 1:n, 2]).mean()
+        print("workgroup %d: %d stages, mean period %.0f cycles (item boundaries included); mean cycles per segment and wave:" % (wg, n, period))
+        for k, nm in enumerate(names):
+            print("  %-22s %s" % (nm, " ".join("%6.0f" % v for v in seg[:, :, k].mean(axis=1))))
+        m = int((it[0, :, 1] > 0).sum())
+        if m > 2:
+            print("  %-22s %s" % ("epilogue", " ".join("%6.0f" % v for v in (it[:, 1:m, 1] - it[:, 1:m, 0]).mean(axis=1))))
+            print("  %-22s %s" % ("item period", " ".join("%6.0f" % v for v in (it[:, 2:m, 0] - it[:, 1:m - 1, 0]).mean(axis=1))))
 
 
 if __name__ == "__main__":

@@ -55,8 +55,11 @@ struct Geo {
   static constexpr int WSTAGE = TPS * NB * 4096;         // bytes: [tap][k-step 2][block][plane 2][1 KB]
   static constexpr int WPIECES = WSTAGE / 1024;
 };
-template <int NC, int IN_POOLED>
-constexpr int lds_bytes() { return W_OFF + 2 * Geo<NC>::WSTAGE + (IN_POOLED ? STG_BYTES : 0); }
+// 32 -> 32 layers (one K chunk, one block): the whole filter of a job -- 3 stages, 36 KB -- stays in LDS
+template <int KC, int NC>
+constexpr bool filter_resident() { return KC == 32 && NC == 32; }
+template <int KC, int NC, int IN_POOLED>
+constexpr int lds_bytes() { return W_OFF + (filter_resident<KC, NC>() ? 3 : 2) * Geo<NC>::WSTAGE + (IN_POOLED ? STG_BYTES : 0); }
 
 // ---------------------------------------------------------------------------------------------------------------------
 // filter statistics + packing
@@ -225,11 +228,49 @@ __device__ __forceinline__ f32x16 mfma_h(const uint4& a, const uint4& b, f32x16 
 // ---------------------------------------------------------------------------------------------------------------------
 // KC: GEMM K channels (input channels of the convolution being evaluated), NC: its output channels, HW: image size of the
 // OUTPUT of this kernel (= of the input, un-pooled).  IN_POOLED: `in` is a pooled gradient + argmax (MaxPool backward).
+// What a lane needs per input-tile piece, computed once per kernel: the byte offset of its 16-byte slot relative to the region's
+// first pixel and the slot's (row, column) in the 18 x 18 tile for the image-border test, packed off << 12 | row << 5 | column
+// (pad slots: row 127, never inside an image).  Per item a piece then costs a dozen instructions instead of forty.
+template <int KC, int HW>
+__device__ __forceinline__ int halo_lane_of(int piece, int lane) {
+  const int g = piece * 64 + lane;
+  const int row = (g * 6242) >> 20;                 // g / 168 for g < 3072
+  const int rem = g - row * HROW;
+  const int px = (rem * 57) >> 9;                   // rem / 9 for rem < 168
+  const int c = rem - px * 9;
+  const bool valid = rem < 162 && c < 8 && row < 18;
+  const int off = ((row - 1) * HW + (px - 1)) * (KC * 4) + (c < 4 ? c * 16 : KC * 2 + (c - 4) * 16);   // |off| < 2^19
+  return valid ? (int)(((unsigned)off << 12) | (unsigned)(row << 5) | (unsigned)px) : (127 << 5);
+}
+template <int HW>
+__device__ __forceinline__ void dma_halo_lane(const char* region_base, const void* zeros, int ry0, int rx0, int packed,
+                                              unsigned lds_dst) {
+  const int off = packed >> 12;
+  const int gy = ry0 - 1 + ((packed >> 5) & 127), gx = rx0 - 1 + (packed & 31);
+  const bool ok = (unsigned)gy < (unsigned)HW && (unsigned)gx < (unsigned)HW;
+  const void* src = ok ? (const void*)(region_base + (ptrdiff_t)off) : zeros;
+  dma16(src, lds_dst);
+}
+
+// diagnostic build only (-DUGN_MM_STAMP, tools/stamp_mm.py): clock stamps of every wave at the phases of a stage / an item
+#ifdef UGN_MM_STAMP
+__device__ unsigned long long* g_mm_stamp = nullptr;
+constexpr int kStampStages = 60, kStampItems = 20;
+constexpr int kStampPerWave = 4 + 5 * kStampStages + 2 * kStampItems;
+#define STAMP_ST(k_) do { if (stamp && lane == 0 && nst < kStampStages) stamp[4 + 5 * nst + (k_)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define STAMP_IT(k_) do { if (stamp && lane == 0 && nit < kStampItems) stamp[4 + 5 * kStampStages + 2 * nit + (k_)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define STAMP_ST(k_) do { } while (0)
+#define STAMP_IT(k_) do { } while (0)
+#endif
+
 template <int KC, int NC, int HW, int IN_POOLED, int EPI>
 __global__ __launch_bounds__(512, 2) void conv_mm_kernel(const MmJobs jt, const void* __restrict__ zeros) {
   using G = Geo<NC>;
   constexpr int NB = G::NB, TPS = G::TPS, NSTG = G::NSTG, WSTAGE = G::WSTAGE, WPIECES = G::WPIECES;
   constexpr int NCHUNK = KC / 32;
+  constexpr bool RES = filter_resident<KC, NC>();
+  constexpr int STG_OFF = W_OFF + (RES ? 3 : 2) * WSTAGE;
   constexpr int RPX = HW / 16, RPI = RPX * RPX;
   static_assert(!IN_POOLED || NSTG >= 2, "the pooled scatter runs in the second stage of a chunk");
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -244,6 +285,11 @@ __global__ __launch_bounds__(512, 2) void conv_mm_kernel(const MmJobs jt, const 
   int item = blockIdx.x;
   const int nitems = jt.start[kMaxJobs];
   if (item >= nitems) return;
+#ifdef UGN_MM_STAMP
+  unsigned long long* stamp = g_mm_stamp ? g_mm_stamp + ((size_t)blockIdx.x * 8 + wave) * kStampPerWave : nullptr;
+  if (stamp && lane == 0) { stamp[0] = __builtin_amdgcn_s_memtime(); stamp[1] = __builtin_amdgcn_s_memrealtime(); }
+  int nst = 0, nit = 0;
+#endif
   int jb = mm_job_of(jt, item), lit = item - jt.start[jb];
 
   auto img_in = [&](const MmJob& J, int img) {      // byte base of image `img` of the input tensor (+ its argmax map)
@@ -268,7 +314,7 @@ __global__ __launch_bounds__(512, 2) void conv_mm_kernel(const MmJobs jt, const 
       const char* ib = img_idx(J, img);
 #pragma unroll
       for (int j = 0; j < STG_PIECES / 4; ++j)
-        dma_pooled_piece<KC, HW>(vb, ib, zeros, ry0, rx0, chunk, rw * (STG_PIECES / 4) + j, lane, sbase + W_OFF + 2 * WSTAGE);
+        dma_pooled_piece<KC, HW>(vb, ib, zeros, ry0, rx0, chunk, rw * (STG_PIECES / 4) + j, lane, sbase + STG_OFF);
     } else {
       const char* vb = img_in(J, img);
 #pragma unroll
@@ -285,17 +331,41 @@ __global__ __launch_bounds__(512, 2) void conv_mm_kernel(const MmJobs jt, const 
     }
   };
 
-  // ---- prologue: input tile of (item, chunk 0) -> halo buffer 0, filter stage 0 -> filter buffer 0
-  if (is_hw) {
+  // RES: every wave fetches a sixth ... eighth of an input tile (6 pieces; pooled input: 2 staging pieces)
+  int hpk[RES && !IN_POOLED ? 6 : 1];
+  if constexpr (RES && !IN_POOLED) {
+#pragma unroll
+    for (int j = 0; j < 6; ++j) hpk[j] = halo_lane_of<KC, HW>(wave * 6 + j, lane);
+  }
+  auto res_piece = [&](const MmJob& J, int lit_, unsigned halo_dst, int j) {     // piece j (0..5; pooled 0..1) of this wave
+    const int img = lit_ / RPI, rrem = lit_ % RPI;
+    const int ry0 = (rrem / RPX) * 16, rx0 = (rrem % RPX) * 16;
+    if constexpr (IN_POOLED) {
+      dma_pooled_piece<KC, HW>(img_in(J, img), img_idx(J, img), zeros, ry0, rx0, 0, wave * 2 + j, lane, sbase + STG_OFF);
+    } else {
+      dma_halo_lane<HW>(img_in(J, img) + (size_t)(ry0 * HW + rx0) * (KC * 4), zeros, ry0, rx0, hpk[RES && !IN_POOLED ? j : 0],
+                        halo_dst + (unsigned)(wave * 6 + j) * 1024u);
+    }
+  };
+  // ---- prologue: input tile of (item, chunk 0) -> halo buffer 0, filter stage 0 -> filter buffer 0 (RES: the whole filter)
+  if constexpr (RES) {
+#pragma unroll
+    for (int j = 0; j < (IN_POOLED ? 2 : 6); ++j) res_piece(jt.job[jb], lit, sbase, j);
+    if (!is_hw) {
+#pragma unroll
+      for (int d = 0; d < 3; ++d) stage_w(jt.job[jb].wpk, d, sbase + W_OFF + (unsigned)d * WSTAGE);
+    }
+  } else if (is_hw) {
 #pragma unroll
     for (int k = 0; k < HSTG; ++k) stage_in(jt.job[jb], lit, 0, sbase, k * HPER, HPER);
   } else {
     stage_w(jt.job[jb].wpk, 0, sbase + W_OFF);
   }
+  int res_job = jb;                 // RES: the job whose filter is in LDS
   if constexpr (IN_POOLED) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    scatter_pooled(smem + W_OFF + 2 * WSTAGE, smem, tid);
+    scatter_pooled(smem + STG_OFF, smem, tid);
   }
   int hbuf = 0, wbuf = 0;
   bool first_item = true;
@@ -329,6 +399,77 @@ __global__ __launch_bounds__(512, 2) void conv_mm_kernel(const MmJobs jt, const 
     constexpr bool ACTPF = EPI == EPI_DGRAD_ACT && NB >= 2;
     unsigned actv[ACTPF ? NB / 2 : 1][16];
 
+    if constexpr (RES) {
+      // ---- one chunk, the filter resident: ONE barrier per item, no filter traffic, the next tile's pieces issued between
+      // the taps (the three-stage form spent 55 % of an item waiting for 12-KB filter stages, at barriers and issuing pieces:
+      // tools/stamp_mm.py, profiles/r03_stage_stamps.txt)
+      bool w_fresh = false;
+      if (jb != res_job) {            // (at most twice per workgroup) every wave has left the previous job's taps
+        __syncthreads();
+        if (!is_hw) {
+#pragma unroll
+          for (int d = 0; d < 3; ++d) stage_w(jt.job[jb].wpk, d, sbase + W_OFF + (unsigned)d * WSTAGE);
+        }
+        res_job = jb;
+        w_fresh = true;
+      }
+      STAMP_ST(0);
+      // The tile of this item was issued during the previous item's taps, BEFORE that item's epilogue stores: vmcnt retires in
+      // issue order, so waiting until at most the stores are outstanding waits for the tile and for none of the stores (a
+      // lower bound of their number is enough: more outstanding operations only make the wait stricter).  Pooled input: the
+      // staging tile was awaited before its scatter.
+      constexpr int EPI_STORES = EPI == EPI_LRELU_POOL ? 8 : 16;       // per wave, one block: 4 windows x (value + argmax) / 16 pixels
+      if (first_item || w_fresh) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else if constexpr (!IN_POOLED) {
+        static_assert(EPI_STORES == 8 || EPI_STORES == 16, "vmcnt immediate");
+        if constexpr (EPI_STORES == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+      }
+      STAMP_ST(1);
+      __syncthreads();
+      STAMP_ST(2);
+      if constexpr (IN_POOLED) {
+        if (more) {
+#pragma unroll
+          for (int j = 0; j < 2; ++j) res_piece(jt.job[jn], nlit, 0u, j);
+        }
+      }
+      STAMP_ST(3);
+      const int a_addr = a_lane + hbuf * HALO_BYTES;
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const int dy = tap / 3, dx = tap % 3;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          const int aoff = (dy * HROW + dx * 9) * 16 + s * 32;
+          const uint4 ah = *reinterpret_cast<const uint4*>(smem + a_addr + aoff);
+          const uint4 al = *reinterpret_cast<const uint4*>(smem + a_addr + aoff + 64);
+          const uint4 bh = *reinterpret_cast<const uint4*>(smem + b_lane + ((tap * 2 + s) * 2 + 0) * 1024);
+          const uint4 bl = *reinterpret_cast<const uint4*>(smem + b_lane + ((tap * 2 + s) * 2 + 1) * 1024);
+          acc[0] = mfma_h(ah, bh, acc[0]);
+          acc[0] = mfma_h(ah, bl, acc[0]);
+          acc[0] = mfma_h(al, bh, acc[0]);
+        }
+        if constexpr (!IN_POOLED) {
+          if (tap < 6 && more) {
+            __builtin_amdgcn_sched_barrier(0);
+            res_piece(jt.job[jn], nlit, sbase + (unsigned)(hbuf ^ 1) * HALO_BYTES, tap);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        } else {
+          if (tap == 4 && more) {     // MaxPool backward of the next tile: staging (issued above) -> the other halo buffer
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            scatter_pooled(smem + STG_OFF, smem + (hbuf ^ 1) * HALO_BYTES, tid);
+          }
+        }
+      }
+      hbuf ^= 1;
+      STAMP_ST(4);
+#ifdef UGN_MM_STAMP
+      ++nst;
+#endif
+    } else {
 #pragma unroll 1
     for (int chunk = 0; chunk < NCHUNK; ++chunk) {
       const bool last_chunk = chunk + 1 == NCHUNK;
@@ -342,10 +483,13 @@ __global__ __launch_bounds__(512, 2) void conv_mm_kernel(const MmJobs jt, const 
         // What this stage reads must have landed: the filter stage (issued a stage ago by waves 0..3), in the first stage of
         // a chunk the input tile (issued a chunk ago by waves 4..7), before the pooled scatter the staging tile.  The first
         // stage of every item but the first was awaited BEFORE the previous item's epilogue (see there).
+        STAMP_ST(0);
         if (!(sg == 0 && chunk == 0 && !first_item)) {
           if ((!is_hw && !(UGN_MM_ABLATE & 16)) || sg == 0 || (IN_POOLED && sg == NSTG - 1)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
+        STAMP_ST(1);
         __syncthreads();                                     // ... and is visible; the other buffers have no readers left
+        STAMP_ST(2);
         if constexpr (ACTPF) {
           if (sg == NSTG - 1 && last_chunk) {
             const char* act = reinterpret_cast<const char*>(jt.job[jb].act) + (size_t)img * HW * HW * NC * 4;
@@ -370,8 +514,9 @@ __global__ __launch_bounds__(512, 2) void conv_mm_kernel(const MmJobs jt, const 
             stage_in(jt.job[nx_job], n_lit, n_chunk, sbase + (unsigned)(hbuf ^ 1) * HALO_BYTES, sg * HPER, HPER);
         }
         if constexpr (IN_POOLED) {   // MaxPool backward of the next tile, staging -> the other halo buffer
-          if (sg == NSTG - 1 && next_tile) scatter_pooled(smem + W_OFF + 2 * WSTAGE, smem + (hbuf ^ 1) * HALO_BYTES, tid);
+          if (sg == NSTG - 1 && next_tile) scatter_pooled(smem + STG_OFF, smem + (hbuf ^ 1) * HALO_BYTES, tid);
         }
+        STAMP_ST(3);
         const int b_addr = b_lane + wbuf * WSTAGE;
 #pragma unroll
         for (int t = 0; t < TPS; ++t) {
@@ -396,12 +541,18 @@ __global__ __launch_bounds__(512, 2) void conv_mm_kernel(const MmJobs jt, const 
           }
         }
         wbuf ^= 1;
+        STAMP_ST(4);
+#ifdef UGN_MM_STAMP
+        ++nst;
+#endif
       }
       hbuf ^= 1;
     }
+    }
     // The next item's first filter stage and input tile are awaited HERE, before this item's stores enter the queue: the
     // first stage of the next item then needs no wait, and the stores have a whole stage to be acknowledged.
-    if (more) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (more && !(RES && !IN_POOLED)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (RES: awaited at the top of the next item)
+    STAMP_IT(0);
     first_item = false;
 
     // ---- epilogue.  acc[nb][4g + i] of lane (col c = lane & 31, half h): window 2g + h, position i of the wave's 8 windows,
@@ -512,9 +663,16 @@ __global__ __launch_bounds__(512, 2) void conv_mm_kernel(const MmJobs jt, const 
         }
       }
     }
+    STAMP_IT(1);
+#ifdef UGN_MM_STAMP
+    ++nit;
+#endif
     jb = jn;
     lit = nlit;
   }
+#ifdef UGN_MM_STAMP
+  if (stamp && lane == 0) { stamp[2] = __builtin_amdgcn_s_memtime(); stamp[3] = __builtin_amdgcn_s_memrealtime(); }
+#endif
   // one atomicMax per WORKGROUP for the job it ends with (not per item or wave: atomics on one address serialise at ~10 ns
   // each; 230 k of them cost a 64x64 layer a millisecond).  No DMA is in flight any more: any LDS serves as scratch.
   h2_publish_amax_block(jt.job[meta_jb].out_meta, mx, reinterpret_cast<float*>(smem), tid, 8);
@@ -528,7 +686,7 @@ int g_persistent_wgs = kGrid;
 template <int KC, int NC, int HW, int IN_POOLED, int EPI>
 int launch_mm(const MmJob* jobs, const int* n, int njobs, hipStream_t st) {
   auto kern = conv_mm_kernel<KC, NC, HW, IN_POOLED, EPI>;
-  constexpr int LDS = lds_bytes<NC, IN_POOLED>();
+  constexpr int LDS = lds_bytes<KC, NC, IN_POOLED>();
   static_assert(LDS <= 163840, "LDS budget");
   static bool attr_done = false;
   if (!attr_done) {
@@ -618,6 +776,13 @@ const void* ugn_mm::zero_block() {
   }
   return z;
 }
+
+#ifdef UGN_MM_STAMP
+extern "C" int ugn_mm_debug_stamps(void* buf) {
+  unsigned long long* p = (unsigned long long*)buf;
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_mm_stamp), &p, sizeof(p));
+}
+#endif
 
 extern "C" int ugn_set_persistent_wgs(int n) {
   UGN_REQUIRE(n == 0 || (n >= 8 && n <= kGrid), "ugn_set_persistent_wgs: 8..%d workgroups, or 0 for the default (got %d)", kGrid, n);
