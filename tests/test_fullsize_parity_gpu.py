@@ -92,8 +92,15 @@ def test_whole_step_matches_the_fp64_oracle(dev, name):
             worst["m%d.%s" % (mi, k)] = _rell2(got["branches"][mi][k], ref.numpy())
     for k, ref in g["head"].items():
         worst["head." + k] = _rell2(got["head"][k], ref.numpy())
-    bad = {k: v for k, v in worst.items() if v > (4e-1 if bf16 else 5e-3)}   # (bf16 at full size: 0.30 on the flow branch's first layer, routing flips included)
+    # bf16 at full size (measured): 0.09 ... 0.15 on the gray / silhouette branches, 0.14 ... 0.30 on the optical-flow branch, 0.02 on
+    # the classifier: decision flips of the losses and of the routing at 8 significant bits included (tests/test_engine_gpu.py
+    # test_branch_gradients_with_a_fixed_cotangent separates the branches from the losses)
+    bad = {k: v for k, v in worst.items() if v > ((3.5e-1 if k.startswith("m0.") else 2.5e-1) if bf16 else 5e-3)}
+    if bf16:
+        assert float(np.median(list(worst.values()))) <= 1.5e-1 and worst["head.wc"] <= 5e-2, worst
     assert not bad, (bad, worst)
+    if bf16:
+        print("%s gradient rel-L2 per tensor: %s" % (name, ", ".join("%s %.3f" % kv for kv in sorted(worst.items(), key=lambda kv: -kv[1]))))
     print("%s: loss %.6f (oracle %.6f), max |sig - oracle| %.2e, worst gradient rel-L2 %.2e (%s)"
           % (name, ls["loss"], float(res["loss"]), np.abs(sig - res["signature"].detach().numpy()).max(),
              max(worst.values()), max(worst, key=worst.get)))
