@@ -188,7 +188,9 @@ __global__ __launch_bounds__(256, UGN_C5_WAVES) void conv5x5_fwd_kernel(const fl
       }
     }
   }
-  if constexpr (H2OUT) ugn_mm::h2_publish_amax(out_meta, ugn_mm::wave_max(h2_mx), lane);
+  // one atomicMax per WORKGROUP (through sP; the helper's first barrier ends the last tile's reads of it): one per wave -- 4,096
+  // atomics on one address -- was a fixed 50 us at the end of every launch of this kernel
+  if constexpr (H2OUT) ugn_mm::h2_publish_amax_block(out_meta, h2_mx, sP, tid, 4);
 }
 
 // global -> LDS without a VGPR destination (LDS address = M0 + lane * 16 or + lane * 4); see conv3x3_wino.hip for why asm

@@ -83,6 +83,9 @@ def _branch_stream(device, mi):
     return st
 
 
+PACK_ON_SIDE_STREAM = os.environ.get("UGN_PACK_SIDE", "1") != "0"      # (experiments: 0 = repack on the main stream, after Adam)
+
+
 @contextlib.contextmanager
 def serial_launches():
     """Every launch on ONE stream (no weight-gradient / branch / forward side streams) while the context is active: the
@@ -591,6 +594,9 @@ class GaitCore:
             self.meta_pool = h2.MetaPool(self.device, 64 * self.nmod)
             for enc in self.encoders:
                 enc.h2 = H2State(enc, self.meta_pool)
+        self._pack_pending = False      # a filter repack is running on the second stream (apply_gradients)
+        for enc in self.encoders:
+            enc.before_conv3 = self._before_conv3
         self.scratch = {}
         self.bufs = {}
         self._tri_cache = {}
@@ -609,6 +615,12 @@ class GaitCore:
             shape = self.store.shapes[name]
             self.store.set(name, np.zeros(shape, np.float32) if name.endswith(".bc") else glorot_uniform(gen, shape))
         self.weights_changed()
+
+    def _before_conv3(self):
+        """Called by forward_h2 / forward_bf between the 5x5 layer and the first 3x3 layer."""
+        if self._pack_pending:
+            torch.cuda.current_stream(self.device).wait_stream(_wgrad_stream(self.device))
+            self._pack_pending = False
 
     def weights_changed(self):
         if self.h2:          # f16 halves + block exponent + L1 bound of every 3x3 filter, both directions: two launches
@@ -920,7 +932,14 @@ class GaitCore:
             ops.adam_step(st.flat[lo:hi], st.grad[lo:hi], st.m[lo:hi], st.v[lo:hi], lr_t, self.beta_1, self.beta_2, self.epsilon, scale)
             return                      # (the convolution filters did not change: no repack)
         ops.adam_step(st.flat, st.grad, st.m, st.v, lr_t, self.beta_1, self.beta_2, self.epsilon, scale)
-        self.weights_changed()
+        if (self.h2 or self.bf) and WGRAD_STREAM and PACK_ON_SIDE_STREAM and not torch.cuda.is_current_stream_capturing():
+            # the repack of the 3x3 filters (3 launches, ~50 us whatever the batch) runs on the second stream, beside the next
+            # step's input copies and 5x5 layer; the first 3x3 layer waits for it (`_before_conv3`)
+            with _side(self.device):
+                self.weights_changed()
+            self._pack_pending = True
+        else:
+            self.weights_changed()
 
     def train_step(self, xs, uses, labels, onehot):
         self.forward_backward(xs, uses, labels, onehot)

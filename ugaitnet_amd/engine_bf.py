@@ -63,6 +63,9 @@ def forward_bf(encs, xs):
         s.x = xf
     a1s = [bf16.conv5x5_in_fwd(xfs[i], encs[i].W("a1"), S[i].t("a1", (geo[i][2], 64, 64, 32)),
                                sign=S[i].t("a1s", (geo[i][2], 64, 64), I32)) for i in R]
+    hook = getattr(encs[0], "before_conv3", None)     # (the packed 3x3 filters: repacked beside the 5x5 layer, engine.apply_gradients)
+    if hook is not None:
+        hook()
     p2s = [S[i].t("p2", (geo[i][2], 32, 32, 32)) for i in R]
     i2s = [S[i].t("i2", (geo[i][2], 32, 32, 32), U8) for i in R]
     bf16.conv3x3_fwd_multi(a1s, [s.wf("a2") for s in S], 32, True, p2s, i2s)

@@ -85,6 +85,9 @@ def forward_h2(encs, xs):
     h2.absmax_multi(xfs, [s.slot("x") for s in S])
     a1s = [h2.conv5x5_in_fwd_h2(xfs[i], S[i].slot("x"), encs[i].W("a1"), S[i].t("a1", (geo[i][2], 64, 64, 32)),
                                 sign=S[i].f32("a1s", (geo[i][2], 64, 64), I32)) for i in R]
+    hook = getattr(encs[0], "before_conv3", None)     # (the packed 3x3 filters: repacked beside the 5x5 layer, engine.apply_gradients)
+    if hook is not None:
+        hook()
     p2s = [S[i].t("p2", (geo[i][2], 32, 32, 32)) for i in R]
     i2s = [S[i].f32("i2", (geo[i][2], 32, 32, 32), U8) for i in R]
     h2.conv3x3_fwd_mm_multi(a1s, [s.wf("a2")[0] for s in S], [s.wf("a2")[1] for s in S], 32, True, p2s, i2s)
