@@ -203,6 +203,9 @@ def roofline_pass(core, batch, steps, dtype, table_path=""):
         elif w and w["bound"] == "hbm":
             d.update(bound="hbm", unit="GB/s", peak=PEAK_HBM / 1e9, achieved=round(w["bytes"] / avg / 1e3, 1),
                      frac=round(w["bytes"] / (avg * 1e-6) / PEAK_HBM, 4), rocprof_kernel=w["kernel"])
+            if w.get("mfma_flops"):      # (bf16 3x3 layers: HBM first, the matrix pipe second)
+                d.update(mfma_tflops=round(w["mfma_flops"] / avg / 1e6, 2), mfma_frac=round(w["mfma_flops"] / (avg * 1e-6) / PEAK_BF16_MFMA, 4),
+                         images_per_launch=w.get("images"))
         return d
     if table_path:
         with open(table_path, "w") as f:
@@ -220,7 +223,8 @@ def roofline_pass(core, batch, steps, dtype, table_path=""):
                    "launch on one stream, HIP-event pairs on that stream); achieved = FLOPs EXECUTED on the matrix pipe / avg "
                    "duration, against the peak of the instruction that executes them: f16x2 kernels run three f16 MFMAs per "
                    "fp32-class product (3x the direct-convolution count `algorithmic_tflops`, dense f16/bf16 peak); Winograd "
-                   "F(2x2,3x3) fp32 kernels 16/36 of it (fp32-MFMA peak)" % steps)
+                   "F(2x2,3x3) fp32 kernels 16/36 of it (fp32-MFMA peak); HBM-bound kernels (and every bf16 3x3 kernel: mfma_frac "
+                   "is their second figure): algorithmic bytes / avg duration against 8 TB/s" % steps)
     # `traffic` is NOT measured in this run: it is the PMC figure (FETCH_SIZE x2-corrected + WRITE_SIZE, separate --pmc passes) of
     # the same kernel and launch size recorded by tools/profile_run.sh; absent (null) when no record matches
     for tname in ("roofline_traffic_%s.json" % dtype, "roofline_traffic.json"):

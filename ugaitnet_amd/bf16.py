@@ -88,7 +88,17 @@ def _work(kind, hw, cin, cout, pooled, ns, act=False):
     else:
         kern = "wgrad_bf_kernel<%d, %d, %d, %d>" % (cin, cout, hw, int(pooled))
     label = "conv3x3_%s[%d->%d @%dx%d%s bf16] %s" % (kind, cin, cout, hw, hw, " pooled" if pooled else "", kern)
-    return label, dict(flops=flops, mfma_flops=flops, bytes=None, kernel=kern, bound="mfma", images=n, dtype="bf16")
+    # Algorithmic HBM bytes (every tensor once): bf16 tensors at 2 B per element, argmax maps 1 B, fp32 weight
+    # gradients negligible.  With bf16 operands the 3x3 layers sit far below the matrix roof (10-40 % busy): the HBM rate is the
+    # figure bench.py reports first for them, the MFMA fraction second.
+    full, pool_ = hw * hw, (hw // 2) * (hw // 2)
+    if kind == "fwd":       # in: full-resolution input; out: (pooled) output (+ argmax bytes)
+        nbytes = n * (full * cin * 2 + (pool_ * cout * 3 if pooled else full * cout * 2))
+    elif kind == "dgrad":   # in: (pooled) output gradient (+ argmax bytes) (+ the activation for LeakyReLU'); out: input gradient
+        nbytes = n * ((pool_ * cout * 3 if pooled else full * cout * 2) + full * cin * 2 + (full * cin * 2 if act else 0))
+    else:                   # in: input + (pooled) output gradient (+ argmax bytes)
+        nbytes = n * (full * cin * 2 + (pool_ * cout * 3 if pooled else full * cout * 2))
+    return label, dict(flops=flops, mfma_flops=flops, bytes=float(nbytes), kernel=kern, bound="hbm", images=n, dtype="bf16")
 
 
 def conv3x3_fwd_multi(xs, wpks, cout, pool, outs, idxs=None):
