@@ -25,6 +25,10 @@ using ugn_mm::H2Meta;
 #ifndef UGN_C5_DS
 #define UGN_C5_DS 32     // floats per pixel of the gradient tile in LDS (36 = padded, the earlier layout)
 #endif
+// pixels per patch row of the weight-gradient kernel's LDS tile.  Two input channels: 21 -- the lanes of an MFMA row block are
+// (tap, channel) pairs, four tap rows of ten floats each: a row stride of 42 floats puts them on forty distinct banks (40 is a
+// 2-way conflict: SQ_LDS_BANK_CONFLICT 0.37 of the active cycles), for one more 256-byte DMA piece in 14.
+constexpr int c5_pitch(int cin) { return cin == 2 ? 21 : UGN_C5_PITCH; }
 constexpr int T5 = 16;          // 16x16 output tile
 constexpr int P5 = T5 + 4;      // 20x20 input patch
 constexpr int RAW = 60, DOM = 64;
@@ -62,7 +66,11 @@ __global__ __launch_bounds__(256, UGN_C5_WAVES) void conv5x5_fwd_kernel(const fl
   constexpr int K = 25 * CIN, KP = (K + 1) / 2;  // k-pairs
   constexpr int PE = P5 * P5;                     // patch pixels
   constexpr int PPT = (PE + 255) / 256;           // patch pixels per thread (2)
-  __shared__ __attribute__((aligned(16))) float sP[PE * CIN];
+  // Floats per patch row in LDS.  A lane half reads 2 rows x 16 pixels (x its channel): with the natural pitch (20 / 40 floats) the
+  // second row falls on banks the first one uses (SQ_LDS_BANK_CONFLICT 0.33-0.36 of the active cycles); 48
+  // (= 16 mod 32) and 41 (odd) put it on the other sixteen.
+  constexpr int FP = CIN == 1 ? 48 : 41;
+  __shared__ __attribute__((aligned(16))) float sP[P5 * FP];
   __shared__ __attribute__((aligned(16))) float sW[2 * KP * 32];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
@@ -109,7 +117,7 @@ __global__ __launch_bounds__(256, UGN_C5_WAVES) void conv5x5_fwd_kernel(const fl
   const int py = (li >> 1) & 1, px = 2 * (li >> 2) + (li & 1);
   int pb[2];
 #pragma unroll
-  for (int m = 0; m < 2; ++m) pb[m] = ((2 * (wave * 2 + m) + py) * P5 + px) * CIN + (CIN == 2 ? lh : 0);
+  for (int m = 0; m < 2; ++m) pb[m] = (2 * (wave * 2 + m) + py) * FP + px * CIN + (CIN == 2 ? lh : 0);
 
   int tile = blockIdx.x;
   if (tile < ntiles) fetch(tile);
@@ -119,7 +127,7 @@ __global__ __launch_bounds__(256, UGN_C5_WAVES) void conv5x5_fwd_kernel(const fl
     for (int j = 0; j < PPT; ++j)
       if (tid + 256 * j < PE) {
 #pragma unroll
-        for (int c = 0; c < CIN; ++c) sP[(tid + 256 * j) * CIN + c] = pv[j][c];
+        for (int c = 0; c < CIN; ++c) sP[pyy[j] * FP + pxx[j] * CIN + c] = pv[j][c];
       }
     __syncthreads();
     const int nt = tile + (int)gridDim.x;
@@ -135,10 +143,10 @@ __global__ __launch_bounds__(256, UGN_C5_WAVES) void conv5x5_fwd_kernel(const fl
     for (int s = 0; s < KP; ++s) {
       int off;
       if constexpr (CIN == 2) {
-        off = ((s / 5) * P5 + (s % 5)) * 2;  // tap s, channel = lane half
+        off = (s / 5) * FP + (s % 5) * 2;    // tap s, channel = lane half
       } else {
         const int k0 = 2 * s, k1 = (2 * s + 1 < K) ? 2 * s + 1 : K - 1;
-        const int o0 = (k0 / 5) * P5 + (k0 % 5), o1 = (k1 / 5) * P5 + (k1 % 5);
+        const int o0 = (k0 / 5) * FP + (k0 % 5), o1 = (k1 / 5) * FP + (k1 % 5);
         off = lh ? o1 : o0;
       }
       const float b = sW[(2 * s + lh) * 32 + li];
@@ -225,7 +233,7 @@ __global__ __launch_bounds__(256) void conv5x5_wgrad_kernel(const float* __restr
   constexpr int DS = UGN_C5_DS;
   constexpr int SDF = T5 * T5 * DS;                       // floats per gradient buffer (32 KB = 32 pieces of 1 KB)
   // patch rows of WP pixels (UGN_C5_PITCH)
-  constexpr int WP = UGN_C5_PITCH;
+  constexpr int WP = c5_pitch(CIN);
   constexpr int PE = P5 * WP * CIN, PPIECES = (PE + 63) / 64, SPF = PPIECES * 64;   // patch dwords, 256-B pieces
   constexpr bool H2DZ = DZFMT == 1, BFDZ = DZFMT == 2;
   constexpr int DPW = BFDZ ? 4 : DS / 4, PPW = (PPIECES + 3) / 4;    // pieces per wave
@@ -460,7 +468,7 @@ static int conv5x5_wgrad_any(const float* x, const float* dz1, const H2Meta* dz_
                 "ugn_conv5x5_in_wgrad: cannot allocate the zero block");
     zeros = p;
   }
-  const int lds = (2 * 256 * UGN_C5_DS + 2 * ((20 * UGN_C5_PITCH * cin + 63) / 64) * 64 + 2 * 256) * 4;
+  const int lds = (2 * 256 * UGN_C5_DS + 2 * ((20 * c5_pitch(cin) * cin + 63) / 64) * 64 + 2 * 256) * 4;
   static bool attr_done[3] = {false, false, false};
   if (!attr_done[cin]) {
     const void* fns[12] = {(const void*)conv5x5_wgrad_kernel<1, false>, (const void*)conv5x5_wgrad_kernel<1, true>,
