@@ -109,7 +109,9 @@ def test_bf16_multi_job_and_first_layer(dev):
     dw_ref, _ = O.conv2d_same_bwd(xf, w.astype(np.float64), dz * np.where(bits, 1.0, 0.3), need_dx=False)
     dw = torch.empty((5, 5, c1, 32), device=dev)
     bf16.conv5x5_in_wgrad(T(x, dev), bf16.from_f32(T(dz.astype(np.float32), dev)), dw, sign=sign)
-    close(dw.cpu().numpy(), dw_ref, 5e-6, "conv5x5 wgrad bf16")
+    # (both operands of the bf16 MFMA are rounded to bf16: the patch values and gradient x LeakyReLU' -- 8 significant bits, as in every
+    #  other layer of this path; the fp32-MFMA form of the round's first half met 5e-6 here)
+    close(dw.cpu().numpy(), dw_ref, 2.0 ** -8, "conv5x5 wgrad bf16")
 
 
 def test_bf16_set_pooling_and_friends(dev):

@@ -119,6 +119,31 @@ __global__ __launch_bounds__(256, UGN_C5_WAVES) void conv5x5_fwd_kernel(const fl
 #pragma unroll
   for (int m = 0; m < 2; ++m) pb[m] = (2 * (wave * 2 + m) + py) * FP + px * CIN + (CIN == 2 ? lh : 0);
 
+  // bf16 output (configs[4]): the layer runs on v_mfma_f32_32x32x16_bf16 -- operands rounded to bf16 like every other layer of that
+  // path, fp32 accumulate.  K = 25 * CIN taps in k-steps of 16: a lane (pixel li, k half lh) gathers its 8 taps of a k-step from the
+  // fp32 patch (offsets fixed per lane), the filter fragments (8 x bf16 per k-step) stay in registers.  2 / 4 MFMAs of 32 cycles per
+  // 32-pixel block instead of 13 / 25 fp32 MFMAs of 64 cycles that block the vector pipe.
+  typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+  constexpr bool BFMM = OFMT == 2;
+  constexpr int KS = (K + 15) / 16;
+  int goff[BFMM ? KS : 1][8];
+  bf8 wfrag[BFMM ? KS : 1];
+  int pbb[2];
+  if constexpr (BFMM) {
+    __syncthreads();            // sW is complete
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int k = 16 * ks + 8 * lh + i;
+        const int tap = k / CIN, ch = k % CIN;
+        goff[ks][i] = k < K ? (tap / 5) * FP + (tap % 5) * CIN + ch : 0;
+        wfrag[ks][i] = (__bf16)(k < K ? sW[k * 32 + li] : 0.f);
+      }
+#pragma unroll
+    for (int m = 0; m < 2; ++m) pbb[m] = (2 * (wave * 2 + m) + py) * FP + px * CIN;
+  }
+
   int tile = blockIdx.x;
   if (tile < ntiles) fetch(tile);
   for (; tile < ntiles; tile += gridDim.x) {
@@ -139,6 +164,17 @@ __global__ __launch_bounds__(256, UGN_C5_WAVES) void conv5x5_fwd_kernel(const fl
     for (int m = 0; m < 2; ++m)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+    if constexpr (BFMM) {
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+          bf8 a;
+#pragma unroll
+          for (int i = 0; i < 8; ++i) a[i] = (__bf16)sP[pbb[m] + goff[ks][i]];
+          acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, wfrag[ks], acc[m], 0, 0, 0);
+        }
+    } else
 #pragma unroll
     for (int s = 0; s < KP; ++s) {
       int off;
@@ -312,6 +348,39 @@ __global__ __launch_bounds__(256) void conv5x5_wgrad_kernel(const float* __restr
     issue_dma(nt < tiles_total ? nt : tile, buf ^ 1);   // branch-free: past the end the current tile is fetched again
     const float* sD = sD0 + buf * SDF;
     const float* sP = sP0 + buf * SPF;
+    if constexpr (BFDZ) {
+      // bf16 gradient (configs[4]): v_mfma_f32_32x32x16_bf16 with K = 16 pixels (one tile row) per step -- the wave's 64 pixels are
+      // 4 MFMAs per row block instead of 32 fp32 ones.  A = the patch values under the lane's (tap, channel) at 8 consecutive
+      // pixels, rounded to bf16; B = the gradient of 8 consecutive pixels of channel li: two transposed reads of the [pixel][32]
+      // tile (as wgrad3x3_bf.hip), times LeakyReLU'(a1) from the sign words.
+      typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+      typedef short s4v __attribute__((ext_vector_type(4)));
+      const int gh = (lane >> 4) & 1, tq = (lane >> 2) & 3, tp = lane & 3;
+      const __attribute__((address_space(3))) char* dzl = (const __attribute__((address_space(3))) char*)sD +
+                                                          (wave * 64 + 8 * lh + tq) * 64 + (16 * gh + 4 * tp) * 2;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const s4v t0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4v*)(dzl + ks * 1024));
+        const s4v t1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4v*)(dzl + ks * 1024 + 256));
+        bf8 bfrag;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          float g = __uint_as_float((unsigned)(unsigned short)(i < 4 ? t0[i] : t1[i - 4]) << 16);
+          if constexpr (SIGN) {
+            const uint32_t wbits = sS0[buf * 256 + wave * 64 + ks * 16 + 8 * lh + i];
+            g *= ((wbits >> li) & 1u) ? 1.f : UGN_LRELU_ALPHA;
+          }
+          bfrag[i] = (__bf16)g;
+        }
+#pragma unroll
+        for (int mb = 0; mb < MBK; ++mb) {
+          bf8 afrag;
+#pragma unroll
+          for (int i = 0; i < 8; ++i) afrag[i] = (__bf16)sP[abase[mb] + (ks * WP + 8 * lh + i - lh) * CIN];
+          acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, bfrag, acc[mb], 0, 0, 0);
+        }
+      }
+    } else
 #pragma unroll
     for (int kp = 0; kp < 32; ++kp) {  // wave's 64 pixels: p = 2*kp + lh, row = p/16, col = p%16
       const int po = ((2 * kp) / 16) * WP + ((2 * kp) % 16);
