@@ -133,6 +133,10 @@ def build_parser():
                     help="run the timed region itself with every launch on one stream (the rocprofv3 kernel-trace target: "
                          "per-kernel durations are then clean); never the headline")
     ap.add_argument("--no-roofline-pass", action="store_true", help="skip the serialised per-kernel timing pass")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay the step as captured hipGraphs (engine.GraphedTrainStep: same kernels, no per-launch host cost); "
+                         "for host-bound set-ups.  Measured on one MI355X box: NOT faster -- 5 clips 2.13 ms against 1.96 eager, 24 "
+                         "clips 6.56 against 6.35 (the replay has one forward chain and no repack beside the 5x5 layer)")
     ap.add_argument("--kernel-table", default="", help="write every row of the serialised per-kernel pass to this CSV file")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed and run the gradient collectives even with one rank (rehearses the RCCL "
@@ -326,12 +330,15 @@ def run(args):
         torch.cuda.synchronize()
 
     def timed(c, bt):
+        step = c.train_step
+        if args.graph and not c.skip_masked:       # (the mask-skipping secondary run launches by the batch's masks: eager)
+            step = engine.GraphedTrainStep(c, *bt).step
         for _ in range(args.warmup):
-            c.train_step(*bt)
+            step(*bt)
         sync_all()
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            c.train_step(*bt)
+            step(*bt)
         sync_all()
         dt = time.perf_counter() - t0
         if world > 1:
@@ -395,7 +402,8 @@ def run(args):
                                launch_schedule="serial (one stream)" if args.serial else
                                ("one launch per layer for all modalities (frame-level layer + set-level twin as jobs of one "
                                 "launch): forward = one chain on the main stream; weight gradients on a second stream beside the "
-                                "data gradients; head forward beside the triplet kernel")),
+                                "data gradients; head forward beside the triplet kernel; filter repack on the second stream beside "
+                                "the next step's 5x5 layer") + ("; replayed as two captured hipGraphs (--graph)" if args.graph else "")),
                    whole_step_tflops=round(value * fpc / 1e12, 2),
                    whole_step_frac_of_matrix_peak=round(value * fpc * exec_factor / world / exec_peak, 4),
                    loss=round(losses["loss"], 5), roofline=roof)
