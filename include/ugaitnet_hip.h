@@ -195,6 +195,10 @@ int ugn_binfc_bwd(const float* feat, const float* w, const float* dout, float* d
 int ugn_binfc_fwd_multi(const float* const* feat, const float* const* w, float* const* out, const int* b, int njobs, void* stream);
 int ugn_binfc_bwd_multi(const float* const* feat, const float* const* w, const float* const* dout, float* const* dw,
                         float* const* dfeat, const int* b, int njobs, void* stream);
+/* the two halves separately: parts = 1 the weight gradient dw only, 2 the feature gradient dfeat only (the one the rest of the
+ * backward pass waits for), 3 both (= ugn_binfc_bwd_multi) */
+int ugn_binfc_bwd_parts_multi(const float* const* feat, const float* const* w, const float* const* dout, float* const* dw,
+                              float* const* dfeat, const int* b, int njobs, int parts, void* stream);
 
 /* ---- gate (:51-54) + fMerge (:814,:1189).  outs/uses: HOST arrays of nmod device pointers; x_m [62,b,256],
  * use_m [b].  fused [62,b,256]; sel uint8 (selected modality). */

@@ -46,6 +46,7 @@ PROTOTYPES = {
     "ugn_hpp_bwd_multi": (_i, [C.POINTER(_p)] * 6 + [C.POINTER(_i), _i, _p]),
     "ugn_binfc_fwd_multi": (_i, [C.POINTER(_p)] * 3 + [C.POINTER(_i), _i, _p]),
     "ugn_binfc_bwd_multi": (_i, [C.POINTER(_p)] * 5 + [C.POINTER(_i), _i, _p]),
+    "ugn_binfc_bwd_parts_multi": (_i, [C.POINTER(_p)] * 5 + [C.POINTER(_i), _i, _i, _p]),
     "ugn_conv3x3_dgrad_wino_routed": (_i, [_p, _p, _p, _p, _p, _i, _p, _i, _i, _i, _i, _p]),
     "ugn_conv3x3_dgrad_wino_pair": (_i, [C.POINTER(_p)] * 7 + [C.POINTER(_i), _i, _i, _i, _p]),
     "ugn_conv3x3_fwd_wino_bf16": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),

@@ -72,6 +72,9 @@ constexpr int FCB_IQ = 32;   // input features per workgroup (grid.y = 128 / FCB
 
 // dW[k][i][o] = sum_b feat[k][b][i] * dout[k][b][o];  dfeat[k][b][i] = sum_o dout[k][b][o] * W[k][i][o].
 // Workgroup (k, iq) owns input features i in [32*iq, 32*iq + 32): 248 workgroups instead of 62.
+// PARTS: 1 = dW only, 2 = dfeat only, 3 = both.  dfeat is on the critical path of the backward pass (HPP backward waits for it), dW is
+// not: the engine launches the two halves on different streams (ugn_binfc_bwd_parts_multi).
+template <int PARTS>
 __global__ __launch_bounds__(256) void binfc_bwd_kernel(const FcJobs jt) {
   const float* __restrict__ feat = jt.feat[blockIdx.z];
   const float* __restrict__ w = jt.w[blockIdx.z];
@@ -85,20 +88,22 @@ __global__ __launch_bounds__(256) void binfc_bwd_kernel(const FcJobs jt) {
   const int k = blockIdx.x, i0 = blockIdx.y * FCB_IQ, tid = threadIdx.x;
   const float* wk = w + ((size_t)k * FEAT + i0) * HID;
   float* dwk = dw + ((size_t)k * FEAT + i0) * HID;
-  for (int e = tid; e < FCB_IQ * HID; e += 256) sW[e / HID][e % HID] = wk[e];
+  if (PARTS & 2)
+    for (int e = tid; e < FCB_IQ * HID; e += 256) sW[e / HID][e % HID] = wk[e];
   for (int b0 = 0; b0 < bsz; b0 += FCB_BT) {
     const int nb = min(FCB_BT, bsz - b0);
     __syncthreads();
-    for (int e = tid; e < FCB_BT * FCB_IQ; e += 256) {
-      const int bb = e / FCB_IQ, i = e % FCB_IQ;
-      sF[bb][i] = bb < nb ? feat[((size_t)k * bsz + b0 + bb) * FEAT + i0 + i] : 0.f;
-    }
+    if (PARTS & 1)
+      for (int e = tid; e < FCB_BT * FCB_IQ; e += 256) {
+        const int bb = e / FCB_IQ, i = e % FCB_IQ;
+        sF[bb][i] = bb < nb ? feat[((size_t)k * bsz + b0 + bb) * FEAT + i0 + i] : 0.f;
+      }
     for (int e = tid; e < FCB_BT * HID; e += 256) {
       const int bb = e / HID, o = e % HID;
       sD[bb][o] = bb < nb ? dout[((size_t)k * bsz + b0 + bb) * HID + o] : 0.f;
     }
     __syncthreads();
-    {   // dW rows of this slice; thread = output feature o
+    if (PARTS & 1) {   // dW rows of this slice; thread = output feature o
       float dreg[FCB_BT];
 #pragma unroll
       for (int bb = 0; bb < FCB_BT; ++bb) dreg[bb] = sD[bb][tid];
@@ -111,7 +116,7 @@ __global__ __launch_bounds__(256) void binfc_bwd_kernel(const FcJobs jt) {
         else dwk[(size_t)i * HID + tid] += acc;
       }
     }
-    {   // dfeat for this slice; thread = (i, sample triple): 32 x 8 threads, 3 samples each
+    if (PARTS & 2) {   // dfeat for this slice; thread = (i, sample triple): 32 x 8 threads, 3 samples each
       const int i = tid & 31, bq = tid >> 5;
       float a0 = 0.f, a1 = 0.f, a2 = 0.f;
 #pragma unroll 8
@@ -603,8 +608,16 @@ extern "C" int ugn_binfc_fwd(const float* feat, const float* w, float* out, int 
   return ugn_binfc_fwd_multi(&feat, &w, &out, &b, 1, stream);
 }
 
+extern "C" int ugn_binfc_bwd_parts_multi(const float* const* feat, const float* const* w, const float* const* dout, float* const* dw,
+                                         float* const* dfeat, const int* b, int njobs, int parts, void* stream);
 extern "C" int ugn_binfc_bwd_multi(const float* const* feat, const float* const* w, const float* const* dout, float* const* dw,
                                    float* const* dfeat, const int* b, int njobs, void* stream) {
+  return ugn_binfc_bwd_parts_multi(feat, w, dout, dw, dfeat, b, njobs, 3, stream);
+}
+
+extern "C" int ugn_binfc_bwd_parts_multi(const float* const* feat, const float* const* w, const float* const* dout, float* const* dw,
+                                         float* const* dfeat, const int* b, int njobs, int parts, void* stream) {
+  UGN_REQUIRE(parts >= 1 && parts <= 3, "ugn_binfc_bwd_parts_multi: parts must be 1 (dW), 2 (dfeat) or 3 (got %d)", parts);
   UGN_REQUIRE(feat && w && dout && dw && dfeat && b && njobs >= 1 && njobs <= kFcJobs,
               "ugn_binfc_bwd_multi: bad arguments (1..%d jobs)", kFcJobs);
   FcJobs jt = {};
@@ -612,7 +625,10 @@ extern "C" int ugn_binfc_bwd_multi(const float* const* feat, const float* const*
     UGN_REQUIRE(feat[j] && w[j] && dout[j] && dw[j] && dfeat[j] && b[j] > 0, "ugn_binfc_bwd_multi: bad job %d", j);
     jt.feat[j] = feat[j]; jt.w[j] = w[j]; jt.dout[j] = dout[j]; jt.out[j] = dw[j]; jt.dfeat[j] = dfeat[j]; jt.b[j] = b[j];
   }
-  hipLaunchKernelGGL(binfc_bwd_kernel, dim3(NBINS, FEAT / FCB_IQ, njobs), dim3(256), 0, (hipStream_t)stream, jt);
+  const dim3 grid(NBINS, FEAT / FCB_IQ, njobs);
+  if (parts == 1) hipLaunchKernelGGL(binfc_bwd_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, jt);
+  else if (parts == 2) hipLaunchKernelGGL(binfc_bwd_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, jt);
+  else hipLaunchKernelGGL(binfc_bwd_kernel<3>, grid, dim3(256), 0, (hipStream_t)stream, jt);
   UGN_CHECK_LAUNCH("binfc_bwd");
   return 0;
 }

@@ -105,8 +105,12 @@ def backward_bf(encs, douts, side):
     R = range(k)
     bs, l0 = [g[0] for g in geo], geo[0][1]
     T = lambda key: [s.bufs[key] for s in S]
-    _, dfeats = ops.binfc_bwd_multi(T("feat"), [e.W("fc") for e in encs], douts, [e.G("fc") for e in encs],
+    fc_args = (T("feat"), [e.W("fc") for e in encs], douts, [e.G("fc") for e in encs],
                                     [S[i].t("dfeat", (NBINS, geo[i][0], FEAT), F32) for i in R])
+    ops.binfc_bwd_multi(*fc_args, parts=2)            # dfeat: the rest of the backward pass waits for it
+    with side(encs[0].store.device):
+        ops.binfc_bwd_multi(*fc_args, parts=1)        # the FC weight gradients: on the second stream
+    dfeats = fc_args[4]
     dm3s = [S[i].t("dm3", (geo[i][0], 16, 16, 128), F32) for i in R]
     dzb4f = [S[i].t("dzb4f", (geo[i][0], 16, 16, 128), F32) for i in R]
     bf16.hpp_bwd_b4_multi(T("m3"), T("s3"), T("b4"), dfeats, dm3s, dzb4f)

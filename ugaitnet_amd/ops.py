@@ -442,10 +442,12 @@ def binfc_fwd_multi(feats, ws, outs):
     return outs
 
 
-def binfc_bwd_multi(feats, ws, douts, dws, dfeats):
+def binfc_bwd_multi(feats, ws, douts, dws, dfeats, parts=3):
+    """parts: 1 = the weight gradients only, 2 = the feature gradients only (what HPP backward waits for), 3 = both."""
     bs = [f.shape[1] for f in feats]
-    call("ugn_binfc_bwd_multi", ptr_array([_chk(f) for f in feats]), ptr_array([_chk(w) for w in ws]),
-         ptr_array([_chk(d) for d in douts]), ptr_array(dws), ptr_array(dfeats), _int_array(bs), len(feats), _stream())
+    call("ugn_binfc_bwd_parts_multi", ptr_array([_chk(f) for f in feats]), ptr_array([_chk(w) for w in ws]),
+         ptr_array([_chk(d) for d in douts]), ptr_array(dws), ptr_array(dfeats), _int_array(bs), len(feats), int(parts), _stream(),
+         label="ugn_binfc_bwd_multi" + {1: "[dW]", 2: "[dfeat]", 3: ""}[int(parts)])
     return dws, dfeats
 
 
