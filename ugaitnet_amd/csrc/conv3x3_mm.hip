@@ -64,6 +64,11 @@ constexpr int lds_bytes() { return W_OFF + (filter_resident<KC, NC>() ? 3 : 2) *
 // ---------------------------------------------------------------------------------------------------------------------
 // filter statistics + packing
 // ---------------------------------------------------------------------------------------------------------------------
+// Which (layer, direction) pairs run on the 16x16x32 kernel (conv_mm16_kernel): 64 or 128 output columns and an un-pooled input.
+// The only pooled-input data gradient with 64 columns is the 64 -> 64 one (a4 / b2): decided by shape, so that the filter
+// packing (which does not know about pooling) and the launch agree.
+__host__ __device__ constexpr bool mm_tile16(int kc, int nc, int dgrad) { return nc >= 64 && !(dgrad && kc == 64 && nc == 64); }
+
 constexpr int kPackJobs = 64;
 struct PackTable {
   const float* w[kPackJobs];
@@ -135,11 +140,21 @@ __global__ void mm_pack_kernel(PackTable t) {
   if (e == 0) t.meta[j]->e = ew;
   _Float16 hi, lo;
   h2_split(ldexpf(v, ew), hi, lo);
+  uint16_t* pk = t.pk[j];
+  if (mm_tile16(kc, nc, dgrad)) {
+    // 16x16x32 kernels: [chunk][tap][16-column tile][plane][lane-linear 1 KB]; lane = k group (8 channels) * 16 + column; tiles 2m,
+    // 2m + 1 hold the even / odd channels of the 32-channel group m (a lane then owns adjacent channels, as in the 32-column form)
+    const int chunk = k >> 5, kg = (k >> 3) & 3, ee = k & 7;
+    const int ct = 2 * (n >> 5) + (n & 1), col = (n & 31) >> 1;
+    const size_t base = (((size_t)chunk * 9 + tap) * (nc / 16) + ct) * 2;
+    pk[(base + 0) * 512 + (kg * 16 + col) * 8 + ee] = (uint16_t)h2_bits(hi);
+    pk[(base + 1) * 512 + (kg * 16 + col) * 8 + ee] = (uint16_t)h2_bits(lo);
+    return;
+  }
   const int nb_all = nc / 32;
   const int chunk = k >> 5, s = (k >> 4) & 1, h = (k >> 3) & 1, ee = k & 7;
   const int nb = mm_block_of(n, nc), col = mm_col_of(n, nc);
   const size_t base = ((((size_t)chunk * 9 + tap) * 2 + s) * nb_all + nb) * 2;
-  uint16_t* pk = t.pk[j];
   pk[(base + 0) * 512 + (h * 32 + col) * 8 + ee] = (uint16_t)h2_bits(hi);
   pk[(base + 1) * 512 + (h * 32 + col) * 8 + ee] = (uint16_t)h2_bits(lo);
 }
@@ -678,6 +693,268 @@ __global__ __launch_bounds__(512, 2) void conv_mm_kernel(const MmJobs jt, const 
   h2_publish_amax_block(jt.job[meta_jb].out_meta, mx, reinterpret_cast<float*>(smem), tid, 8);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// the same convolution on v_mfma_f32_16x16x32_f16 (64 / 128 output channels, un-pooled input)
+// ---------------------------------------------------------------------------------------------------------------------
+// One k-step = the whole 32-channel chunk; the wave's 32 pixels are two row tiles of 16 (windows 0..3 | 4..7 in pool order: a
+// lane's four accumulator registers of a tile are the four positions of ONE pooling window), the output channels 16-column tiles.
+// Same FLOPs, LDS reads, bytes and accumulator registers as the 32x32x16 form; the chip holds a higher clock on this shape and a
+// tap's products are 2 x NC/16 independent accumulator chains instead of NC/32: 13-23 % on the weight gradients that use it
+// (wgrad3x3_mm.hip).  A fragment: lane (row = lane & 15, k group kg = lane >> 4) reads the 16 bytes of channels 8 kg .. 8 kg + 7 of its
+// pixel: with 10 slots per pixel (8 + 2 pad) and 184 per row the four 16-lane groups of a ds_read_b128 hit 16 distinct slots.
+constexpr int PS16 = 10, HROW16 = 184;
+constexpr int HPIECES16 = 52;                       // 18 rows x 184 slots = 3312 -> 51.75 pieces (13 per fetching wave)
+constexpr int HALO16_BYTES = HPIECES16 * 1024;      // 53,248
+constexpr int W_OFF16 = 2 * HALO16_BYTES;
+template <int NC>
+constexpr int lds_bytes16() { return W_OFF16 + 2 * Geo<NC>::WSTAGE; }
+
+template <int KC, int HW>
+__device__ __forceinline__ void dma_halo_piece16(const char* __restrict__ img_base, const void* __restrict__ zeros, int ry0,
+                                                 int rx0, int chunk, int piece, int lane, unsigned lds_byte_base) {
+  const int g = piece * 64 + lane;
+  const int row = (g * 5699) >> 20;                 // g / 184 for g < 3328
+  const int rem = g - row * HROW16;
+  const int px = (rem * 205) >> 11;                 // rem / 10 for rem < 184
+  const int c = rem - px * PS16;
+  const int gy = ry0 - 1 + row, gx = rx0 - 1 + px;
+  const bool ok = rem < 18 * PS16 && c < 8 && row < 18 && (unsigned)gy < (unsigned)HW && (unsigned)gx < (unsigned)HW;
+  const unsigned off = (unsigned)(gy * HW + gx) * (unsigned)(KC * 4) + (unsigned)(chunk * 64) +
+                       (c < 4 ? (unsigned)(c * 16) : (unsigned)(KC * 2 + (c - 4) * 16));
+  const void* src = ok ? (const void*)(img_base + off) : zeros;
+  dma16(src, lds_byte_base + (unsigned)piece * 1024u);
+}
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 mfma16_h(const uint4& a, const uint4& b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, a), __builtin_bit_cast(h8, b), c, 0, 0, 0);
+}
+
+template <int KC, int NC, int HW, int EPI>
+__global__ __launch_bounds__(512, 2) void conv_mm16_kernel(const MmJobs jt, const void* __restrict__ zeros) {
+  using G = Geo<NC>;
+  constexpr int TPS = G::TPS, NSTG = G::NSTG, WSTAGE = G::WSTAGE, WPIECES = G::WPIECES;
+  constexpr int NT = NC / 16, NG = NC / 32;           // 16-column tiles, 32-channel groups (a lane owns a channel pair of each)
+  constexpr int NCHUNK = KC / 32;
+  constexpr int RPX = HW / 16, RPI = RPX * RPX;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const unsigned sbase = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // A-side role: row r16 of a 16-row tile = window (r16 >> 2) of the tile, position q; k group kg
+  const int r16 = lane & 15, kg = lane >> 4, q = r16 & 3;
+  int a_lane[2];
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt)
+    a_lane[rt] = ((2 * wave + (q >> 1)) * HROW16 + (2 * (4 * rt + (r16 >> 2)) + (q & 1)) * PS16) * 16 + kg * 16;
+  const int b_lane = W_OFF16 + lane * 16;
+  // C-side role: column col of a tile, window rg of the row tile (registers = positions 0..3)
+  const int col = lane & 15, rg = lane >> 4;
+
+  int item = blockIdx.x;
+  const int nitems = jt.start[kMaxJobs];
+  if (item >= nitems) return;
+  int jb = mm_job_of(jt, item), lit = item - jt.start[jb];
+
+  auto img_in = [&](const MmJob& J, int img) { return reinterpret_cast<const char*>(J.in) + (size_t)img * HW * HW * KC * 4; };
+  const bool is_hw = wave >= 4;
+  const int rw = wave & 3;
+  constexpr int HSTG = NSTG == 3 ? 2 : 7;           // stages of a chunk that issue halo pieces (13 per wave)
+  constexpr int HPER = NSTG == 3 ? 7 : 2;
+  auto stage_in = [&](const MmJob& J, int lit_, int chunk, unsigned halo_dst, int sgi) {
+    const int img = lit_ / RPI, rrem = lit_ % RPI;
+    const int ry0 = (rrem / RPX) * 16, rx0 = (rrem % RPX) * 16;
+    const char* vb = img_in(J, img);
+#pragma unroll
+    for (int j = 0; j < HPER; ++j) {
+      const int k = sgi * HPER + j;
+      if (k < 13) dma_halo_piece16<KC, HW>(vb, zeros, ry0, rx0, chunk, rw * 13 + k, lane, halo_dst);
+    }
+  };
+  auto stage_w = [&](const uint16_t* wpk, int st, unsigned dst) {
+    const char* src = reinterpret_cast<const char*>(wpk) + (size_t)st * WSTAGE;
+#pragma unroll
+    for (int j = 0; j < WPIECES / 4; ++j) {
+      const int p = rw + 4 * j;
+      dma16(src + p * 1024 + lane * 16, dst + (unsigned)p * 1024u);
+    }
+  };
+
+  if (is_hw) {
+#pragma unroll
+    for (int k = 0; k < HSTG; ++k) stage_in(jt.job[jb], lit, 0, sbase, k);
+  } else {
+    stage_w(jt.job[jb].wpk, 0, sbase + W_OFF16);
+  }
+  int hbuf = 0, wbuf = 0;
+  bool first_item = true;
+  int meta_jb = -1, e_out = 0;
+  float factor = 1.f, mx = 0.f;
+
+  for (; item < nitems; item += gridDim.x) {
+    const int next_item = item + gridDim.x;
+    const bool more = next_item < nitems;
+    const int jn = more ? mm_job_of(jt, next_item) : jb, nlit = more ? next_item - jt.start[jn] : lit;
+    if (jb != meta_jb) {
+      if (meta_jb >= 0) h2_publish_amax(jt.job[meta_jb].out_meta, wave_max(mx), lane);
+      mx = 0.f;
+      const MmJob& Jm = jt.job[jb];
+      const int e_in = Jm.in_meta->e;
+      const float amax_in = h2_true_amax(e_in, Jm.in_meta->amax);
+      e_out = h2_exp_for_bound(amax_in * Jm.wmeta->l1);
+      factor = ldexpf(1.f, e_out - e_in - Jm.wmeta->e);
+      meta_jb = jb;
+    }
+    f32x4 acc[2][NT];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+      for (int ct = 0; ct < NT; ++ct) acc[rt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int img = lit / RPI, rrem = lit % RPI;
+    const int ry0 = (rrem / RPX) * 16, rx0 = (rrem % RPX) * 16;
+    constexpr bool ACTPF = EPI == EPI_DGRAD_ACT;
+    unsigned actv[ACTPF ? NG : 1][8];       // H halves of the layer's input at the lane's 8 pixels x channel pair of group m
+
+#pragma unroll 1
+    for (int chunk = 0; chunk < NCHUNK; ++chunk) {
+      const bool last_chunk = chunk + 1 == NCHUNK;
+      const bool next_tile = !last_chunk || more;
+      const bool to_next = last_chunk && more;
+      const int n_chunk = last_chunk ? 0 : chunk + 1;
+      const int nx_job = to_next ? jn : jb, n_lit = to_next ? nlit : lit;
+#pragma unroll
+      for (int sg = 0; sg < NSTG; ++sg) {
+        if (!(sg == 0 && chunk == 0 && !first_item)) {
+          if (!is_hw || sg == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();
+        if constexpr (ACTPF) {
+          if (sg == NSTG - 1 && last_chunk) {
+            const char* act = reinterpret_cast<const char*>(jt.job[jb].act) + (size_t)img * HW * HW * NC * 4;
+#pragma unroll
+            for (int m = 0; m < NG; ++m)
+#pragma unroll
+              for (int r = 0; r < 8; ++r) {
+                const int rt = r >> 2, i = r & 3;
+                const unsigned pix = (unsigned)((ry0 + 2 * wave + (i >> 1)) * HW + rx0 + 2 * (4 * rt + rg) + (i & 1));
+                actv[m][r] = *reinterpret_cast<const unsigned*>(act + pix * (unsigned)(NC * 4) + (unsigned)(32 * m + 2 * col) * 2u);
+              }
+          }
+        }
+        if (!is_hw) {
+          if (sg + 1 < NSTG) {
+            stage_w(jt.job[jb].wpk, chunk * NSTG + sg + 1, sbase + W_OFF16 + (unsigned)(wbuf ^ 1) * WSTAGE);
+          } else if (next_tile) {
+            stage_w(jt.job[nx_job].wpk, n_chunk * NSTG, sbase + W_OFF16 + (unsigned)(wbuf ^ 1) * WSTAGE);
+          }
+        } else if (next_tile && sg < HSTG) {
+          stage_in(jt.job[nx_job], n_lit, n_chunk, sbase + (unsigned)(hbuf ^ 1) * HALO16_BYTES, sg);
+        }
+        const int b_addr = b_lane + wbuf * WSTAGE;
+#pragma unroll
+        for (int t = 0; t < TPS; ++t) {
+          const int tap = sg * TPS + t, dy = tap / 3, dx = tap % 3;
+          const int aoff = (dy * HROW16 + dx * PS16) * 16 + hbuf * HALO16_BYTES;
+          uint4 ah[2], al[2];
+#pragma unroll
+          for (int rt = 0; rt < 2; ++rt) {
+            ah[rt] = *reinterpret_cast<const uint4*>(smem + a_lane[rt] + aoff);
+            al[rt] = *reinterpret_cast<const uint4*>(smem + a_lane[rt] + aoff + 64);
+          }
+          // all B fragments of the tap first (NT x 2 x 4 registers: two waves per SIMD leave room), then the MFMAs: read one tile at
+          // a time, every tile's six MFMAs waited for its own reads
+          uint4 bh[NT], bl[NT];
+#pragma unroll
+          for (int ct = 0; ct < NT; ++ct) {
+            bh[ct] = *reinterpret_cast<const uint4*>(smem + b_addr + ((t * NT + ct) * 2 + 0) * 1024);
+            bl[ct] = *reinterpret_cast<const uint4*>(smem + b_addr + ((t * NT + ct) * 2 + 1) * 1024);
+          }
+#pragma unroll
+          for (int ct = 0; ct < NT; ++ct)
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) acc[rt][ct] = mfma16_h(ah[rt], bh[ct], acc[rt][ct]);
+#pragma unroll
+          for (int ct = 0; ct < NT; ++ct)
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) acc[rt][ct] = mfma16_h(ah[rt], bl[ct], acc[rt][ct]);
+#pragma unroll
+          for (int ct = 0; ct < NT; ++ct)
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) acc[rt][ct] = mfma16_h(al[rt], bh[ct], acc[rt][ct]);
+        }
+        wbuf ^= 1;
+      }
+      hbuf ^= 1;
+    }
+    if (more) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    first_item = false;
+
+    // ---- epilogue.  acc[rt][ct][i] of lane (col, rg): window 4 rt + rg of the wave's 8, position i; tiles 2m, 2m + 1 = channels
+    // 32 m + 2 col, 32 m + 2 col + 1
+    const MmJob& J = jt.job[jb];
+    if (lit == 0 && tid == 0) J.out_meta->e = e_out;
+    constexpr bool POOL = EPI == EPI_LRELU_POOL;
+    constexpr int HO = POOL ? HW / 2 : HW;
+    char* out = reinterpret_cast<char*>(J.out) + (size_t)img * HO * HO * NC * 4;
+#pragma unroll
+    for (int m = 0; m < NG; ++m) {
+      const unsigned chb = (unsigned)(32 * m + 2 * col) * 2u;       // byte offset of the lane's channel pair in a plane
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt) {
+        const int wx = 4 * rt + rg;
+        if constexpr (POOL) {
+          float best[2];
+          unsigned bi[2];
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            best[e] = acc[rt][2 * m + e][0];
+            bi[e] = 0;
+#pragma unroll
+            for (int i = 1; i < 4; ++i) {
+              const float v = acc[rt][2 * m + e][i];
+              if (v > best[e]) { best[e] = v; bi[e] = i; }     // strict >: the FIRST maximum wins (TF MaxPoolGrad)
+            }
+            best[e] = ugn_lrelu(best[e] * factor);
+            mx = fmaxf(mx, fabsf(best[e]));
+          }
+          const unsigned pix = (unsigned)((ry0 / 2 + wave) * HO + rx0 / 2 + wx);
+          _Float16 h0, l0, h1, l1;
+          h2_split(best[0], h0, l0);
+          h2_split(best[1], h1, l1);
+          UGN_ST(unsigned, out + pix * (unsigned)(NC * 4) + chb, h2_pack(h0, h1));
+          UGN_ST(unsigned, out + pix * (unsigned)(NC * 4) + (unsigned)(NC * 2) + chb, h2_pack(l0, l1));
+          uint8_t* oi = J.out_idx + (size_t)img * HO * HO * NC;
+          UGN_ST(uint16_t, oi + pix * (unsigned)NC + (unsigned)(32 * m + 2 * col), bi[0] | (bi[1] << 8));
+        } else {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const unsigned pix = (unsigned)((ry0 + 2 * wave + (i >> 1)) * HW + rx0 + 2 * wx + (i & 1));
+            float v0 = acc[rt][2 * m][i] * factor, v1 = acc[rt][2 * m + 1][i] * factor;
+            if constexpr (EPI == EPI_LRELU) {
+              v0 = ugn_lrelu(v0);
+              v1 = ugn_lrelu(v1);
+            } else if constexpr (EPI == EPI_DGRAD_ACT) {
+              const unsigned ah2 = actv[m][4 * rt + i];
+              v0 *= (short)(ah2 & 0xffffu) > 0 ? 1.f : UGN_LRELU_ALPHA;      // LeakyReLU' from the sign of the H half
+              v1 *= (short)(ah2 >> 16) > 0 ? 1.f : UGN_LRELU_ALPHA;
+            }
+            mx = fmaxf(mx, fmaxf(fabsf(v0), fabsf(v1)));
+            _Float16 h0, l0, h1, l1;
+            h2_split(v0, h0, l0);
+            h2_split(v1, h1, l1);
+            UGN_ST(unsigned, out + pix * (unsigned)(NC * 4) + chb, h2_pack(h0, h1));
+            UGN_ST(unsigned, out + pix * (unsigned)(NC * 4) + (unsigned)(NC * 2) + chb, h2_pack(l0, l1));
+          }
+        }
+      }
+    }
+    jb = jn;
+    lit = nlit;
+  }
+  h2_publish_amax_block(jt.job[meta_jb].out_meta, mx, reinterpret_cast<float*>(smem), tid, 8);
+}
+
 // Persistent workgroups of the forward / data-gradient launches (one per CU by default).  Under data parallelism RCCL's channels
 // need CUs of their own while the backward pass still runs: ugn_set_persistent_wgs(n < 256) leaves 256 - n of them free.  Results
 // do not depend on it (an item's arithmetic is the same whichever workgroup runs it).
@@ -704,10 +981,35 @@ int launch_mm(const MmJob* jobs, const int* n, int njobs, hipStream_t st) {
   return 0;
 }
 
+template <int KC, int NC, int HW, int EPI>
+int launch_mm16(const MmJob* jobs, const int* n, int njobs, hipStream_t st) {
+  auto kern = conv_mm16_kernel<KC, NC, HW, EPI>;
+  constexpr int LDS = lds_bytes16<NC>();
+  static_assert(LDS <= 163840, "LDS budget");
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    if (e != hipSuccess) { ugn_set_error("conv_mm16: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
+    attr_done = true;
+  }
+  const void* zeros = zero_block();
+  if (!zeros) { ugn_set_error("conv_mm16: cannot allocate the zero block"); return UGN_EINVAL; }
+  MmJobs jt;
+  const int nitems = make_mm_table(jt, jobs, n, njobs, (HW / 16) * (HW / 16));
+  const int grid = nitems < g_persistent_wgs ? nitems : g_persistent_wgs;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), LDS, st, jt, zeros);
+  UGN_CHECK_LAUNCH("conv_mm16");
+  return 0;
+}
+
 int dispatch_fwd(const MmJob* jobs, const int* n, int njobs, int hw, int cin, int cout, int pool, hipStream_t st) {
-#define MF(KC_, NC_, HW_, P_)                                              \
-  if (cin == KC_ && cout == NC_ && hw == HW_ && (pool != 0) == (P_ != 0))  \
-    return launch_mm<KC_, NC_, HW_, 0, P_ ? EPI_LRELU_POOL : EPI_LRELU>(jobs, n, njobs, st);
+#define MF(KC_, NC_, HW_, P_)                                                \
+  if (cin == KC_ && cout == NC_ && hw == HW_ && (pool != 0) == (P_ != 0)) {  \
+    if constexpr (mm_tile16(KC_, NC_, 0))                                    \
+      return launch_mm16<KC_, NC_, HW_, P_ ? EPI_LRELU_POOL : EPI_LRELU>(jobs, n, njobs, st); \
+    else                                                                     \
+      return launch_mm<KC_, NC_, HW_, 0, P_ ? EPI_LRELU_POOL : EPI_LRELU>(jobs, n, njobs, st); \
+  }
   MF(32, 32, 64, 1) MF(32, 64, 32, 0) MF(64, 64, 32, 1) MF(64, 128, 16, 0) MF(128, 128, 16, 0)
 #undef MF
   ugn_set_error("ugn_mm_conv3x3_fwd: unsupported shape cin=%d cout=%d hw=%d pool=%d", cin, cout, hw, pool);
@@ -717,9 +1019,14 @@ int dispatch_fwd(const MmJob* jobs, const int* n, int njobs, int hw, int cin, in
 // data gradient of the forward layer cin -> cout at hw x hw: K = cout, N = cin
 int dispatch_dgrad(const MmJob* jobs, const int* n, int njobs, int hw, int cin, int cout, int unpool, bool act, hipStream_t st) {
 #define MD(CI_, CO_, HW_, U_)                                                                     \
-  if (cin == CI_ && cout == CO_ && hw == HW_ && unpool == U_)                                     \
-    return act ? launch_mm<CO_, CI_, HW_, U_, EPI_DGRAD_ACT>(jobs, n, njobs, st)                  \
-               : launch_mm<CO_, CI_, HW_, U_, EPI_DGRAD>(jobs, n, njobs, st);
+  if (cin == CI_ && cout == CO_ && hw == HW_ && unpool == U_) {                                   \
+    if constexpr (mm_tile16(CO_, CI_, 1) && !U_)                                                  \
+      return act ? launch_mm16<CO_, CI_, HW_, EPI_DGRAD_ACT>(jobs, n, njobs, st)                  \
+                 : launch_mm16<CO_, CI_, HW_, EPI_DGRAD>(jobs, n, njobs, st);                     \
+    else                                                                                          \
+      return act ? launch_mm<CO_, CI_, HW_, U_, EPI_DGRAD_ACT>(jobs, n, njobs, st)                \
+                 : launch_mm<CO_, CI_, HW_, U_, EPI_DGRAD>(jobs, n, njobs, st);                   \
+  }
   MD(32, 32, 64, 1) MD(32, 64, 32, 0) MD(64, 64, 32, 1) MD(64, 128, 16, 0) MD(128, 128, 16, 0)
 #undef MD
   ugn_set_error("ugn_mm_conv3x3_dgrad: unsupported shape cin=%d cout=%d hw=%d unpool=%d", cin, cout, hw, unpool);
