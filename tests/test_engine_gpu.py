@@ -226,7 +226,7 @@ def test_bf16_operand_mode_against_the_oracle(dev, bfmode):
         build(kinds, ncls, 'sign_max', p64, conv_precision='fp8')
 
 
-@pytest.mark.parametrize("prec,bar_out,bar_grad,bar_med", [("bf16", 1e-2, 3e-1, 1e-1), ("h2", 2e-6, 2e-3, 5e-6)])
+@pytest.mark.parametrize("prec,bar_out,bar_grad,bar_med", [("bf16", 1e-2, 3e-1, 1e-1), ("h2", 2e-6, 1e-1, 5e-6)])
 def test_branch_gradients_with_a_fixed_cotangent(dev, prec, bar_out, bar_grad, bar_med):
     """The encoder branches alone, with the SAME output cotangent on both sides: <out, dout> differentiated by the fp64 torch
     oracle (oracle/torch_ref.py branch, reference nets/mj_uwyhNets_ba.py:419-484) and by the HIP path's forward_* / backward_*.
@@ -237,8 +237,10 @@ def test_branch_gradients_with_a_fixed_cotangent(dev, prec, bar_out, bar_grad, b
     Measured: bf16 -- outputs 3e-3 ... 4e-3 of their scale, gradients 0.04 ... 0.23 relative L2 (median 0.07; worst = the first
     two layers of the optical-flow branch, ten 8-bit-operand layers below the cotangent): an 8-bit significand in every operand
     of every convolution does not support 5e-2 on the early layers, with or without bf16 storage (the fp32-storage 'bf16w' mode
-    measures the same); f16x2 -- outputs 4e-7, gradients 1e-6 (median) with 3e-4 on the frame-level layers below a set-max,
-    where an argmax over frames that differs from the fp64 oracle's at a 1e-7 near-tie moves a whole routing decision."""
+    measures the same); f16x2 -- outputs 4e-7, gradients 1e-6 ... 2e-6 (median) with 3e-4 ... 3e-2 on the frame-level layers below a
+    set-max or MaxPool whose argmax differs from the fp64 oracle's at a 1e-7 near-tie: one flipped routing decision under a
+    white-noise cotangent is that large, and which near-tie flips changes with any change of summation order in the kernels
+    (hence the wide bar on the worst tensor; the test below removes the flips and holds 2e-5)."""
     from oracle import torch_ref as T
     from ugaitnet_amd import engine_bf, engine_h2, engine
     kinds, b, l, ncls = ('of', 'gray', 'depth'), 6, 5, 10
@@ -316,16 +318,14 @@ def _forced_branch(x, p, route, T):
     return torch.matmul(torch.cat(feats, dim=1).permute(1, 0, 2), p['fc'])
 
 
-@pytest.mark.parametrize("prec,bar,bar_med", [("bf16", 8e-2, 4e-2), ("h2", 1e-3, 5e-6)])
+@pytest.mark.parametrize("prec,bar,bar_med", [("bf16", 8e-2, 4e-2), ("h2", 2e-5, 5e-6)])
 def test_branch_gradients_with_the_hip_paths_routing(dev, prec, bar, bar_med):
     """the ARITHMETIC of the gradient, separated from routing flips.  Same set-up as the test above (fixed
     white-noise cotangent), but the fp64 oracle takes every routing decision -- the argmax of the three MaxPools, of the three set
     poolings and of the HPP strip maxima -- from the HIP path's own saved tensors.  What remains is rounding.  Measured: bf16 -- 8-bit
     operands in ten stacked convolutions, fp32 accumulate -- 0.003 ... 0.063 relative L2 per tensor, median 0.032 (the 5e-2 the verdict
-    names holds for all but the first two layers of two branches; without the forcing the worst tensor is at 0.23); f16x2 -- 1e-6
-    (median) with 3e-4 on the four frame-level layers of the optical-flow branch: their gradient tensors span more than 2^18 in
-    magnitude below the block bound, where the L half of an H2 value runs out of exponent -- not routing (forcing does not
-    change it), and invisible at the step level (every fp32 bar of the whole-step tests holds)."""
+    names holds for all but the first two layers of two branches; without the forcing the worst tensor is at 0.23); f16x2 -- every
+    tensor within 4e-6 (median 1e-6): fp32-class arithmetic; without the forcing single tensors sit at 3e-4 ... 3e-2."""
     from oracle import torch_ref as T
     from ugaitnet_amd import bf16 as BF, engine, engine_bf, engine_h2
     kinds, b, l, ncls = ('of', 'gray', 'depth'), 6, 5, 10

@@ -67,7 +67,12 @@ constexpr int lds_bytes() { return W_OFF + (filter_resident<KC, NC>() ? 3 : 2) *
 // Which (layer, direction) pairs run on the 16x16x32 kernel (conv_mm16_kernel): 64 or 128 output columns and an un-pooled input.
 // The only pooled-input data gradient with 64 columns is the 64 -> 64 one (a4 / b2): decided by shape, so that the filter
 // packing (which does not know about pooling) and the launch agree.
-__host__ __device__ constexpr bool mm_tile16(int kc, int nc, int dgrad) { return nc >= 64 && !(dgrad && kc == 64 && nc == 64); }
+#ifndef UGN_T16_MIN
+#define UGN_T16_MIN 32
+#endif
+__host__ __device__ constexpr bool mm_tile16(int kc, int nc, int dgrad) {
+  return nc >= UGN_T16_MIN && !(dgrad && kc == 64 && nc == 64) && !(dgrad && kc == 32 && nc == 32);
+}
 
 constexpr int kPackJobs = 64;
 struct PackTable {
