@@ -196,11 +196,20 @@ __global__ __launch_bounds__(512, 2) void wgrad_bf_kernel(const WgJobs jt, const
     bh = __builtin_bit_cast(h8, make_uint4(fh[0], fh[1], fh[2], fh[3]));
   };
 
-  f32x16 acc[9];
+  // M16 (64 output channels per workgroup, un-pooled gradient): v_mfma_f32_16x16x32_bf16, K = 32 pixels (the wave's two rows) per step,
+  // the 32 x 32 block of a tap as four 16 x 16 tiles -- see wgrad3x3_mm.hip
+  constexpr bool M16 = PW == 2 && !POOLED;
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  f32x16 acc[M16 ? 1 : 9];
+  f32x4 a4[M16 ? 9 : 1][4];          // [tap][ci tile * 2 + co tile]
 #pragma unroll
-  for (int t = 0; t < 9; ++t)
+  for (int t = 0; t < (M16 ? 1 : 9); ++t)
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+#pragma unroll
+  for (int t = 0; t < (M16 ? 9 : 1); ++t)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) a4[t][k] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // ---- prologue: tiles of strip s0 -> set 0
   {
@@ -218,6 +227,31 @@ __global__ __launch_bounds__(512, 2) void wgrad_bf_kernel(const WgJobs jt, const
     const StripSrc Sin = strip_src(have_in ? s + 1 : s);
     const LDS_PTR(char) in_b = lds + b * SET + ks * RPW * (18 * 64) + lane_off;
     const LDS_PTR(char) dz_b = lds + b * SET + IN_BYTES + pair * 8192 + ks * RPW * (16 * 64) + lane_off;
+    if constexpr (M16) {
+      const int kg = lane >> 4;
+      const LDS_PTR(char) in_m = lds + b * SET + ks * RPW * (18 * 64) + ((kg >> 1) * 18 + 8 * (kg & 1) + q) * 64 + 4 * p * 2;
+      const LDS_PTR(char) dz_m = lds + b * SET + IN_BYTES + pair * 8192 + ks * RPW * (16 * 64) + ((kg >> 1) * 16 + 8 * (kg & 1) + q) * 64 + 4 * p * 2;
+      h8 bh[2];
+#pragma unroll
+      for (int cot = 0; cot < 2; ++cot) bh[cot] = tr_pair(dz_m, cot * 32, cot * 32 + 4 * 64);
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const int o = ((t / 3) * 18 + (t % 3)) * 64;
+#pragma unroll
+        for (int cit = 0; cit < 2; ++cit) {
+          const h8 ah = tr_pair(in_m, o + cit * 32, o + cit * 32 + 4 * 64);
+#pragma unroll
+          for (int cot = 0; cot < 2; ++cot)
+            a4[t][cit * 2 + cot] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(b8, ah), __builtin_bit_cast(b8, bh[cot]),
+                                                                           a4[t][cit * 2 + cot], 0, 0, 0);
+        }
+        if (t < NJ && have_in) {
+          __builtin_amdgcn_sched_barrier(0);
+          issue(t, Sin, b ^ 1);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    } else
 #pragma unroll
     for (int rr = 0; rr < RPW; ++rr) {
       // k-step = pixel row rr of the wave: lane half h covers pixels 8h .. 8h+7 (two 4-pixel blocks)
@@ -252,9 +286,18 @@ __global__ __launch_bounds__(512, 2) void wgrad_bf_kernel(const WgJobs jt, const
 #pragma unroll 1
       for (int t = 0; t < 9; ++t) {
         __syncthreads();
-        f32x16 a = acc[0];
+        f32x16 a;
+        if constexpr (M16) {
+          f32x4 q0 = a4[0][0], q1 = a4[0][1], q2 = a4[0][2], q3 = a4[0][3];
 #pragma unroll
-        for (int u = 1; u < 9; ++u) if (t == u) a = acc[u];
+          for (int u = 1; u < 9; ++u) if (t == u) { q0 = a4[u][0]; q1 = a4[u][1]; q2 = a4[u][2]; q3 = a4[u][3]; }
+#pragma unroll
+          for (int i = 0; i < 4; ++i) { a[i] = q0[i]; a[4 + i] = q1[i]; a[8 + i] = q2[i]; a[12 + i] = q3[i]; }
+        } else {
+          a = acc[0];
+#pragma unroll
+          for (int u = 1; u < 9; ++u) if (t == u) a = acc[u];
+        }
 #pragma unroll
         for (int i = 0; i < 16; ++i) scr[wave * 1024 + i * 64 + lane] = a[i];
         __syncthreads();
@@ -265,14 +308,19 @@ __global__ __launch_bounds__(512, 2) void wgrad_bf_kernel(const WgJobs jt, const
 #pragma unroll
           for (int w = 0; w < KS; ++w) sum += scr[(w * PW + pr) * 1024 + idx];
           const int reg = idx >> 6, ln = idx & 63;
-          const int ci = (reg & 3) + 8 * (reg >> 2) + 4 * (ln >> 5), co = pr * 32 + (ln & 31);
+          const int ci = M16 ? 16 * (reg >> 3) + 4 * (ln >> 4) + (reg & 3) : (reg & 3) + 8 * (reg >> 2) + 4 * (ln >> 5);
+          const int co = pr * 32 + (M16 ? 16 * ((reg >> 2) & 1) + (ln & 15) : (ln & 31));
           slab[(t * 32 + ci) * COW + co] = sum;
         }
       }
 #pragma unroll
-      for (int t = 0; t < 9; ++t)
+      for (int t = 0; t < (M16 ? 1 : 9); ++t)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+#pragma unroll
+      for (int t = 0; t < (M16 ? 9 : 1); ++t)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) a4[t][k] = f32x4{0.f, 0.f, 0.f, 0.f};
       jb = jn;
     }
     b ^= 1;
