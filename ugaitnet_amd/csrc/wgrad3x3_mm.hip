@@ -219,11 +219,37 @@ __global__ __launch_bounds__(512, 2) void wgrad_mm_kernel(const WgJobs jt, const
     bh = __builtin_bit_cast(h8, make_uint4(fh[0], fh[1], fh[2], fh[3]));
     bl = __builtin_bit_cast(h8, make_uint4(fl[0], fl[1], fl[2], fl[3]));
   };
+  // the same for the 16x16x32 form: lane (channel 16 cot + (lane & 15), k group kg) = pixels 8 (kg & 1) .. + 7 of strip row y
+  auto pooled_frag16 = [&](int b, int y, int cot, h8& bh, h8& bl) {
+    const int xh = (lane >> 4) & 1;
+    const LDS_PTR(char) pv = lds + b * SET + IN_BYTES + pair * 2048 + (y >> 1) * 512 + (4 * xh + q) * 64 + (16 * cot + 4 * p) * 2;
+    const s4 ph = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s4))pv);
+    const s4 pl = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s4))(pv + PW * 2048));
+    const unsigned char* pi8 = reinterpret_cast<const unsigned char*>(smem) + b * SET + IN_BYTES + G::PZ_VAL +
+                               ((y >> 1) * 8 + 4 * xh) * COW + pair * 32 + 16 * cot + (lane & 15);
+    const unsigned posa = 2u * (unsigned)(y & 1);
+    const uint2 hv = __builtin_bit_cast(uint2, ph), lv = __builtin_bit_cast(uint2, pl);
+    unsigned fh[4], fl[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const unsigned ix = pi8[j * COW];
+      const unsigned m = (ix == posa ? 0x0000ffffu : 0u) | (ix == posa + 1u ? 0xffff0000u : 0u);
+      const unsigned h2w = j < 2 ? hv.x : hv.y, l2w = j < 2 ? lv.x : lv.y;
+      const unsigned hs = (j & 1) ? (h2w >> 16) : (h2w & 0xffffu), ls = (j & 1) ? (l2w >> 16) : (l2w & 0xffffu);
+      fh[j] = (hs | (hs << 16)) & m;
+      fl[j] = (ls | (ls << 16)) & m;
+    }
+    bh = __builtin_bit_cast(h8, make_uint4(fh[0], fh[1], fh[2], fh[3]));
+    bl = __builtin_bit_cast(h8, make_uint4(fl[0], fl[1], fl[2], fl[3]));
+  };
 
   // M16 (64 output channels per workgroup, un-pooled gradient): v_mfma_f32_16x16x32_f16 -- K = 32 pixels (the wave's two rows) per
   // step, the 32 x 32 block of a tap as four 16 x 16 tiles.  Same operand reads, same FLOPs and accumulator registers as two
   // 32x32x16 steps, but the chip holds a higher clock on this shape: 6-12 % on these launches (profiles/r03_stage_stamps.txt).
-  constexpr bool M16 = PW == 2 && !POOLED;
+#ifndef UGN_WG_POOLED16
+#define UGN_WG_POOLED16 1
+#endif
+  constexpr bool M16 = PW == 2 && (!POOLED || UGN_WG_POOLED16);
   typedef float f32x4 __attribute__((ext_vector_type(4)));
   f32x16 acc[M16 ? 1 : 9];
   f32x4 a4[M16 ? 9 : 1][4];          // [tap][ci tile * 2 + co tile]
@@ -274,8 +300,12 @@ __global__ __launch_bounds__(512, 2) void wgrad_mm_kernel(const WgJobs jt, const
       h8 bh[2], bl[2];
 #pragma unroll
       for (int cot = 0; cot < 2; ++cot) {
-        bh[cot] = tr_pair(dz_m, cot * 32, cot * 32 + 4 * 64);
-        bl[cot] = tr_pair(dz_m, PW * 8192 + cot * 32, PW * 8192 + cot * 32 + 4 * 64);
+        if constexpr (POOLED) {
+          pooled_frag16(b, ks * RPW + (kg >> 1), cot, bh[cot], bl[cot]);
+        } else {
+          bh[cot] = tr_pair(dz_m, cot * 32, cot * 32 + 4 * 64);
+          bl[cot] = tr_pair(dz_m, PW * 8192 + cot * 32, PW * 8192 + cot * 32 + 4 * 64);
+        }
       }
 #pragma unroll
       for (int t = 0; t < 9; ++t) {
