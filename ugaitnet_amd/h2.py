@@ -142,9 +142,11 @@ def _mm_work(kind, hw, cin, cout, pooled, ns, act=False):
     n = int(sum(ns))
     flops = 2.0 * 9 * cin * cout * hw * hw * n
     if kind == "fwd":
-        kern = "conv_mm_kernel<%d, %d, %d, 0, %d>" % (cin, cout, hw, 1 if pooled else 0)
+        # (the name rocprofv3 reports: un-pooled inputs run on the 16x16x32 kernel, csrc/conv3x3_mm.hip mm_tile16)
+        kern = "conv_mm16_kernel<%d, %d, %d, %d>" % (cin, cout, hw, 1 if pooled else 0)
     else:
-        kern = "conv_mm_kernel<%d, %d, %d, %d, %d>" % (cout, cin, hw, int(pooled), 3 if act else 2)
+        kern = ("conv_mm_kernel<%d, %d, %d, %d, %d>" % (cout, cin, hw, int(pooled), 3 if act else 2) if pooled else
+                "conv_mm16_kernel<%d, %d, %d, %d>" % (cout, cin, hw, 3 if act else 2))
     label = "conv3x3_%s[%d->%d @%dx%d%s h2] %s" % (kind, cin, cout, hw, hw, " pooled" if pooled else "", kern)
     # three f16 MFMAs per fp32-equivalent product: the matrix pipe executes 3x the algorithmic FLOPs
     return label, dict(flops=flops, mfma_flops=3.0 * flops, bytes=None, kernel=kern, bound="mfma", images=n, dtype="f16x2")
