@@ -304,6 +304,16 @@ int ugn_mm_conv3x3_dgrad_multi(const uint16_t* const* dz, const uint8_t* const* 
  * setting (the one piece of mutable state besides the error message): under data parallelism a value below 256 leaves CUs to RCCL's
  * channels while the backward pass runs.  Results do not depend on it. */
 int ugn_set_persistent_wgs(int n);
+/* Data gradient of the pooled 32 -> 32 layer (a2: Conv2DBackpropInput + MaxPoolGrad, nets/mj_uwyhNets_ba.py:431-434) fused with the
+ * weight gradient of the 5x5 first layer (Conv2DBackpropFilter of :428-430, LeakyReluGrad from the a1 sign words): dL/da1 is never
+ * written.  dz: dL/dp2 as H2 [n][32][32][2][32] + argmax bytes; x: the network input fp32 [n][60][60][cin], x_meta = {0, bits(max|x|)};
+ * dw5[j]: [5][5][cin][32] fp32; scale[j]: a scratch ugn_h2meta record; ws: ugn_mm_dgrad32_wgrad5_ws(njobs) bytes. */
+size_t ugn_mm_dgrad32_wgrad5_ws(int njobs);
+int ugn_mm_dgrad32_wgrad5_multi(const uint16_t* const* dz, const void* const* dz_meta, const uint8_t* const* dz_idx,
+                                const uint16_t* const* wpk, const void* const* wmeta, const float* const* x,
+                                const void* const* x_meta, const uint32_t* const* a1_sign, float* const* dw5,
+                                void* const* scale, const int* n, const int* cin, int njobs, void* ws, size_t ws_bytes,
+                                void* stream);
 /* Weight gradient dw HWIO [3,3,cin,cout] (fp32) = sum in (x) dz over images and pixels; in H2 [n][hw][hw][2][cin], dz as in
  * the data gradient (pooled + argmax bytes when dz_idx is given).  ws: >= ugn_mm_conv3x3_wgrad_ws(hw, cin, cout) bytes of
  * scratch for the partial-sum slabs (fixed-order reduction, no atomics: bitwise reproducible). */

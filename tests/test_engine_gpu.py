@@ -365,6 +365,27 @@ def test_branch_gradients_with_the_hip_paths_routing(dev, prec, bar, bar_med):
     assert max(worst.values()) <= bar and med <= bar_med, worst
 
 
+def test_fused_first_layer_weight_gradient(dev, monkeypatch):
+    """UGN_FUSE_W5=1 (engine_h2.FUSE_W5): the data gradient of the pooled 32 -> 32 layer fused with the 5x5 layer's weight gradient
+    (ugn_mm_dgrad32_wgrad5_multi) gives the first layer the gradient the two separate launches give it."""
+    from ugaitnet_amd import engine_h2
+    kinds, b, l, ncls = ('of', 'gray', 'depth'), 6, 4, 10
+    xs, uses, labels, onehot = make_batch(kinds, b, l, ncls, ids=3, seed=4)
+    p64 = oracle_params(kinds, ncls)
+    grads = []
+    for fuse in (False, True):
+        monkeypatch.setattr(engine_h2, "FUSE_W5", fuse)
+        core = build(kinds, ncls, 'sign_max', p64, conv_precision='h2')
+        core.forward_backward(xs, uses, labels, onehot)
+        torch.cuda.synchronize()
+        grads.append(core.get_grads_numpy())
+    for mi in range(3):
+        ref, got = grads[0]['branches'][mi]['a1'].astype(np.float64), grads[1]['branches'][mi]['a1']
+        assert rell2(got, ref) <= 2e-6, (mi, rell2(got, ref))
+        for k in ('a2', 'a3', 'fc'):     # everything else is computed by the same launches: bit-identical
+            assert np.array_equal(grads[0]['branches'][mi][k], grads[1]['branches'][mi][k]), (mi, k)
+
+
 def test_h2_path_properties(dev):
     """The H2 path on a batch with masked modalities: skipping the masked (clip, modality) pairs changes nothing (their gate is
     0), two runs agree bit for bit (no atomics besides an order-independent max), and the path is not the fp32 one."""

@@ -88,6 +88,8 @@ PROTOTYPES = {
     "ugn_mm_pack_multi": (_i, [C.POINTER(_p)] * 3 + [C.POINTER(_i)] * 3 + [_i, _p]),
     "ugn_mm_conv3x3_fwd_multi": (_i, [C.POINTER(_p)] * 7 + [C.POINTER(_i), _i, _i, _i, _i, _i, _p]),
     "ugn_mm_conv3x3_dgrad_multi": (_i, [C.POINTER(_p)] * 8 + [C.POINTER(_i), _i, _i, _i, _i, _p]),
+    "ugn_mm_dgrad32_wgrad5_ws": (_sz, [_i]),
+    "ugn_mm_dgrad32_wgrad5_multi": (_i, [C.POINTER(_p)] * 10 + [C.POINTER(_i), C.POINTER(_i), _i, _p, _sz, _p]),
     "ugn_conv5x5_in_fwd_h2": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _p]),
     "ugn_conv5x5_in_wgrad_h2": (_i, [_p, _p, _p, _p, _p, _i, _i, _p, _sz, _p]),
     "ugn_absmax_multi": (_i, [C.POINTER(_p), C.POINTER(_sz), C.POINTER(_p), _i, _p]),

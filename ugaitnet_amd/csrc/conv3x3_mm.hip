@@ -960,6 +960,275 @@ __global__ __launch_bounds__(512, 2) void conv_mm16_kernel(const MmJobs jt, cons
   h2_publish_amax_block(jt.job[meta_jb].out_meta, mx, reinterpret_cast<float*>(smem), tid, 8);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// data gradient of the pooled 32 -> 32 layer (a2) FUSED with the weight gradient of the 5x5 first layer
+// ---------------------------------------------------------------------------------------------------------------------
+// dz1 = dL/da1 (the output of this data gradient, 315 MB per 600 frames) has ONE consumer: the 5x5 layer's weight gradient
+//   dW1[tap][c][co] = sum over pixels of x[pixel + tap][c] * dz1[pixel][co] * LeakyReLU'(a1[pixel][co])
+// A lane of the 32-row MFMA block holds, after the taps, dz1 of ONE channel at 16 pixels of the region -- which is a B fragment
+// (K = pixels, N = channel) as it stands.  So the workgroup multiplies it here with the matching input patch (A: M = the 25 * cin
+// (tap, channel) rows, gathered from a 20 x 20 patch of x in LDS, split into f16 halves on the fly) and keeps dW1 in accumulator
+// registers across all items of a job: dz1 is never written (0.94 GB per launch at 24 clips) or read back (the same again), and the
+// three conv5x5_wgrad launches of a step disappear.  Structure otherwise = the filter_resident pooled path of conv_mm_kernel.
+struct W5Job {
+  const uint16_t* in;          // pooled gradient dL/dp2, H2 [n][32][32][2][32]
+  const uint8_t* in_idx;       // argmax bytes of the a2 pooling
+  const H2Meta* in_meta;
+  const uint16_t* wpk;         // packed data-gradient filter of a2
+  const WMeta* wmeta;
+  const float* x;              // network input fp32 [n][60][60][cin]
+  const H2Meta* x_meta;        // {0, bits(max|x|)}
+  const uint32_t* sign;        // a1 sign words [n][64][64] (bit c: a1[..][c] > 0)
+  H2Meta* scale;               // out: e = exponent to undo on the slab sums (e_dz + e_x)
+  float* slab;                 // [workgroups][50][32] partial sums of this job
+  int cin;                     // 1 or 2
+};
+struct W5Jobs {
+  W5Job job[kMaxJobs];
+  int start[kMaxJobs + 1];
+};
+constexpr int W5_PATCH_BYTES = 13 * 256;      // 20 x 20 x 2 floats = 3200 B -> 13 dword pieces of 256 B
+constexpr int W5_LDS = W_OFF + 3 * Geo<32>::WSTAGE + STG_BYTES + 2 * W5_PATCH_BYTES;
+
+__device__ __forceinline__ void dma4(const void* gsrc, unsigned lds_dst_uniform) {      // 4 B per lane (LDS address = M0 + lane * 4)
+  unsigned keep;
+  const unsigned dst = __builtin_amdgcn_readfirstlane(lds_dst_uniform);
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(gsrc), "s"(dst)
+               : "memory");
+}
+
+__global__ __launch_bounds__(512, 2) void dgrad32_w5_kernel(const W5Jobs jt, const void* __restrict__ zeros) {
+  constexpr int KC = 32, HW = 64, WSTAGE = Geo<32>::WSTAGE, WPIECES = Geo<32>::WPIECES;
+  constexpr int RPX = HW / 16, RPI = RPX * RPX;
+  constexpr int STG_OFF = W_OFF + 3 * WSTAGE, PATCH_OFF = STG_OFF + STG_BYTES;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const unsigned sbase = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5, win = r >> 2, q = r & 3;
+  const int a_lane = ((2 * wave + (q >> 1)) * HROW + (2 * win + (q & 1)) * 9) * 16 + h * 16;
+  const int b_lane = W_OFF + lane * 16;
+  const int c = lane & 31;
+
+  int item = blockIdx.x;
+  const int nitems = jt.start[kMaxJobs];
+  if (item >= nitems) return;
+  auto job_of = [&](int it) {
+    int jb = 0;
+#pragma unroll
+    for (int j = 1; j < kMaxJobs; ++j) jb += it >= jt.start[j] ? 1 : 0;
+    return jb;
+  };
+  int jb = job_of(item), lit = item - jt.start[jb];
+
+  // staging tile (2 pieces per wave) and input patch (<= 2 dword pieces per wave) of item lit_ of job J
+  auto fetch = [&](const W5Job& J, int lit_, int pb) {
+    const int img = lit_ / RPI, rrem = lit_ % RPI;
+    const int ry0 = (rrem / RPX) * 16, rx0 = (rrem % RPX) * 16;
+    const char* vb = reinterpret_cast<const char*>(J.in) + (size_t)img * 32 * 32 * KC * 4;
+    const char* ib = reinterpret_cast<const char*>(J.in_idx) + (size_t)img * 32 * 32 * KC;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) dma_pooled_piece<KC, HW>(vb, ib, zeros, ry0, rx0, 0, wave * 2 + j, lane, sbase + STG_OFF);
+    const int cin = J.cin;
+    const float* xb = J.x + (size_t)img * 3600 * cin;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int p = wave * 2 + j;
+      if (p < 13) {
+        const int e = p * 64 + lane, pe = cin == 2 ? e >> 1 : e, ch = cin == 2 ? (e & 1) : 0;
+        const int yy = (pe * 3277) >> 16, xx = pe - yy * 20;              // pe / 20 for pe < 800
+        const int ry = ry0 - 4 + yy, rx = rx0 - 4 + xx;
+        const bool ok = pe < 400 && (unsigned)ry < 60u && (unsigned)rx < 60u;
+        dma4(ok ? (const void*)(xb + (ry * 60 + rx) * cin + ch) : zeros, sbase + PATCH_OFF + (unsigned)pb * W5_PATCH_BYTES + (unsigned)p * 256u);
+      }
+    }
+  };
+  auto load_filter = [&](const uint16_t* wpk) {
+    if (wave < 4) {
+#pragma unroll
+      for (int d = 0; d < 3; ++d) {
+        const char* src = reinterpret_cast<const char*>(wpk) + (size_t)d * WSTAGE;
+#pragma unroll
+        for (int j = 0; j < WPIECES / 4; ++j) {
+          const int p = wave + 4 * j;
+          dma16(src + p * 1024 + lane * 16, sbase + W_OFF + (unsigned)d * WSTAGE + (unsigned)p * 1024u);
+        }
+      }
+    }
+  };
+  // dW1 partial sums of the current job: rows (tap, channel) 0..31 and 32..63 (50 used with two input channels)
+  f32x16 acc5[2];
+  auto zero5 = [&]() {
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc5[mb][i] = 0.f;
+  };
+  // add the eight waves' sums of job j through LDS (`scr`: 32 KB nobody else touches at that point) and write the workgroup's slab
+  auto flush5 = [&](int j, float* scr) {
+    const int rows = 25 * jt.job[j].cin;
+    float* slab = jt.job[j].slab + (size_t)blockIdx.x * (50 * 32);
+#pragma unroll 1
+    for (int mb = 0; mb < 2; ++mb) {
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < 16; ++i) scr[wave * 1024 + i * 64 + lane] = acc5[mb][i];
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int e = tid + 512 * k, reg = e >> 6, ln = e & 63;
+        float sum = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) sum += scr[w * 1024 + e];
+        const int row = mb * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (ln >> 5);
+        if (row < rows) slab[row * 32 + (ln & 31)] = sum;
+      }
+    }
+    __syncthreads();
+  };
+
+  // ---- prologue
+  fetch(jt.job[jb], lit, 0);
+  load_filter(jt.job[jb].wpk);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  scatter_pooled(smem + STG_OFF, smem, tid);
+  int hbuf = 0, pbuf = 0, cur_job = -1, e_dz = 0, e_x = 0, cin = 1;
+  float factor = 1.f, xs = 1.f;
+  zero5();
+
+  for (; item < nitems; item += gridDim.x) {
+    const int next_item = item + gridDim.x;
+    const bool more = next_item < nitems;
+    const int jn = more ? job_of(next_item) : jb, nlit = more ? next_item - jt.start[jn] : lit;
+    if (jb != cur_job) {               // (wave-uniform; at most kMaxJobs times per workgroup)
+      if (cur_job >= 0) {
+        // every wave has left the previous item's taps (the barrier inside flush5); the halo buffer that item read is free
+        flush5(cur_job, reinterpret_cast<float*>(smem + (hbuf ^ 1) * HALO_BYTES));
+        zero5();
+        load_filter(jt.job[jb].wpk);
+      }
+      const W5Job& Jm = jt.job[jb];
+      const int e_in = Jm.in_meta->e;
+      e_dz = h2_exp_for_bound(h2_true_amax(e_in, Jm.in_meta->amax) * Jm.wmeta->l1);
+      factor = ldexpf(1.f, e_dz - e_in - Jm.wmeta->e);
+      e_x = h2_exp_for_bound(__uint_as_float(Jm.x_meta->amax));
+      xs = ldexpf(1.f, e_x);
+      cin = Jm.cin;
+      if (lit == 0 && tid == 0) Jm.scale->e = e_dz + e_x;
+      cur_job = jb;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    const int img = lit / RPI, rrem = lit % RPI;
+    const int ry0 = (rrem / RPX) * 16, rx0 = (rrem % RPX) * 16;
+    if (more) fetch(jt.job[jn], nlit, pbuf ^ 1);
+    // LeakyReLU'(a1) of the lane's 16 pixels: the sign words (bit c), fetched under the taps
+    uint32_t sw[16];
+    {
+      const uint32_t* sg = jt.job[jb].sign + (size_t)img * HW * HW;
+#pragma unroll
+      for (int rr = 0; rr < 16; ++rr) {
+        const int g = rr >> 2, i = rr & 3;
+        sw[rr] = sg[(ry0 + 2 * wave + (i >> 1)) * HW + rx0 + 2 * (2 * g + h) + (i & 1)];
+      }
+    }
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    const int a_addr = a_lane + hbuf * HALO_BYTES;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int dy = tap / 3, dx = tap % 3;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const int aoff = (dy * HROW + dx * 9) * 16 + s * 32;
+        const uint4 ah = *reinterpret_cast<const uint4*>(smem + a_addr + aoff);
+        const uint4 al = *reinterpret_cast<const uint4*>(smem + a_addr + aoff + 64);
+        const uint4 bh = *reinterpret_cast<const uint4*>(smem + b_lane + ((tap * 2 + s) * 2 + 0) * 1024);
+        const uint4 bl = *reinterpret_cast<const uint4*>(smem + b_lane + ((tap * 2 + s) * 2 + 1) * 1024);
+        acc = mfma_h(ah, bh, acc);
+        acc = mfma_h(ah, bl, acc);
+        acc = mfma_h(al, bh, acc);
+      }
+      if (tap == 4 && more) {     // MaxPool backward of the next tile: staging -> the other halo buffer (its patch has landed too)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        scatter_pooled(smem + STG_OFF, smem + (hbuf ^ 1) * HALO_BYTES, tid);
+      }
+    }
+    // ---- dz1 of channel c at the lane's 16 pixels = two B fragments (k = 8 registers each); A = the input patch under (tap, channel) row
+    const float* patch = reinterpret_cast<const float*>(smem + PATCH_OFF + pbuf * W5_PATCH_BYTES);
+    const int sh = cin - 1;           // (patch index of a pixel = pixel << sh | channel)
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      unsigned bhw[4], blw[4];
+#pragma unroll
+      for (int k2 = 0; k2 < 4; ++k2) {
+        _Float16 hh[2], ll[2];
+#pragma unroll
+        for (int e2 = 0; e2 < 2; ++e2) {
+          const int rr = 8 * s + 2 * k2 + e2;
+          const float v = acc[rr] * factor * (((sw[rr] >> c) & 1u) ? 1.f : UGN_LRELU_ALPHA);
+          h2_split(v, hh[e2], ll[e2]);
+        }
+        bhw[k2] = h2_pack(hh[0], hh[1]);
+        blw[k2] = h2_pack(ll[0], ll[1]);
+      }
+      const uint4 bh = make_uint4(bhw[0], bhw[1], bhw[2], bhw[3]), bl = make_uint4(blw[0], blw[1], blw[2], blw[3]);
+#pragma unroll
+      for (int mb = 0; mb < 2; ++mb) {
+        if (mb == 1 && cin == 1) break;          // (wave-uniform: 25 rows fit the first block)
+        const int k5 = mb * 32 + (lane & 31);
+        const int kk = k5 < 25 * cin ? k5 : 0;   // (padded rows: any valid address, the sums are discarded)
+        const int tp = cin == 2 ? kk >> 1 : kk, ch = cin == 2 ? (kk & 1) : 0;
+        const int ty = (tp * 13) >> 6, tx = tp - ty * 5;      // tp / 5 for tp < 25
+        const int base = ((((2 * wave + ty) * 20 + tx + 2 * h + 8 * s)) << sh) + ch;
+        unsigned ahw[4], alw[4];
+#pragma unroll
+        for (int k2 = 0; k2 < 4; ++k2) {
+          _Float16 hh[2], ll[2];
+#pragma unroll
+          for (int e2 = 0; e2 < 2; ++e2) {
+            const int i8 = 2 * k2 + e2;
+            const float xv = patch[base + (((((i8 >> 1) & 1) * 20) + 4 * (i8 >> 2) + (i8 & 1)) << sh)] * xs;
+            h2_split(xv, hh[e2], ll[e2]);
+          }
+          ahw[k2] = h2_pack(hh[0], hh[1]);
+          alw[k2] = h2_pack(ll[0], ll[1]);
+        }
+        const uint4 ah = make_uint4(ahw[0], ahw[1], ahw[2], ahw[3]), al = make_uint4(alw[0], alw[1], alw[2], alw[3]);
+        acc5[mb] = mfma_h(ah, bh, acc5[mb]);
+        acc5[mb] = mfma_h(ah, bl, acc5[mb]);
+        acc5[mb] = mfma_h(al, bh, acc5[mb]);
+      }
+    }
+    hbuf ^= 1;
+    pbuf ^= 1;
+    jb = jn;
+    lit = nlit;
+  }
+  flush5(cur_job, reinterpret_cast<float*>(smem));      // (nothing is in flight any more)
+}
+
+struct W5Reduce {
+  const float* slab[kMaxJobs];
+  const H2Meta* scale[kMaxJobs];
+  float* dw[kMaxJobs];
+  int cin[kMaxJobs];
+};
+// dW1[k][co] = 2^-(e_dz + e_x) * sum over the workgroups' slabs, in order
+__global__ __launch_bounds__(256) void w5_reduce_kernel(const W5Reduce rt, int nwg) {
+  const int j = blockIdx.y, e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= 25 * rt.cin[j] * 32) return;
+  float sum = 0.f;
+  for (int g = 0; g < nwg; ++g) sum += rt.slab[j][(size_t)g * (50 * 32) + e];
+  rt.dw[j][e] = ldexpf(sum, -rt.scale[j]->e);
+}
+
 // Persistent workgroups of the forward / data-gradient launches (one per CU by default).  Under data parallelism RCCL's channels
 // need CUs of their own while the backward pass still runs: ugn_set_persistent_wgs(n < 256) leaves 256 - n of them free.  Results
 // do not depend on it (an item's arithmetic is the same whichever workgroup runs it).
@@ -1095,6 +1364,57 @@ extern "C" int ugn_mm_debug_stamps(void* buf) {
   return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_mm_stamp), &p, sizeof(p));
 }
 #endif
+
+
+extern "C" size_t ugn_mm_dgrad32_wgrad5_ws(int njobs) { return (size_t)njobs * kGrid * 50 * 32 * sizeof(float); }
+
+/* data gradient of the pooled 32 -> 32 layer fused with the 5x5 first layer's weight gradient (see dgrad32_w5_kernel): dw5[j] =
+ * dL/dW1 [5][5][cin][32] fp32; no dL/da1 tensor is produced.  scale[j]: an ugn_h2meta record the launch uses for its exponents. */
+extern "C" int ugn_mm_dgrad32_wgrad5_multi(const uint16_t* const* dz, const void* const* dz_meta, const uint8_t* const* dz_idx,
+                                           const uint16_t* const* wpk, const void* const* wmeta, const float* const* x,
+                                           const void* const* x_meta, const uint32_t* const* a1_sign, float* const* dw5,
+                                           void* const* scale, const int* n, const int* cin, int njobs, void* ws, size_t ws_bytes,
+                                           void* stream) {
+  UGN_REQUIRE(dz && dz_meta && dz_idx && wpk && wmeta && x && x_meta && a1_sign && dw5 && scale && n && cin && ws,
+              "ugn_mm_dgrad32_wgrad5_multi: null array");
+  UGN_REQUIRE(njobs >= 1 && njobs <= kMaxJobs, "ugn_mm_dgrad32_wgrad5_multi: njobs must be 1..%d (got %d)", kMaxJobs, njobs);
+  UGN_REQUIRE(ws_bytes >= ugn_mm_dgrad32_wgrad5_ws(njobs), "ugn_mm_dgrad32_wgrad5_multi: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute((const void*)dgrad32_w5_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, W5_LDS);
+    if (e != hipSuccess) { ugn_set_error("dgrad32_w5: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
+    attr_done = true;
+  }
+  const void* zeros = zero_block();
+  if (!zeros) { ugn_set_error("dgrad32_w5: cannot allocate the zero block"); return UGN_EINVAL; }
+  W5Jobs jt = {};
+  W5Reduce rt = {};
+  int total = 0;
+  for (int j = 0; j < kMaxJobs; ++j) {
+    const int jj = j < njobs ? j : njobs - 1;
+    UGN_REQUIRE(dz[jj] && dz_meta[jj] && dz_idx[jj] && wpk[jj] && wmeta[jj] && x[jj] && x_meta[jj] && a1_sign[jj] && dw5[jj] && scale[jj] &&
+                n[jj] > 0 && (cin[jj] == 1 || cin[jj] == 2), "ugn_mm_dgrad32_wgrad5_multi: bad job %d", jj);
+    W5Job& J = jt.job[j];
+    J.in = dz[jj]; J.in_idx = dz_idx[jj]; J.in_meta = (const H2Meta*)dz_meta[jj]; J.wpk = wpk[jj]; J.wmeta = (const WMeta*)wmeta[jj];
+    J.x = x[jj]; J.x_meta = (const H2Meta*)x_meta[jj]; J.sign = a1_sign[jj]; J.scale = (H2Meta*)scale[jj];
+    J.slab = (float*)ws + (size_t)jj * kGrid * 50 * 32; J.cin = cin[jj];
+    jt.start[j] = total;
+    if (j < njobs) {
+      total += n[j] * 16;
+      rt.slab[j] = J.slab; rt.scale[j] = J.scale; rt.dw[j] = dw5[j]; rt.cin[j] = cin[j];
+    }
+  }
+  jt.start[kMaxJobs] = total;
+  const int grid = total < g_persistent_wgs ? total : g_persistent_wgs;
+  hipError_t me = hipMemsetAsync(ws, 0, ugn_mm_dgrad32_wgrad5_ws(njobs), st);     // (a workgroup writes only the jobs it met)
+  if (me != hipSuccess) { ugn_set_error("dgrad32_w5: memset: %s", hipGetErrorString(me)); return (int)me; }
+  hipLaunchKernelGGL(dgrad32_w5_kernel, dim3(grid), dim3(512), W5_LDS, st, jt, zeros);
+  UGN_CHECK_LAUNCH("dgrad32_w5");
+  hipLaunchKernelGGL(w5_reduce_kernel, dim3((50 * 32 + 255) / 256, njobs), dim3(256), 0, st, rt, kGrid);
+  UGN_CHECK_LAUNCH("w5_reduce");
+  return 0;
+}
 
 extern "C" int ugn_set_persistent_wgs(int n) {
   UGN_REQUIRE(n == 0 || (n >= 8 && n <= kGrid), "ugn_set_persistent_wgs: 8..%d workgroups, or 0 for the default (got %d)", kGrid, n);

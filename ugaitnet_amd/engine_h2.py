@@ -8,6 +8,8 @@ kernels that read it.  One launch per layer for all modalities (frame-level laye
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from . import h2, ops
@@ -17,6 +19,11 @@ U8 = torch.uint8
 I16 = torch.int16
 I32 = torch.int32
 NBINS, FEAT, HIDDEN = 62, 128, 256
+# UGN_FUSE_W5=1: the a2 data gradient multiplies its registers with the input patch in place and dL/da1 is never written
+# (dgrad32_w5_kernel).  Correct (tests/test_engine_gpu.py) but not the default: the fused launch takes 704 us against 469 + 278 for
+# the two it replaces, and those 278 ran on the second stream -- the step got 0.12 ms LONGER (the patch gather and the on-the-fly
+# split of both operands cost more vector instructions than the stores they replace).
+FUSE_W5 = os.environ.get("UGN_FUSE_W5", "0") != "0"
 # 3x3 layers: name, cin, cout, spatial size, pooled
 LAYERS3 = (("a2", 32, 32, 64, True), ("b1", 32, 64, 32, False), ("b2", 64, 64, 32, True), ("a3", 32, 64, 32, False),
            ("a4", 64, 64, 32, True), ("b3", 64, 128, 16, False), ("b4", 128, 128, 16, False), ("a5", 64, 128, 16, False),
@@ -181,6 +188,13 @@ def backward_h2(encs, douts, side):
     i2 = T("i2")
     with side(dev):
         h2.conv3x3_wgrad_mm_multi(T("a1"), dp2, 32, [e.G("a2") for e in encs], dz_idxs=i2)
+    if FUSE_W5:
+        # dL/da1 has one consumer, the 5x5 layer's weight gradient: the a2 data gradient multiplies its registers with the input
+        # patch in place (dgrad32_w5_kernel) -- 0.94 GB per step neither written nor read back, three launches fewer
+        h2.dgrad32_wgrad5_multi(dp2, i2, [s.wd("a2")[0] for s in S], [s.wd("a2")[1] for s in S], [s.x for s in S],
+                                [s.slot("x") for s in S], [s.bufs["a1s"] for s in S], [e.G("a1") for e in encs],
+                                [s.slot("w5scale") for s in S])
+        return
     dz1 = [S[i].t("dz1", (geo[i][2], 64, 64, 32)) for i in R]
     h2.conv3x3_dgrad_mm_multi(dp2, [s.wd("a2")[0] for s in S], [s.wd("a2")[1] for s in S], 64, 32, 32, dz1, dz_idxs=i2)
     with side(dev):

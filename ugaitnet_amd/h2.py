@@ -257,6 +257,25 @@ def conv5x5_in_fwd_h2(x, x_meta, w, out, sign=None):
     return out
 
 
+def dgrad32_wgrad5_multi(dzs, dz_idxs, wpks, wmetas, xs, x_metas, signs, dws, scales):
+    """Data gradient of the pooled 32 -> 32 layer fused with the 5x5 first layer's weight gradient (csrc/conv3x3_mm.hip
+    dgrad32_w5_kernel): dws[j] = dL/dW1 [5,5,cin,32]; dL/da1 is never materialised.  dzs: dL/dp2 (H2, pooled) + argmax bytes; xs:
+    network inputs fp32 [n,60,60,cin]; x_metas: {0, bits(max|x|)}; signs: a1 sign words; scales: scratch meta records."""
+    njobs = len(dzs)
+    ns = [d.shape[0] for d in dzs]
+    cins = [x.shape[3] for x in xs]
+    nbytes = _lib.load().ugn_mm_dgrad32_wgrad5_ws(njobs)
+    ws = _workspace(nbytes, xs[0].device)
+    n = int(sum(ns))
+    flops = 2.0 * 9 * 32 * 32 * 64 * 64 * n
+    label = "conv3x3_dgrad[32->32 @64x64 pooled h2]+conv5x5_wgrad dgrad32_w5_kernel"
+    work = dict(flops=flops, mfma_flops=3.0 * flops, bytes=None, kernel="dgrad32_w5_kernel", bound="mfma", images=n, dtype="f16x2")
+    call("ugn_mm_dgrad32_wgrad5_multi", ptr_array([d.data for d in dzs]), ptr_array([d.meta for d in dzs]), ptr_array(dz_idxs),
+         ptr_array(wpks), ptr_array(wmetas), ptr_array(xs), ptr_array(x_metas), ptr_array(signs), ptr_array(dws), ptr_array(scales),
+         _ints(ns), _ints(cins), njobs, ptr(ws), ws.numel(), _stream(), label=label, work=work)
+    return dws
+
+
 def conv5x5_in_wgrad_h2(x, dz1, dw, sign=None):
     n, cin = x.shape[0], x.shape[3]
     nbytes = _lib.load().ugn_conv5x5_in_wgrad_ws(n, cin)
