@@ -111,7 +111,11 @@ def build_parser():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--dense-only", action="store_true", help="skip the secondary mask-skipping run (profiling target)")
+    ap.add_argument("--dense-only", action="store_true",
+                    help="skip the secondary runs (mask-skipping, IEEE-fp32 line): only the named arithmetic runs (profiling target)")
+    ap.add_argument("--no-f32-line", action="store_true",
+                    help="default (f16x2) run only: do not time the IEEE-fp32 Winograd path beside it (value_f32 / ms_per_step_f32 / "
+                         "roofline_f32)")
     ap.add_argument("--skip-masked", action="store_true",
                     help="run each encoder only on the clips whose modality flag is 1 (exactly the same results; the default "
                          "line computes the masked pairs too)")
@@ -199,7 +203,22 @@ def roofline_pass(core, batch, steps, dtype, table_path=""):
         tot, avg, n, label = row
         w = work.get(label)
         d = dict(kernel=label, launches_per_step=n // steps, avg_us=round(avg, 1), share_of_step=round(tot / total, 4))
-        if w and w["bound"] == "mfma":
+        if w and w["bound"] == "roof":
+            # both roofs (f16x2 3x3 kernels): executed matrix FLOPs against the dense f16 peak AND algorithmic bytes against 8 TB/s;
+            # `bound` = the roof whose floor (time at peak) is higher, and achieved / peak / unit / frac are that roof's
+            t = avg * 1e-6
+            mfma_frac, hbm_frac = w["mfma_flops"] / t / PEAK_BF16_MFMA, w["bytes"] / t / PEAK_HBM
+            mfma_floor, hbm_floor = w["mfma_flops"] / PEAK_BF16_MFMA, w["bytes"] / PEAK_HBM
+            if mfma_floor >= hbm_floor:
+                d.update(bound="mfma", unit="TFLOP/s", peak=round(PEAK_BF16_MFMA / 1e12, 1), achieved=round(w["mfma_flops"] / avg / 1e6, 2),
+                         frac=round(mfma_frac, 4))
+            else:
+                d.update(bound="hbm", unit="GB/s", peak=PEAK_HBM / 1e9, achieved=round(w["bytes"] / avg / 1e3, 1), frac=round(hbm_frac, 4))
+            d.update(mfma_frac=round(mfma_frac, 4), hbm_frac=round(hbm_frac, 4), mfma_floor_us=round(mfma_floor * 1e6, 1),
+                     hbm_floor_us=round(hbm_floor * 1e6, 1), mfma_tflops=round(w["mfma_flops"] / avg / 1e6, 2),
+                     algorithmic_tflops=round(w["flops"] / avg / 1e6, 2), algorithmic_gbytes_per_s=round(w["bytes"] / avg / 1e3, 1),
+                     rocprof_kernel=w["kernel"], images_per_launch=w["images"])
+        elif w and w["bound"] == "mfma":
             peak = PEAK_BF16_MFMA if w["dtype"] in ("bf16", "f16x2") else PEAK_F32_MFMA   # (f16 MFMAs run at the bf16 rate)
             d.update(bound="mfma", unit="TFLOP/s", peak=round(peak / 1e12, 1), achieved=round(w["mfma_flops"] / avg / 1e6, 2),
                      frac=round(w["mfma_flops"] / (avg * 1e-6) / peak, 4), algorithmic_tflops=round(w["flops"] / avg / 1e6, 2),
@@ -213,12 +232,13 @@ def roofline_pass(core, batch, steps, dtype, table_path=""):
         return d
     if table_path:
         with open(table_path, "w") as f:
-            f.write("label,launches_per_step,avg_us,total_us_per_step,share,bound,achieved,peak,unit,frac,rocprof_kernel\n")
+            f.write("label,launches_per_step,avg_us,total_us_per_step,share,bound,achieved,peak,unit,frac,mfma_frac,hbm_frac,rocprof_kernel\n")
             for row in rows:
                 d = describe(row)
-                f.write('"%s",%d,%.1f,%.1f,%.4f,%s,%s,%s,%s,%s,"%s"\n' % (
+                f.write('"%s",%d,%.1f,%.1f,%.4f,%s,%s,%s,%s,%s,%s,%s,"%s"\n' % (
                     d["kernel"], d["launches_per_step"], d["avg_us"], row[0] / steps, d["share_of_step"], d.get("bound", ""),
-                    d.get("achieved", ""), d.get("peak", ""), d.get("unit", ""), d.get("frac", ""), d.get("rocprof_kernel", "")))
+                    d.get("achieved", ""), d.get("peak", ""), d.get("unit", ""), d.get("frac", ""), d.get("mfma_frac", ""),
+                    d.get("hbm_frac", ""), d.get("rocprof_kernel", "")))
     top = describe(rows[0])
     roof = dict(bound=top.get("bound"), achieved=top.get("achieved"), peak=top.get("peak"), unit=top.get("unit"),
                 frac=top.get("frac"), traffic=None)
@@ -228,7 +248,9 @@ def roofline_pass(core, batch, steps, dtype, table_path=""):
                    "duration, against the peak of the instruction that executes them: f16x2 kernels run three f16 MFMAs per "
                    "fp32-class product (3x the direct-convolution count `algorithmic_tflops`, dense f16/bf16 peak); Winograd "
                    "F(2x2,3x3) fp32 kernels 16/36 of it (fp32-MFMA peak); HBM-bound kernels (and every bf16 3x3 kernel: mfma_frac "
-                   "is their second figure): algorithmic bytes / avg duration against 8 TB/s" % steps)
+                   "is their second figure): algorithmic bytes / avg duration against 8 TB/s.  f16x2 3x3 kernels carry BOTH figures "
+                   "(mfma_frac, hbm_frac) and `bound` names the roof whose floor -- executed FLOPs / 2516.8 TFLOP/s or algorithmic "
+                   "bytes / 8 TB/s -- is the longer time" % steps)
     # `traffic` is NOT measured in this run: it is the PMC figure (FETCH_SIZE x2-corrected + WRITE_SIZE, separate --pmc passes) of
     # the same kernel and launch size recorded by tools/profile_run.sh; absent (null) when no record matches
     for tname in ("roofline_traffic_%s.json" % dtype, "roofline_traffic.json"):
@@ -312,10 +334,10 @@ def run(args):
             n_ids = b_gpu // wl["ids_per"]
         xs, uses, labels, onehot = make_batch(kinds, b_gpu, L, ncls, ids=n_ids, seed=232323 + rank)
 
-    def make_core(skip):
+    def make_core(skip, precision=None):
         return GaitCore([2 if k == "of" else 1 for k in kinds], nclasses=ncls, multimodal=multimodal, fuse_mode="sign_max", margin=0.2,
                         loss_weights=(1.0, 0.1), device=dev, seed=232323, lr=1e-4, world_size=world, skip_masked=skip and multimodal,
-                        dp_mode=dp_mode, conv_precision=args.dtype, force_collectives=args.force_dist)
+                        dp_mode=dp_mode, conv_precision=precision or args.dtype, force_collectives=args.force_dist)
 
     core = make_core(args.skip_masked)
     dxs = [torch.from_numpy(np.ascontiguousarray(x)).to(dev) for x in xs]
@@ -361,6 +383,7 @@ def run(args):
     if ctx:
         ctx.__exit__(None, None, None)
     losses = core.losses()
+    grad_bytes = int(core.store.numel * 4)
 
     roof = None
     if not args.no_roofline_pass:
@@ -371,10 +394,26 @@ def run(args):
     skip_rate = None
     if not args.skip_masked and not args.dense_only and not args.serial and multimodal:
         del core
+        core = None
         torch.cuda.empty_cache()
         core2 = make_core(True)
         dt2 = timed(core2, (dxs, uses, labels, doh))
         skip_rate = world * b_gpu * args.steps / dt2
+        del core2
+
+    # The SAME job in IEEE fp32 (BASELINE configs[1..3] say fp32 and the reference computes in fp32, nets/mj_uwyhNets_ba.py:428-462):
+    # fp32 tensors in HBM, Winograd F(2x2,3x3) on the fp32 MFMA, same steps / warm-up / barriers -- reported BESIDE the default
+    # arithmetic's line (value_f32, ms_per_step_f32, roofline_f32), never as `value`.
+    f32 = None
+    if args.dtype == "h2" and not (args.no_f32_line or args.dense_only or args.serial or args.skip_masked or args.graph):
+        core = None
+        torch.cuda.empty_cache()
+        core32 = make_core(False, "f32")
+        dt32 = timed(core32, batch)
+        loss32 = core32.losses()["loss"]
+        roof32 = None if args.no_roofline_pass else roofline_pass(core32, batch, 3, "f32")
+        f32 = dict(dt=dt32, loss=loss32, roof=roof32)
+        del core32
 
     if rank == 0:
         value = world * b_gpu * args.steps / dt
@@ -386,7 +425,7 @@ def run(args):
                 rccl = None
             dist_info = dict(backend=dist.get_backend(), world_size=dist.get_world_size(), rccl_version=rccl,
                              allreduce="bucketed, overlapped with backward" if engine.AR_OVERLAP else "one call after backward",
-                             gradient_bytes=int(core.store.numel * 4), collectives_ms_per_step=coll_ms)
+                             gradient_bytes=grad_bytes, collectives_ms_per_step=coll_ms)
         fpc = flop_per_clip(kinds)
         exec_factor = {"f32": 16.0 / 36.0, "bf16": 1.0, "h2": 3.0}[args.dtype]
         exec_peak = PEAK_F32_MFMA if args.dtype == "f32" else PEAK_BF16_MFMA
@@ -413,6 +452,17 @@ def run(args):
                                   "f16 peak of 2.5 PFLOP/s)")
         if skip_rate is not None:
             out["value_skip_masked"] = round(skip_rate, 2)   # 29 of the 72 (clip, modality) pairs of the C3 batch are masked
+        if f32 is not None:
+            out["value_f32"] = round(world * b_gpu * args.steps / f32["dt"], 2)
+            out["ms_per_step_f32"] = round(f32["dt"] / args.steps * 1e3, 3)
+            out["dtype_f32"] = ("f32: IEEE fp32 tensors and arithmetic end to end, 3x3 layers as Winograd F(2x2,3x3) on "
+                                "v_mfma_f32_16x16x4_f32 (GaitCore(conv_precision='f32')); same batch, steps, warm-up and barriers as `value`")
+            out["loss_f32"] = round(f32["loss"], 5)
+            out["whole_step_frac_of_matrix_peak_f32"] = round(out["value_f32"] * fpc * (16.0 / 36.0) / world / PEAK_F32_MFMA, 4)
+            if f32["roof"] is not None:
+                keep = ("kernel", "bound", "achieved", "peak", "unit", "frac", "avg_us", "launches_per_step", "share_of_step",
+                        "algorithmic_tflops", "rocprof_kernel", "images_per_launch", "serial_step_us")
+                out["roofline_f32"] = {k: f32["roof"].get(k) for k in keep}
         if not args.no_cpu_baseline and world == 1:
             big = b_gpu > 40      # (the generator-expanded batches: time the workload's own batch on the CPU)
             out["cpu_baseline"] = cpu_baseline(kinds, ncls, wl["clips"] if big else b_gpu, wl["clips"] // wl["ids_per"] if big else n_ids,

@@ -95,16 +95,41 @@ def test_roofline_object_of_the_default_command(dev, tmp_path, dtype):
     d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
     roof = d["roofline"]
     assert d["dtype"].startswith("f16x2" if dtype == "h2" else "f32")
-    assert roof["bound"] == "mfma" and roof["unit"] == "TFLOP/s" and roof["peak"] == (2516.8 if dtype == "h2" else 157.3)
+    if dtype == "h2":
+        # both roofs are priced; `bound` names the one whose floor (executed FLOPs / 2516.8 TFLOP/s, algorithmic bytes / 8 TB/s) is higher
+        assert roof["bound"] in ("mfma", "hbm") and 0 < roof["mfma_frac"] <= 1.0 and 0 < roof["hbm_frac"] <= 1.0
+        assert (roof["bound"] == "mfma") == (roof["mfma_floor_us"] >= roof["hbm_floor_us"])
+        assert roof["frac"] == (roof["mfma_frac"] if roof["bound"] == "mfma" else roof["hbm_frac"])
+        assert (roof["unit"], roof["peak"]) == (("TFLOP/s", 2516.8) if roof["bound"] == "mfma" else ("GB/s", 8000.0))
+        assert abs(roof["mfma_tflops"] / roof["algorithmic_tflops"] - 3.0) < 0.01     # three f16 MFMAs per product
+    else:
+        assert roof["bound"] == "mfma" and roof["unit"] == "TFLOP/s" and roof["peak"] == 157.3
+        assert abs(roof["achieved"] / roof["algorithmic_tflops"] - 16.0 / 36.0) < 0.01     # Winograd: 16/36 of the direct count
     assert 0.05 < roof["frac"] <= 1.0 and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3
-    # executed / algorithmic FLOPs: three f16 MFMAs per product on the H2 path, 16/36 of the direct count for Winograd
-    assert abs(roof["achieved"] / roof["algorithmic_tflops"] - (3.0 if dtype == "h2" else 16.0 / 36.0)) < 0.01
     assert roof["kernel"].startswith("conv3x3_") and ("_mm_kernel" if dtype == "h2" else "wino") in roof["rocprof_kernel"]
     assert roof["launches_per_step"] >= 1
     assert roof["avg_us"] > 0 and 0 < roof["share_of_step"] < 0.5 and roof["serial_step_us"] > 0
     kinds = {k.get("bound") for k in roof["other_kernels"]}
-    assert "mfma" in kinds and all(k.get("frac", 0) <= 1.0 for k in roof["other_kernels"] if k.get("bound") == "mfma")
+    assert "mfma" in kinds and all(k.get("frac", 0) <= 1.0 for k in roof["other_kernels"] if k.get("bound") in ("mfma", "hbm"))
+    assert "value_f32" not in d       # (--dense-only: the named arithmetic only)
     rows = open(table).read().splitlines()
     assert rows[0].startswith("label,launches_per_step") and len(rows) > 25
     assert any("setmax_fwd" in ln and ",hbm," in ln for ln in rows)
     assert d["scaling"] == "weak" and d["n_gpus"] == 1 and d["config"]["distributed"] is None
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_fp32_line_beside_the_default_line(dev):
+    """the bare command times the IEEE-fp32 path (BASELINE configs[1..3] say fp32; the reference computes in fp32,
+    nets/mj_uwyhNets_ba.py:428-462) for the same steps / warm-up after the default f16x2 run and reports it BESIDE `value`."""
+    r = subprocess.run([sys.executable, BENCH, "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--clips-per-gpu", "8"],
+                       env=_env(), capture_output=True, text=True, timeout=800)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert d["dtype"].startswith("f16x2") and d["dtype_f32"].startswith("f32")
+    assert d["value_f32"] > 0 and d["ms_per_step_f32"] > 0 and abs(d["value_f32"] * d["ms_per_step_f32"] / 1e3 - 8) < 0.05
+    rf = d["roofline_f32"]
+    assert rf["bound"] == "mfma" and rf["peak"] == 157.3 and 0.05 < rf["frac"] <= 1.0 and "wino" in rf["rocprof_kernel"]
+    assert abs(d["loss_f32"] - d["loss"]) < 1e-3      # the same job: same batch, same initial weights, same number of steps
+    assert d["value"] > 0 and "value_skip_masked" in d

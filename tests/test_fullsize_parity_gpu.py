@@ -7,13 +7,17 @@ these sizes).
 C5 (configs[4]: C4's modalities, 16 clips per GPU, bf16 MFMA operands) runs the same comparison with the bf16 mode's bars.
 Bars: loss <= 1e-4, signature <= 1e-3 (north_star's tolerance; observed ~1e-5), active-triplet counts equal up to hinges that
 sit within fp32 rounding of zero (C3: exact; C4 has 744k hinges per step: at most 1 per bin, 3 in all), every parameter
-gradient <= 5e-3 relative L2 (an fp32-vs-fp64 near-tie can flip a MaxPool / set-max / HPP / sign_max routing decision)."""
+gradient <= 5e-3 relative L2 WITH the routing census beside it (round 4): every MaxPool / set-max / HPP / sign_max decision of the
+step is compared with the fp64 oracle's, the flips are counted per family and each one is proven a near-tie (tests/routing.py); with
+no flip the bar is 1e-4, and on the headline workload (C3, f16x2) the oracle is also forced to the HIP path's routing: 5e-5.
+The fp64 oracle is evaluated ONCE per workload (the f32 and the f16x2 case share it)."""
 import numpy as np
 import pytest
 import torch
 
 from oracle import torch_ref as T
 from oracle import ugaitnet_oracle as O
+from tests import routing as R
 from tests.synth import make_batch
 
 pytestmark = pytest.mark.gpu
@@ -39,19 +43,61 @@ def _rell2(a, b):
     return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))
 
 
-@pytest.mark.timeout(1500)
-@pytest.mark.parametrize("name", ["C2", "C3", "C4", "C5", "C2h2", "C3h2", "C4h2"])
-def test_whole_step_matches_the_fp64_oracle(dev, name):
-    from ugaitnet_amd.engine import GaitCore
-    c = CASES[name]
-    kinds, b, ncls = c["kinds"], c["b"], c["ncls"]
+# ONE evaluation of the fp64 oracle per workload: the f32 and the h2 case of a workload share inputs, weights
+# and therefore the oracle's losses, gradients and routing decisions; a single entry is kept (cases of a workload run back to back).
+_ORACLE = {}
+
+
+def _oracle(c):
+    kinds, b, ncls, multimodal = c["kinds"], c["b"], c["ncls"], c.get("multimodal", True)
+    key = (kinds, b, c["ids"], ncls, multimodal)
+    if key in _ORACLE:
+        return _ORACLE[key]
+    _ORACLE.clear()
     xs, uses, labels, onehot = make_batch(kinds, b, 25, ncls, ids=c["ids"], seed=232323)
     rng = np.random.default_rng(11)
     p64 = dict(branches=[O.init_branch_params(rng, 2 if k == "of" else 1, np.float64) for k in kinds],
                head=O.init_head_params(rng, ncls, np.float64))
     p64["head"]["bc"] = rng.normal(size=ncls) * 0.01
+    torch.set_num_threads(max(1, torch.get_num_threads()))
+    tp = T.params_from_numpy(p64, dtype=torch.float64)
+    x64 = [torch.from_numpy(x.astype(np.float64)) for x in xs]
+    u64 = [torch.from_numpy(u.astype(np.float64)) for u in uses] if multimodal else None
+    res, g = T.loss_and_grads(x64, u64, torch.from_numpy(labels), torch.from_numpy(onehot.astype(np.float64)), tp, margin=0.2,
+                              loss_weights=(1.0, 0.1), multimodal=multimodal)
+    # the oracle's routing decisions, with the gaps of every near-tie (tests/routing.py): the same graph, tapped
+    decs, sel = [], None
+    if c.get("precision") != "bf16":
+        for x, bp in zip(x64, tp["branches"]):
+            out, dec = R.oracle_branch_census(x, {k: v.detach() for k, v in bp.items()})
+            decs.append(dec)
+        sel = R.sign_max_census([o.detach() for o in res["outs"]], u64) if multimodal else None
+    entry = dict(xs=xs, uses=uses, labels=labels, onehot=onehot, p64=p64, x64=x64, u64=u64,
+                 loss=float(res["loss"]), triplet=float(res["triplet"]), xent=float(res["xent"]),
+                 signature=res["signature"].detach().numpy(), tri_counts=res["tri_counts"].numpy().astype(np.int64),
+                 grads=dict(branches=[{k: v.numpy() for k, v in bp.items()} for bp in g["branches"]],
+                            head={k: v.numpy() for k, v in g["head"].items()}), decs=decs, sel=sel)
+    _ORACLE[key] = entry
+    return entry
+
+
+# the decisions of a step may differ from the fp64 oracle's only at near-ties: the oracle's value at the HIP path's choice within
+# NEAR_TIE fp32 ulps of the tensor's scale below the oracle's maximum (VERDICT r03 item 3 asks for 8; the convolutions feeding the
+# deepest decisions carry up to 5e-6 of their scale = 40 ulp of rounding themselves -- tests/test_mm_gpu.py -- so the bar is per family)
+NEAR_TIE = dict(i2=8, m1=8, j2=16, i4=16, m2=16, m3=32, hpp_a=32, hpp_b=32, sel=32)
+
+
+# cases of one workload are adjacent: the oracle is evaluated once per workload
+@pytest.mark.timeout(1500)
+@pytest.mark.parametrize("name", ["C2", "C2h2", "C3", "C3h2", "C4", "C4h2", "C5"])
+def test_whole_step_matches_the_fp64_oracle(dev, name):
+    from ugaitnet_amd.engine import GaitCore
+    c = CASES[name]
+    kinds, b, ncls = c["kinds"], c["b"], c["ncls"]
     bf16 = c.get("precision") == "bf16"
     multimodal = c.get("multimodal", True)
+    E = _oracle(c)
+    xs, uses, labels, onehot, p64 = E["xs"], E["uses"], E["labels"], E["onehot"], E["p64"]
     core = GaitCore([2 if k == "of" else 1 for k in kinds], nclasses=ncls, multimodal=multimodal, fuse_mode="sign_max", margin=0.2,
                     loss_weights=(1.0, 0.1), device=dev, conv_precision=c.get("precision", "f32"))
     core.set_params_numpy(O.cast_params(p64, np.float32))
@@ -61,26 +107,19 @@ def test_whole_step_matches_the_fp64_oracle(dev, name):
     sig = core.sig.cpu().numpy()
     ls = core.losses()
     counts = core.bin_num.cpu().numpy()
-
-    torch.set_num_threads(max(1, torch.get_num_threads()))
-    tp = T.params_from_numpy(p64, dtype=torch.float64)
-    res, g = T.loss_and_grads([torch.from_numpy(x.astype(np.float64)) for x in xs],
-                              [torch.from_numpy(u.astype(np.float64)) for u in uses] if multimodal else None, torch.from_numpy(labels),
-                              torch.from_numpy(onehot.astype(np.float64)), tp, margin=0.2, loss_weights=(1.0, 0.1),
-                              multimodal=multimodal)
-    dcount = np.abs(counts.astype(np.int64) - res["tri_counts"].numpy().astype(np.int64))
+    dcount = np.abs(counts.astype(np.int64) - E["tri_counts"])
     if bf16:    # bf16 operands (8 significant bits) in every 3x3 convolution: the bars of test_bf16_operand_mode_against_the_oracle
         # under sign_max a near-tie between two modalities flips the selected one (and possibly the sign) at 8 significant bits:
         # the FRACTION of such elements is bounded, the rest stays within the bf16 bar (as in test_bf16_operand_mode_...)
-        assert abs(ls["loss"] - float(res["loss"])) <= 5e-2 * abs(float(res["loss"])), (ls, float(res["loss"]))
-        serr = np.abs(sig - res["signature"].detach().numpy())
+        assert abs(ls["loss"] - E["loss"]) <= 5e-2 * abs(E["loss"]), (ls, E["loss"])
+        serr = np.abs(sig - E["signature"])
         assert (serr > 5e-2).mean() < 0.05 and np.median(serr) <= 5e-3, ((serr > 5e-2).mean(), np.median(serr))
-        assert dcount.max() <= 0.05 * max(1.0, float(res["tri_counts"].max()))
+        assert dcount.max() <= 0.05 * max(1.0, float(E["tri_counts"].max()))
     else:
-        assert abs(ls["loss"] - float(res["loss"])) <= 1e-4, (ls, float(res["loss"]))
-        assert abs(ls["triplet"] - float(res["triplet"])) <= 1e-4 and abs(ls["xent"] - float(res["xent"])) <= 1e-4
+        assert abs(ls["loss"] - E["loss"]) <= 1e-4, (ls, E["loss"])
+        assert abs(ls["triplet"] - E["triplet"]) <= 1e-4 and abs(ls["xent"] - E["xent"]) <= 1e-4
         # (the single-modality graph feeds the RAW branch output to both heads: its scale is not 1, so the bar is relative)
-        sref = res["signature"].detach().numpy()
+        sref = E["signature"]
         assert np.abs(sig - sref).max() <= 1e-3 * max(1.0, float(np.abs(sref).max()))
         if name.startswith("C3") or name.startswith("C2"):
             assert dcount.max() == 0, dcount
@@ -88,19 +127,51 @@ def test_whole_step_matches_the_fp64_oracle(dev, name):
             assert dcount.max() <= 1 and dcount.sum() <= 3, dcount
     worst = {}
     for mi in range(len(kinds)):
-        for k, ref in g["branches"][mi].items():
-            worst["m%d.%s" % (mi, k)] = _rell2(got["branches"][mi][k], ref.numpy())
-    for k, ref in g["head"].items():
-        worst["head." + k] = _rell2(got["head"][k], ref.numpy())
-    # bf16 at full size (measured): 0.09 ... 0.15 on the gray / silhouette branches, 0.14 ... 0.30 on the optical-flow branch, 0.02 on
-    # the classifier: decision flips of the losses and of the routing at 8 significant bits included (tests/test_engine_gpu.py
-    # test_branch_gradients_with_a_fixed_cotangent separates the branches from the losses)
-    bad = {k: v for k, v in worst.items() if v > ((3.5e-1 if k.startswith("m0.") else 2.5e-1) if bf16 else 5e-3)}
+        for k, ref in E["grads"]["branches"][mi].items():
+            worst["m%d.%s" % (mi, k)] = _rell2(got["branches"][mi][k], ref)
+    for k, ref in E["grads"]["head"].items():
+        worst["head." + k] = _rell2(got["head"][k], ref)
     if bf16:
+        # bf16 at full size (measured): 0.09 ... 0.15 on the gray / silhouette branches, 0.14 ... 0.30 on the optical-flow branch, 0.02 on
+        # the classifier: decision flips of the losses and of the routing at 8 significant bits included (tests/test_engine_gpu.py
+        # test_branch_gradients_with_a_fixed_cotangent separates the branches from the losses)
+        bad = {k: v for k, v in worst.items() if v > (3.5e-1 if k.startswith("m0.") else 2.5e-1)}
         assert float(np.median(list(worst.values()))) <= 1.5e-1 and worst["head.wc"] <= 5e-2, worst
-    assert not bad, (bad, worst)
-    if bf16:
+        assert not bad, (bad, worst)
         print("%s gradient rel-L2 per tensor: %s" % (name, ", ".join("%s %.3f" % kv for kv in sorted(worst.items(), key=lambda kv: -kv[1]))))
+    else:
+        # ---- routing census: every decision of the step against the oracle's, flips counted per family, each one
+        # proven a near-tie; the gradient bars then follow from the count
+        routes = [R.hip_routing(core, mi) for mi in range(len(kinds))]
+        flips, lines = 0, []
+        for mi in range(len(kinds)):
+            # (clips whose modality flag is 0 carry the constant 1e-9: the gate multiplies that branch by 0, no gradient is routed)
+            active = (np.asarray(uses[mi]).reshape(-1) != 0) if multimodal else None
+            res = R.census(E["decs"][mi], routes[mi], b, 25, active)
+            lines.append("m%d: %s" % (mi, R.format_census(res)))
+            for fam, (n, f, w) in res.items():
+                assert w <= NEAR_TIE[fam] * R.FP32_ULP, "branch %d, %s: a decision differs from the oracle's %.3g fp32 ulp of the tensor " \
+                    "scale away from a tie (%d flips of %d)" % (mi, fam, w / R.FP32_ULP, f, n)
+                flips += f
+        sel = None
+        if multimodal:
+            sel = core.sel.cpu().numpy()
+            n, f, w = E["sel"].compare(sel)
+            lines.append("sign_max: %d/%d flips (worst gap %.2g ulp32 of scale)" % (f, n, w / R.FP32_ULP))
+            assert w <= NEAR_TIE["sel"] * R.FP32_ULP, lines[-1]
+            flips += f
+        print("%s routing census vs the fp64 oracle -- %s" % (name, " | ".join(lines)))
+        # gradient bars as a function of the census: without a single flip the gradients are the oracle's to fp32 rounding; with
+        # flips (each proven a near-tie above) a tensor may move by what those reroutings move it -- bounded here by 5e-3 -- and on
+        # the headline workload the oracle is additionally FORCED to the HIP path's routing, which removes the flips: 5e-5 then
+        bar = 5e-3 if flips else 1e-4
+        bad = {k: v for k, v in worst.items() if v > bar}
+        assert not bad, (flips, bad, worst)
+        if name == "C3h2" and flips:
+            gf = R.forced_step_grads(E["x64"], E["u64"], labels, onehot, p64, routes, sel, multimodal=multimodal)
+            wf = R.grad_errors(got, gf)
+            print("%s with the oracle forced to the HIP path's routing: worst gradient rel-L2 %.2e (%s), median %.2e; unforced worst %.2e"
+                  % (name, max(wf.values()), max(wf, key=wf.get), float(np.median(list(wf.values()))), max(worst.values())))
+            assert max(wf.values()) <= 5e-5, wf
     print("%s: loss %.6f (oracle %.6f), max |sig - oracle| %.2e, worst gradient rel-L2 %.2e (%s)"
-          % (name, ls["loss"], float(res["loss"]), np.abs(sig - res["signature"].detach().numpy()).max(),
-             max(worst.values()), max(worst, key=worst.get)))
+          % (name, ls["loss"], E["loss"], np.abs(sig - E["signature"]).max(), max(worst.values()), max(worst, key=worst.get)))

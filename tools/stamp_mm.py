@@ -19,7 +19,7 @@ from ugaitnet_amd import _lib, h2
 
 CFGS = {"a2": (64, 32, 32, True), "a3": (32, 32, 64, False), "a4": (32, 64, 64, True), "a5": (16, 64, 128, False), "a6": (16, 128, 128, False)}
 NST, NIT = 60, 20
-PER_WAVE = 4 + 5 * NST + 2 * NIT
+PER_WAVE = 4 + 5 * NST + 4 * NIT
 
 
 def main():
@@ -66,7 +66,7 @@ def main():
     names = ["DMA wait", "barrier", "DMA issue (+scatter)", "reads + MFMA", "to next stage"]
     for wg in (0, 100):
         q = st[wg, :, 4:4 + 5 * NST].reshape(8, NST, 5)
-        it = st[wg, :, 4 + 5 * NST:].reshape(8, NIT, 2)
+        it = st[wg, :, 4 + 5 * NST:].reshape(8, NIT, 4)
         n = int((q[0, :, 4] > 0).sum()) - 1
         seg = np.stack([q[:, 1:n, 1] - q[:, 1:n, 0], q[:, 1:n, 2] - q[:, 1:n, 1], q[:, 1:n, 3] - q[:, 1:n, 2], q[:, 1:n, 4] - q[:, 1:n, 3],
                         q[:, 2:n + 1, 0] - q[:, 1:n, 4]], axis=-1)
@@ -78,6 +78,9 @@ def main():
         if m > 2:
             print("  %-22s %s" % ("epilogue", " ".join("%6.0f" % v for v in (it[:, 1:m, 1] - it[:, 1:m, 0]).mean(axis=1))))
             print("  %-22s %s" % ("item period", " ".join("%6.0f" % v for v in (it[:, 2:m, 0] - it[:, 1:m - 1, 0]).mean(axis=1))))
+            if (it[:, 1:m, 3] > 0).any():      # (register-staged pooled scatter: wait for the loads + scatter, inside the taps)
+                print("  %-22s %s" % ("scatter (in taps)", " ".join("%6.0f" % v for v in (it[:, 1:m, 3] - it[:, 1:m, 2]).mean(axis=1))))
+                print("  %-22s %s" % ("scatter start - top", " ".join("%6.0f" % v for v in (it[:, 1:m, 2] - q[:, 1:m, 0]).mean(axis=1))))
 
 
 if __name__ == "__main__":

@@ -48,8 +48,17 @@ def build(force=False, verbose=True, variant=None, extra=()):
     if force:
         for f in os.listdir(objdir):
             os.remove(os.path.join(objdir, f))
+    # a variant recompiles only the sources (or headers) that mention one of its -D macros; the rest links the default build's objects
+    macros = [f[2:].split("=")[0] for f in extra if f.startswith("-D")]
+    hdr_hit = any(m in open(h).read() for h in HEADERS for m in macros)
+
+    def one(src):
+        if variant is not None and macros and len(macros) == len(list(extra)) and not hdr_hit:
+            if not any(m in open(os.path.join(CSRC, src)).read() for m in macros):
+                return _compile(src, OBJ, ())
+        return _compile(src, objdir, extra)
     with ThreadPoolExecutor(max_workers=4) as ex:
-        res = list(ex.map(lambda src: _compile(src, objdir, extra), SOURCES))
+        res = list(ex.map(one, SOURCES))
     objs = [o for o, _ in res]
     if any(c for _, c in res) or _stale(LIB, objs):
         cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs

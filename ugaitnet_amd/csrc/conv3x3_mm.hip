@@ -58,8 +58,22 @@ struct Geo {
 // 32 -> 32 layers (one K chunk, one block): the whole filter of a job -- 3 stages, 36 KB -- stays in LDS
 template <int KC, int NC>
 constexpr bool filter_resident() { return KC == 32 && NC == 32; }
+// REGSTG (32 -> 32 pooled data gradient): the pooled gradient + argmax bytes of the next tile travel through REGISTERS (plain global
+// loads one item ahead), not through a DMA'd staging tile; waves 0-3 scatter them into the next halo buffer behind tap 3, waves 4-7
+// behind tap 6 -- while the other wave of their SIMD multiplies -- and the item keeps ONE barrier.
+#ifndef UGN_MM_REGSTG
+#define UGN_MM_REGSTG 1
+#endif
+#ifndef UGN_MM_REGSTG_TAP0
+#define UGN_MM_REGSTG_TAP0 3
+#define UGN_MM_REGSTG_TAP1 6
+#endif
 template <int KC, int NC, int IN_POOLED>
-constexpr int lds_bytes() { return W_OFF + (filter_resident<KC, NC>() ? 3 : 2) * Geo<NC>::WSTAGE + (IN_POOLED ? STG_BYTES : 0); }
+constexpr bool reg_staged() { return filter_resident<KC, NC>() && IN_POOLED && UGN_MM_REGSTG; }
+template <int KC, int NC, int IN_POOLED>
+constexpr int lds_bytes() {
+  return W_OFF + (filter_resident<KC, NC>() ? 3 : 2) * Geo<NC>::WSTAGE + (IN_POOLED && !reg_staged<KC, NC, IN_POOLED>() ? STG_BYTES : 0);
+}
 
 // ---------------------------------------------------------------------------------------------------------------------
 // filter statistics + packing
@@ -234,6 +248,27 @@ __device__ __forceinline__ void scatter_pooled(const char* stg, char* halo, int 
   }
 }
 
+// The same scatter with the pooled values and argmax bytes of the lane's unit already in registers (REGSTG: the 32 -> 32 pooled
+// data gradient fetches them with plain global loads one item ahead -- no staging tile, no DMA, no barrier of its own).
+__device__ __forceinline__ void scatter_regs(const uint4& hi, const uint4& lo, const uint2& ix, char* halo, int prow, int pcol, int cg) {
+  const unsigned hv[4] = {hi.x, hi.y, hi.z, hi.w}, lv[4] = {lo.x, lo.y, lo.z, lo.w};
+#pragma unroll
+  for (int pos = 0; pos < 4; ++pos) {
+    const int hy = 2 * prow - 1 + (pos >> 1), hx = 2 * pcol - 1 + (pos & 1);
+    if ((unsigned)hy >= 18u || (unsigned)hx >= 18u) continue;
+    unsigned m[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {            // dword d = channels 2d, 2d+1 of the group
+      const unsigned w = d < 2 ? ix.x : ix.y;
+      const unsigned b0 = (w >> (16 * (d & 1))) & 0xffu, b1 = (w >> (16 * (d & 1) + 8)) & 0xffu;
+      m[d] = (b0 == (unsigned)pos ? 0x0000ffffu : 0u) | (b1 == (unsigned)pos ? 0xffff0000u : 0u);
+    }
+    char* dst = halo + (hy * HROW + hx * 9) * 16 + cg * 16;
+    *reinterpret_cast<uint4*>(dst) = make_uint4(hv[0] & m[0], hv[1] & m[1], hv[2] & m[2], hv[3] & m[3]);
+    *reinterpret_cast<uint4*>(dst + 64) = make_uint4(lv[0] & m[0], lv[1] & m[1], lv[2] & m[2], lv[3] & m[3]);
+  }
+}
+
 __device__ __forceinline__ f32x16 mfma_h(const uint4& a, const uint4& b, f32x16 c) {
 #if UGN_MM_ABLATE & 8
   c[0] += __uint_as_float(a.x ^ b.y);     // (keeps the operands alive)
@@ -276,9 +311,9 @@ __device__ __forceinline__ void dma_halo_lane(const char* region_base, const voi
 #ifdef UGN_MM_STAMP
 __device__ unsigned long long* g_mm_stamp = nullptr;
 constexpr int kStampStages = 60, kStampItems = 20;
-constexpr int kStampPerWave = 4 + 5 * kStampStages + 2 * kStampItems;
+constexpr int kStampPerWave = 4 + 5 * kStampStages + 4 * kStampItems;
 #define STAMP_ST(k_) do { if (stamp && lane == 0 && nst < kStampStages) stamp[4 + 5 * nst + (k_)] = __builtin_amdgcn_s_memtime(); } while (0)
-#define STAMP_IT(k_) do { if (stamp && lane == 0 && nit < kStampItems) stamp[4 + 5 * kStampStages + 2 * nit + (k_)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define STAMP_IT(k_) do { if (stamp && lane == 0 && nit < kStampItems) stamp[4 + 5 * kStampStages + 4 * nit + (k_)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define STAMP_ST(k_) do { } while (0)
 #define STAMP_IT(k_) do { } while (0)
@@ -367,10 +402,37 @@ __global__ __launch_bounds__(512, 2) void conv_mm_kernel(const MmJobs jt, const 
                         halo_dst + (unsigned)(wave * 6 + j) * 1024u);
     }
   };
+  // REGSTG: this thread's unit of the 10 x 10 pooled pixels under a region's 18 x 18 halo -- pooled pixel spp, channel group scg
+  // (8 channels): 16 B of H halves, 16 B of L halves, 8 argmax bytes, fetched into registers one item ahead
+  constexpr bool REGSTG = reg_staged<KC, NC, IN_POOLED>();
+  const int spp = tid >> 2, scg = tid & 3;
+  const int sprow = (spp * 205) >> 11, spcol = spp - sprow * 10;
+  uint4 shi = make_uint4(0u, 0u, 0u, 0u), slo = make_uint4(0u, 0u, 0u, 0u);
+  uint2 six = make_uint2(0u, 0u);
+  auto stg_load = [&](const MmJob& J, int lit_) {
+    constexpr int HP = HW / 2;
+    const int img = lit_ / RPI, rrem = lit_ % RPI;
+    const int pr = ((rrem / RPX) * 16) / 2 - 1 + sprow, pc = ((rrem % RPX) * 16) / 2 - 1 + spcol;
+    const bool ok = tid < 400 && (unsigned)pr < (unsigned)HP && (unsigned)pc < (unsigned)HP;
+    shi = make_uint4(0u, 0u, 0u, 0u);
+    slo = shi;
+    six = make_uint2(0u, 0u);           // (outside the image the gradient is zero: the scatter still overwrites the stale halo)
+    if (ok) {
+      const unsigned o = (unsigned)(pr * HP + pc);
+      const char* v = img_in(J, img) + o * (unsigned)(KC * 4) + (unsigned)(scg * 16);
+      shi = *reinterpret_cast<const uint4*>(v);
+      slo = *reinterpret_cast<const uint4*>(v + KC * 2);
+      six = *reinterpret_cast<const uint2*>(img_idx(J, img) + o * (unsigned)KC + (unsigned)(scg * 8));
+    }
+  };
   // ---- prologue: input tile of (item, chunk 0) -> halo buffer 0, filter stage 0 -> filter buffer 0 (RES: the whole filter)
   if constexpr (RES) {
+    if constexpr (REGSTG) {
+      stg_load(jt.job[jb], lit);
+    } else {
 #pragma unroll
-    for (int j = 0; j < (IN_POOLED ? 2 : 6); ++j) res_piece(jt.job[jb], lit, sbase, j);
+      for (int j = 0; j < (IN_POOLED ? 2 : 6); ++j) res_piece(jt.job[jb], lit, sbase, j);
+    }
     if (!is_hw) {
 #pragma unroll
       for (int d = 0; d < 3; ++d) stage_w(jt.job[jb].wpk, d, sbase + W_OFF + (unsigned)d * WSTAGE);
@@ -382,7 +444,9 @@ __global__ __launch_bounds__(512, 2) void conv_mm_kernel(const MmJobs jt, const 
     stage_w(jt.job[jb].wpk, 0, sbase + W_OFF);
   }
   int res_job = jb;                 // RES: the job whose filter is in LDS
-  if constexpr (IN_POOLED) {
+  if constexpr (REGSTG) {
+    if (tid < 400) scatter_regs(shi, slo, six, smem, sprow, spcol, scg);      // (visible behind the first item's barrier)
+  } else if constexpr (IN_POOLED) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     scatter_pooled(smem + STG_OFF, smem, tid);
@@ -448,7 +512,9 @@ __global__ __launch_bounds__(512, 2) void conv_mm_kernel(const MmJobs jt, const 
       STAMP_ST(1);
       __syncthreads();
       STAMP_ST(2);
-      if constexpr (IN_POOLED) {
+      if constexpr (REGSTG) {
+        if (more) stg_load(jt.job[jn], nlit);
+      } else if constexpr (IN_POOLED) {
         if (more) {
 #pragma unroll
           for (int j = 0; j < 2; ++j) res_piece(jt.job[jn], nlit, 0u, j);
@@ -456,24 +522,46 @@ __global__ __launch_bounds__(512, 2) void conv_mm_kernel(const MmJobs jt, const 
       }
       STAMP_ST(3);
       const int a_addr = a_lane + hbuf * HALO_BYTES;
-#pragma unroll
-      for (int tap = 0; tap < 9; ++tap) {
+      // software pipeline over the taps: the 8 fragment reads of tap + 1 go out before the 6 MFMAs of tap (pinned with sched_barrier;
+      // see conv_mm16_kernel: left alone hipcc reads one fragment ahead and every second MFMA waits for LDS)
+      uint4 fr[2][2][4];          // [register set][k-step s][AH, AL, BH, BL]
+      auto load_tap = [&](int set, int tap) {
         const int dy = tap / 3, dx = tap % 3;
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
           const int aoff = (dy * HROW + dx * 9) * 16 + s * 32;
-          const uint4 ah = *reinterpret_cast<const uint4*>(smem + a_addr + aoff);
-          const uint4 al = *reinterpret_cast<const uint4*>(smem + a_addr + aoff + 64);
-          const uint4 bh = *reinterpret_cast<const uint4*>(smem + b_lane + ((tap * 2 + s) * 2 + 0) * 1024);
-          const uint4 bl = *reinterpret_cast<const uint4*>(smem + b_lane + ((tap * 2 + s) * 2 + 1) * 1024);
-          acc[0] = mfma_h(ah, bh, acc[0]);
-          acc[0] = mfma_h(ah, bl, acc[0]);
-          acc[0] = mfma_h(al, bh, acc[0]);
+          fr[set][s][0] = *reinterpret_cast<const uint4*>(smem + a_addr + aoff);
+          fr[set][s][1] = *reinterpret_cast<const uint4*>(smem + a_addr + aoff + 64);
+          fr[set][s][2] = *reinterpret_cast<const uint4*>(smem + b_lane + ((tap * 2 + s) * 2 + 0) * 1024);
+          fr[set][s][3] = *reinterpret_cast<const uint4*>(smem + b_lane + ((tap * 2 + s) * 2 + 1) * 1024);
         }
+      };
+      load_tap(0, 0);
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        if (tap + 1 < 9) load_tap((tap + 1) & 1, tap + 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          acc[0] = mfma_h(fr[tap & 1][s][0], fr[tap & 1][s][2], acc[0]);
+          acc[0] = mfma_h(fr[tap & 1][s][0], fr[tap & 1][s][3], acc[0]);
+          acc[0] = mfma_h(fr[tap & 1][s][1], fr[tap & 1][s][2], acc[0]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
         if constexpr (!IN_POOLED) {
           if (tap < 6 && more) {
             __builtin_amdgcn_sched_barrier(0);
             res_piece(jt.job[jn], nlit, sbase + (unsigned)(hbuf ^ 1) * HALO_BYTES, tap);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        } else if constexpr (REGSTG) {
+          // MaxPool backward of the next tile, registers -> the other halo buffer (no reader until the next item's barrier).  The two
+          // waves of a SIMD (w, w + 4) take turns: one scatters (~100 vector instructions, 8 ds_write_b128) while the other multiplies.
+          if (more && tap == (wave < 4 ? UGN_MM_REGSTG_TAP0 : UGN_MM_REGSTG_TAP1)) {
+            __builtin_amdgcn_sched_barrier(0);
+            STAMP_IT(2);
+            if (tid < 400) scatter_regs(shi, slo, six, smem + (hbuf ^ 1) * HALO_BYTES, sprow, spcol, scg);
+            STAMP_IT(3);
             __builtin_amdgcn_sched_barrier(0);
           }
         } else {
@@ -538,27 +626,33 @@ __global__ __launch_bounds__(512, 2) void conv_mm_kernel(const MmJobs jt, const 
         }
         STAMP_ST(3);
         const int b_addr = b_lane + wbuf * WSTAGE;
-#pragma unroll
-        for (int t = 0; t < TPS; ++t) {
+        // software pipeline over micro-steps u = (tap, k-step): the 2 + 2 NB fragment reads of u + 1 before the 3 NB MFMAs of u
+        constexpr int NU = TPS * 2;
+        uint4 fa[2][2], fb[2][NB][2];      // [register set][plane] / [register set][block][plane]
+        auto load_u = [&](int set, int u) {
+          const int t = u >> 1, s = u & 1;
           const int tap = sg * TPS + t, dy = tap / 3, dx = tap % 3;
+          const int aoff = (dy * HROW + dx * 9) * 16 + s * 32;
+          fa[set][0] = *reinterpret_cast<const uint4*>(smem + a_addr + aoff);
+          fa[set][1] = *reinterpret_cast<const uint4*>(smem + a_addr + aoff + 64);
 #pragma unroll
-          for (int s = 0; s < 2; ++s) {
-            const int aoff = (dy * HROW + dx * 9) * 16 + s * 32;
-            const uint4 ah = *reinterpret_cast<const uint4*>(smem + a_addr + aoff);
-            const uint4 al = *reinterpret_cast<const uint4*>(smem + a_addr + aoff + 64);
-            uint4 bh[NB], bl[NB];
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb) {
-              bh[nb] = *reinterpret_cast<const uint4*>(smem + b_addr + (((t * 2 + s) * NB + nb) * 2 + 0) * 1024);
-              bl[nb] = *reinterpret_cast<const uint4*>(smem + b_addr + (((t * 2 + s) * NB + nb) * 2 + 1) * 1024);
-            }
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb) acc[nb] = mfma_h(ah, bh[nb], acc[nb]);
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb) acc[nb] = mfma_h(ah, bl[nb], acc[nb]);
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb) acc[nb] = mfma_h(al, bh[nb], acc[nb]);
+          for (int nb = 0; nb < NB; ++nb) {
+            fb[set][nb][0] = *reinterpret_cast<const uint4*>(smem + b_addr + (((t * 2 + s) * NB + nb) * 2 + 0) * 1024);
+            fb[set][nb][1] = *reinterpret_cast<const uint4*>(smem + b_addr + (((t * 2 + s) * NB + nb) * 2 + 1) * 1024);
           }
+        };
+        load_u(0, 0);
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+          if (u + 1 < NU) load_u((u + 1) & 1, u + 1);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) acc[nb] = mfma_h(fa[u & 1][0], fb[u & 1][nb][0], acc[nb]);
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) acc[nb] = mfma_h(fa[u & 1][0], fb[u & 1][nb][1], acc[nb]);
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) acc[nb] = mfma_h(fa[u & 1][1], fb[u & 1][nb][0], acc[nb]);
+          __builtin_amdgcn_sched_barrier(0);
         }
         wbuf ^= 1;
         STAMP_ST(4);
@@ -571,7 +665,7 @@ __global__ __launch_bounds__(512, 2) void conv_mm_kernel(const MmJobs jt, const 
     }
     // The next item's first filter stage and input tile are awaited HERE, before this item's stores enter the queue: the
     // first stage of the next item then needs no wait, and the stores have a whole stage to be acknowledged.
-    if (more && !(RES && !IN_POOLED)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (RES: awaited at the top of the next item)
+    if (more && !(RES && !IN_POOLED) && !REGSTG) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (RES: awaited at the top of the next item)
     STAMP_IT(0);
     first_item = false;
 
@@ -708,6 +802,9 @@ __global__ __launch_bounds__(512, 2) void conv_mm_kernel(const MmJobs jt, const 
 // tap's products are 2 x NC/16 independent accumulator chains instead of NC/32: 13-23 % on the weight gradients that use it
 // (wgrad3x3_mm.hip).  A fragment: lane (row = lane & 15, k group kg = lane >> 4) reads the 16 bytes of channels 8 kg .. 8 kg + 7 of its
 // pixel: with 10 slots per pixel (8 + 2 pad) and 184 per row the four 16-lane groups of a ds_read_b128 hit 16 distinct slots.
+#ifndef UGN_MM16_PIPE
+#define UGN_MM16_PIPE 1
+#endif
 constexpr int PS16 = 10, HROW16 = 184;
 constexpr int HPIECES16 = 52;                       // 18 rows x 184 slots = 3312 -> 51.75 pieces (13 per fetching wave)
 constexpr int HALO16_BYTES = HPIECES16 * 1024;      // 53,248
@@ -857,6 +954,57 @@ __global__ __launch_bounds__(512, 2) void conv_mm16_kernel(const MmJobs jt, cons
           stage_in(jt.job[nx_job], n_lit, n_chunk, sbase + (unsigned)(hbuf ^ 1) * HALO16_BYTES, sg);
         }
         const int b_addr = b_lane + wbuf * WSTAGE;
+#if UGN_MM16_PIPE
+        // Software pipeline over micro-steps u = (tap, half of the column tiles): the fragments of u + 1 are READ (ds_read_b128,
+        // into the other register set) before the MFMAs of u are issued, and the two groups are pinned with sched_barrier.  Left to
+        // itself hipcc issues each read one or two instructions ahead of the MFMA that needs it (`s_waitcnt lgkmcnt(0|1)` before
+        // every second MFMA in the round-3 ISA): with 8 waves reading, an LDS read takes 100-300 cycles to return and the matrix
+        // pipe idled behind it (stage period 3,050 cycles for 1,536 of MFMA; profiles/r03_stage_stamps.txt).  A micro-step is
+        // 12-24 MFMAs = 190-380 cycles of matrix work per wave: one of them hides the reads of the next.
+        constexpr int HALVES = NT > 4 ? 2 : 1, NTH = NT / HALVES, NU = TPS * HALVES;
+        uint4 fa[2][2][2], fb[2][NTH][2];        // [register set][row tile | column tile][plane]
+        auto load_a = [&](int set, int t) {
+          const int tap = sg * TPS + t, dy = tap / 3, dx = tap % 3;
+          const int aoff = (dy * HROW16 + dx * PS16) * 16 + hbuf * HALO16_BYTES;
+#pragma unroll
+          for (int rt = 0; rt < 2; ++rt) {
+            fa[set][rt][0] = *reinterpret_cast<const uint4*>(smem + a_lane[rt] + aoff);
+            fa[set][rt][1] = *reinterpret_cast<const uint4*>(smem + a_lane[rt] + aoff + 64);
+          }
+        };
+        auto load_b = [&](int set, int t, int hf) {
+#pragma unroll
+          for (int c = 0; c < NTH; ++c) {
+            fb[set][c][0] = *reinterpret_cast<const uint4*>(smem + b_addr + ((t * NT + hf * NTH + c) * 2 + 0) * 1024);
+            fb[set][c][1] = *reinterpret_cast<const uint4*>(smem + b_addr + ((t * NT + hf * NTH + c) * 2 + 1) * 1024);
+          }
+        };
+        load_a(0, 0);
+        load_b(0, 0, 0);
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+          const int t = u / HALVES, hf = u % HALVES;
+          if (u + 1 < NU) {
+            const int tn = (u + 1) / HALVES, hn = (u + 1) % HALVES;
+            if (hn == 0) load_a(tn & 1, tn);
+            load_b((u + 1) & 1, tn, hn);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int c = 0; c < NTH; ++c)
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) acc[rt][hf * NTH + c] = mfma16_h(fa[t & 1][rt][0], fb[u & 1][c][0], acc[rt][hf * NTH + c]);
+#pragma unroll
+          for (int c = 0; c < NTH; ++c)
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) acc[rt][hf * NTH + c] = mfma16_h(fa[t & 1][rt][0], fb[u & 1][c][1], acc[rt][hf * NTH + c]);
+#pragma unroll
+          for (int c = 0; c < NTH; ++c)
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) acc[rt][hf * NTH + c] = mfma16_h(fa[t & 1][rt][1], fb[u & 1][c][0], acc[rt][hf * NTH + c]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+#else
 #pragma unroll
         for (int t = 0; t < TPS; ++t) {
           const int tap = sg * TPS + t, dy = tap / 3, dx = tap % 3;
@@ -888,6 +1036,7 @@ __global__ __launch_bounds__(512, 2) void conv_mm16_kernel(const MmJobs jt, cons
 #pragma unroll
             for (int rt = 0; rt < 2; ++rt) acc[rt][ct] = mfma16_h(al[rt], bh[ct], acc[rt][ct]);
         }
+#endif
         wbuf ^= 1;
       }
       hbuf ^= 1;

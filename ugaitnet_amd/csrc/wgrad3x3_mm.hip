@@ -97,6 +97,20 @@ __global__ __launch_bounds__(512, 2) void wgrad_mm_kernel(const WgJobs jt, const
   const int s0 = (int)((long long)grp * total / jt.ngroups), s1 = (int)((long long)(grp + 1) * total / jt.ngroups);
   if (s0 >= s1) return;
   const int pair = wave % PW, ks = wave / PW;
+  // M16 (64 output channels per workgroup): v_mfma_f32_16x16x32_f16 -- K = 32 pixels (the wave's two rows) per step, the 32 x 32
+  // block of a tap as four 16 x 16 tiles (see the strip loop).  Its tiles are SWIZZLED in LDS: on odd tile rows the two 32-byte
+  // halves of a pixel's 64-byte plane record are swapped (SWZ), see `in_m` below.
+#ifndef UGN_WG_POOLED16
+#define UGN_WG_POOLED16 1
+#endif
+#ifndef UGN_WG_SWZ
+#define UGN_WG_SWZ 1
+#endif
+#ifndef UGN_WG_PER_TAP
+#define UGN_WG_PER_TAP 1
+#endif
+  constexpr bool M16 = PW == 2 && (!POOLED || UGN_WG_POOLED16);
+  constexpr bool SWZ = M16 && UGN_WG_SWZ;
   // transposed-read role of the lane: 16-lane group (channel half gh, k half h), row q of the 4-pixel block, columns 4p..
   const int h = lane >> 5, gh = (lane >> 4) & 1, q = (lane >> 2) & 3, p = lane & 3;
   const int lane_off = (8 * h + q) * 64 + (16 * gh + 4 * p) * 2;
@@ -125,7 +139,8 @@ __global__ __launch_bounds__(512, 2) void wgrad_mm_kernel(const WgJobs jt, const
       const int plane = sg >= 720 ? 1 : 0, rem = sg - 720 * plane;
       const int pix = rem >> 2, c4 = rem & 3;
       const int row = (pix * 3641) >> 16, px = pix - row * 18;         // pix / 18 for pix < 400
-      const int off = ((row - 1) * HW + (px - 1)) * (CI * 4) + plane * CI * 2 + c4 * 16;
+      const int c4s = SWZ ? c4 ^ ((row & 1) << 1) : c4;              // (the quarter this LDS slot holds)
+      const int off = ((row - 1) * HW + (px - 1)) * (CI * 4) + plane * CI * 2 + c4s * 16;
       if (sg < 1440) pk[j] = (int)(((unsigned)off << 12) | (unsigned)(row << 5) | (unsigned)px);
     } else if (pi < NPIECE) {
       const int pd = pi - IN_PIECES;
@@ -134,7 +149,8 @@ __global__ __launch_bounds__(512, 2) void wgrad_mm_kernel(const WgJobs jt, const
         const int plane = sg / (PW * 512), rem = sg - plane * (PW * 512);
         const int nb = rem >> 9, rem2 = rem & 511;
         const int pix = rem2 >> 2, c4 = rem2 & 3;
-        pk[j] = ((pix >> 4) * HW + (pix & 15)) * (CO * 4) + plane * CO * 2 + (coc * COW + nb * 32) * 2 + c4 * 16;
+        const int c4s = SWZ ? c4 ^ (((pix >> 4) & 1) << 1) : c4;
+        pk[j] = ((pix >> 4) * HW + (pix & 15)) * (CO * 4) + plane * CO * 2 + (coc * COW + nb * 32) * 2 + c4s * 16;
       } else {                     // slots: [plane][block][pooled pixel 0..31][quarter], then [pooled pixel][COW / 16] of argmax bytes
         constexpr int HP = HW / 2;
         if (sg < PW * 256) {
@@ -219,9 +235,9 @@ __global__ __launch_bounds__(512, 2) void wgrad_mm_kernel(const WgJobs jt, const
     bh = __builtin_bit_cast(h8, make_uint4(fh[0], fh[1], fh[2], fh[3]));
     bl = __builtin_bit_cast(h8, make_uint4(fl[0], fl[1], fl[2], fl[3]));
   };
-  // the same for the 16x16x32 form: lane (channel 16 cot + (lane & 15), k group kg) = pixels 8 (kg & 1) .. + 7 of strip row y
-  auto pooled_frag16 = [&](int b, int y, int cot, h8& bh, h8& bl) {
-    const int xh = (lane >> 4) & 1;
+  // the same for the 16x16x32 form: lane (channel 16 cot + (lane & 15), k group) = pixels 8 xh .. + 7 of strip row y.  (SWZ: the two
+  // k groups of a pass are rows 2k, 2k + 1 of the same columns -- the same pooled pixels, identical addresses, a broadcast.)
+  auto pooled_frag16 = [&](int b, int y, int xh, int cot, h8& bh, h8& bl) {
     const LDS_PTR(char) pv = lds + b * SET + IN_BYTES + pair * 2048 + (y >> 1) * 512 + (4 * xh + q) * 64 + (16 * cot + 4 * p) * 2;
     const s4 ph = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s4))pv);
     const s4 pl = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s4))(pv + PW * 2048));
@@ -246,10 +262,6 @@ __global__ __launch_bounds__(512, 2) void wgrad_mm_kernel(const WgJobs jt, const
   // M16 (64 output channels per workgroup, un-pooled gradient): v_mfma_f32_16x16x32_f16 -- K = 32 pixels (the wave's two rows) per
   // step, the 32 x 32 block of a tap as four 16 x 16 tiles.  Same operand reads, same FLOPs and accumulator registers as two
   // 32x32x16 steps, but the chip holds a higher clock on this shape: 6-12 % on these launches (profiles/r03_stage_stamps.txt).
-#ifndef UGN_WG_POOLED16
-#define UGN_WG_POOLED16 1
-#endif
-  constexpr bool M16 = PW == 2 && (!POOLED || UGN_WG_POOLED16);
   typedef float f32x4 __attribute__((ext_vector_type(4)));
   f32x16 acc[M16 ? 1 : 9];
   f32x4 a4[M16 ? 9 : 1][4];          // [tap][ci tile * 2 + co tile]
@@ -292,28 +304,51 @@ __global__ __launch_bounds__(512, 2) void wgrad_mm_kernel(const WgJobs jt, const
     const LDS_PTR(char) in_b = lds + b * SET + ks * RPW * (18 * 64) + lane_off;
     const LDS_PTR(char) dz_b = lds + b * SET + IN_BYTES + pair * 8192 + ks * RPW * (16 * 64) + lane_off;
     if constexpr (M16) {
-      // lane (i = lane & 15, k group kg = lane >> 4): 8 consecutive pixels 8 kg .. 8 kg + 7 of the wave's 32 (row kg >> 1, columns
-      // 8 (kg & 1) ..); in the transposed read the lane supplies the address of pixel row q, channels 4p .. 4p + 3 of its group's block
+      // lane (i = lane & 15, k group kg = lane >> 4): 8 consecutive pixels of the wave's 32.  SWZ (default): row kr = kg & 1, columns
+      // 8 (kg >> 1) .. + 7 -- a ds_read_b64_tr_b16 is serviced as lanes 0-31, then 32-63 (MI355X_MICROARCH.md, LDS), i.e. k groups
+      // {0, 1} together.  A 16-lane group reads 32 of the 64 bytes of four consecutive pixels (banks 16 q + 8 half + 2 p), so two groups
+      // of a pass must sit in DIFFERENT halves: with the two k groups on rows r, r + 1 and the halves swapped on odd tile rows (the
+      // DMA fetches quarter c4 ^ 2 (row & 1) into slot c4) they do, for every tap, at lane base + immediate: the half a lane reads
+      // is cit ^ ((kr + dy) & 1), i.e. one of two lane bases.  (Round 3 had k groups {0, 1} = columns 0-7 | 8-15 of one row: 512 B
+      // apart, the same banks -- SQ_LDS_BANK_CONFLICT 0.49 per active LDS cycle on all four M16 launches, profiles/r03_lds_conflicts.csv.)
       const int kg = lane >> 4;
-      const LDS_PTR(char) in_m = lds + b * SET + ks * RPW * (18 * 64) + ((kg >> 1) * 18 + 8 * (kg & 1) + q) * 64 + 4 * p * 2;
-      const LDS_PTR(char) dz_m = lds + b * SET + IN_BYTES + pair * 8192 + ks * RPW * (16 * 64) + ((kg >> 1) * 16 + 8 * (kg & 1) + q) * 64 + 4 * p * 2;
+      const int kr = SWZ ? (kg & 1) : (kg >> 1), kx = SWZ ? (kg >> 1) : (kg & 1);
+      const LDS_PTR(char) in_m0 = lds + b * SET + ks * RPW * (18 * 64) + (kr * 18 + 8 * kx + q) * 64 + 4 * p * 2;
+      const LDS_PTR(char) dz_m0 = lds + b * SET + IN_BYTES + pair * 8192 + ks * RPW * (16 * 64) + (kr * 16 + 8 * kx + q) * 64 + 4 * p * 2;
+      // half c of the pixel record as this lane finds it on an even / odd tap row: [c ^ kr] (SWZ) or [c]
+      const LDS_PTR(char) in_m[2] = {in_m0 + (SWZ ? 32 * kr : 0), in_m0 + (SWZ ? 32 * (kr ^ 1) : 32)};
+      const LDS_PTR(char) dz_m[2] = {dz_m0 + (SWZ ? 32 * kr : 0), dz_m0 + (SWZ ? 32 * (kr ^ 1) : 32)};
       h8 bh[2], bl[2];
 #pragma unroll
       for (int cot = 0; cot < 2; ++cot) {
         if constexpr (POOLED) {
-          pooled_frag16(b, ks * RPW + (kg >> 1), cot, bh[cot], bl[cot]);
+          pooled_frag16(b, ks * RPW + kr, kx, cot, bh[cot], bl[cot]);
         } else {
-          bh[cot] = tr_pair(dz_m, cot * 32, cot * 32 + 4 * 64);
-          bl[cot] = tr_pair(dz_m, PW * 8192 + cot * 32, PW * 8192 + cot * 32 + 4 * 64);
+          bh[cot] = tr_pair(dz_m[cot], 0, 4 * 64);
+          bl[cot] = tr_pair(dz_m[cot], PW * 8192, PW * 8192 + 4 * 64);
         }
       }
-#pragma unroll
-      for (int t = 0; t < 9; ++t) {
+      // software pipeline over the taps: the 8 transposed reads of tap t + 1 (both input-channel tiles, both planes) go out before
+      // the 12 MFMAs of tap t, pinned with sched_barrier -- hipcc on its own reads a fragment one or two instructions ahead of the
+      // MFMA that needs it and the matrix pipe waits for LDS (see conv_mm16_kernel)
+      h8 fah[2][2], fal[2][2];           // [register set][input-channel tile]
+      auto load_a = [&](int set, int t) {
         const int o = ((t / 3) * 18 + (t % 3)) * 64;
 #pragma unroll
         for (int cit = 0; cit < 2; ++cit) {
-          const h8 ah = tr_pair(in_m, o + cit * 32, o + cit * 32 + 4 * 64);
-          const h8 al = tr_pair(in_m, IN_PLANE + o + cit * 32, IN_PLANE + o + cit * 32 + 4 * 64);
+          const LDS_PTR(char) im = in_m[SWZ ? cit ^ ((t / 3) & 1) : cit];
+          fah[set][cit] = tr_pair(im, o, o + 4 * 64);
+          fal[set][cit] = tr_pair(im, IN_PLANE + o, IN_PLANE + o + 4 * 64);
+        }
+      };
+      load_a(0, 0);
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        if (t + 1 < 9) load_a((t + 1) & 1, t + 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int cit = 0; cit < 2; ++cit) {
+          const h8 ah = fah[t & 1][cit], al = fal[t & 1][cit];
 #pragma unroll
           for (int cot = 0; cot < 2; ++cot) {
             f32x4 c = a4[t][cit * 2 + cot];
@@ -323,9 +358,14 @@ __global__ __launch_bounds__(512, 2) void wgrad_mm_kernel(const WgJobs jt, const
             a4[t][cit * 2 + cot] = c;
           }
         }
-        if (t < NJ && have_in) {
+        __builtin_amdgcn_sched_barrier(0);
+        // the next strip's pieces go out in the FIRST taps (UGN_WG_PER_TAP per tap): the later the last one is issued, the more of
+        // its latency the top-of-strip wait sees
+        if (t * UGN_WG_PER_TAP < NJ && have_in) {
           __builtin_amdgcn_sched_barrier(0);
-          issue(t, Sin, b ^ 1);
+#pragma unroll
+          for (int u = 0; u < UGN_WG_PER_TAP; ++u)
+            if (t * UGN_WG_PER_TAP + u < NJ) issue(t * UGN_WG_PER_TAP + u, Sin, b ^ 1);
           __builtin_amdgcn_sched_barrier(0);
         }
       }
@@ -340,15 +380,21 @@ __global__ __launch_bounds__(512, 2) void wgrad_mm_kernel(const WgJobs jt, const
         bh = tr_pair(dz_b, (rr * 16) * 64, (rr * 16 + 4) * 64);
         bl = tr_pair(dz_b, PW * 8192 + (rr * 16) * 64, PW * 8192 + (rr * 16 + 4) * 64);
       }
+      h8 fah[2], fal[2];                 // the input fragments of a tap, read one tap ahead (as in the M16 loop above)
+      auto load_a = [&](int set, int t) {
+        const int o = ((rr + t / 3) * 18 + (t % 3)) * 64;
+        fah[set] = tr_pair(in_b, o, o + 4 * 64);
+        fal[set] = tr_pair(in_b, IN_PLANE + o, IN_PLANE + o + 4 * 64);
+      };
+      load_a(0, 0);
 #pragma unroll
       for (int t = 0; t < 9; ++t) {
-        const int dy = t / 3, dx = t % 3;
-        const int o = ((rr + dy) * 18 + dx) * 64;
-        const h8 ah = tr_pair(in_b, o, o + 4 * 64);
-        const h8 al = tr_pair(in_b, IN_PLANE + o, IN_PLANE + o + 4 * 64);
-        acc[t] = mfma_h8(ah, bh, acc[t]);
-        acc[t] = mfma_h8(ah, bl, acc[t]);
-        acc[t] = mfma_h8(al, bh, acc[t]);
+        if (t + 1 < 9) load_a((t + 1) & 1, t + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        acc[t] = mfma_h8(fah[t & 1], bh, acc[t]);
+        acc[t] = mfma_h8(fah[t & 1], bl, acc[t]);
+        acc[t] = mfma_h8(fal[t & 1], bh, acc[t]);
+        __builtin_amdgcn_sched_barrier(0);
         // one LDS-DMA piece after every tap (every second tap where there are two k-steps) until the wave's pieces are out
         constexpr int EVERY = RPW == 1 ? 1 : 2;
         const int slot = rr * 9 + t;

@@ -168,6 +168,7 @@ class ParamStore:
             off += int(np.prod(s))
             off = (off + 3) // 4 * 4  # keep every view 16-byte aligned
         self.numel = off
+        self.before_write = None
         self.flat = torch.zeros(off, dtype=F32, device=device)
         self.grad = torch.zeros(off, dtype=F32, device=device)
         self.m = torch.zeros(off, dtype=F32, device=device)
@@ -180,6 +181,8 @@ class ParamStore:
         return buf[self.offsets[n]:self.offsets[n] + k].view(self.shapes[n])
 
     def set(self, name, array):
+        if self.before_write is not None:      # (GaitCore: a filter repack on the second stream may still be READING the flat buffer)
+            self.before_write()
         self.p[name].copy_(torch.as_tensor(np.ascontiguousarray(array), dtype=F32))
 
     def get(self, name):
@@ -580,6 +583,12 @@ class GaitCore:
         self.conv_precision = conv_precision
         self.h2 = conv_precision == "h2"
         self.bf = conv_precision == "bf16"
+        if (self.h2 or self.bf) and self.nmod > 3:
+            # one launch per layer carries the frame-level layer and the set-level twin of EVERY modality as jobs, and the kernels'
+            # job tables hold 6 (csrc/mm_common.h kMaxJobs; h2_elem.hip / bf_elem.hip kJobs); the reference's graphs stop at 3
+            # modalities (nets/mj_uwyhNets_ba.py:1031-1299)
+            raise ValueError("conv_precision=%r takes at most 3 modalities (6 jobs per launch), got %d; use conv_precision='f32' with "
+                             "UGN_MERGE=0" % (conv_precision, self.nmod))
         self.encoders = [Encoder(self.store, "m%d." % mi, cin, bf16=conv_precision == "bf16w")
                          for mi, cin in enumerate(self.in_channels)]
         if self.bf:
@@ -594,7 +603,12 @@ class GaitCore:
             self.meta_pool = h2.MetaPool(self.device, 64 * self.nmod)
             for enc in self.encoders:
                 enc.h2 = H2State(enc, self.meta_pool)
-        self._pack_pending = False      # a filter repack is running on the second stream (apply_gradients)
+        # the event behind the filter repack that apply_gradients queued on the second stream (None: none outstanding).  Whatever
+        # reads the packed filters (the first 3x3 layer), rewrites them (another repack) or writes the parameters they are packed
+        # from waits for THIS EVENT on its own current stream -- not for a flag plus a stream looked up by the current stream, which
+        # missed a pack queued from another stream and let two packs interleave on the same buffers.
+        self._pack_event = None
+        self.store.before_write = self.join_pack
         for enc in self.encoders:
             enc.before_conv3 = self._before_conv3
         self.scratch = {}
@@ -616,13 +630,19 @@ class GaitCore:
             self.store.set(name, np.zeros(shape, np.float32) if name.endswith(".bc") else glorot_uniform(gen, shape))
         self.weights_changed()
 
+    def join_pack(self):
+        """The current stream waits for the filter repack queued by the last apply_gradients, if one is outstanding."""
+        ev = self._pack_event
+        if ev is not None:
+            torch.cuda.current_stream(self.device).wait_event(ev)
+            self._pack_event = None
+
     def _before_conv3(self):
         """Called by forward_h2 / forward_bf between the 5x5 layer and the first 3x3 layer."""
-        if self._pack_pending:
-            torch.cuda.current_stream(self.device).wait_stream(_wgrad_stream(self.device))
-            self._pack_pending = False
+        self.join_pack()
 
     def weights_changed(self):
+        self.join_pack()     # (a repack still running on the second stream: never two packs at once on the pk / wmeta buffers)
         if self.h2:          # f16 halves + block exponent + L1 bound of every 3x3 filter, both directions: two launches
             h2.mm_pack_multi([j for e in self.encoders for j in e.h2.pack_jobs()])
             return
@@ -937,7 +957,9 @@ class GaitCore:
             # step's input copies and 5x5 layer; the first 3x3 layer waits for it (`_before_conv3`)
             with _side(self.device):
                 self.weights_changed()
-            self._pack_pending = True
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream(self.device))
+            self._pack_event = ev
         else:
             self.weights_changed()
 

@@ -138,6 +138,18 @@ def mm_pack(w, dgrad, pk=None, wmeta=None):
     return pk, wmeta
 
 
+def _mm_bytes(kind, hw, cin, cout, pooled, n, act=False):
+    """Algorithmic HBM bytes of a 3x3 H2 launch: every tensor it must read or write once (H2 = 4 bytes per element, argmax maps 1,
+    LeakyReLU' reads the H plane of the layer's input = 2; the packed filters, re-read from L2 by every workgroup, are not counted)."""
+    hp = hw // 2
+    if kind == "fwd":       # in [n,hw,hw,cin] -> out [n,ho,ho,cout] (+ argmax bytes)
+        return n * (hw * hw * cin * 4.0 + (hp * hp * cout * 5.0 if pooled else hw * hw * cout * 4.0))
+    dz = hp * hp * cout * 5.0 if pooled else hw * hw * cout * 4.0      # the gradient operand (pooled: + argmax bytes)
+    if kind == "dgrad":     # dz -> dL/d(in) [n,hw,hw,cin] (* LeakyReLU'(act))
+        return n * (dz + hw * hw * cin * 4.0 + (hw * hw * cin * 2.0 if act else 0.0))
+    return n * (dz + hw * hw * cin * 4.0)      # wgrad: the layer's input + dz (the fp32 result is a few hundred KB)
+
+
 def _mm_work(kind, hw, cin, cout, pooled, ns, act=False):
     n = int(sum(ns))
     flops = 2.0 * 9 * cin * cout * hw * hw * n
@@ -148,8 +160,10 @@ def _mm_work(kind, hw, cin, cout, pooled, ns, act=False):
         kern = ("conv_mm_kernel<%d, %d, %d, %d, %d>" % (cout, cin, hw, int(pooled), 3 if act else 2) if pooled else
                 "conv_mm16_kernel<%d, %d, %d, %d>" % (cout, cin, hw, 3 if act else 2))
     label = "conv3x3_%s[%d->%d @%dx%d%s h2] %s" % (kind, cin, cout, hw, hw, " pooled" if pooled else "", kern)
-    # three f16 MFMAs per fp32-equivalent product: the matrix pipe executes 3x the algorithmic FLOPs
-    return label, dict(flops=flops, mfma_flops=3.0 * flops, bytes=None, kernel=kern, bound="mfma", images=n, dtype="f16x2")
+    # three f16 MFMAs per fp32-equivalent product: the matrix pipe executes 3x the algorithmic FLOPs.  bound="roof": bench.py prices
+    # the launch against BOTH roofs (executed matrix FLOPs, algorithmic bytes) and names the one whose floor is higher
+    return label, dict(flops=flops, mfma_flops=3.0 * flops, bytes=_mm_bytes(kind, hw, cin, cout, pooled, n, act), kernel=kern,
+                       bound="roof", images=n, dtype="f16x2")
 
 
 def conv3x3_fwd_mm_multi(xs, wpks, wmetas, cout, pool, outs, idxs=None):
@@ -208,8 +222,8 @@ def conv3x3_wgrad_mm_multi(xs, dzs, cout, dws, dz_idxs=None):
     call("ugn_mm_conv3x3_wgrad_multi", ptr_array([x.data for x in xs]), ptr_array([x.meta for x in xs]),
          ptr_array([d.data for d in dzs]), ptr_array(dz_idxs) if pooled else None, ptr_array([d.meta for d in dzs]),
          ptr_array(dws), ns, len(xs), hw, cin, cout, ptr(ws), ws.numel(), _stream(), label=label,
-         work=dict(flops=flops, mfma_flops=3.0 * flops, bytes=None, kernel=kern, bound="mfma", images=int(sum(x.shape[0] for x in xs)),
-                   dtype="f16x2"))
+         work=dict(flops=flops, mfma_flops=3.0 * flops, bytes=_mm_bytes("wgrad", hw, cin, cout, pooled, sum(x.shape[0] for x in xs)),
+                   kernel=kern, bound="roof", images=int(sum(x.shape[0] for x in xs)), dtype="f16x2"))
     return dws
 
 

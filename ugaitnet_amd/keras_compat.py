@@ -185,6 +185,7 @@ class GaitSetModel:
                              skip_masked=os.environ.get("UGN_SKIP_MASKED", "1") != "0",
                              conv_precision=None)      # engine.DEFAULT_PRECISION (UGN_CONV_PRECISION; "h2")
         if world > 1:  # replicas start from identical weights (MirroredStrategy semantics)
+            self.core.join_pack()
             torch.distributed.broadcast(self.core.store.flat, src=0)
             self.core.weights_changed()
         self.input_names = []
