@@ -11,7 +11,8 @@
  *   - `stream` is a hipStream_t passed as void* (NULL = default stream); calls only enqueue work;
  *   - return 0 on success, a positive hipError_t on a HIP failure, UGN_EINVAL on a shape the kernels do
  *     not implement.  ugn_last_error() returns a static description of the last failure of the thread;
- *   - thread-compatible: no global mutable state besides that message.
+ *   - thread-compatible: no global mutable state besides that message and ONE process-wide launch setting,
+ *     ugn_set_persistent_wgs (how many CUs the persistent launches occupy; results do not depend on it).
  */
 #ifndef UGAITNET_HIP_H
 #define UGAITNET_HIP_H
@@ -300,9 +301,13 @@ int ugn_mm_conv3x3_dgrad_multi(const uint16_t* const* dz, const uint8_t* const* 
                                uint16_t* const* out, void* const* out_meta, const int* n, int njobs, int hw, int cin, int cout,
                                void* stream);
 
-/* Persistent workgroups of the ugn_mm_conv3x3_{fwd,dgrad}_multi launches: 8..256, 0 = default (256 = one per CU).  A process-wide
- * setting (the one piece of mutable state besides the error message): under data parallelism a value below 256 leaves CUs to RCCL's
- * channels while the backward pass runs.  Results do not depend on it. */
+/* Persistent workgroups per launch: 8..256, 0 = default (256 = one per CU).  A process-wide setting (the one piece of mutable state
+ * besides the error message): under data parallelism a value below 256 leaves 256 - n CUs to RCCL's channels while the backward pass
+ * runs (mains/mj_trainUWYHGaitNet_DataGen_CasiaB.py:342-349: the gradient all-reduce of MirroredStrategy).  It sizes EVERY persistent
+ * launch that owns its CUs' whole LDS: the f16x2 and bf16 3x3 forward / data-gradient kernels (items stride over n, or 2n,
+ * workgroups), their weight gradients (the grid holds the largest multiple of 8 groups per block combination that fits n; a
+ * workgroup then walks several of the launch's FIXED shares in turn) and the 5x5 forward (4n workgroups).  Every result is
+ * bit-identical for every n.  Call it between launches, not concurrently with them. */
 int ugn_set_persistent_wgs(int n);
 /* Data gradient of the pooled 32 -> 32 layer (a2: Conv2DBackpropInput + MaxPoolGrad, nets/mj_uwyhNets_ba.py:431-434) fused with the
  * weight gradient of the 5x5 first layer (Conv2DBackpropFilter of :428-430, LeakyReluGrad from the a1 sign words): dL/da1 is never

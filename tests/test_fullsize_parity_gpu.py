@@ -63,15 +63,25 @@ def _oracle(c):
     tp = T.params_from_numpy(p64, dtype=torch.float64)
     x64 = [torch.from_numpy(x.astype(np.float64)) for x in xs]
     u64 = [torch.from_numpy(u.astype(np.float64)) for u in uses] if multimodal else None
-    res, g = T.loss_and_grads(x64, u64, torch.from_numpy(labels), torch.from_numpy(onehot.astype(np.float64)), tp, margin=0.2,
-                              loss_weights=(1.0, 0.1), multimodal=multimodal)
-    # the oracle's routing decisions, with the gaps of every near-tie (tests/routing.py): the same graph, tapped
+    # the oracle's own evaluation (oracle/torch_ref.py loss_and_grads), with its `branch` replaced by the statement-for-statement
+    # tapped copy of tests/routing.py: ONE forward pass yields the losses, the gradients AND the routing / LeakyReLU decisions with
+    # the gaps of every near-tie (bf16 case: no census)
     decs, sel = [], None
-    if c.get("precision") != "bf16":
-        for x, bp in zip(x64, tp["branches"]):
-            out, dec = R.oracle_branch_census(x, {k: v.detach() for k, v in bp.items()})
-            decs.append(dec)
-        sel = R.sign_max_census([o.detach() for o in res["outs"]], u64) if multimodal else None
+    census = c.get("precision") != "bf16"
+
+    def tapped(x, p):
+        dec = {} if census else None
+        decs.append(dec)
+        return R.branch_tapped(x, p, dec)
+    orig = T.branch
+    T.branch = tapped
+    try:
+        res, g = T.loss_and_grads(x64, u64, torch.from_numpy(labels), torch.from_numpy(onehot.astype(np.float64)), tp, margin=0.2,
+                                  loss_weights=(1.0, 0.1), multimodal=multimodal)
+    finally:
+        T.branch = orig
+    if census and multimodal:
+        sel = R.sign_max_census([o.detach() for o in res["outs"]], u64)
     entry = dict(xs=xs, uses=uses, labels=labels, onehot=onehot, p64=p64, x64=x64, u64=u64,
                  loss=float(res["loss"]), triplet=float(res["triplet"]), xent=float(res["xent"]),
                  signature=res["signature"].detach().numpy(), tri_counts=res["tri_counts"].numpy().astype(np.int64),
@@ -82,9 +92,9 @@ def _oracle(c):
 
 
 # the decisions of a step may differ from the fp64 oracle's only at near-ties: the oracle's value at the HIP path's choice within
-# NEAR_TIE fp32 ulps of the tensor's scale below the oracle's maximum (VERDICT r03 item 3 asks for 8; the convolutions feeding the
-# deepest decisions carry up to 5e-6 of their scale = 40 ulp of rounding themselves -- tests/test_mm_gpu.py -- so the bar is per family)
-NEAR_TIE = dict(i2=8, m1=8, j2=16, i4=16, m2=16, m3=32, hpp_a=32, hpp_b=32, sel=32)
+# NEAR_TIE fp32 ulps of the tensor's scale below the oracle's maximum -- for a LeakyReLU: the oracle's value within that of zero
+# (8 ulp; measured at full size: 0-6 flips per family of 10^5 ... 10^7 decisions, the worst 1.5 ulp)
+NEAR_TIE = 8
 
 
 # cases of one workload are adjacent: the oracle is evaluated once per workload
@@ -150,7 +160,7 @@ def test_whole_step_matches_the_fp64_oracle(dev, name):
             res = R.census(E["decs"][mi], routes[mi], b, 25, active)
             lines.append("m%d: %s" % (mi, R.format_census(res)))
             for fam, (n, f, w) in res.items():
-                assert w <= NEAR_TIE[fam] * R.FP32_ULP, "branch %d, %s: a decision differs from the oracle's %.3g fp32 ulp of the tensor " \
+                assert w <= NEAR_TIE * R.FP32_ULP, "branch %d, %s: a decision differs from the oracle's %.3g fp32 ulp of the tensor " \
                     "scale away from a tie (%d flips of %d)" % (mi, fam, w / R.FP32_ULP, f, n)
                 flips += f
         sel = None
@@ -158,7 +168,7 @@ def test_whole_step_matches_the_fp64_oracle(dev, name):
             sel = core.sel.cpu().numpy()
             n, f, w = E["sel"].compare(sel)
             lines.append("sign_max: %d/%d flips (worst gap %.2g ulp32 of scale)" % (f, n, w / R.FP32_ULP))
-            assert w <= NEAR_TIE["sel"] * R.FP32_ULP, lines[-1]
+            assert w <= NEAR_TIE * R.FP32_ULP, lines[-1]
             flips += f
         print("%s routing census vs the fp64 oracle -- %s" % (name, " | ".join(lines)))
         # gradient bars as a function of the census: without a single flip the gradients are the oracle's to fp32 rounding; with

@@ -25,7 +25,8 @@ def test_census_of_an_fp32_run_and_of_the_oracle_itself():
         p64 = {k: torch.from_numpy(v) for k, v in p.items()}
         out, dec = R.oracle_branch_census(x64, p64)
         assert tuple(out.shape) == (62, b, 256)
-        assert torch.allclose(out, T.branch(x64, p64), rtol=0, atol=1e-12)       # the tapped graph IS the oracle's graph
+        assert torch.equal(out, T.branch(x64, p64))       # the tapped graph IS the oracle's graph, statement for statement
+        assert set(R.SIGN_KEYS) <= {k[3:] for k in dec if k.startswith("sg_")}
         own = R.census(dec, R.route_from_torch(x64, p64), b, l)
         assert all(f == 0 for _, f, _ in own.values()), own
         r32 = R.route_from_torch(x64.float(), {k: v.float() for k, v in p64.items()})

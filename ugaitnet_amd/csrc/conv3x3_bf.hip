@@ -382,7 +382,7 @@ int launch_bf(const MmJob* jobs, const int* n, int njobs, hipStream_t st) {
   const int nitems = make_mm_table(jt, jobs, n, njobs, (HW / 16) * (HW / 16));
   // (two persistent workgroups per CU where the LDS allows it -- the 32 -> 32 forward, 72 KB: the second one's MFMAs cover
   //  the first one's tile wait and epilogue)
-  constexpr int WGS = G::LDS <= 81920 ? 2 * kGrid : kGrid;
+  const int WGS = (G::LDS <= 81920 ? 2 : 1) * persistent_wgs();
   const int grid = nitems < WGS ? nitems : WGS;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), G::LDS, st, jt, zeros);
   UGN_CHECK_LAUNCH("conv_bf");

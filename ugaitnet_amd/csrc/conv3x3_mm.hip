@@ -58,11 +58,13 @@ struct Geo {
 // 32 -> 32 layers (one K chunk, one block): the whole filter of a job -- 3 stages, 36 KB -- stays in LDS
 template <int KC, int NC>
 constexpr bool filter_resident() { return KC == 32 && NC == 32; }
-// REGSTG (32 -> 32 pooled data gradient): the pooled gradient + argmax bytes of the next tile travel through REGISTERS (plain global
-// loads one item ahead), not through a DMA'd staging tile; waves 0-3 scatter them into the next halo buffer behind tap 3, waves 4-7
-// behind tap 6 -- while the other wave of their SIMD multiplies -- and the item keeps ONE barrier.
+// REGSTG (experiment, -DUGN_MM_REGSTG=1; 32 -> 32 pooled data gradient): the pooled gradient + argmax bytes of the next tile travel
+// through REGISTERS (plain global loads one item ahead), not through a DMA'd staging tile; waves 0-3 scatter them into the next halo
+// buffer behind tap 3, waves 4-7 behind tap 6 -- while the other wave of their SIMD multiplies -- and the item keeps ONE barrier.
+// Bit-identical results, one barrier and 16 DMA pieces fewer per item -- and not faster: the item period in MICROSECONDS did not move
+// (4.81 -> 4.91 us; in cycles 9,790 -> 10,770 at a clock that rose from 2.04 to 2.19 GHz), see DESIGN.md "what bounds the 3x3 kernels".
 #ifndef UGN_MM_REGSTG
-#define UGN_MM_REGSTG 1
+#define UGN_MM_REGSTG 0       /* measured: 1-3 % slower than the DMA'd staging tile + scatter pass (profiles/r04_kernel_experiments.txt) */
 #endif
 #ifndef UGN_MM_REGSTG_TAP0
 #define UGN_MM_REGSTG_TAP0 3
@@ -522,32 +524,22 @@ __global__ __launch_bounds__(512, 2) void conv_mm_kernel(const MmJobs jt, const 
       }
       STAMP_ST(3);
       const int a_addr = a_lane + hbuf * HALO_BYTES;
-      // software pipeline over the taps: the 8 fragment reads of tap + 1 go out before the 6 MFMAs of tap (pinned with sched_barrier;
-      // see conv_mm16_kernel: left alone hipcc reads one fragment ahead and every second MFMA waits for LDS)
-      uint4 fr[2][2][4];          // [register set][k-step s][AH, AL, BH, BL]
-      auto load_tap = [&](int set, int tap) {
+      // (reads and MFMAs in hipcc's own order here: pinning the 8 fragment reads of tap + 1 before the 6 MFMAs of tap, as the staged
+      //  loop below and conv_mm16_kernel do, measured 6 % SLOWER on this single-accumulator chain -- profiles/r04_kernel_experiments.txt)
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
         const int dy = tap / 3, dx = tap % 3;
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
           const int aoff = (dy * HROW + dx * 9) * 16 + s * 32;
-          fr[set][s][0] = *reinterpret_cast<const uint4*>(smem + a_addr + aoff);
-          fr[set][s][1] = *reinterpret_cast<const uint4*>(smem + a_addr + aoff + 64);
-          fr[set][s][2] = *reinterpret_cast<const uint4*>(smem + b_lane + ((tap * 2 + s) * 2 + 0) * 1024);
-          fr[set][s][3] = *reinterpret_cast<const uint4*>(smem + b_lane + ((tap * 2 + s) * 2 + 1) * 1024);
+          const uint4 ah = *reinterpret_cast<const uint4*>(smem + a_addr + aoff);
+          const uint4 al = *reinterpret_cast<const uint4*>(smem + a_addr + aoff + 64);
+          const uint4 bh = *reinterpret_cast<const uint4*>(smem + b_lane + ((tap * 2 + s) * 2 + 0) * 1024);
+          const uint4 bl = *reinterpret_cast<const uint4*>(smem + b_lane + ((tap * 2 + s) * 2 + 1) * 1024);
+          acc[0] = mfma_h(ah, bh, acc[0]);
+          acc[0] = mfma_h(ah, bl, acc[0]);
+          acc[0] = mfma_h(al, bh, acc[0]);
         }
-      };
-      load_tap(0, 0);
-#pragma unroll
-      for (int tap = 0; tap < 9; ++tap) {
-        if (tap + 1 < 9) load_tap((tap + 1) & 1, tap + 1);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-          acc[0] = mfma_h(fr[tap & 1][s][0], fr[tap & 1][s][2], acc[0]);
-          acc[0] = mfma_h(fr[tap & 1][s][0], fr[tap & 1][s][3], acc[0]);
-          acc[0] = mfma_h(fr[tap & 1][s][1], fr[tap & 1][s][2], acc[0]);
-        }
-        __builtin_amdgcn_sched_barrier(0);
         if constexpr (!IN_POOLED) {
           if (tap < 6 && more) {
             __builtin_amdgcn_sched_barrier(0);
@@ -1110,6 +1102,388 @@ __global__ __launch_bounds__(512, 2) void conv_mm16_kernel(const MmJobs jt, cons
 }
 
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// 32 -> 32 layers, TWO workgroups per CU ("D2"): dense swizzled halo tile + resident filter = 78 KB of LDS
+// ---------------------------------------------------------------------------------------------------------------------
+// The 32-channel layers (a2: 64 x 64 frames, a quarter of the step's 3x3 time) have ONE K chunk and ONE 32-column group: an item is
+// 108 MFMAs per wave between a tile wait, two barriers and an epilogue, and with one workgroup per CU nothing runs beside those.
+// Two workgroups per CU need <= 80 KB each.  (i) The halo tile is DENSE -- 18 x 18 pixels x the 128-byte record of HBM, no pad
+// slots: 41,472 B instead of 52,992 -- and conflict-free by a SWIZZLE instead of a pitch: record quarter jj of pixel (row, col) lives
+// in slot jj ^ g, g = ((col >> 1) & 3) << 1 | (row & 1) (the DMA fetches quarter slot ^ g into each slot: free).  The 16 lanes of a
+// ds_read_b128 group read slot (plane * 4 + k group) of 16 pixels = 4 windows x 4 positions; 8 of them have an even pixel index and 8
+// an odd one (which half of the 16 slots = 256 B a record sits in), and inside each half the 8 values of g -- 4 windows (distinct
+// mod 4) x 2 rows -- are distinct, for every tap.  A lane's address is lane base(dx, dy parity) + immediate.  (ii) ONE halo buffer:
+// the next tile is fetched behind a second barrier, while the epilogue stores are issued -- the other workgroup of the CU multiplies
+// meanwhile.  (iii) The whole filter of a job (36 KB, 16x16x32 tile order) stays in LDS.
+#ifndef UGN_MM_D2
+#define UGN_MM_D2 3       /* bit 0: the forward kernel, bit 1: the pooled data gradient */
+#endif
+constexpr int D2_SLOTS = 18 * 18 * 8;              // 2592 slots of 16 B
+constexpr int D2_PIECES = (D2_SLOTS + 63) / 64;    // 41 (the last one half used: the filter starts behind it)
+constexpr int D2_W_OFF = 42 * 1024;
+constexpr int D2_WBYTES = 9 * 2 * 2 * 1024;        // [tap][16-column tile][plane][lane-linear 1 KB]
+constexpr int D2_LDS = D2_W_OFF + D2_WBYTES;       // 79,872 B
+static_assert(D2_PIECES * 1024 <= D2_W_OFF && 2 * D2_LDS <= 163840, "two workgroups per CU");
+
+template <int HW, int EPI>
+__global__ __launch_bounds__(512, 4) void conv32_d2_kernel(const MmJobs jt, const void* __restrict__ zeros) {
+  constexpr int KC = 32, NC = 32, NT = 2;
+  constexpr int RPX = HW / 16, RPI = RPX * RPX;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const unsigned sbase = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // A-side role (as conv_mm16_kernel): row r16 of a 16-row tile = window (r16 >> 2) of the tile, position q; k group kg
+  const int r16 = lane & 15, kg = lane >> 4, q = r16 & 3, wq = r16 >> 2;
+  const int row0 = 2 * wave + (q >> 1), col0 = 2 * wq + (q & 1);          // halo pixel of row tile 0 under tap (0, 0); row tile 1: + 8 columns
+  int abase[3][2];                                                         // [dx][parity of dy]: H plane; L plane = ^ 64
+#pragma unroll
+  for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+    for (int dp = 0; dp < 2; ++dp) {
+      const int g = ((((col0 + dx) >> 1) & 3) << 1) | ((row0 + dp) & 1);
+      abase[dx][dp] = (row0 * 18 + col0) * 128 + ((g ^ kg) << 4);
+    }
+  const int b_lane = D2_W_OFF + lane * 16;
+  const int col = lane & 15, rg = lane >> 4;                               // C-side role
+
+  int item = blockIdx.x;
+  const int nitems = jt.start[kMaxJobs];
+  if (item >= nitems) return;
+  int jb = mm_job_of(jt, item), lit = item - jt.start[jb];
+
+  // LDS-DMA pieces of this wave (pi = wave + 8 j): what a lane fetches into slot pi * 64 + lane, precomputed (offset << 12 | row << 5 | col)
+  constexpr int NJ = (D2_PIECES + 7) / 8;      // 6
+  int hpk[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int sg = (wave + 8 * j) * 64 + lane;
+    const int row = sg / 144, rem = sg - row * 144, px = rem >> 3, js = rem & 7;
+    const int g = (((px >> 1) & 3) << 1) | (row & 1);
+    const int off = ((row - 1) * HW + (px - 1)) * (KC * 4) + ((js ^ g) << 4);          // |off| < 2^19
+    hpk[j] = sg < D2_SLOTS ? (int)(((unsigned)off << 12) | (unsigned)(row << 5) | (unsigned)px) : (127 << 5);
+  }
+  auto issue_tile = [&](const MmJob& J, int lit_) {
+    const int img = lit_ / RPI, rrem = lit_ % RPI;
+    const int ry0 = (rrem / RPX) * 16, rx0 = (rrem % RPX) * 16;
+    const char* base = reinterpret_cast<const char*>(J.in) + ((size_t)img * HW * HW + (size_t)(ry0 * HW + rx0)) * (KC * 4);
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+      if (wave + 8 * j < D2_PIECES) dma_halo_lane<HW>(base, zeros, ry0, rx0, hpk[j], sbase + (unsigned)(wave + 8 * j) * 1024u);
+  };
+  auto issue_filter = [&](const uint16_t* wpk) {
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      const int p = wave + 8 * j;
+      if (p < D2_WBYTES / 1024) dma16(reinterpret_cast<const char*>(wpk) + p * 1024 + lane * 16, sbase + D2_W_OFF + (unsigned)p * 1024u);
+    }
+  };
+  issue_tile(jt.job[jb], lit);
+  issue_filter(jt.job[jb].wpk);
+  int res_job = jb;
+  bool first_item = true;
+  int meta_jb = -1, e_out = 0;
+  float factor = 1.f, mx = 0.f;
+
+  for (; item < nitems; item += gridDim.x) {
+    const int next_item = item + gridDim.x;
+    const bool more = next_item < nitems;
+    const int jn = more ? mm_job_of(jt, next_item) : jb, nlit = more ? next_item - jt.start[jn] : lit;
+    if (jb != meta_jb) {
+      if (meta_jb >= 0) h2_publish_amax(jt.job[meta_jb].out_meta, wave_max(mx), lane);
+      mx = 0.f;
+      const MmJob& Jm = jt.job[jb];
+      const int e_in = Jm.in_meta->e;
+      const float amax_in = h2_true_amax(e_in, Jm.in_meta->amax);
+      e_out = h2_exp_for_bound(amax_in * Jm.wmeta->l1);
+      factor = ldexpf(1.f, e_out - e_in - Jm.wmeta->e);
+      meta_jb = jb;
+    }
+    bool w_fresh = false;
+    if (jb != res_job) {              // (at most five times per workgroup) the taps of the previous job are done: barrier B below
+      issue_filter(jt.job[jb].wpk);
+      res_job = jb;
+      w_fresh = true;
+    }
+    // the tile was issued BEFORE the previous item's epilogue stores: a counted wait covers it and none of them (conv_mm_kernel, RES)
+    constexpr int EPI_STORES = EPI == EPI_LRELU_POOL ? 6 : 16;
+    if (first_item || w_fresh) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if constexpr (EPI_STORES == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    __syncthreads();                  // A: tile (and filter) visible
+    first_item = false;
+
+    f32x4 acc[2][NT];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+      for (int ct = 0; ct < NT; ++ct) acc[rt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int dy = tap / 3, dx = tap % 3;
+      const int aoff = (dy * 18 + dx) * 128;
+      const int ab = abase[dx][dy & 1];
+      uint4 ah[2], al[2], bh[NT], bl[NT];
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt) {
+        ah[rt] = *reinterpret_cast<const uint4*>(smem + ab + aoff + rt * 1024);
+        al[rt] = *reinterpret_cast<const uint4*>(smem + (ab ^ 64) + aoff + rt * 1024);
+      }
+#pragma unroll
+      for (int ct = 0; ct < NT; ++ct) {
+        bh[ct] = *reinterpret_cast<const uint4*>(smem + b_lane + ((tap * NT + ct) * 2 + 0) * 1024);
+        bl[ct] = *reinterpret_cast<const uint4*>(smem + b_lane + ((tap * NT + ct) * 2 + 1) * 1024);
+      }
+#pragma unroll
+      for (int ct = 0; ct < NT; ++ct)
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) acc[rt][ct] = mfma16_h(ah[rt], bh[ct], acc[rt][ct]);
+#pragma unroll
+      for (int ct = 0; ct < NT; ++ct)
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) acc[rt][ct] = mfma16_h(ah[rt], bl[ct], acc[rt][ct]);
+#pragma unroll
+      for (int ct = 0; ct < NT; ++ct)
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) acc[rt][ct] = mfma16_h(al[rt], bh[ct], acc[rt][ct]);
+    }
+    __syncthreads();                  // B: every wave has read its last fragment: the halo buffer (and, on a job change, the filter) is free
+    if (more) issue_tile(jt.job[jn], nlit);
+
+    // ---- epilogue (conv_mm16_kernel's, one channel group): acc[rt][ct][i] of lane (col, rg): window 4 rt + rg of the wave's 8,
+    // position i; tiles 0, 1 = channels 2 col, 2 col + 1
+    const int img = lit / RPI, rrem = lit % RPI;
+    const int ry0 = (rrem / RPX) * 16, rx0 = (rrem % RPX) * 16;
+    const MmJob& J = jt.job[jb];
+    if (lit == 0 && tid == 0) J.out_meta->e = e_out;
+    constexpr bool POOL = EPI == EPI_LRELU_POOL;
+    constexpr int HO = POOL ? HW / 2 : HW;
+    char* out = reinterpret_cast<char*>(J.out) + (size_t)img * HO * HO * NC * 4;
+    const unsigned chb = (unsigned)(2 * col) * 2u;
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+      const int wx = 4 * rt + rg;
+      if constexpr (POOL) {
+        float best[2];
+        unsigned bi[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          best[e] = acc[rt][e][0];
+          bi[e] = 0;
+#pragma unroll
+          for (int i = 1; i < 4; ++i) {
+            const float v = acc[rt][e][i];
+            if (v > best[e]) { best[e] = v; bi[e] = i; }     // strict >: the FIRST maximum wins (TF MaxPoolGrad)
+          }
+          best[e] = ugn_lrelu(best[e] * factor);
+          mx = fmaxf(mx, fabsf(best[e]));
+        }
+        const unsigned pix = (unsigned)((ry0 / 2 + wave) * HO + rx0 / 2 + wx);
+        _Float16 h0, l0, h1, l1;
+        h2_split(best[0], h0, l0);
+        h2_split(best[1], h1, l1);
+        UGN_ST(unsigned, out + pix * (unsigned)(NC * 4) + chb, h2_pack(h0, h1));
+        UGN_ST(unsigned, out + pix * (unsigned)(NC * 4) + (unsigned)(NC * 2) + chb, h2_pack(l0, l1));
+        uint8_t* oi = J.out_idx + (size_t)img * HO * HO * NC;
+        UGN_ST(uint16_t, oi + pix * (unsigned)NC + (unsigned)(2 * col), bi[0] | (bi[1] << 8));
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const unsigned pix = (unsigned)((ry0 + 2 * wave + (i >> 1)) * HW + rx0 + 2 * wx + (i & 1));
+          float v0 = acc[rt][0][i] * factor, v1 = acc[rt][1][i] * factor;
+          if constexpr (EPI == EPI_LRELU) {
+            v0 = ugn_lrelu(v0);
+            v1 = ugn_lrelu(v1);
+          }
+          mx = fmaxf(mx, fmaxf(fabsf(v0), fabsf(v1)));
+          _Float16 h0, l0, h1, l1;
+          h2_split(v0, h0, l0);
+          h2_split(v1, h1, l1);
+          UGN_ST(unsigned, out + pix * (unsigned)(NC * 4) + chb, h2_pack(h0, h1));
+          UGN_ST(unsigned, out + pix * (unsigned)(NC * 4) + (unsigned)(NC * 2) + chb, h2_pack(l0, l1));
+        }
+      }
+    }
+    jb = jn;
+    lit = nlit;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  h2_publish_amax_block(jt.job[meta_jb].out_meta, mx, reinterpret_cast<float*>(smem), tid, 8);
+}
+
+
+// The same for the POOLED data gradient of the layer (a2: dL/dp2 + argmax bytes -> dL/da1, the largest tensor of the backward pass).
+// 32x32x16 shape (the data-gradient filters of this layer are packed for it; the fused first-layer kernel below reads them too),
+// one accumulator block per wave, the one-block epilogue of conv_mm_kernel.  MaxPool backward: the pooled values + argmax bytes
+// of the tile AFTER the next one travel through registers (plain global loads, an item ahead) and are scattered into the single halo
+// buffer behind barrier B, in the swizzled order the fragment reads expect.
+template <int HW>
+__global__ __launch_bounds__(512, 4) void conv32_d2p_kernel(const MmJobs jt) {
+  constexpr int KC = 32, NC = 32, HP = HW / 2;
+  constexpr int RPX = HW / 16, RPI = RPX * RPX;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const unsigned sbase = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // A-side role (conv_mm_kernel): row r of the wave's 32-pixel block = window win, position q; k half h
+  const int r = lane & 31, h = lane >> 5, win = r >> 2, q = r & 3;
+  const int row0 = 2 * wave + (q >> 1), col0 = 2 * win + (q & 1);
+  int abase[3][2];                      // [dx][parity of dy]: slot (k-step 0, H plane); k-step 1: ^ 32, L plane: ^ 64
+#pragma unroll
+  for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+    for (int dp = 0; dp < 2; ++dp) {
+      const int g = ((((col0 + dx) >> 1) & 3) << 1) | ((row0 + dp) & 1);
+      abase[dx][dp] = (row0 * 18 + col0) * 128 + ((g ^ h) << 4);
+    }
+  const int b_lane = D2_W_OFF + lane * 16;
+  const int c = lane & 31;
+
+  int item = blockIdx.x;
+  const int nitems = jt.start[kMaxJobs];
+  if (item >= nitems) return;
+  int jb = mm_job_of(jt, item), lit = item - jt.start[jb];
+
+  // this thread's unit of the 10 x 10 pooled pixels under a region's halo: pooled pixel spp, channel group scg (8 channels)
+  const int spp = tid >> 2, scg = tid & 3;
+  const int sprow = (spp * 205) >> 11, spcol = spp - sprow * 10;
+  uint4 shi = make_uint4(0u, 0u, 0u, 0u), slo = shi;
+  uint2 six = make_uint2(0u, 0u);
+  auto stg_load = [&](const MmJob& J, int lit_) {
+    const int img = lit_ / RPI, rrem = lit_ % RPI;
+    const int pr = ((rrem / RPX) * 16) / 2 - 1 + sprow, pc = ((rrem % RPX) * 16) / 2 - 1 + spcol;
+    const bool ok = tid < 400 && (unsigned)pr < (unsigned)HP && (unsigned)pc < (unsigned)HP;
+    shi = make_uint4(0u, 0u, 0u, 0u);
+    slo = shi;
+    six = make_uint2(0u, 0u);
+    if (ok) {
+      const unsigned o = (unsigned)(pr * HP + pc);
+      const char* v = reinterpret_cast<const char*>(J.in) + ((size_t)img * HP * HP + o) * (KC * 4) + (unsigned)(scg * 16);
+      shi = *reinterpret_cast<const uint4*>(v);
+      slo = *reinterpret_cast<const uint4*>(v + KC * 2);
+      six = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(J.in_idx) + ((size_t)img * HP * HP + o) * KC + (unsigned)(scg * 8));
+    }
+  };
+  auto scatter = [&]() {              // registers -> the halo tile: quarter jj of pixel (hy, hx) into slot jj ^ g(hy, hx)
+    if (tid >= 400) return;
+    const unsigned hv[4] = {shi.x, shi.y, shi.z, shi.w}, lv[4] = {slo.x, slo.y, slo.z, slo.w};
+#pragma unroll
+    for (int pos = 0; pos < 4; ++pos) {
+      const int hy = 2 * sprow - 1 + (pos >> 1), hx = 2 * spcol - 1 + (pos & 1);
+      if ((unsigned)hy >= 18u || (unsigned)hx >= 18u) continue;
+      unsigned m[4];
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        const unsigned w = d < 2 ? six.x : six.y;
+        const unsigned b0 = (w >> (16 * (d & 1))) & 0xffu, b1 = (w >> (16 * (d & 1) + 8)) & 0xffu;
+        m[d] = (b0 == (unsigned)pos ? 0x0000ffffu : 0u) | (b1 == (unsigned)pos ? 0xffff0000u : 0u);
+      }
+      const int g = (((hx >> 1) & 3) << 1) | (hy & 1);
+      char* rec = smem + (hy * 18 + hx) * 128;
+      *reinterpret_cast<uint4*>(rec + ((scg ^ g) << 4)) = make_uint4(hv[0] & m[0], hv[1] & m[1], hv[2] & m[2], hv[3] & m[3]);
+      *reinterpret_cast<uint4*>(rec + (((4 + scg) ^ g) << 4)) = make_uint4(lv[0] & m[0], lv[1] & m[1], lv[2] & m[2], lv[3] & m[3]);
+    }
+  };
+  auto issue_filter = [&](const uint16_t* wpk) {
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      const int p = wave + 8 * j;
+      if (p < D2_WBYTES / 1024) dma16(reinterpret_cast<const char*>(wpk) + p * 1024 + lane * 16, sbase + D2_W_OFF + (unsigned)p * 1024u);
+    }
+  };
+  // ---- prologue: tile of the first item -> halo, the second item's pooled pixels -> registers, the job's filter -> LDS
+  stg_load(jt.job[jb], lit);
+  issue_filter(jt.job[jb].wpk);
+  scatter();
+  {
+    const int ni = item + gridDim.x;
+    if (ni < nitems) { const int j2 = mm_job_of(jt, ni); stg_load(jt.job[j2], ni - jt.start[j2]); }
+  }
+  int res_job = jb;
+  bool first_item = true;
+  int meta_jb = -1, e_out = 0;
+  float factor = 1.f, mx = 0.f;
+
+  for (; item < nitems; item += gridDim.x) {
+    const int next_item = item + gridDim.x, next2 = item + 2 * (int)gridDim.x;
+    const bool more = next_item < nitems;
+    const int jn = more ? mm_job_of(jt, next_item) : jb, nlit = more ? next_item - jt.start[jn] : lit;
+    if (jb != meta_jb) {
+      if (meta_jb >= 0) h2_publish_amax(jt.job[meta_jb].out_meta, wave_max(mx), lane);
+      mx = 0.f;
+      const MmJob& Jm = jt.job[jb];
+      const int e_in = Jm.in_meta->e;
+      const float amax_in = h2_true_amax(e_in, Jm.in_meta->amax);
+      e_out = h2_exp_for_bound(amax_in * Jm.wmeta->l1);
+      factor = ldexpf(1.f, e_out - e_in - Jm.wmeta->e);
+      meta_jb = jb;
+    }
+    if (jb != res_job) {              // the previous job's taps ended behind barrier B
+      issue_filter(jt.job[jb].wpk);
+      res_job = jb;
+      first_item = true;
+    }
+    if (first_item) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the filter DMA; the scatter awaited its loads itself)
+    __syncthreads();                  // A: the scattered tile (and the filter) visible
+    first_item = false;
+
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int dy = tap / 3, dx = tap % 3;
+      const int aoff = (dy * 18 + dx) * 128;
+      const int ab = abase[dx][dy & 1];
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const uint4 ah = *reinterpret_cast<const uint4*>(smem + (ab ^ (s << 5)) + aoff);
+        const uint4 al = *reinterpret_cast<const uint4*>(smem + (ab ^ (s << 5) ^ 64) + aoff);
+        const uint4 bh = *reinterpret_cast<const uint4*>(smem + b_lane + ((tap * 2 + s) * 2 + 0) * 1024);
+        const uint4 bl = *reinterpret_cast<const uint4*>(smem + b_lane + ((tap * 2 + s) * 2 + 1) * 1024);
+        acc = mfma_h(ah, bh, acc);
+        acc = mfma_h(ah, bl, acc);
+        acc = mfma_h(al, bh, acc);
+      }
+    }
+    __syncthreads();                  // B: the halo buffer is free
+    if (more) {
+      scatter();                      // the next item's tile (its loads were issued an item ago)
+      if (next2 < nitems) { const int j2 = mm_job_of(jt, next2); stg_load(jt.job[j2], next2 - jt.start[j2]); }
+    }
+
+    // ---- epilogue (conv_mm_kernel, one block): lane c owns channel c; lanes (c, c ^ 1) exchange halves: the even lane stores the H
+    // pair, the odd lane the L pair.  acc[4g + i]: window 2g + h of the wave's 8, position i
+    const int img = lit / RPI, rrem = lit % RPI;
+    const int ry0 = (rrem / RPX) * 16, rx0 = (rrem % RPX) * 16;
+    const MmJob& J = jt.job[jb];
+    if (lit == 0 && tid == 0) J.out_meta->e = e_out;
+    char* out = reinterpret_cast<char*>(J.out) + (size_t)img * HW * HW * NC * 4;
+    const unsigned sel = (c & 1) ? 0x03020706u : 0x05040100u;
+    const unsigned chb = (c & 1) ? (unsigned)(NC * 2 + (c - 1) * 2) : (unsigned)(c * 2);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int wx = 2 * g + h;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const unsigned pix = (unsigned)((ry0 + 2 * wave + (i >> 1)) * HW + rx0 + 2 * wx + (i & 1));
+        const float v = acc[4 * g + i] * factor;
+        mx = fmaxf(mx, fabsf(v));
+        _Float16 hi, lo;
+        h2_split(v, hi, lo);
+        const unsigned own = h2_pack(hi, lo);
+        const unsigned oth = (unsigned)__builtin_amdgcn_update_dpp(0, (int)own, 0xB1, 0xf, 0xf, false);   // quad_perm [1,0,3,2]
+        UGN_ST(unsigned, out + pix * (unsigned)(NC * 4) + chb, __builtin_amdgcn_perm(oth, own, sel));
+      }
+    }
+    jb = jn;
+    lit = nlit;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  h2_publish_amax_block(jt.job[meta_jb].out_meta, mx, reinterpret_cast<float*>(smem), tid, 8);
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // data gradient of the pooled 32 -> 32 layer (a2) FUSED with the weight gradient of the 5x5 first layer
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1425,7 +1799,49 @@ int launch_mm16(const MmJob* jobs, const int* n, int njobs, hipStream_t st) {
   return 0;
 }
 
+template <int HW, int EPI>
+int launch_d2(const MmJob* jobs, const int* n, int njobs, hipStream_t st) {
+  auto kern = conv32_d2_kernel<HW, EPI>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, D2_LDS);
+    if (e != hipSuccess) { ugn_set_error("conv32_d2: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
+    attr_done = true;
+  }
+  const void* zeros = zero_block();
+  if (!zeros) { ugn_set_error("conv32_d2: cannot allocate the zero block"); return UGN_EINVAL; }
+  MmJobs jt;
+  const int nitems = make_mm_table(jt, jobs, n, njobs, (HW / 16) * (HW / 16));
+  const int wgs = 2 * g_persistent_wgs;        // two workgroups per CU
+  const int grid = nitems < wgs ? nitems : wgs;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), D2_LDS, st, jt, zeros);
+  UGN_CHECK_LAUNCH("conv32_d2");
+  return 0;
+}
+
+template <int HW>
+int launch_d2p(const MmJob* jobs, const int* n, int njobs, hipStream_t st) {
+  auto kern = conv32_d2p_kernel<HW>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, D2_LDS);
+    if (e != hipSuccess) { ugn_set_error("conv32_d2p: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
+    attr_done = true;
+  }
+  MmJobs jt;
+  const int nitems = make_mm_table(jt, jobs, n, njobs, (HW / 16) * (HW / 16));
+  const int wgs = 2 * g_persistent_wgs;
+  const int grid = nitems < wgs ? nitems : wgs;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), D2_LDS, st, jt);
+  UGN_CHECK_LAUNCH("conv32_d2p");
+  return 0;
+}
+
 int dispatch_fwd(const MmJob* jobs, const int* n, int njobs, int hw, int cin, int cout, int pool, hipStream_t st) {
+  if constexpr ((UGN_MM_D2 & 1) != 0) {
+    if (cin == 32 && cout == 32 && hw == 64 && pool) return launch_d2<64, EPI_LRELU_POOL>(jobs, n, njobs, st);
+  }
+
 #define MF(KC_, NC_, HW_, P_)                                                \
   if (cin == KC_ && cout == NC_ && hw == HW_ && (pool != 0) == (P_ != 0)) {  \
     if constexpr (mm_tile16(KC_, NC_, 0))                                    \
@@ -1441,6 +1857,9 @@ int dispatch_fwd(const MmJob* jobs, const int* n, int njobs, int hw, int cin, in
 
 // data gradient of the forward layer cin -> cout at hw x hw: K = cout, N = cin
 int dispatch_dgrad(const MmJob* jobs, const int* n, int njobs, int hw, int cin, int cout, int unpool, bool act, hipStream_t st) {
+  if constexpr ((UGN_MM_D2 & 2) != 0) {
+    if (cin == 32 && cout == 32 && hw == 64 && unpool && !act) return launch_d2p<64>(jobs, n, njobs, st);
+  }
 #define MD(CI_, CO_, HW_, U_)                                                                     \
   if (cin == CI_ && cout == CO_ && hw == HW_ && unpool == U_) {                                   \
     if constexpr (mm_tile16(CO_, CI_, 1) && !U_)                                                  \
@@ -1496,6 +1915,8 @@ __global__ void h2_decode_kernel(const uint16_t* __restrict__ y, const H2Meta* m
 }
 
 }  // namespace
+
+int ugn_mm::persistent_wgs() { return g_persistent_wgs; }
 
 const void* ugn_mm::zero_block() {
   static void* z = nullptr;

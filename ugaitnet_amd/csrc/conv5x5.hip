@@ -15,6 +15,9 @@ using ugn_mm::H2Meta;
 #ifndef UGN_C5_WAVES
 #define UGN_C5_WAVES 4     // waves per SIMD the forward kernel is compiled for (measured: 4 and 6 equal, 8 spills)
 #endif
+#ifndef UGN_C5_H2MM
+#define UGN_C5_H2MM 1     // H2 output: multiply on the f16 matrix pipe (x and w split into f16 halves on the fly) instead of the fp32 MFMA
+#endif
 #ifndef UGN_C5_GRID
 #define UGN_C5_GRID 1024   // persistent workgroups of the forward kernel (256 CUs x 4 workgroups of 256 threads)
 #endif
@@ -59,7 +62,7 @@ __device__ __forceinline__ void stage_patch(float* sP, const float* __restrict__
 // which every workgroup forms from the filter it has just staged; the stored maximum is gathered per workgroup.
 // OFMT: 0 fp32 a1, 1 H2 (above), 2 bf16 (configs[4]: [pixel][32] bf16, no exponent)
 template <int CIN, bool SIGN, int OFMT = 0>
-__global__ __launch_bounds__(256, UGN_C5_WAVES) void conv5x5_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+__global__ __launch_bounds__(256, (OFMT == 1 && UGN_C5_H2MM) ? 3 : UGN_C5_WAVES) void conv5x5_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                                         float* __restrict__ a1, uint32_t* __restrict__ sign_out,
                                                                         int ntiles, const H2Meta* __restrict__ x_meta = nullptr,
                                                                         H2Meta* __restrict__ out_meta = nullptr) {
@@ -77,15 +80,30 @@ __global__ __launch_bounds__(256, UGN_C5_WAVES) void conv5x5_fwd_kernel(const fl
 
   for (int e = tid; e < 2 * KP * 32; e += 256) sW[e] = e < K * 32 ? w[e] : 0.f;
   constexpr bool H2OUT = OFMT == 1;
-  float h2_factor = 1.f, h2_mx = 0.f;
+  // H2MM (H2 output, default): the layer multiplies on v_mfma_f32_32x32x16_f16 like the 3x3 layers -- x * 2^ex and w * 2^ew split into
+  // f16 halves (the patch once per tile while it is written to LDS, the filter once per workgroup into registers), three MFMAs per
+  // product (hi*hi + hi*lo + lo*hi, fp32 accumulate): 6 / 12 MFMAs of 32 cycles per 32-pixel block instead of 13 / 25 fp32 MFMAs of
+  // 64 cycles that also block the vector pipe.  The layer is then bound by writing a1, as its byte count says it should be.
+  constexpr bool H2MM = H2OUT && UGN_C5_H2MM;
+  float h2_factor = 1.f, h2_mx = 0.f, x_scale = 1.f, w_scale = 1.f;
   if constexpr (H2OUT) {
     __syncthreads();
-    float l1 = 0.f;
-    for (int k = 0; k < K; ++k) l1 += fabsf(sW[k * 32 + li]);      // lane li = output channel (both lane halves alike)
+    float l1 = 0.f, wmax = 0.f;
+    for (int k = 0; k < K; ++k) {      // lane li = output channel (both lane halves alike)
+      l1 += fabsf(sW[k * 32 + li]);
+      wmax = fmaxf(wmax, fabsf(sW[k * 32 + li]));
+    }
     l1 = ugn_mm::wave_max(l1) * 1.0001f;
-    const int e_out = ugn_mm::h2_exp_for_bound(ugn_mm::h2_true_amax(x_meta->e, x_meta->amax) * l1);
+    const float xmax = ugn_mm::h2_true_amax(x_meta->e, x_meta->amax);
+    const int e_out = ugn_mm::h2_exp_for_bound(xmax * l1);
     h2_factor = ldexpf(1.f, e_out);
     if (blockIdx.x == 0 && tid == 0) out_meta->e = e_out;
+    if constexpr (H2MM) {
+      const int ex = ugn_mm::h2_exp_for_bound(xmax), ew = ugn_mm::h2_exp_for_bound(ugn_mm::wave_max(wmax));
+      x_scale = ldexpf(1.f, ex);
+      w_scale = ldexpf(1.f, ew);
+      h2_factor = ldexpf(1.f, e_out - ex - ew);       // the accumulators hold x * w * 2^(ex + ew)
+    }
   }
   // patch pixel e = tid + 256 * j of tile t: (yy, xx) = (e / 20, e % 20) -> raw pixel (ty0 - 4 + yy, tx0 - 4 + xx)
   int pyy[PPT], pxx[PPT];
@@ -126,10 +144,13 @@ __global__ __launch_bounds__(256, UGN_C5_WAVES) void conv5x5_fwd_kernel(const fl
   typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
   constexpr bool BFMM = OFMT == 2;
   constexpr int KS = (K + 15) / 16;
-  int goff[BFMM ? KS : 1][8];
+  int goff[BFMM || H2MM ? KS : 1][8];
   bf8 wfrag[BFMM ? KS : 1];
+  // filter fragments as f16 halves of w * 2^ew: [k-step][plane][lane-linear 1 KB] in LDS (identical for the four waves; in registers
+  // they are 8 KS VGPRs that push the two-channel kernel into scratch)
+  __shared__ __attribute__((aligned(16))) uint4 sWf[(OFMT == 1 && UGN_C5_H2MM) ? KS * 2 * 64 : 1];
   int pbb[2];
-  if constexpr (BFMM) {
+  if constexpr (BFMM || H2MM) {
     __syncthreads();            // sW is complete
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks)
@@ -138,7 +159,16 @@ __global__ __launch_bounds__(256, UGN_C5_WAVES) void conv5x5_fwd_kernel(const fl
         const int k = 16 * ks + 8 * lh + i;
         const int tap = k / CIN, ch = k % CIN;
         goff[ks][i] = k < K ? (tap / 5) * FP + (tap % 5) * CIN + ch : 0;
-        wfrag[ks][i] = (__bf16)(k < K ? sW[k * 32 + li] : 0.f);
+        const float wv = k < K ? sW[k * 32 + li] : 0.f;
+        if constexpr (BFMM) wfrag[ks][i] = (__bf16)wv;
+        if constexpr (H2MM) {
+          if (wave == 0) {
+            _Float16 hi, lo;
+            ugn_mm::h2_split(wv * w_scale, hi, lo);
+            reinterpret_cast<_Float16*>(sWf)[((ks * 2 + 0) * 64 + lane) * 8 + i] = hi;
+            reinterpret_cast<_Float16*>(sWf)[((ks * 2 + 1) * 64 + lane) * 8 + i] = lo;
+          }
+        }
       }
 #pragma unroll
     for (int m = 0; m < 2; ++m) pbb[m] = (2 * (wave * 2 + m) + py) * FP + px * CIN;
@@ -152,7 +182,15 @@ __global__ __launch_bounds__(256, UGN_C5_WAVES) void conv5x5_fwd_kernel(const fl
     for (int j = 0; j < PPT; ++j)
       if (tid + 256 * j < PE) {
 #pragma unroll
-        for (int c = 0; c < CIN; ++c) sP[pyy[j] * FP + pxx[j] * CIN + c] = pv[j][c];
+        for (int c = 0; c < CIN; ++c) {
+          if constexpr (H2MM) {       // the patch as packed halves (H | L << 16) of x * 2^ex: split ONCE per value, not per gather
+            _Float16 hi, lo;
+            ugn_mm::h2_split(pv[j][c] * x_scale, hi, lo);
+            reinterpret_cast<unsigned*>(sP)[pyy[j] * FP + pxx[j] * CIN + c] = ugn_mm::h2_pack(hi, lo);
+          } else {
+            sP[pyy[j] * FP + pxx[j] * CIN + c] = pv[j][c];
+          }
+        }
       }
     __syncthreads();
     const int nt = tile + (int)gridDim.x;
@@ -173,6 +211,27 @@ __global__ __launch_bounds__(256, UGN_C5_WAVES) void conv5x5_fwd_kernel(const fl
 #pragma unroll
           for (int i = 0; i < 8; ++i) a[i] = (__bf16)sP[pbb[m] + goff[ks][i]];
           acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, wfrag[ks], acc[m], 0, 0, 0);
+        }
+    } else if constexpr (H2MM) {
+      const unsigned* sPu = reinterpret_cast<const unsigned*>(sP);
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+          unsigned d[8];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) d[i] = sPu[pbb[m] + goff[ks][i]];
+          // the lane's 8 taps: low halves -> the H fragment, high halves -> the L fragment (v_perm_b32)
+          const uint4 ah = make_uint4(__builtin_amdgcn_perm(d[1], d[0], 0x05040100u), __builtin_amdgcn_perm(d[3], d[2], 0x05040100u),
+                                      __builtin_amdgcn_perm(d[5], d[4], 0x05040100u), __builtin_amdgcn_perm(d[7], d[6], 0x05040100u));
+          const uint4 al = make_uint4(__builtin_amdgcn_perm(d[1], d[0], 0x07060302u), __builtin_amdgcn_perm(d[3], d[2], 0x07060302u),
+                                      __builtin_amdgcn_perm(d[5], d[4], 0x07060302u), __builtin_amdgcn_perm(d[7], d[6], 0x07060302u));
+          const ugn_mm::h8 fah = __builtin_bit_cast(ugn_mm::h8, ah), fal = __builtin_bit_cast(ugn_mm::h8, al);
+          const ugn_mm::h8 wh = __builtin_bit_cast(ugn_mm::h8, sWf[(ks * 2 + 0) * 64 + lane]);
+          const ugn_mm::h8 wl = __builtin_bit_cast(ugn_mm::h8, sWf[(ks * 2 + 1) * 64 + lane]);
+          acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah, wh, acc[m], 0, 0, 0);
+          acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah, wl, acc[m], 0, 0, 0);
+          acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fal, wh, acc[m], 0, 0, 0);
         }
     } else
 #pragma unroll
@@ -448,7 +507,8 @@ extern "C" int ugn_conv5x5_in_fwd(const float* x, const float* w, float* a1, uin
   UGN_REQUIRE(cin == 1 || cin == 2, "ugn_conv5x5_in_fwd: cin must be 1 or 2 (got %d)", cin);
   hipStream_t st = (hipStream_t)stream;
   const int ntiles = n * 16;
-  const int grid = ntiles < UGN_C5_GRID ? ntiles : UGN_C5_GRID;
+  const int c5grid = UGN_C5_GRID / ugn_mm::kGrid * ugn_mm::persistent_wgs();     // (4 workgroups per CU of those left to this library)
+  const int grid = ntiles < c5grid ? ntiles : c5grid;
 #define UGN_C5F(C_, S_) hipLaunchKernelGGL((conv5x5_fwd_kernel<C_, S_>), dim3(grid), dim3(256), 0, st, x, w, a1, a1_sign, ntiles)
   if (cin == 1) {
     if (a1_sign) UGN_C5F(1, true); else UGN_C5F(1, false);
@@ -468,7 +528,8 @@ extern "C" int ugn_conv5x5_in_fwd_h2(const float* x, const void* x_meta, const f
   UGN_REQUIRE(UGN_C5_DS == 32, "ugn_conv5x5_in_fwd_h2: built with a padded gradient tile");
   hipStream_t st = (hipStream_t)stream;
   const int ntiles = n * 16;
-  const int grid = ntiles < UGN_C5_GRID ? ntiles : UGN_C5_GRID;
+  const int c5grid = UGN_C5_GRID / ugn_mm::kGrid * ugn_mm::persistent_wgs();     // (4 workgroups per CU of those left to this library)
+  const int grid = ntiles < c5grid ? ntiles : c5grid;
 #define UGN_C5F(C_, S_) hipLaunchKernelGGL((conv5x5_fwd_kernel<C_, S_, 1>), dim3(grid), dim3(256), 0, st, x, w, (float*)a1, a1_sign, \
                                            ntiles, (const H2Meta*)x_meta, (H2Meta*)a1_meta)
   if (cin == 1) {
@@ -511,7 +572,8 @@ extern "C" int ugn_conv5x5_in_fwd_bf(const float* x, const float* w, uint16_t* a
   UGN_REQUIRE(cin == 1 || cin == 2, "ugn_conv5x5_in_fwd_bf: cin must be 1 or 2 (got %d)", cin);
   hipStream_t st = (hipStream_t)stream;
   const int ntiles = n * 16;
-  const int grid = ntiles < UGN_C5_GRID ? ntiles : UGN_C5_GRID;
+  const int c5grid = UGN_C5_GRID / ugn_mm::kGrid * ugn_mm::persistent_wgs();     // (4 workgroups per CU of those left to this library)
+  const int grid = ntiles < c5grid ? ntiles : c5grid;
 #define UGN_C5F(C_, S_) hipLaunchKernelGGL((conv5x5_fwd_kernel<C_, S_, 2>), dim3(grid), dim3(256), 0, st, x, w, (float*)a1, a1_sign, ntiles)
   if (cin == 1) {
     if (a1_sign) UGN_C5F(1, true); else UGN_C5F(1, false);
@@ -529,6 +591,8 @@ static int conv5x5_wgrad_any(const float* x, const float* dz1, const H2Meta* dz_
   UGN_REQUIRE(ws_bytes >= ugn_conv5x5_in_wgrad_ws(n, cin), "ugn_conv5x5_in_wgrad: workspace too small");
   hipStream_t st = (hipStream_t)stream;
   const int tiles = n * 16;
+  // (not sized by ugn_set_persistent_wgs: a workgroup's slab is the sum over ITS tiles, so another grid is another grouping of the
+  //  fp32 sums; at 2 workgroups of 70 KB LDS and 8 waves per CU this launch leaves RCCL's channels room on every CU anyway)
   const int groups = tiles < WG5_GROUPS ? tiles : WG5_GROUPS;
   static float* zeros = nullptr;   // LDS-DMA source for the pad and the out-of-image lanes
   if (!zeros) {

@@ -136,5 +136,14 @@ __host__ __device__ constexpr int mm_block_of(int n, int nc) { return nc == 32 ?
 __host__ __device__ constexpr int mm_col_of(int n, int nc) { return nc == 32 ? n : (n & 63) >> 1; }
 
 const void* zero_block();   // 256 B of zeros in HBM (conv3x3_mm.hip)
+// Persistent workgroups per launch (ugn_set_persistent_wgs; default kGrid = one per CU).  Every persistent launch of the library
+// that owns its CUs' LDS sizes its grid from it: f16x2 and bf16 forward / data gradient (items stride over the grid), weight gradients
+// (groups per block combination on the grid, a multiple of 8; the launch's shares stay fixed), the 5x5 forward (4 workgroups per CU).
+int persistent_wgs();
+// groups per block combination of a weight-gradient launch: the largest multiple of 8 with groups * ncombo <= persistent_wgs()
+inline int persistent_groups(int ng_full, int ncombo) {
+  int g = (persistent_wgs() / ncombo) / 8 * 8;
+  return g < 8 ? 8 : (g > ng_full ? ng_full : g);
+}
 
 }  // namespace ugn_mm

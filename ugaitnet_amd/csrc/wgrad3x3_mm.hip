@@ -42,7 +42,8 @@ struct WgJob {
 struct WgJobs {
   WgJob job[kWgMaxJobs];
   int start[kWgMaxJobs + 1]; // first strip of job j; [njobs..] = total
-  int ngroups;               // groups per block combination (a multiple of 8)
+  int ngroups;               // groups per block combination (a multiple of 8): fixed per kernel shape
+  int gstep;                 // groups per combination that the grid holds at once (= ngroups on the full grid)
 };
 
 template <int CO>
@@ -91,11 +92,10 @@ __global__ __launch_bounds__(512, 2) void wgrad_mm_kernel(const WgJobs jt, const
   // workgroup -> (combination, group): all combinations of a group sit on ONE XCD (blockIdx % 8), so the strip both read
   // comes from HBM once per XCD and from that XCD's L2 afterwards
   const int bid = blockIdx.x, xcd = bid & 7, rest = bid >> 3;
-  const int combo = rest % NCOMBO, grp = (rest / NCOMBO) * 8 + xcd;
+  const int combo = rest % NCOMBO;
+  int grp = (rest / NCOMBO) * 8 + xcd;      // the first group of this workgroup; further ones gstep apart (reduced grids)
   const int cic = combo / NCOC, coc = combo % NCOC;
   const int total = jt.start[kWgMaxJobs];
-  const int s0 = (int)((long long)grp * total / jt.ngroups), s1 = (int)((long long)(grp + 1) * total / jt.ngroups);
-  if (s0 >= s1) return;
   const int pair = wave % PW, ks = wave / PW;
   // M16 (64 output channels per workgroup): v_mfma_f32_16x16x32_f16 -- K = 32 pixels (the wave's two rows) per step, the 32 x 32
   // block of a tap as four 16 x 16 tiles (see the strip loop).  Its tiles are SWIZZLED in LDS: on odd tile rows the two 32-byte
@@ -282,6 +282,13 @@ __global__ __launch_bounds__(512, 2) void wgrad_mm_kernel(const WgJobs jt, const
 #else
 #define WG_STAMP(k_) do { } while (0)
 #endif
+  // A launch always has jt.ngroups groups per block combination -- the shares, the slabs and the order of every sum are fixed by
+  // the job sizes alone -- and a workgroup takes the groups grp, grp + gstep, ...: on the full grid (gstep = ngroups) exactly one,
+  // on a reduced grid (ugn_set_persistent_wgs: CUs left to RCCL) several in turn.  Results are bit-identical on every grid.
+  for (bool first_group = true; grp < jt.ngroups; grp += jt.gstep, first_group = false) {
+  const int s0 = (int)((long long)grp * total / jt.ngroups), s1 = (int)((long long)(grp + 1) * total / jt.ngroups);
+  if (s0 >= s1) continue;
+  if (!first_group) __syncthreads();        // the previous group's slab combine has finished reading its scratch
   // ---- prologue: tiles of strip s0 -> set 0
   {
     const StripSrc S0 = strip_src(s0);
@@ -459,6 +466,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_mm_kernel(const WgJobs jt, const
     }
     b ^= 1;
   }
+  }
 #ifdef UGN_WG_STAMP
   if (stamp && lane == 0) { stamp[2] = __builtin_amdgcn_s_memtime(); stamp[3] = __builtin_amdgcn_s_memrealtime(); }
 #endif
@@ -513,7 +521,11 @@ int launch_wgrad(const uint16_t* const* in, const void* const* in_meta, const ui
     if (j < njobs) total += n[j] * SPI;
   }
   jt.start[kWgMaxJobs] = total;
+  // (ugn_set_persistent_wgs: a grid of NGE < NG groups per block combination leaves CUs to RCCL; every workgroup then walks
+  //  several of the NG shares -- same shares, same slabs, same sums)
+  const int NGE = persistent_groups(NG, NCOMBO);
   jt.ngroups = NG;
+  jt.gstep = NGE;
   const size_t slab_floats = (size_t)9 * 32 * G::COW;
   size_t used = 0;
   for (int j = 0; j < kWgMaxJobs; ++j) {
@@ -540,7 +552,7 @@ int launch_wgrad(const uint16_t* const* in, const void* const* in_meta, const ui
     hipError_t me = hipMemsetAsync(ws, 0, used * sizeof(float), st);
     if (me != hipSuccess) { ugn_set_error("wgrad_mm: memset: %s", hipGetErrorString(me)); return (int)me; }
   }
-  hipLaunchKernelGGL(kern, dim3(NG * NCOMBO), dim3(512), LDS, st, jt, zeros);
+  hipLaunchKernelGGL(kern, dim3(NGE * NCOMBO), dim3(512), LDS, st, jt, zeros);
   UGN_CHECK_LAUNCH("wgrad_mm");
   hipLaunchKernelGGL(wgrad_mm_finish, dim3((9 * CI * CO + 255) / 256, njobs), dim3(256), 0, st, ft, CI, CO, G::COW);
   UGN_CHECK_LAUNCH("wgrad_mm finish");

@@ -43,6 +43,9 @@ NBINS, FEAT, HIDDEN = 62, 128, 256
 #         fp32 accumulate, fp32 master weights and Adam (engine_bf.py)
 #   "bf16w" (round 1-2) fp32 tensors, Winograd with bf16-rounded MFMA operands
 DEFAULT_PRECISION = os.environ.get("UGN_CONV_PRECISION", "h2")
+# Arithmetic of forward-only queries behind the Keras surface (model.predict, get_layer(...).output taps, UWYHSemiNet.encode):
+# "f32" by default -- see GaitCore.arithmetic; "same" keeps the training arithmetic (UGN_INFER_PRECISION).
+INFER_PRECISION = os.environ.get("UGN_INFER_PRECISION", "f32")
 
 # Winograd F(2x2,3x3) kernels for the 3x3 forward convolutions and data gradients (UGN_WINO=0 selects the direct
 # implicit-GEMM kernels, whose MaxPool tie-breaking on exactly equal activations follows the reference's first-max rule).
@@ -595,11 +598,15 @@ class GaitCore:
             for enc in self.encoders:
                 enc.bf = BFState(enc)
         if self.h2:
-            # UGN_PERSISTENT_WGS=n (< 256): the persistent convolution launches leave 256 - n CUs free -- room for RCCL's channels
-            # when the bucketed all-reduce (UGN_AR_OVERLAP=1) overlaps the backward pass.  Results do not depend on it
-            # (tests/test_mm_gpu.py); unmeasured on multi-GPU hardware, hence not a default.
+            # UGN_PERSISTENT_WGS=n (< 256): the persistent launches leave 256 - n CUs free -- room for RCCL's channels when the
+            # bucketed all-reduce (UGN_AR_OVERLAP=1) overlaps the backward pass.  Results do not depend on it (tests/test_mm_gpu.py).
             if os.environ.get("UGN_PERSISTENT_WGS"):
                 h2.set_persistent_wgs(int(os.environ["UGN_PERSISTENT_WGS"]))
+            elif self.world > 1 and AR_OVERLAP:
+                # the bucketed all-reduce runs BESIDE the rest of the backward pass: leave RCCL's channels 32 of the 256 CUs
+                # (every persistent launch of the library -- forward / data gradient, weight gradients, the 5x5 layer -- then
+                # starts 224 workgroups or the matching number of groups; unmeasured on multi-GPU hardware: UGN_PERSISTENT_WGS overrides)
+                h2.set_persistent_wgs(224)
             self.meta_pool = h2.MetaPool(self.device, 64 * self.nmod)
             for enc in self.encoders:
                 enc.h2 = H2State(enc, self.meta_pool)
@@ -656,6 +663,26 @@ class GaitCore:
             return
         for e in self.encoders:
             e.repack()
+
+    @contextlib.contextmanager
+    def arithmetic(self, precision):
+        """`with core.arithmetic("f32"):` -- run the enclosed FORWARD passes with the 3x3 layers in another arithmetic than the model
+        trains in; used by the Keras surface for `predict` / `encode` (INFER_PRECISION): a model that trains in f16x2 (one block
+        exponent per tensor: what a clip gets depends on the largest clip of its batch, csrc/mm_common.h) answers inference queries
+        in IEEE fp32, where an embedding does not depend on the other clips of the batch beyond what the reference's own
+        batch-axis normalisation does.  Parameters must not change inside the block (the f16x2 / bf16 filter packs stay valid)."""
+        if precision is None or precision == self.conv_precision or self.conv_precision not in ("h2", "bf16"):
+            yield                   # (fp32 models, and the fp32-tensor 'bf16w' mode, answer in their own arithmetic)
+            return
+        if precision != "f32":
+            raise ValueError("arithmetic(%r): only 'f32' inside an 'h2' / 'bf16' model" % (precision,))
+        saved = (self.conv_precision, self.h2, self.bf)
+        self.conv_precision, self.h2, self.bf = "f32", False, False
+        try:
+            self.weights_changed()          # the Winograd-transformed filters of the current parameters (one launch)
+            yield
+        finally:
+            self.conv_precision, self.h2, self.bf = saved
 
     def set_params_numpy(self, params):
         """params in the oracle's layout: dict(branches=[{a1..fc}], head={wc,bc})."""

@@ -290,13 +290,15 @@ class GaitSetModel:
     def predict(self, X, batch_size=None, verbose=0):
         """Outputs of the compiled graph: [signature [62,B,256], classprob [B,ncls]] (or the signature alone)."""
         xs, uses = self._split_x(X)
-        sig, _, probs = self.core.predict(xs, uses)
+        with self.core.arithmetic(_infer_precision()):
+            sig, _, probs = self.core.predict(xs, uses)
         sig = sig.cpu().numpy()
         return [sig, probs.cpu().numpy()] if self.nclasses else sig
 
     def predict_layer(self, name, X):
         xs, uses = self._split_x(X)
-        sig, flat, probs = self.core.predict(xs, uses)
+        with self.core.arithmetic(_infer_precision()):
+            sig, flat, probs = self.core.predict(xs, uses)
         if name == "flatten":
             return flat.cpu().numpy()
         if name in ("signature", "mat_mul", self.sig_name):
@@ -454,6 +456,12 @@ def _call(callbacks, method, *args):
         fn = getattr(cb, method, None)
         if fn is not None:
             fn(*args)
+
+
+def _infer_precision():
+    """engine.INFER_PRECISION ('f32': inference in IEEE fp32 whatever the training arithmetic; 'same': the model's own)"""
+    from . import engine
+    return None if engine.INFER_PRECISION == "same" else engine.INFER_PRECISION
 
 
 class SubModel:

@@ -238,7 +238,9 @@ class UWYHSemiNet:
         saved = core.fuse_mode
         core.fuse_mode = "max"
         try:
-            sig = core.forward(xs, uses)
+            from ..keras_compat import _infer_precision
+            with core.arithmetic(_infer_precision()):       # (IEEE fp32 unless UGN_INFER_PRECISION=same: engine.GaitCore.arithmetic)
+                sig = core.forward(xs, uses)
             return sig.cpu().numpy()
         finally:
             core.fuse_mode = saved
