@@ -380,7 +380,7 @@ def format_census(res):
 
 
 def check_gradients(core, ref_grads, xs, uses, labels, onehot, p64, tight, mode='sign_max', margin=0.2, loss_weights=(1.0, 0.1),
-                    multimodal=True, near_tie=8, forced_bar=5e-5, label=""):
+                    multimodal=True, near_tie=8, forced_bar=5e-5, label="", loose=None):
     """The gradient bar of the end-to-end tests, stated through the census.  Every parameter tensor within
     `tight` (relative L2) of the oracle's gradient, OR -- when a tensor is beyond it -- (1) every MaxPool / set-max / HPP / LeakyReLU
     decision in which the HIP path differs from the fp64 oracle is a near-tie (`near_tie` fp32 ulp of the tensor's scale), and (2) the
@@ -388,6 +388,9 @@ def check_gradients(core, ref_grads, xs, uses, labels, onehot, p64, tight, mode=
     got = core.get_grads_numpy()
     worst = grad_errors(got, ref_grads)
     if max(worst.values()) <= tight:
+        return max(worst.values()), None
+    if loose is not None:         # (a sibling case of the same encoders carries the census: only the flat bar here)
+        assert max(worst.values()) <= loose, (label, worst)
         return max(worst.values()), None
     nmod = len(core.encoders)
     bsz, L = xs[0].shape[0], xs[0].shape[1]

@@ -1117,19 +1117,29 @@ __global__ __launch_bounds__(512, 2) void conv_mm16_kernel(const MmJobs jt, cons
 // the next tile is fetched behind a second barrier, while the epilogue stores are issued -- the other workgroup of the CU multiplies
 // meanwhile.  (iii) The whole filter of a job (36 KB, 16x16x32 tile order) stays in LDS.
 #ifndef UGN_MM_D2
-#define UGN_MM_D2 3       /* bit 0: the forward kernel, bit 1: the pooled data gradient */
+#define UGN_MM_D2 3       /* bit 0: the 32 -> 32 forward kernel, bit 1: its pooled data gradient; bit 2 (experiment, measured 2-17 %
+                             SLOWER: profiles/r04_kernel_experiments.txt): the other un-pooled launches with <= 64 columns */
 #endif
 constexpr int D2_SLOTS = 18 * 18 * 8;              // 2592 slots of 16 B
 constexpr int D2_PIECES = (D2_SLOTS + 63) / 64;    // 41 (the last one half used: the filter starts behind it)
 constexpr int D2_W_OFF = 42 * 1024;
-constexpr int D2_WBYTES = 9 * 2 * 2 * 1024;        // [tap][16-column tile][plane][lane-linear 1 KB]
+constexpr int D2_WBYTES = 9 * 2 * 2 * 1024;        // a 32-column chunk filter: [tap][16-column tile][plane][lane-linear 1 KB]
 constexpr int D2_LDS = D2_W_OFF + D2_WBYTES;       // 79,872 B
 static_assert(D2_PIECES * 1024 <= D2_W_OFF && 2 * D2_LDS <= 163840, "two workgroups per CU");
+// filter bytes in LDS: 32 columns -> the chunk's whole filter (9 taps, 36 KB, fetched once per chunk: no barrier inside a chunk);
+// 64 columns -> one tap at a time (8 KB), double-buffered, fetched one tap ahead
+template <int NC>
+constexpr int d2_lds_bytes() { return D2_W_OFF + (NC == 32 ? D2_WBYTES : 2 * (NC / 16) * 2048); }
 
-template <int HW, int EPI>
-__global__ __launch_bounds__(512, 4) void conv32_d2_kernel(const MmJobs jt, const void* __restrict__ zeros) {
-  constexpr int KC = 32, NC = 32, NT = 2;
+// KC / NC: GEMM K and N channels (NC 32 or 64), HW: image size, EPI: EPI_LRELU | EPI_LRELU_POOL | EPI_DGRAD.  16x16x32 tiles as
+// conv_mm16_kernel (same filter packing, same epilogue).
+template <int KC, int NC, int HW, int EPI>
+__global__ __launch_bounds__(512, 4) void conv_d2_kernel(const MmJobs jt, const void* __restrict__ zeros) {
+  constexpr int NT = NC / 16, NG = NC / 32, NCHUNK = KC / 32;
+  constexpr bool FRES = NC == 32;                    // the chunk's filter resident (else tap by tap)
+  constexpr int TAPB = NT * 2048;                    // filter bytes of one tap
   constexpr int RPX = HW / 16, RPI = RPX * RPX;
+  static_assert(NC == 32 || NC == 64, "two workgroups per CU: 128 registers per lane");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const unsigned sbase = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem);
   const int tid = threadIdx.x, lane = tid & 63;
@@ -1161,28 +1171,31 @@ __global__ __launch_bounds__(512, 4) void conv32_d2_kernel(const MmJobs jt, cons
     const int sg = (wave + 8 * j) * 64 + lane;
     const int row = sg / 144, rem = sg - row * 144, px = rem >> 3, js = rem & 7;
     const int g = (((px >> 1) & 3) << 1) | (row & 1);
-    const int off = ((row - 1) * HW + (px - 1)) * (KC * 4) + ((js ^ g) << 4);          // |off| < 2^19
+    const int jj = js ^ g;                       // the record quarter this slot holds: 0..3 H plane, 4..7 L plane of the chunk
+    const int off = ((row - 1) * HW + (px - 1)) * (KC * 4) + (jj < 4 ? jj * 16 : KC * 2 + (jj - 4) * 16);      // |off| < 2^19
     hpk[j] = sg < D2_SLOTS ? (int)(((unsigned)off << 12) | (unsigned)(row << 5) | (unsigned)px) : (127 << 5);
   }
-  auto issue_tile = [&](const MmJob& J, int lit_) {
+  auto issue_tile = [&](const MmJob& J, int lit_, int chunk) {
     const int img = lit_ / RPI, rrem = lit_ % RPI;
     const int ry0 = (rrem / RPX) * 16, rx0 = (rrem % RPX) * 16;
-    const char* base = reinterpret_cast<const char*>(J.in) + ((size_t)img * HW * HW + (size_t)(ry0 * HW + rx0)) * (KC * 4);
+    const char* base = reinterpret_cast<const char*>(J.in) + ((size_t)img * HW * HW + (size_t)(ry0 * HW + rx0)) * (KC * 4) + chunk * 64;
 #pragma unroll
     for (int j = 0; j < NJ; ++j)
       if (wave + 8 * j < D2_PIECES) dma_halo_lane<HW>(base, zeros, ry0, rx0, hpk[j], sbase + (unsigned)(wave + 8 * j) * 1024u);
   };
-  auto issue_filter = [&](const uint16_t* wpk) {
+  // filter bytes [first, first + count) KB of a chunk's (tap-major) packed filter -> LDS at dst
+  auto issue_w = [&](const uint16_t* wpk, int chunk, int tap0, int kb, unsigned dst) {
+    const char* src = reinterpret_cast<const char*>(wpk) + ((size_t)chunk * 9 + tap0) * TAPB;
 #pragma unroll
     for (int j = 0; j < 5; ++j) {
       const int p = wave + 8 * j;
-      if (p < D2_WBYTES / 1024) dma16(reinterpret_cast<const char*>(wpk) + p * 1024 + lane * 16, sbase + D2_W_OFF + (unsigned)p * 1024u);
+      if (p < kb) dma16(src + p * 1024 + lane * 16, dst + (unsigned)p * 1024u);
     }
   };
-  issue_tile(jt.job[jb], lit);
-  issue_filter(jt.job[jb].wpk);
-  int res_job = jb;
+  issue_tile(jt.job[jb], lit, 0);
+  issue_w(jt.job[jb].wpk, 0, 0, FRES ? 36 : TAPB / 1024, sbase + D2_W_OFF);
   bool first_item = true;
+  int wbuf = 0;
   int meta_jb = -1, e_out = 0;
   float factor = 1.f, mx = 0.f;
 
@@ -1200,59 +1213,84 @@ __global__ __launch_bounds__(512, 4) void conv32_d2_kernel(const MmJobs jt, cons
       factor = ldexpf(1.f, e_out - e_in - Jm.wmeta->e);
       meta_jb = jb;
     }
-    bool w_fresh = false;
-    if (jb != res_job) {              // (at most five times per workgroup) the taps of the previous job are done: barrier B below
-      issue_filter(jt.job[jb].wpk);
-      res_job = jb;
-      w_fresh = true;
-    }
-    // the tile was issued BEFORE the previous item's epilogue stores: a counted wait covers it and none of them (conv_mm_kernel, RES)
-    constexpr int EPI_STORES = EPI == EPI_LRELU_POOL ? 6 : 16;
-    if (first_item || w_fresh) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else if constexpr (EPI_STORES == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-    __syncthreads();                  // A: tile (and filter) visible
-    first_item = false;
-
     f32x4 acc[2][NT];
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
       for (int ct = 0; ct < NT; ++ct) acc[rt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-      const int dy = tap / 3, dx = tap % 3;
-      const int aoff = (dy * 18 + dx) * 128;
-      const int ab = abase[dx][dy & 1];
-      uint4 ah[2], al[2], bh[NT], bl[NT];
-#pragma unroll
-      for (int rt = 0; rt < 2; ++rt) {
-        ah[rt] = *reinterpret_cast<const uint4*>(smem + ab + aoff + rt * 1024);
-        al[rt] = *reinterpret_cast<const uint4*>(smem + (ab ^ 64) + aoff + rt * 1024);
-      }
-#pragma unroll
-      for (int ct = 0; ct < NT; ++ct) {
-        bh[ct] = *reinterpret_cast<const uint4*>(smem + b_lane + ((tap * NT + ct) * 2 + 0) * 1024);
-        bl[ct] = *reinterpret_cast<const uint4*>(smem + b_lane + ((tap * NT + ct) * 2 + 1) * 1024);
-      }
-#pragma unroll
-      for (int ct = 0; ct < NT; ++ct)
-#pragma unroll
-        for (int rt = 0; rt < 2; ++rt) acc[rt][ct] = mfma16_h(ah[rt], bh[ct], acc[rt][ct]);
-#pragma unroll
-      for (int ct = 0; ct < NT; ++ct)
-#pragma unroll
-        for (int rt = 0; rt < 2; ++rt) acc[rt][ct] = mfma16_h(ah[rt], bl[ct], acc[rt][ct]);
-#pragma unroll
-      for (int ct = 0; ct < NT; ++ct)
-#pragma unroll
-        for (int rt = 0; rt < 2; ++rt) acc[rt][ct] = mfma16_h(al[rt], bh[ct], acc[rt][ct]);
-    }
-    __syncthreads();                  // B: every wave has read its last fragment: the halo buffer (and, on a job change, the filter) is free
-    if (more) issue_tile(jt.job[jn], nlit);
+    constexpr int EPI_STORES = EPI == EPI_LRELU_POOL ? NG * 6 : NG * 16;       // per wave and item
 
-    // ---- epilogue (conv_mm16_kernel's, one channel group): acc[rt][ct][i] of lane (col, rg): window 4 rt + rg of the wave's 8,
-    // position i; tiles 0, 1 = channels 2 col, 2 col + 1
+#pragma unroll 1
+    for (int chunk = 0; chunk < NCHUNK; ++chunk) {
+      const bool last_chunk = chunk + 1 == NCHUNK;
+      const bool next_tile = !last_chunk || more;
+      const int n_chunk = last_chunk ? 0 : chunk + 1;
+      const int nx_job = last_chunk ? jn : jb, n_lit = last_chunk ? nlit : lit;
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        if (tap == 0 || !FRES) {
+          // what this stage reads has landed: the tile and the (first) filter stage were issued behind barrier B of the previous
+          // chunk -- for the first chunk of an item BEFORE the previous item's epilogue stores, so a counted wait covers them and
+          // none of the stores; a later tap's filter one tap ago
+          if (tap == 0 && chunk == 0 && !first_item) {
+            static_assert(EPI_STORES == 6 || EPI_STORES == 12 || EPI_STORES == 16 || EPI_STORES == 32, "vmcnt immediate");
+            if constexpr (EPI_STORES == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else if constexpr (EPI_STORES == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            else if constexpr (EPI_STORES == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+          } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          }
+          __syncthreads();            // A: visible; (tap by tap:) the other filter buffer has no readers left
+          if constexpr (!FRES) {
+            if (tap + 1 < 9) issue_w(jt.job[jb].wpk, chunk, tap + 1, TAPB / 1024, sbase + D2_W_OFF + (unsigned)(wbuf ^ 1) * TAPB);
+          }
+        }
+        const int dy = tap / 3, dx = tap % 3;
+        const int aoff = (dy * 18 + dx) * 128;
+        const int ab = abase[dx][dy & 1];
+        const int b_addr = b_lane + (FRES ? tap * TAPB : wbuf * TAPB);
+        uint4 ah[2], al[2];
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+          ah[rt] = *reinterpret_cast<const uint4*>(smem + ab + aoff + rt * 1024);
+          al[rt] = *reinterpret_cast<const uint4*>(smem + (ab ^ 64) + aoff + rt * 1024);
+        }
+#pragma unroll
+        for (int cp = 0; cp < NT; cp += 2) {        // two column tiles at a time: 16 fragment registers
+          uint4 bh[2], bl[2];
+#pragma unroll
+          for (int c2 = 0; c2 < 2; ++c2) {
+            bh[c2] = *reinterpret_cast<const uint4*>(smem + b_addr + ((cp + c2) * 2 + 0) * 1024);
+            bl[c2] = *reinterpret_cast<const uint4*>(smem + b_addr + ((cp + c2) * 2 + 1) * 1024);
+          }
+#pragma unroll
+          for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) acc[rt][cp + c2] = mfma16_h(ah[rt], bh[c2], acc[rt][cp + c2]);
+#pragma unroll
+          for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) acc[rt][cp + c2] = mfma16_h(ah[rt], bl[c2], acc[rt][cp + c2]);
+#pragma unroll
+          for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) acc[rt][cp + c2] = mfma16_h(al[rt], bh[c2], acc[rt][cp + c2]);
+        }
+        if constexpr (!FRES) wbuf ^= 1;
+      }
+      __syncthreads();                // B: every wave has read its last fragment of the chunk: tile and filter buffers are free
+      if (next_tile) {
+        issue_tile(jt.job[nx_job], n_lit, n_chunk);
+        // (one chunk of 32 columns: the filter in LDS is the whole filter of the job and stays until the job changes)
+        if (!(FRES && NCHUNK == 1 && nx_job == jb))
+          issue_w(jt.job[nx_job].wpk, n_chunk, 0, FRES ? 36 : TAPB / 1024, sbase + D2_W_OFF + (FRES ? 0u : (unsigned)wbuf * TAPB));
+      }
+    }
+    first_item = false;
+
+    // ---- epilogue (conv_mm16_kernel's): acc[rt][ct][i] of lane (col, rg): window 4 rt + rg of the wave's 8, position i; tiles 2m,
+    // 2m + 1 = channels 32 m + 2 col, 32 m + 2 col + 1
     const int img = lit / RPI, rrem = lit % RPI;
     const int ry0 = (rrem / RPX) * 16, rx0 = (rrem % RPX) * 16;
     const MmJob& J = jt.job[jb];
@@ -1260,48 +1298,51 @@ __global__ __launch_bounds__(512, 4) void conv32_d2_kernel(const MmJobs jt, cons
     constexpr bool POOL = EPI == EPI_LRELU_POOL;
     constexpr int HO = POOL ? HW / 2 : HW;
     char* out = reinterpret_cast<char*>(J.out) + (size_t)img * HO * HO * NC * 4;
-    const unsigned chb = (unsigned)(2 * col) * 2u;
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt) {
-      const int wx = 4 * rt + rg;
-      if constexpr (POOL) {
-        float best[2];
-        unsigned bi[2];
+    for (int m = 0; m < NG; ++m) {
+      const unsigned chb = (unsigned)(32 * m + 2 * col) * 2u;
 #pragma unroll
-        for (int e = 0; e < 2; ++e) {
-          best[e] = acc[rt][e][0];
-          bi[e] = 0;
+      for (int rt = 0; rt < 2; ++rt) {
+        const int wx = 4 * rt + rg;
+        if constexpr (POOL) {
+          float best[2];
+          unsigned bi[2];
 #pragma unroll
-          for (int i = 1; i < 4; ++i) {
-            const float v = acc[rt][e][i];
-            if (v > best[e]) { best[e] = v; bi[e] = i; }     // strict >: the FIRST maximum wins (TF MaxPoolGrad)
+          for (int e = 0; e < 2; ++e) {
+            best[e] = acc[rt][2 * m + e][0];
+            bi[e] = 0;
+#pragma unroll
+            for (int i = 1; i < 4; ++i) {
+              const float v = acc[rt][2 * m + e][i];
+              if (v > best[e]) { best[e] = v; bi[e] = i; }     // strict >: the FIRST maximum wins (TF MaxPoolGrad)
+            }
+            best[e] = ugn_lrelu(best[e] * factor);
+            mx = fmaxf(mx, fabsf(best[e]));
           }
-          best[e] = ugn_lrelu(best[e] * factor);
-          mx = fmaxf(mx, fabsf(best[e]));
-        }
-        const unsigned pix = (unsigned)((ry0 / 2 + wave) * HO + rx0 / 2 + wx);
-        _Float16 h0, l0, h1, l1;
-        h2_split(best[0], h0, l0);
-        h2_split(best[1], h1, l1);
-        UGN_ST(unsigned, out + pix * (unsigned)(NC * 4) + chb, h2_pack(h0, h1));
-        UGN_ST(unsigned, out + pix * (unsigned)(NC * 4) + (unsigned)(NC * 2) + chb, h2_pack(l0, l1));
-        uint8_t* oi = J.out_idx + (size_t)img * HO * HO * NC;
-        UGN_ST(uint16_t, oi + pix * (unsigned)NC + (unsigned)(2 * col), bi[0] | (bi[1] << 8));
-      } else {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const unsigned pix = (unsigned)((ry0 + 2 * wave + (i >> 1)) * HW + rx0 + 2 * wx + (i & 1));
-          float v0 = acc[rt][0][i] * factor, v1 = acc[rt][1][i] * factor;
-          if constexpr (EPI == EPI_LRELU) {
-            v0 = ugn_lrelu(v0);
-            v1 = ugn_lrelu(v1);
-          }
-          mx = fmaxf(mx, fmaxf(fabsf(v0), fabsf(v1)));
+          const unsigned pix = (unsigned)((ry0 / 2 + wave) * HO + rx0 / 2 + wx);
           _Float16 h0, l0, h1, l1;
-          h2_split(v0, h0, l0);
-          h2_split(v1, h1, l1);
+          h2_split(best[0], h0, l0);
+          h2_split(best[1], h1, l1);
           UGN_ST(unsigned, out + pix * (unsigned)(NC * 4) + chb, h2_pack(h0, h1));
           UGN_ST(unsigned, out + pix * (unsigned)(NC * 4) + (unsigned)(NC * 2) + chb, h2_pack(l0, l1));
+          uint8_t* oi = J.out_idx + (size_t)img * HO * HO * NC;
+          UGN_ST(uint16_t, oi + pix * (unsigned)NC + (unsigned)(32 * m + 2 * col), bi[0] | (bi[1] << 8));
+        } else {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const unsigned pix = (unsigned)((ry0 + 2 * wave + (i >> 1)) * HW + rx0 + 2 * wx + (i & 1));
+            float v0 = acc[rt][2 * m][i] * factor, v1 = acc[rt][2 * m + 1][i] * factor;
+            if constexpr (EPI == EPI_LRELU) {
+              v0 = ugn_lrelu(v0);
+              v1 = ugn_lrelu(v1);
+            }
+            mx = fmaxf(mx, fmaxf(fabsf(v0), fabsf(v1)));
+            _Float16 h0, l0, h1, l1;
+            h2_split(v0, h0, l0);
+            h2_split(v1, h1, l1);
+            UGN_ST(unsigned, out + pix * (unsigned)(NC * 4) + chb, h2_pack(h0, h1));
+            UGN_ST(unsigned, out + pix * (unsigned)(NC * 4) + (unsigned)(NC * 2) + chb, h2_pack(l0, l1));
+          }
         }
       }
     }
@@ -1311,7 +1352,6 @@ __global__ __launch_bounds__(512, 4) void conv32_d2_kernel(const MmJobs jt, cons
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   h2_publish_amax_block(jt.job[meta_jb].out_meta, mx, reinterpret_cast<float*>(smem), tid, 8);
 }
-
 
 // The same for the POOLED data gradient of the layer (a2: dL/dp2 + argmax bytes -> dL/da1, the largest tensor of the backward pass).
 // 32x32x16 shape (the data-gradient filters of this layer are packed for it; the fused first-layer kernel below reads them too),
@@ -1799,23 +1839,24 @@ int launch_mm16(const MmJob* jobs, const int* n, int njobs, hipStream_t st) {
   return 0;
 }
 
-template <int HW, int EPI>
+template <int KC, int NC, int HW, int EPI>
 int launch_d2(const MmJob* jobs, const int* n, int njobs, hipStream_t st) {
-  auto kern = conv32_d2_kernel<HW, EPI>;
+  auto kern = conv_d2_kernel<KC, NC, HW, EPI>;
+  constexpr int LDS = d2_lds_bytes<NC>();
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, D2_LDS);
-    if (e != hipSuccess) { ugn_set_error("conv32_d2: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    if (e != hipSuccess) { ugn_set_error("conv_d2: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
     attr_done = true;
   }
   const void* zeros = zero_block();
-  if (!zeros) { ugn_set_error("conv32_d2: cannot allocate the zero block"); return UGN_EINVAL; }
+  if (!zeros) { ugn_set_error("conv_d2: cannot allocate the zero block"); return UGN_EINVAL; }
   MmJobs jt;
   const int nitems = make_mm_table(jt, jobs, n, njobs, (HW / 16) * (HW / 16));
   const int wgs = 2 * g_persistent_wgs;        // two workgroups per CU
   const int grid = nitems < wgs ? nitems : wgs;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), D2_LDS, st, jt, zeros);
-  UGN_CHECK_LAUNCH("conv32_d2");
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), LDS, st, jt, zeros);
+  UGN_CHECK_LAUNCH("conv_d2");
   return 0;
 }
 
@@ -1839,7 +1880,11 @@ int launch_d2p(const MmJob* jobs, const int* n, int njobs, hipStream_t st) {
 
 int dispatch_fwd(const MmJob* jobs, const int* n, int njobs, int hw, int cin, int cout, int pool, hipStream_t st) {
   if constexpr ((UGN_MM_D2 & 1) != 0) {
-    if (cin == 32 && cout == 32 && hw == 64 && pool) return launch_d2<64, EPI_LRELU_POOL>(jobs, n, njobs, st);
+    if (cin == 32 && cout == 32 && hw == 64 && pool) return launch_d2<32, 32, 64, EPI_LRELU_POOL>(jobs, n, njobs, st);
+  }
+  if constexpr ((UGN_MM_D2 & 4) != 0) {
+    if (cin == 32 && cout == 64 && hw == 32 && !pool) return launch_d2<32, 64, 32, EPI_LRELU>(jobs, n, njobs, st);
+    if (cin == 64 && cout == 64 && hw == 32 && pool) return launch_d2<64, 64, 32, EPI_LRELU_POOL>(jobs, n, njobs, st);
   }
 
 #define MF(KC_, NC_, HW_, P_)                                                \
@@ -1859,6 +1904,10 @@ int dispatch_fwd(const MmJob* jobs, const int* n, int njobs, int hw, int cin, in
 int dispatch_dgrad(const MmJob* jobs, const int* n, int njobs, int hw, int cin, int cout, int unpool, bool act, hipStream_t st) {
   if constexpr ((UGN_MM_D2 & 2) != 0) {
     if (cin == 32 && cout == 32 && hw == 64 && unpool && !act) return launch_d2p<64>(jobs, n, njobs, st);
+  }
+  if constexpr ((UGN_MM_D2 & 4) != 0) {        // (GEMM K = cout, N = cin)
+    if (cin == 32 && cout == 64 && hw == 32 && !unpool && !act) return launch_d2<64, 32, 32, EPI_DGRAD>(jobs, n, njobs, st);
+    if (cin == 64 && cout == 128 && hw == 16 && !unpool && !act) return launch_d2<128, 64, 16, EPI_DGRAD>(jobs, n, njobs, st);
   }
 #define MD(CI_, CO_, HW_, U_)                                                                     \
   if (cin == CI_ && cout == CO_ && hw == HW_ && unpool == U_) {                                   \

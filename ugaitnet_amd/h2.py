@@ -153,9 +153,13 @@ def _mm_bytes(kind, hw, cin, cout, pooled, n, act=False):
 def _mm_work(kind, hw, cin, cout, pooled, ns, act=False):
     n = int(sum(ns))
     flops = 2.0 * 9 * cin * cout * hw * hw * n
+    # (the names rocprofv3 reports, csrc/conv3x3_mm.hip: the 32 -> 32 @64x64 layer runs the two-workgroups-per-CU kernels, the other
+    #  un-pooled inputs the 16x16x32 kernel, the pooled 64 -> 64 data gradient the 32x32x16 one)
+    a2 = cin == 32 and cout == 32 and hw == 64 and pooled
     if kind == "fwd":
-        # (the name rocprofv3 reports: un-pooled inputs run on the 16x16x32 kernel, csrc/conv3x3_mm.hip mm_tile16)
-        kern = "conv_mm16_kernel<%d, %d, %d, %d>" % (cin, cout, hw, 1 if pooled else 0)
+        kern = "conv_d2_kernel<32, 32, 64, 1>" if a2 else "conv_mm16_kernel<%d, %d, %d, %d>" % (cin, cout, hw, 1 if pooled else 0)
+    elif a2 and not act:
+        kern = "conv32_d2p_kernel<64>"
     else:
         kern = ("conv_mm_kernel<%d, %d, %d, %d, %d>" % (cout, cin, hw, int(pooled), 3 if act else 2) if pooled else
                 "conv_mm16_kernel<%d, %d, %d, %d>" % (cout, cin, hw, 3 if act else 2))
