@@ -258,8 +258,10 @@ def roofline_pass(core, batch, steps, dtype, table_path=""):
         if not os.path.exists(tfile):
             continue
         t = json.load(open(tfile))
-        if t.get("rocprof_kernel") == top.get("rocprof_kernel") and t.get("images_per_launch") == top.get("images_per_launch"):
-            roof["traffic"] = t.get("hbm_bytes_per_launch")
+        hit = [r for r in t.get("kernels", [t]) if r.get("rocprof_kernel") == top.get("rocprof_kernel") and
+               r.get("images_per_launch") == top.get("images_per_launch")]
+        if hit:
+            roof["traffic"] = hit[0].get("hbm_bytes_per_launch")
             roof["traffic_source"] = "profiles/" + tname + " (rocprofv3 --pmc passes of this kernel at this launch size; not this run)"
             break
     roof["serial_step_us"] = round(total / steps, 1)
