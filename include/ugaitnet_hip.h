@@ -334,6 +334,11 @@ int ugn_conv5x5_in_fwd_h2(const float* x, const void* x_meta, const float* w, ui
 /* its weight gradient with dz1 given as H2 [n][64][64][2][32] */
 int ugn_conv5x5_in_wgrad_h2(const float* x, const uint16_t* dz1, const void* dz1_meta, const uint32_t* a1_sign, float* dw, int n,
                             int cin, void* ws, size_t ws_bytes, void* stream);
+/* the same weight gradient multiplied on the f16 matrix pipe (the default path since round 4): the input patch is split into f16
+ * halves of x * 2^ex (x_meta = {0, bits(max|x|)} as for ugn_conv5x5_in_fwd_h2), the gradient's halves are used as stored, and
+ * LeakyReLU'(a1) = 0.3 + 0.7 [a1 > 0] is applied as 0.3 * sum + 0.7 * (sum over the pixels whose a1_sign bit is set) */
+int ugn_conv5x5_in_wgrad_h2x(const float* x, const void* x_meta, const uint16_t* dz1, const void* dz1_meta, const uint32_t* a1_sign,
+                             float* dw, int n, int cin, void* ws, size_t ws_bytes, void* stream);
 /* meta[j] <- {0, bits(max|x[j]|)} for up to 6 fp32 tensors (metas zero on entry) */
 int ugn_absmax_multi(const float* const* x, const size_t* n, void* const* meta, int njobs, void* stream);
 /* fp32 [npix][c] -> H2 for up to 6 tensors; amax_meta[j] from ugn_absmax_multi, meta[j] (another record) is filled */

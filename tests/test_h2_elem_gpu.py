@@ -60,6 +60,18 @@ def test_conv5x5_h2(dev, cin, xscale):
     dw = torch.empty((5, 5, cin, 32), device=dev)
     h2.conv5x5_in_wgrad_h2(xd, dzt, dw, sign=sign)
     close(dw, dw_ref, 5e-6, "conv5x5 wgrad h2")
+    # the same on the f16 matrix pipe (round 4; what the engine runs): x split into f16 halves with the exponent of max|x|, LeakyReLU' as
+    # 0.3 * sum + 0.7 * (sum over the pixels with a1 > 0); and without the sign bits (plain product)
+    dw2 = torch.empty((5, 5, cin, 32), device=dev)
+    h2.conv5x5_in_wgrad_h2(xd, dzt, dw2, sign=sign, x_meta=xm)
+    close(dw2, dw_ref, 5e-6, "conv5x5 wgrad h2 on the f16 pipe")
+    again = torch.empty_like(dw2)
+    h2.conv5x5_in_wgrad_h2(xd, dzt, again, sign=sign, x_meta=xm)
+    assert torch.equal(dw2, again)
+    dw_plain_ref, _ = O.conv2d_same_bwd(xf.astype(np.float64), w.astype(np.float64), dzt.numpy(), need_dx=False)
+    dw3 = torch.empty((5, 5, cin, 32), device=dev)
+    h2.conv5x5_in_wgrad_h2(xd, dzt, dw3, sign=None, x_meta=xm)
+    close(dw3, dw_plain_ref, 5e-6, "conv5x5 wgrad h2 on the f16 pipe, no LeakyReLU'")
 
 
 def _frames(rng, b, l, hw, c, scale, ties=True):

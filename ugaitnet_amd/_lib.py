@@ -92,6 +92,7 @@ PROTOTYPES = {
     "ugn_mm_dgrad32_wgrad5_multi": (_i, [C.POINTER(_p)] * 10 + [C.POINTER(_i), C.POINTER(_i), _i, _p, _sz, _p]),
     "ugn_conv5x5_in_fwd_h2": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _p]),
     "ugn_conv5x5_in_wgrad_h2": (_i, [_p, _p, _p, _p, _p, _i, _i, _p, _sz, _p]),
+    "ugn_conv5x5_in_wgrad_h2x": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _p, _sz, _p]),
     "ugn_absmax_multi": (_i, [C.POINTER(_p), C.POINTER(_sz), C.POINTER(_p), _i, _p]),
     "ugn_h2_encode_multi": (_i, [C.POINTER(_p)] * 4 + [C.POINTER(_sz), _i, _i, _p]),
     "ugn_h2_setmax_fwd_multi": (_i, [C.POINTER(_p)] * 8 + [C.POINTER(_i), _i, _i, _i, _i, _p]),

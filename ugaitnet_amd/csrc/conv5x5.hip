@@ -319,18 +319,24 @@ __device__ __forceinline__ void dma4_c5(const void* gsrc, unsigned lds_dst_unifo
 // or in the pad read a zero block) while the current tile is multiplied: the kernel runs at the rate dz1 can be read.
 // H2DZ: dz1 is an H2 tensor ([pixel][2][32] halves: the same 128 bytes per pixel, so the LDS-DMA staging is unchanged); a
 // gradient value is re-assembled from its two halves when it is read, the block exponent is undone by reduce5_kernel.
-// DZFMT: 0 fp32 dz1, 1 H2, 2 bf16 ([pixel][32] bf16: 64-byte records, half the gradient tile)
+// DZFMT: 0 fp32 dz1, 1 H2, 2 bf16 ([pixel][32] bf16: 64-byte records, half the gradient tile), 3 H2 multiplied on the f16 matrix pipe
+// (round 4): K = 16 pixels per v_mfma_f32_32x32x16_f16 step; the gradient fragments -- 8 consecutive pixels of one channel per lane,
+// H and L halves -- by transposed reads of the [pixel][2][32] tile; the patch as packed halves of x * 2^ex (converted in place once
+// per tile); LeakyReLU'(a1) WITHOUT re-splitting a scaled gradient: slope = 0.3 + 0.7 [a1 > 0], so the kernel keeps two sums,
+// acc_all += x * g and acc_pos += x * (g AND mask) -- masking the halves is exact -- and leaves 0.3 acc_all + 0.7 acc_pos.
+// 6 f16 MFMAs of 32 cycles per 16 pixels and row block instead of 8 fp32 MFMAs of 64 that block the vector pipe.
 template <int CIN, bool SIGN, int DZFMT = 0>
 __global__ __launch_bounds__(256) void conv5x5_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dz1,
                                                             float* __restrict__ slab, const float* __restrict__ zeros,
-                                                            const uint32_t* __restrict__ a1_sign, int tiles_total) {
+                                                            const uint32_t* __restrict__ a1_sign, int tiles_total,
+                                                            const H2Meta* __restrict__ x_meta = nullptr) {
   constexpr int K = 25 * CIN, MBK = (K + 31) / 32;
   constexpr int DS = UGN_C5_DS;
   constexpr int SDF = T5 * T5 * DS;                       // floats per gradient buffer (32 KB = 32 pieces of 1 KB)
   // patch rows of WP pixels (UGN_C5_PITCH)
   constexpr int WP = c5_pitch(CIN);
   constexpr int PE = P5 * WP * CIN, PPIECES = (PE + 63) / 64, SPF = PPIECES * 64;   // patch dwords, 256-B pieces
-  constexpr bool H2DZ = DZFMT == 1, BFDZ = DZFMT == 2;
+  constexpr bool H2X = DZFMT == 3, H2DZ = DZFMT == 1 || H2X, BFDZ = DZFMT == 2;
   constexpr int DPW = BFDZ ? 4 : DS / 4, PPW = (PPIECES + 3) / 4;    // pieces per wave
   extern __shared__ __attribute__((aligned(16))) float smem5[];
   float* sD0 = smem5;                 // [2][SDF]
@@ -345,6 +351,15 @@ __global__ __launch_bounds__(256) void conv5x5_wgrad_kernel(const float* __restr
   const int li = lane & 31, lh = lane >> 5;
 
   f32x16 acc[MBK];
+  f32x16 accp[H2X && SIGN ? MBK : 1];      // H2X: the sum over the pixels with a1 > 0
+  float x_scale = 1.f;
+  if constexpr (H2X) {
+    x_scale = ldexpf(1.f, ugn_mm::h2_exp_for_bound(ugn_mm::h2_true_amax(x_meta->e, x_meta->amax)));
+#pragma unroll
+    for (int mb = 0; mb < (SIGN ? MBK : 1); ++mb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) accp[mb][r] = 0.f;
+  }
   int abase[MBK];
 #pragma unroll
   for (int mb = 0; mb < MBK; ++mb) {
@@ -407,7 +422,62 @@ __global__ __launch_bounds__(256) void conv5x5_wgrad_kernel(const float* __restr
     issue_dma(nt < tiles_total ? nt : tile, buf ^ 1);   // branch-free: past the end the current tile is fetched again
     const float* sD = sD0 + buf * SDF;
     const float* sP = sP0 + buf * SPF;
-    if constexpr (BFDZ) {
+    if constexpr (H2X) {
+      // the patch of this tile -> packed halves (H | L << 16) of x * 2^ex, in place: once per value, not once per gather
+      unsigned* sPu = reinterpret_cast<unsigned*>(sP0 + buf * SPF);
+      for (int e = tid; e < PE; e += 256) {
+        _Float16 hi, lo;
+        ugn_mm::h2_split(sP[e] * x_scale, hi, lo);
+        sPu[e] = ugn_mm::h2_pack(hi, lo);
+      }
+      __syncthreads();
+      typedef short s4v __attribute__((ext_vector_type(4)));
+      const int gh = (lane >> 4) & 1, tq = (lane >> 2) & 3, tp = lane & 3;
+      const __attribute__((address_space(3))) char* dzl = (const __attribute__((address_space(3))) char*)sD +
+                                                          (wave * 64 + 8 * lh + tq) * 128 + (16 * gh + 4 * tp) * 2;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {      // tile row 4 wave + ks: 16 pixels
+        const s4v h0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4v*)(dzl + ks * 2048));
+        const s4v h1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4v*)(dzl + ks * 2048 + 512));
+        const s4v l0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4v*)(dzl + ks * 2048 + 64));
+        const s4v l1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4v*)(dzl + ks * 2048 + 512 + 64));
+        const uint2 hv0 = __builtin_bit_cast(uint2, h0), hv1 = __builtin_bit_cast(uint2, h1);
+        const uint2 lv0 = __builtin_bit_cast(uint2, l0), lv1 = __builtin_bit_cast(uint2, l1);
+        const uint4 gh4 = make_uint4(hv0.x, hv0.y, hv1.x, hv1.y), gl4 = make_uint4(lv0.x, lv0.y, lv1.x, lv1.y);
+        uint4 mh4 = gh4, ml4 = gl4;
+        if constexpr (SIGN) {                 // halves of the pixels with a1[pixel][li] > 0, zero elsewhere
+          unsigned m[4];
+#pragma unroll
+          for (int d = 0; d < 4; ++d) {
+            const uint32_t w0 = sS0[buf * 256 + wave * 64 + ks * 16 + 8 * lh + 2 * d], w1 = sS0[buf * 256 + wave * 64 + ks * 16 + 8 * lh + 2 * d + 1];
+            m[d] = (((w0 >> li) & 1u) ? 0x0000ffffu : 0u) | (((w1 >> li) & 1u) ? 0xffff0000u : 0u);
+          }
+          mh4 = make_uint4(gh4.x & m[0], gh4.y & m[1], gh4.z & m[2], gh4.w & m[3]);
+          ml4 = make_uint4(gl4.x & m[0], gl4.y & m[1], gl4.z & m[2], gl4.w & m[3]);
+        }
+        const ugn_mm::h8 bh = __builtin_bit_cast(ugn_mm::h8, gh4), bl = __builtin_bit_cast(ugn_mm::h8, gl4);
+        const ugn_mm::h8 ph = __builtin_bit_cast(ugn_mm::h8, mh4), pl = __builtin_bit_cast(ugn_mm::h8, ml4);
+#pragma unroll
+        for (int mb = 0; mb < MBK; ++mb) {
+          unsigned d[8];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) d[i] = sPu[abase[mb] + (ks * WP + 8 * lh + i - lh) * CIN];
+          const uint4 a_h = make_uint4(__builtin_amdgcn_perm(d[1], d[0], 0x05040100u), __builtin_amdgcn_perm(d[3], d[2], 0x05040100u),
+                                       __builtin_amdgcn_perm(d[5], d[4], 0x05040100u), __builtin_amdgcn_perm(d[7], d[6], 0x05040100u));
+          const uint4 a_l = make_uint4(__builtin_amdgcn_perm(d[1], d[0], 0x07060302u), __builtin_amdgcn_perm(d[3], d[2], 0x07060302u),
+                                       __builtin_amdgcn_perm(d[5], d[4], 0x07060302u), __builtin_amdgcn_perm(d[7], d[6], 0x07060302u));
+          const ugn_mm::h8 ah = __builtin_bit_cast(ugn_mm::h8, a_h), al = __builtin_bit_cast(ugn_mm::h8, a_l);
+          acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[mb], 0, 0, 0);
+          acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[mb], 0, 0, 0);
+          acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[mb], 0, 0, 0);
+          if constexpr (SIGN) {
+            accp[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, ph, accp[mb], 0, 0, 0);
+            accp[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, pl, accp[mb], 0, 0, 0);
+            accp[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, ph, accp[mb], 0, 0, 0);
+          }
+        }
+      }
+    } else if constexpr (BFDZ) {
       // bf16 gradient (configs[4]): v_mfma_f32_32x32x16_bf16 with K = 16 pixels (one tile row) per step -- the wave's 64 pixels are
       // 4 MFMAs per row block instead of 32 fp32 ones.  A = the patch values under the lane's (tap, channel) at 8 consecutive
       // pixels, rounded to bf16; B = the gradient of 8 consecutive pixels of channel li: two transposed reads of the [pixel][32]
@@ -461,6 +531,14 @@ __global__ __launch_bounds__(256) void conv5x5_wgrad_kernel(const float* __restr
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if constexpr (H2X) {        // LeakyReLU' = 0.3 + 0.7 [a1 > 0]; the x exponent is undone here, the gradient's by reduce5_kernel
+    const float inv = 1.f / x_scale;
+#pragma unroll
+    for (int mb = 0; mb < MBK; ++mb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        acc[mb][r] = (SIGN ? UGN_LRELU_ALPHA * acc[mb][r] + (1.f - UGN_LRELU_ALPHA) * accp[SIGN ? mb : 0][r] : acc[mb][r]) * inv;
+  }
   // cross-wave reduction through LDS (reuse sD: 4 waves x MBK x 16 x 64 floats <= 8192 floats = one gradient buffer)
   __syncthreads();
 #pragma unroll
@@ -550,7 +628,7 @@ extern "C" size_t ugn_conv5x5_in_wgrad_ws(int n, int cin) {
 }
 
 static int conv5x5_wgrad_any(const float* x, const float* dz1, const H2Meta* dz_meta, const uint32_t* a1_sign, float* dw, int n,
-                             int cin, void* ws, size_t ws_bytes, void* stream, bool bf = false);
+                             int cin, void* ws, size_t ws_bytes, void* stream, bool bf = false, const H2Meta* x_meta = nullptr);
 extern "C" int ugn_conv5x5_in_wgrad(const float* x, const float* dz1, const uint32_t* a1_sign, float* dw, int n, int cin,
                                     void* ws, size_t ws_bytes, void* stream) {
   return conv5x5_wgrad_any(x, dz1, nullptr, a1_sign, dw, n, cin, ws, ws_bytes, stream);
@@ -560,6 +638,13 @@ extern "C" int ugn_conv5x5_in_wgrad_h2(const float* x, const uint16_t* dz1, cons
                                        int n, int cin, void* ws, size_t ws_bytes, void* stream) {
   UGN_REQUIRE(dz1_meta, "ugn_conv5x5_in_wgrad_h2: null meta");
   return conv5x5_wgrad_any(x, reinterpret_cast<const float*>(dz1), (const H2Meta*)dz1_meta, a1_sign, dw, n, cin, ws, ws_bytes, stream);
+}
+/* the same on the f16 matrix pipe: x_meta = {0, bits(max|x|)} (ugn_absmax_multi) gives the exponent the input patch is split with */
+extern "C" int ugn_conv5x5_in_wgrad_h2x(const float* x, const void* x_meta, const uint16_t* dz1, const void* dz1_meta,
+                                        const uint32_t* a1_sign, float* dw, int n, int cin, void* ws, size_t ws_bytes, void* stream) {
+  UGN_REQUIRE(dz1_meta && x_meta, "ugn_conv5x5_in_wgrad_h2x: null meta");
+  return conv5x5_wgrad_any(x, reinterpret_cast<const float*>(dz1), (const H2Meta*)dz1_meta, a1_sign, dw, n, cin, ws, ws_bytes, stream,
+                           false, (const H2Meta*)x_meta);
 }
 /* dz1 as a bf16 tensor [n][64][64][32] (configs[4]) */
 extern "C" int ugn_conv5x5_in_wgrad_bf(const float* x, const uint16_t* dz1, const uint32_t* a1_sign, float* dw, int n, int cin, void* ws,
@@ -585,7 +670,7 @@ extern "C" int ugn_conv5x5_in_fwd_bf(const float* x, const float* w, uint16_t* a
   return 0;
 }
 static int conv5x5_wgrad_any(const float* x, const float* dz1, const H2Meta* dz_meta, const uint32_t* a1_sign, float* dw, int n,
-                             int cin, void* ws, size_t ws_bytes, void* stream, bool bf) {
+                             int cin, void* ws, size_t ws_bytes, void* stream, bool bf, const H2Meta* x_meta) {
   UGN_REQUIRE(x && dz1 && dw && ws && n > 0, "ugn_conv5x5_in_wgrad: null pointer or n <= 0");
   UGN_REQUIRE(cin == 1 || cin == 2, "ugn_conv5x5_in_wgrad: cin must be 1 or 2 (got %d)", cin);
   UGN_REQUIRE(ws_bytes >= ugn_conv5x5_in_wgrad_ws(n, cin), "ugn_conv5x5_in_wgrad: workspace too small");
@@ -604,14 +689,16 @@ static int conv5x5_wgrad_any(const float* x, const float* dz1, const H2Meta* dz_
   const int lds = (2 * 256 * UGN_C5_DS + 2 * ((20 * c5_pitch(cin) * cin + 63) / 64) * 64 + 2 * 256) * 4;
   static bool attr_done[3] = {false, false, false};
   if (!attr_done[cin]) {
-    const void* fns[12] = {(const void*)conv5x5_wgrad_kernel<1, false>, (const void*)conv5x5_wgrad_kernel<1, true>,
+    const void* fns[16] = {(const void*)conv5x5_wgrad_kernel<1, false>, (const void*)conv5x5_wgrad_kernel<1, true>,
                            (const void*)conv5x5_wgrad_kernel<1, false, 1>, (const void*)conv5x5_wgrad_kernel<1, true, 1>,
                            (const void*)conv5x5_wgrad_kernel<1, false, 2>, (const void*)conv5x5_wgrad_kernel<1, true, 2>,
+                           (const void*)conv5x5_wgrad_kernel<1, false, 3>, (const void*)conv5x5_wgrad_kernel<1, true, 3>,
                            (const void*)conv5x5_wgrad_kernel<2, false>, (const void*)conv5x5_wgrad_kernel<2, true>,
                            (const void*)conv5x5_wgrad_kernel<2, false, 1>, (const void*)conv5x5_wgrad_kernel<2, true, 1>,
-                           (const void*)conv5x5_wgrad_kernel<2, false, 2>, (const void*)conv5x5_wgrad_kernel<2, true, 2>};
-    for (int v = 0; v < 6; ++v) {
-      hipError_t e = hipFuncSetAttribute(fns[(cin - 1) * 6 + v], hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+                           (const void*)conv5x5_wgrad_kernel<2, false, 2>, (const void*)conv5x5_wgrad_kernel<2, true, 2>,
+                           (const void*)conv5x5_wgrad_kernel<2, false, 3>, (const void*)conv5x5_wgrad_kernel<2, true, 3>};
+    for (int v = 0; v < 8; ++v) {
+      hipError_t e = hipFuncSetAttribute(fns[(cin - 1) * 8 + v], hipFuncAttributeMaxDynamicSharedMemorySize, lds);
       UGN_REQUIRE(e == hipSuccess, "ugn_conv5x5_in_wgrad: hipFuncSetAttribute: %s", hipGetErrorString(e));
     }
     attr_done[cin] = true;
@@ -621,6 +708,9 @@ static int conv5x5_wgrad_any(const float* x, const float* dz1, const H2Meta* dz_
     if (bf)                                                                                                                   \
       hipLaunchKernelGGL((conv5x5_wgrad_kernel<C_, S_, 2>), dim3(groups), dim3(256), lds, st, x, dz1, (float*)ws,             \
                          (const float*)zeros, a1_sign, tiles);                                                                \
+    else if (dz_meta && x_meta)                                                                                               \
+      hipLaunchKernelGGL((conv5x5_wgrad_kernel<C_, S_, 3>), dim3(groups), dim3(256), lds, st, x, dz1, (float*)ws,             \
+                         (const float*)zeros, a1_sign, tiles, x_meta);                                                        \
     else if (dz_meta)                                                                                                         \
       hipLaunchKernelGGL((conv5x5_wgrad_kernel<C_, S_, 1>), dim3(groups), dim3(256), lds, st, x, dz1, (float*)ws,             \
                          (const float*)zeros, a1_sign, tiles);                                                                \

@@ -199,4 +199,4 @@ def backward_h2(encs, douts, side):
     h2.conv3x3_dgrad_mm_multi(dp2, [s.wd("a2")[0] for s in S], [s.wd("a2")[1] for s in S], 64, 32, 32, dz1, dz_idxs=i2)
     with side(dev):
         for i, e in enumerate(encs):
-            h2.conv5x5_in_wgrad_h2(S[i].x, dz1[i], e.G("a1"), sign=S[i].bufs["a1s"])
+            h2.conv5x5_in_wgrad_h2(S[i].x, dz1[i], e.G("a1"), sign=S[i].bufs["a1s"], x_meta=S[i].slot("x"))

@@ -294,10 +294,21 @@ def dgrad32_wgrad5_multi(dzs, dz_idxs, wpks, wmetas, xs, x_metas, signs, dws, sc
     return dws
 
 
-def conv5x5_in_wgrad_h2(x, dz1, dw, sign=None):
+# UGN_C5_WGRAD_F16=0: the first layer's weight gradient on the fp32 MFMA (rounds 1-3) instead of the f16 matrix pipe
+C5_WGRAD_F16 = __import__("os").environ.get("UGN_C5_WGRAD_F16", "1") != "0"
+
+
+def conv5x5_in_wgrad_h2(x, dz1, dw, sign=None, x_meta=None):
+    """dL/dW of the 5x5 first layer from dz1 = dL/da1 (H2) and the network input x; x_meta = {0, bits(max|x|)} selects the f16-pipe kernel."""
     n, cin = x.shape[0], x.shape[3]
     nbytes = _lib.load().ugn_conv5x5_in_wgrad_ws(n, cin)
     ws = _workspace(nbytes, x.device)
+    if x_meta is not None and C5_WGRAD_F16:
+        call("ugn_conv5x5_in_wgrad_h2x", ptr(x), ptr(x_meta), ptr(dz1.data), ptr(dz1.meta), ptr(sign), ptr(dw), n, cin, ptr(ws), ws.numel(),
+             _stream(), label="conv5x5_wgrad[cin=%d h2]" % cin,
+             work=_hbm("conv5x5_wgrad_kernel<%d, %s, 3>" % (cin, "true" if sign is not None else "false"),
+                       n * (3600.0 * cin * 4 + 4096 * 32 * 4 + (4096 * 4 if sign is not None else 0))))
+        return dw
     call("ugn_conv5x5_in_wgrad_h2", ptr(x), ptr(dz1.data), ptr(dz1.meta), ptr(sign), ptr(dw), n, cin, ptr(ws), ws.numel(), _stream(),
          label="conv5x5_wgrad[cin=%d h2]" % cin,
          work=_hbm("conv5x5_wgrad_kernel<%d, %s, true>" % (cin, "true" if sign is not None else "false"),
