@@ -40,6 +40,10 @@ enum { EPI_LRELU = 0, EPI_LRELU_POOL = 1, EPI_DGRAD = 2, EPI_DGRAD_ACT = 3 };
 #define UGN_ST(T_, ptr_, val_) *reinterpret_cast<T_*>(ptr_) = (T_)(val_)
 #endif
 
+#ifndef UGN_MM16_PIPE
+#define UGN_MM16_PIPE 0      /* 1: fragment reads pinned a micro-step ahead of their MFMAs (round-4 experiment 3: equal in isolation,
+                                1 % SLOWER in the step -- 5.77 against 5.83 ms, same box, both orders) */
+#endif
 constexpr int HROW = 168;                       // 16-byte slots per halo row (18 pixels x 9 + 6 pad; = 8 mod 16)
 constexpr int HPIECES = 48;                     // 18 rows x 168 slots = 3024 -> 48 pieces of 64 slots (6 per wave)
 constexpr int HALO_BYTES = HPIECES * 1024;      // 49,152
@@ -618,6 +622,7 @@ __global__ __launch_bounds__(512, 2) void conv_mm_kernel(const MmJobs jt, const 
         }
         STAMP_ST(3);
         const int b_addr = b_lane + wbuf * WSTAGE;
+#if UGN_MM16_PIPE
         // software pipeline over micro-steps u = (tap, k-step): the 2 + 2 NB fragment reads of u + 1 before the 3 NB MFMAs of u
         constexpr int NU = TPS * 2;
         uint4 fa[2][2], fb[2][NB][2];      // [register set][plane] / [register set][block][plane]
@@ -646,6 +651,30 @@ __global__ __launch_bounds__(512, 2) void conv_mm_kernel(const MmJobs jt, const 
           for (int nb = 0; nb < NB; ++nb) acc[nb] = mfma_h(fa[u & 1][1], fb[u & 1][nb][0], acc[nb]);
           __builtin_amdgcn_sched_barrier(0);
         }
+#else
+#pragma unroll
+        for (int t = 0; t < TPS; ++t) {
+          const int tap = sg * TPS + t, dy = tap / 3, dx = tap % 3;
+#pragma unroll
+          for (int s = 0; s < 2; ++s) {
+            const int aoff = (dy * HROW + dx * 9) * 16 + s * 32;
+            const uint4 ah = *reinterpret_cast<const uint4*>(smem + a_addr + aoff);
+            const uint4 al = *reinterpret_cast<const uint4*>(smem + a_addr + aoff + 64);
+            uint4 bh[NB], bl[NB];
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+              bh[nb] = *reinterpret_cast<const uint4*>(smem + b_addr + (((t * 2 + s) * NB + nb) * 2 + 0) * 1024);
+              bl[nb] = *reinterpret_cast<const uint4*>(smem + b_addr + (((t * 2 + s) * NB + nb) * 2 + 1) * 1024);
+            }
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) acc[nb] = mfma_h(ah, bh[nb], acc[nb]);
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) acc[nb] = mfma_h(ah, bl[nb], acc[nb]);
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) acc[nb] = mfma_h(al, bh[nb], acc[nb]);
+          }
+        }
+#endif
         wbuf ^= 1;
         STAMP_ST(4);
 #ifdef UGN_MM_STAMP
@@ -794,9 +823,6 @@ __global__ __launch_bounds__(512, 2) void conv_mm_kernel(const MmJobs jt, const 
 // tap's products are 2 x NC/16 independent accumulator chains instead of NC/32: 13-23 % on the weight gradients that use it
 // (wgrad3x3_mm.hip).  A fragment: lane (row = lane & 15, k group kg = lane >> 4) reads the 16 bytes of channels 8 kg .. 8 kg + 7 of its
 // pixel: with 10 slots per pixel (8 + 2 pad) and 184 per row the four 16-lane groups of a ds_read_b128 hit 16 distinct slots.
-#ifndef UGN_MM16_PIPE
-#define UGN_MM16_PIPE 1
-#endif
 constexpr int PS16 = 10, HROW16 = 184;
 constexpr int HPIECES16 = 52;                       // 18 rows x 184 slots = 3312 -> 51.75 pieces (13 per fetching wave)
 constexpr int HALO16_BYTES = HPIECES16 * 1024;      // 53,248

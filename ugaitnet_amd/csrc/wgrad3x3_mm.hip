@@ -109,6 +109,10 @@ __global__ __launch_bounds__(512, 2) void wgrad_mm_kernel(const WgJobs jt, const
 #ifndef UGN_WG_PER_TAP
 #define UGN_WG_PER_TAP 1
 #endif
+#ifndef UGN_WG_PIPE
+#define UGN_WG_PIPE 1         /* a tap's transposed reads pinned one tap ahead of its MFMAs (round-4 experiment 3: equal in isolation,
+                                 40-110 us better over the five launches inside the step, same box, both orders) */
+#endif
   constexpr bool M16 = PW == 2 && (!POOLED || UGN_WG_POOLED16);
   constexpr bool SWZ = M16 && UGN_WG_SWZ;
   // transposed-read role of the lane: 16-lane group (channel half gh, k half h), row q of the 4-pixel block, columns 4p..
@@ -348,11 +352,15 @@ __global__ __launch_bounds__(512, 2) void wgrad_mm_kernel(const WgJobs jt, const
           fal[set][cit] = tr_pair(im, IN_PLANE + o, IN_PLANE + o + 4 * 64);
         }
       };
-      load_a(0, 0);
+      if (UGN_WG_PIPE) load_a(0, 0);
 #pragma unroll
       for (int t = 0; t < 9; ++t) {
-        if (t + 1 < 9) load_a((t + 1) & 1, t + 1);
-        __builtin_amdgcn_sched_barrier(0);
+        if (UGN_WG_PIPE) {
+          if (t + 1 < 9) load_a((t + 1) & 1, t + 1);
+          __builtin_amdgcn_sched_barrier(0);
+        } else {
+          load_a(t & 1, t);
+        }
 #pragma unroll
         for (int cit = 0; cit < 2; ++cit) {
           const h8 ah = fah[t & 1][cit], al = fal[t & 1][cit];
@@ -365,7 +373,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_mm_kernel(const WgJobs jt, const
             a4[t][cit * 2 + cot] = c;
           }
         }
-        __builtin_amdgcn_sched_barrier(0);
+        if (UGN_WG_PIPE) __builtin_amdgcn_sched_barrier(0);
         // the next strip's pieces go out in the FIRST taps (UGN_WG_PER_TAP per tap): the later the last one is issued, the more of
         // its latency the top-of-strip wait sees
         if (t * UGN_WG_PER_TAP < NJ && have_in) {
@@ -393,15 +401,19 @@ __global__ __launch_bounds__(512, 2) void wgrad_mm_kernel(const WgJobs jt, const
         fah[set] = tr_pair(in_b, o, o + 4 * 64);
         fal[set] = tr_pair(in_b, IN_PLANE + o, IN_PLANE + o + 4 * 64);
       };
-      load_a(0, 0);
+      if (UGN_WG_PIPE) load_a(0, 0);
 #pragma unroll
       for (int t = 0; t < 9; ++t) {
-        if (t + 1 < 9) load_a((t + 1) & 1, t + 1);
-        __builtin_amdgcn_sched_barrier(0);
+        if (UGN_WG_PIPE) {
+          if (t + 1 < 9) load_a((t + 1) & 1, t + 1);
+          __builtin_amdgcn_sched_barrier(0);
+        } else {
+          load_a(t & 1, t);
+        }
         acc[t] = mfma_h8(fah[t & 1], bh, acc[t]);
         acc[t] = mfma_h8(fah[t & 1], bl, acc[t]);
         acc[t] = mfma_h8(fal[t & 1], bh, acc[t]);
-        __builtin_amdgcn_sched_barrier(0);
+        if (UGN_WG_PIPE) __builtin_amdgcn_sched_barrier(0);
         // one LDS-DMA piece after every tap (every second tap where there are two k-steps) until the wave's pieces are out
         constexpr int EVERY = RPW == 1 ? 1 : 2;
         const int slot = rr * 9 + t;
