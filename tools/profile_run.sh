@@ -14,8 +14,10 @@ stats() {   # $1 = name, rest = bench flags
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$TAG/$name -o $name -- python3 $BENCH "$@" > $OUT/prof_$TAG/$name.log 2>&1
   cp $(find $OUT/prof_$TAG/$name -name "${name}_kernel_stats.csv" | head -1) $OUT/${TAG}_kernel_stats_$name.csv && echo "kernel stats: $name"
 }
+if [ -z "${PMC_ONLY:-}" ]; then      # PMC_ONLY=1: counters only (an experiment's build, named by UGN_LIB)
 stats serial --serial --steps 20 --warmup 5
 stats default --steps 20 --warmup 5
+fi
 pmc() {     # $1 = prefix, rest = counters
   local name=$1; shift
   rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $OUT/prof_$TAG/pmc -o $name -- python3 $BENCH --serial --steps 3 --warmup 1 > $OUT/prof_$TAG/pmc_$name.log 2>&1
