@@ -360,6 +360,21 @@ int ugn_h2_setmax_bwd_multi(const uint16_t* const* p, const void* const* p_meta,
                             const void* const* dm_meta, int dm_is_f32, const uint16_t* const* addend,
                             const void* const* addend_meta, uint16_t* const* out, void* const* out_meta, const int* b, int njobs,
                             int l, int npix, int c, int apply_lrelu, void* stream);
+/* Routed set pooling (the default of the f16x2 path since round 4).  The forward pass also writes ROUTING WORDS, u32
+ * [b][npix][2][c]: plane 0 = bit t set where frame t of the clip holds the maximum (ties: several bits), plane 1 = bit t set where
+ * frame t is positive; l <= 32.  The gradient reads them instead of the l frames -- bit-identical to ugn_h2_setmax_bwd_multi, a
+ * third (with an addend) to a half (without) fewer bytes. */
+int ugn_h2_setmax_fwd_routed_multi(const uint16_t* const* p, const void* const* p_meta, const uint16_t* const* addend,
+                                   const void* const* addend_meta, uint16_t* const* m, void* const* m_meta, uint16_t* const* sum,
+                                   void* const* sum_meta, uint32_t* const* route, const int* b, int njobs, int l, int npix, int c,
+                                   void* stream);
+int ugn_h2_setmax_fwd_f32_routed_multi(const uint16_t* const* p, const void* const* p_meta, const uint16_t* const* addend,
+                                       const void* const* addend_meta, float* const* m, float* const* sum, uint32_t* const* route,
+                                       const int* b, int njobs, int l, int npix, int c, void* stream);
+int ugn_h2_setmax_bwd_routed_multi(const uint32_t* const* route, const void* const* dm, const void* const* dm_meta, int dm_is_f32,
+                                   const uint16_t* const* addend, const void* const* addend_meta, uint16_t* const* out,
+                                   void* const* out_meta, const int* b, int njobs, int l, int npix, int c, int apply_lrelu,
+                                   void* stream);
 /* out = g * LeakyReLU'(act), all H2 [npix][2][c] */
 int ugn_h2_lrelu_bwd_multi(const uint16_t* const* g, const void* const* g_meta, const uint16_t* const* act,
                            uint16_t* const* out, void* const* out_meta, const size_t* npix, int njobs, int c, void* stream);

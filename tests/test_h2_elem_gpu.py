@@ -136,9 +136,31 @@ def test_setmax_bwd_h2(dev, hw, c, with_add, f32dm):
         adds = [adt]
         out = h2.H2Tensor(adt.data, torch.zeros(2, dtype=torch.int32, device=dev))     # in place over the addend, own meta
     ref = ref * np.where(pv > 0, 1.0, 0.3)
+    keep = adt.data.clone() if with_add else None
     h2.setmax_bwd_h2_multi([pt], dms, dm_metas, [b], l, True, [out], addends=adds, dm_is_f32=f32dm)
     close(out.numpy().reshape(b, l, hw, hw, c), ref, 3e-7, "setmax bwd h2")
     bound_ok(out, "setmax bwd out")
+    # the routed form (what the engine runs): the forward pass writes which frames hold the maximum / are positive, the gradient
+    # reads those words instead of the frames -- the same bits out, and no frame pointer at all
+    route = torch.empty((b, hw, hw, 2, c), dtype=torch.int32, device=dev)
+    h2.setmax_fwd_h2_multi([pt], [b], l, ms=[h2.H2Tensor.empty((b, hw, hw, c), dev)], routes=[route])
+    words = route.cpu().numpy().view(np.uint32)
+    bits = lambda mask: sum((mask[:, t].astype(np.uint32) << np.uint32(t)) for t in range(l))
+    assert np.array_equal(words[:, :, :, 0], bits(pv == pv.max(axis=1, keepdims=True))), "maximum bits (ties: several frames)"
+    assert np.array_equal(words[:, :, :, 1], bits(pv > 0)), "sign bits"
+    first = out.data.clone()
+    first_meta = out.meta.clone()
+    out2 = h2.H2Tensor.empty((b * l, hw, hw, c), dev)
+    if with_add:
+        adt.data.copy_(keep)
+        out2 = h2.H2Tensor(adt.data, torch.zeros(2, dtype=torch.int32, device=dev))
+    h2.setmax_bwd_h2_multi(None, dms, dm_metas, [b], l, True, [out2], addends=adds, dm_is_f32=f32dm, routes=[route])
+    assert torch.equal(out2.data, first) and torch.equal(out2.meta, first_meta), "routed gradient differs from the one that reads the frames"
+    # fp32-output forward (the last set pooling) writes the same words
+    route3 = torch.zeros_like(route)
+    mf = torch.empty((b, hw, hw, c), device=dev)
+    h2.setmax_fwd_h2_f32_multi([pt], [b], l, [mf], None, None, routes=[route3])
+    assert torch.equal(route3, route)
 
 
 def test_lrelu_bwd_and_encode_multi(dev):

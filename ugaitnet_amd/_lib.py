@@ -98,6 +98,9 @@ PROTOTYPES = {
     "ugn_h2_setmax_fwd_multi": (_i, [C.POINTER(_p)] * 8 + [C.POINTER(_i), _i, _i, _i, _i, _p]),
     "ugn_h2_setmax_fwd_f32_multi": (_i, [C.POINTER(_p)] * 6 + [C.POINTER(_i), _i, _i, _i, _i, _p]),
     "ugn_h2_setmax_bwd_multi": (_i, [C.POINTER(_p)] * 4 + [_i] + [C.POINTER(_p)] * 4 + [C.POINTER(_i), _i, _i, _i, _i, _i, _p]),
+    "ugn_h2_setmax_fwd_routed_multi": (_i, [C.POINTER(_p)] * 9 + [C.POINTER(_i), _i, _i, _i, _i, _p]),
+    "ugn_h2_setmax_fwd_f32_routed_multi": (_i, [C.POINTER(_p)] * 7 + [C.POINTER(_i), _i, _i, _i, _i, _p]),
+    "ugn_h2_setmax_bwd_routed_multi": (_i, [C.POINTER(_p)] * 3 + [_i] + [C.POINTER(_p)] * 4 + [C.POINTER(_i), _i, _i, _i, _i, _i, _p]),
     "ugn_h2_lrelu_bwd_multi": (_i, [C.POINTER(_p)] * 5 + [C.POINTER(_sz), _i, _i, _p]),
     "ugn_hpp_bwd_b4h2_multi": (_i, [C.POINTER(_p)] * 6 + [C.POINTER(_i), _i, _p]),
     "ugn_set_persistent_wgs": (_i, [_i]),

@@ -42,8 +42,20 @@ struct SetJobs {
   H2Meta* sum_meta[kJobs];
   float* m_f32[kJobs];           // fwd, F32OUT: maxima / sums as fp32 [b][pix][c] (the inputs of HPP)
   float* sum_f32[kJobs];
+  uint32_t* route[kJobs];        // routing words [b][pix][2][c] (fwd: written when set; bwd: read INSTEAD of p), see setmax_route
   int b[kJobs];
 };
+
+// Routing words of one (clip, pixel, channel): plane 0 = bit t set where frame t holds the maximum, plane 1 = bit t set where
+// frame t is positive (its LeakyReLU' slope is 1).  8 bytes per 4 * l bytes of frames: with them the gradient kernel does not
+// read the frames again -- a third (with an addend) to a half (without) of its bytes.
+struct Route4 { uint4 mx, sg; };
+__device__ __forceinline__ void route_bits(Route4& r, int t, V4 v, V4 m) {
+  r.mx.x |= (v.x == m.x ? 1u : 0u) << t; r.mx.y |= (v.y == m.y ? 1u : 0u) << t;
+  r.mx.z |= (v.z == m.z ? 1u : 0u) << t; r.mx.w |= (v.w == m.w ? 1u : 0u) << t;
+  r.sg.x |= (v.x > 0.f ? 1u : 0u) << t; r.sg.y |= (v.y > 0.f ? 1u : 0u) << t;
+  r.sg.z |= (v.z > 0.f ? 1u : 0u) << t; r.sg.w |= (v.w > 0.f ? 1u : 0u) << t;
+}
 
 // grid: (pixel-channel quads / 128, b, jobs).  npix = pixels per image, c = channels.
 template <bool F32OUT>
@@ -66,14 +78,41 @@ __global__ __launch_bounds__(128) void setmax_fwd_h2_kernel(const SetJobs jt, in
   const size_t rec = (size_t)2 * c;                                   // halves per pixel record
   const uint16_t* src = jt.p[j] + ((size_t)b * l * npix + pix) * rec;
   const size_t fstride = (size_t)npix * rec;
-  V4 mx = ld4(src, c, ch);
-  int t = 1;
-  for (; t + 4 <= l; t += 4) {       // four frames (8 loads of 8 bytes) in flight per lane
-    const V4 v0 = ld4(src + (size_t)t * fstride, c, ch), v1 = ld4(src + (size_t)(t + 1) * fstride, c, ch);
-    const V4 v2 = ld4(src + (size_t)(t + 2) * fstride, c, ch), v3 = ld4(src + (size_t)(t + 3) * fstride, c, ch);
-    mx = max4(max4(mx, v0), max4(max4(v1, v2), v3));
+  V4 mx;
+  if (jt.route[j]) {                 // one pass: a frame above the running maximum restarts its bit mask, an equal one joins it
+    Route4 r = {make_uint4(1u, 1u, 1u, 1u), make_uint4(0u, 0u, 0u, 0u)};
+    mx = ld4(src, c, ch);
+    r.sg = make_uint4(mx.x > 0.f ? 1u : 0u, mx.y > 0.f ? 1u : 0u, mx.z > 0.f ? 1u : 0u, mx.w > 0.f ? 1u : 0u);
+    auto take = [&](float v, float& m, unsigned& mb, unsigned& sb, int t) {
+      const unsigned bit = 1u << t;
+      mb = v > m ? bit : (v == m ? mb | bit : mb);
+      m = fmaxf(m, v);
+      sb |= v > 0.f ? bit : 0u;
+    };
+    auto take4 = [&](V4 v, int t) {
+      take(v.x, mx.x, r.mx.x, r.sg.x, t); take(v.y, mx.y, r.mx.y, r.sg.y, t);
+      take(v.z, mx.z, r.mx.z, r.sg.z, t); take(v.w, mx.w, r.mx.w, r.sg.w, t);
+    };
+    int t = 1;
+    for (; t + 4 <= l; t += 4) {       // four frames (8 loads of 8 bytes) in flight per lane
+      const V4 v0 = ld4(src + (size_t)t * fstride, c, ch), v1 = ld4(src + (size_t)(t + 1) * fstride, c, ch);
+      const V4 v2 = ld4(src + (size_t)(t + 2) * fstride, c, ch), v3 = ld4(src + (size_t)(t + 3) * fstride, c, ch);
+      take4(v0, t); take4(v1, t + 1); take4(v2, t + 2); take4(v3, t + 3);
+    }
+    for (; t < l; ++t) take4(ld4(src + (size_t)t * fstride, c, ch), t);
+    uint32_t* rp = jt.route[j] + ((size_t)b * npix + pix) * 2 * c + ch;
+    *reinterpret_cast<uint4*>(rp) = r.mx;
+    *reinterpret_cast<uint4*>(rp + c) = r.sg;
+  } else {
+    mx = ld4(src, c, ch);
+    int t = 1;
+    for (; t + 4 <= l; t += 4) {       // four frames (8 loads of 8 bytes) in flight per lane
+      const V4 v0 = ld4(src + (size_t)t * fstride, c, ch), v1 = ld4(src + (size_t)(t + 1) * fstride, c, ch);
+      const V4 v2 = ld4(src + (size_t)(t + 2) * fstride, c, ch), v3 = ld4(src + (size_t)(t + 3) * fstride, c, ch);
+      mx = max4(max4(mx, v0), max4(max4(v1, v2), v3));
+    }
+    for (; t < l; ++t) mx = max4(mx, ld4(src + (size_t)t * fstride, c, ch));
   }
-  for (; t < l; ++t) mx = max4(mx, ld4(src + (size_t)t * fstride, c, ch));
   const size_t o = (size_t)b * npix + pix;
   V4 sm = mx;
   if (has_add) {
@@ -98,7 +137,7 @@ __global__ __launch_bounds__(128) void setmax_fwd_h2_kernel(const SetJobs jt, in
 
 // TF reduce_max gradient (equal split among the maxima) + the second gradient path + LeakyReLU'(p), as setmax_bwd_kernel of
 // pool_set.hip:   out = ((p == max ? dm / #maxima : 0) + addend) * LeakyReLU'(p)
-template <bool DM_F32>
+template <bool DM_F32, bool ROUTED>
 __global__ __launch_bounds__(128) void setmax_bwd_h2_kernel(const SetJobs jt, int l, int npix, int c, int lrelu) {
   const int j = blockIdx.z, b = blockIdx.y;
   const int e = blockIdx.x * 128 + threadIdx.x, q = c / 4;
@@ -111,23 +150,28 @@ __global__ __launch_bounds__(128) void setmax_bwd_h2_kernel(const SetJobs jt, in
   if (e >= npix * q) return;
   const int pix = e / q, ch = (e - pix * q) * 4;
   const size_t rec = (size_t)2 * c, fstride = (size_t)npix * rec;
-  const uint16_t* src = jt.p[j] + ((size_t)b * l * npix + pix) * rec;
-  V4 v[MAXL];
-#pragma unroll
-  for (int t = 0; t < MAXL; ++t)
-    if (t < l) v[t] = ld4(src + (size_t)t * fstride, c, ch);
-  V4 mx = v[0];
-#pragma unroll
-  for (int t = 1; t < MAXL; ++t)
-    if (t < l) mx = max4(mx, v[t]);
-  V4 cnt = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int t = 0; t < MAXL; ++t)
-    if (t < l) {
-      cnt.x += v[t].x == mx.x ? 1.f : 0.f; cnt.y += v[t].y == mx.y ? 1.f : 0.f;
-      cnt.z += v[t].z == mx.z ? 1.f : 0.f; cnt.w += v[t].w == mx.w ? 1.f : 0.f;
-    }
   const size_t o = (size_t)b * npix + pix;
+  // which frames hold the maximum / are positive: from the forward pass's routing words, or from the frames themselves
+  Route4 r = {make_uint4(0u, 0u, 0u, 0u), make_uint4(0u, 0u, 0u, 0u)};
+  if constexpr (ROUTED) {
+    const uint32_t* rp = jt.route[j] + o * 2 * c + ch;
+    r.mx = *reinterpret_cast<const uint4*>(rp);
+    r.sg = *reinterpret_cast<const uint4*>(rp + c);
+  } else {
+    const uint16_t* src = jt.p[j] + ((size_t)b * l * npix + pix) * rec;
+    V4 v[MAXL];
+#pragma unroll
+    for (int t = 0; t < MAXL; ++t)
+      if (t < l) v[t] = ld4(src + (size_t)t * fstride, c, ch);
+    V4 mx = v[0];
+#pragma unroll
+    for (int t = 1; t < MAXL; ++t)
+      if (t < l) mx = max4(mx, v[t]);
+#pragma unroll
+    for (int t = 0; t < MAXL; ++t)
+      if (t < l) route_bits(r, t, v[t], mx);
+  }
+  const V4 cnt = {(float)__popc(r.mx.x), (float)__popc(r.mx.y), (float)__popc(r.mx.z), (float)__popc(r.mx.w)};
   V4 g;
   if constexpr (DM_F32) {
     const float4 t4 = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(jt.dm[j]) + o * c + ch);
@@ -139,19 +183,29 @@ __global__ __launch_bounds__(128) void setmax_bwd_h2_kernel(const SetJobs jt, in
   const V4 gs = {g.x * fg / cnt.x, g.y * fg / cnt.y, g.z * fg / cnt.z, g.w * fg / cnt.w};
   const uint16_t* asrc = has_add ? jt.add[j] + ((size_t)b * l * npix + pix) * rec : nullptr;
   uint16_t* dst = jt.m[j] + ((size_t)b * l * npix + pix) * rec;
-  auto route = [&](float vv, float mm, float gg, float aa) {
-    float r = (vv == mm ? gg : 0.f) + aa;
-    if (lrelu) r *= ugn_lrelu_slope(vv);
-    return r;
+  auto route = [&](unsigned mbits, unsigned sbits, int t, float gg, float aa) {
+    float rr = ((mbits >> t) & 1u ? gg : 0.f) + aa;
+    if (lrelu) rr *= (sbits >> t) & 1u ? 1.f : UGN_LRELU_ALPHA;
+    return rr;
   };
+  // (the addends of four frames in flight: with the routing words nothing else hides the latency of this read)
+  constexpr int PF = 4;
 #pragma unroll
-  for (int t = 0; t < MAXL; ++t)
-    if (t < l) {
-      V4 a = {0.f, 0.f, 0.f, 0.f};
-      if (has_add) { a = ld4(asrc + (size_t)t * fstride, c, ch); a = {a.x * fa, a.y * fa, a.z * fa, a.w * fa}; }
-      st4(dst + (size_t)t * fstride, c, ch, {route(v[t].x, mx.x, gs.x, a.x), route(v[t].y, mx.y, gs.y, a.y),
-                                             route(v[t].z, mx.z, gs.z, a.z), route(v[t].w, mx.w, gs.w, a.w)});
+  for (int t0 = 0; t0 < MAXL; t0 += PF) {
+    V4 a[PF];
+#pragma unroll
+    for (int k = 0; k < PF; ++k) {
+      a[k] = {0.f, 0.f, 0.f, 0.f};
+      if (has_add && t0 + k < l) a[k] = ld4(asrc + (size_t)(t0 + k) * fstride, c, ch);
     }
+#pragma unroll
+    for (int k = 0; k < PF; ++k) {
+      const int t = t0 + k;
+      if (t < l)
+        st4(dst + (size_t)t * fstride, c, ch, {route(r.mx.x, r.sg.x, t, gs.x, a[k].x * fa), route(r.mx.y, r.sg.y, t, gs.y, a[k].y * fa),
+                                               route(r.mx.z, r.sg.z, t, gs.z, a[k].z * fa), route(r.mx.w, r.sg.w, t, gs.w, a[k].w * fa)});
+    }
+  }
 }
 
 struct EltJobs {
@@ -232,14 +286,22 @@ static int fill_set(SetJobs& jt, const uint16_t* const* p, const void* const* p_
   return 0;
 }
 
-/* maxima over the l frames of each clip (+ optional set-level addend): H2 outputs m (optional) and sum = m + addend */
-extern "C" int ugn_h2_setmax_fwd_multi(const uint16_t* const* p, const void* const* p_meta, const uint16_t* const* addend,
-                                       const void* const* addend_meta, uint16_t* const* m, void* const* m_meta,
-                                       uint16_t* const* sum, void* const* sum_meta, const int* b, int njobs, int l, int npix,
-                                       int c, void* stream) {
+static int set_routes(SetJobs& jt, uint32_t* const* route, int njobs, int l, const char* who) {
+  for (int j = 0; j < njobs; ++j) jt.route[j] = route ? route[j] : nullptr;
+  UGN_REQUIRE(!route || l <= MAXL, "%s: routing words hold at most %d frames", who, MAXL);
+  return 0;
+}
+
+/* maxima over the l frames of each clip (+ optional set-level addend): H2 outputs m (optional) and sum = m + addend.
+ * route (optional; l <= 32): routing words u32 [b][npix][2][c] for ugn_h2_setmax_bwd_routed_multi */
+extern "C" int ugn_h2_setmax_fwd_routed_multi(const uint16_t* const* p, const void* const* p_meta, const uint16_t* const* addend,
+                                              const void* const* addend_meta, uint16_t* const* m, void* const* m_meta,
+                                              uint16_t* const* sum, void* const* sum_meta, uint32_t* const* route, const int* b,
+                                              int njobs, int l, int npix, int c, void* stream) {
   SetJobs jt = {};
   int bmax;
   if (int rc = fill_set(jt, p, p_meta, addend, addend_meta, njobs, b, &bmax, "ugn_h2_setmax_fwd_multi")) return rc;
+  if (int rc = set_routes(jt, route, njobs, l, "ugn_h2_setmax_fwd_routed_multi")) return rc;
   UGN_REQUIRE(l > 0 && npix > 0 && c > 0 && c % 4 == 0, "ugn_h2_setmax_fwd_multi: c must be a multiple of 4");
   for (int j = 0; j < njobs; ++j) {
     jt.m[j] = m ? m[j] : nullptr; jt.m_meta[j] = (m && m[j]) ? (H2Meta*)m_meta[j] : nullptr;
@@ -253,14 +315,22 @@ extern "C" int ugn_h2_setmax_fwd_multi(const uint16_t* const* p, const void* con
   UGN_CHECK_LAUNCH("h2_setmax_fwd");
   return 0;
 }
+extern "C" int ugn_h2_setmax_fwd_multi(const uint16_t* const* p, const void* const* p_meta, const uint16_t* const* addend,
+                                       const void* const* addend_meta, uint16_t* const* m, void* const* m_meta,
+                                       uint16_t* const* sum, void* const* sum_meta, const int* b, int njobs, int l, int npix,
+                                       int c, void* stream) {
+  return ugn_h2_setmax_fwd_routed_multi(p, p_meta, addend, addend_meta, m, m_meta, sum, sum_meta, nullptr, b, njobs, l, npix, c, stream);
+}
 
 /* the same with fp32 outputs [b][npix][c] (true values): the last set pooling feeds HPP, which stays fp32 */
-extern "C" int ugn_h2_setmax_fwd_f32_multi(const uint16_t* const* p, const void* const* p_meta, const uint16_t* const* addend,
-                                           const void* const* addend_meta, float* const* m, float* const* sum, const int* b,
-                                           int njobs, int l, int npix, int c, void* stream) {
+extern "C" int ugn_h2_setmax_fwd_f32_routed_multi(const uint16_t* const* p, const void* const* p_meta, const uint16_t* const* addend,
+                                                  const void* const* addend_meta, float* const* m, float* const* sum,
+                                                  uint32_t* const* route, const int* b, int njobs, int l, int npix, int c,
+                                                  void* stream) {
   SetJobs jt = {};
   int bmax;
   if (int rc = fill_set(jt, p, p_meta, addend, addend_meta, njobs, b, &bmax, "ugn_h2_setmax_fwd_f32_multi")) return rc;
+  if (int rc = set_routes(jt, route, njobs, l, "ugn_h2_setmax_fwd_f32_routed_multi")) return rc;
   UGN_REQUIRE(l > 0 && npix > 0 && c > 0 && c % 4 == 0, "ugn_h2_setmax_fwd_f32_multi: c must be a multiple of 4");
   for (int j = 0; j < njobs; ++j) {
     jt.m_f32[j] = m ? m[j] : nullptr; jt.sum_f32[j] = sum ? sum[j] : nullptr;
@@ -272,31 +342,70 @@ extern "C" int ugn_h2_setmax_fwd_f32_multi(const uint16_t* const* p, const void*
   UGN_CHECK_LAUNCH("h2_setmax_fwd_f32");
   return 0;
 }
+extern "C" int ugn_h2_setmax_fwd_f32_multi(const uint16_t* const* p, const void* const* p_meta, const uint16_t* const* addend,
+                                           const void* const* addend_meta, float* const* m, float* const* sum, const int* b,
+                                           int njobs, int l, int npix, int c, void* stream) {
+  return ugn_h2_setmax_fwd_f32_routed_multi(p, p_meta, addend, addend_meta, m, sum, nullptr, b, njobs, l, npix, c, stream);
+}
 
 /* out = ((p == max over l ? dm / #maxima : 0) + addend) * (apply_lrelu ? LeakyReLU'(p) : 1).  dm: H2 [b][npix][2][c], or with
  * dm_is_f32 an fp32 tensor [b][npix][c] whose dm_meta is {0, bits(max|dm|)} (ugn_absmax_multi).  out may alias addend's data
- * (its meta must be a different record). */
+ * (its meta must be a different record).  Which frames hold the maximum and which are positive comes from the frames p, or --
+ * `route` given, p ignored (may be null) -- from the routing words the forward pass wrote: bit-identical results without reading
+ * the l frames again. */
+static int setmax_bwd_any(const uint16_t* const* p, const void* const* p_meta, const uint32_t* const* route, const void* const* dm,
+                          const void* const* dm_meta, int dm_is_f32, const uint16_t* const* addend, const void* const* addend_meta,
+                          uint16_t* const* out, void* const* out_meta, const int* b, int njobs, int l, int npix, int c, int apply_lrelu,
+                          void* stream, const char* who) {
+  SetJobs jt = {};
+  int bmax = 0;
+  if (route) {
+    UGN_REQUIRE(b && njobs >= 1 && njobs <= kJobs, "%s: bad arguments (1..%d jobs)", who, kJobs);
+    for (int j = 0; j < njobs; ++j) {
+      UGN_REQUIRE(route[j] && b[j] > 0, "%s: null routing words or b <= 0 in job %d", who, j);
+      jt.route[j] = const_cast<uint32_t*>(route[j]);
+      jt.add[j] = addend ? addend[j] : nullptr;
+      jt.add_meta[j] = (addend && addend[j]) ? (const H2Meta*)addend_meta[j] : nullptr;
+      UGN_REQUIRE(!jt.add[j] || jt.add_meta[j], "%s: addend without its meta in job %d", who, j);
+      jt.b[j] = b[j];
+      if (b[j] > bmax) bmax = b[j];
+    }
+  } else if (int rc = fill_set(jt, p, p_meta, addend, addend_meta, njobs, b, &bmax, who)) {
+    return rc;
+  }
+  UGN_REQUIRE(dm && dm_meta && out && out_meta, "%s: null array", who);
+  UGN_REQUIRE(l > 0 && l <= MAXL && npix > 0 && c > 0 && c % 4 == 0, "%s: l must be 1..%d, c a multiple of 4", who, MAXL);
+  for (int j = 0; j < njobs; ++j) {
+    UGN_REQUIRE(dm[j] && dm_meta[j] && out[j] && out_meta[j], "%s: null pointer in job %d", who, j);
+    UGN_REQUIRE(out_meta[j] != (addend_meta ? addend_meta[j] : nullptr), "%s: out_meta must not be addend_meta (job %d)", who, j);
+    jt.dm[j] = dm[j]; jt.dm_meta[j] = (const H2Meta*)dm_meta[j]; jt.m[j] = out[j]; jt.m_meta[j] = (H2Meta*)out_meta[j];
+  }
+  const dim3 grid((unsigned)(((size_t)npix * (c / 4) + 127) / 128), bmax, njobs);
+  hipStream_t st = (hipStream_t)stream;
+  if (route) {
+    if (dm_is_f32) hipLaunchKernelGGL((setmax_bwd_h2_kernel<true, true>), grid, dim3(128), 0, st, jt, l, npix, c, apply_lrelu);
+    else hipLaunchKernelGGL((setmax_bwd_h2_kernel<false, true>), grid, dim3(128), 0, st, jt, l, npix, c, apply_lrelu);
+  } else {
+    if (dm_is_f32) hipLaunchKernelGGL((setmax_bwd_h2_kernel<true, false>), grid, dim3(128), 0, st, jt, l, npix, c, apply_lrelu);
+    else hipLaunchKernelGGL((setmax_bwd_h2_kernel<false, false>), grid, dim3(128), 0, st, jt, l, npix, c, apply_lrelu);
+  }
+  UGN_CHECK_LAUNCH("h2_setmax_bwd");
+  return 0;
+}
 extern "C" int ugn_h2_setmax_bwd_multi(const uint16_t* const* p, const void* const* p_meta, const void* const* dm,
                                        const void* const* dm_meta, int dm_is_f32, const uint16_t* const* addend,
                                        const void* const* addend_meta, uint16_t* const* out, void* const* out_meta, const int* b,
                                        int njobs, int l, int npix, int c, int apply_lrelu, void* stream) {
-  SetJobs jt = {};
-  int bmax;
-  if (int rc = fill_set(jt, p, p_meta, addend, addend_meta, njobs, b, &bmax, "ugn_h2_setmax_bwd_multi")) return rc;
-  UGN_REQUIRE(dm && dm_meta && out && out_meta, "ugn_h2_setmax_bwd_multi: null array");
-  UGN_REQUIRE(l > 0 && l <= MAXL && npix > 0 && c > 0 && c % 4 == 0, "ugn_h2_setmax_bwd_multi: l must be 1..%d, c a multiple of 4", MAXL);
-  for (int j = 0; j < njobs; ++j) {
-    UGN_REQUIRE(dm[j] && dm_meta[j] && out[j] && out_meta[j], "ugn_h2_setmax_bwd_multi: null pointer in job %d", j);
-    UGN_REQUIRE(out_meta[j] != (addend_meta ? addend_meta[j] : nullptr), "ugn_h2_setmax_bwd_multi: out_meta must not be addend_meta (job %d)", j);
-    jt.dm[j] = dm[j]; jt.dm_meta[j] = (const H2Meta*)dm_meta[j]; jt.m[j] = out[j]; jt.m_meta[j] = (H2Meta*)out_meta[j];
-  }
-  const unsigned gx = (unsigned)(((size_t)npix * (c / 4) + 127) / 128);
-  if (dm_is_f32)
-    hipLaunchKernelGGL(setmax_bwd_h2_kernel<true>, dim3(gx, bmax, njobs), dim3(128), 0, (hipStream_t)stream, jt, l, npix, c, apply_lrelu);
-  else
-    hipLaunchKernelGGL(setmax_bwd_h2_kernel<false>, dim3(gx, bmax, njobs), dim3(128), 0, (hipStream_t)stream, jt, l, npix, c, apply_lrelu);
-  UGN_CHECK_LAUNCH("h2_setmax_bwd");
-  return 0;
+  return setmax_bwd_any(p, p_meta, nullptr, dm, dm_meta, dm_is_f32, addend, addend_meta, out, out_meta, b, njobs, l, npix, c, apply_lrelu,
+                        stream, "ugn_h2_setmax_bwd_multi");
+}
+extern "C" int ugn_h2_setmax_bwd_routed_multi(const uint32_t* const* route, const void* const* dm, const void* const* dm_meta,
+                                              int dm_is_f32, const uint16_t* const* addend, const void* const* addend_meta,
+                                              uint16_t* const* out, void* const* out_meta, const int* b, int njobs, int l, int npix,
+                                              int c, int apply_lrelu, void* stream) {
+  UGN_REQUIRE(route, "ugn_h2_setmax_bwd_routed_multi: null routing words");
+  return setmax_bwd_any(nullptr, nullptr, route, dm, dm_meta, dm_is_f32, addend, addend_meta, out, out_meta, b, njobs, l, npix, c,
+                        apply_lrelu, stream, "ugn_h2_setmax_bwd_routed_multi");
 }
 
 extern "C" int ugn_h2_lrelu_bwd_multi(const uint16_t* const* g, const void* const* g_meta, const uint16_t* const* act,

@@ -24,6 +24,8 @@ NBINS, FEAT, HIDDEN = 62, 128, 256
 # the two it replaces, and those 278 ran on the second stream -- the step got 0.12 ms LONGER (the patch gather and the on-the-fly
 # split of both operands cost more vector instructions than the stores they replace).
 FUSE_W5 = os.environ.get("UGN_FUSE_W5", "0") != "0"
+# UGN_SET_ROUTED=0: the set-pooling gradients find the maximum frames by reading the frames again (the round-3 kernels; same results)
+SET_ROUTED = os.environ.get("UGN_SET_ROUTED", "1") != "0"
 # 3x3 layers: name, cin, cout, spatial size, pooled
 LAYERS3 = (("a2", 32, 32, 64, True), ("b1", 32, 64, 32, False), ("b2", 64, 64, 32, True), ("a3", 32, 64, 32, False),
            ("a4", 64, 64, 32, True), ("b3", 64, 128, 16, False), ("b4", 128, 128, 16, False), ("a5", 64, 128, 16, False),
@@ -99,7 +101,10 @@ def forward_h2(encs, xs):
     i2s = [S[i].f32("i2", (geo[i][2], 32, 32, 32), U8) for i in R]
     h2.conv3x3_fwd_mm_multi(a1s, [s.wf("a2")[0] for s in S], [s.wf("a2")[1] for s in S], 32, True, p2s, i2s)
     m1s = [S[i].t("m1", (geo[i][0], 32, 32, 32)) for i in R]
-    h2.setmax_fwd_h2_multi(p2s, bs, l0, ms=m1s)
+    # routing words of the three set poolings (which frames hold the maximum / are positive): their gradients read these 8 bytes
+    # per set element instead of the l frames again
+    routes = lambda key, hw, c: [S[i].f32(key, (geo[i][0], hw, hw, 2, c), I32) for i in R] if SET_ROUTED and l0 <= 32 else None
+    h2.setmax_fwd_h2_multi(p2s, bs, l0, ms=m1s, routes=routes("r1", 32, 32))
 
     def pair_layer(na, nb, xa, xb, cout, hw, pool, ka, kb, ia=None, ib=None):
         """frame-level layer `na` on xa and its set-level twin `nb` on xb for every modality: jobs = [frame..., set...]"""
@@ -115,13 +120,13 @@ def forward_h2(encs, xs):
     a3s, b1s = pair_layer("a3", "b1", p2s, m1s, 64, 32, False, "a3", "b1")
     p4s, q2s = pair_layer("a4", "b2", a3s, b1s, 64, 32, True, "p4", "q2", "i4", "j2")
     s2s = [S[i].t("s2", (geo[i][0], 16, 16, 64)) for i in R]
-    h2.setmax_fwd_h2_multi(p4s, bs, l0, addends=q2s, sums=s2s)
+    h2.setmax_fwd_h2_multi(p4s, bs, l0, addends=q2s, sums=s2s, routes=routes("r2", 16, 64))
     a5s, b3s = pair_layer("a5", "b3", p4s, s2s, 128, 16, False, "a5", "b3")
     a6s, b4s = pair_layer("a6", "b4", a5s, b3s, 128, 16, False, "a6", "b4")
     # the last set pooling leaves the H2 part of the path: HPP and the per-bin FC stay fp32
     m3s = [S[i].f32("m3", (geo[i][0], 16, 16, 128)) for i in R]
     s3s = [S[i].f32("s3", (geo[i][0], 16, 16, 128)) for i in R]
-    h2.setmax_fwd_h2_f32_multi(a6s, bs, l0, m3s, b4s, s3s)
+    h2.setmax_fwd_h2_f32_multi(a6s, bs, l0, m3s, b4s, s3s, routes=routes("r3", 16, 128))
     feats = ops.hpp_fwd_multi(m3s, s3s, [S[i].f32("feat", (NBINS, geo[i][0], FEAT)) for i in R])
     outs = ops.binfc_fwd_multi(feats, [e.W("fc") for e in encs], [S[i].f32("out", (NBINS, geo[i][0], HIDDEN)) for i in R])
     for e, o in zip(encs, outs):
@@ -139,6 +144,7 @@ def backward_h2(encs, douts, side):
     R = range(k)
     bs, l0 = [g[0] for g in geo], geo[0][1]
     T = lambda key: [s.bufs[key] for s in S]
+    RT = lambda key: T(key) if SET_ROUTED and l0 <= 32 else None       # routing words of a set pooling (forward_h2)
     fc_args = (T("feat"), [e.W("fc") for e in encs], douts, [e.G("fc") for e in encs],
                                     [S[i].f32("dfeat", (NBINS, geo[i][0], FEAT)) for i in R])
     ops.binfc_bwd_multi(*fc_args, parts=2)            # dfeat: the rest of the backward pass waits for it
@@ -153,7 +159,7 @@ def backward_h2(encs, douts, side):
     h2.absmax_multi(dm3s + dzb4f, [s.slot("dm3") for s in S] + [s.slot("dzb4f") for s in S])
     dzb4 = h2.encode_multi(dzb4f, [s.slot("dzb4f") for s in S], [S[i].t("dzb4", (geo[i][0], 16, 16, 128)) for i in R])
     dz6 = h2.setmax_bwd_h2_multi(T("a6"), dm3s, [s.slot("dm3") for s in S], bs, l0, True,
-                                 [S[i].t("dz6", (geo[i][2], 16, 16, 128)) for i in R], dm_is_f32=True)
+                                 [S[i].t("dz6", (geo[i][2], 16, 16, 128)) for i in R], dm_is_f32=True, routes=RT("r3"))
 
     def wgrad(na, nb, xa, xb, dza, dzb, cout, ia=None, ib=None):
         with side(dev):
@@ -177,13 +183,15 @@ def backward_h2(encs, douts, side):
     # p4, * LeakyReLU'(p4)), a small elementwise kernel the set-level one (* LeakyReLU'(q2))
     raw4, ds2 = dgrad("a5", "b3", dz5, dzb3, 16, 64, 128, "g4", "ds2")
     dq2 = h2.lrelu_bwd_h2_multi(ds2, T("q2"), [S[i].t("dq2", (geo[i][0], 16, 16, 64)) for i in R])
-    dp4 = h2.setmax_bwd_h2_multi(T("p4"), ds2, [d.meta for d in ds2], bs, l0, True, [S[i].alias("dp4", raw4[i]) for i in R], addends=raw4)
+    dp4 = h2.setmax_bwd_h2_multi(T("p4"), ds2, [d.meta for d in ds2], bs, l0, True, [S[i].alias("dp4", raw4[i]) for i in R], addends=raw4,
+                                 routes=RT("r2"))
     # block 2 (a3, a4) with block 1 of the global branch (b1, b2); a4 / b2 are pooled
     wgrad("a4", "b2", T("a3"), T("b1"), dp4, dq2, 64, T("i4"), T("j2"))
     dz3, dzb1 = dgrad("a4", "b2", dp4, dq2, 32, 64, 64, "dz3", "dzb1", T("i4"), T("j2"), T("a3"), T("b1"))
     wgrad("a3", "b1", T("p2"), T("m1"), dz3, dzb1, 64)
     raw2, dm1 = dgrad("a3", "b1", dz3, dzb1, 32, 32, 64, "g2", "dm1")
-    dp2 = h2.setmax_bwd_h2_multi(T("p2"), dm1, [d.meta for d in dm1], bs, l0, True, [S[i].alias("dp2", raw2[i]) for i in R], addends=raw2)
+    dp2 = h2.setmax_bwd_h2_multi(T("p2"), dm1, [d.meta for d in dm1], bs, l0, True, [S[i].alias("dp2", raw2[i]) for i in R], addends=raw2,
+                                 routes=RT("r1"))
     # block 1 (a1, a2): dz1 = dL/da1; the first layer's LeakyReLU' comes from its sign bits inside the 5x5 weight gradient
     i2 = T("i2")
     with side(dev):

@@ -316,37 +316,47 @@ def conv5x5_in_wgrad_h2(x, dz1, dw, sign=None, x_meta=None):
     return dw
 
 
-def setmax_fwd_h2_multi(ps, bs, l, ms=None, addends=None, sums=None):
-    """H2 set pooling: ms[j] (optional) = max over the l frames, sums[j] = ms[j] + addends[j] (H2 outputs)."""
+def setmax_fwd_h2_multi(ps, bs, l, ms=None, addends=None, sums=None, routes=None):
+    """H2 set pooling: ms[j] (optional) = max over the l frames, sums[j] = ms[j] + addends[j] (H2 outputs).  routes (optional):
+    int32 tensors [b, h, w, 2, c] that receive the routing words (which frames hold the maximum / are positive)."""
     n, h, w, c = ps[0].shape
-    call("ugn_h2_setmax_fwd_multi", ptr_array([p.data for p in ps]), ptr_array([p.meta for p in ps]), _opt(addends, "data"),
-         _opt(addends, "meta"), _opt(ms, "data"), _opt(ms, "meta"), _opt(sums, "data"), _opt(sums, "meta"), _ints(bs), len(ps), l,
-         h * w, c, _stream(), label="setmax_fwd[%dx%dx%d h2]" % (h, w, c),
-         work=_hbm("setmax_fwd_h2_kernel<false>", sum(bs) * (l + 1.0) * h * w * c * 4))
+    extra = 8.0 if routes is not None else 0.0
+    call("ugn_h2_setmax_fwd_routed_multi", ptr_array([p.data for p in ps]), ptr_array([p.meta for p in ps]), _opt(addends, "data"),
+         _opt(addends, "meta"), _opt(ms, "data"), _opt(ms, "meta"), _opt(sums, "data"), _opt(sums, "meta"), _opt(routes), _ints(bs),
+         len(ps), l, h * w, c, _stream(), label="setmax_fwd[%dx%dx%d h2]" % (h, w, c),
+         work=_hbm("setmax_fwd_h2_kernel<false>", sum(bs) * ((l + 1.0) * 4 + extra) * h * w * c))
     return ms, sums
 
 
-def setmax_fwd_h2_f32_multi(ps, bs, l, ms, addends, sums):
+def setmax_fwd_h2_f32_multi(ps, bs, l, ms, addends, sums, routes=None):
     """H2 frames (+ H2 set-level addend) -> fp32 maxima ms and sums (the inputs of HPP)."""
     n, h, w, c = ps[0].shape
-    call("ugn_h2_setmax_fwd_f32_multi", ptr_array([p.data for p in ps]), ptr_array([p.meta for p in ps]), _opt(addends, "data"),
-         _opt(addends, "meta"), _opt(ms), _opt(sums), _ints(bs), len(ps), l, h * w, c, _stream(),
+    extra = 8.0 if routes is not None else 0.0
+    call("ugn_h2_setmax_fwd_f32_routed_multi", ptr_array([p.data for p in ps]), ptr_array([p.meta for p in ps]), _opt(addends, "data"),
+         _opt(addends, "meta"), _opt(ms), _opt(sums), _opt(routes), _ints(bs), len(ps), l, h * w, c, _stream(),
          label="setmax_fwd[%dx%dx%d h2->f32]" % (h, w, c),
-         work=_hbm("setmax_fwd_h2_kernel<true>", sum(bs) * (l + 1.0) * h * w * c * 4))
+         work=_hbm("setmax_fwd_h2_kernel<true>", sum(bs) * ((l + 1.0) * 4 + extra) * h * w * c))
     return ms, sums
 
 
-def setmax_bwd_h2_multi(ps, dms, dm_metas, bs, l, lrelu, outs, addends=None, dm_is_f32=False):
+def setmax_bwd_h2_multi(ps, dms, dm_metas, bs, l, lrelu, outs, addends=None, dm_is_f32=False, routes=None):
     """outs[j] (H2Tensor; its data may be addends[j].data) = ((p == max ? dm / #maxima : 0) + addend) * LeakyReLU'(p).
-    dms: H2Tensors, or with dm_is_f32 fp32 tensors whose dm_metas hold {0, bits(max|dm|)}."""
-    n, h, w, c = ps[0].shape
+    dms: H2Tensors, or with dm_is_f32 fp32 tensors whose dm_metas hold {0, bits(max|dm|)}.  routes: the routing words of the
+    forward pass -- with them the frames ps are not read (same results)."""
+    n, h, w, c = outs[0].shape
     dm_ptrs = ptr_array(dms) if dm_is_f32 else ptr_array([d.data for d in dms])
-    call("ugn_h2_setmax_bwd_multi", ptr_array([p.data for p in ps]), ptr_array([p.meta for p in ps]), dm_ptrs, ptr_array(dm_metas),
-         int(bool(dm_is_f32)), _opt(addends, "data"), _opt(addends, "meta"), ptr_array([o.data for o in outs]),
-         ptr_array([o.meta for o in outs]), _ints(bs), len(ps), l, h * w, c, int(bool(lrelu)), _stream(),
-         label="setmax_bwd[%dx%dx%d h2%s]" % (h, w, c, " +addend" if addends is not None else ""),
-         work=_hbm("setmax_bwd_h2_kernel<%s>" % ("true" if dm_is_f32 else "false"),
-                   sum(bs) * l * h * w * c * 4.0 * (3 if addends is not None else 2)))
+    tail = (int(bool(dm_is_f32)), _opt(addends, "data"), _opt(addends, "meta"), ptr_array([o.data for o in outs]),
+            ptr_array([o.meta for o in outs]), _ints(bs), len(outs), l, h * w, c, int(bool(lrelu)), _stream())
+    label = "setmax_bwd[%dx%dx%d h2%s]" % (h, w, c, " +addend" if addends is not None else "")
+    streams = 2 if addends is not None else 1         # frame-sized tensors moved besides the frames themselves
+    if routes is not None:
+        call("ugn_h2_setmax_bwd_routed_multi", ptr_array(routes), dm_ptrs, ptr_array(dm_metas), *tail, label=label,
+             work=_hbm("setmax_bwd_h2_kernel<%s, true>" % ("true" if dm_is_f32 else "false"),
+                       sum(bs) * h * w * c * (l * 4.0 * streams + 12.0)))
+    else:
+        call("ugn_h2_setmax_bwd_multi", ptr_array([p.data for p in ps]), ptr_array([p.meta for p in ps]), dm_ptrs, ptr_array(dm_metas),
+             *tail, label=label, work=_hbm("setmax_bwd_h2_kernel<%s, false>" % ("true" if dm_is_f32 else "false"),
+                                           sum(bs) * l * h * w * c * 4.0 * (streams + 1)))
     return outs
 
 
