@@ -27,10 +27,12 @@ typedef short s8 __attribute__((ext_vector_type(8)));
 #define LDS_PTR(T) __attribute__((address_space(3))) T*
 
 constexpr int kWgMaxJobs = 6;
-constexpr int IN_PIX = 10 * 18;
-constexpr int IN_PLANE = IN_PIX * 64;          // 11,520 B
-constexpr int IN_PIECES = 23;                  // 2 planes x 180 pixels x 4 slots = 1440 slots -> 22.5 pieces
-constexpr int IN_BYTES = IN_PIECES * 1024;
+// Rows of a strip.  32 output channels (a2): one 32x32 block pair, the 8 waves split K, so an 8-row strip is ONE k-step (27 MFMAs,
+// 864 cycles) per wave between two barriers, a tile wait and the DMA issue -- 1,730 of a 4,490-cycle strip period on the matrix
+// pipe (tools/stamp_wgrad.py).  A 16-row strip gives the wave two k-steps for the same fixed costs.
+#ifndef UGN_WG_SR32
+#define UGN_WG_SR32 16
+#endif
 
 struct WgJob {
   const uint16_t* in;        // H2 [n][hw][hw][2][ci]
@@ -51,17 +53,28 @@ struct WGeo {
   static constexpr int COW = CO >= 64 ? 64 : 32;     // output channels of a workgroup
   static constexpr int PW = COW / 32;                // 32x32 block pairs
   static constexpr int KS = 8 / PW;                  // waves sharing a pair (K split)
-  static constexpr int RPW = 8 / KS;                 // pixel rows of a strip per wave
-  static constexpr int DZ_BYTES = PW * 16384;        // [plane][block][128 pixels][64 B]
-  // pooled layers: the gradient tile is the POOLED one, [plane][block][32 pooled pixels][64 B], + [32 pooled pixels][COW] argmax bytes
-  static constexpr int PZ_VAL = PW * 4096;
-  static constexpr int PZ_PIECES = PW * 5;           // 4 of values + 1 of argmax bytes per block
+  static constexpr int SR = CO >= 64 ? 8 : UGN_WG_SR32;   // pixel rows of a strip
+  static constexpr int RPW = SR / KS;                // pixel rows of a strip per wave
+  static constexpr int IN_PIX = (SR + 2) * 18;       // halo of the input chunk
+  static constexpr int IN_PLANE = IN_PIX * 64;       // 11,520 B (8 rows)
+  static constexpr int IN_SLOTS = 2 * IN_PIX * 4;    // 2 planes x pixels x 4 quarters: 1440 slots (8 rows) -> 22.5 pieces
+  static constexpr int IN_PIECES = (IN_SLOTS + 63) / 64;
+  static constexpr int IN_BYTES = IN_PIECES * 1024;
+  static constexpr int DZ_BLOCK = SR * 1024;         // [plane][block][SR x 16 pixels][64 B]
+  static constexpr int DZ_PLANE = PW * DZ_BLOCK;
+  static constexpr int DZ_BYTES = 2 * DZ_PLANE;
+  // pooled layers: the gradient tile is the POOLED one, [plane][block][SR / 2 x 8 pooled pixels][64 B], + [pooled pixels][COW] argmax bytes
+  static constexpr int PZ_PIX = SR * 4;
+  static constexpr int PZ_BLOCK = PZ_PIX * 64;
+  static constexpr int PZ_PLANE = PW * PZ_BLOCK;
+  static constexpr int PZ_VAL = 2 * PZ_PLANE;
+  static constexpr int PZ_PIECES = PZ_VAL / 1024 + PZ_PIX * COW / 1024;      // values + argmax bytes (8 rows: 4 + 1 per block)
   static constexpr int PZ_BYTES = PZ_PIECES * 1024;
 };
 // buffer set = input halo + gradient tile (pooled: the pooled gradient tile); + 32 KB of scratch for the K-split combine where a
 // set is smaller than that
 template <int CO, int POOLED>
-constexpr int wg_set_bytes() { return IN_BYTES + (POOLED ? WGeo<CO>::PZ_BYTES : WGeo<CO>::DZ_BYTES); }
+constexpr int wg_set_bytes() { return WGeo<CO>::IN_BYTES + (POOLED ? WGeo<CO>::PZ_BYTES : WGeo<CO>::DZ_BYTES); }
 template <int CO, int POOLED>
 constexpr int wg_lds_bytes() { return 2 * wg_set_bytes<CO, POOLED>() + (wg_set_bytes<CO, POOLED>() < 32768 ? 32768 : 0); }
 
@@ -81,9 +94,11 @@ constexpr int kWgStampPerWave = 4 + 6 * 60;
 template <int CI, int CO, int HW, int POOLED>
 __global__ __launch_bounds__(512, 2) void wgrad_mm_kernel(const WgJobs jt, const void* __restrict__ zeros) {
   using G = WGeo<CO>;
-  constexpr int COW = G::COW, PW = G::PW, KS = G::KS, RPW = G::RPW, SET = wg_set_bytes<CO, POOLED>();
+  constexpr int COW = G::COW, PW = G::PW, KS = G::KS, RPW = G::RPW, SR = G::SR, SET = wg_set_bytes<CO, POOLED>();
+  constexpr int IN_PIX = G::IN_PIX, IN_PLANE = G::IN_PLANE, IN_PIECES = G::IN_PIECES, IN_BYTES = G::IN_BYTES;
   constexpr int NCOC = CO / COW, NCOMBO = (CI / 32) * NCOC;
-  constexpr int SPX = HW / 16, SPI = (HW / 8) * SPX;        // strips per image row / per image
+  constexpr int SPX = HW / 16, SPI = (HW / SR) * SPX;       // strips per image row / per image
+  static_assert(HW % SR == 0 && (SR == 8 || SR == 16) && RPW * KS == SR && IN_PIX < 400, "strip geometry");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const LDS_PTR(char) lds = (LDS_PTR(char))smem;
   const unsigned sbase = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)lds);
@@ -131,7 +146,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_mm_kernel(const WgJobs jt, const
   // image); for the pooled staging tile bit 0 says "argmax bytes" (a base of their own).  Per strip a piece then costs a dozen
   // instructions, and the pieces are issued BETWEEN the taps of the MFMA loop (they were a phase of 1,200-3,700 cycles per
   // strip in which no wave multiplied; in-kernel stamps, tools/stamp_wgrad.py).
-  constexpr int NPIECE = IN_PIECES + (POOLED ? G::PZ_PIECES : PW * 16);
+  constexpr int NPIECE = IN_PIECES + (POOLED ? G::PZ_PIECES : G::DZ_BYTES / 1024);
   constexpr int NJ = (NPIECE + 7) / 8;
   int pk[NJ];
 #pragma unroll
@@ -139,33 +154,33 @@ __global__ __launch_bounds__(512, 2) void wgrad_mm_kernel(const WgJobs jt, const
     const int pi = wave + 8 * j;
     pk[j] = 127 << 5;
     if (pi < IN_PIECES) {
-      const int sg = pi * 64 + lane;                         // slot: [plane][pixel 0..179][quarter]
-      const int plane = sg >= 720 ? 1 : 0, rem = sg - 720 * plane;
+      const int sg = pi * 64 + lane;                         // slot: [plane][pixel 0..IN_PIX - 1][quarter]
+      const int plane = sg >= IN_PIX * 4 ? 1 : 0, rem = sg - IN_PIX * 4 * plane;
       const int pix = rem >> 2, c4 = rem & 3;
       const int row = (pix * 3641) >> 16, px = pix - row * 18;         // pix / 18 for pix < 400
       const int c4s = SWZ ? c4 ^ ((row & 1) << 1) : c4;              // (the quarter this LDS slot holds)
       const int off = ((row - 1) * HW + (px - 1)) * (CI * 4) + plane * CI * 2 + c4s * 16;
-      if (sg < 1440) pk[j] = (int)(((unsigned)off << 12) | (unsigned)(row << 5) | (unsigned)px);
+      if (sg < G::IN_SLOTS) pk[j] = (int)(((unsigned)off << 12) | (unsigned)(row << 5) | (unsigned)px);
     } else if (pi < NPIECE) {
       const int pd = pi - IN_PIECES;
       const int sg = pd * 64 + lane;
-      if constexpr (!POOLED) {                               // slot: [plane][block][pixel 0..127][quarter]
-        const int plane = sg / (PW * 512), rem = sg - plane * (PW * 512);
-        const int nb = rem >> 9, rem2 = rem & 511;
+      if constexpr (!POOLED) {                               // slot: [plane][block][pixel 0..SR * 16 - 1][quarter]
+        const int plane = sg / (PW * SR * 64), rem = sg - plane * (PW * SR * 64);
+        const int nb = rem / (SR * 64), rem2 = rem - nb * (SR * 64);
         const int pix = rem2 >> 2, c4 = rem2 & 3;
         const int c4s = SWZ ? c4 ^ (((pix >> 4) & 1) << 1) : c4;
         pk[j] = ((pix >> 4) * HW + (pix & 15)) * (CO * 4) + plane * CO * 2 + (coc * COW + nb * 32) * 2 + c4s * 16;
-      } else {                     // slots: [plane][block][pooled pixel 0..31][quarter], then [pooled pixel][COW / 16] of argmax bytes
-        constexpr int HP = HW / 2;
-        if (sg < PW * 256) {
-          const int plane = sg / (PW * 128), rem = sg - plane * (PW * 128);
-          const int nb = rem >> 7, rem2 = rem & 127;
+      } else {                     // slots: [plane][block][pooled pixel][quarter], then [pooled pixel][COW / 16] of argmax bytes
+        constexpr int HP = HW / 2, PZ_PIX = G::PZ_PIX;
+        if (sg < 2 * PW * PZ_PIX * 4) {
+          const int plane = sg / (PW * PZ_PIX * 4), rem = sg - plane * (PW * PZ_PIX * 4);
+          const int nb = rem / (PZ_PIX * 4), rem2 = rem - nb * (PZ_PIX * 4);
           const int pp = rem2 >> 2, c4 = rem2 & 3;
           pk[j] = (((pp >> 3) * HP + (pp & 7)) * (CO * 4) + plane * CO * 2 + (coc * COW + nb * 32) * 2 + c4 * 16) << 1;
         } else {
-          const int si = sg - PW * 256;
+          const int si = sg - 2 * PW * PZ_PIX * 4;
           const int pp = si / (COW / 16), part = si - pp * (COW / 16);
-          pk[j] = pp < 32 ? ((((pp >> 3) * HP + (pp & 7)) * CO + coc * COW + part * 16) << 1) | 1 : -2;     // (-2: pad slot)
+          pk[j] = pp < PZ_PIX ? ((((pp >> 3) * HP + (pp & 7)) * CO + coc * COW + part * 16) << 1) | 1 : -2;     // (-2: pad slot)
         }
       }
     }
@@ -176,7 +191,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_mm_kernel(const WgJobs jt, const
     const int jb = job_of(s), ls = s - jt.start[jb];
     const int img = ls / SPI, r = ls % SPI;
     StripSrc S;
-    S.sy0 = (r / SPX) * 8;
+    S.sy0 = (r / SPX) * SR;
     S.sx0 = (r % SPX) * 16;
     S.in = reinterpret_cast<const char*>(jt.job[jb].in) + (size_t)img * HW * HW * CI * 4 + cic * 64 +
            (size_t)(S.sy0 * HW + S.sx0) * (CI * 4);
@@ -219,9 +234,9 @@ __global__ __launch_bounds__(512, 2) void wgrad_mm_kernel(const WgJobs jt, const
   // gradient tile: 950-1,450 cycles per strip and a second barrier, tools/stamp_wgrad.py.)
   const int lane_off_p = (4 * h + q) * 64 + (16 * gh + 4 * p) * 2;
   auto pooled_frag = [&](int b, int y, h8& bh, h8& bl) {
-    const LDS_PTR(char) pv = lds + b * SET + IN_BYTES + pair * 2048 + (y >> 1) * 512 + lane_off_p;
+    const LDS_PTR(char) pv = lds + b * SET + IN_BYTES + pair * G::PZ_BLOCK + (y >> 1) * 512 + lane_off_p;
     const s4 ph = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s4))pv);
-    const s4 pl = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s4))(pv + PW * 2048));
+    const s4 pl = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s4))(pv + G::PZ_PLANE));
     const unsigned char* pi8 = reinterpret_cast<const unsigned char*>(smem) + b * SET + IN_BYTES + G::PZ_VAL +
                                ((y >> 1) * 8 + 4 * h) * COW + pair * 32 + (lane & 31);
     const unsigned posa = 2u * (unsigned)(y & 1);
@@ -242,9 +257,9 @@ __global__ __launch_bounds__(512, 2) void wgrad_mm_kernel(const WgJobs jt, const
   // the same for the 16x16x32 form: lane (channel 16 cot + (lane & 15), k group) = pixels 8 xh .. + 7 of strip row y.  (SWZ: the two
   // k groups of a pass are rows 2k, 2k + 1 of the same columns -- the same pooled pixels, identical addresses, a broadcast.)
   auto pooled_frag16 = [&](int b, int y, int xh, int cot, h8& bh, h8& bl) {
-    const LDS_PTR(char) pv = lds + b * SET + IN_BYTES + pair * 2048 + (y >> 1) * 512 + (4 * xh + q) * 64 + (16 * cot + 4 * p) * 2;
+    const LDS_PTR(char) pv = lds + b * SET + IN_BYTES + pair * G::PZ_BLOCK + (y >> 1) * 512 + (4 * xh + q) * 64 + (16 * cot + 4 * p) * 2;
     const s4 ph = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s4))pv);
-    const s4 pl = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s4))(pv + PW * 2048));
+    const s4 pl = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s4))(pv + G::PZ_PLANE));
     const unsigned char* pi8 = reinterpret_cast<const unsigned char*>(smem) + b * SET + IN_BYTES + G::PZ_VAL +
                                ((y >> 1) * 8 + 4 * xh) * COW + pair * 32 + 16 * cot + (lane & 15);
     const unsigned posa = 2u * (unsigned)(y & 1);
@@ -313,7 +328,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_mm_kernel(const WgJobs jt, const
     WG_STAMP(3);
     WG_STAMP(4);
     const LDS_PTR(char) in_b = lds + b * SET + ks * RPW * (18 * 64) + lane_off;
-    const LDS_PTR(char) dz_b = lds + b * SET + IN_BYTES + pair * 8192 + ks * RPW * (16 * 64) + lane_off;
+    const LDS_PTR(char) dz_b = lds + b * SET + IN_BYTES + pair * G::DZ_BLOCK + ks * RPW * (16 * 64) + lane_off;
     if constexpr (M16) {
       // lane (i = lane & 15, k group kg = lane >> 4): 8 consecutive pixels of the wave's 32.  SWZ (default): row kr = kg & 1, columns
       // 8 (kg >> 1) .. + 7 -- a ds_read_b64_tr_b16 is serviced as lanes 0-31, then 32-63 (MI355X_MICROARCH.md, LDS), i.e. k groups
@@ -325,7 +340,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_mm_kernel(const WgJobs jt, const
       const int kg = lane >> 4;
       const int kr = SWZ ? (kg & 1) : (kg >> 1), kx = SWZ ? (kg >> 1) : (kg & 1);
       const LDS_PTR(char) in_m0 = lds + b * SET + ks * RPW * (18 * 64) + (kr * 18 + 8 * kx + q) * 64 + 4 * p * 2;
-      const LDS_PTR(char) dz_m0 = lds + b * SET + IN_BYTES + pair * 8192 + ks * RPW * (16 * 64) + (kr * 16 + 8 * kx + q) * 64 + 4 * p * 2;
+      const LDS_PTR(char) dz_m0 = lds + b * SET + IN_BYTES + pair * G::DZ_BLOCK + ks * RPW * (16 * 64) + (kr * 16 + 8 * kx + q) * 64 + 4 * p * 2;
       // half c of the pixel record as this lane finds it on an even / odd tap row: [c ^ kr] (SWZ) or [c]
       const LDS_PTR(char) in_m[2] = {in_m0 + (SWZ ? 32 * kr : 0), in_m0 + (SWZ ? 32 * (kr ^ 1) : 32)};
       const LDS_PTR(char) dz_m[2] = {dz_m0 + (SWZ ? 32 * kr : 0), dz_m0 + (SWZ ? 32 * (kr ^ 1) : 32)};
@@ -336,7 +351,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_mm_kernel(const WgJobs jt, const
           pooled_frag16(b, ks * RPW + kr, kx, cot, bh[cot], bl[cot]);
         } else {
           bh[cot] = tr_pair(dz_m[cot], 0, 4 * 64);
-          bl[cot] = tr_pair(dz_m[cot], PW * 8192, PW * 8192 + 4 * 64);
+          bl[cot] = tr_pair(dz_m[cot], G::DZ_PLANE, G::DZ_PLANE + 4 * 64);
         }
       }
       // software pipeline over the taps: the 8 transposed reads of tap t + 1 (both input-channel tiles, both planes) go out before
@@ -393,7 +408,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_mm_kernel(const WgJobs jt, const
         pooled_frag(b, ks * RPW + rr, bh, bl);
       } else {
         bh = tr_pair(dz_b, (rr * 16) * 64, (rr * 16 + 4) * 64);
-        bl = tr_pair(dz_b, PW * 8192 + (rr * 16) * 64, PW * 8192 + (rr * 16 + 4) * 64);
+        bl = tr_pair(dz_b, G::DZ_PLANE + (rr * 16) * 64, G::DZ_PLANE + (rr * 16 + 4) * 64);
       }
       h8 fah[2], fal[2];                 // the input fragments of a tap, read one tap ahead (as in the M16 loop above)
       auto load_a = [&](int set, int t) {
@@ -513,7 +528,7 @@ int launch_wgrad(const uint16_t* const* in, const void* const* in_meta, const ui
                  const void* const* dz_meta, float* const* dw, const int* n, int njobs, float* ws, size_t ws_floats, hipStream_t st) {
   using G = WGeo<CO>;
   constexpr int NCOMBO = (CI / 32) * (CO / G::COW), NG = wg_ngroups<CI, CO>();
-  constexpr int SPI = (HW / 8) * (HW / 16);
+  constexpr int SPI = (HW / G::SR) * (HW / 16);
   constexpr int LDS = wg_lds_bytes<CO, POOLED>();
   static_assert(LDS <= 163840 && NG % 8 == 0, "geometry");
   auto kern = wgrad_mm_kernel<CI, CO, HW, POOLED>;
