@@ -406,6 +406,15 @@ int ugn_bf_setmax_fwd_f32_multi(const uint16_t* const* p, const uint16_t* const*
                                 const int* b, int njobs, int l, int npix, int c, void* stream);
 int ugn_bf_setmax_bwd_multi(const uint16_t* const* p, const void* const* dm, int dm_is_f32, const uint16_t* const* addend,
                             uint16_t* const* out, const int* b, int njobs, int l, int npix, int c, int apply_lrelu, void* stream);
+/* routed forms (as ugn_h2_setmax_*_routed_multi): the forward pass also writes the routing words u32 [b][npix][2][c], the gradient
+ * reads them instead of the l frames */
+int ugn_bf_setmax_fwd_routed_multi(const uint16_t* const* p, const uint16_t* const* addend, uint16_t* const* m, uint16_t* const* sum,
+                                   uint32_t* const* route, const int* b, int njobs, int l, int npix, int c, void* stream);
+int ugn_bf_setmax_fwd_f32_routed_multi(const uint16_t* const* p, const uint16_t* const* addend, float* const* m, float* const* sum,
+                                       uint32_t* const* route, const int* b, int njobs, int l, int npix, int c, void* stream);
+int ugn_bf_setmax_bwd_routed_multi(const uint32_t* const* route, const void* const* dm, int dm_is_f32, const uint16_t* const* addend,
+                                   uint16_t* const* out, const int* b, int njobs, int l, int npix, int c, int apply_lrelu,
+                                   void* stream);
 int ugn_bf_lrelu_bwd_multi(const uint16_t* const* g, const uint16_t* const* act, uint16_t* const* out, const size_t* npix, int njobs,
                            int c, void* stream);
 int ugn_bf_convert_multi(const float* const* x, uint16_t* const* y, const size_t* n, int njobs, void* stream);

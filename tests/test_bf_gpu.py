@@ -136,6 +136,18 @@ def test_bf16_set_pooling_and_friends(dev):
     ref = (O.setmax_bwd(p, p.max(axis=1), dm) + ad.reshape(b, l, hw, hw, c)) * np.where(p > 0, 1.0, 0.3)
     bf16.setmax_bwd_multi([pt], [bf16.from_f32(T(dm.astype(np.float32), dev))], [b], l, True, [adt], addends=[adt])
     close(bf16.to_numpy(adt).reshape(b, l, hw, hw, c), ref, 2.0 ** -8, "setmax bwd bf16")
+    # the routed form (what the engine runs): routing words from the forward pass, the gradient without the frames -- the same bits
+    route = torch.empty((b, hw, hw, 2, c), dtype=torch.int32, device=dev)
+    bf16.setmax_fwd_multi([pt], [b], l, ms=[m], routes=[route])
+    words = route.cpu().numpy().view(np.uint32)
+    bits = lambda mask: sum((mask[:, t].astype(np.uint32) << np.uint32(t)) for t in range(l))
+    assert np.array_equal(words[:, :, :, 0], bits(p == p.max(axis=1, keepdims=True))) and np.array_equal(words[:, :, :, 1], bits(p > 0))
+    adt2 = bf16.from_f32(T(ad.astype(np.float32), dev))
+    bf16.setmax_bwd_multi(None, [bf16.from_f32(T(dm.astype(np.float32), dev))], [b], l, True, [adt2], addends=[adt2], routes=[route])
+    assert torch.equal(adt2, adt), "routed gradient differs from the one that reads the frames"
+    route3 = torch.zeros_like(route)
+    bf16.setmax_fwd_f32_multi([pt], [b], l, [mf], None, None, routes=[route3])
+    assert torch.equal(route3, route)
     out = bf16.empty((b, hw, hw, c), dev)
     g = bfr(rng.normal(size=(b, hw, hw, c)))
     bf16.lrelu_bwd_multi([bf16.from_f32(T(g.astype(np.float32), dev))], [qt], [out])

@@ -115,6 +115,9 @@ PROTOTYPES = {
     "ugn_bf_setmax_fwd_multi": (_i, [C.POINTER(_p)] * 4 + [C.POINTER(_i), _i, _i, _i, _i, _p]),
     "ugn_bf_setmax_fwd_f32_multi": (_i, [C.POINTER(_p)] * 4 + [C.POINTER(_i), _i, _i, _i, _i, _p]),
     "ugn_bf_setmax_bwd_multi": (_i, [C.POINTER(_p)] * 2 + [_i] + [C.POINTER(_p)] * 2 + [C.POINTER(_i), _i, _i, _i, _i, _i, _p]),
+    "ugn_bf_setmax_fwd_routed_multi": (_i, [C.POINTER(_p)] * 5 + [C.POINTER(_i), _i, _i, _i, _i, _p]),
+    "ugn_bf_setmax_fwd_f32_routed_multi": (_i, [C.POINTER(_p)] * 5 + [C.POINTER(_i), _i, _i, _i, _i, _p]),
+    "ugn_bf_setmax_bwd_routed_multi": (_i, [C.POINTER(_p)] * 2 + [_i] + [C.POINTER(_p)] * 2 + [C.POINTER(_i), _i, _i, _i, _i, _i, _p]),
     "ugn_bf_lrelu_bwd_multi": (_i, [C.POINTER(_p)] * 3 + [C.POINTER(_sz), _i, _i, _p]),
     "ugn_bf_convert_multi": (_i, [C.POINTER(_p)] * 2 + [C.POINTER(_sz), _i, _p]),
     "ugn_hpp_bwd_b4bf_multi": (_i, [C.POINTER(_p)] * 6 + [C.POINTER(_i), _i, _p]),

@@ -163,27 +163,38 @@ def conv5x5_in_wgrad(x, dz1, dw, sign=None):
     return dw
 
 
-def setmax_fwd_multi(ps, bs, l, ms=None, addends=None, sums=None):
+def setmax_fwd_multi(ps, bs, l, ms=None, addends=None, sums=None, routes=None):
+    """routes (optional): int32 tensors [b, h, w, 2, c] that receive the routing words (h2.setmax_fwd_h2_multi)."""
     n, h, w, c = ps[0].shape
-    call("ugn_bf_setmax_fwd_multi", ptr_array(ps), _opt(addends), _opt(ms), _opt(sums), _ints(bs), len(ps), l, h * w, c, _stream(),
-         label="setmax_fwd[%dx%dx%d bf16]" % (h, w, c), work=_hbm("setmax_fwd_bf_kernel<false>", sum(bs) * (l + 1.0) * h * w * c * 2))
+    call("ugn_bf_setmax_fwd_routed_multi", ptr_array(ps), _opt(addends), _opt(ms), _opt(sums), _opt(routes), _ints(bs), len(ps), l, h * w, c,
+         _stream(), label="setmax_fwd[%dx%dx%d bf16]" % (h, w, c),
+         work=_hbm("setmax_fwd_bf_kernel<false>", sum(bs) * ((l + 1.0) * 2 + (8.0 if routes is not None else 0.0)) * h * w * c))
     return ms, sums
 
 
-def setmax_fwd_f32_multi(ps, bs, l, ms, addends, sums):
+def setmax_fwd_f32_multi(ps, bs, l, ms, addends, sums, routes=None):
     n, h, w, c = ps[0].shape
-    call("ugn_bf_setmax_fwd_f32_multi", ptr_array(ps), _opt(addends), _opt(ms), _opt(sums), _ints(bs), len(ps), l, h * w, c, _stream(),
-         label="setmax_fwd[%dx%dx%d bf16->f32]" % (h, w, c), work=_hbm("setmax_fwd_bf_kernel<true>", sum(bs) * (l + 2.0) * h * w * c * 2))
+    call("ugn_bf_setmax_fwd_f32_routed_multi", ptr_array(ps), _opt(addends), _opt(ms), _opt(sums), _opt(routes), _ints(bs), len(ps), l,
+         h * w, c, _stream(), label="setmax_fwd[%dx%dx%d bf16->f32]" % (h, w, c),
+         work=_hbm("setmax_fwd_bf_kernel<true>", sum(bs) * ((l + 2.0) * 2 + (8.0 if routes is not None else 0.0)) * h * w * c))
     return ms, sums
 
 
-def setmax_bwd_multi(ps, dms, bs, l, lrelu, outs, addends=None, dm_is_f32=False):
-    n, h, w, c = ps[0].shape
-    call("ugn_bf_setmax_bwd_multi", ptr_array(ps), ptr_array(dms), int(bool(dm_is_f32)), _opt(addends), ptr_array(outs), _ints(bs),
-         len(ps), l, h * w, c, int(bool(lrelu)), _stream(),
-         label="setmax_bwd[%dx%dx%d bf16%s]" % (h, w, c, " +addend" if addends is not None else ""),
-         work=_hbm("setmax_bwd_bf_kernel<%s>" % ("true" if dm_is_f32 else "false"),
-                   sum(bs) * l * h * w * c * 2.0 * (3 if addends is not None else 2)))
+def setmax_bwd_multi(ps, dms, bs, l, lrelu, outs, addends=None, dm_is_f32=False, routes=None):
+    """routes: the routing words of the forward pass -- with them the frames ps are not read (same results)."""
+    n, h, w, c = outs[0].shape
+    tail = (ptr_array(dms), int(bool(dm_is_f32)), _opt(addends), ptr_array(outs), _ints(bs), len(outs), l, h * w, c, int(bool(lrelu)),
+            _stream())
+    label = "setmax_bwd[%dx%dx%d bf16%s]" % (h, w, c, " +addend" if addends is not None else "")
+    streams = 2 if addends is not None else 1
+    if routes is not None:
+        call("ugn_bf_setmax_bwd_routed_multi", ptr_array(routes), *tail, label=label,
+             work=_hbm("setmax_bwd_bf_kernel<%s, true>" % ("true" if dm_is_f32 else "false"),
+                       sum(bs) * h * w * c * (l * 2.0 * streams + 10.0)))
+    else:
+        call("ugn_bf_setmax_bwd_multi", ptr_array(ps), *tail, label=label,
+             work=_hbm("setmax_bwd_bf_kernel<%s, false>" % ("true" if dm_is_f32 else "false"),
+                       sum(bs) * l * h * w * c * 2.0 * (streams + 1)))
     return outs
 
 

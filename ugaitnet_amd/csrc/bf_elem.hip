@@ -38,8 +38,11 @@ struct SetJobs {
   H2Meta* sum_meta[kJobs];
   float* m_f32[kJobs];           // fwd, F32OUT: maxima / sums as fp32 [b][pix][c] (the inputs of HPP)
   float* sum_f32[kJobs];
-  int b[kJobs];
+  uint32_t* route[kJobs];        // routing words u32 [b][pix][2][c] (h2_elem.hip): written by the forward pass when set, read by the
+  int b[kJobs];                  // gradient INSTEAD of the frames
 };
+
+struct Route4 { uint4 mx, sg; };
 
 // grid: (pixel-channel quads / 128, b, jobs).  npix = pixels per image, c = channels.
 template <bool F32OUT>
@@ -54,13 +57,37 @@ __global__ __launch_bounds__(128) void setmax_fwd_bf_kernel(const SetJobs jt, in
   const uint16_t* src = jt.p[j] + ((size_t)b * l * npix + pix) * rec;
   const size_t fstride = (size_t)npix * rec;
   V4 mx = ld4(src, c, ch);
-  int t = 1;
-  for (; t + 4 <= l; t += 4) {       // four frames (8 loads of 8 bytes) in flight per lane
-    const V4 v0 = ld4(src + (size_t)t * fstride, c, ch), v1 = ld4(src + (size_t)(t + 1) * fstride, c, ch);
-    const V4 v2 = ld4(src + (size_t)(t + 2) * fstride, c, ch), v3 = ld4(src + (size_t)(t + 3) * fstride, c, ch);
-    mx = max4(max4(mx, v0), max4(max4(v1, v2), v3));
+  if (jt.route[j]) {                 // one pass: a frame above the running maximum restarts its bit mask, an equal one joins it
+    Route4 r = {make_uint4(1u, 1u, 1u, 1u), make_uint4(mx.x > 0.f ? 1u : 0u, mx.y > 0.f ? 1u : 0u, mx.z > 0.f ? 1u : 0u, mx.w > 0.f ? 1u : 0u)};
+    auto take = [&](float v, float& m, unsigned& mb, unsigned& sb, int t) {
+      const unsigned bit = 1u << t;
+      mb = v > m ? bit : (v == m ? mb | bit : mb);
+      m = fmaxf(m, v);
+      sb |= v > 0.f ? bit : 0u;
+    };
+    auto take4 = [&](V4 v, int t) {
+      take(v.x, mx.x, r.mx.x, r.sg.x, t); take(v.y, mx.y, r.mx.y, r.sg.y, t);
+      take(v.z, mx.z, r.mx.z, r.sg.z, t); take(v.w, mx.w, r.mx.w, r.sg.w, t);
+    };
+    int t = 1;
+    for (; t + 4 <= l; t += 4) {
+      const V4 v0 = ld4(src + (size_t)t * fstride, c, ch), v1 = ld4(src + (size_t)(t + 1) * fstride, c, ch);
+      const V4 v2 = ld4(src + (size_t)(t + 2) * fstride, c, ch), v3 = ld4(src + (size_t)(t + 3) * fstride, c, ch);
+      take4(v0, t); take4(v1, t + 1); take4(v2, t + 2); take4(v3, t + 3);
+    }
+    for (; t < l; ++t) take4(ld4(src + (size_t)t * fstride, c, ch), t);
+    uint32_t* rp = jt.route[j] + ((size_t)b * npix + pix) * 2 * c + ch;
+    *reinterpret_cast<uint4*>(rp) = r.mx;
+    *reinterpret_cast<uint4*>(rp + c) = r.sg;
+  } else {
+    int t = 1;
+    for (; t + 4 <= l; t += 4) {       // four frames (8 loads of 8 bytes) in flight per lane
+      const V4 v0 = ld4(src + (size_t)t * fstride, c, ch), v1 = ld4(src + (size_t)(t + 1) * fstride, c, ch);
+      const V4 v2 = ld4(src + (size_t)(t + 2) * fstride, c, ch), v3 = ld4(src + (size_t)(t + 3) * fstride, c, ch);
+      mx = max4(max4(mx, v0), max4(max4(v1, v2), v3));
+    }
+    for (; t < l; ++t) mx = max4(mx, ld4(src + (size_t)t * fstride, c, ch));
   }
-  for (; t < l; ++t) mx = max4(mx, ld4(src + (size_t)t * fstride, c, ch));
   const size_t o = (size_t)b * npix + pix;
   V4 sm = mx;
   if (has_add) {
@@ -78,7 +105,7 @@ __global__ __launch_bounds__(128) void setmax_fwd_bf_kernel(const SetJobs jt, in
 
 // TF reduce_max gradient (equal split among the maxima) + the second gradient path + LeakyReLU'(p), as setmax_bwd_kernel of
 // pool_set.hip:   out = ((p == max ? dm / #maxima : 0) + addend) * LeakyReLU'(p)
-template <bool DM_F32>
+template <bool DM_F32, bool ROUTED>
 __global__ __launch_bounds__(128) void setmax_bwd_bf_kernel(const SetJobs jt, int l, int npix, int c, int lrelu) {
   const int j = blockIdx.z, b = blockIdx.y;
   const int e = blockIdx.x * 128 + threadIdx.x, q = c / 4;
@@ -87,23 +114,33 @@ __global__ __launch_bounds__(128) void setmax_bwd_bf_kernel(const SetJobs jt, in
   if (e >= npix * q) return;
   const int pix = e / q, ch = (e - pix * q) * 4;
   const size_t rec = (size_t)c, fstride = (size_t)npix * rec;
-  const uint16_t* src = jt.p[j] + ((size_t)b * l * npix + pix) * rec;
-  V4 v[MAXL];
-#pragma unroll
-  for (int t = 0; t < MAXL; ++t)
-    if (t < l) v[t] = ld4(src + (size_t)t * fstride, c, ch);
-  V4 mx = v[0];
-#pragma unroll
-  for (int t = 1; t < MAXL; ++t)
-    if (t < l) mx = max4(mx, v[t]);
-  V4 cnt = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int t = 0; t < MAXL; ++t)
-    if (t < l) {
-      cnt.x += v[t].x == mx.x ? 1.f : 0.f; cnt.y += v[t].y == mx.y ? 1.f : 0.f;
-      cnt.z += v[t].z == mx.z ? 1.f : 0.f; cnt.w += v[t].w == mx.w ? 1.f : 0.f;
-    }
   const size_t o = (size_t)b * npix + pix;
+  // which frames hold the maximum / are positive: the forward pass's routing words, or the frames themselves
+  Route4 r = {make_uint4(0u, 0u, 0u, 0u), make_uint4(0u, 0u, 0u, 0u)};
+  if constexpr (ROUTED) {
+    const uint32_t* rp = jt.route[j] + o * 2 * c + ch;
+    r.mx = *reinterpret_cast<const uint4*>(rp);
+    r.sg = *reinterpret_cast<const uint4*>(rp + c);
+  } else {
+    const uint16_t* src = jt.p[j] + ((size_t)b * l * npix + pix) * rec;
+    V4 v[MAXL];
+#pragma unroll
+    for (int t = 0; t < MAXL; ++t)
+      if (t < l) v[t] = ld4(src + (size_t)t * fstride, c, ch);
+    V4 mx = v[0];
+#pragma unroll
+    for (int t = 1; t < MAXL; ++t)
+      if (t < l) mx = max4(mx, v[t]);
+#pragma unroll
+    for (int t = 0; t < MAXL; ++t)
+      if (t < l) {
+        r.mx.x |= (v[t].x == mx.x ? 1u : 0u) << t; r.mx.y |= (v[t].y == mx.y ? 1u : 0u) << t;
+        r.mx.z |= (v[t].z == mx.z ? 1u : 0u) << t; r.mx.w |= (v[t].w == mx.w ? 1u : 0u) << t;
+        r.sg.x |= (v[t].x > 0.f ? 1u : 0u) << t; r.sg.y |= (v[t].y > 0.f ? 1u : 0u) << t;
+        r.sg.z |= (v[t].z > 0.f ? 1u : 0u) << t; r.sg.w |= (v[t].w > 0.f ? 1u : 0u) << t;
+      }
+  }
+  const V4 cnt = {(float)__popc(r.mx.x), (float)__popc(r.mx.y), (float)__popc(r.mx.z), (float)__popc(r.mx.w)};
   V4 g;
   if constexpr (DM_F32) {
     const float4 t4 = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(jt.dm[j]) + o * c + ch);
@@ -114,19 +151,28 @@ __global__ __launch_bounds__(128) void setmax_bwd_bf_kernel(const SetJobs jt, in
   const V4 gs = {g.x / cnt.x, g.y / cnt.y, g.z / cnt.z, g.w / cnt.w};
   const uint16_t* asrc = has_add ? jt.add[j] + ((size_t)b * l * npix + pix) * rec : nullptr;
   uint16_t* dst = jt.m[j] + ((size_t)b * l * npix + pix) * rec;
-  auto route = [&](float vv, float mm, float gg, float aa) {
-    float r = (vv == mm ? gg : 0.f) + aa;
-    if (lrelu) r *= ugn_lrelu_slope(vv);
-    return r;
+  auto route = [&](unsigned mbits, unsigned sbits, int t, float gg, float aa) {
+    float rr = ((mbits >> t) & 1u ? gg : 0.f) + aa;
+    if (lrelu) rr *= (sbits >> t) & 1u ? 1.f : UGN_LRELU_ALPHA;
+    return rr;
   };
+  constexpr int PF = 4;          // addends of four frames in flight
 #pragma unroll
-  for (int t = 0; t < MAXL; ++t)
-    if (t < l) {
-      V4 a = {0.f, 0.f, 0.f, 0.f};
-      if (has_add) a = ld4(asrc + (size_t)t * fstride, c, ch);
-      st4(dst + (size_t)t * fstride, c, ch, {route(v[t].x, mx.x, gs.x, a.x), route(v[t].y, mx.y, gs.y, a.y),
-                                             route(v[t].z, mx.z, gs.z, a.z), route(v[t].w, mx.w, gs.w, a.w)});
+  for (int t0 = 0; t0 < MAXL; t0 += PF) {
+    V4 a[PF];
+#pragma unroll
+    for (int k = 0; k < PF; ++k) {
+      a[k] = {0.f, 0.f, 0.f, 0.f};
+      if (has_add && t0 + k < l) a[k] = ld4(asrc + (size_t)(t0 + k) * fstride, c, ch);
     }
+#pragma unroll
+    for (int k = 0; k < PF; ++k) {
+      const int t = t0 + k;
+      if (t < l)
+        st4(dst + (size_t)t * fstride, c, ch, {route(r.mx.x, r.sg.x, t, gs.x, a[k].x), route(r.mx.y, r.sg.y, t, gs.y, a[k].y),
+                                               route(r.mx.z, r.sg.z, t, gs.z, a[k].z), route(r.mx.w, r.sg.w, t, gs.w, a[k].w)});
+    }
+  }
 }
 
 struct EltJobs {
@@ -177,12 +223,28 @@ static int fill(SetJobs& jt, const uint16_t* const* p, const uint16_t* const* ad
   return 0;
 }
 
-/* bf16 set pooling: m (optional) = max over the l frames, sum = m + addend (bf16 [b][npix][c]) */
+static int set_routes(SetJobs& jt, uint32_t* const* route, int njobs, int l, const char* who) {
+  for (int j = 0; j < njobs; ++j) jt.route[j] = route ? route[j] : nullptr;
+  UGN_REQUIRE(!route || l <= MAXL, "%s: routing words hold at most %d frames", who, MAXL);
+  return 0;
+}
+
+/* bf16 set pooling: m (optional) = max over the l frames, sum = m + addend (bf16 [b][npix][c]); route (optional): routing words
+ * u32 [b][npix][2][c] as ugn_h2_setmax_fwd_routed_multi writes them */
+extern "C" int ugn_bf_setmax_fwd_routed_multi(const uint16_t* const* p, const uint16_t* const* addend, uint16_t* const* m,
+                                              uint16_t* const* sum, uint32_t* const* route, const int* b, int njobs, int l, int npix,
+                                              int c, void* stream);
 extern "C" int ugn_bf_setmax_fwd_multi(const uint16_t* const* p, const uint16_t* const* addend, uint16_t* const* m,
                                        uint16_t* const* sum, const int* b, int njobs, int l, int npix, int c, void* stream) {
+  return ugn_bf_setmax_fwd_routed_multi(p, addend, m, sum, nullptr, b, njobs, l, npix, c, stream);
+}
+extern "C" int ugn_bf_setmax_fwd_routed_multi(const uint16_t* const* p, const uint16_t* const* addend, uint16_t* const* m,
+                                              uint16_t* const* sum, uint32_t* const* route, const int* b, int njobs, int l, int npix,
+                                              int c, void* stream) {
   SetJobs jt = {};
   int bmax;
   if (int rc = fill(jt, p, addend, b, njobs, &bmax, "ugn_bf_setmax_fwd_multi")) return rc;
+  if (int rc = set_routes(jt, route, njobs, l, "ugn_bf_setmax_fwd_routed_multi")) return rc;
   UGN_REQUIRE(l > 0 && npix > 0 && c > 0 && c % 4 == 0, "ugn_bf_setmax_fwd_multi: c must be a multiple of 4");
   for (int j = 0; j < njobs; ++j) {
     jt.m[j] = m ? m[j] : nullptr; jt.sum[j] = sum ? sum[j] : nullptr;
@@ -196,11 +258,20 @@ extern "C" int ugn_bf_setmax_fwd_multi(const uint16_t* const* p, const uint16_t*
 }
 
 /* the same with fp32 outputs [b][npix][c] (the inputs of HPP) */
+extern "C" int ugn_bf_setmax_fwd_f32_routed_multi(const uint16_t* const* p, const uint16_t* const* addend, float* const* m,
+                                                  float* const* sum, uint32_t* const* route, const int* b, int njobs, int l,
+                                                  int npix, int c, void* stream);
 extern "C" int ugn_bf_setmax_fwd_f32_multi(const uint16_t* const* p, const uint16_t* const* addend, float* const* m, float* const* sum,
                                            const int* b, int njobs, int l, int npix, int c, void* stream) {
+  return ugn_bf_setmax_fwd_f32_routed_multi(p, addend, m, sum, nullptr, b, njobs, l, npix, c, stream);
+}
+extern "C" int ugn_bf_setmax_fwd_f32_routed_multi(const uint16_t* const* p, const uint16_t* const* addend, float* const* m,
+                                                  float* const* sum, uint32_t* const* route, const int* b, int njobs, int l,
+                                                  int npix, int c, void* stream) {
   SetJobs jt = {};
   int bmax;
   if (int rc = fill(jt, p, addend, b, njobs, &bmax, "ugn_bf_setmax_fwd_f32_multi")) return rc;
+  if (int rc = set_routes(jt, route, njobs, l, "ugn_bf_setmax_fwd_f32_routed_multi")) return rc;
   UGN_REQUIRE(l > 0 && npix > 0 && c > 0 && c % 4 == 0, "ugn_bf_setmax_fwd_f32_multi: c must be a multiple of 4");
   for (int j = 0; j < njobs; ++j) {
     jt.m_f32[j] = m ? m[j] : nullptr; jt.sum_f32[j] = sum ? sum[j] : nullptr;
@@ -213,26 +284,54 @@ extern "C" int ugn_bf_setmax_fwd_f32_multi(const uint16_t* const* p, const uint1
   return 0;
 }
 
-/* out = ((p == max over l ? dm / #maxima : 0) + addend) * (apply_lrelu ? LeakyReLU'(p) : 1); dm bf16 [b][npix][c] or (dm_is_f32) fp32 */
+/* out = ((p == max over l ? dm / #maxima : 0) + addend) * (apply_lrelu ? LeakyReLU'(p) : 1); dm bf16 [b][npix][c] or (dm_is_f32) fp32.
+ * With `route` (the forward pass's routing words) the frames p are not read (p may be null): same results. */
+static int bf_setmax_bwd_any(const uint16_t* const* p, const uint32_t* const* route, const void* const* dm, int dm_is_f32,
+                             const uint16_t* const* addend, uint16_t* const* out, const int* b, int njobs, int l, int npix, int c,
+                             int apply_lrelu, void* stream, const char* who) {
+  SetJobs jt = {};
+  int bmax = 0;
+  if (route) {
+    UGN_REQUIRE(b && njobs >= 1 && njobs <= kJobs, "%s: bad arguments (1..%d jobs)", who, kJobs);
+    for (int j = 0; j < njobs; ++j) {
+      UGN_REQUIRE(route[j] && b[j] > 0, "%s: null routing words or b <= 0 in job %d", who, j);
+      jt.route[j] = const_cast<uint32_t*>(route[j]);
+      jt.add[j] = addend ? addend[j] : nullptr;
+      jt.b[j] = b[j];
+      if (b[j] > bmax) bmax = b[j];
+    }
+  } else if (int rc = fill(jt, p, addend, b, njobs, &bmax, who)) {
+    return rc;
+  }
+  UGN_REQUIRE(dm && out, "%s: null array", who);
+  UGN_REQUIRE(l > 0 && l <= MAXL && npix > 0 && c > 0 && c % 4 == 0, "%s: l must be 1..%d, c a multiple of 4", who, MAXL);
+  for (int j = 0; j < njobs; ++j) {
+    UGN_REQUIRE(dm[j] && out[j], "%s: null pointer in job %d", who, j);
+    jt.dm[j] = dm[j]; jt.m[j] = out[j];
+  }
+  const dim3 grid((unsigned)(((size_t)npix * (c / 4) + 127) / 128), bmax, njobs);
+  hipStream_t st = (hipStream_t)stream;
+  if (route) {
+    if (dm_is_f32) hipLaunchKernelGGL((setmax_bwd_bf_kernel<true, true>), grid, dim3(128), 0, st, jt, l, npix, c, apply_lrelu);
+    else hipLaunchKernelGGL((setmax_bwd_bf_kernel<false, true>), grid, dim3(128), 0, st, jt, l, npix, c, apply_lrelu);
+  } else {
+    if (dm_is_f32) hipLaunchKernelGGL((setmax_bwd_bf_kernel<true, false>), grid, dim3(128), 0, st, jt, l, npix, c, apply_lrelu);
+    else hipLaunchKernelGGL((setmax_bwd_bf_kernel<false, false>), grid, dim3(128), 0, st, jt, l, npix, c, apply_lrelu);
+  }
+  UGN_CHECK_LAUNCH("bf_setmax_bwd");
+  return 0;
+}
 extern "C" int ugn_bf_setmax_bwd_multi(const uint16_t* const* p, const void* const* dm, int dm_is_f32, const uint16_t* const* addend,
                                        uint16_t* const* out, const int* b, int njobs, int l, int npix, int c, int apply_lrelu,
                                        void* stream) {
-  SetJobs jt = {};
-  int bmax;
-  if (int rc = fill(jt, p, addend, b, njobs, &bmax, "ugn_bf_setmax_bwd_multi")) return rc;
-  UGN_REQUIRE(dm && out, "ugn_bf_setmax_bwd_multi: null array");
-  UGN_REQUIRE(l > 0 && l <= MAXL && npix > 0 && c > 0 && c % 4 == 0, "ugn_bf_setmax_bwd_multi: l must be 1..%d, c a multiple of 4", MAXL);
-  for (int j = 0; j < njobs; ++j) {
-    UGN_REQUIRE(dm[j] && out[j], "ugn_bf_setmax_bwd_multi: null pointer in job %d", j);
-    jt.dm[j] = dm[j]; jt.m[j] = out[j];
-  }
-  const unsigned gx = (unsigned)(((size_t)npix * (c / 4) + 127) / 128);
-  if (dm_is_f32)
-    hipLaunchKernelGGL(setmax_bwd_bf_kernel<true>, dim3(gx, bmax, njobs), dim3(128), 0, (hipStream_t)stream, jt, l, npix, c, apply_lrelu);
-  else
-    hipLaunchKernelGGL(setmax_bwd_bf_kernel<false>, dim3(gx, bmax, njobs), dim3(128), 0, (hipStream_t)stream, jt, l, npix, c, apply_lrelu);
-  UGN_CHECK_LAUNCH("bf_setmax_bwd");
-  return 0;
+  return bf_setmax_bwd_any(p, nullptr, dm, dm_is_f32, addend, out, b, njobs, l, npix, c, apply_lrelu, stream, "ugn_bf_setmax_bwd_multi");
+}
+extern "C" int ugn_bf_setmax_bwd_routed_multi(const uint32_t* const* route, const void* const* dm, int dm_is_f32,
+                                              const uint16_t* const* addend, uint16_t* const* out, const int* b, int njobs, int l,
+                                              int npix, int c, int apply_lrelu, void* stream) {
+  UGN_REQUIRE(route, "ugn_bf_setmax_bwd_routed_multi: null routing words");
+  return bf_setmax_bwd_any(nullptr, route, dm, dm_is_f32, addend, out, b, njobs, l, npix, c, apply_lrelu, stream,
+                           "ugn_bf_setmax_bwd_routed_multi");
 }
 
 extern "C" int ugn_bf_lrelu_bwd_multi(const uint16_t* const* g, const uint16_t* const* act, uint16_t* const* out, const size_t* npix,

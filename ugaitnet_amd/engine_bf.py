@@ -10,6 +10,7 @@ from __future__ import annotations
 import torch
 
 from . import bf16, ops
+from .engine_h2 import SET_ROUTED
 
 F32 = torch.float32
 U8 = torch.uint8
@@ -70,7 +71,9 @@ def forward_bf(encs, xs):
     i2s = [S[i].t("i2", (geo[i][2], 32, 32, 32), U8) for i in R]
     bf16.conv3x3_fwd_multi(a1s, [s.wf("a2") for s in S], 32, True, p2s, i2s)
     m1s = [S[i].t("m1", (geo[i][0], 32, 32, 32)) for i in R]
-    bf16.setmax_fwd_multi(p2s, bs, l0, ms=m1s)
+    # routing words of the three set poolings (engine_h2.forward_h2): their gradients read these instead of the l frames
+    routes = lambda key, hw, c: [S[i].t(key, (geo[i][0], hw, hw, 2, c), I32) for i in R] if SET_ROUTED and l0 <= 32 else None
+    bf16.setmax_fwd_multi(p2s, bs, l0, ms=m1s, routes=routes("r1", 32, 32))
 
     def pair_layer(na, nb, xa, xb, cout, hw, pool, ka, kb, ia=None, ib=None):
         ho = hw // 2 if pool else hw
@@ -84,12 +87,12 @@ def forward_bf(encs, xs):
     a3s, b1s = pair_layer("a3", "b1", p2s, m1s, 64, 32, False, "a3", "b1")
     p4s, q2s = pair_layer("a4", "b2", a3s, b1s, 64, 32, True, "p4", "q2", "i4", "j2")
     s2s = [S[i].t("s2", (geo[i][0], 16, 16, 64)) for i in R]
-    bf16.setmax_fwd_multi(p4s, bs, l0, addends=q2s, sums=s2s)
+    bf16.setmax_fwd_multi(p4s, bs, l0, addends=q2s, sums=s2s, routes=routes("r2", 16, 64))
     a5s, b3s = pair_layer("a5", "b3", p4s, s2s, 128, 16, False, "a5", "b3")
     a6s, b4s = pair_layer("a6", "b4", a5s, b3s, 128, 16, False, "a6", "b4")
     m3s = [S[i].t("m3", (geo[i][0], 16, 16, 128), F32) for i in R]
     s3s = [S[i].t("s3", (geo[i][0], 16, 16, 128), F32) for i in R]
-    bf16.setmax_fwd_f32_multi(a6s, bs, l0, m3s, b4s, s3s)
+    bf16.setmax_fwd_f32_multi(a6s, bs, l0, m3s, b4s, s3s, routes=routes("r3", 16, 128))
     feats = ops.hpp_fwd_multi(m3s, s3s, [S[i].t("feat", (NBINS, geo[i][0], FEAT), F32) for i in R])
     outs = ops.binfc_fwd_multi(feats, [e.W("fc") for e in encs], [S[i].t("out", (NBINS, geo[i][0], HIDDEN), F32) for i in R])
     for e, o in zip(encs, outs):
@@ -105,6 +108,7 @@ def backward_bf(encs, douts, side):
     R = range(k)
     bs, l0 = [g[0] for g in geo], geo[0][1]
     T = lambda key: [s.bufs[key] for s in S]
+    RT = lambda key: T(key) if SET_ROUTED and l0 <= 32 else None       # routing words of a set pooling (forward_bf)
     fc_args = (T("feat"), [e.W("fc") for e in encs], douts, [e.G("fc") for e in encs],
                                     [S[i].t("dfeat", (NBINS, geo[i][0], FEAT), F32) for i in R])
     ops.binfc_bwd_multi(*fc_args, parts=2)            # dfeat: the rest of the backward pass waits for it
@@ -115,7 +119,8 @@ def backward_bf(encs, douts, side):
     dzb4f = [S[i].t("dzb4f", (geo[i][0], 16, 16, 128), F32) for i in R]
     bf16.hpp_bwd_b4_multi(T("m3"), T("s3"), T("b4"), dfeats, dm3s, dzb4f)
     dzb4 = bf16.convert_multi(dzb4f, [S[i].t("dzb4", (geo[i][0], 16, 16, 128)) for i in R])
-    dz6 = bf16.setmax_bwd_multi(T("a6"), dm3s, bs, l0, True, [S[i].t("dz6", (geo[i][2], 16, 16, 128)) for i in R], dm_is_f32=True)
+    dz6 = bf16.setmax_bwd_multi(T("a6"), dm3s, bs, l0, True, [S[i].t("dz6", (geo[i][2], 16, 16, 128)) for i in R], dm_is_f32=True,
+                                routes=RT("r3"))
 
     def wgrad(na, nb, xa, xb, dza, dzb, cout, ia=None, ib=None):
         with side(dev):
@@ -135,12 +140,12 @@ def backward_bf(encs, douts, side):
     wgrad("a5", "b3", T("p4"), T("s2"), dz5, dzb3, 128)
     raw4, ds2 = dgrad("a5", "b3", dz5, dzb3, 16, 64, 128, "g4", "ds2")
     dq2 = bf16.lrelu_bwd_multi(ds2, T("q2"), [S[i].t("dq2", (geo[i][0], 16, 16, 64)) for i in R])
-    dp4 = bf16.setmax_bwd_multi(T("p4"), ds2, bs, l0, True, raw4, addends=raw4)          # in place over the second gradient path
+    dp4 = bf16.setmax_bwd_multi(T("p4"), ds2, bs, l0, True, raw4, addends=raw4, routes=RT("r2"))          # in place over the second gradient path
     wgrad("a4", "b2", T("a3"), T("b1"), dp4, dq2, 64, T("i4"), T("j2"))
     dz3, dzb1 = dgrad("a4", "b2", dp4, dq2, 32, 64, 64, "dz3", "dzb1", T("i4"), T("j2"), T("a3"), T("b1"))
     wgrad("a3", "b1", T("p2"), T("m1"), dz3, dzb1, 64)
     raw2, dm1 = dgrad("a3", "b1", dz3, dzb1, 32, 32, 64, "g2", "dm1")
-    dp2 = bf16.setmax_bwd_multi(T("p2"), dm1, bs, l0, True, raw2, addends=raw2)
+    dp2 = bf16.setmax_bwd_multi(T("p2"), dm1, bs, l0, True, raw2, addends=raw2, routes=RT("r1"))
     i2 = T("i2")
     with side(dev):
         bf16.conv3x3_wgrad_multi(T("a1"), dp2, 32, [e.G("a2") for e in encs], dz_idxs=i2)
