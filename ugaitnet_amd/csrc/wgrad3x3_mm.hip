@@ -48,12 +48,17 @@ struct WgJobs {
   int gstep;                 // groups per combination that the grid holds at once (= ngroups on the full grid)
 };
 
-template <int CO>
+// Pooled layers on the SPARSE matrix pipe (wgrad_mm_kernel<..., SP = 1>; see the strip loop): 16-row strips, a wave = 4 rows = K 64.
+#ifndef UGN_WG_SPARSE
+#define UGN_WG_SPARSE 1
+#endif
+constexpr int wg_default_sr(int co) { return co >= 64 ? 8 : UGN_WG_SR32; }
+template <int CO, int SRV = wg_default_sr(CO)>
 struct WGeo {
   static constexpr int COW = CO >= 64 ? 64 : 32;     // output channels of a workgroup
   static constexpr int PW = COW / 32;                // 32x32 block pairs
   static constexpr int KS = 8 / PW;                  // waves sharing a pair (K split)
-  static constexpr int SR = CO >= 64 ? 8 : UGN_WG_SR32;   // pixel rows of a strip
+  static constexpr int SR = SRV;                     // pixel rows of a strip
   static constexpr int RPW = SR / KS;                // pixel rows of a strip per wave
   static constexpr int IN_PIX = (SR + 2) * 18;       // halo of the input chunk
   static constexpr int IN_PLANE = IN_PIX * 64;       // 11,520 B (8 rows)
@@ -73,10 +78,10 @@ struct WGeo {
 };
 // buffer set = input halo + gradient tile (pooled: the pooled gradient tile); + 32 KB of scratch for the K-split combine where a
 // set is smaller than that
-template <int CO, int POOLED>
-constexpr int wg_set_bytes() { return WGeo<CO>::IN_BYTES + (POOLED ? WGeo<CO>::PZ_BYTES : WGeo<CO>::DZ_BYTES); }
-template <int CO, int POOLED>
-constexpr int wg_lds_bytes() { return 2 * wg_set_bytes<CO, POOLED>() + (wg_set_bytes<CO, POOLED>() < 32768 ? 32768 : 0); }
+template <int CO, int POOLED, int SRV = wg_default_sr(CO)>
+constexpr int wg_set_bytes() { return WGeo<CO, SRV>::IN_BYTES + (POOLED ? WGeo<CO, SRV>::PZ_BYTES : WGeo<CO, SRV>::DZ_BYTES); }
+template <int CO, int POOLED, int SRV = wg_default_sr(CO)>
+constexpr int wg_lds_bytes() { return 2 * wg_set_bytes<CO, POOLED, SRV>() + (wg_set_bytes<CO, POOLED, SRV>() < 32768 ? 32768 : 0); }
 
 __device__ __forceinline__ h8 tr_pair(const LDS_PTR(char) base, int off0, int off1) {
   const s4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s4))(base + off0));
@@ -91,14 +96,18 @@ __device__ unsigned long long* g_wg_stamp = nullptr;
 constexpr int kWgStampPerWave = 4 + 6 * 60;
 #endif
 
-template <int CI, int CO, int HW, int POOLED>
+typedef _Float16 h16 __attribute__((ext_vector_type(16)));
+
+template <int CI, int CO, int HW, int POOLED, int SP = 0>
 __global__ __launch_bounds__(512, 2) void wgrad_mm_kernel(const WgJobs jt, const void* __restrict__ zeros) {
-  using G = WGeo<CO>;
-  constexpr int COW = G::COW, PW = G::PW, KS = G::KS, RPW = G::RPW, SR = G::SR, SET = wg_set_bytes<CO, POOLED>();
+  static_assert(!SP || POOLED, "the sparse form is the MaxPool-backward one");
+  constexpr int SRV = SP ? 16 : wg_default_sr(CO);
+  using G = WGeo<CO, SRV>;
+  constexpr int COW = G::COW, PW = G::PW, KS = G::KS, RPW = G::RPW, SR = G::SR, SET = wg_set_bytes<CO, POOLED, SRV>();
   constexpr int IN_PIX = G::IN_PIX, IN_PLANE = G::IN_PLANE, IN_PIECES = G::IN_PIECES, IN_BYTES = G::IN_BYTES;
   constexpr int NCOC = CO / COW, NCOMBO = (CI / 32) * NCOC;
   constexpr int SPX = HW / 16, SPI = (HW / SR) * SPX;       // strips per image row / per image
-  static_assert(HW % SR == 0 && (SR == 8 || SR == 16) && RPW * KS == SR && IN_PIX < 400, "strip geometry");
+  static_assert(HW % SR == 0 && (SR == 8 || SR == 16) && (SP || RPW * KS == SR) && IN_PIX < 400, "strip geometry");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const LDS_PTR(char) lds = (LDS_PTR(char))smem;
   const unsigned sbase = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)lds);
@@ -128,7 +137,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_mm_kernel(const WgJobs jt, const
 #define UGN_WG_PIPE 1         /* a tap's transposed reads pinned one tap ahead of its MFMAs (round-4 experiment 3: equal in isolation,
                                  40-110 us better over the five launches inside the step, same box, both orders) */
 #endif
-  constexpr bool M16 = PW == 2 && (!POOLED || UGN_WG_POOLED16);
+  constexpr bool M16 = PW == 2 && (!POOLED || UGN_WG_POOLED16) && !SP;
   constexpr bool SWZ = M16 && UGN_WG_SWZ;
   // transposed-read role of the lane: 16-lane group (channel half gh, k half h), row q of the 4-pixel block, columns 4p..
   const int h = lane >> 5, gh = (lane >> 4) & 1, q = (lane >> 2) & 3, p = lane & 3;
@@ -282,14 +291,17 @@ __global__ __launch_bounds__(512, 2) void wgrad_mm_kernel(const WgJobs jt, const
   // step, the 32 x 32 block of a tap as four 16 x 16 tiles.  Same operand reads, same FLOPs and accumulator registers as two
   // 32x32x16 steps, but the chip holds a higher clock on this shape: 6-12 % on these launches (profiles/r03_stage_stamps.txt).
   typedef float f32x4 __attribute__((ext_vector_type(4)));
-  f32x16 acc[M16 ? 1 : 9];
-  f32x4 a4[M16 ? 9 : 1][4];          // [tap][ci tile * 2 + co tile]
+  // SP: [tap][co tile * NCIT + ci tile] of the wave's unit (64 output channels: unit = 32-channel block, both input-channel tiles;
+  // 32: unit = input-channel tile)
+  constexpr int NCIT = PW == 2 ? 2 : 1, NT = 2 * NCIT;
+  f32x16 acc[(M16 || SP) ? 1 : 9];
+  f32x4 a4[(M16 || SP) ? 9 : 1][4];          // [tap][ci tile * 2 + co tile]  (SP: [tap][co tile * NCIT + ci tile])
 #pragma unroll
-  for (int t = 0; t < (M16 ? 1 : 9); ++t)
+  for (int t = 0; t < ((M16 || SP) ? 1 : 9); ++t)
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
 #pragma unroll
-  for (int t = 0; t < (M16 ? 9 : 1); ++t)
+  for (int t = 0; t < ((M16 || SP) ? 9 : 1); ++t)
 #pragma unroll
     for (int k = 0; k < 4; ++k) a4[t][k] = f32x4{0.f, 0.f, 0.f, 0.f};
 
@@ -329,7 +341,82 @@ __global__ __launch_bounds__(512, 2) void wgrad_mm_kernel(const WgJobs jt, const
     WG_STAMP(4);
     const LDS_PTR(char) in_b = lds + b * SET + ks * RPW * (18 * 64) + lane_off;
     const LDS_PTR(char) dz_b = lds + b * SET + IN_BYTES + pair * G::DZ_BLOCK + ks * RPW * (16 * 64) + lane_off;
-    if constexpr (M16) {
+    if constexpr (SP) {
+      // ---- pooled layers on the SPARSE matrix pipe.  The un-pooled gradient has ONE non-zero per 2x2 window, so along a pixel row
+      // every pair (2j, 2j + 1) holds at most one: 2:4 structured along K = pixels.  v_smfmac_f32_16x16x64_f16 takes the sparse
+      // operand compressed -- per lane (m, k block kb) the 8 kept values of its 16 k and a 2-bit position for each -- and issues at
+      // the rate of the dense 16x16x32 (tools/experiments/smfmac_rate.hip: 2.81 against 2.67 ms): HALF the matrix time.  Operand
+      // layout (tools/experiments/smfmac_probe.hip): A lane (m = lane & 15, kb = lane >> 4): slots s = 0..7 = dense k
+      // 16 kb + 4 (s >> 1) + position; B lane (n = lane & 15, kb): elements 0-7 = k 8 kb .., 8-15 = k 32 + 8 kb ..
+      // So: M = output channels (dz^T, sparse), N = input channels (x, dense), K 64 = 4 strip rows x 16 pixels, k = 16 row + pixel.
+      //   * the compressed operand IS the pooled tensor: slot s of row y = the pooled gradient of window (y >> 1, s) where the
+      //     window's argmax sits in row y & 1 (else 0), position 2 (s & 1) + (argmax & 1): no un-pooling at all, built once per strip;
+      //   * the dense operand of a tap = two of the 16x16x32 fragments (rows kb >> 1 and 2 + (kb >> 1), pixels 8 (kb & 1) .. + 7).
+      // wave = (row group rg, unit).
+      const int rg = wave & 3, unit = wave >> 2;
+      const int kb = lane >> 4, mi = lane & 15;
+      const int y = 4 * rg + kb;
+      const int blk = PW == 2 ? unit : 0;
+      h8 sah[2], sal[2];
+      int sidx[2];
+#pragma unroll
+      for (int cot = 0; cot < 2; ++cot) {
+        const LDS_PTR(char) pv = lds + b * SET + IN_BYTES + blk * G::PZ_BLOCK + (y >> 1) * 512 + q * 64 + (16 * cot + 4 * p) * 2;
+        const uint2 h0 = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s4))pv));
+        const uint2 h1 = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s4))(pv + 4 * 64)));
+        const uint2 l0 = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s4))(pv + G::PZ_PLANE)));
+        const uint2 l1 = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s4))(pv + G::PZ_PLANE + 4 * 64)));
+        const unsigned char* pi8 = reinterpret_cast<const unsigned char*>(smem) + b * SET + IN_BYTES + G::PZ_VAL +
+                                   ((y >> 1) * 8) * COW + blk * 32 + 16 * cot + mi;
+        const unsigned hv[4] = {h0.x, h0.y, h1.x, h1.y}, lv[4] = {l0.x, l0.y, l1.x, l1.y};
+        unsigned hm[4], lm[4], iw = 0;
+        const unsigned rowpar = (unsigned)(y & 1);
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {            // dword d = slots 2d, 2d + 1 = pooled columns 2d, 2d + 1
+          const unsigned i0 = pi8[(2 * d) * COW], i1 = pi8[(2 * d + 1) * COW];
+          const unsigned m = ((i0 >> 1) == rowpar ? 0x0000ffffu : 0u) | ((i1 >> 1) == rowpar ? 0xffff0000u : 0u);
+          hm[d] = hv[d] & m;
+          lm[d] = lv[d] & m;
+          iw |= ((i0 & 1u) | ((2u | (i1 & 1u)) << 2)) << (4 * d);
+        }
+        sah[cot] = __builtin_bit_cast(h8, make_uint4(hm[0], hm[1], hm[2], hm[3]));
+        sal[cot] = __builtin_bit_cast(h8, make_uint4(lm[0], lm[1], lm[2], lm[3]));
+        sidx[cot] = (int)iw;
+      }
+      const LDS_PTR(char) in_s = lds + b * SET + ((4 * rg + (kb >> 1)) * 18 + 8 * (kb & 1) + q) * 64 + 4 * p * 2 +
+                                 (PW == 2 ? 0 : 32 * unit);
+      h16 fbh[2], fbl[2];                 // [register set]: the dense fragments of a micro-step (tap, input-channel tile)
+      auto load_b = [&](int set, int u) {
+        const int t = u / NCIT, cit = u % NCIT;
+        const int o = ((t / 3) * 18 + (t % 3)) * 64 + 32 * cit;
+        const h8 a0 = tr_pair(in_s, o, o + 4 * 64), a1 = tr_pair(in_s, o + 2 * 18 * 64, o + 2 * 18 * 64 + 4 * 64);
+        const h8 c0 = tr_pair(in_s, IN_PLANE + o, IN_PLANE + o + 4 * 64);
+        const h8 c1 = tr_pair(in_s, IN_PLANE + o + 2 * 18 * 64, IN_PLANE + o + 2 * 18 * 64 + 4 * 64);
+        fbh[set] = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
+        fbl[set] = __builtin_shufflevector(c0, c1, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
+      };
+      constexpr int NU = 9 * NCIT;
+      load_b(0, 0);
+#pragma unroll
+      for (int u = 0; u < NU; ++u) {
+        const int t = u / NCIT, cit = u % NCIT;
+        if (u + 1 < NU) load_b((u + 1) & 1, u + 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int cot = 0; cot < 2; ++cot) {
+          f32x4 c = a4[t][cot * NCIT + cit];
+          c = __builtin_amdgcn_smfmac_f32_16x16x64_f16(sah[cot], fbh[u & 1], c, sidx[cot], 0, 0);
+          c = __builtin_amdgcn_smfmac_f32_16x16x64_f16(sah[cot], fbl[u & 1], c, sidx[cot], 0, 0);
+          c = __builtin_amdgcn_smfmac_f32_16x16x64_f16(sal[cot], fbh[u & 1], c, sidx[cot], 0, 0);
+          a4[t][cot * NCIT + cit] = c;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (cit == NCIT - 1 && t < NJ && have_in) {      // one LDS-DMA piece of the next strip per tap
+          issue(t, Sin, b ^ 1);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    } else if constexpr (M16) {
       // lane (i = lane & 15, k group kg = lane >> 4): 8 consecutive pixels of the wave's 32.  SWZ (default): row kr = kg & 1, columns
       // 8 (kg >> 1) .. + 7 -- a ds_read_b64_tr_b16 is serviced as lanes 0-31, then 32-63 (MI355X_MICROARCH.md, LDS), i.e. k groups
       // {0, 1} together.  A 16-lane group reads 32 of the 64 bytes of four consecutive pixels (banks 16 q + 8 half + 2 p), so two groups
@@ -453,7 +540,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_mm_kernel(const WgJobs jt, const
       for (int t = 0; t < 9; ++t) {
         __syncthreads();
         f32x16 a;
-        if constexpr (M16) {
+        if constexpr (M16 || SP) {
           f32x4 q0 = a4[0][0], q1 = a4[0][1], q2 = a4[0][2], q3 = a4[0][3];
 #pragma unroll
           for (int u = 1; u < 9; ++u) if (t == u) { q0 = a4[u][0]; q1 = a4[u][1]; q2 = a4[u][2]; q3 = a4[u][3]; }
@@ -467,6 +554,22 @@ __global__ __launch_bounds__(512, 2) void wgrad_mm_kernel(const WgJobs jt, const
 #pragma unroll
         for (int i = 0; i < 16; ++i) scr[wave * 1024 + i * 64 + lane] = a[i];
         __syncthreads();
+        if constexpr (SP) {
+          // tiles of unit u from its four row-group waves (wave = 4 u + rg), in order.  Tile register r of lane l = output channel
+          // 4 (l >> 4) + r (M), input channel l & 15 (N) of the tile
+#pragma unroll
+          for (int k = 0; k < 2 * PW; ++k) {
+            const int e = tid + 512 * k, u = e / (NT * 256), rem = e - u * (NT * 256);
+            const int tile = rem >> 8, r = (rem >> 6) & 3, ln = rem & 63;
+            float sum = 0.f;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) sum += scr[(u * 4 + g) * 1024 + (tile * 4 + r) * 64 + ln];
+            const int cot = tile / NCIT, citl = tile % NCIT;
+            const int co = (PW == 2 ? 32 * u : 0) + 16 * cot + 4 * (ln >> 4) + r;
+            const int ci = 16 * (PW == 2 ? citl : u) + (ln & 15);
+            slab[(t * 32 + ci) * COW + co] = sum;
+          }
+        } else
 #pragma unroll
         for (int k = 0; k < 2 * PW; ++k) {
           const int e = tid + 512 * k, pr = e >> 10, idx = e & 1023;
@@ -482,11 +585,11 @@ __global__ __launch_bounds__(512, 2) void wgrad_mm_kernel(const WgJobs jt, const
         }
       }
 #pragma unroll
-      for (int t = 0; t < (M16 ? 1 : 9); ++t)
+      for (int t = 0; t < ((M16 || SP) ? 1 : 9); ++t)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
 #pragma unroll
-      for (int t = 0; t < (M16 ? 9 : 1); ++t)
+      for (int t = 0; t < ((M16 || SP) ? 9 : 1); ++t)
 #pragma unroll
         for (int k = 0; k < 4; ++k) a4[t][k] = f32x4{0.f, 0.f, 0.f, 0.f};
       jb = jn;
@@ -523,15 +626,16 @@ __global__ __launch_bounds__(256) void wgrad_mm_finish(const WgFinish ft, int CI
 template <int CI, int CO>
 constexpr int wg_ngroups() { return 256 / ((CI / 32) * (CO / WGeo<CO>::COW)); }
 
-template <int CI, int CO, int HW, int POOLED>
+template <int CI, int CO, int HW, int POOLED, int SP = 0>
 int launch_wgrad(const uint16_t* const* in, const void* const* in_meta, const uint16_t* const* dz, const uint8_t* const* dz_idx,
                  const void* const* dz_meta, float* const* dw, const int* n, int njobs, float* ws, size_t ws_floats, hipStream_t st) {
-  using G = WGeo<CO>;
+  constexpr int SRV = SP ? 16 : wg_default_sr(CO);
+  using G = WGeo<CO, SRV>;
   constexpr int NCOMBO = (CI / 32) * (CO / G::COW), NG = wg_ngroups<CI, CO>();
   constexpr int SPI = (HW / G::SR) * (HW / 16);
-  constexpr int LDS = wg_lds_bytes<CO, POOLED>();
+  constexpr int LDS = wg_lds_bytes<CO, POOLED, SRV>();
   static_assert(LDS <= 163840 && NG % 8 == 0, "geometry");
-  auto kern = wgrad_mm_kernel<CI, CO, HW, POOLED>;
+  auto kern = wgrad_mm_kernel<CI, CO, HW, POOLED, SP>;
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -625,7 +729,7 @@ extern "C" int ugn_mm_conv3x3_wgrad_multi(const uint16_t* const* in, const void*
   const size_t wfl = ws_bytes / sizeof(float);
 #define WG(CI_, CO_, HW_, P_)                                        \
   if (cin == CI_ && cout == CO_ && hw == HW_ && pooled == (P_ != 0)) \
-    return launch_wgrad<CI_, CO_, HW_, P_>(in, in_meta, dz, dz_idx, dz_meta, dw, n, njobs, wsf, wfl, st);
+    return launch_wgrad<CI_, CO_, HW_, P_, (P_ && UGN_WG_SPARSE) ? 1 : 0>(in, in_meta, dz, dz_idx, dz_meta, dw, n, njobs, wsf, wfl, st);
   WG(32, 32, 64, 1) WG(32, 64, 32, 0) WG(64, 64, 32, 1) WG(64, 128, 16, 0) WG(128, 128, 16, 0)
 #undef WG
   ugn_set_error("ugn_mm_conv3x3_wgrad_multi: unsupported shape cin=%d cout=%d hw=%d pooled=%d", cin, cout, hw, (int)pooled);
