@@ -52,6 +52,15 @@ struct WgJobs {
 #ifndef UGN_WG_SPARSE
 #define UGN_WG_SPARSE 1
 #endif
+#ifndef UGN_SP_ABL
+#define UGN_SP_ABL 0          /* timing-only ablations of the sparse path (WRONG results): 1 no MFMA, 2 no dense-fragment reads, 4 no LDS-DMA */
+#endif
+#ifndef UGN_WG_SPD
+#define UGN_WG_SPD 3          /* micro-steps (6 MFMAs) the dense fragments are read ahead: 32 output channels per workgroup ... */
+#endif
+#ifndef UGN_WG_SPD64
+#define UGN_WG_SPD64 0        /* ... and 64 (144 accumulator registers: one step ahead spills 10 and measures the same) */
+#endif
 constexpr int wg_default_sr(int co) { return co >= 64 ? 8 : UGN_WG_SR32; }
 template <int CO, int SRV = wg_default_sr(CO)>
 struct WGeo {
@@ -80,8 +89,15 @@ struct WGeo {
 // set is smaller than that
 template <int CO, int POOLED, int SRV = wg_default_sr(CO)>
 constexpr int wg_set_bytes() { return WGeo<CO, SRV>::IN_BYTES + (POOLED ? WGeo<CO, SRV>::PZ_BYTES : WGeo<CO, SRV>::DZ_BYTES); }
-template <int CO, int POOLED, int SRV = wg_default_sr(CO)>
-constexpr int wg_lds_bytes() { return 2 * wg_set_bytes<CO, POOLED, SRV>() + (wg_set_bytes<CO, POOLED, SRV>() < 32768 ? 32768 : 0); }
+// buffer sets: two (the next strip streams in while this one is multiplied); THREE for the sparse 32-channel kernel, which waits for
+// HBM rather than for the matrix pipe (tile wait 800-1,600 cycles of a 6,500-cycle strip with one strip in flight): two strips ahead
+#ifndef UGN_WG_SP3
+#define UGN_WG_SP3 0       /* measured: 395 against 397 us -- the launch is not short of bytes in flight */
+#endif
+template <int CO, int SP>
+constexpr int wg_nsets() { return (SP && CO < 64 && UGN_WG_SP3) ? 3 : 2; }
+template <int CO, int POOLED, int SRV = wg_default_sr(CO), int NSET = 2>
+constexpr int wg_lds_bytes() { return NSET * wg_set_bytes<CO, POOLED, SRV>() + (wg_set_bytes<CO, POOLED, SRV>() < 32768 ? 32768 : 0); }
 
 __device__ __forceinline__ h8 tr_pair(const LDS_PTR(char) base, int off0, int off1) {
   const s4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s4))(base + off0));
@@ -167,7 +183,8 @@ __global__ __launch_bounds__(512, 2) void wgrad_mm_kernel(const WgJobs jt, const
       const int plane = sg >= IN_PIX * 4 ? 1 : 0, rem = sg - IN_PIX * 4 * plane;
       const int pix = rem >> 2, c4 = rem & 3;
       const int row = (pix * 3641) >> 16, px = pix - row * 18;         // pix / 18 for pix < 400
-      const int c4s = SWZ ? c4 ^ ((row & 1) << 1) : c4;              // (the quarter this LDS slot holds)
+      // (the quarter this LDS slot holds; SP: the 32-byte halves of a plane record are swapped for tile columns 8-15, see the strip loop)
+      const int c4s = SP ? c4 ^ (((px >> 3) & 1) << 1) : (SWZ ? c4 ^ ((row & 1) << 1) : c4);
       const int off = ((row - 1) * HW + (px - 1)) * (CI * 4) + plane * CI * 2 + c4s * 16;
       if (sg < G::IN_SLOTS) pk[j] = (int)(((unsigned)off << 12) | (unsigned)(row << 5) | (unsigned)px);
     } else if (pi < NPIECE) {
@@ -291,11 +308,10 @@ __global__ __launch_bounds__(512, 2) void wgrad_mm_kernel(const WgJobs jt, const
   // step, the 32 x 32 block of a tap as four 16 x 16 tiles.  Same operand reads, same FLOPs and accumulator registers as two
   // 32x32x16 steps, but the chip holds a higher clock on this shape: 6-12 % on these launches (profiles/r03_stage_stamps.txt).
   typedef float f32x4 __attribute__((ext_vector_type(4)));
-  // SP: [tap][co tile * NCIT + ci tile] of the wave's unit (64 output channels: unit = 32-channel block, both input-channel tiles;
-  // 32: unit = input-channel tile)
-  constexpr int NCIT = PW == 2 ? 2 : 1, NT = 2 * NCIT;
+  // SP: [tap][co tile of the wave's 32-channel block]
   f32x16 acc[(M16 || SP) ? 1 : 9];
-  f32x4 a4[(M16 || SP) ? 9 : 1][4];          // [tap][ci tile * 2 + co tile]  (SP: [tap][co tile * NCIT + ci tile])
+  constexpr int SPT = SP ? 2 * PW : 4;        // SP: tiles of a wave per tap, [co tile * PW + ci tile of the wave]
+  f32x4 a4[(M16 || SP) ? 9 : 1][SPT];         // [tap][ci tile * 2 + co tile]
 #pragma unroll
   for (int t = 0; t < ((M16 || SP) ? 1 : 9); ++t)
 #pragma unroll
@@ -303,7 +319,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_mm_kernel(const WgJobs jt, const
 #pragma unroll
   for (int t = 0; t < ((M16 || SP) ? 9 : 1); ++t)
 #pragma unroll
-    for (int k = 0; k < 4; ++k) a4[t][k] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < SPT; ++k) a4[t][k] = f32x4{0.f, 0.f, 0.f, 0.f};
 
 #ifdef UGN_WG_STAMP
   unsigned long long* stamp = g_wg_stamp ? g_wg_stamp + ((size_t)blockIdx.x * 8 + wave) * kWgStampPerWave : nullptr;
@@ -320,23 +336,40 @@ __global__ __launch_bounds__(512, 2) void wgrad_mm_kernel(const WgJobs jt, const
   const int s0 = (int)((long long)grp * total / jt.ngroups), s1 = (int)((long long)(grp + 1) * total / jt.ngroups);
   if (s0 >= s1) continue;
   if (!first_group) __syncthreads();        // the previous group's slab combine has finished reading its scratch
-  // ---- prologue: tiles of strip s0 -> set 0
+  // ---- prologue: tiles of strip s0 -> set 0 (three sets: and of strip s0 + 1 -> set 1)
+  constexpr int NSET = wg_nsets<CO, SP>(), AHEAD = NSET - 1;
   {
     const StripSrc S0 = strip_src(s0);
 #pragma unroll
     for (int j = 0; j < NJ; ++j) issue(j, S0, 0);
+    if (NSET == 3 && s0 + 1 < s1) {
+      const StripSrc S1 = strip_src(s0 + 1);
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) issue(j, S1, 1);
+    }
   }
   int b = 0;
   int jb = job_of(s0);
+  // pieces this wave issues per strip (LDS-DMA retires in order: a counted wait that leaves the newest strip's pieces in flight)
+  const bool seven = wave + 8 * (NJ - 1) < NPIECE;
+  bool newer_in_flight = NSET == 3 && s0 + 1 < s1;
   for (int s = s0; s < s1; ++s) {
     WG_STAMP(0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (NSET == 3 && newer_in_flight) {
+      static_assert(NSET == 2 || NJ == 7, "vmcnt immediates");
+      if (seven) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     WG_STAMP(1);
-    __syncthreads();      // strip s is in set b; nobody reads the other set any more
+    __syncthreads();      // strip s is in set b; nobody reads the set the next pieces go to any more
     WG_STAMP(2);
-    // the tiles of strip s + 1 -> the other set, issued between the taps below
-    const bool have_in = s + 1 < s1;
-    const StripSrc Sin = strip_src(have_in ? s + 1 : s);
+    // the tiles of strip s + AHEAD -> the set that strip s - 1 left, issued between the taps below
+    const bool have_in = s + AHEAD < s1;
+    newer_in_flight = NSET == 3 && s + 1 < s1 && have_in;      // (at the top of strip s + 1: were pieces issued behind its own?)
+    const StripSrc Sin = strip_src(have_in ? s + AHEAD : s);
+    const int bn = NSET == 3 ? (b + 2 >= 3 ? b - 1 : b + 2) : (b ^ 1);
     WG_STAMP(3);
     WG_STAMP(4);
     const LDS_PTR(char) in_b = lds + b * SET + ks * RPW * (18 * 64) + lane_off;
@@ -352,67 +385,99 @@ __global__ __launch_bounds__(512, 2) void wgrad_mm_kernel(const WgJobs jt, const
       //   * the compressed operand IS the pooled tensor: slot s of row y = the pooled gradient of window (y >> 1, s) where the
       //     window's argmax sits in row y & 1 (else 0), position 2 (s & 1) + (argmax & 1): no un-pooling at all, built once per strip;
       //   * the dense operand of a tap = two of the 16x16x32 fragments (rows kb >> 1 and 2 + (kb >> 1), pixels 8 (kb & 1) .. + 7).
-      // wave = (row group rg, unit).
+      // wave = (row group rg: strip rows 4 rg .. 4 rg + 3 = the K 64 of one v_smfmac, unit).  32 output channels: unit = input-channel
+      // tile (2 x 1 tiles per tap, 72 accumulator registers); 64: unit = 32-channel output block, both input-channel tiles (2 x 2
+      // tiles, 144 registers -- the form with 72, two row groups of 8 rows, builds the sparse operands twice as often and measured
+      // 262 -> 279 us).
       const int rg = wave & 3, unit = wave >> 2;
-      const int kb = lane >> 4, mi = lane & 15;
-      const int y = 4 * rg + kb;
       const int blk = PW == 2 ? unit : 0;
+      const int kb = lane >> 4, mi = lane & 15;
       h8 sah[2], sal[2];
       int sidx[2];
+      {
+        const int y = 4 * rg + kb;
 #pragma unroll
-      for (int cot = 0; cot < 2; ++cot) {
-        const LDS_PTR(char) pv = lds + b * SET + IN_BYTES + blk * G::PZ_BLOCK + (y >> 1) * 512 + q * 64 + (16 * cot + 4 * p) * 2;
-        const uint2 h0 = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s4))pv));
-        const uint2 h1 = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s4))(pv + 4 * 64)));
-        const uint2 l0 = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s4))(pv + G::PZ_PLANE)));
-        const uint2 l1 = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s4))(pv + G::PZ_PLANE + 4 * 64)));
-        const unsigned char* pi8 = reinterpret_cast<const unsigned char*>(smem) + b * SET + IN_BYTES + G::PZ_VAL +
-                                   ((y >> 1) * 8) * COW + blk * 32 + 16 * cot + mi;
-        const unsigned hv[4] = {h0.x, h0.y, h1.x, h1.y}, lv[4] = {l0.x, l0.y, l1.x, l1.y};
-        unsigned hm[4], lm[4], iw = 0;
-        const unsigned rowpar = (unsigned)(y & 1);
+        for (int cot = 0; cot < 2; ++cot) {
+          const LDS_PTR(char) pv = lds + b * SET + IN_BYTES + blk * G::PZ_BLOCK + (y >> 1) * 512 + q * 64 + (16 * cot + 4 * p) * 2;
+          const uint2 h0 = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s4))pv));
+          const uint2 h1 = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s4))(pv + 4 * 64)));
+          const uint2 l0 = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s4))(pv + G::PZ_PLANE)));
+          const uint2 l1 = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s4))(pv + G::PZ_PLANE + 4 * 64)));
+          const unsigned char* pi8 = reinterpret_cast<const unsigned char*>(smem) + b * SET + IN_BYTES + G::PZ_VAL +
+                                     ((y >> 1) * 8) * COW + blk * 32 + 16 * cot + mi;
+          const unsigned hv[4] = {h0.x, h0.y, h1.x, h1.y}, lv[4] = {l0.x, l0.y, l1.x, l1.y};
+          unsigned hm[4], lm[4], iw = 0;
+          const unsigned rowpar = (unsigned)(y & 1);
 #pragma unroll
-        for (int d = 0; d < 4; ++d) {            // dword d = slots 2d, 2d + 1 = pooled columns 2d, 2d + 1
-          const unsigned i0 = pi8[(2 * d) * COW], i1 = pi8[(2 * d + 1) * COW];
-          const unsigned m = ((i0 >> 1) == rowpar ? 0x0000ffffu : 0u) | ((i1 >> 1) == rowpar ? 0xffff0000u : 0u);
-          hm[d] = hv[d] & m;
-          lm[d] = lv[d] & m;
-          iw |= ((i0 & 1u) | ((2u | (i1 & 1u)) << 2)) << (4 * d);
+          for (int d = 0; d < 4; ++d) {            // dword d = slots 2d, 2d + 1 = pooled columns 2d, 2d + 1
+            const unsigned i0 = pi8[(2 * d) * COW], i1 = pi8[(2 * d + 1) * COW];
+            const unsigned m = ((i0 >> 1) == rowpar ? 0x0000ffffu : 0u) | ((i1 >> 1) == rowpar ? 0xffff0000u : 0u);
+            hm[d] = hv[d] & m;
+            lm[d] = lv[d] & m;
+            iw |= ((i0 & 1u) | ((2u | (i1 & 1u)) << 2)) << (4 * d);
+          }
+          sah[cot] = __builtin_bit_cast(h8, make_uint4(hm[0], hm[1], hm[2], hm[3]));
+          sal[cot] = __builtin_bit_cast(h8, make_uint4(lm[0], lm[1], lm[2], lm[3]));
+          sidx[cot] = (int)iw;
         }
-        sah[cot] = __builtin_bit_cast(h8, make_uint4(hm[0], hm[1], hm[2], hm[3]));
-        sal[cot] = __builtin_bit_cast(h8, make_uint4(lm[0], lm[1], lm[2], lm[3]));
-        sidx[cot] = (int)iw;
       }
-      const LDS_PTR(char) in_s = lds + b * SET + ((4 * rg + (kb >> 1)) * 18 + 8 * (kb & 1) + q) * 64 + 4 * p * 2 +
-                                 (PW == 2 ? 0 : 32 * unit);
-      h16 fbh[2], fbl[2];                 // [register set]: the dense fragments of a micro-step (tap, input-channel tile)
+      // Dense fragments: lanes 0-31 of a transposed read (k blocks 0, 1) are pixels 0-7 | 8-15 of ONE row, 512 B apart = the same
+      // banks if both read the same 32-byte half of their records.  The halo tile therefore holds the two halves of a plane record
+      // SWAPPED for tile columns 8-15 (16, 17: not): the k blocks of a pass then sit in different halves for every tap -- a lane's
+      // half is cit ^ ((column >> 3) & 1), column = 8 (kb & 1) + q + dx (+ 4 for the second read of a pair), which leaves the lane's
+      // 8-column block only in that second read and only for q + dx >= 4: three lane bases.
+      const int hsel = kb & 1;            // the half that holds input-channel tile 0 at this lane's first column
+      const LDS_PTR(char) in_r = lds + b * SET + ((4 * rg + (kb >> 1)) * 18 + 8 * (kb & 1) + q) * 64 + 4 * p * 2;
+      // [dx]: byte offset of tile 0's half for the SECOND read of a pair (the first: 32 hsel)
+      const int sec0[3] = {32 * hsel, 32 * (hsel ^ (q + 1 >= 4 ? 1 : 0)), 32 * (hsel ^ (q + 2 >= 4 ? 1 : 0))};
+      // the dense fragments of micro-step u + SPD are read before the 6 MFMAs of micro-step u = (tap, input-channel tile) (a ring of
+      // SPD + 1 register sets)
+      constexpr int NCW = PW == 2 ? 2 : 1;        // input-channel tiles of a wave
+      constexpr int SPD = PW == 2 ? UGN_WG_SPD64 : UGN_WG_SPD, NS = SPD + 1, NU = 9 * NCW;
+      h16 fbh[NS], fbl[NS];
+      auto tr2 = [&](const LDS_PTR(char) first, const LDS_PTR(char) second, int off) {
+        const s4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s4))(first + off));
+        const s4 c = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s4))(second + off + 4 * 64));
+        const s8 v = __builtin_shufflevector(a, c, 0, 1, 2, 3, 4, 5, 6, 7);
+        return __builtin_bit_cast(h8, v);
+      };
       auto load_b = [&](int set, int u) {
-        const int t = u / NCIT, cit = u % NCIT;
-        const int o = ((t / 3) * 18 + (t % 3)) * 64 + 32 * cit;
-        const h8 a0 = tr_pair(in_s, o, o + 4 * 64), a1 = tr_pair(in_s, o + 2 * 18 * 64, o + 2 * 18 * 64 + 4 * 64);
-        const h8 c0 = tr_pair(in_s, IN_PLANE + o, IN_PLANE + o + 4 * 64);
-        const h8 c1 = tr_pair(in_s, IN_PLANE + o + 2 * 18 * 64, IN_PLANE + o + 2 * 18 * 64 + 4 * 64);
+        const int t = u / NCW, cit = PW == 2 ? u % NCW : unit;
+        const int o = ((t / 3) * 18 + (t % 3)) * 64;
+        // tile cit's half = tile 0's half ^ cit
+        const LDS_PTR(char) fst = in_r + ((32 * hsel) ^ (32 * cit));
+        const LDS_PTR(char) sec = in_r + (sec0[t % 3] ^ (32 * cit));
+        const h8 a0 = tr2(fst, sec, o), a1 = tr2(fst, sec, o + 2 * 18 * 64);
+        const h8 c0 = tr2(fst, sec, IN_PLANE + o), c1 = tr2(fst, sec, IN_PLANE + o + 2 * 18 * 64);
         fbh[set] = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
         fbl[set] = __builtin_shufflevector(c0, c1, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
       };
-      constexpr int NU = 9 * NCIT;
-      load_b(0, 0);
+#pragma unroll
+      for (int u = 0; u < SPD; ++u) load_b(u % NS, u);
 #pragma unroll
       for (int u = 0; u < NU; ++u) {
-        const int t = u / NCIT, cit = u % NCIT;
-        if (u + 1 < NU) load_b((u + 1) & 1, u + 1);
+        const int t = u / NCW, cw = u % NCW;
+#if UGN_SP_ABL & 2
+        if (u + SPD < NU && u + SPD < 2) load_b((u + SPD) % NS, u + SPD);
+#else
+        if (u + SPD < NU) load_b((u + SPD) % NS, u + SPD);
+#endif
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int cot = 0; cot < 2; ++cot) {
-          f32x4 c = a4[t][cot * NCIT + cit];
-          c = __builtin_amdgcn_smfmac_f32_16x16x64_f16(sah[cot], fbh[u & 1], c, sidx[cot], 0, 0);
-          c = __builtin_amdgcn_smfmac_f32_16x16x64_f16(sah[cot], fbl[u & 1], c, sidx[cot], 0, 0);
-          c = __builtin_amdgcn_smfmac_f32_16x16x64_f16(sal[cot], fbh[u & 1], c, sidx[cot], 0, 0);
-          a4[t][cot * NCIT + cit] = c;
+          f32x4 c = a4[t][cot * NCW + cw];
+#if UGN_SP_ABL & 1
+          c[0] += (float)fbh[u % NS][0] * (float)sah[cot][0] + (float)fbl[u % NS][1] * (float)sal[cot][1] + (float)sidx[cot];
+#else
+          c = __builtin_amdgcn_smfmac_f32_16x16x64_f16(sah[cot], fbh[u % NS], c, sidx[cot], 0, 0);
+          c = __builtin_amdgcn_smfmac_f32_16x16x64_f16(sah[cot], fbl[u % NS], c, sidx[cot], 0, 0);
+          c = __builtin_amdgcn_smfmac_f32_16x16x64_f16(sal[cot], fbh[u % NS], c, sidx[cot], 0, 0);
+#endif
+          a4[t][cot * NCW + cw] = c;
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (cit == NCIT - 1 && t < NJ && have_in) {      // one LDS-DMA piece of the next strip per tap
-          issue(t, Sin, b ^ 1);
+        if (cw == NCW - 1 && t < NJ && have_in && !(UGN_SP_ABL & 4)) {      // one LDS-DMA piece of the next strip per tap
+          issue(t, Sin, bn);
           __builtin_amdgcn_sched_barrier(0);
         }
       }
@@ -482,7 +547,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_mm_kernel(const WgJobs jt, const
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
           for (int u = 0; u < UGN_WG_PER_TAP; ++u)
-            if (t * UGN_WG_PER_TAP + u < NJ) issue(t * UGN_WG_PER_TAP + u, Sin, b ^ 1);
+            if (t * UGN_WG_PER_TAP + u < NJ) issue(t * UGN_WG_PER_TAP + u, Sin, bn);
           __builtin_amdgcn_sched_barrier(0);
         }
       }
@@ -521,7 +586,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_mm_kernel(const WgJobs jt, const
         const int slot = rr * 9 + t;
         if (slot % EVERY == 0 && slot / EVERY < NJ && have_in) {
           __builtin_amdgcn_sched_barrier(0);
-          issue(slot / EVERY, Sin, b ^ 1);
+          issue(slot / EVERY, Sin, bn);
           __builtin_amdgcn_sched_barrier(0);
         }
       }
@@ -540,7 +605,13 @@ __global__ __launch_bounds__(512, 2) void wgrad_mm_kernel(const WgJobs jt, const
       for (int t = 0; t < 9; ++t) {
         __syncthreads();
         f32x16 a;
-        if constexpr (M16 || SP) {
+        if constexpr (SP && PW == 1) {       // two tiles per wave
+          f32x4 q0 = a4[0][0], q1 = a4[0][1];
+#pragma unroll
+          for (int u = 1; u < 9; ++u) if (t == u) { q0 = a4[u][0]; q1 = a4[u][1]; }
+#pragma unroll
+          for (int i = 0; i < 4; ++i) { a[i] = q0[i]; a[4 + i] = q1[i]; a[8 + i] = 0.f; a[12 + i] = 0.f; }
+        } else if constexpr (M16 || SP) {
           f32x4 q0 = a4[0][0], q1 = a4[0][1], q2 = a4[0][2], q3 = a4[0][3];
 #pragma unroll
           for (int u = 1; u < 9; ++u) if (t == u) { q0 = a4[u][0]; q1 = a4[u][1]; q2 = a4[u][2]; q3 = a4[u][3]; }
@@ -552,21 +623,21 @@ __global__ __launch_bounds__(512, 2) void wgrad_mm_kernel(const WgJobs jt, const
           for (int u = 1; u < 9; ++u) if (t == u) a = acc[u];
         }
 #pragma unroll
-        for (int i = 0; i < 16; ++i) scr[wave * 1024 + i * 64 + lane] = a[i];
+        for (int i = 0; i < (SP ? 4 * SPT : 16); ++i) scr[wave * 1024 + i * 64 + lane] = a[i];
         __syncthreads();
         if constexpr (SP) {
-          // tiles of unit u from its four row-group waves (wave = 4 u + rg), in order.  Tile register r of lane l = output channel
-          // 4 (l >> 4) + r (M), input channel l & 15 (N) of the tile
+          // the tiles of unit u from its four row-group waves (wave = 4 u + rg), in order.  Tile register r of lane l = output channel
+          // 4 (l >> 4) + r (M), input channel l & 15 (N) of the tile; tile = co tile * PW + ci tile of the wave
 #pragma unroll
           for (int k = 0; k < 2 * PW; ++k) {
-            const int e = tid + 512 * k, u = e / (NT * 256), rem = e - u * (NT * 256);
+            const int e = tid + 512 * k, u = e / (SPT * 256), rem = e - u * (SPT * 256);
             const int tile = rem >> 8, r = (rem >> 6) & 3, ln = rem & 63;
             float sum = 0.f;
 #pragma unroll
             for (int g = 0; g < 4; ++g) sum += scr[(u * 4 + g) * 1024 + (tile * 4 + r) * 64 + ln];
-            const int cot = tile / NCIT, citl = tile % NCIT;
+            const int cot = tile / PW, cw = tile % PW;
             const int co = (PW == 2 ? 32 * u : 0) + 16 * cot + 4 * (ln >> 4) + r;
-            const int ci = 16 * (PW == 2 ? citl : u) + (ln & 15);
+            const int ci = 16 * (PW == 2 ? cw : u) + (ln & 15);
             slab[(t * 32 + ci) * COW + co] = sum;
           }
         } else
@@ -591,10 +662,10 @@ __global__ __launch_bounds__(512, 2) void wgrad_mm_kernel(const WgJobs jt, const
 #pragma unroll
       for (int t = 0; t < ((M16 || SP) ? 9 : 1); ++t)
 #pragma unroll
-        for (int k = 0; k < 4; ++k) a4[t][k] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int k = 0; k < SPT; ++k) a4[t][k] = f32x4{0.f, 0.f, 0.f, 0.f};
       jb = jn;
     }
-    b ^= 1;
+    b = NSET == 3 ? (b == 2 ? 0 : b + 1) : (b ^ 1);
   }
   }
 #ifdef UGN_WG_STAMP
@@ -633,7 +704,7 @@ int launch_wgrad(const uint16_t* const* in, const void* const* in_meta, const ui
   using G = WGeo<CO, SRV>;
   constexpr int NCOMBO = (CI / 32) * (CO / G::COW), NG = wg_ngroups<CI, CO>();
   constexpr int SPI = (HW / G::SR) * (HW / 16);
-  constexpr int LDS = wg_lds_bytes<CO, POOLED, SRV>();
+  constexpr int LDS = wg_lds_bytes<CO, POOLED, SRV, wg_nsets<CO, SP>()>();
   static_assert(LDS <= 163840 && NG % 8 == 0, "geometry");
   auto kern = wgrad_mm_kernel<CI, CO, HW, POOLED, SP>;
   static bool attr_done = false;

@@ -223,12 +223,15 @@ def conv3x3_wgrad_mm_multi(xs, dzs, cout, dws, dz_idxs=None):
     ws = _workspace(nbytes, xs[0].device)
     pooled = dz_idxs is not None
     flops = 2.0 * 9 * cin * cout * hw * hw * sum(x.shape[0] for x in xs)
-    kern = "wgrad_mm_kernel<%d, %d, %d, %d>" % (cin, cout, hw, int(pooled))
+    # pooled layers run on the SPARSE matrix pipe (v_smfmac_f32_16x16x64_f16: the un-pooled gradient is 2:4 structured along the pixels):
+    # half the dense instruction count, so the matrix-pipe time they are priced with is that of 1.5x the algorithmic FLOPs
+    kern = "wgrad_mm_kernel<%d, %d, %d, %d, %d>" % (cin, cout, hw, int(pooled), int(pooled))
+    pipe = 1.5 if pooled else 3.0
     label = "conv3x3_wgrad[%d->%d @%dx%d%s h2] %s" % (cin, cout, hw, hw, " pooled" if pooled else "", kern)
     call("ugn_mm_conv3x3_wgrad_multi", ptr_array([x.data for x in xs]), ptr_array([x.meta for x in xs]),
          ptr_array([d.data for d in dzs]), ptr_array(dz_idxs) if pooled else None, ptr_array([d.meta for d in dzs]),
          ptr_array(dws), ns, len(xs), hw, cin, cout, ptr(ws), ws.numel(), _stream(), label=label,
-         work=dict(flops=flops, mfma_flops=3.0 * flops, bytes=_mm_bytes("wgrad", hw, cin, cout, pooled, sum(x.shape[0] for x in xs)),
+         work=dict(flops=flops, mfma_flops=pipe * flops, bytes=_mm_bytes("wgrad", hw, cin, cout, pooled, sum(x.shape[0] for x in xs)),
                    kernel=kern, bound="roof", images=int(sum(x.shape[0] for x in xs)), dtype="f16x2"))
     return dws
 
