@@ -101,12 +101,14 @@ def test_roofline_object_of_the_default_command(dev, tmp_path, dtype):
         assert (roof["bound"] == "mfma") == (roof["mfma_floor_us"] >= roof["hbm_floor_us"])
         assert roof["frac"] == (roof["mfma_frac"] if roof["bound"] == "mfma" else roof["hbm_frac"])
         assert (roof["unit"], roof["peak"]) == (("TFLOP/s", 2516.8) if roof["bound"] == "mfma" else ("GB/s", 8000.0))
-        assert abs(roof["mfma_tflops"] / roof["algorithmic_tflops"] - 3.0) < 0.01     # three f16 MFMAs per product
+        # three f16 MFMAs per product; the pooled weight gradients on the sparse pipe execute half of them
+        assert min(abs(roof["mfma_tflops"] / roof["algorithmic_tflops"] - r) for r in (3.0, 1.5)) < 0.01
     else:
         assert roof["bound"] == "mfma" and roof["unit"] == "TFLOP/s" and roof["peak"] == 157.3
         assert abs(roof["achieved"] / roof["algorithmic_tflops"] - 16.0 / 36.0) < 0.01     # Winograd: 16/36 of the direct count
     assert 0.05 < roof["frac"] <= 1.0 and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3
-    assert roof["kernel"].startswith("conv3x3_") and ("_mm_kernel" if dtype == "h2" else "wino") in roof["rocprof_kernel"]
+    names = ("_mm_kernel", "conv_mm16_kernel", "conv_nr_kernel", "conv_d2_kernel", "conv32_d2p_kernel") if dtype == "h2" else ("wino",)
+    assert roof["kernel"].startswith("conv3x3_") and any(n in roof["rocprof_kernel"] for n in names)
     assert roof["launches_per_step"] >= 1
     assert roof["avg_us"] > 0 and 0 < roof["share_of_step"] < 0.5 and roof["serial_step_us"] > 0
     kinds = {k.get("bound") for k in roof["other_kernels"]}

@@ -44,6 +44,17 @@ enum { EPI_LRELU = 0, EPI_LRELU_POOL = 1, EPI_DGRAD = 2, EPI_DGRAD_ACT = 3 };
 #define UGN_MM16_PIPE 0      /* 1: fragment reads pinned a micro-step ahead of their MFMAs (round-4 experiment 3: equal in isolation,
                                 1 % SLOWER in the step -- 5.77 against 5.83 ms, same box, both orders) */
 #endif
+// First item of a persistent workgroup.  Workgroup w runs on XCD w % 8 (round-robin dispatch), so with item = w the 4 / 16 regions of
+// an image -- whose 18 x 18 halos overlap by 27 % -- are read on different XCDs, each through its own L2 (FETCH_SIZE of the 32 -> 32
+// forward: 1131 MB for 944 MB of input).  Here an XCD's workgroups take a CONTIGUOUS range of a round's items: the regions of an image
+// are in flight on one XCD at the same time.  (Later rounds: + gridDim.x, as before.)
+#ifndef UGN_MM_XCD
+#define UGN_MM_XCD 1
+#endif
+__device__ __forceinline__ int xcd_first_item() {
+  const int w = blockIdx.x, g = gridDim.x;
+  return (UGN_MM_XCD && (g & 7) == 0) ? (w & 7) * (g >> 3) + (w >> 3) : w;
+}
 constexpr int HROW = 168;                       // 16-byte slots per halo row (18 pixels x 9 + 6 pad; = 8 mod 16)
 constexpr int HPIECES = 48;                     // 18 rows x 168 slots = 3024 -> 48 pieces of 64 slots (6 per wave)
 constexpr int HALO_BYTES = HPIECES * 1024;      // 49,152
@@ -362,7 +373,7 @@ __global__ __launch_bounds__(512, 2) void conv_mm_kernel(const MmJobs jt, const 
   const int a_lane = ((2 * wave + (q >> 1)) * HROW + (2 * win + (q & 1)) * 9) * 16 + h * 16;
   const int b_lane = W_OFF + lane * 16;
 
-  int item = blockIdx.x;
+  int item = xcd_first_item();
   const int nitems = jt.start[kMaxJobs];
   if (item >= nitems) return;
 #ifdef UGN_MM_STAMP
@@ -891,7 +902,7 @@ __global__ __launch_bounds__(512, 2) void conv_mm16_kernel(const MmJobs jt, cons
   // C-side role: column col of a tile, window rg of the row tile (registers = positions 0..3)
   const int col = lane & 15, rg = lane >> 4;
 
-  int item = blockIdx.x;
+  int item = xcd_first_item();
   const int nitems = jt.start[kMaxJobs];
   if (item >= nitems) return;
   int jb = mm_job_of(jt, item), lit = item - jt.start[jb];
@@ -1203,7 +1214,7 @@ __global__ __launch_bounds__(512, 4) void conv_d2_kernel(const MmJobs jt, const 
   const int b_lane = D2_W_OFF + lane * 16;
   const int col = lane & 15, rg = lane >> 4;                               // C-side role
 
-  int item = blockIdx.x;
+  int item = xcd_first_item();
   const int nitems = jt.start[kMaxJobs];
   if (item >= nitems) return;
   int jb = mm_job_of(jt, item), lit = item - jt.start[jb];
@@ -1425,7 +1436,7 @@ __global__ __launch_bounds__(512, 4) void conv32_d2p_kernel(const MmJobs jt) {
   const int b_lane = D2_W_OFF + lane * 16;
   const int c = lane & 31;
 
-  int item = blockIdx.x;
+  int item = xcd_first_item();
   const int nitems = jt.start[kMaxJobs];
   if (item >= nitems) return;
   int jb = mm_job_of(jt, item), lit = item - jt.start[jb];
@@ -1619,7 +1630,7 @@ __global__ __launch_bounds__(512, 2) void conv_nr_kernel(const MmJobs jt, const 
 #pragma unroll
   for (int dx = 0; dx < 3; ++dx) ab[dx] = ((mh * ROWS) * 18 + x + dx) * 128 + (nr_slot(kg, x + dx) << 4);
 
-  int item = blockIdx.x;
+  int item = xcd_first_item();
   const int nitems = jt.start[kMaxJobs];
   if (item >= nitems) return;
   int jb = mm_job_of(jt, item), lit = item - jt.start[jb];
@@ -1909,7 +1920,7 @@ __global__ __launch_bounds__(512, 2) void dgrad32_w5_kernel(const W5Jobs jt, con
   const int b_lane = W_OFF + lane * 16;
   const int c = lane & 31;
 
-  int item = blockIdx.x;
+  int item = xcd_first_item();
   const int nitems = jt.start[kMaxJobs];
   if (item >= nitems) return;
   auto job_of = [&](int it) {
