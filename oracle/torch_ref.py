@@ -118,8 +118,9 @@ def triplet_hard(labels, emb, margin):
     return torch.clamp_min(hp - hn + margin, 0.0).mean(dim=(1, 2)).mean()
 
 
-def forward(xs, uses, params, mode='sign_max', multimodal=True):
-    outs = [branch(x, bp) for x, bp in zip(xs, params['branches'])]
+def forward(xs, uses, params, mode='sign_max', multimodal=True, branch_fn=None):
+    # (branch_fn: a statement-for-statement copy of `branch` that also records its routing decisions, tests/routing.py)
+    outs = [(branch_fn or branch)(x, bp) for x, bp in zip(xs, params['branches'])]
     if multimodal:
         gs = [o * u.reshape(1, -1, 1) for o, u in zip(outs, uses)]
         if mode == 'sign_max':
@@ -140,7 +141,7 @@ def forward(xs, uses, params, mode='sign_max', multimodal=True):
 
 
 def loss_and_grads(xs, uses, labels, onehot, params, margin=0.2, loss_weights=(1.0, 0.1),
-                   mode='sign_max', multimodal=True):
+                   mode='sign_max', multimodal=True, branch_fn=None):
     leaves = []
     for bp in params['branches']:
         leaves += list(bp.values())
@@ -149,7 +150,7 @@ def loss_and_grads(xs, uses, labels, onehot, params, margin=0.2, loss_weights=(1
     for t in leaves:
         t.requires_grad_(True)
         t.grad = None
-    res = forward(xs, uses, params, mode, multimodal)
+    res = forward(xs, uses, params, mode, multimodal, branch_fn=branch_fn)
     tri, res['tri_counts'] = triplet(labels, res['signature'], margin, return_counts=True)
     total = loss_weights[0] * tri
     res['triplet'] = tri.detach()

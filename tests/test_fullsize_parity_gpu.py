@@ -11,6 +11,15 @@ gradient <= 5e-3 relative L2 WITH the routing census beside it (round 4): every 
 step is compared with the fp64 oracle's, the flips are counted per family and each one is proven a near-tie (tests/routing.py); with
 no flip the bar is 1e-4, and on the headline workload (C3, f16x2) the oracle is also forced to the HIP path's routing: 5e-5.
 The fp64 oracle is evaluated ONCE per workload (the f32 and the f16x2 case share it)."""
+import atexit
+import os
+import pickle
+import shutil
+import subprocess
+import sys
+import tempfile
+import time
+
 import numpy as np
 import pytest
 import torch
@@ -44,26 +53,25 @@ def _rell2(a, b):
 
 
 # ONE evaluation of the fp64 oracle per workload: the f32 and the h2 case of a workload share inputs, weights
-# and therefore the oracle's losses, gradients and routing decisions; a single entry is kept (cases of a workload run back to back).
-_ORACLE = {}
+# and therefore the oracle's losses, gradients and routing decisions.  The evaluations need only the host's cores, so they run AHEAD of
+# the tests in a child process (tests/conftest.py starts it at session start and moves this module's tests to the end of the
+# session): while the other GPU tests run, the first workloads are evaluated; at most MAX_AHEAD finished entries are held (an entry is
+# up to ~11 GB: inputs, gradients and every routing decision of the step with its gap).
+WORKLOAD = {"C2": "C2", "C2h2": "C2", "C3": "C3", "C3h2": "C3", "C4": "C4", "C4h2": "C4", "C5": "C5"}
+MAX_AHEAD = 3
 
 
-def _oracle(c):
+def _evaluate(c):
     kinds, b, ncls, multimodal = c["kinds"], c["b"], c["ncls"], c.get("multimodal", True)
-    key = (kinds, b, c["ids"], ncls, multimodal)
-    if key in _ORACLE:
-        return _ORACLE[key]
-    _ORACLE.clear()
     xs, uses, labels, onehot = make_batch(kinds, b, 25, ncls, ids=c["ids"], seed=232323)
     rng = np.random.default_rng(11)
     p64 = dict(branches=[O.init_branch_params(rng, 2 if k == "of" else 1, np.float64) for k in kinds],
                head=O.init_head_params(rng, ncls, np.float64))
     p64["head"]["bc"] = rng.normal(size=ncls) * 0.01
-    torch.set_num_threads(max(1, torch.get_num_threads()))
     tp = T.params_from_numpy(p64, dtype=torch.float64)
     x64 = [torch.from_numpy(x.astype(np.float64)) for x in xs]
     u64 = [torch.from_numpy(u.astype(np.float64)) for u in uses] if multimodal else None
-    # the oracle's own evaluation (oracle/torch_ref.py loss_and_grads), with its `branch` replaced by the statement-for-statement
+    # the oracle's own evaluation (oracle/torch_ref.py loss_and_grads) with its `branch` replaced by the statement-for-statement
     # tapped copy of tests/routing.py: ONE forward pass yields the losses, the gradients AND the routing / LeakyReLU decisions with
     # the gaps of every near-tie (bf16 case: no census)
     decs, sel = [], None
@@ -73,22 +81,76 @@ def _oracle(c):
         dec = {} if census else None
         decs.append(dec)
         return R.branch_tapped(x, p, dec)
-    orig = T.branch
-    T.branch = tapped
-    try:
-        res, g = T.loss_and_grads(x64, u64, torch.from_numpy(labels), torch.from_numpy(onehot.astype(np.float64)), tp, margin=0.2,
-                                  loss_weights=(1.0, 0.1), multimodal=multimodal)
-    finally:
-        T.branch = orig
+    res, g = T.loss_and_grads(x64, u64, torch.from_numpy(labels), torch.from_numpy(onehot.astype(np.float64)), tp, margin=0.2,
+                              loss_weights=(1.0, 0.1), multimodal=multimodal, branch_fn=tapped)
     if census and multimodal:
         sel = R.sign_max_census([o.detach() for o in res["outs"]], u64)
-    entry = dict(xs=xs, uses=uses, labels=labels, onehot=onehot, p64=p64, x64=x64, u64=u64,
-                 loss=float(res["loss"]), triplet=float(res["triplet"]), xent=float(res["xent"]),
-                 signature=res["signature"].detach().numpy(), tri_counts=res["tri_counts"].numpy().astype(np.int64),
-                 grads=dict(branches=[{k: v.numpy() for k, v in bp.items()} for bp in g["branches"]],
-                            head={k: v.numpy() for k, v in g["head"].items()}), decs=decs, sel=sel)
-    _ORACLE[key] = entry
-    return entry
+    return dict(xs=xs, uses=uses, labels=labels, onehot=onehot, p64=p64, x64=x64, u64=u64,
+                loss=float(res["loss"]), triplet=float(res["triplet"]), xent=float(res["xent"]),
+                signature=res["signature"].detach().numpy(), tri_counts=res["tri_counts"].numpy().astype(np.int64),
+                grads=dict(branches=[{k: v.numpy() for k, v in bp.items()} for bp in g["branches"]],
+                           head={k: v.numpy() for k, v in g["head"].items()}), decs=decs, sel=sel)
+
+
+class _Prefetch:
+    """Evaluates the workloads `wanted` (in order) in a CHILD PROCESS with its own torch thread pool (a thread of this process shares
+    the pool with the foreground tests' CPU work and slowed them 3-6x), at most MAX_AHEAD finished-and-unread entries at a time.
+    Entries travel as pickles in a /dev/shm directory; the child never touches the GPU."""
+
+    def __init__(self):
+        self.proc, self.dir, self.wanted = None, None, []
+
+    def start(self, wanted):
+        if self.proc is not None:
+            return
+        self.wanted = list(wanted)
+        self.dir = tempfile.mkdtemp(prefix="ugn_oracle_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+        env = dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="",
+                   OMP_NUM_THREADS=str(max(8, (os.cpu_count() or 16) // 4)))
+        self.proc = subprocess.Popen([sys.executable, "-m", "tests.test_fullsize_parity_gpu", self.dir] + self.wanted,
+                                     cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), env=env)
+        atexit.register(self.close)
+
+    def get(self, w):
+        if self.proc is None:           # (a run that did not go through conftest's session fixture)
+            self.start([w])
+        if w not in self.wanted:
+            raise RuntimeError("workload %s was not scheduled for the oracle process (%s)" % (w, self.wanted))
+        path = os.path.join(self.dir, w + ".pkl")
+        while not os.path.exists(path):
+            if self.proc.poll() is not None and not os.path.exists(path):
+                raise RuntimeError("the fp64 oracle process ended (exit code %s) without writing %s" % (self.proc.returncode, path))
+            time.sleep(0.2)
+        with open(path, "rb") as f:
+            return pickle.load(f)
+
+    def release(self, w):
+        try:
+            os.remove(os.path.join(self.dir, w + ".pkl"))
+        except OSError:
+            pass
+
+    def close(self):
+        if self.proc is not None and self.proc.poll() is None:
+            self.proc.kill()          # (the exact child this object started)
+        if self.dir:
+            shutil.rmtree(self.dir, ignore_errors=True)
+
+
+def _worker(outdir, wanted):
+    """Child process: evaluate the workloads in order; wait while MAX_AHEAD finished entries are still unread."""
+    for w in wanted:
+        while len([f for f in os.listdir(outdir) if f.endswith(".pkl")]) >= MAX_AHEAD:
+            time.sleep(0.2)
+        entry = _evaluate(CASES[w])
+        tmp = os.path.join(outdir, w + ".tmp")
+        with open(tmp, "wb") as f:
+            pickle.dump(entry, f, protocol=pickle.HIGHEST_PROTOCOL)
+        os.rename(tmp, os.path.join(outdir, w + ".pkl"))
+
+
+PREFETCH = _Prefetch()
+LAST_CASE = {"C2": "C2h2", "C3": "C3h2", "C4": "C4h2", "C5": "C5"}      # the case after which a workload's entry is dropped
 
 
 # the decisions of a step may differ from the fp64 oracle's only at near-ties: the oracle's value at the HIP path's choice within
@@ -101,12 +163,22 @@ NEAR_TIE = 8
 @pytest.mark.timeout(1500)
 @pytest.mark.parametrize("name", ["C2", "C2h2", "C3", "C3h2", "C4", "C4h2", "C5"])
 def test_whole_step_matches_the_fp64_oracle(dev, name):
+    w = WORKLOAD[name]
+    try:
+        _whole_step(dev, name, CASES[name], PREFETCH.get(w))
+    finally:
+        if LAST_SELECTED.get(w, LAST_CASE[w]) == name:       # the last case of this session that reads the workload's entry
+            PREFETCH.release(w)
+
+
+LAST_SELECTED = {}      # (filled by tests/conftest.py from the session's selection: workload -> its last selected case)
+
+
+def _whole_step(dev, name, c, E):
     from ugaitnet_amd.engine import GaitCore
-    c = CASES[name]
     kinds, b, ncls = c["kinds"], c["b"], c["ncls"]
     bf16 = c.get("precision") == "bf16"
     multimodal = c.get("multimodal", True)
-    E = _oracle(c)
     xs, uses, labels, onehot, p64 = E["xs"], E["uses"], E["labels"], E["onehot"], E["p64"]
     core = GaitCore([2 if k == "of" else 1 for k in kinds], nclasses=ncls, multimodal=multimodal, fuse_mode="sign_max", margin=0.2,
                     loss_weights=(1.0, 0.1), device=dev, conv_precision=c.get("precision", "f32"))
@@ -186,3 +258,7 @@ def test_whole_step_matches_the_fp64_oracle(dev, name):
             assert max(wf.values()) <= 5e-5, wf
     print("%s: loss %.6f (oracle %.6f), max |sig - oracle| %.2e, worst gradient rel-L2 %.2e (%s)"
           % (name, ls["loss"], E["loss"], np.abs(sig - E["signature"]).max(), max(worst.values()), max(worst, key=worst.get)))
+
+
+if __name__ == "__main__":      # the oracle child process: python -m tests.test_fullsize_parity_gpu <dir> <workload> ...
+    _worker(sys.argv[1], sys.argv[2:])
