@@ -101,8 +101,11 @@ constexpr int lds_bytes() {
 #ifndef UGN_T16_MIN
 #define UGN_T16_MIN 32
 #endif
+#ifndef UGN_NR_POOLED
+#define UGN_NR_POOLED 1   /* the pooled 64 -> 64 data gradient on conv_nr_kernel<..., IN_POOLED> (else conv_mm_kernel, 32x32x16) */
+#endif
 __host__ __device__ constexpr bool mm_tile16(int kc, int nc, int dgrad) {
-  return nc >= UGN_T16_MIN && !(dgrad && kc == 64 && nc == 64) && !(dgrad && kc == 32 && nc == 32);
+  return nc >= UGN_T16_MIN && !(dgrad && kc == 64 && nc == 64 && !UGN_NR_POOLED) && !(dgrad && kc == 32 && nc == 32);
 }
 // ... and which of those run on conv_nr_kernel (64 / 128 columns; filter tiles of 16 consecutive channels)
 #ifndef UGN_MM_NR
@@ -120,7 +123,9 @@ __host__ __device__ constexpr bool mm_tile16(int kc, int nc, int dgrad) {
 #ifndef UGN_NR_MINNC
 #define UGN_NR_MINNC 128
 #endif
-__host__ __device__ constexpr bool mm_nr(int kc, int nc, int dgrad) { return UGN_MM_NR && nc >= UGN_NR_MINNC && mm_tile16(kc, nc, dgrad); }
+__host__ __device__ constexpr bool mm_nr(int kc, int nc, int dgrad) {
+  return UGN_MM_NR && mm_tile16(kc, nc, dgrad) && (nc >= UGN_NR_MINNC || (UGN_NR_POOLED && dgrad && kc == 64 && nc == 64));
+}
 
 constexpr int kPackJobs = 64;
 struct PackTable {
@@ -1614,7 +1619,10 @@ __device__ __forceinline__ float dpp_swap1(float v) {       // value of lane ^ 1
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, false));
 }
 
-template <int KC, int NC, int HW, int EPI>
+// IN_POOLED (the 64 -> 64 pooled data gradient): `in` is the POOLED gradient + argmax bytes; a thread's pooled pixel x 8 channels of
+// the chunk after the next travel through registers (plain global loads a chunk ahead) and are scattered -- MaxPool backward: the value
+// where the argmax byte names the position, zero elsewhere -- into the other halo buffer a few rows into the chunk.
+template <int KC, int NC, int HW, int EPI, int IN_POOLED = 0>
 __global__ __launch_bounds__(512, 2) void conv_nr_kernel(const MmJobs jt, const void* __restrict__ zeros) {
   constexpr int NT = NC / 16, MPARTS = 8 / NT > 0 ? 8 / NT : 1, ROWS = 16 / MPARTS, NCHUNK = KC / 32;
   constexpr int RPX = HW / 16, RPI = RPX * RPX;
@@ -1662,7 +1670,59 @@ __global__ __launch_bounds__(512, 2) void conv_nr_kernel(const MmJobs jt, const 
       nb[dy][1] = *reinterpret_cast<const uint4*>(p + dy * (3 * NT * 2048) + 1024);
     }
   };
-  issue_tile(jt.job[jb], lit, 0, sbase);
+  // IN_POOLED: this thread's unit of the 10 x 10 pooled pixels under a region's halo -- pooled pixel spp, channel group scg (8 channels)
+  const int spp = tid >> 2, scg = tid & 3;
+  const int sprow = (spp * 205) >> 11, spcol = spp - sprow * 10;
+  uint4 shi = make_uint4(0u, 0u, 0u, 0u), slo = shi;
+  uint2 six = make_uint2(0u, 0u);
+  auto stg_load = [&](const MmJob& J, int lit_, int chunk) {
+    constexpr int HP = HW / 2;
+    const int img = lit_ / RPI, rrem = lit_ % RPI;
+    const int pr = ((rrem / RPX) * 16) / 2 - 1 + sprow, pc = ((rrem % RPX) * 16) / 2 - 1 + spcol;
+    const bool ok = tid < 400 && (unsigned)pr < (unsigned)HP && (unsigned)pc < (unsigned)HP;
+    shi = make_uint4(0u, 0u, 0u, 0u);
+    slo = shi;
+    six = make_uint2(0u, 0u);           // (outside the image the gradient is zero: the scatter still overwrites the stale halo)
+    if (ok) {
+      const size_t o = (size_t)img * HP * HP + (size_t)(pr * HP + pc);
+      const char* v = reinterpret_cast<const char*>(J.in) + o * (KC * 4) + chunk * 64 + scg * 16;
+      shi = *reinterpret_cast<const uint4*>(v);
+      slo = *reinterpret_cast<const uint4*>(v + KC * 2);
+      six = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(J.in_idx) + o * KC + chunk * 32 + scg * 8);
+    }
+  };
+  auto scatter = [&](int buf) {       // registers -> halo buffer `buf`: quarter jj of pixel (hy, hx) into slot nr_slot(jj, hx)
+    if (tid >= 400) return;
+    const unsigned hv[4] = {shi.x, shi.y, shi.z, shi.w}, lv[4] = {slo.x, slo.y, slo.z, slo.w};
+#pragma unroll
+    for (int pos = 0; pos < 4; ++pos) {
+      const int hy = 2 * sprow - 1 + (pos >> 1), hx = 2 * spcol - 1 + (pos & 1);
+      if ((unsigned)hy >= 18u || (unsigned)hx >= 18u) continue;
+      unsigned m[4];
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        const unsigned w = d < 2 ? six.x : six.y;
+        const unsigned b0 = (w >> (16 * (d & 1))) & 0xffu, b1 = (w >> (16 * (d & 1) + 8)) & 0xffu;
+        m[d] = (b0 == (unsigned)pos ? 0x0000ffffu : 0u) | (b1 == (unsigned)pos ? 0xffff0000u : 0u);
+      }
+      char* rec = smem + buf * NR_BUF + (hy * 18 + hx) * 128;
+      *reinterpret_cast<uint4*>(rec + (nr_slot(scg, hx) << 4)) = make_uint4(hv[0] & m[0], hv[1] & m[1], hv[2] & m[2], hv[3] & m[3]);
+      *reinterpret_cast<uint4*>(rec + (nr_slot(4 + scg, hx) << 4)) = make_uint4(lv[0] & m[0], lv[1] & m[1], lv[2] & m[2], lv[3] & m[3]);
+    }
+  };
+  // tile after (item, chunk): (job, local item, chunk); valid = there is one
+  if constexpr (IN_POOLED) {
+    stg_load(jt.job[jb], lit, 0);
+    scatter(0);
+    if (NCHUNK > 1) {
+      stg_load(jt.job[jb], lit, 1);
+    } else {
+      const int ni = item + gridDim.x;
+      if (ni < nitems) { const int j2 = mm_job_of(jt, ni); stg_load(jt.job[j2], ni - jt.start[j2], 0); }
+    }
+  } else {
+    issue_tile(jt.job[jb], lit, 0, sbase);
+  }
   load_b(jt.job[jb].wpk, 0, 0);
   int hbuf = 0;
   bool first_item = true;
@@ -1728,7 +1788,21 @@ __global__ __launch_bounds__(512, 2) void conv_nr_kernel(const MmJobs jt, const 
       //  column -- it does not see the DMA -- would otherwise wait for the DMA issued in front of it)
       auto tile_ahead = [&]() {
         __builtin_amdgcn_sched_barrier(0);
-        if (next_tile) issue_tile(jt.job[nx_job], n_lit, n_chunk, sbase + (unsigned)(hbuf ^ 1) * NR_BUF);
+        if constexpr (IN_POOLED) {
+          if (next_tile) {
+            scatter(hbuf ^ 1);              // the next tile (its values arrived a chunk ago) ...
+            // ... and the loads of the one after it: chunk n_chunk + 1 of the same item, or chunk 0 of the item after nx
+            if (n_chunk + 1 < NCHUNK) {
+              stg_load(jt.job[nx_job], n_lit, n_chunk + 1);
+            } else {
+              const int base_item = last_chunk ? next_item : item;      // the item the next tile belongs to
+              const int ni = base_item + gridDim.x;
+              if (ni < nitems) { const int j2 = mm_job_of(jt, ni); stg_load(jt.job[j2], ni - jt.start[j2], 0); }
+            }
+          }
+        } else {
+          if (next_tile) issue_tile(jt.job[nx_job], n_lit, n_chunk, sbase + (unsigned)(hbuf ^ 1) * NR_BUF);
+        }
         __builtin_amdgcn_sched_barrier(0);
       };
 #pragma unroll
@@ -2204,9 +2278,9 @@ int launch_d2(const MmJob* jobs, const int* n, int njobs, hipStream_t st) {
   return 0;
 }
 
-template <int KC, int NC, int HW, int EPI>
+template <int KC, int NC, int HW, int EPI, int IN_POOLED = 0>
 int launch_nr(const MmJob* jobs, const int* n, int njobs, hipStream_t st) {
-  auto kern = conv_nr_kernel<KC, NC, HW, EPI>;
+  auto kern = conv_nr_kernel<KC, NC, HW, EPI, IN_POOLED>;
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, NR_LDS);
@@ -2273,6 +2347,10 @@ int dispatch_dgrad(const MmJob* jobs, const int* n, int njobs, int hw, int cin, 
   if constexpr ((UGN_MM_D2 & 4) != 0) {        // (GEMM K = cout, N = cin)
     if (cin == 32 && cout == 64 && hw == 32 && !unpool && !act) return launch_d2<64, 32, 32, EPI_DGRAD>(jobs, n, njobs, st);
     if (cin == 64 && cout == 128 && hw == 16 && !unpool && !act) return launch_d2<128, 64, 16, EPI_DGRAD>(jobs, n, njobs, st);
+  }
+  if constexpr (mm_nr(64, 64, 1)) {      // the pooled 64 -> 64 data gradient (a4 / b2) on conv_nr_kernel
+    if (cin == 64 && cout == 64 && hw == 32 && unpool)
+      return act ? launch_nr<64, 64, 32, EPI_DGRAD_ACT, 1>(jobs, n, njobs, st) : launch_nr<64, 64, 32, EPI_DGRAD, 1>(jobs, n, njobs, st);
   }
 #define MD(CI_, CO_, HW_, U_)                                                                     \
   if (cin == CI_ && cout == CO_ && hw == HW_ && unpool == U_) {                                   \
