@@ -154,17 +154,15 @@ def _mm_work(kind, hw, cin, cout, pooled, ns, act=False):
     n = int(sum(ns))
     flops = 2.0 * 9 * cin * cout * hw * hw * n
     # (the names rocprofv3 reports, csrc/conv3x3_mm.hip: the 32 -> 32 @64x64 layer runs the two-workgroups-per-CU kernels, launches
-    #  with 128 output columns conv_nr_kernel, the other un-pooled inputs the 16x16x32 kernel, the pooled 64 -> 64 data gradient the
-    #  32x32x16 one)
+    #  with 128 output columns and the pooled 64 -> 64 data gradient conv_nr_kernel, the other un-pooled inputs conv_mm16_kernel)
     a2 = cin == 32 and cout == 32 and hw == 64 and pooled
-    t16 = lambda kc, nc, epi: ("conv_nr_kernel" if nc >= 128 else "conv_mm16_kernel") + "<%d, %d, %d, %d>" % (kc, nc, hw, epi)
+    t16 = lambda kc, nc, epi: ("conv_nr_kernel<%d, %d, %d, %d, 0>" if nc >= 128 else "conv_mm16_kernel<%d, %d, %d, %d>") % (kc, nc, hw, epi)
     if kind == "fwd":
         kern = "conv_d2_kernel<32, 32, 64, 1>" if a2 else t16(cin, cout, 1 if pooled else 0)
     elif a2 and not act:
         kern = "conv32_d2p_kernel<64>"
     else:
-        kern = ("conv_mm_kernel<%d, %d, %d, %d, %d>" % (cout, cin, hw, int(pooled), 3 if act else 2) if pooled else
-                t16(cout, cin, 3 if act else 2))
+        kern = ("conv_nr_kernel<%d, %d, %d, %d, 1>" % (cout, cin, hw, 3 if act else 2) if pooled else t16(cout, cin, 3 if act else 2))
     label = "conv3x3_%s[%d->%d @%dx%d%s h2] %s" % (kind, cin, cout, hw, hw, " pooled" if pooled else "", kern)
     # three f16 MFMAs per fp32-equivalent product: the matrix pipe executes 3x the algorithmic FLOPs.  bound="roof": bench.py prices
     # the launch against BOTH roofs (executed matrix FLOPs, algorithmic bytes) and names the one whose floor is higher
