@@ -21,6 +21,9 @@ using ugn_mm::H2Meta;
 #ifndef UGN_C5_GRID
 #define UGN_C5_GRID 1024   // persistent workgroups of the forward kernel (256 CUs x 4 workgroups of 256 threads)
 #endif
+#ifndef UGN_C5_PADK
+#define UGN_C5_PADK(K_, mb_) ((mb_) == 0 ? 0 : (K_) - 1)
+#endif
 #ifndef UGN_C5_PITCH
 #define UGN_C5_PITCH 20  // pixels per patch row in the weight-gradient kernel's LDS tile: 26 would be bank-conflict free
                          // for the five tap rows, but its extra LDS-DMA pieces cost more than the conflicts (+2-3 %)
@@ -366,7 +369,7 @@ __global__ __launch_bounds__(256) void conv5x5_wgrad_kernel(const float* __restr
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[mb][r] = 0.f;
     int k = mb * 32 + li;
-    if (k >= K) k = 0;  // padded rows: any valid address, result discarded
+    if (k >= K) k = UGN_C5_PADK(K, mb);  // padded rows: a valid address (a broadcast of a lane of this block), result discarded
     const int tap = k / CIN, c = k % CIN;
     abase[mb] = ((tap / 5) * WP + (tap % 5)) * CIN + c + ((wave * 4) * WP + lh) * CIN;  // wave owns tile rows 4w..4w+3
   }
