@@ -210,6 +210,12 @@ int ugn_gate_fuse_bwd(const float* dfused, const uint8_t* sel, const float* cons
 /* ---- tf.math.l2_normalize(x, axis=1) on [62,b,256] (axis 1 = batch), :817,:1191 ----------------------- */
 int ugn_l2norm_batch_fwd(const float* f, float* sig, int b, void* stream);
 int ugn_l2norm_batch_bwd(const float* f, const float* sig, const float* dsig, float* df, int b, void* stream);
+/* the gate / fMerge and the batch-axis normalisation in one launch, and their gradients in one (b <= 32 clips per replica): the same
+ * arithmetic and the same outputs as the two calls each replaces */
+int ugn_gate_norm_fwd(const float* const* outs_host, const float* const* uses_host, int nmod, int mode, float* fused, uint8_t* sel,
+                      float* sig, int b, void* stream);
+int ugn_gate_norm_bwd(const float* f, const float* sig, const float* dsig, const uint8_t* sel, const float* const* uses_host,
+                      float* const* douts_host, int nmod, int mode, int b, void* stream);
 
 /* ---- classification head: transpose+Flatten+Dense(softmax) + categorical cross-entropy, :848-850,:865 ---
  * sig [62,b,256], wc [15872,ncls], bc [ncls].  part: workspace [248,b,ncls] floats.

@@ -452,6 +452,35 @@ def test_l2norm_batch(dev):
     close(got[:, :, 5], ref[:, :, 5], 3e-6, "l2norm bwd clamped column")
 
 
+@pytest.mark.parametrize("mode", ["sign_max", "max", "avg"])
+@pytest.mark.parametrize("b", [24, 5, 32])
+def test_gate_and_normalisation_in_one_launch(dev, mode, b):
+    """ugn_gate_norm_fwd / _bwd (what the engine runs for a local batch of at most 32 clips) against the two launches each replaces:
+    the same bits in every output, forward and backward, ties and an all-masked clip included."""
+    from ugaitnet_amd import ops
+    rng = np.random.default_rng(70 + b)
+    nmod = 3
+    outs = [rng.normal(size=(62, b, 256)).astype(np.float32) for _ in range(nmod)]
+    outs[1][:, :, :64] = -outs[0][:, :, :64]
+    outs[2][:, :, 7] = 0.0
+    outs[0][:, :, 7] = 0.0
+    outs[1][:, :, 7] = 0.0           # an all-zero column: the 1e-12 clamp of the normalisation
+    uses = [(rng.uniform(size=(b,)) > 0.4).astype(np.float32) for _ in range(nmod)]
+    for u in uses:
+        u[0] = 0                      # an all-masked clip
+    ot, ut = [T(o, dev) for o in outs], [T(u, dev) for u in uses]
+    fused, sel = ops.gate_fuse_fwd(ot, ut, mode)
+    sig = ops.l2norm_batch_fwd(fused)
+    f2, s2, g2 = torch.empty_like(fused), torch.empty_like(sel), torch.empty_like(sig)
+    ops.gate_norm_fwd(ot, ut, mode, f2, s2, g2)
+    assert torch.equal(f2, fused) and torch.equal(s2, sel) and torch.equal(g2, sig)
+    dsig = T(rng.normal(size=(62, b, 256)).astype(np.float32), dev)
+    ref = ops.gate_fuse_bwd(ops.l2norm_batch_bwd(fused, sig, dsig), sel, ut, mode)
+    got = ops.gate_norm_bwd(fused, sig, dsig, sel, ut, mode, [torch.empty_like(fused) for _ in range(nmod)])
+    for g, r in zip(got, ref):
+        assert torch.equal(g, r)
+
+
 @pytest.mark.parametrize("b,ncls", [(24, 150), (40, 74)])
 def test_head(dev, b, ncls):
     from ugaitnet_amd import ops

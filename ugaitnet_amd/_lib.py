@@ -71,6 +71,8 @@ PROTOTYPES = {
     "ugn_gate_fuse_bwd": (_i, [_p, _p, C.POINTER(_p), C.POINTER(_p), _i, _i, _i, _p]),
     "ugn_l2norm_batch_fwd": (_i, [_p, _p, _i, _p]),
     "ugn_l2norm_batch_bwd": (_i, [_p, _p, _p, _p, _i, _p]),
+    "ugn_gate_norm_fwd": (_i, [C.POINTER(_p), C.POINTER(_p), _i, _i, _p, _p, _p, _i, _p]),
+    "ugn_gate_norm_bwd": (_i, [_p, _p, _p, _p, C.POINTER(_p), C.POINTER(_p), _i, _i, _i, _p]),
     "ugn_head_fwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _f, _i, _i, _p]),
     "ugn_head_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
     "ugn_triplet_indices_host": (_i, [_p, _i, _p, _p, C.POINTER(_i), C.POINTER(_i)]),

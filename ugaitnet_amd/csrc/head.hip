@@ -375,6 +375,95 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
 }
 
 // ------------------------------------------------------------------------------------------------------
+// gate + fMerge + batch-axis normalisation in ONE launch (and their gradients in one): the per-replica batch (<= GF_MAXB clips) of a
+// (bin, feature) column stays in registers between the two stages.  Same arithmetic, statement for statement, as
+// gate_fuse_fwd_kernel + l2norm_fwd_kernel and l2norm_bwd_kernel + gate_fuse_bwd_kernel (bit-identical results); two launches and a
+// round trip of `fused` / `df` through HBM less on the turn-around of the step, where nothing else runs.
+// ------------------------------------------------------------------------------------------------------
+constexpr int GF_MAXB = 32;
+
+__device__ __forceinline__ float gate_one(const ModPtrs& mp, int nmod, int mode, size_t e, int b, int& s) {
+  float g[4];
+  for (int m = 0; m < nmod; ++m) g[m] = mp.x[m][e] * mp.use[m][b];
+  float out;
+  s = 0;
+  if (mode == UGN_FUSE_SIGN_MAX) {
+    float best = fabsf(g[0]);
+    for (int m = 1; m < nmod; ++m)
+      if (fabsf(g[m]) > best) { best = fabsf(g[m]); s = m; }
+    out = g[s];
+  } else if (mode == UGN_FUSE_MAX) {
+    out = g[0];
+    for (int m = 1; m < nmod; ++m)
+      if (g[m] > out) { out = g[m]; s = m; }
+  } else {
+    out = 0.f;
+    for (int m = 0; m < nmod; ++m) out += g[m];
+    out /= (float)nmod;
+    s = 255;
+  }
+  return out;
+}
+
+__global__ __launch_bounds__(64) void gate_norm_fwd_kernel(ModPtrs mp, int nmod, int mode, float* __restrict__ fused,
+                                                           uint8_t* __restrict__ sel, float* __restrict__ sig, int bsz) {
+  const int col = blockIdx.x * blockDim.x + threadIdx.x;
+  if (col >= NBINS * HID) return;
+  const int k = col / HID, d = col % HID;
+  const size_t base = (size_t)k * bsz * HID + d;
+  float v[GF_MAXB];
+  float ss = 0.f;
+#pragma unroll
+  for (int b = 0; b < GF_MAXB; ++b)
+    if (b < bsz) {
+      int s;
+      v[b] = gate_one(mp, nmod, mode, base + (size_t)b * HID, b, s);
+      fused[base + (size_t)b * HID] = v[b];
+      sel[base + (size_t)b * HID] = (uint8_t)s;
+    }
+#pragma unroll
+  for (int b = 0; b < GF_MAXB; ++b)
+    if (b < bsz) ss = fmaf(v[b], v[b], ss);
+  const float inv = 1.f / sqrtf(fmaxf(ss, 1e-12f));
+#pragma unroll
+  for (int b = 0; b < GF_MAXB; ++b)
+    if (b < bsz) sig[base + (size_t)b * HID] = v[b] * inv;
+}
+
+__global__ __launch_bounds__(64) void gate_norm_bwd_kernel(ModPtrs mp, int nmod, int mode, const float* __restrict__ f,
+                                                           const float* __restrict__ sig, const float* __restrict__ dsig,
+                                                           const uint8_t* __restrict__ sel, int bsz) {
+  const int col = blockIdx.x * blockDim.x + threadIdx.x;
+  if (col >= NBINS * HID) return;
+  const int k = col / HID, d = col % HID;
+  const size_t base = (size_t)k * bsz * HID + d;
+  float sv[GF_MAXB], gv[GF_MAXB];
+  float ss = 0.f, dot = 0.f;
+#pragma unroll
+  for (int b = 0; b < GF_MAXB; ++b)
+    if (b < bsz) {
+      const float v = f[base + (size_t)b * HID];
+      sv[b] = sig[base + (size_t)b * HID];
+      gv[b] = dsig[base + (size_t)b * HID];
+      ss = fmaf(v, v, ss);
+      dot = fmaf(sv[b], gv[b], dot);
+    }
+  const bool active = ss > 1e-12f;
+  const float inv = 1.f / sqrtf(fmaxf(ss, 1e-12f));
+#pragma unroll
+  for (int b = 0; b < GF_MAXB; ++b)
+    if (b < bsz) {
+      const size_t o = base + (size_t)b * HID;
+      const float g = active ? (gv[b] - sv[b] * dot) * inv : gv[b] * inv;
+      const int s = sel[o];
+      for (int m = 0; m < nmod; ++m) {
+        const float part = mode == UGN_FUSE_AVG ? g / (float)nmod : (s == m ? g : 0.f);
+        mp.dx[m][o] = part * mp.use[m][b];
+      }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
 constexpr int TR_DC = 32;  // feature chunk staged in LDS
 
 // The part every triplet variant shares (nets/triplet_loss_all.py:70-77 `batch_dist`): Gram matrix of a bin's m embeddings in
@@ -662,6 +751,30 @@ extern "C" int ugn_gate_fuse_bwd(const float* dfused, const uint8_t* sel, const 
   hipLaunchKernelGGL(gate_fuse_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, mp,
                      nmod, mode, dfused, sel, b, total);
   UGN_CHECK_LAUNCH("gate_fuse_bwd");
+  return 0;
+}
+
+/* ugn_gate_fuse_fwd + ugn_l2norm_batch_fwd in one launch (b <= 32): fused, sel and sig as the two calls write them */
+extern "C" int ugn_gate_norm_fwd(const float* const* outs_host, const float* const* uses_host, int nmod, int mode, float* fused,
+                                 uint8_t* sel, float* sig, int b, void* stream) {
+  UGN_REQUIRE(outs_host && uses_host && fused && sel && sig && b > 0 && b <= GF_MAXB, "ugn_gate_norm_fwd: bad arguments (b = 1..%d)", GF_MAXB);
+  UGN_REQUIRE(nmod >= 1 && nmod <= 4 && mode >= 0 && mode <= 2, "ugn_gate_norm_fwd: nmod 1..4, mode 0..2");
+  ModPtrs mp = {};
+  for (int m = 0; m < nmod; ++m) { mp.x[m] = outs_host[m]; mp.use[m] = uses_host[m]; }
+  hipLaunchKernelGGL(gate_norm_fwd_kernel, dim3(NBINS * HID / 64), dim3(64), 0, (hipStream_t)stream, mp, nmod, mode, fused, sel, sig, b);
+  UGN_CHECK_LAUNCH("gate_norm_fwd");
+  return 0;
+}
+
+/* ugn_l2norm_batch_bwd + ugn_gate_fuse_bwd in one launch (b <= 32): douts as the two calls write them */
+extern "C" int ugn_gate_norm_bwd(const float* f, const float* sig, const float* dsig, const uint8_t* sel,
+                                 const float* const* uses_host, float* const* douts_host, int nmod, int mode, int b, void* stream) {
+  UGN_REQUIRE(f && sig && dsig && sel && uses_host && douts_host && b > 0 && b <= GF_MAXB, "ugn_gate_norm_bwd: bad arguments (b = 1..%d)", GF_MAXB);
+  UGN_REQUIRE(nmod >= 1 && nmod <= 4 && mode >= 0 && mode <= 2, "ugn_gate_norm_bwd: nmod 1..4, mode 0..2");
+  ModPtrs mp = {};
+  for (int m = 0; m < nmod; ++m) { mp.dx[m] = douts_host[m]; mp.use[m] = uses_host[m]; }
+  hipLaunchKernelGGL(gate_norm_bwd_kernel, dim3(NBINS * HID / 64), dim3(64), 0, (hipStream_t)stream, mp, nmod, mode, f, sig, dsig, sel, b);
+  UGN_CHECK_LAUNCH("gate_norm_bwd");
   return 0;
 }
 

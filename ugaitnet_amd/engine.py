@@ -44,6 +44,8 @@ NBINS, FEAT, HIDDEN = 62, 128, 256
 #   "bf16w" (round 1-2) fp32 tensors, Winograd with bf16-rounded MFMA operands
 DEFAULT_PRECISION = os.environ.get("UGN_CONV_PRECISION", "h2")
 # Arithmetic of forward-only queries behind the Keras surface (model.predict, get_layer(...).output taps, UWYHSemiNet.encode):
+# UGN_GATE_NORM_FUSED=0: the gate / fMerge and the batch normalisation as two launches each way (rounds 1-3; same results)
+GATE_NORM_FUSED = os.environ.get("UGN_GATE_NORM_FUSED", "1") != "0"
 # "f32" by default -- see GaitCore.arithmetic; "same" keeps the training arithmetic (UGN_INFER_PRECISION).
 INFER_PRECISION = os.environ.get("UGN_INFER_PRECISION", "f32")
 
@@ -808,6 +810,12 @@ class GaitCore:
             self.sig = dp.gather_batch_axis(outs[0], 1, self.pg, check=False, force=self.force) if gather else outs[0]
             return self.sig
         self.uses = [self._dev(u, (b,)) for u in uses]
+        if not gather and GATE_NORM_FUSED and b <= ops.GATE_NORM_MAXB:
+            # gate / fMerge and the normalisation over the (local) batch in one launch: same results, one launch and one round trip less
+            self.fused, self.sel, self.sig = ops.gate_norm_fwd(outs, self.uses, self.fuse_mode, self._buf("fused", (NBINS, b, HIDDEN)),
+                                                               self._buf("sel", (NBINS, b, HIDDEN), torch.uint8),
+                                                               self._buf("sig", (NBINS, b, HIDDEN)))
+            return self.sig
         self.fused, self.sel = ops.gate_fuse_fwd(outs, self.uses, self.fuse_mode, self._buf("fused", (NBINS, b, HIDDEN)),
                                                  self._buf("sel", (NBINS, b, HIDDEN), torch.uint8))
         if gather:
@@ -875,7 +883,10 @@ class GaitCore:
             return
         bl, lo = self.last_b, self.row0
         own = (lambda t: t[:, lo:lo + bl].contiguous()) if self.global_batch else (lambda t: t)
-        if self.multimodal:
+        if self.multimodal and not self.global_batch and GATE_NORM_FUSED and b <= ops.GATE_NORM_MAXB:
+            douts = ops.gate_norm_bwd(self.fused, sig, dsig, self.sel, self.uses, self.fuse_mode,
+                                      [self._buf("dout%d" % m, (NBINS, bl, HIDDEN)) for m in range(self.nmod)])
+        elif self.multimodal:
             df = own(ops.l2norm_batch_bwd(self.fused, sig, dsig, self._buf("df", (NBINS, b, HIDDEN))))
             douts = ops.gate_fuse_bwd(df, self.sel, self.uses, self.fuse_mode,
                                       [self._buf("dout%d" % m, (NBINS, bl, HIDDEN)) for m in range(self.nmod)])

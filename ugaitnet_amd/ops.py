@@ -498,6 +498,23 @@ def gate_fuse_bwd(dfused, sel, uses, mode, douts=None):
     return douts
 
 
+GATE_NORM_MAXB = 32
+
+
+def gate_norm_fwd(outs, uses, mode, fused, sel, sig):
+    """gate_fuse_fwd + l2norm_batch_fwd in one launch (at most GATE_NORM_MAXB clips): the same three outputs."""
+    call("ugn_gate_norm_fwd", ptr_array(outs), ptr_array(uses), len(outs), _lib.FUSE_MODES[mode], ptr(fused), ptr(sel), ptr(sig),
+         outs[0].shape[1], _stream())
+    return fused, sel, sig
+
+
+def gate_norm_bwd(f, sig, dsig, sel, uses, mode, douts):
+    """l2norm_batch_bwd + gate_fuse_bwd in one launch (at most GATE_NORM_MAXB clips): the same douts."""
+    call("ugn_gate_norm_bwd", ptr(_chk(f)), ptr(_chk(sig)), ptr(_chk(dsig)), ptr(sel), ptr_array(uses), ptr_array(douts), len(uses),
+         _lib.FUSE_MODES[mode], f.shape[1], _stream())
+    return douts
+
+
 def l2norm_batch_fwd(f, sig=None):
     sig = torch.empty_like(f) if sig is None else sig
     call("ugn_l2norm_batch_fwd", ptr(_chk(f)), ptr(sig), f.shape[1], _stream())
