@@ -193,10 +193,16 @@ def _whole_step(dev, name, c, E):
     if bf16:    # bf16 operands (8 significant bits) in every 3x3 convolution: the bars of test_bf16_operand_mode_against_the_oracle
         # under sign_max a near-tie between two modalities flips the selected one (and possibly the sign) at 8 significant bits:
         # the FRACTION of such elements is bounded, the rest stays within the bf16 bar (as in test_bf16_operand_mode_...)
-        assert abs(ls["loss"] - E["loss"]) <= 5e-2 * abs(E["loss"]), (ls, E["loss"])
+        # measured at full size (round 4): loss 1.8e-4 relative, signature median 3.4e-4 / 99th percentile 3.0e-3 / 0.05 % of the elements
+        # (the sign_max near-ties that flip the selected modality) above 5e-2, active-triplet counts within 6 of 612: bars at ~3x those
+        assert abs(ls["loss"] - E["loss"]) <= 1e-3 * abs(E["loss"]), (ls, E["loss"])
         serr = np.abs(sig - E["signature"])
-        assert (serr > 5e-2).mean() < 0.05 and np.median(serr) <= 5e-3, ((serr > 5e-2).mean(), np.median(serr))
-        assert dcount.max() <= 0.05 * max(1.0, float(E["tri_counts"].max()))
+        print("%s signature: median |error| %.2e, 99th percentile %.2e, share above 5e-2 %.4f, above 2e-2 %.4f; loss %.5f (oracle %.5f); "
+              "active-triplet count differences: max %d of %d" % (name, np.median(serr), np.quantile(serr, 0.99), (serr > 5e-2).mean(),
+                                                                    (serr > 2e-2).mean(), ls["loss"], E["loss"], dcount.max(), E["tri_counts"].max()))
+        assert (serr > 5e-2).mean() < 2e-3 and np.median(serr) <= 1e-3 and np.quantile(serr, 0.99) <= 1e-2, \
+            ((serr > 5e-2).mean(), np.median(serr), np.quantile(serr, 0.99))
+        assert dcount.max() <= 0.03 * max(1.0, float(E["tri_counts"].max()))
     else:
         assert abs(ls["loss"] - E["loss"]) <= 1e-4, (ls, E["loss"])
         assert abs(ls["triplet"] - E["triplet"]) <= 1e-4 and abs(ls["xent"] - E["xent"]) <= 1e-4
