@@ -381,86 +381,122 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
 // round trip of `fused` / `df` through HBM less on the turn-around of the step, where nothing else runs.
 // ------------------------------------------------------------------------------------------------------
 constexpr int GF_MAXB = 32;
+constexpr int GF_COLS = 32, GF_BG = 8;        // a workgroup: 32 consecutive features of a bin x 8 clip groups (clips bg, bg + 8, ...)
 
-__device__ __forceinline__ float gate_one(const ModPtrs& mp, int nmod, int mode, size_t e, int b, int& s) {
-  float g[4];
-  for (int m = 0; m < nmod; ++m) g[m] = mp.x[m][e] * mp.use[m][b];
-  float out;
+// gate + fMerge of one element (NMOD a template parameter: no indexed private arrays); s = the selected modality (255: average)
+template <int NMOD>
+__device__ __forceinline__ float gate_one(const ModPtrs& mp, int mode, size_t e, int b, int& s) {
+  float g[NMOD];
+#pragma unroll
+  for (int m = 0; m < NMOD; ++m) g[m] = mp.x[m][e] * mp.use[m][b];
+  float out = g[0];
   s = 0;
   if (mode == UGN_FUSE_SIGN_MAX) {
     float best = fabsf(g[0]);
-    for (int m = 1; m < nmod; ++m)
-      if (fabsf(g[m]) > best) { best = fabsf(g[m]); s = m; }
-    out = g[s];
+#pragma unroll
+    for (int m = 1; m < NMOD; ++m)
+      if (fabsf(g[m]) > best) { best = fabsf(g[m]); s = m; out = g[m]; }      // first index wins ties (tf.argmax)
   } else if (mode == UGN_FUSE_MAX) {
-    out = g[0];
-    for (int m = 1; m < nmod; ++m)
-      if (g[m] > out) { out = g[m]; s = m; }
+#pragma unroll
+    for (int m = 1; m < NMOD; ++m)
+      if (g[m] > out) { out = g[m]; s = m; }                                    // tf.maximum gradient: ties to the first argument
   } else {
     out = 0.f;
-    for (int m = 0; m < nmod; ++m) out += g[m];
-    out /= (float)nmod;
+#pragma unroll
+    for (int m = 0; m < NMOD; ++m) out += g[m];
+    out /= (float)NMOD;
     s = 255;
   }
   return out;
 }
 
-__global__ __launch_bounds__(64) void gate_norm_fwd_kernel(ModPtrs mp, int nmod, int mode, float* __restrict__ fused,
-                                                           uint8_t* __restrict__ sel, float* __restrict__ sig, int bsz) {
-  const int col = blockIdx.x * blockDim.x + threadIdx.x;
-  if (col >= NBINS * HID) return;
-  const int k = col / HID, d = col % HID;
+// The squares of a column are summed by ONE thread in clip order (fmaf chain), as l2norm_fwd_kernel does: bit-identical.
+template <int NMOD>
+__global__ __launch_bounds__(GF_COLS * GF_BG) void gate_norm_fwd_kernel(ModPtrs mp, int mode, float* __restrict__ fused,
+                                                                        uint8_t* __restrict__ sel, float* __restrict__ sig, int bsz) {
+  __shared__ float sV[GF_MAXB][GF_COLS];
+  __shared__ float sInv[GF_COLS];
+  const int c = threadIdx.x % GF_COLS, bg = threadIdx.x / GF_COLS;
+  const int col = blockIdx.x * GF_COLS + c, k = col / HID, d = col % HID;      // (HID is a multiple of GF_COLS: one bin per workgroup)
   const size_t base = (size_t)k * bsz * HID + d;
-  float v[GF_MAXB];
-  float ss = 0.f;
+  float v[GF_MAXB / GF_BG];
 #pragma unroll
-  for (int b = 0; b < GF_MAXB; ++b)
+  for (int i = 0; i < GF_MAXB / GF_BG; ++i) {
+    const int b = bg + GF_BG * i;
     if (b < bsz) {
       int s;
-      v[b] = gate_one(mp, nmod, mode, base + (size_t)b * HID, b, s);
-      fused[base + (size_t)b * HID] = v[b];
+      v[i] = gate_one<NMOD>(mp, mode, base + (size_t)b * HID, b, s);
+      fused[base + (size_t)b * HID] = v[i];
       sel[base + (size_t)b * HID] = (uint8_t)s;
+      sV[b][c] = v[i];
     }
+  }
+  __syncthreads();
+  if (bg == 0) {
+    float ss = 0.f;
+    for (int b = 0; b < bsz; ++b) ss = fmaf(sV[b][c], sV[b][c], ss);
+    sInv[c] = 1.f / sqrtf(fmaxf(ss, 1e-12f));
+  }
+  __syncthreads();
+  const float inv = sInv[c];
 #pragma unroll
-  for (int b = 0; b < GF_MAXB; ++b)
-    if (b < bsz) ss = fmaf(v[b], v[b], ss);
-  const float inv = 1.f / sqrtf(fmaxf(ss, 1e-12f));
-#pragma unroll
-  for (int b = 0; b < GF_MAXB; ++b)
-    if (b < bsz) sig[base + (size_t)b * HID] = v[b] * inv;
+  for (int i = 0; i < GF_MAXB / GF_BG; ++i) {
+    const int b = bg + GF_BG * i;
+    if (b < bsz) sig[base + (size_t)b * HID] = v[i] * inv;
+  }
 }
 
-__global__ __launch_bounds__(64) void gate_norm_bwd_kernel(ModPtrs mp, int nmod, int mode, const float* __restrict__ f,
-                                                           const float* __restrict__ sig, const float* __restrict__ dsig,
-                                                           const uint8_t* __restrict__ sel, int bsz) {
-  const int col = blockIdx.x * blockDim.x + threadIdx.x;
-  if (col >= NBINS * HID) return;
-  const int k = col / HID, d = col % HID;
+template <int NMOD>
+__global__ __launch_bounds__(GF_COLS * GF_BG) void gate_norm_bwd_kernel(ModPtrs mp, int mode, const float* __restrict__ f,
+                                                                        const float* __restrict__ sig, const float* __restrict__ dsig,
+                                                                        const uint8_t* __restrict__ sel, int bsz) {
+  __shared__ float sF[GF_MAXB][GF_COLS], sS[GF_MAXB][GF_COLS], sG[GF_MAXB][GF_COLS];
+  __shared__ float sDot[GF_COLS], sInv[GF_COLS];
+  __shared__ int sAct[GF_COLS];
+  const int c = threadIdx.x % GF_COLS, bg = threadIdx.x / GF_COLS;
+  const int col = blockIdx.x * GF_COLS + c, k = col / HID, d = col % HID;
   const size_t base = (size_t)k * bsz * HID + d;
-  float sv[GF_MAXB], gv[GF_MAXB];
-  float ss = 0.f, dot = 0.f;
+  float sv[GF_MAXB / GF_BG], gv[GF_MAXB / GF_BG];
 #pragma unroll
-  for (int b = 0; b < GF_MAXB; ++b)
-    if (b < bsz) {
-      const float v = f[base + (size_t)b * HID];
-      sv[b] = sig[base + (size_t)b * HID];
-      gv[b] = dsig[base + (size_t)b * HID];
-      ss = fmaf(v, v, ss);
-      dot = fmaf(sv[b], gv[b], dot);
-    }
-  const bool active = ss > 1e-12f;
-  const float inv = 1.f / sqrtf(fmaxf(ss, 1e-12f));
-#pragma unroll
-  for (int b = 0; b < GF_MAXB; ++b)
+  for (int i = 0; i < GF_MAXB / GF_BG; ++i) {
+    const int b = bg + GF_BG * i;
     if (b < bsz) {
       const size_t o = base + (size_t)b * HID;
-      const float g = active ? (gv[b] - sv[b] * dot) * inv : gv[b] * inv;
+      sv[i] = sig[o];
+      gv[i] = dsig[o];
+      sF[b][c] = f[o];
+      sS[b][c] = sv[i];
+      sG[b][c] = gv[i];
+    }
+  }
+  __syncthreads();
+  if (bg == 0) {       // the two sums of l2norm_bwd_kernel, in its order
+    float ss = 0.f, dot = 0.f;
+    for (int b = 0; b < bsz; ++b) {
+      ss = fmaf(sF[b][c], sF[b][c], ss);
+      dot = fmaf(sS[b][c], sG[b][c], dot);
+    }
+    sAct[c] = ss > 1e-12f ? 1 : 0;
+    sInv[c] = 1.f / sqrtf(fmaxf(ss, 1e-12f));
+    sDot[c] = dot;
+  }
+  __syncthreads();
+  const bool active = sAct[c] != 0;
+  const float inv = sInv[c], dot = sDot[c];
+#pragma unroll
+  for (int i = 0; i < GF_MAXB / GF_BG; ++i) {
+    const int b = bg + GF_BG * i;
+    if (b < bsz) {
+      const size_t o = base + (size_t)b * HID;
+      const float g = active ? (gv[i] - sv[i] * dot) * inv : gv[i] * inv;
       const int s = sel[o];
-      for (int m = 0; m < nmod; ++m) {
-        const float part = mode == UGN_FUSE_AVG ? g / (float)nmod : (s == m ? g : 0.f);
+#pragma unroll
+      for (int m = 0; m < NMOD; ++m) {
+        const float part = mode == UGN_FUSE_AVG ? g / (float)NMOD : (s == m ? g : 0.f);
         mp.dx[m][o] = part * mp.use[m][b];
       }
     }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -761,7 +797,14 @@ extern "C" int ugn_gate_norm_fwd(const float* const* outs_host, const float* con
   UGN_REQUIRE(nmod >= 1 && nmod <= 4 && mode >= 0 && mode <= 2, "ugn_gate_norm_fwd: nmod 1..4, mode 0..2");
   ModPtrs mp = {};
   for (int m = 0; m < nmod; ++m) { mp.x[m] = outs_host[m]; mp.use[m] = uses_host[m]; }
-  hipLaunchKernelGGL(gate_norm_fwd_kernel, dim3(NBINS * HID / 64), dim3(64), 0, (hipStream_t)stream, mp, nmod, mode, fused, sel, sig, b);
+  const dim3 grid(NBINS * HID / GF_COLS), block(GF_COLS * GF_BG);
+  hipStream_t st = (hipStream_t)stream;
+  switch (nmod) {
+    case 1: hipLaunchKernelGGL(gate_norm_fwd_kernel<1>, grid, block, 0, st, mp, mode, fused, sel, sig, b); break;
+    case 2: hipLaunchKernelGGL(gate_norm_fwd_kernel<2>, grid, block, 0, st, mp, mode, fused, sel, sig, b); break;
+    case 3: hipLaunchKernelGGL(gate_norm_fwd_kernel<3>, grid, block, 0, st, mp, mode, fused, sel, sig, b); break;
+    default: hipLaunchKernelGGL(gate_norm_fwd_kernel<4>, grid, block, 0, st, mp, mode, fused, sel, sig, b); break;
+  }
   UGN_CHECK_LAUNCH("gate_norm_fwd");
   return 0;
 }
@@ -773,7 +816,14 @@ extern "C" int ugn_gate_norm_bwd(const float* f, const float* sig, const float* 
   UGN_REQUIRE(nmod >= 1 && nmod <= 4 && mode >= 0 && mode <= 2, "ugn_gate_norm_bwd: nmod 1..4, mode 0..2");
   ModPtrs mp = {};
   for (int m = 0; m < nmod; ++m) { mp.dx[m] = douts_host[m]; mp.use[m] = uses_host[m]; }
-  hipLaunchKernelGGL(gate_norm_bwd_kernel, dim3(NBINS * HID / 64), dim3(64), 0, (hipStream_t)stream, mp, nmod, mode, f, sig, dsig, sel, b);
+  const dim3 grid(NBINS * HID / GF_COLS), block(GF_COLS * GF_BG);
+  hipStream_t st = (hipStream_t)stream;
+  switch (nmod) {
+    case 1: hipLaunchKernelGGL(gate_norm_bwd_kernel<1>, grid, block, 0, st, mp, mode, f, sig, dsig, sel, b); break;
+    case 2: hipLaunchKernelGGL(gate_norm_bwd_kernel<2>, grid, block, 0, st, mp, mode, f, sig, dsig, sel, b); break;
+    case 3: hipLaunchKernelGGL(gate_norm_bwd_kernel<3>, grid, block, 0, st, mp, mode, f, sig, dsig, sel, b); break;
+    default: hipLaunchKernelGGL(gate_norm_bwd_kernel<4>, grid, block, 0, st, mp, mode, f, sig, dsig, sel, b); break;
+  }
   UGN_CHECK_LAUNCH("gate_norm_bwd");
   return 0;
 }
