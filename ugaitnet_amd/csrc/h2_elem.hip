@@ -14,6 +14,9 @@ namespace {
 
 constexpr int kJobs = 6;
 constexpr int MAXL = 32;
+#ifndef UGN_SETMAX_PF
+#define UGN_SETMAX_PF 4
+#endif
 
 // 4 channels of one pixel: two 8-byte loads (H, L) -> 4 stored values
 struct V4 { float x, y, z, w; };
@@ -94,10 +97,12 @@ __global__ __launch_bounds__(128) void setmax_fwd_h2_kernel(const SetJobs jt, in
       take(v.z, mx.z, r.mx.z, r.sg.z, t); take(v.w, mx.w, r.mx.w, r.sg.w, t);
     };
     int t = 1;
-    for (; t + 4 <= l; t += 4) {       // four frames (8 loads of 8 bytes) in flight per lane
-      const V4 v0 = ld4(src + (size_t)t * fstride, c, ch), v1 = ld4(src + (size_t)(t + 1) * fstride, c, ch);
-      const V4 v2 = ld4(src + (size_t)(t + 2) * fstride, c, ch), v3 = ld4(src + (size_t)(t + 3) * fstride, c, ch);
-      take4(v0, t); take4(v1, t + 1); take4(v2, t + 2); take4(v3, t + 3);
+    for (; t + UGN_SETMAX_PF <= l; t += UGN_SETMAX_PF) {       // UGN_SETMAX_PF frames (2 loads of 8 bytes each) in flight per lane
+      V4 vv[UGN_SETMAX_PF];
+#pragma unroll
+      for (int i = 0; i < UGN_SETMAX_PF; ++i) vv[i] = ld4(src + (size_t)(t + i) * fstride, c, ch);
+#pragma unroll
+      for (int i = 0; i < UGN_SETMAX_PF; ++i) take4(vv[i], t + i);
     }
     for (; t < l; ++t) take4(ld4(src + (size_t)t * fstride, c, ch), t);
     uint32_t* rp = jt.route[j] + ((size_t)b * npix + pix) * 2 * c + ch;
