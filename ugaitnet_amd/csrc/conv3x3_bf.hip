@@ -13,6 +13,10 @@
 
 using namespace ugn_mm;
 
+#ifndef UGN_BF_XCD
+#define UGN_BF_XCD 1
+#endif
+
 namespace {
 
 enum { EPI_LRELU = 0, EPI_LRELU_POOL = 1, EPI_DGRAD = 2, EPI_DGRAD_ACT = 3 };
@@ -143,7 +147,9 @@ __global__ __launch_bounds__(512, 2) void conv_bf_kernel(const MmJobs jt, const 
   const int a_lane = ((2 * wave + (q >> 1)) * G::HROW + (2 * win + (q & 1)) * G::PS) * 16 + h * 16;
   const int b_lane = W_OFF + lane * 16;
 
-  int item = blockIdx.x;
+  // (XCD-aware first item, as conv3x3_mm.hip: an XCD's workgroups take a contiguous range of a round's items, so the regions of an
+  //  image -- overlapping halos -- are in flight on ONE XCD and the overlap comes from its L2)
+  int item = (UGN_BF_XCD && (gridDim.x & 7) == 0) ? (int)((blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3)) : (int)blockIdx.x;
   const int nitems = jt.start[kMaxJobs];
   if (item >= nitems) return;
   int jb = mm_job_of(jt, item), lit = item - jt.start[jb];

@@ -13,9 +13,13 @@ typedef short s8 __attribute__((ext_vector_type(8)));
 #define LDS_PTR(T) __attribute__((address_space(3))) T*
 
 constexpr int kWgMaxJobs = 6;
-constexpr int IN_PIX = 10 * 18;
-constexpr int IN_PIECES = 12;                  // 180 pixels x 4 slots = 720 slots -> 11.25 pieces
-constexpr int IN_BYTES = IN_PIECES * 1024;
+// Rows of a strip.  With one bf16 MFMA per tap a strip's matrix work is a third of the f16x2 kernels' while its fixed costs (two
+// barriers, the strip's base arithmetic, the tile wait) are the same: the POOLED layers -- whose gradient tile is a quarter of the
+// un-pooled one, so the buffers stay small -- take 32-row strips (UGN_BF_SR_POOLED); the un-pooled 64-wide ones keep 8 (the 16x16x32
+// loop multiplies exactly a wave's two rows).
+#ifndef UGN_BF_SR_POOLED
+#define UGN_BF_SR_POOLED 32
+#endif
 
 struct WgJob {
   const uint16_t* in;        // bf16 [n][hw][hw][ci]
@@ -31,26 +35,33 @@ struct WgJobs {
   int gstep;                 // groups per combination that the grid holds at once (= ngroups on the full grid)
 };
 
-template <int CO>
+template <int CO, int POOLED>
 struct WGeo {
   static constexpr int COW = CO >= 64 ? 64 : 32;     // output channels of a workgroup
   static constexpr int PW = COW / 32;                // 32x32 block pairs
   static constexpr int KS = 8 / PW;                  // waves sharing a pair (K split)
-  static constexpr int RPW = 8 / KS;                 // pixel rows of a strip per wave
-  static constexpr int DZ_BYTES = PW * 8192;         // [block][128 pixels][64 B]
-  // pooled layers: the gradient tile is the POOLED one, [block][32 pooled pixels][64 B], + [32 pooled pixels][COW] argmax bytes
-  static constexpr int PZ_VAL = PW * 2048;
-  static constexpr int PZ_PIECES = PW * 3;           // 2 of values + 1 of argmax bytes per block
+  static constexpr int SR = POOLED ? UGN_BF_SR_POOLED : 8;      // pixel rows of a strip
+  static constexpr int RPW = SR / KS;                // pixel rows of a strip per wave
+  static constexpr int IN_PIX = (SR + 2) * 18;
+  static constexpr int IN_SLOTS = IN_PIX * 4;        // 180 pixels x 4 slots = 720 slots -> 11.25 pieces (8 rows)
+  static constexpr int IN_PIECES = (IN_SLOTS + 63) / 64;
+  static constexpr int IN_BYTES = IN_PIECES * 1024;
+  static constexpr int DZ_BLOCK = SR * 1024;         // [block][SR x 16 pixels][64 B]
+  static constexpr int DZ_BYTES = PW * DZ_BLOCK;
+  // pooled layers: the gradient tile is the POOLED one, [block][SR / 2 x 8 pooled pixels][64 B], + [pooled pixels][COW] argmax bytes
+  static constexpr int PZ_PIX = SR * 4;
+  static constexpr int PZ_BLOCK = PZ_PIX * 64;
+  static constexpr int PZ_VAL = PW * PZ_BLOCK;
+  static constexpr int PZ_PIECES = (PZ_VAL + PZ_PIX * COW) / 1024;      // values + argmax bytes (8 rows: 2 + 1 per block)
   static constexpr int PZ_BYTES = PZ_PIECES * 1024;
+  static_assert(SR % KS == 0 && (PZ_VAL + PZ_PIX * COW) % 1024 == 0, "strip geometry");
 };
-// buffer set = input halo + gradient tile (pooled: the pooled gradient tile); + 32 KB of scratch for the K-split combine (a
-// bf16 set -- 15 ... 28 KB -- is smaller than the 8 waves x 4 KB it needs)
+// buffer set = input halo + gradient tile (pooled: the pooled gradient tile); the K-split combine needs 8 waves x 4 KB of scratch:
+// the set just multiplied where a set is that large, 32 KB of its own behind the two sets otherwise
 template <int CO, int POOLED>
-constexpr int wg_set_bytes() { return IN_BYTES + (POOLED ? WGeo<CO>::PZ_BYTES : WGeo<CO>::DZ_BYTES); }
+constexpr int wg_set_bytes() { return WGeo<CO, POOLED>::IN_BYTES + (POOLED ? WGeo<CO, POOLED>::PZ_BYTES : WGeo<CO, POOLED>::DZ_BYTES); }
 template <int CO, int POOLED>
-constexpr int wg_scr_off() { return 2 * wg_set_bytes<CO, POOLED>(); }
-template <int CO, int POOLED>
-constexpr int wg_lds_bytes() { return wg_scr_off<CO, POOLED>() + 32768; }
+constexpr int wg_lds_bytes() { return 2 * wg_set_bytes<CO, POOLED>() + (wg_set_bytes<CO, POOLED>() < 32768 ? 32768 : 0); }
 
 __device__ __forceinline__ h8 tr_pair(const LDS_PTR(char) base, int off0, int off1) {
   const s4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s4))(base + off0));
@@ -65,10 +76,12 @@ __device__ __forceinline__ f32x16 mfma_b8(h8 a, h8 b, f32x16 c) {
 
 template <int CI, int CO, int HW, int POOLED>
 __global__ __launch_bounds__(512, 2) void wgrad_bf_kernel(const WgJobs jt, const void* __restrict__ zeros) {
-  using G = WGeo<CO>;
-  constexpr int COW = G::COW, PW = G::PW, KS = G::KS, RPW = G::RPW, SET = wg_set_bytes<CO, POOLED>();
+  using G = WGeo<CO, POOLED>;
+  constexpr int COW = G::COW, PW = G::PW, KS = G::KS, RPW = G::RPW, SR = G::SR, SET = wg_set_bytes<CO, POOLED>();
+  constexpr int IN_PIECES = G::IN_PIECES, IN_BYTES = G::IN_BYTES;
   constexpr int NCOC = CO / COW, NCOMBO = (CI / 32) * NCOC;
-  constexpr int SPX = HW / 16, SPI = (HW / 8) * SPX;        // strips per image row / per image
+  constexpr int SPX = HW / 16, SPI = (HW / SR) * SPX;       // strips per image row / per image
+  static_assert(HW % SR == 0, "strip geometry");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const LDS_PTR(char) lds = (LDS_PTR(char))smem;
   const unsigned sbase = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)lds);
@@ -98,7 +111,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_bf_kernel(const WgJobs jt, const
   // image); for the pooled staging tile bit 0 says "argmax bytes" (a base of their own).  Per strip a piece then costs a dozen
   // instructions, and the pieces are issued BETWEEN the taps of the MFMA loop (they were a phase of 1,200-3,700 cycles per
   // strip in which no wave multiplied; in-kernel stamps, tools/stamp_wgrad.py).
-  constexpr int NPIECE = IN_PIECES + (POOLED ? G::PZ_PIECES : PW * 8);
+  constexpr int NPIECE = IN_PIECES + (POOLED ? G::PZ_PIECES : G::DZ_BYTES / 1024);
   constexpr int NJ = (NPIECE + 7) / 8;
   int pk[NJ];
 #pragma unroll
@@ -106,28 +119,28 @@ __global__ __launch_bounds__(512, 2) void wgrad_bf_kernel(const WgJobs jt, const
     const int pi = wave + 8 * j;
     pk[j] = 127 << 5;
     if (pi < IN_PIECES) {
-      const int sg = pi * 64 + lane;                         // slot: [pixel 0..179][quarter]
+      const int sg = pi * 64 + lane;                         // slot: [pixel 0..IN_PIX - 1][quarter]
       const int pix = sg >> 2, c4 = sg & 3;
-      const int row = (pix * 3641) >> 16, px = pix - row * 18;         // pix / 18 for pix < 400
+      const int row = pix / 18, px = pix - row * 18;
       const int off = ((row - 1) * HW + (px - 1)) * (CI * 2) + c4 * 16;
-      if (sg < 720) pk[j] = (int)(((unsigned)off << 12) | (unsigned)(row << 5) | (unsigned)px);
+      if (sg < G::IN_SLOTS) pk[j] = (int)(((unsigned)off << 12) | (unsigned)(row << 5) | (unsigned)px);
     } else if (pi < NPIECE) {
       const int pd = pi - IN_PIECES;
       const int sg = pd * 64 + lane;
-      if constexpr (!POOLED) {                               // slot: [block][pixel 0..127][quarter]
-        const int nb = sg >> 9, rem2 = sg & 511;
+      if constexpr (!POOLED) {                               // slot: [block][pixel 0..SR * 16 - 1][quarter]
+        const int nb = sg / (SR * 64), rem2 = sg - nb * (SR * 64);
         const int pix = rem2 >> 2, c4 = rem2 & 3;
         pk[j] = ((pix >> 4) * HW + (pix & 15)) * (CO * 2) + (coc * COW + nb * 32) * 2 + c4 * 16;
-      } else {                     // slots: [block][pooled pixel 0..31][quarter], then [pooled pixel][COW / 16] of argmax bytes
-        constexpr int HP = HW / 2;
-        if (sg < PW * 128) {
-          const int nb = sg >> 7, rem2 = sg & 127;
+      } else {                     // slots: [block][pooled pixel][quarter], then [pooled pixel][COW / 16] of argmax bytes
+        constexpr int HP = HW / 2, PZ_PIX = G::PZ_PIX;
+        if (sg < PW * PZ_PIX * 4) {
+          const int nb = sg / (PZ_PIX * 4), rem2 = sg - nb * (PZ_PIX * 4);
           const int pp = rem2 >> 2, c4 = rem2 & 3;
           pk[j] = (((pp >> 3) * HP + (pp & 7)) * (CO * 2) + (coc * COW + nb * 32) * 2 + c4 * 16) << 1;
         } else {
-          const int si = sg - PW * 128;
+          const int si = sg - PW * PZ_PIX * 4;
           const int pp = si / (COW / 16), part = si - pp * (COW / 16);
-          pk[j] = pp < 32 ? ((((pp >> 3) * HP + (pp & 7)) * CO + coc * COW + part * 16) << 1) | 1 : -2;     // (-2: pad slot)
+          pk[j] = pp < PZ_PIX ? ((((pp >> 3) * HP + (pp & 7)) * CO + coc * COW + part * 16) << 1) | 1 : -2;     // (-2: pad slot)
         }
       }
     }
@@ -138,7 +151,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_bf_kernel(const WgJobs jt, const
     const int jb = job_of(s), ls = s - jt.start[jb];
     const int img = ls / SPI, r = ls % SPI;
     StripSrc S;
-    S.sy0 = (r / SPX) * 8;
+    S.sy0 = (r / SPX) * SR;
     S.sx0 = (r % SPX) * 16;
     S.in = reinterpret_cast<const char*>(jt.job[jb].in) + (size_t)img * HW * HW * CI * 2 + cic * 64 +
            (size_t)(S.sy0 * HW + S.sx0) * (CI * 2);
@@ -178,7 +191,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_bf_kernel(const WgJobs jt, const
   // 4h .. 4h+3 of pooled row y / 2), the four argmax bytes, and the selects.
   const int lane_off_p = (4 * h + q) * 64 + (16 * gh + 4 * p) * 2;
   auto pooled_frag = [&](int b, int y, h8& bh) {
-    const LDS_PTR(char) pv = lds + b * SET + IN_BYTES + pair * 2048 + (y >> 1) * 512 + lane_off_p;
+    const LDS_PTR(char) pv = lds + b * SET + IN_BYTES + pair * G::PZ_BLOCK + (y >> 1) * 512 + lane_off_p;
     const s4 ph = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s4))pv);
     const unsigned char* pi8 = reinterpret_cast<const unsigned char*>(smem) + b * SET + IN_BYTES + G::PZ_VAL +
                                ((y >> 1) * 8 + 4 * h) * COW + pair * 32 + (lane & 31);
@@ -233,11 +246,11 @@ __global__ __launch_bounds__(512, 2) void wgrad_bf_kernel(const WgJobs jt, const
     const bool have_in = s + 1 < s1;
     const StripSrc Sin = strip_src(have_in ? s + 1 : s);
     const LDS_PTR(char) in_b = lds + b * SET + ks * RPW * (18 * 64) + lane_off;
-    const LDS_PTR(char) dz_b = lds + b * SET + IN_BYTES + pair * 8192 + ks * RPW * (16 * 64) + lane_off;
+    const LDS_PTR(char) dz_b = lds + b * SET + IN_BYTES + pair * G::DZ_BLOCK + ks * RPW * (16 * 64) + lane_off;
     if constexpr (M16) {
       const int kg = lane >> 4;
       const LDS_PTR(char) in_m = lds + b * SET + ks * RPW * (18 * 64) + ((kg >> 1) * 18 + 8 * (kg & 1) + q) * 64 + 4 * p * 2;
-      const LDS_PTR(char) dz_m = lds + b * SET + IN_BYTES + pair * 8192 + ks * RPW * (16 * 64) + ((kg >> 1) * 16 + 8 * (kg & 1) + q) * 64 + 4 * p * 2;
+      const LDS_PTR(char) dz_m = lds + b * SET + IN_BYTES + pair * G::DZ_BLOCK + ks * RPW * (16 * 64) + ((kg >> 1) * 16 + 8 * (kg & 1) + q) * 64 + 4 * p * 2;
       h8 bh[2];
 #pragma unroll
       for (int cot = 0; cot < 2; ++cot) bh[cot] = tr_pair(dz_m, cot * 32, cot * 32 + 4 * 64);
@@ -289,7 +302,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_bf_kernel(const WgJobs jt, const
       // ---- job (or share) finished: add the K-split waves of a pair through LDS in a fixed order, write the slab.  The
       // scratch is the buffer set just multiplied (the next strip streams into the other one).
       float* slab = jt.job[jb].slab + ((size_t)combo * jt.job[jb].ng + (grp - jt.job[jb].g0)) * (9 * 32 * COW);
-      float* scr = reinterpret_cast<float*>(smem + wg_scr_off<CO, POOLED>());
+      float* scr = reinterpret_cast<float*>(smem + (SET < 32768 ? 2 * SET : b * SET));
 #pragma unroll 1
       for (int t = 0; t < 9; ++t) {
         __syncthreads();
@@ -355,14 +368,14 @@ __global__ __launch_bounds__(256) void wgrad_bf_finish(const WgFinish ft, int CI
 }
 
 template <int CI, int CO>
-constexpr int wg_ngroups() { return 256 / ((CI / 32) * (CO / WGeo<CO>::COW)); }
+constexpr int wg_ngroups() { return 256 / ((CI / 32) * (CO / WGeo<CO, 0>::COW)); }
 
 template <int CI, int CO, int HW, int POOLED>
 int launch_wgrad(const uint16_t* const* in, const uint16_t* const* dz, const uint8_t* const* dz_idx, float* const* dw, const int* n,
                  int njobs, float* ws, size_t ws_floats, hipStream_t st) {
-  using G = WGeo<CO>;
+  using G = WGeo<CO, POOLED>;
   constexpr int NCOMBO = (CI / 32) * (CO / G::COW), NG = wg_ngroups<CI, CO>();
-  constexpr int SPI = (HW / 8) * (HW / 16);
+  constexpr int SPI = (HW / G::SR) * (HW / 16);
   constexpr int LDS = wg_lds_bytes<CO, POOLED>();
   static_assert(LDS <= 163840 && NG % 8 == 0, "geometry");
   auto kern = wgrad_bf_kernel<CI, CO, HW, POOLED>;
@@ -421,7 +434,7 @@ int launch_wgrad(const uint16_t* const* in, const uint16_t* const* dz, const uin
 
 template <int CI, int CO>
 size_t ws_floats_for(int njobs) {
-  using G = WGeo<CO>;
+  using G = WGeo<CO, 0>;
   constexpr int NCOMBO = (CI / 32) * (CO / G::COW), NG = wg_ngroups<CI, CO>();
   return (size_t)NCOMBO * (NG + njobs) * 9 * 32 * G::COW;
 }
