@@ -20,6 +20,9 @@ constexpr int kWgMaxJobs = 6;
 #ifndef UGN_BF_SR_POOLED
 #define UGN_BF_SR_POOLED 32
 #endif
+#ifndef UGN_BF_SR_M16
+#define UGN_BF_SR_M16 8       /* un-pooled 64-wide layers (16x16x32 loop); 16 = two K = 32 steps per wave and strip: measured the same (1.998 | 1.997 ms) */
+#endif
 
 struct WgJob {
   const uint16_t* in;        // bf16 [n][hw][hw][ci]
@@ -40,7 +43,7 @@ struct WGeo {
   static constexpr int COW = CO >= 64 ? 64 : 32;     // output channels of a workgroup
   static constexpr int PW = COW / 32;                // 32x32 block pairs
   static constexpr int KS = 8 / PW;                  // waves sharing a pair (K split)
-  static constexpr int SR = POOLED ? UGN_BF_SR_POOLED : 8;      // pixel rows of a strip
+  static constexpr int SR = POOLED ? UGN_BF_SR_POOLED : (CO >= 64 ? UGN_BF_SR_M16 : 8);      // pixel rows of a strip
   static constexpr int RPW = SR / KS;                // pixel rows of a strip per wave
   static constexpr int IN_PIX = (SR + 2) * 18;
   static constexpr int IN_SLOTS = IN_PIX * 4;        // 180 pixels x 4 slots = 720 slots -> 11.25 pieces (8 rows)
@@ -249,26 +252,31 @@ __global__ __launch_bounds__(512, 2) void wgrad_bf_kernel(const WgJobs jt, const
     const LDS_PTR(char) dz_b = lds + b * SET + IN_BYTES + pair * G::DZ_BLOCK + ks * RPW * (16 * 64) + lane_off;
     if constexpr (M16) {
       const int kg = lane >> 4;
-      const LDS_PTR(char) in_m = lds + b * SET + ks * RPW * (18 * 64) + ((kg >> 1) * 18 + 8 * (kg & 1) + q) * 64 + 4 * p * 2;
-      const LDS_PTR(char) dz_m = lds + b * SET + IN_BYTES + pair * G::DZ_BLOCK + ks * RPW * (16 * 64) + ((kg >> 1) * 16 + 8 * (kg & 1) + q) * 64 + 4 * p * 2;
-      h8 bh[2];
+      static_assert(!M16 || RPW % 2 == 0, "a K = 32 step is two rows of the wave");
 #pragma unroll
-      for (int cot = 0; cot < 2; ++cot) bh[cot] = tr_pair(dz_m, cot * 32, cot * 32 + 4 * 64);
+      for (int kk = 0; kk < RPW / 2; ++kk) {        // K = 32 steps of the wave: its rows 2 kk, 2 kk + 1
+        const LDS_PTR(char) in_m = lds + b * SET + (ks * RPW + 2 * kk) * (18 * 64) + ((kg >> 1) * 18 + 8 * (kg & 1) + q) * 64 + 4 * p * 2;
+        const LDS_PTR(char) dz_m = lds + b * SET + IN_BYTES + pair * G::DZ_BLOCK + (ks * RPW + 2 * kk) * (16 * 64) +
+                                   ((kg >> 1) * 16 + 8 * (kg & 1) + q) * 64 + 4 * p * 2;
+        h8 bh[2];
 #pragma unroll
-      for (int t = 0; t < 9; ++t) {
-        const int o = ((t / 3) * 18 + (t % 3)) * 64;
+        for (int cot = 0; cot < 2; ++cot) bh[cot] = tr_pair(dz_m, cot * 32, cot * 32 + 4 * 64);
 #pragma unroll
-        for (int cit = 0; cit < 2; ++cit) {
-          const h8 ah = tr_pair(in_m, o + cit * 32, o + cit * 32 + 4 * 64);
+        for (int t = 0; t < 9; ++t) {
+          const int o = ((t / 3) * 18 + (t % 3)) * 64;
 #pragma unroll
-          for (int cot = 0; cot < 2; ++cot)
-            a4[t][cit * 2 + cot] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(b8, ah), __builtin_bit_cast(b8, bh[cot]),
-                                                                           a4[t][cit * 2 + cot], 0, 0, 0);
-        }
-        if (t < NJ && have_in) {
-          __builtin_amdgcn_sched_barrier(0);
-          issue(t, Sin, b ^ 1);
-          __builtin_amdgcn_sched_barrier(0);
+          for (int cit = 0; cit < 2; ++cit) {
+            const h8 ah = tr_pair(in_m, o + cit * 32, o + cit * 32 + 4 * 64);
+#pragma unroll
+            for (int cot = 0; cot < 2; ++cot)
+              a4[t][cit * 2 + cot] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(b8, ah), __builtin_bit_cast(b8, bh[cot]),
+                                                                             a4[t][cit * 2 + cot], 0, 0, 0);
+          }
+          if (kk * 9 + t < NJ && have_in) {
+            __builtin_amdgcn_sched_barrier(0);
+            issue(kk * 9 + t, Sin, b ^ 1);
+            __builtin_amdgcn_sched_barrier(0);
+          }
         }
       }
     } else
