@@ -505,20 +505,45 @@ constexpr int TR_DC = 32;  // feature chunk staged in LDS
 // The part every triplet variant shares (nets/triplet_loss_all.py:70-77 `batch_dist`): Gram matrix of a bin's m embeddings in
 // LDS, then d_ij = sqrt(max(|y_i|^2 + |y_j|^2 - 2 y_i.y_j, 0)), exactly 0 where the argument is <= 0.  Leaves sD = distances,
 // sG = 0; sY is scratch ([m][TR_DC+1], its first m floats are reused as a vector afterwards).
-__device__ __forceinline__ void bin_distances(const float* __restrict__ Y, float* sD, float* sG, float* sY, int m, int tid) {
+// WHOLE (batches of at most TR_WHOLE_M clips): the bin's m x 256 embeddings are staged in LDS ONCE (sY = [m][HID + 1], sN behind it)
+// and stay there for the backward half -- instead of eight chunk rounds with two barriers each here and 2 m^2 global reads per
+// thread there.  The sums run in the same order (32-feature partial sums added chunk by chunk): bit-identical results.
+constexpr int TR_WHOLE_M = 64;
+template <bool WHOLE>
+__device__ __forceinline__ void bin_distances(const float* __restrict__ Y, float* sD, float* sG, float* sY, float* sN, int m, int tid) {
   const int mm = m * m;
-  for (int p = tid; p < mm; p += 256) { sD[p] = 0.f; sG[p] = 0.f; }
-  for (int d0 = 0; d0 < HID; d0 += TR_DC) {
-    __syncthreads();
-    for (int e = tid; e < m * TR_DC; e += 256) sY[(e / TR_DC) * (TR_DC + 1) + (e % TR_DC)] = Y[(size_t)(e / TR_DC) * HID + d0 + (e % TR_DC)];
+  if constexpr (WHOLE) {
+    for (int e = tid; e < m * HID; e += 256) sY[(e / HID) * (HID + 1) + (e % HID)] = Y[e];
+    for (int p = tid; p < mm; p += 256) sG[p] = 0.f;
     __syncthreads();
     for (int p = tid; p < mm; p += 256) {
       const int i = p / m, j = p % m;
       if (j < i) continue;  // symmetric: compute the upper triangle, mirror below
-      float acc = 0.f;
+      const float* yi = sY + i * (HID + 1);
+      const float* yj = sY + j * (HID + 1);
+      float tot = 0.f;
+      for (int d0 = 0; d0 < HID; d0 += TR_DC) {
+        float acc = 0.f;
 #pragma unroll
-      for (int dd = 0; dd < TR_DC; ++dd) acc = fmaf(sY[i * (TR_DC + 1) + dd], sY[j * (TR_DC + 1) + dd], acc);
-      sD[p] += acc;
+        for (int dd = 0; dd < TR_DC; ++dd) acc = fmaf(yi[d0 + dd], yj[d0 + dd], acc);
+        tot += acc;
+      }
+      sD[p] = tot;
+    }
+  } else {
+    for (int p = tid; p < mm; p += 256) { sD[p] = 0.f; sG[p] = 0.f; }
+    for (int d0 = 0; d0 < HID; d0 += TR_DC) {
+      __syncthreads();
+      for (int e = tid; e < m * TR_DC; e += 256) sY[(e / TR_DC) * (TR_DC + 1) + (e % TR_DC)] = Y[(size_t)(e / TR_DC) * HID + d0 + (e % TR_DC)];
+      __syncthreads();
+      for (int p = tid; p < mm; p += 256) {
+        const int i = p / m, j = p % m;
+        if (j < i) continue;  // symmetric: compute the upper triangle, mirror below
+        float acc = 0.f;
+#pragma unroll
+        for (int dd = 0; dd < TR_DC; ++dd) acc = fmaf(sY[i * (TR_DC + 1) + dd], sY[j * (TR_DC + 1) + dd], acc);
+        sD[p] += acc;
+      }
     }
   }
   __syncthreads();
@@ -528,7 +553,6 @@ __device__ __forceinline__ void bin_distances(const float* __restrict__ Y, float
   }
   __syncthreads();
   // squared norms = diagonal of the Gram matrix (same summation order -> d_ii is exactly 0)
-  float* sN = sY;  // reuse: m floats
   for (int i = tid; i < m; i += 256) sN[i] = sD[i * m + i];
   __syncthreads();
   for (int p = tid; p < mm; p += 256) {
@@ -542,8 +566,9 @@ __device__ __forceinline__ void bin_distances(const float* __restrict__ Y, float
 
 // From sG = dL/d(dist) (unscaled) to dL/dY of the bin: dL/d(sqdist) = dL/d(dist) * scale / (2 dist) (0 where dist == 0),
 // S = dq + dq^T, dY_i = 2 * (rowsum_i * Y_i - sum_j S_ij Y_j); thread = feature d.
-__device__ __forceinline__ void bin_backprop(const float* __restrict__ Y, float* __restrict__ dY, float* sD, float* sG, float* sN,
-                                             float scale, int m, int tid) {
+template <bool WHOLE>
+__device__ __forceinline__ void bin_backprop(const float* __restrict__ Y, const float* sY, float* __restrict__ dY, float* sD, float* sG,
+                                             float* sN, float scale, int m, int tid) {
   const int mm = m * m;
   // dL/d(sqdist) = dL/d(dist) / (2 dist), 0 where dist == 0
   for (int p = tid; p < mm; p += 256) {
@@ -565,14 +590,15 @@ __device__ __forceinline__ void bin_backprop(const float* __restrict__ Y, float*
   __syncthreads();
   // dY_i = 2 * (rows_i * Y_i - sum_j S_ij Y_j); thread = feature d
   for (int i = 0; i < m; ++i) {
-    float acc = sN[i] * Y[(size_t)i * HID + tid];
-    for (int j = 0; j < m; ++j) acc = fmaf(-sD[i * m + j], Y[(size_t)j * HID + tid], acc);
+    float acc = sN[i] * (WHOLE ? sY[i * (HID + 1) + tid] : Y[(size_t)i * HID + tid]);
+    for (int j = 0; j < m; ++j) acc = fmaf(-sD[i * m + j], WHOLE ? sY[j * (HID + 1) + tid] : Y[(size_t)j * HID + tid], acc);
     dY[(size_t)i * HID + tid] = 2.f * acc;
   }
 }
 
 // batch-all triplet loss: one workgroup per bin, Gram/distance matrix in LDS (m <= 128)
 // ------------------------------------------------------------------------------------------------------
+template <bool WHOLE>
 __global__ __launch_bounds__(256) void triplet_kernel(const float* __restrict__ sig, const int32_t* __restrict__ hp,
                                                       const int32_t* __restrict__ hn, int kp, int kn, float margin,
                                                       float* __restrict__ bin_loss, float* __restrict__ bin_num,
@@ -585,8 +611,8 @@ __global__ __launch_bounds__(256) void triplet_kernel(const float* __restrict__ 
   const int k = blockIdx.x, tid = threadIdx.x;
   const float* Y = sig + (size_t)k * m * HID;
 
-  bin_distances(Y, sD, sG, sY, m, tid);
-  float* sN = sY;
+  float* sN = WHOLE ? sY + m * (HID + 1) : sY;        // [m] (chunked form: the chunk buffer is free by then)
+  bin_distances<WHOLE>(Y, sD, sG, sY, sN, m, tid);
   // pass A: items (row r, positive a): hinge sum, active count, gradient of the positive distance
   float lsum = 0.f, lnum = 0.f;
   for (int it = tid; it < m * kp; it += 256) {
@@ -621,7 +647,7 @@ __global__ __launch_bounds__(256) void triplet_kernel(const float* __restrict__ 
   }
   const float scale = tnum != 0.f ? grad_scale / (tnum * (float)NBINS) : 0.f;
   __syncthreads();
-  bin_backprop(Y, dsig + (size_t)k * m * HID, sD, sG, sN, scale, m, tid);
+  bin_backprop<WHOLE>(Y, sY, dsig + (size_t)k * m * HID, sD, sG, sN, scale, m, tid);
 }
 
 // Batch-HARD triplet loss per bin (the mode nets/mj_uwyhNets_ba.py:1301-1306 `compile_hard` names: tfa.losses.TripletHardLoss,
@@ -630,6 +656,7 @@ __global__ __launch_bounds__(256) void triplet_kernel(const float* __restrict__ 
 //   hn_a = min over the samples of other identities of d_an     (tfa _masked_minimum; no such sample: the row maximum)
 //   L_bin = mean_a max(hp_a - hn_a + margin, 0)
 // Gradient: reduce_max / reduce_min split it equally among tied extrema.  bin_num = anchors with a positive hinge.
+template <bool WHOLE>
 __global__ __launch_bounds__(256) void triplet_hard_kernel(const float* __restrict__ sig, const int32_t* __restrict__ labels,
                                                            float margin, float* __restrict__ bin_loss,
                                                            float* __restrict__ bin_num, float* __restrict__ dsig,
@@ -641,8 +668,8 @@ __global__ __launch_bounds__(256) void triplet_hard_kernel(const float* __restri
   __shared__ float sRed[4];
   const int k = blockIdx.x, tid = threadIdx.x;
   const float* Y = sig + (size_t)k * m * HID;
-  bin_distances(Y, sD, sG, sY, m, tid);
-  float* sN = sY;
+  float* sN = WHOLE ? sY + m * (HID + 1) : sY;        // [m] (chunked form: the chunk buffer is free by then)
+  bin_distances<WHOLE>(Y, sD, sG, sY, sN, m, tid);
   float lsum = 0.f, lnum = 0.f;
   for (int a = tid; a < m; a += 256) {
     const int la = labels[a];
@@ -684,7 +711,7 @@ __global__ __launch_bounds__(256) void triplet_hard_kernel(const float* __restri
     bin_num[k] = tnum;
   }
   __syncthreads();
-  bin_backprop(Y, dsig + (size_t)k * m * HID, sD, sG, sN, grad_scale / ((float)m * (float)NBINS), m, tid);
+  bin_backprop<WHOLE>(Y, sY, dsig + (size_t)k * m * HID, sD, sG, sN, grad_scale / ((float)m * (float)NBINS), m, tid);
 }
 
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
@@ -903,15 +930,21 @@ extern "C" int ugn_triplet_fwd_bwd(const float* sig, const int32_t* hp, const in
     return 0;
   }
   UGN_REQUIRE(hp && hn, "ugn_triplet_fwd_bwd: null index list");
-  const int lds = (2 * m * m + m * (TR_DC + 1)) * (int)sizeof(float);
-  static int lds_set = 0;
-  if (lds > lds_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)triplet_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  const bool whole = m <= TR_WHOLE_M;
+  const int lds = (2 * m * m + (whole ? m * (HID + 1) + m : m * (TR_DC + 1))) * (int)sizeof(float);
+  static int lds_set[2] = {0, 0};
+  if (lds > lds_set[whole]) {
+    hipError_t e = hipFuncSetAttribute(whole ? (const void*)triplet_kernel<true> : (const void*)triplet_kernel<false>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) { ugn_set_error("triplet: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
-    lds_set = lds;
+    lds_set[whole] = lds;
   }
-  hipLaunchKernelGGL(triplet_kernel, dim3(NBINS), dim3(256), lds, (hipStream_t)stream, sig, hp, hn, kp, kn, margin,
-                     bin_loss, bin_num, dsig, grad_scale, m);
+  if (whole)
+    hipLaunchKernelGGL(triplet_kernel<true>, dim3(NBINS), dim3(256), lds, (hipStream_t)stream, sig, hp, hn, kp, kn, margin,
+                       bin_loss, bin_num, dsig, grad_scale, m);
+  else
+    hipLaunchKernelGGL(triplet_kernel<false>, dim3(NBINS), dim3(256), lds, (hipStream_t)stream, sig, hp, hn, kp, kn, margin,
+                       bin_loss, bin_num, dsig, grad_scale, m);
   UGN_CHECK_LAUNCH("triplet");
   return 0;
 }
@@ -920,15 +953,21 @@ extern "C" int ugn_triplet_hard_fwd_bwd(const float* sig, const int32_t* labels,
                                         float* dsig, float grad_scale, int m, void* stream) {
   UGN_REQUIRE(sig && labels && bin_loss && bin_num && dsig, "ugn_triplet_hard_fwd_bwd: null pointer");
   UGN_REQUIRE(m >= 1 && m <= 128, "ugn_triplet_hard_fwd_bwd: batch size must be 1..128 (got %d)", m);
-  const int lds = (2 * m * m + m * (TR_DC + 1)) * (int)sizeof(float);
-  static int lds_set = 0;
-  if (lds > lds_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)triplet_hard_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  const bool whole = m <= TR_WHOLE_M;
+  const int lds = (2 * m * m + (whole ? m * (HID + 1) + m : m * (TR_DC + 1))) * (int)sizeof(float);
+  static int lds_set[2] = {0, 0};
+  if (lds > lds_set[whole]) {
+    hipError_t e = hipFuncSetAttribute(whole ? (const void*)triplet_hard_kernel<true> : (const void*)triplet_hard_kernel<false>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) { ugn_set_error("triplet hard: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
-    lds_set = lds;
+    lds_set[whole] = lds;
   }
-  hipLaunchKernelGGL(triplet_hard_kernel, dim3(NBINS), dim3(256), lds, (hipStream_t)stream, sig, labels, margin, bin_loss, bin_num,
-                     dsig, grad_scale, m);
+  if (whole)
+    hipLaunchKernelGGL(triplet_hard_kernel<true>, dim3(NBINS), dim3(256), lds, (hipStream_t)stream, sig, labels, margin, bin_loss,
+                       bin_num, dsig, grad_scale, m);
+  else
+    hipLaunchKernelGGL(triplet_hard_kernel<false>, dim3(NBINS), dim3(256), lds, (hipStream_t)stream, sig, labels, margin, bin_loss,
+                       bin_num, dsig, grad_scale, m);
   UGN_CHECK_LAUNCH("triplet hard");
   return 0;
 }
