@@ -101,11 +101,16 @@ constexpr int lds_bytes() {
 #ifndef UGN_T16_MIN
 #define UGN_T16_MIN 32
 #endif
+#ifndef UGN_D2P16
+#define UGN_D2P16 1       /* the pooled 32 -> 32 data gradient on conv_d2_kernel<..., IN_POOLED> (16x16x32 tiles) instead of conv32_d2p_kernel
+                             (32x32x16): 400 -> 362 us in the step.  (The fused dgrad32_w5 kernel reads that filter in the 32-column block
+                             layout: its caller packs a copy with flag bit 1 of ugn_mm_pack_multi.) */
+#endif
 #ifndef UGN_NR_POOLED
 #define UGN_NR_POOLED 1   /* the pooled 64 -> 64 data gradient on conv_nr_kernel<..., IN_POOLED> (else conv_mm_kernel, 32x32x16) */
 #endif
 __host__ __device__ constexpr bool mm_tile16(int kc, int nc, int dgrad) {
-  return nc >= UGN_T16_MIN && !(dgrad && kc == 64 && nc == 64 && !UGN_NR_POOLED) && !(dgrad && kc == 32 && nc == 32);
+  return nc >= UGN_T16_MIN && !(dgrad && kc == 64 && nc == 64 && !UGN_NR_POOLED) && !(dgrad && kc == 32 && nc == 32 && !UGN_D2P16);
 }
 // ... and which of those run on conv_nr_kernel (64 / 128 columns; filter tiles of 16 consecutive channels)
 #ifndef UGN_MM_NR
@@ -147,7 +152,7 @@ __global__ __launch_bounds__(256) void mm_wstats_zero_kernel(PackTable t, int nj
 __global__ __launch_bounds__(256) void mm_wstats_kernel(PackTable t) {
   const int j = blockIdx.y, sl = blockIdx.x, tid = threadIdx.x;
   const float* w = t.w[j];
-  const int cin = t.cin[j], cout = t.cout[j], dgrad = t.dgrad[j];
+  const int cin = t.cin[j], cout = t.cout[j], dgrad = t.dgrad[j] & 1;
   __shared__ float sp[256];
   float amax = 0.f;
   const int total = 9 * cin * cout, per = (total + kStatSlices - 1) / kStatSlices;
@@ -186,7 +191,7 @@ __global__ __launch_bounds__(256) void mm_wstats_kernel(PackTable t) {
 //   data gradient: g[tap][k = cout][n = cin] = w[8 - tap][cin][cout]
 __global__ void mm_pack_kernel(PackTable t) {
   const int j = blockIdx.y;
-  const int cin = t.cin[j], cout = t.cout[j], dgrad = t.dgrad[j];
+  const int cin = t.cin[j], cout = t.cout[j], dgrad = t.dgrad[j] & 1, blocks32 = t.dgrad[j] >> 1;
   const int kc = dgrad ? cout : cin, nc = dgrad ? cin : cout;
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= 9 * kc * nc) return;
@@ -199,7 +204,7 @@ __global__ void mm_pack_kernel(PackTable t) {
   _Float16 hi, lo;
   h2_split(ldexpf(v, ew), hi, lo);
   uint16_t* pk = t.pk[j];
-  if (mm_tile16(kc, nc, dgrad)) {
+  if (mm_tile16(kc, nc, dgrad) && !blocks32) {
     // 16x16x32 kernels: [chunk][tap][16-column tile][plane][lane-linear 1 KB]; lane = k group (8 channels) * 16 + column; tiles 2m,
     // 2m + 1 hold the even / odd channels of the 32-channel group m (a lane then owns adjacent channels, as in the 32-column form)
     const int chunk = k >> 5, kg = (k >> 3) & 3, ee = k & 7;
@@ -1194,9 +1199,13 @@ constexpr int d2_lds_bytes() { return D2_W_OFF + (NC == 32 ? D2_WBYTES : 2 * (NC
 
 // KC / NC: GEMM K and N channels (NC 32 or 64), HW: image size, EPI: EPI_LRELU | EPI_LRELU_POOL | EPI_DGRAD.  16x16x32 tiles as
 // conv_mm16_kernel (same filter packing, same epilogue).
-template <int KC, int NC, int HW, int EPI>
+// IN_POOLED (-DUGN_D2P16: the 32 -> 32 pooled data gradient on the 16x16x32 tiles of this kernel instead of conv32_d2p_kernel's
+// 32x32x16 block): the tile is built as conv32_d2p_kernel builds it -- pooled values + argmax bytes through registers an item ahead,
+// scattered into the swizzled halo behind barrier B.
+template <int KC, int NC, int HW, int EPI, int IN_POOLED = 0>
 __global__ __launch_bounds__(512, 4) void conv_d2_kernel(const MmJobs jt, const void* __restrict__ zeros) {
   constexpr int NT = NC / 16, NG = NC / 32, NCHUNK = KC / 32;
+  static_assert(!IN_POOLED || (KC == 32 && NC == 32), "pooled input: one K chunk, resident filter");
   constexpr bool FRES = NC == 32;                    // the chunk's filter resident (else tap by tap)
   constexpr int TAPB = NT * 2048;                    // filter bytes of one tap
   constexpr int RPX = HW / 16, RPI = RPX * RPX;
@@ -1253,9 +1262,57 @@ __global__ __launch_bounds__(512, 4) void conv_d2_kernel(const MmJobs jt, const 
       if (p < kb) dma16(src + p * 1024 + lane * 16, dst + (unsigned)p * 1024u);
     }
   };
-  issue_tile(jt.job[jb], lit, 0);
+  // IN_POOLED: this thread's unit of the 10 x 10 pooled pixels under a region's halo: pooled pixel spp, channel group scg (8 channels)
+  const int spp = tid >> 2, scg = tid & 3;
+  const int sprow = (spp * 205) >> 11, spcol = spp - sprow * 10;
+  uint4 shi = make_uint4(0u, 0u, 0u, 0u), slo = shi;
+  uint2 six = make_uint2(0u, 0u);
+  auto stg_load = [&](const MmJob& J, int lit_) {
+    constexpr int HP = HW / 2;
+    const int img = lit_ / RPI, rrem = lit_ % RPI;
+    const int pr = ((rrem / RPX) * 16) / 2 - 1 + sprow, pc = ((rrem % RPX) * 16) / 2 - 1 + spcol;
+    const bool ok = tid < 400 && (unsigned)pr < (unsigned)HP && (unsigned)pc < (unsigned)HP;
+    shi = make_uint4(0u, 0u, 0u, 0u);
+    slo = shi;
+    six = make_uint2(0u, 0u);
+    if (ok) {
+      const size_t o = (size_t)img * HP * HP + (size_t)(pr * HP + pc);
+      const char* v = reinterpret_cast<const char*>(J.in) + o * (KC * 4) + (unsigned)(scg * 16);
+      shi = *reinterpret_cast<const uint4*>(v);
+      slo = *reinterpret_cast<const uint4*>(v + KC * 2);
+      six = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(J.in_idx) + o * KC + (unsigned)(scg * 8));
+    }
+  };
+  auto scatter = [&]() {              // registers -> the halo tile: quarter jj of pixel (hy, hx) into slot jj ^ g(hy, hx)
+    if (tid >= 400) return;
+    const unsigned hv[4] = {shi.x, shi.y, shi.z, shi.w}, lv[4] = {slo.x, slo.y, slo.z, slo.w};
+#pragma unroll
+    for (int pos = 0; pos < 4; ++pos) {
+      const int hy = 2 * sprow - 1 + (pos >> 1), hx = 2 * spcol - 1 + (pos & 1);
+      if ((unsigned)hy >= 18u || (unsigned)hx >= 18u) continue;
+      unsigned m[4];
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        const unsigned w = d < 2 ? six.x : six.y;
+        const unsigned b0 = (w >> (16 * (d & 1))) & 0xffu, b1 = (w >> (16 * (d & 1) + 8)) & 0xffu;
+        m[d] = (b0 == (unsigned)pos ? 0x0000ffffu : 0u) | (b1 == (unsigned)pos ? 0xffff0000u : 0u);
+      }
+      const int g = (((hx >> 1) & 3) << 1) | (hy & 1);
+      char* rec = smem + (hy * 18 + hx) * 128;
+      *reinterpret_cast<uint4*>(rec + ((scg ^ g) << 4)) = make_uint4(hv[0] & m[0], hv[1] & m[1], hv[2] & m[2], hv[3] & m[3]);
+      *reinterpret_cast<uint4*>(rec + (((4 + scg) ^ g) << 4)) = make_uint4(lv[0] & m[0], lv[1] & m[1], lv[2] & m[2], lv[3] & m[3]);
+    }
+  };
+  if constexpr (IN_POOLED) {
+    stg_load(jt.job[jb], lit);
+    scatter();
+    const int ni = item + gridDim.x;
+    if (ni < nitems) { const int j2 = mm_job_of(jt, ni); stg_load(jt.job[j2], ni - jt.start[j2]); }
+  } else {
+    issue_tile(jt.job[jb], lit, 0);
+  }
   issue_w(jt.job[jb].wpk, 0, 0, FRES ? 36 : TAPB / 1024, sbase + D2_W_OFF);
-  bool first_item = true;
+  bool first_item = true, filter_pending = true;
   int wbuf = 0;
   int meta_jb = -1, e_out = 0;
   float factor = 1.f, mx = 0.f;
@@ -1293,7 +1350,10 @@ __global__ __launch_bounds__(512, 4) void conv_d2_kernel(const MmJobs jt, const 
           // what this stage reads has landed: the tile and the (first) filter stage were issued behind barrier B of the previous
           // chunk -- for the first chunk of an item BEFORE the previous item's epilogue stores, so a counted wait covers them and
           // none of the stores; a later tap's filter one tap ago
-          if (tap == 0 && chunk == 0 && !first_item) {
+          if (IN_POOLED && !first_item && !filter_pending) {
+            // (pooled input: the tile came through registers -- the scatter waited for its loads -- and the loads of the tile after the
+            //  next are in flight: nothing to wait for unless a filter was fetched)
+          } else if (tap == 0 && chunk == 0 && !first_item && !IN_POOLED) {
             static_assert(EPI_STORES == 6 || EPI_STORES == 12 || EPI_STORES == 16 || EPI_STORES == 32, "vmcnt immediate");
             if constexpr (EPI_STORES == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
             else if constexpr (EPI_STORES == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
@@ -1302,6 +1362,7 @@ __global__ __launch_bounds__(512, 4) void conv_d2_kernel(const MmJobs jt, const 
           } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           }
+          filter_pending = false;
           __syncthreads();            // A: visible; (tap by tap:) the other filter buffer has no readers left
           if constexpr (!FRES) {
             if (tap + 1 < 9) issue_w(jt.job[jb].wpk, chunk, tap + 1, TAPB / 1024, sbase + D2_W_OFF + (unsigned)(wbuf ^ 1) * TAPB);
@@ -1342,10 +1403,18 @@ __global__ __launch_bounds__(512, 4) void conv_d2_kernel(const MmJobs jt, const 
       }
       __syncthreads();                // B: every wave has read its last fragment of the chunk: tile and filter buffers are free
       if (next_tile) {
-        issue_tile(jt.job[nx_job], n_lit, n_chunk);
+        if constexpr (IN_POOLED) {
+          scatter();                  // the next item's tile (its loads were issued an item ago) ...
+          const int n2 = item + 2 * (int)gridDim.x;       // ... and the loads of the one after it
+          if (n2 < nitems) { const int j2 = mm_job_of(jt, n2); stg_load(jt.job[j2], n2 - jt.start[j2]); }
+        } else {
+          issue_tile(jt.job[nx_job], n_lit, n_chunk);
+        }
         // (one chunk of 32 columns: the filter in LDS is the whole filter of the job and stays until the job changes)
-        if (!(FRES && NCHUNK == 1 && nx_job == jb))
+        if (!(FRES && NCHUNK == 1 && nx_job == jb)) {
           issue_w(jt.job[nx_job].wpk, n_chunk, 0, FRES ? 36 : TAPB / 1024, sbase + D2_W_OFF + (FRES ? 0u : (unsigned)wbuf * TAPB));
+          filter_pending = true;
+        }
       }
     }
     first_item = false;
@@ -1396,6 +1465,11 @@ __global__ __launch_bounds__(512, 4) void conv_d2_kernel(const MmJobs jt, const 
             if constexpr (EPI == EPI_LRELU) {
               v0 = ugn_lrelu(v0);
               v1 = ugn_lrelu(v1);
+            } else if constexpr (EPI == EPI_DGRAD_ACT) {      // LeakyReLU' from the sign of the H half of the layer's input
+              const unsigned ah2 = *reinterpret_cast<const unsigned*>(reinterpret_cast<const char*>(J.act) + (size_t)img * HW * HW * NC * 4 +
+                                                                      pix * (unsigned)(NC * 4) + chb);
+              v0 *= (short)(ah2 & 0xffffu) > 0 ? 1.f : UGN_LRELU_ALPHA;
+              v1 *= (short)(ah2 >> 16) > 0 ? 1.f : UGN_LRELU_ALPHA;
             }
             mx = fmaxf(mx, fmaxf(fabsf(v0), fabsf(v1)));
             _Float16 h0, l0, h1, l1;
@@ -2257,9 +2331,9 @@ int launch_mm16(const MmJob* jobs, const int* n, int njobs, hipStream_t st) {
   return 0;
 }
 
-template <int KC, int NC, int HW, int EPI>
+template <int KC, int NC, int HW, int EPI, int IN_POOLED = 0>
 int launch_d2(const MmJob* jobs, const int* n, int njobs, hipStream_t st) {
-  auto kern = conv_d2_kernel<KC, NC, HW, EPI>;
+  auto kern = conv_d2_kernel<KC, NC, HW, EPI, IN_POOLED>;
   constexpr int LDS = d2_lds_bytes<NC>();
   static bool attr_done = false;
   if (!attr_done) {
@@ -2342,7 +2416,9 @@ int dispatch_fwd(const MmJob* jobs, const int* n, int njobs, int hw, int cin, in
 // data gradient of the forward layer cin -> cout at hw x hw: K = cout, N = cin
 int dispatch_dgrad(const MmJob* jobs, const int* n, int njobs, int hw, int cin, int cout, int unpool, bool act, hipStream_t st) {
   if constexpr ((UGN_MM_D2 & 2) != 0) {
-    if (cin == 32 && cout == 32 && hw == 64 && unpool && !act) return launch_d2p<64>(jobs, n, njobs, st);
+    if (cin == 32 && cout == 32 && hw == 64 && unpool && !act)
+      return UGN_D2P16 ? launch_d2<32, 32, 64, EPI_DGRAD, 1>(jobs, n, njobs, st) : launch_d2p<64>(jobs, n, njobs, st);
+    if (UGN_D2P16 && cin == 32 && cout == 32 && hw == 64 && unpool && act) return launch_d2<32, 32, 64, EPI_DGRAD_ACT, 1>(jobs, n, njobs, st);
   }
   if constexpr ((UGN_MM_D2 & 4) != 0) {        // (GEMM K = cout, N = cin)
     if (cin == 32 && cout == 64 && hw == 32 && !unpool && !act) return launch_d2<64, 32, 32, EPI_DGRAD>(jobs, n, njobs, st);
@@ -2497,11 +2573,12 @@ extern "C" int ugn_mm_pack_multi(const float* const* w_hwio_host, uint16_t* cons
     const int ci = cin_host[j], co = cout_host[j];
     UGN_REQUIRE(w_hwio_host[j] && wpk_host[j] && wmeta_host[j], "ugn_mm_pack_multi: null pointer in job %d", j);
     UGN_REQUIRE(ci > 0 && co > 0 && ci % 32 == 0 && co % 32 == 0, "ugn_mm_pack_multi: channels must be multiples of 32 (job %d)", j);
-    const int nc = dgrad_host[j] ? ci : co;
+    const int nc = (dgrad_host[j] & 1) ? ci : co;
     UGN_REQUIRE(nc == 32 || nc == 64 || nc == 128, "ugn_mm_pack_multi: %d output channels of the GEMM (32, 64 or 128; job %d)", nc, j);
     t.w[j] = w_hwio_host[j]; t.pk[j] = wpk_host[j]; t.meta[j] = (WMeta*)wmeta_host[j];
     t.amax[j] = reinterpret_cast<unsigned*>(wmeta_host[j]) + 2;
-    t.cin[j] = ci; t.cout[j] = co; t.dgrad[j] = dgrad_host[j] ? 1 : 0;
+    // (bit 1 of a job's flag: the 32-column block layout of conv_mm_kernel / dgrad32_w5_kernel whatever the shape's default kernel)
+    t.cin[j] = ci; t.cout[j] = co; t.dgrad[j] = (dgrad_host[j] & 1) | (dgrad_host[j] & 2);
     if (9 * ci * co > maxe) maxe = 9 * ci * co;
   }
   hipLaunchKernelGGL(mm_wstats_zero_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, t, njobs);

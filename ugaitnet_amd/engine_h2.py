@@ -46,7 +46,13 @@ class H2State:
         self.bufs = {}
 
     def pack_jobs(self):
-        return [(self.enc.W(name), self.pk[name][d][0], self.pk[name][d][1], d == 1) for name, *_ in LAYERS3 for d in (0, 1)]
+        jobs = [(self.enc.W(name), self.pk[name][d][0], self.pk[name][d][1], d) for name, *_ in LAYERS3 for d in (0, 1)]
+        if FUSE_W5:     # the fused kernel reads the a2 data-gradient filter in the 32-column block layout: a copy of its own
+            if "a2w5" not in self.pk:
+                dev = self.enc.store.device
+                self.pk["a2w5"] = (torch.empty((18 * 32 * 32,), dtype=I16, device=dev), torch.zeros(4, dtype=I32, device=dev))
+            jobs.append((self.enc.W("a2"), self.pk["a2w5"][0], self.pk["a2w5"][1], 3))
+        return jobs
 
     def wf(self, name):
         return self.pk[name][0]
@@ -199,7 +205,7 @@ def backward_h2(encs, douts, side):
     if FUSE_W5:
         # dL/da1 has one consumer, the 5x5 layer's weight gradient: the a2 data gradient multiplies its registers with the input
         # patch in place (dgrad32_w5_kernel) -- 0.94 GB per step neither written nor read back, three launches fewer
-        h2.dgrad32_wgrad5_multi(dp2, i2, [s.wd("a2")[0] for s in S], [s.wd("a2")[1] for s in S], [s.x for s in S],
+        h2.dgrad32_wgrad5_multi(dp2, i2, [s.pk["a2w5"][0] for s in S], [s.pk["a2w5"][1] for s in S], [s.x for s in S],
                                 [s.slot("x") for s in S], [s.bufs["a1s"] for s in S], [e.G("a1") for e in encs],
                                 [s.slot("w5scale") for s in S])
         return

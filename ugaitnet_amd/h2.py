@@ -121,13 +121,14 @@ def absmax(x, meta):
 
 
 def mm_pack_multi(jobs):
-    """jobs: list of (w HWIO fp32 tensor, packed int16 tensor of 18*cin*cout elements, wmeta int32[4], dgrad flag)."""
+    """jobs: list of (w HWIO fp32 tensor, packed int16 tensor of 18*cin*cout elements, wmeta int32[4], flags): flags bit 0 = data
+    gradient (taps mirrored, K = cout), bit 1 = the 32-column block layout whatever the shape's default kernel (dgrad32_wgrad5_multi)."""
     for k in range(0, len(jobs), 64):
         part = jobs[k:k + 64]
         n = len(part)
         call("ugn_mm_pack_multi", ptr_array([j[0] for j in part]), ptr_array([j[1] for j in part]), ptr_array([j[2] for j in part]),
              (C.c_int * n)(*[j[0].shape[2] for j in part]), (C.c_int * n)(*[j[0].shape[3] for j in part]),
-             (C.c_int * n)(*[int(bool(j[3])) for j in part]), n, _stream())
+             (C.c_int * n)(*[int(j[3]) & 3 for j in part]), n, _stream())
 
 
 def mm_pack(w, dgrad, pk=None, wmeta=None):
@@ -158,9 +159,9 @@ def _mm_work(kind, hw, cin, cout, pooled, ns, act=False):
     a2 = cin == 32 and cout == 32 and hw == 64 and pooled
     t16 = lambda kc, nc, epi: ("conv_nr_kernel<%d, %d, %d, %d, 0>" if nc >= 128 else "conv_mm16_kernel<%d, %d, %d, %d>") % (kc, nc, hw, epi)
     if kind == "fwd":
-        kern = "conv_d2_kernel<32, 32, 64, 1>" if a2 else t16(cin, cout, 1 if pooled else 0)
-    elif a2 and not act:
-        kern = "conv32_d2p_kernel<64>"
+        kern = "conv_d2_kernel<32, 32, 64, 1, 0>" if a2 else t16(cin, cout, 1 if pooled else 0)
+    elif a2:
+        kern = "conv_d2_kernel<32, 32, 64, %d, 1>" % (3 if act else 2)
     else:
         kern = ("conv_nr_kernel<%d, %d, %d, %d, 1>" % (cout, cin, hw, 3 if act else 2) if pooled else t16(cout, cin, 3 if act else 2))
     label = "conv3x3_%s[%d->%d @%dx%d%s h2] %s" % (kind, cin, cout, hw, hw, " pooled" if pooled else "", kern)
