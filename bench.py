@@ -65,7 +65,8 @@ DTYPE_TEXT = {
     "bf16": "bf16: activations, gradients and saved tensors bf16 in HBM, 3x3 layers on v_mfma_f32_32x32x16_bf16 with f32 accumulate, "
             "f32 weight gradients / master weights / Adam (BASELINE configs[4])",
     "h2": "f16x2: fp32-class values held as two f16 halves + a block exponent (22 significant bits); 3x3 layers = three "
-          "v_mfma_f32_32x32x16_f16 per product (hi*hi + hi*lo + lo*hi), f32 accumulate; everything else f32",
+          "v_mfma_f32_16x16x32_f16 per product (hi*hi + hi*lo + lo*hi; the MaxPool'ed layers' weight gradients: v_smfmac_f32_16x16x64_f16, "
+          "the pooled gradient being 2:4 sparse along a pixel row), f32 accumulate; everything else f32",
 }
 PEAK_F32_MFMA = 157.3e12   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 / 16x16x4_f32 dense peak
 PEAK_BF16_MFMA = 16 * PEAK_F32_MFMA   # same guide: the f32 MFMA rate is 1/16 of the dense bf16 rate (~2.5 PFLOP/s)
