@@ -16,6 +16,9 @@
 //   * Pooled layers: the pooled gradient + argmax bytes are staged and scattered LDS -> LDS (MaxPool backward) per strip.
 //   * At the end of a share (or a job boundary inside it) the K-split waves are added through LDS in a fixed order and the
 //     partial sums leave as a slab; wgrad_mm_finish adds the slabs in a fixed order and applies 2^-(e_in + e_dz).  No atomics.
+//   * Round 4: the un-pooled 64-wide launches multiply on v_mfma_f32_16x16x32_f16 (M16), and the two POOLED layers on the SPARSE
+//     matrix pipe, v_smfmac_f32_16x16x64_f16 (SP = 1; 16-row strips): MaxPool backward is 2:4 sparse along a pixel row and the
+//     compressed operand is the pooled gradient as stored -- see the SP branch of the strip loop.
 #include "mm_common.h"
 
 using namespace ugn_mm;
