@@ -104,7 +104,10 @@ class _Prefetch:
         if self.proc is not None:
             return
         self.wanted = list(wanted)
-        self.dir = tempfile.mkdtemp(prefix="ugn_oracle_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+        try:
+            self.dir = tempfile.mkdtemp(prefix="ugn_oracle_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+        except OSError:         # (/dev/shm not writable: the default temporary directory)
+            self.dir = tempfile.mkdtemp(prefix="ugn_oracle_")
         env = dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="",
                    OMP_NUM_THREADS=str(max(8, (os.cpu_count() or 16) // 4)))
         self.proc = subprocess.Popen([sys.executable, "-m", "tests.test_fullsize_parity_gpu", self.dir] + self.wanted,
