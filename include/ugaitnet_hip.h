@@ -427,6 +427,35 @@ int ugn_bf_convert_multi(const float* const* x, uint16_t* const* y, const size_t
 int ugn_hpp_bwd_b4bf_multi(const float* const* a, const float* const* s3, const uint16_t* const* b4, const float* const* dfeat,
                            float* const* dm3, float* const* dzb4, const int* b, int njobs, void* stream);
 
+/* ---- "x3": the 3x3 layers of nets/mj_uwyhNets_ba.py:431-462 on IEEE fp32 tensors, multiplied on the bf16 matrix pipe through the
+ * EXACT three-way bf16 split of both operands (x = x0 + x1 + x2, 24 = 8 + 8 + 8 bits, fp32's exponent range): six of the nine
+ * partial products per fp32 product, fp32 accumulate; the dropped ones are below 2^-23 of the product, i.e. below the rounding of the
+ * accumulation (csrc/x3_common.h; measured error against fp64 at or below an fp32 MFMA chain's).  Tensors, index maps, shapes and
+ * epilogues are those of the fp32 entries above (ugn_conv3x3_fwd_wino_multi ...); only the filters are consumed in a packed form.
+ * ugn_x3_pack_multi: HWIO fp32 [3,3,cin,cout] -> three bf16 planes in the order the kernels stream them, 54 * cin * cout bytes per
+ * job; dgrad = 1 packs the flipped, transposed filter of the data gradient.  Up to 64 (layer, direction) jobs per launch. */
+/* The split itself (tests, documentation of the format): planes[k * n + i] = bf16 bit pattern of x_k[i], k = 0, 1, 2, with
+ * x0 = bf16(x), x1 = bf16(x - x0), x2 = x - x0 - x1 (round to nearest even); x0 + x1 + x2 == x exactly for every finite fp32 x. */
+int ugn_x3_split(const float* x, uint16_t* planes, size_t n, void* stream);
+int ugn_x3_pack_multi(const float* const* w_hwio_host, uint16_t* const* wpk_host, const int* cin_host, const int* cout_host,
+                      const int* dgrad_host, int njobs, void* stream);
+/* out = LeakyReLU(conv(in)) (+ MaxPooling2D(2,2) and first-maximum argmax bytes when pool != 0) for up to 6 jobs of one shape
+ * (the frame-level layer and the set-level twin of every modality): Conv2D + LeakyReLU + MaxPooling2D, :431-462. */
+int ugn_x3_conv3x3_fwd_multi(const float* const* in, const uint16_t* const* wpk, float* const* out, uint8_t* const* out_idx,
+                             const int* n, int njobs, int hw, int cin, int cout, int pool, void* stream);
+/* Data gradient of the layer cin -> cout at hw x hw (Conv2DBackpropInput; with dz_idx: dz is the POOLED gradient [n,hw/2,hw/2,cout]
+ * and is scattered through the argmax bytes while it is staged = MaxPoolGrad; with act [n,hw,hw,cin]: out *= LeakyReLU'(act) =
+ * LeakyReluGrad).  All jobs or none take dz_idx / act.  wpk from ugn_x3_pack_multi(dgrad = 1). */
+int ugn_x3_conv3x3_dgrad_multi(const float* const* dz, const uint8_t* const* dz_idx, const uint16_t* const* wpk,
+                               const float* const* act, float* const* out, const int* n, int njobs, int hw, int cin, int cout,
+                               void* stream);
+/* Weight gradient dw HWIO [3,3,cin,cout] = sum over images and pixels of in (x) dz (Conv2DBackpropFilter (+ MaxPoolGrad when dz_idx
+ * is given)), both operands split in registers while they are staged.  ws: >= ugn_x3_conv3x3_wgrad_ws(hw, cin, cout) bytes for the
+ * partial-sum slabs (fixed-order reduction, no atomics: bitwise reproducible). */
+size_t ugn_x3_conv3x3_wgrad_ws(int hw, int cin, int cout);
+int ugn_x3_conv3x3_wgrad_multi(const float* const* in, const float* const* dz, const uint8_t* const* dz_idx, float* const* dw,
+                               const int* n, int njobs, int hw, int cin, int cout, void* ws, size_t ws_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -36,7 +36,7 @@ def oracle_params(kinds, nclasses, seed=5):
 
 # "f32": the Winograd fp32-MFMA kernels; "h2": activations / gradients as split-fp16 halves, 3x3 layers on the f16 matrix pipe
 # (ugaitnet_amd/engine_h2.py).  Both are held to the SAME bars: the H2 path claims fp32-class arithmetic.
-PRECISIONS = ["f32", "h2"]
+PRECISIONS = ["f32x3", "f32", "h2"]
 
 
 @pytest.mark.parametrize("prec", PRECISIONS)

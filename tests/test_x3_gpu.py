@@ -1,0 +1,190 @@
+"""Parity of the "x3" 3x3 kernels (ugaitnet_amd/csrc/conv3x3_x3.hip, wgrad3x3_x3.hip: IEEE fp32 tensors, products through the exact
+three-way bf16 split on the bf16 matrix pipe) against the fp64 numpy oracle at the bars of the fp32 kernels they stand in for
+(tests/test_kernels_gpu.py), on the RAW fp32 inputs -- there is no storage format in between -- and, side by side, against the
+fp32-MFMA kernels of the library on the same inputs: the split products must be at least as close to fp64 as an fp32 MFMA chain.
+Reference call sites: nets/mj_uwyhNets_ba.py:431-462."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ugaitnet_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+CONV_CFGS = [  # (hw, cin, cout, pool)  == the five 3x3 shapes of the encoder
+    (64, 32, 32, True), (32, 32, 64, False), (32, 64, 64, True), (16, 64, 128, False), (16, 128, 128, False)]
+
+
+def T(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def err_of(got, ref):
+    got = got.detach().cpu().numpy() if isinstance(got, torch.Tensor) else np.asarray(got)
+    scale = float(np.abs(ref).max()) + 1e-300
+    return float(np.abs(got.astype(np.float64) - ref.astype(np.float64)).max()) / scale
+
+
+def close(got, ref, rtol, name=""):
+    e = err_of(got, ref)
+    assert e <= rtol, "%s: max abs err %.3e of the tensor's scale (bar %.1e)" % (name, e, rtol)
+    return e
+
+
+def test_x3_split_planes(dev):
+    """x0 + x1 + x2 == x bit for bit, each plane is the round-to-nearest-even bf16 of what the planes before it left, over fp32's
+    normal range, signed zeros and values that are already bf16."""
+    from ugaitnet_amd import x3
+    rng = np.random.default_rng(1)
+    x = np.concatenate([rng.standard_normal(4096) * 10.0 ** rng.uniform(-30, 30, 4096), rng.uniform(-1, 1, 4096),
+                        [0.0, -0.0, 1.0, -1.0, 1.0 + 2.0 ** -8, 1.0 + 2.0 ** -9, 1.0 + 2.0 ** -7 + 2.0 ** -23, 3.0e38, -1.0e-30, 0.1]]).astype(np.float32)
+    planes = x3.split(T(x, dev)).cpu().numpy().view(np.uint16).astype(np.uint32) << 16
+    p = planes.view(np.float32).astype(np.float64)            # [3, n]
+    assert np.array_equal((p[0] + p[1] + p[2]).astype(np.float32), x) and np.array_equal(p[0] + p[1] + p[2], x.astype(np.float64))
+
+    def bf16_rne(v):
+        u = v.astype(np.float32).view(np.uint32).astype(np.uint64)
+        return (((u + 0x7fff + ((u >> 16) & 1)) >> 16) << 16).astype(np.uint32).view(np.float32).astype(np.float64)
+    assert np.array_equal(p[0], bf16_rne(x))
+    assert np.array_equal(p[1], bf16_rne(x.astype(np.float64) - p[0]))
+    assert np.array_equal(p[2], x.astype(np.float64) - p[0] - p[1])
+
+
+@pytest.mark.parametrize("hw,cin,cout,pool", CONV_CFGS)
+@pytest.mark.parametrize("xscale", [1.0, 1e-5])
+def test_x3_fwd_and_dgrad(dev, hw, cin, cout, pool, xscale):
+    from ugaitnet_amd import ops, x3
+    rng = np.random.default_rng(9000 + hw + cin + cout)
+    n = 9 if hw <= 32 else 5   # more items than one workgroup round for the small images: exercises the item pipeline
+    x = (rng.uniform(-1, 1, (n, hw, hw, cin)) * xscale).astype(np.float32)
+    w = rng.uniform(-0.2, 0.2, (3, 3, cin, cout)).astype(np.float32)
+    xt, wt = T(x, dev), T(w, dev)
+    act = O.leaky(O.conv2d_same(x.astype(np.float64), w.astype(np.float64)))
+    wf = x3.pack(wt, False)
+    ho = hw // 2 if pool else hw
+    out = torch.empty((n, ho, ho, cout), device=dev)
+    # the fp32-MFMA direct kernel of the library on the same inputs (UGN_WINO=0 path): the yardstick for "fp32-grade"
+    ref32 = ops.conv3x3_fwd(xt, ops.pack3x3(wt), pool)
+    if pool:
+        idx = torch.empty((n, ho, ho, cout), dtype=torch.uint8, device=dev)
+        x3.conv3x3_fwd_multi([xt], [wf], cout, True, [out], [idx])
+        pref, iref = O.maxpool2x2(act)
+        e = close(out, pref, 2e-6, "x3 fwd+pool")
+        e32 = err_of(ref32[0], pref)
+        idx = idx.cpu().numpy()
+        win = act.reshape(n, hw // 2, 2, hw // 2, 2, cout).transpose(0, 1, 3, 2, 4, 5).reshape(n, hw // 2, hw // 2, 4, cout)
+        srt = np.sort(win, axis=3)
+        clear = (srt[:, :, :, 3, :] - srt[:, :, :, 2, :]) > 1e-4 * xscale
+        assert idx.max() <= 3 and np.array_equal(idx[clear], iref[clear])
+    else:
+        x3.conv3x3_fwd_multi([xt], [wf], cout, False, [out])
+        e = close(out, act, 2e-6, "x3 fwd")
+        e32 = err_of(ref32, act)
+    assert e <= 2.0 * e32 + 1e-8, "x3 forward error %.3e against the fp32-MFMA kernel's %.3e" % (e, e32)
+    # data gradient, plain and with LeakyReLU'(act of the layer's input); pooled layers take the pooled gradient + argmax
+    gscale = 1e-4 * xscale
+    act_prev = rng.normal(size=(n, hw, hw, cin)).astype(np.float32)
+    if pool:
+        dp = (rng.normal(size=(n, hw // 2, hw // 2, cout)) * gscale).astype(np.float32)
+        pidx = rng.integers(0, 4, size=dp.shape).astype(np.uint8)
+        dzt = T(dp, dev)
+        dz = O.maxpool2x2_bwd(pidx, dp.astype(np.float64))
+        idx_t = [T(pidx, dev)]
+    else:
+        dzf = (rng.normal(size=(n, hw, hw, cout)) * gscale).astype(np.float32)
+        dzt = T(dzf, dev)
+        dz = dzf.astype(np.float64)
+        idx_t = None
+    _, dx_ref = O.conv2d_same_bwd(x.astype(np.float64), w.astype(np.float64), dz)
+    wd = x3.pack(wt, True)
+    dx = torch.empty((n, hw, hw, cin), device=dev)
+    x3.conv3x3_dgrad_multi([dzt], [wd], hw, cin, cout, [dx], dz_idxs=idx_t)
+    e = close(dx, dx_ref, 3e-6, "x3 dgrad plain")
+    dx32 = ops.conv3x3_dgrad(dzt, wt, hw, dz_idx=None if idx_t is None else idx_t[0])
+    e32 = err_of(dx32, dx_ref)
+    assert e <= 2.0 * e32 + 1e-8, "x3 data-gradient error %.3e against the fp32-MFMA kernel's %.3e" % (e, e32)
+    at = T(act_prev, dev)
+    dx2 = torch.empty((n, hw, hw, cin), device=dev)
+    x3.conv3x3_dgrad_multi([dzt], [wd], hw, cin, cout, [dx2], dz_idxs=idx_t, acts=[at])
+    close(dx2, np.where(act_prev > 0, dx_ref, 0.3 * dx_ref), 3e-6, "x3 dgrad * LeakyReLU'")
+
+
+@pytest.mark.parametrize("hw,cin,cout,pool", CONV_CFGS)
+def test_x3_wgrad(dev, hw, cin, cout, pool):
+    from ugaitnet_amd import ops, x3
+    rng = np.random.default_rng(4100 + hw + cin + cout)
+    n = 11 if hw <= 32 else 3
+    x = rng.uniform(-1, 1, (n, hw, hw, cin)).astype(np.float32)
+    hz = hw // 2 if pool else hw
+    dzf = (rng.normal(size=(n, hz, hz, cout)) * 1e-3).astype(np.float32)
+    if pool:
+        pidx = rng.integers(0, 4, size=dzf.shape).astype(np.uint8)
+        dz = O.maxpool2x2_bwd(pidx, dzf.astype(np.float64))
+        idx_t = [T(pidx, dev)]
+    else:
+        dz, idx_t = dzf.astype(np.float64), None
+    dw_ref, _ = O.conv2d_same_bwd(x.astype(np.float64), np.zeros((3, 3, cin, cout)), dz)
+    dw = torch.full((3, 3, cin, cout), float("nan"), device=dev)
+    x3.conv3x3_wgrad_multi([T(x, dev)], [T(dzf, dev)], cout, [dw], dz_idxs=idx_t)
+    e = close(dw, dw_ref, 3e-6, "x3 wgrad")
+    dw32 = ops.conv3x3_wgrad(T(x, dev), T(dzf, dev), cout, dz_idx=None if idx_t is None else idx_t[0])
+    e32 = err_of(dw32, dw_ref)
+    assert e <= 3.0 * e32 + 1e-8, "x3 weight-gradient error %.3e against the fp32-MFMA kernel's %.3e" % (e, e32)
+    # bitwise reproducible (fixed-order reduction, no atomics)
+    dw2 = torch.empty_like(dw)
+    x3.conv3x3_wgrad_multi([T(x, dev)], [T(dzf, dev)], cout, [dw2], dz_idxs=idx_t)
+    assert torch.equal(dw, dw2)
+
+
+def test_x3_multi_job(dev):
+    """Six jobs of one shape in one launch (three modalities x frame-level + set-level), each with its own filters, sizes and
+    magnitudes: every job must equal its single-job launch bit for bit, and the oracle within the fp32 bar."""
+    from ugaitnet_amd import x3
+    rng = np.random.default_rng(77)
+    hw, cin, cout = 16, 64, 128
+    ns = [7, 5, 6, 2, 1, 3]
+    scales = [1.0, 0.01, 30.0, 1.0, 1e-3, 5.0]
+    xs, ws, wfs, outs, refs, dzs, dws = [], [], [], [], [], [], []
+    for n, s in zip(ns, scales):
+        x = (rng.uniform(-1, 1, (n, hw, hw, cin)) * s).astype(np.float32)
+        w = rng.uniform(-0.1, 0.1, (3, 3, cin, cout)).astype(np.float32)
+        xs.append(T(x, dev))
+        ws.append(T(w, dev))
+        wfs.append(x3.pack(ws[-1], False))
+        outs.append(torch.empty((n, hw, hw, cout), device=dev))
+        refs.append(O.leaky(O.conv2d_same(x.astype(np.float64), w.astype(np.float64))))
+        dzs.append(T((rng.normal(size=(n, hw, hw, cout)) * s * 1e-3).astype(np.float32), dev))
+        dws.append(torch.empty((3, 3, cin, cout), device=dev))
+    x3.conv3x3_fwd_multi(xs, wfs, cout, False, outs)
+    x3.conv3x3_wgrad_multi(xs, dzs, cout, dws)
+    for j, (o, r) in enumerate(zip(outs, refs)):
+        close(o, r, 2e-6, "job %d" % j)
+        single = torch.empty_like(o)
+        x3.conv3x3_fwd_multi([xs[j]], [wfs[j]], cout, False, [single])
+        assert torch.equal(single, o), "job %d differs from its single-job launch" % j
+        dw_ref, _ = O.conv2d_same_bwd(xs[j].cpu().numpy().astype(np.float64), np.zeros((3, 3, cin, cout)),
+                                      dzs[j].cpu().numpy().astype(np.float64))
+        close(dws[j], dw_ref, 3e-6, "wgrad job %d" % j)
+
+
+def test_x3_split_is_exact_and_full_range(dev):
+    """The three-way split loses nothing (x0 + x1 + x2 == x bit for bit) over fp32's whole normal range -- no block exponent, no
+    dependence on the other elements of a tensor: a convolution of one image is the same inside any batch and at any scale."""
+    from ugaitnet_amd import x3
+    rng = np.random.default_rng(3)
+    hw, cin, cout = 16, 64, 128
+    w = rng.uniform(-0.1, 0.1, (3, 3, cin, cout)).astype(np.float32)
+    wf = x3.pack(T(w, dev), False)
+    base = rng.uniform(-1, 1, (1, hw, hw, cin)).astype(np.float32)
+    ref = O.leaky(O.conv2d_same(base.astype(np.float64), w.astype(np.float64)))
+    alone = torch.empty((1, hw, hw, cout), device=dev)
+    x3.conv3x3_fwd_multi([T(base, dev)], [wf], cout, False, [alone])
+    for k in (-80, -24, 0, 30, 90):
+        s = np.float32(2.0) ** k
+        # the same image scaled by a power of two, in a batch whose other images are 2^40 times larger
+        batch = np.concatenate([base * s, base * s * np.float32(2.0) ** 20, base * s * np.float32(2.0) ** -20]).astype(np.float32)
+        out = torch.empty((3, hw, hw, cout), device=dev)
+        x3.conv3x3_fwd_multi([T(batch, dev)], [wf], cout, False, [out])
+        got = out[0:1].cpu().numpy().astype(np.float64) / float(s)
+        assert np.array_equal(got, alone.cpu().numpy().astype(np.float64)), "2^%d: scaling by a power of two must commute bit for bit" % k
+        close(got, ref, 2e-6, "scale 2^%d" % k)

@@ -13,8 +13,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "csrc", "_obj")
 LIB = os.path.join(HERE, "libugaitnet_hip.so")
-SOURCES = ["conv3x3.hip", "conv3x3_wino.hip", "conv3x3_wino_tall.hip", "wgrad3x3_wino.hip", "conv3x3_mm.hip", "wgrad3x3_mm.hip", "h2_elem.hip", "conv3x3_bf.hip", "wgrad3x3_bf.hip", "bf_elem.hip", "conv5x5.hip", "pool_set.hip", "head.hip", "knn.hip", "assemble.hip", "error.cpp"]
-HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "wino_common.h"), os.path.join(CSRC, "mm_common.h"), os.path.join(HERE, "..", "include", "ugaitnet_hip.h")]
+SOURCES = ["conv3x3.hip", "conv3x3_wino.hip", "conv3x3_wino_tall.hip", "wgrad3x3_wino.hip", "conv3x3_mm.hip", "wgrad3x3_mm.hip", "h2_elem.hip", "conv3x3_bf.hip", "wgrad3x3_bf.hip", "bf_elem.hip", "conv3x3_x3.hip", "wgrad3x3_x3.hip", "conv5x5.hip", "pool_set.hip", "head.hip", "knn.hip", "assemble.hip", "error.cpp"]
+HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "wino_common.h"), os.path.join(CSRC, "mm_common.h"), os.path.join(CSRC, "x3_common.h"), os.path.join(HERE, "..", "include", "ugaitnet_hip.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-fno-slp-vectorize"]
 FLAGS += os.environ.get("UGN_EXTRA_HIPCC_FLAGS", "").split()   # experiments only (e.g. -DUGN_...); the default build sets none

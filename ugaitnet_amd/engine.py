@@ -18,7 +18,7 @@ import torch
 import contextlib
 import os
 
-from . import _lib, dp, h2, ops
+from . import _lib, dp, h2, ops, x3
 from .engine_bf import BFState, backward_bf, forward_bf
 from .engine_h2 import H2State, backward_h2, forward_h2
 
@@ -38,7 +38,10 @@ NBINS, FEAT, HIDDEN = 62, 128, 256
 # Arithmetic of the 3x3 layers when a model does not name one (GaitCore(conv_precision=...), UGN_CONV_PRECISION):
 #   "h2"  (default) activations / gradients between the 3x3 layers as split-fp16 halves + block exponent (22 significant bits),
 #         3x3 layers as direct convolutions on the f16 matrix pipe: holds every fp32 parity bar of tests/ and is 1.4x faster
-#   "f32" Winograd F(2x2,3x3) on the fp32 MFMA
+#   "f32x3" IEEE fp32 tensors everywhere; the 3x3 layers multiply them on the bf16 matrix pipe through the exact three-way bf16
+#         split of both operands (six partial products per fp32 product, fp32 accumulate: csrc/x3_common.h) -- fp32-grade results
+#         with no storage format, block exponent or dependence on the other clips of a batch
+#   "f32" IEEE fp32 tensors, Winograd F(2x2,3x3) on the fp32 MFMA
 #   "bf16" BASELINE configs[4]: bf16 activations / gradients / saved tensors in HBM, direct convolutions on the bf16 matrix pipe,
 #         fp32 accumulate, fp32 master weights and Adam (engine_bf.py)
 #   "bf16w" (round 1-2) fp32 tensors, Winograd with bf16-rounded MFMA operands
@@ -204,6 +207,9 @@ class Encoder:
         self.bf16 = bool(bf16)
         if self.bf16 and not (USE_WINOGRAD and PAIR_LAUNCHES and not ROUTED):
             raise ValueError("conv_precision='bf16' needs the default Winograd pair-launch path")
+        self.x3 = False    # 3x3 layers on the x3 kernels (GaitCore(conv_precision="f32x3")): fp32 tensors, three-way bf16 split
+        self.xf = {}       # x3: packed filter planes, forward
+        self.xd = {}       # x3: packed filter planes, data gradient
         self.wp = {}       # packed forward weights of the 3x3 layers (direct kernels)
         self.uf = {}       # Winograd-transformed filters, forward
         self.ud = {}       # Winograd-transformed filters, data gradient
@@ -230,9 +236,24 @@ class Encoder:
                 jobs.append((w, store[name], dgrad, pool))   # a pooled layer's dgrad takes dz at pooled resolution
         return jobs
 
+    def x3_pack_jobs(self):
+        """(w, packed planes, dgrad) of every 3x3 layer and direction of this branch, for x3.pack_multi."""
+        jobs = []
+        for name, k, _, _, _, _ in CONV_SPECS:
+            if k != 3:
+                continue
+            w = self.W(name)
+            for store, dgrad in ((self.xf, False), (self.xd, True)):
+                if name not in store:
+                    store[name] = x3.packed_empty(w.shape[2], w.shape[3], w.device)
+                jobs.append((w, store[name], dgrad))
+        return jobs
+
     def repack(self):
         """Refresh the kernel-ready copies of the 3x3 weights (after every optimizer step)."""
-        if USE_WINOGRAD:
+        if self.x3:
+            x3.pack_multi(self.x3_pack_jobs())
+        elif USE_WINOGRAD:
             ops.wino_pack_multi(self.pack_jobs(), bf16=self.bf16)
         else:
             for name, k, _, _, _, _ in CONV_SPECS:
@@ -415,16 +436,43 @@ def _merged_ok():
     return MERGE_MODALITIES and USE_WINOGRAD and PAIR_LAUNCHES and not ROUTED
 
 
+class _Conv3:
+    """The 3x3 kernel set the merged forward / backward passes run on: Winograd on the fp32 MFMA (ops.*_wino_multi, transformed
+    filters e.uf / e.ud) or x3 (x3.*_multi, packed bf16 planes e.xf / e.xd).  Same tensors, same epilogues, same call shapes."""
+
+    def __init__(self, enc):
+        self.x3, self.bf16 = enc.x3, enc.bf16
+
+    def ready(self, e):
+        return bool(e.xf) if self.x3 else bool(e.uf)
+
+    def fwd(self, encs, names, xs, cout, pool, outs, idxs=None):
+        if self.x3:
+            return x3.conv3x3_fwd_multi(xs, [e.xf[n] for n in names for e in encs], cout, pool, outs, idxs)
+        return ops.conv3x3_fwd_wino_multi(xs, [e.uf[n] for n in names for e in encs], cout, pool, outs, idxs, bf16=self.bf16)
+
+    def dgrad(self, encs, names, dzs, hw, cin, cout, outs, dz_idxs=None, acts=None):
+        if self.x3:
+            return x3.conv3x3_dgrad_multi(dzs, [e.xd[n] for n in names for e in encs], hw, cin, cout, outs, dz_idxs=dz_idxs, acts=acts)
+        return ops.conv3x3_dgrad_wino_multi(dzs, [e.ud[n] for n in names for e in encs], hw, cin, cout, outs, dz_idxs=dz_idxs, acts=acts,
+                                            bf16=self.bf16)
+
+    def wgrad(self, xs, dzs, cout, dws, dz_idxs=None):
+        if self.x3:
+            return x3.conv3x3_wgrad_multi(xs, dzs, cout, dws, dz_idxs=dz_idxs)
+        return ops.conv3x3_wgrad_wino_multi(xs, dzs, cout, dws, dz_idxs=dz_idxs, bf16=self.bf16)
+
+
 def forward_merged(encs, xs):
     """Encoder.forward of several modality branches in lockstep: [x_m [B_m,L,60,60,C_m]] -> [[62,B_m,256]]."""
     U8 = torch.uint8
-    bf16 = encs[0].bf16
+    C3 = _Conv3(encs[0])
     geo = []
     for e, x in zip(encs, xs):
         b, l = x.shape[0], x.shape[1]
         if e.act is None or e.shape != (b, l):
             e.act, e.shape = {}, (b, l)
-        if not e.uf:
+        if not C3.ready(e):
             e.repack()
         geo.append((b, l, b * l))
     A = [e.act for e in encs]
@@ -436,9 +484,11 @@ def forward_merged(encs, xs):
         e.act["x"] = xf
         a1s.append(ops.conv5x5_in_fwd(xf, e.W("a1"), B(e, e.act, "a1", (n, 64, 64, 32)),
                                       sign=B(e, e.act, "a1s", (n, 64, 64), torch.int32) if A1_SIGN_BITS else None))
-    p2s, i2s = ops.conv3x3_fwd_wino_multi(a1s, [e.uf["a2"] for e in encs], 32, True,
-                                          [B(e, e.act, "p2", (g[2], 32, 32, 32)) for e, g in zip(encs, geo)],
-                                          [B(e, e.act, "i2", (g[2], 32, 32, 32), U8) for e, g in zip(encs, geo)], bf16=bf16)
+    hook = getattr(encs[0], "before_conv3", None)     # (a filter repack queued on the second stream: GaitCore.apply_gradients)
+    if hook is not None:
+        hook()
+    p2s, i2s = C3.fwd(encs, ("a2",), a1s, 32, True, [B(e, e.act, "p2", (g[2], 32, 32, 32)) for e, g in zip(encs, geo)],
+                      [B(e, e.act, "i2", (g[2], 32, 32, 32), U8) for e, g in zip(encs, geo)])
     bs, l0 = [g[0] for g in geo], geo[0][1]
     assert all(g[1] == l0 for g in geo), "the modalities of a batch share the set length"
     m1s = ops.setmax_fwd_multi(p2s, bs, l0, [B(e, e.act, "m1", (g[0], 32, 32, 32)) for e, g in zip(encs, geo)])
@@ -452,8 +502,7 @@ def forward_merged(encs, xs):
         if pool:
             idxs = [B(e, e.act, ia, (g[2], ho, ho, cout), U8) for e, g in zip(encs, geo)] + \
                    [B(e, e.act, ib, (g[0], ho, ho, cout), U8) for e, g in zip(encs, geo)]
-        ops.conv3x3_fwd_wino_multi(list(xa) + list(xb), [e.uf[na] for e in encs] + [e.uf[nb] for e in encs], cout, pool, outs, idxs,
-                                   bf16=bf16)
+        C3.fwd(encs, (na, nb), list(xa) + list(xb), cout, pool, outs, idxs)
         k = len(encs)
         return outs[:k], outs[k:]
 
@@ -471,7 +520,7 @@ def forward_merged(encs, xs):
 
 def backward_merged(encs, douts, scratches):
     """Encoder.backward of several modality branches in lockstep (same arithmetic, one launch per layer for all of them)."""
-    bf16 = encs[0].bf16
+    C3 = _Conv3(encs[0])
     dev = encs[0].store.device
     geo = [(e.shape[0], e.shape[1], e.shape[0] * e.shape[1]) for e in encs]
     A = [e.act for e in encs]
@@ -487,13 +536,12 @@ def backward_merged(encs, douts, scratches):
 
     def wgrad(na, nb, xa, xb, dza, dzb, cout, ia=None, ib=None):
         with _side(dev):
-            ops.conv3x3_wgrad_wino_multi(list(xa) + list(xb), list(dza) + list(dzb), cout, [e.G(na) for e in encs] + [e.G(nb) for e in encs],
-                                         dz_idxs=None if ia is None else list(ia) + list(ib), bf16=bf16)
+            C3.wgrad(list(xa) + list(xb), list(dza) + list(dzb), cout, [e.G(na) for e in encs] + [e.G(nb) for e in encs],
+                     dz_idxs=None if ia is None else list(ia) + list(ib))
 
     def dgrad(na, nb, dza, dzb, hw, cin, cout, outa, outb, ia=None, ib=None, acta=None, actb=None):
-        ops.conv3x3_dgrad_wino_multi(list(dza) + list(dzb), [e.ud[na] for e in encs] + [e.ud[nb] for e in encs], hw, cin, cout,
-                                     list(outa) + list(outb), dz_idxs=None if ia is None else list(ia) + list(ib),
-                                     acts=None if acta is None else list(acta) + list(actb), bf16=bf16)
+        C3.dgrad(encs, (na, nb), list(dza) + list(dzb), hw, cin, cout, list(outa) + list(outb),
+                 dz_idxs=None if ia is None else list(ia) + list(ib), acts=None if acta is None else list(acta) + list(actb))
         return outa, outb
 
     # block 3 of the frame stack (a5, a6) with block 2 of the global branch (b3, b4)
@@ -519,9 +567,9 @@ def backward_merged(encs, douts, scratches):
     # block 1 (a1, a2)
     i2 = [a["i2"] for a in A]
     with _side(dev):
-        ops.conv3x3_wgrad_wino_multi([a["a1"] for a in A], dp2, 32, [e.G("a2") for e in encs], dz_idxs=i2, bf16=bf16)
-    dz1 = ops.conv3x3_dgrad_wino_multi(dp2, [e.ud["a2"] for e in encs], 64, 32, 32, [buf(i, "dz1", (geo[i][2], 64, 64, 32)) for i in R],
-                                       dz_idxs=i2, acts=None if A1_SIGN_BITS else [a["a1"] for a in A], bf16=bf16)
+        C3.wgrad([a["a1"] for a in A], dp2, 32, [e.G("a2") for e in encs], dz_idxs=i2)
+    dz1 = C3.dgrad(encs, ("a2",), dp2, 64, 32, 32, [buf(i, "dz1", (geo[i][2], 64, 64, 32)) for i in R],
+                   dz_idxs=i2, acts=None if A1_SIGN_BITS else [a["a1"] for a in A])
     with _side(dev):
         for i, e in enumerate(encs):
             ops.conv5x5_in_wgrad(A[i]["x"], dz1[i], e.G("a1"), sign=A[i]["a1s"] if A1_SIGN_BITS else None)
@@ -583,12 +631,16 @@ class GaitCore:
         # between the 3x3 layers held as split-fp16 halves + block exponent, 3x3 layers on the f16 matrix pipe at fp32-class
         # accuracy (engine_h2.py, csrc/mm_common.h)
         conv_precision = DEFAULT_PRECISION if conv_precision is None else conv_precision
-        if conv_precision not in ("f32", "bf16", "bf16w", "h2"):
-            raise ValueError("conv_precision must be 'h2', 'f32', 'bf16' or 'bf16w', got %r" % (conv_precision,))
+        if conv_precision not in ("f32x3", "f32", "bf16", "bf16w", "h2"):
+            raise ValueError("conv_precision must be 'f32x3', 'f32', 'h2', 'bf16' or 'bf16w', got %r" % (conv_precision,))
         self.conv_precision = conv_precision
         self.h2 = conv_precision == "h2"
         self.bf = conv_precision == "bf16"
-        if (self.h2 or self.bf) and self.nmod > 3:
+        self.x3 = conv_precision == "f32x3"
+        if self.x3 and not (USE_WINOGRAD and PAIR_LAUNCHES and not ROUTED and MERGE_MODALITIES and A1_SIGN_BITS):
+            raise ValueError("conv_precision='f32x3' runs on the merged one-launch-per-layer path (UGN_WINO / UGN_PAIR / UGN_MERGE / "
+                             "UGN_A1_BITS at their defaults, UGN_ROUTED off)")
+        if (self.h2 or self.bf or self.x3) and self.nmod > 3:
             # one launch per layer carries the frame-level layer and the set-level twin of EVERY modality as jobs, and the kernels'
             # job tables hold 6 (csrc/mm_common.h kMaxJobs; h2_elem.hip / bf_elem.hip kJobs); the reference's graphs stop at 3
             # modalities (nets/mj_uwyhNets_ba.py:1031-1299)
@@ -596,6 +648,8 @@ class GaitCore:
                              "UGN_MERGE=0" % (conv_precision, self.nmod))
         self.encoders = [Encoder(self.store, "m%d." % mi, cin, bf16=conv_precision == "bf16w")
                          for mi, cin in enumerate(self.in_channels)]
+        for enc in self.encoders:
+            enc.x3 = self.x3
         if self.bf:
             for enc in self.encoders:
                 enc.bf = BFState(enc)
@@ -659,6 +713,9 @@ class GaitCore:
             from . import bf16
             bf16.pack_multi([j for e in self.encoders for j in e.bf.pack_jobs()])
             return
+        if self.x3:          # the three bf16 planes of every 3x3 filter, both directions: one launch for all branches
+            x3.pack_multi([j for e in self.encoders for j in e.x3_pack_jobs()])
+            return
         if USE_WINOGRAD:     # one launch for the filters of all branches
             jobs = [j for e in self.encoders for j in e.pack_jobs()]
             ops.wino_pack_multi(jobs, bf16=self.encoders[0].bf16)
@@ -673,7 +730,7 @@ class GaitCore:
         exponent per tensor: what a clip gets depends on the largest clip of its batch, csrc/mm_common.h) answers inference queries
         in IEEE fp32, where an embedding does not depend on the other clips of the batch beyond what the reference's own
         batch-axis normalisation does.  Parameters must not change inside the block (the f16x2 / bf16 filter packs stay valid)."""
-        if precision is None or precision == self.conv_precision or self.conv_precision not in ("h2", "bf16"):
+        if precision is None or precision == self.conv_precision or self.conv_precision not in ("h2", "bf16"):   # (f32x3: IEEE fp32 tensors already)
             yield                   # (fp32 models, and the fp32-tensor 'bf16w' mode, answer in their own arithmetic)
             return
         if precision != "f32":
@@ -758,7 +815,7 @@ class GaitCore:
         xs = [self._dev(x) for x in xs]
         b = xs[0].shape[0]
         self._active = None
-        merged = (_merged_ok() and len(self.encoders) > 1) or self.h2 or self.bf
+        merged = (_merged_ok() and len(self.encoders) > 1) or self.h2 or self.bf or self.x3
         if self.h2:
             self.meta_pool.reset()      # every H2 meta of the step gathers its maximum from zero: one memset
         fwd_many = forward_h2 if self.h2 else (forward_bf if self.bf else forward_merged)
@@ -779,7 +836,7 @@ class GaitCore:
                 outs[mi].zero_()
                 if len(rows):
                     sub.append((mi, idx, x.index_select(0, idx).contiguous()))
-            if merged and (len(sub) > 1 or ((self.h2 or self.bf) and sub)):
+            if merged and (len(sub) > 1 or ((self.h2 or self.bf or self.x3) and sub)):
                 res = fwd_many([self.encoders[mi] for mi, _, _ in sub], [x for _, _, x in sub])
             else:
                 res = [self.encoders[mi].forward(x) for mi, _, x in sub]
@@ -892,7 +949,7 @@ class GaitCore:
                                       [self._buf("dout%d" % m, (NBINS, bl, HIDDEN)) for m in range(self.nmod)])
         else:
             douts = [own(dsig)]
-        if self.h2 or self.bf or (_merged_ok() and self.nmod > 1 and not BRANCH_STREAMS):
+        if self.h2 or self.bf or self.x3 or (_merged_ok() and self.nmod > 1 and not BRANCH_STREAMS):
             encs, ds = [], []
             for mi, (enc, d) in enumerate(zip(self.encoders, douts)):
                 idx = self._active[mi] if self._active is not None else None
@@ -908,7 +965,7 @@ class GaitCore:
             if self.h2 or self.bf:
                 if encs:
                     (backward_h2 if self.h2 else backward_bf)(encs, ds, _side)
-            elif len(encs) > 1:
+            elif len(encs) > 1 or (self.x3 and encs):
                 backward_merged(encs, ds, [self.scratch.setdefault(self.encoders.index(e), {}) for e in encs])
             elif encs:
                 encs[0].backward(ds[0], self.scratch.setdefault(self.encoders.index(encs[0]), {}))
@@ -990,7 +1047,7 @@ class GaitCore:
             ops.adam_step(st.flat[lo:hi], st.grad[lo:hi], st.m[lo:hi], st.v[lo:hi], lr_t, self.beta_1, self.beta_2, self.epsilon, scale)
             return                      # (the convolution filters did not change: no repack)
         ops.adam_step(st.flat, st.grad, st.m, st.v, lr_t, self.beta_1, self.beta_2, self.epsilon, scale)
-        if (self.h2 or self.bf) and WGRAD_STREAM and PACK_ON_SIDE_STREAM and not torch.cuda.is_current_stream_capturing():
+        if (self.h2 or self.bf or self.x3) and WGRAD_STREAM and PACK_ON_SIDE_STREAM and not torch.cuda.is_current_stream_capturing():
             # the repack of the 3x3 filters (3 launches, ~50 us whatever the batch) runs on the second stream, beside the next
             # step's input copies and 5x5 layer; the first 3x3 layer waits for it (`_before_conv3`)
             with _side(self.device):
