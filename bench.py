@@ -61,7 +61,12 @@ def flop_per_clip(kinds):
 
 
 DTYPE_TEXT = {
-    "f32": "f32",
+    "f32x3": "f32: IEEE fp32 tensors in HBM end to end (no storage format, no block exponent); the 3x3 layers multiply them on "
+             "v_mfma_f32_16x16x32_bf16 through the EXACT three-way bf16 split of both operands (x = x0 + x1 + x2, 24 = 8 + 8 + 8 bits, "
+             "fp32's exponent range), six of the nine partial products per fp32 product (the dropped ones < 2^-23 of the product), fp32 "
+             "accumulate: error against fp64 at the level of the fp32-MFMA kernels of the same library on the same inputs "
+             "(tests/test_x3_gpu.py, tools/x3_accuracy.py); 5x5 layer, pooling, head, losses, Adam in fp32",
+    "f32": "f32: IEEE fp32 tensors and arithmetic end to end, 3x3 layers as Winograd F(2x2,3x3) on v_mfma_f32_16x16x4_f32",
     "bf16": "bf16: activations, gradients and saved tensors bf16 in HBM, 3x3 layers on v_mfma_f32_32x32x16_bf16 with f32 accumulate, "
             "f32 weight gradients / master weights / Adam (BASELINE configs[4])",
     "h2": "f16x2: fp32-class values held as two f16 halves + a block exponent (22 significant bits); 3x3 layers = three "
@@ -71,7 +76,11 @@ DTYPE_TEXT = {
 PEAK_F32_MFMA = 157.3e12   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 / 16x16x4_f32 dense peak
 PEAK_BF16_MFMA = 16 * PEAK_F32_MFMA   # same guide: the f32 MFMA rate is 1/16 of the dense bf16 rate (~2.5 PFLOP/s)
 PEAK_HBM = 8.0e12          # same guide: HBM3E spec peak (6.3 TB/s is what a float4 copy achieves)
-DEFAULT_DTYPE = os.environ.get("UGN_BENCH_DTYPE", "h2")     # the product's default arithmetic (engine.DEFAULT_PRECISION)
+DEFAULT_DTYPE = os.environ.get("UGN_BENCH_DTYPE", "f32x3")     # the product's default arithmetic (engine.DEFAULT_PRECISION)
+# the SAME job in the library's other fp32-class arithmetics, timed after the headline run and reported beside it (never as `value`):
+# key suffix -> conv_precision
+SECONDARY = {"f32x3": (("f32_mfma", "f32"), ("h2", "h2")), "f32": (("h2", "h2"),), "h2": (("f32_mfma", "f32"),), "bf16": ()}
+EXEC_FACTOR = {"f32x3": 6.0, "f32": 16.0 / 36.0, "bf16": 1.0, "h2": 3.0}
 
 
 def cpu_baseline(kinds, ncls, clips, n_ids, seconds_budget=30.0, multimodal=True):
@@ -114,9 +123,9 @@ def build_parser():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dense-only", action="store_true",
                     help="skip the secondary runs (mask-skipping, IEEE-fp32 line): only the named arithmetic runs (profiling target)")
-    ap.add_argument("--no-f32-line", action="store_true",
-                    help="default (f16x2) run only: do not time the IEEE-fp32 Winograd path beside it (value_f32 / ms_per_step_f32 / "
-                         "roofline_f32)")
+    ap.add_argument("--no-secondary-lines", "--no-f32-line", dest="no_f32_line", action="store_true",
+                    help="headline arithmetic only: do not time the same job in the other fp32-class arithmetics beside it "
+                         "(value_f32_mfma = Winograd on the fp32 MFMA, value_h2 = f16x2 tensors)")
     ap.add_argument("--skip-masked", action="store_true",
                     help="run each encoder only on the clips whose modality flag is 1 (exactly the same results; the default "
                          "line computes the masked pairs too)")
@@ -124,10 +133,10 @@ def build_parser():
                     help="N > 1: 'replica' = the reference's MirroredStrategy (losses per replica slice, one gradient "
                          "all-reduce; default for weak scaling); 'global' = all-gather the fused features so the losses see the "
                          "whole batch (default for --scaling strong: N GPUs then compute the one-GPU step)")
-    ap.add_argument("--dtype", choices=("f32", "bf16", "h2"), default=DEFAULT_DTYPE,
-                    help="f32 = Winograd fp32-MFMA kernels; h2 = fp32-class values as two f16 halves, 3x3 layers on the f16 matrix "
-                         "pipe (the default when it holds every fp32 parity bar); bf16 = BASELINE configs[4] arithmetic, never the "
-                         "headline")
+    ap.add_argument("--dtype", choices=("f32x3", "f32", "bf16", "h2"), default=DEFAULT_DTYPE,
+                    help="f32x3 (default) = fp32 tensors, 3x3 products through the exact three-way bf16 split on the bf16 matrix pipe; "
+                         "f32 = fp32 tensors, Winograd on the fp32 MFMA; h2 = fp32-class values stored as two f16 halves + a block "
+                         "exponent (22 bits), 3x3 layers on the f16 matrix pipe; bf16 = BASELINE configs[4] arithmetic, never the headline")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c3", help="c3 is the headline workload")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
                     help="strong: the workload's batch is split over the ranks (c4: 40 / N clips per GPU)")
@@ -249,7 +258,7 @@ def roofline_pass(core, batch, steps, dtype, table_path=""):
                    "duration, against the peak of the instruction that executes them: f16x2 kernels run three f16 MFMAs per "
                    "fp32-class product (3x the direct-convolution count `algorithmic_tflops`, dense f16/bf16 peak); Winograd "
                    "F(2x2,3x3) fp32 kernels 16/36 of it (fp32-MFMA peak); HBM-bound kernels (and every bf16 3x3 kernel: mfma_frac "
-                   "is their second figure): algorithmic bytes / avg duration against 8 TB/s.  f16x2 3x3 kernels carry BOTH figures "
+                   "is their second figure): algorithmic bytes / avg duration against 8 TB/s.  x3 and f16x2 3x3 kernels carry BOTH figures "
                    "(mfma_frac, hbm_frac) and `bound` names the roof whose floor -- executed FLOPs / 2516.8 TFLOP/s or algorithmic "
                    "bytes / 8 TB/s -- is the longer time" % steps)
     # `traffic` is NOT measured in this run: it is the PMC figure (FETCH_SIZE x2-corrected + WRITE_SIZE, separate --pmc passes) of
@@ -404,19 +413,19 @@ def run(args):
         skip_rate = world * b_gpu * args.steps / dt2
         del core2
 
-    # The SAME job in IEEE fp32 (BASELINE configs[1..3] say fp32 and the reference computes in fp32, nets/mj_uwyhNets_ba.py:428-462):
-    # fp32 tensors in HBM, Winograd F(2x2,3x3) on the fp32 MFMA, same steps / warm-up / barriers -- reported BESIDE the default
-    # arithmetic's line (value_f32, ms_per_step_f32, roofline_f32), never as `value`.
-    f32 = None
-    if args.dtype == "h2" and not (args.no_f32_line or args.dense_only or args.serial or args.skip_masked or args.graph):
-        core = None
-        torch.cuda.empty_cache()
-        core32 = make_core(False, "f32")
-        dt32 = timed(core32, batch)
-        loss32 = core32.losses()["loss"]
-        roof32 = None if args.no_roofline_pass else roofline_pass(core32, batch, 3, "f32")
-        f32 = dict(dt=dt32, loss=loss32, roof=roof32)
-        del core32
+    # The SAME job -- batch, initial weights, steps, warm-up, barriers -- in the library's other fp32-class arithmetics, reported BESIDE
+    # the headline line (value_<tag>, ms_per_step_<tag>, roofline_<tag>, loss_<tag>), never as `value`.
+    others = []
+    if not (args.no_f32_line or args.dense_only or args.serial or args.skip_masked or args.graph):
+        for tag, prec in SECONDARY[args.dtype]:
+            core = None
+            torch.cuda.empty_cache()
+            c2 = make_core(False, prec)
+            dt2_ = timed(c2, batch)
+            loss2 = c2.losses()["loss"]
+            roof2 = None if args.no_roofline_pass else roofline_pass(c2, batch, 3, prec)
+            others.append(dict(tag=tag, prec=prec, dt=dt2_, loss=loss2, roof=roof2))
+            del c2
 
     if rank == 0:
         value = world * b_gpu * args.steps / dt
@@ -430,7 +439,7 @@ def run(args):
                              allreduce="bucketed, overlapped with backward" if engine.AR_OVERLAP else "one call after backward",
                              gradient_bytes=grad_bytes, collectives_ms_per_step=coll_ms)
         fpc = flop_per_clip(kinds)
-        exec_factor = {"f32": 16.0 / 36.0, "bf16": 1.0, "h2": 3.0}[args.dtype]
+        exec_factor = EXEC_FACTOR[args.dtype]
         exec_peak = PEAK_F32_MFMA if args.dtype == "f32" else PEAK_BF16_MFMA
         out = dict(metric="clips/sec (%s, L=25, 60x60) fwd+bwd+Adam" % ("3-mod" if len(kinds) == 3 else "%d-mod" % len(kinds)),
                    value=round(value, 2), unit="clips/s",
@@ -450,22 +459,23 @@ def run(args):
                    whole_step_frac_of_matrix_peak=round(value * fpc * exec_factor / world / exec_peak, 4),
                    loss=round(losses["loss"], 5), roofline=roof)
         out["whole_step_note"] = ("whole_step_tflops prices the step with SURVEY 8(d)'s algorithmic FLOPs per clip (71.3 G for 3 "
-                                  "modalities); the fraction beside it counts the FLOPs the matrix pipe executes for them (f32 / "
-                                  "bf16-operand Winograd: 16/36 against the fp32-MFMA / bf16 peak; f16x2: 3x against the dense "
-                                  "f16 peak of 2.5 PFLOP/s)")
+                                  "modalities); the fraction beside it counts the FLOPs the matrix pipe executes for them (f32x3: 6x "
+                                  "against the dense bf16 peak of 2.5 PFLOP/s; Winograd f32: 16/36 against the fp32-MFMA peak; f16x2: 3x "
+                                  "against the dense f16 peak)")
         if skip_rate is not None:
             out["value_skip_masked"] = round(skip_rate, 2)   # 29 of the 72 (clip, modality) pairs of the C3 batch are masked
-        if f32 is not None:
-            out["value_f32"] = round(world * b_gpu * args.steps / f32["dt"], 2)
-            out["ms_per_step_f32"] = round(f32["dt"] / args.steps * 1e3, 3)
-            out["dtype_f32"] = ("f32: IEEE fp32 tensors and arithmetic end to end, 3x3 layers as Winograd F(2x2,3x3) on "
-                                "v_mfma_f32_16x16x4_f32 (GaitCore(conv_precision='f32')); same batch, steps, warm-up and barriers as `value`")
-            out["loss_f32"] = round(f32["loss"], 5)
-            out["whole_step_frac_of_matrix_peak_f32"] = round(out["value_f32"] * fpc * (16.0 / 36.0) / world / PEAK_F32_MFMA, 4)
-            if f32["roof"] is not None:
+        for o in others:
+            tag, prec = o["tag"], o["prec"]
+            out["value_" + tag] = round(world * b_gpu * args.steps / o["dt"], 2)
+            out["ms_per_step_" + tag] = round(o["dt"] / args.steps * 1e3, 3)
+            out["dtype_" + tag] = DTYPE_TEXT[prec] + " (GaitCore(conv_precision=%r)); same batch, steps, warm-up and barriers as `value`" % prec
+            out["loss_" + tag] = round(o["loss"], 5)
+            out["whole_step_frac_of_matrix_peak_" + tag] = round(out["value_" + tag] * fpc * EXEC_FACTOR[prec] / world /
+                                                                 (PEAK_F32_MFMA if prec == "f32" else PEAK_BF16_MFMA), 4)
+            if o["roof"] is not None:
                 keep = ("kernel", "bound", "achieved", "peak", "unit", "frac", "avg_us", "launches_per_step", "share_of_step",
-                        "algorithmic_tflops", "rocprof_kernel", "images_per_launch", "serial_step_us")
-                out["roofline_f32"] = {k: f32["roof"].get(k) for k in keep}
+                        "algorithmic_tflops", "mfma_frac", "hbm_frac", "rocprof_kernel", "images_per_launch", "serial_step_us")
+                out["roofline_" + tag] = {k: o["roof"].get(k) for k in keep if o["roof"].get(k) is not None}
         if not args.no_cpu_baseline and world == 1:
             big = b_gpu > 40      # (the generator-expanded batches: time the workload's own batch on the CPU)
             out["cpu_baseline"] = cpu_baseline(kinds, ncls, wl["clips"] if big else b_gpu, wl["clips"] // wl["ids_per"] if big else n_ids,

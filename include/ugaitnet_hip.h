@@ -175,6 +175,14 @@ int ugn_setmax_fwd_multi(const float* const* p, const float* const* addend, floa
                          const int* b, int njobs, int l, size_t s, void* stream);
 int ugn_setmax_bwd_multi(const float* const* p, const float* const* dm, const float* const* addend, float* const* out,
                          const int* b, int njobs, int l, size_t s, int apply_lrelu, void* stream);
+/* Set pooling with ROUTING WORDS: the forward pass also writes, per (clip, element), two u32 words -- route [b][s/4][2][4]: word 0 of
+ * a channel = bit t set iff frame t holds the maximum, word 1 = bit t set iff frame t is positive (l <= 32) -- and the gradient reads
+ * those 8 bytes per element INSTEAD of the l frames (4 l bytes): the same results as ugn_setmax_fwd_multi / ugn_setmax_bwd_multi bit
+ * for bit (reduce_max + its gradient, nets/mj_uwyhNets_ba.py:435,451,463). */
+int ugn_setmax_fwd_routed_multi(const float* const* p, const float* const* addend, float* const* m, float* const* sum_out,
+                                uint32_t* const* route, const int* b, int njobs, int l, size_t s, void* stream);
+int ugn_setmax_bwd_routed_multi(const uint32_t* const* route, const float* const* dm, const float* const* addend, float* const* out,
+                                const int* b, int njobs, int l, size_t s, int apply_lrelu, void* stream);
 int ugn_lrelu_bwd_multi(const float* const* g, const float* const* act, float* const* out, const size_t* n, int njobs,
                         void* stream);
 

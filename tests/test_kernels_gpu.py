@@ -377,6 +377,60 @@ def test_setmax(dev, with_add):
     close(got, O.leaky_bwd_from_out(p, ref + extra), 1e-6, "setmax bwd + addend + lrelu'")
 
 
+@pytest.mark.parametrize("l", [25, 1, 32, 7])
+def test_setmax_routed(dev, l):
+    """Set pooling with routing words (csrc/pool_set.hip, round 5): the words against numpy, the maxima and the gradient (plain, with
+    LeakyReLU', with an in-place addend) bit for bit against the kernels that read the frames again, and against the oracle."""
+    from ugaitnet_amd import ops
+    rng = np.random.default_rng(30 + l)
+    bs, shape = [3, 2], (16, 16, 64)
+    s = int(np.prod(shape))
+    ps, adds, dms = [], [], []
+    for b in bs:
+        p5 = rng.normal(size=(b, l) + shape).astype(np.float32)
+        if l > 7:
+            p5[:, 3] = p5[:, 7]          # exact ties between frames 3 and 7
+        p5[0, :, 0, 0, :] = 0.5          # an l-way tie
+        p5[0, :, 0, 1, :] = -0.25        # ... and a negative one
+        p5[0, :, 1, 0, :] = 0.0          # zeros: not positive (LeakyReLU' = 0.3 at 0)
+        ps.append(p5.reshape((b * l,) + shape))
+        adds.append(rng.normal(size=(b,) + shape).astype(np.float32))
+        dms.append(rng.normal(size=(b,) + shape).astype(np.float32))
+    pt = [T(p, dev) for p in ps]
+    ms = [torch.empty((b,) + shape, device=dev) for b in bs]
+    sums = [torch.empty((b,) + shape, device=dev) for b in bs]
+    routes = [torch.empty((b, s // 4, 2, 4), dtype=torch.int32, device=dev) for b in bs]
+    ops.setmax_fwd_routed_multi(pt, bs, l, ms, routes, addends=[T(a, dev) for a in adds], sum_outs=sums)
+    m0 = [torch.empty((b,) + shape, device=dev) for b in bs]
+    ops.setmax_fwd_multi(pt, bs, l, m0)
+    for j, b in enumerate(bs):
+        p5 = ps[j].reshape((b, l, s))
+        m_ref = p5.max(axis=1)
+        assert torch.equal(ms[j], m0[j]) and np.array_equal(ms[j].cpu().numpy().reshape(b, s), m_ref)
+        assert np.array_equal(sums[j].cpu().numpy().reshape(b, s), m_ref + adds[j].reshape(b, s))
+        w = routes[j].cpu().numpy().view(np.uint32)                   # [b, s/4, 2, 4] -> [b, s] per word kind
+        bits = (1 << np.arange(l, dtype=np.uint64))[None, :, None]
+        mask_ref = ((p5 == m_ref[:, None, :]) * bits).sum(axis=1).astype(np.uint32)
+        pos_ref = ((p5 > 0) * bits).sum(axis=1).astype(np.uint32)
+        assert np.array_equal(w[:, :, 0, :].reshape(b, s), mask_ref) and np.array_equal(w[:, :, 1, :].reshape(b, s), pos_ref)
+    dmt = [T(d, dev) for d in dms]
+    for lrelu in (False, True):
+        a = [torch.empty_like(p) for p in pt]
+        ops.setmax_bwd_multi(pt, dmt, bs, l, lrelu, a)
+        r = [torch.empty_like(p) for p in pt]
+        ops.setmax_bwd_routed_multi(routes, dmt, bs, l, lrelu, r)
+        assert all(torch.equal(x, y) for x, y in zip(a, r)), "routed gradient differs (lrelu=%r)" % lrelu
+    extra = [rng.normal(size=p.shape).astype(np.float32) for p in ps]
+    a, r = [T(e, dev) for e in extra], [T(e, dev) for e in extra]
+    ops.setmax_bwd_multi(pt, dmt, bs, l, True, a, addends=a)
+    ops.setmax_bwd_routed_multi(routes, dmt, bs, l, True, r, addends=r)                  # in place over the addend
+    assert all(torch.equal(x, y) for x, y in zip(a, r))
+    for j, b in enumerate(bs):
+        p5 = ps[j].reshape((b, l) + shape)
+        ref = O.setmax_bwd(p5, O.setmax(p5), dms[j]).reshape(ps[j].shape)
+        close(r[j], O.leaky_bwd_from_out(ps[j], ref + extra[j]), 1e-6, "routed setmax bwd + addend + lrelu'")
+
+
 def test_hpp(dev):
     from ugaitnet_amd import ops
     rng = np.random.default_rng(4)
@@ -533,6 +587,28 @@ def test_triplet(dev, labels):
     assert np.all(np.abs(bn.cpu().numpy() - aux["num"]) <= fragile)
     assert abs(float(bl.mean()) - loss_ref) <= 2e-5 * max(1.0, abs(loss_ref))
     close(dsig, O.triplet_all_bwd(sig.astype(np.float64), aux), 2e-4, "triplet dsig")
+
+
+def test_triplet_reference_example_through_the_hip_kernel(dev):
+    """The only numeric example the reference holds -- nets/triplet_loss_all.py:113-118: 6 x 3 embeddings, labels 1,1,2,2,3,3, margin
+    0.2 -- fed to the HIP path itself: zero-padded to 256 features (distances unchanged) and replicated to the 62 bins, through
+    ugn_triplet_indices_host + ugn_triplet_fwd_bwd, against the python-loop brute force of tests/test_oracle_kat.py."""
+    from ugaitnet_amd import ops
+    from tests.test_oracle_kat import KAT_EMB, KAT_LAB, brute_force_triplet
+    ref_loss, ref_active = brute_force_triplet(KAT_EMB, KAT_LAB, 0.2)
+    sig = np.zeros((62, 6, 256), np.float32)
+    sig[:, :, :3] = KAT_EMB.astype(np.float32)[None]
+    hp, hn, kp, kn = ops.triplet_indices(KAT_LAB)
+    hp_ref, hn_ref, kp_ref, kn_ref = O.triplet_index_lists(KAT_LAB)
+    assert (kp, kn) == (kp_ref, kn_ref) == (2, 4) and np.array_equal(hp, hp_ref) and np.array_equal(hn, hn_ref)
+    bl, bn, dsig = ops.triplet_fwd_bwd(T(sig, dev), T(hp, dev), T(hn, dev), kp, kn, 0.2, 1.0)
+    bl, bn = bl.cpu().numpy(), bn.cpu().numpy()
+    assert np.all(bn == ref_active), (bn[:4], ref_active)                  # active-triplet count of every bin: exact
+    assert np.all(np.abs(bl - ref_loss) <= 2e-6 * max(1.0, abs(ref_loss))), (bl[:4], ref_loss)
+    # the gradient against the fp64 oracle on the same 62-bin tensor, and nothing leaks into the padded features
+    _, aux = O.triplet_all(KAT_LAB, sig.astype(np.float64), 0.2)
+    close(dsig, O.triplet_all_bwd(sig.astype(np.float64), aux), 2e-5, "triplet dsig (reference example)")
+    assert float(dsig[:, :, 3:].abs().max()) == 0.0
 
 
 @pytest.mark.parametrize("labels", [np.repeat(np.arange(12), 2), np.repeat(np.arange(4), 10), np.array([0, 0, 0, 1, 2, 2, 3]),

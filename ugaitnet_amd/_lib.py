@@ -41,6 +41,8 @@ PROTOTYPES = {
     "ugn_scale": (_i, [_p, _f, _sz, _p]),
     "ugn_setmax_fwd_multi": (_i, [C.POINTER(_p)] * 4 + [C.POINTER(_i), _i, _i, _sz, _p]),
     "ugn_setmax_bwd_multi": (_i, [C.POINTER(_p)] * 4 + [C.POINTER(_i), _i, _i, _sz, _i, _p]),
+    "ugn_setmax_fwd_routed_multi": (_i, [C.POINTER(_p)] * 5 + [C.POINTER(_i), _i, _i, _sz, _p]),
+    "ugn_setmax_bwd_routed_multi": (_i, [C.POINTER(_p)] * 4 + [C.POINTER(_i), _i, _i, _sz, _i, _p]),
     "ugn_lrelu_bwd_multi": (_i, [C.POINTER(_p)] * 3 + [C.POINTER(_sz), _i, _p]),
     "ugn_hpp_fwd_multi": (_i, [C.POINTER(_p)] * 3 + [C.POINTER(_i), _i, _p]),
     "ugn_hpp_bwd_multi": (_i, [C.POINTER(_p)] * 6 + [C.POINTER(_i), _i, _p]),

@@ -1186,6 +1186,13 @@ __global__ __launch_bounds__(512, 2) void conv_mm16_kernel(const MmJobs jt, cons
 #define UGN_MM_D2 3       /* bit 0: the 32 -> 32 forward kernel, bit 1: its pooled data gradient; bit 2 (experiment, measured 2-17 %
                              SLOWER: profiles/r04_kernel_experiments.txt): the other un-pooled launches with <= 64 columns */
 #endif
+// The packed-filter layout (mm_pack_kernel: mm_tile16 / mm_nr, i.e. UGN_D2P16, UGN_NR_POOLED, UGN_MM_NR) and the kernel a pooled data
+// gradient is dispatched to (UGN_MM_D2, mm_nr) must name the same kernel family: an ablation build that switches one without the
+// other would read tile16-packed filters through the 32-column block loader and return wrong gradients without any error.
+static_assert(!UGN_D2P16 || (UGN_MM_D2 & 2), "-DUGN_MM_D2 without bit 1 needs -DUGN_D2P16=0: the pooled 32 -> 32 data gradient would run "
+                                            "launch_mm on filters packed for conv_d2_kernel");
+static_assert(!UGN_NR_POOLED || UGN_MM_NR, "-DUGN_MM_NR=0 needs -DUGN_NR_POOLED=0: the pooled 64 -> 64 data gradient would run launch_mm on "
+                                           "filters packed for conv_nr_kernel");
 constexpr int D2_SLOTS = 18 * 18 * 8;              // 2592 slots of 16 B
 constexpr int D2_PIECES = (D2_SLOTS + 63) / 64;    // 41 (the last one half used: the filter starts behind it)
 constexpr int D2_W_OFF = 42 * 1024;

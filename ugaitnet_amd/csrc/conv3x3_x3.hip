@@ -122,12 +122,19 @@ __global__ __launch_bounds__(256) void x3_split_kernel(const float* __restrict__
 }
 
 // ---- the convolution --------------------------------------------------------------------------------------------------
-template <int KC, int NC, int HW, int EPI, int IN_POOLED>
-__global__ __launch_bounds__(512, 2) void conv_x3_kernel(const X3Jobs jt) {
-  constexpr int NT = NC / 16, MPARTS = 8 / NT, ROWS = 16 / MPARTS, NCHUNK = KC / 32;
-  constexpr bool RES = NCHUNK == 1;            // the job's whole filter tile stays in registers
+// WAVES = 8: one workgroup per CU, the halo tile double buffered, the next tile split and written between the MFMAs of the current one.
+// WAVES = 4: TWO independent workgroups per CU (62 KB of LDS each, one halo buffer): a workgroup multiplies a tile, then -- behind a
+// second barrier -- splits and writes the next one and runs its epilogue while the OTHER workgroup multiplies.  Inside one workgroup the
+// matrix work and everything else add up (the waves move in lock-step from barrier to barrier; re-ordering the same work changes
+// nothing: tools/bench_x3.py ablations in profiles/r05_x3_experiments.txt); two workgroups drift into anti-phase.
+template <int KC, int NC, int HW, int EPI, int IN_POOLED, int WAVES>
+__global__ __launch_bounds__(64 * WAVES, 2) void conv_x3_kernel(const X3Jobs jt) {
+  constexpr int NTHR = 64 * WAVES;
+  constexpr bool DB = WAVES == 8;              // double-buffered halo, staging interleaved with the MFMAs
+  constexpr int NT = NC / 16, MPARTS = WAVES / NT, ROWS = 16 / MPARTS, NCHUNK = KC / 32;
+  constexpr bool RES = NCHUNK == 1 && DB;      // the job's whole filter tile stays in registers
   constexpr int RPX = HW / 16, RPI = RPX * RPX;
-  static_assert(NC == 32 || NC == 64 || NC == 128, "a wave = one 16-channel tile x 4 / 8 / 16 rows");
+  static_assert((NC == 32 || NC == 64 || NC == 128) && MPARTS >= 1 && ROWS * MPARTS == 16, "a wave = one 16-channel tile x ROWS rows");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -143,34 +150,38 @@ __global__ __launch_bounds__(512, 2) void conv_x3_kernel(const X3Jobs jt) {
   if (item >= ir.end) return;
   int jb = job_of(jt, item), lit = item - jt.start[jb];
 
-  // ---- staging of an un-pooled tile: unit u = tid + 512 s -> halo pixel u >> 2, channels 8 (u & 3) .. + 7 of the chunk.  The 240
+  // ---- staging of an un-pooled tile: unit u = tid + NTHR s -> halo pixel u >> 2, channels 8 (u & 3) .. + 7 of the chunk.  The 240
   // slots beyond the 1296 units repeat units 1056 .. 1295 (same loads, same values to the same addresses): every thread runs the
   // same straight-line code, so the split can be scheduled between the MFMAs of a row instead of behind a branch
-  int st_lds[3], st_g[3], st_rc[3];
+  constexpr int NSLOT = IN_POOLED ? (400 + NTHR - 1) / NTHR : (X3_UNITS + NTHR - 1) / NTHR;      // 3 (8 waves) or 6; pooled: 1 or 2
+  int st_lds[IN_POOLED ? 1 : NSLOT], st_g[IN_POOLED ? 1 : NSLOT], st_rc[IN_POOLED ? 1 : NSLOT];
+  if constexpr (!IN_POOLED) {
 #pragma unroll
-  for (int s = 0; s < 3; ++s) {
-    int u = tid + 512 * s;
-    if (u >= X3_UNITS) u -= 1536 - X3_UNITS;
-    const int hp = u >> 2, skg = u & 3;
-    const int hr = hp / 18, hc = hp - hr * 18;
-    st_lds[s] = hp * 64 + (x3_slot(skg, hc) << 4);
-    st_g[s] = ((hr - 1) * HW + (hc - 1)) * KC + skg * 8;
-    st_rc[s] = (hr << 8) | hc;
+    for (int s = 0; s < NSLOT; ++s) {
+      int u = tid + NTHR * s;
+      if (u >= X3_UNITS) u -= NSLOT * NTHR - X3_UNITS;
+      const int hp = u >> 2, skg = u & 3;
+      const int hr = hp / 18, hc = hp - hr * 18;
+      st_lds[s] = hp * 64 + (x3_slot(skg, hc) << 4);
+      st_g[s] = ((hr - 1) * HW + (hc - 1)) * KC + skg * 8;
+      st_rc[s] = (hr << 8) | hc;
+    }
   }
-  float4 sv[3][2];
-  auto stage_load = [&](const X3Job& J, int lit_, int chunk) {
+  float4 sv[NSLOT][2];      // (4 waves, rounds of SROUND slots: the compiler reuses the registers of a finished round)
+  auto stage_load = [&](const X3Job& J, int lit_, int chunk, int sa, int sb) {
     const int img = lit_ / RPI, rrem = lit_ % RPI;
     const int ry0 = (rrem / RPX) * 16, rx0 = (rrem % RPX) * 16;
     const float* base = J.in + ((size_t)img * HW * HW + (size_t)(ry0 * HW + rx0)) * KC + chunk * 32;
 #pragma unroll
-    for (int s = 0; s < 3; ++s) {
-      const int y = ry0 + (st_rc[s] >> 8) - 1, xx = rx0 + (st_rc[s] & 255) - 1;
+    for (int s = 0; s < NSLOT; ++s) {
+      if (s < sa || s >= sb) continue;
+      const int y = ry0 + (st_rc[IN_POOLED ? 0 : s] >> 8) - 1, xx = rx0 + (st_rc[IN_POOLED ? 0 : s] & 255) - 1;
       const bool ok = (unsigned)y < (unsigned)HW && (unsigned)xx < (unsigned)HW;
       sv[s][0] = make_float4(0.f, 0.f, 0.f, 0.f);
       sv[s][1] = sv[s][0];
       if (ok) {
-        sv[s][0] = *reinterpret_cast<const float4*>(base + st_g[s]);
-        sv[s][1] = *reinterpret_cast<const float4*>(base + st_g[s] + 4);
+        sv[s][0] = *reinterpret_cast<const float4*>(base + st_g[IN_POOLED ? 0 : s]);
+        sv[s][1] = *reinterpret_cast<const float4*>(base + st_g[IN_POOLED ? 0 : s] + 4);
       }
     }
   };
@@ -178,63 +189,78 @@ __global__ __launch_bounds__(512, 2) void conv_x3_kernel(const X3Jobs jt) {
     char* dst = smem + buf * X3_BUF;
     uint4 p0, p1, p2;
     split8(sv[s][0], sv[s][1], p0, p1, p2);
-    *reinterpret_cast<uint4*>(dst + st_lds[s]) = p0;
-    *reinterpret_cast<uint4*>(dst + X3_PLANE + st_lds[s]) = p1;
-    *reinterpret_cast<uint4*>(dst + 2 * X3_PLANE + st_lds[s]) = p2;
+    *reinterpret_cast<uint4*>(dst + st_lds[IN_POOLED ? 0 : s]) = p0;
+    *reinterpret_cast<uint4*>(dst + X3_PLANE + st_lds[IN_POOLED ? 0 : s]) = p1;
+    *reinterpret_cast<uint4*>(dst + 2 * X3_PLANE + st_lds[IN_POOLED ? 0 : s]) = p2;
   };
-  // ---- staging of a pooled tile (MaxPool backward): unit = (one of the 10 x 10 pooled pixels under the halo, 8 channels); threads
-  // 400 .. 511 repeat units 288 .. 399, and a window position outside the halo repeats the unit's position inside it (straight-line code)
-  const int pu = tid < 400 ? tid : tid - 112;
-  const int spp = pu >> 2, scg = pu & 3;
-  const int sprow = (spp * 205) >> 11, spcol = spp - sprow * 10;
-  int pl_lds[4], pl_pos[4];
+  // ---- staging of a pooled tile (MaxPool backward): unit = (one of the 10 x 10 pooled pixels under the halo, 8 channels); slots
+  // beyond the 400 units repeat units 288 .. 399, and a window position outside the halo repeats the unit's position inside it
+  int sprow[IN_POOLED ? NSLOT : 1], spcol[IN_POOLED ? NSLOT : 1], scg[IN_POOLED ? NSLOT : 1];
+  int pl_lds[IN_POOLED ? NSLOT : 1][4], pl_pos[IN_POOLED ? NSLOT : 1][4];
+  uint2 pidx[IN_POOLED ? NSLOT : 1];
+  if constexpr (IN_POOLED) {
 #pragma unroll
-  for (int pos = 0; pos < 4; ++pos) {
-    int hy = 2 * sprow - 1 + (pos >> 1), hx = 2 * spcol - 1 + (pos & 1);
-    hy = hy < 0 ? 0 : (hy > 17 ? 17 : hy);
-    hx = hx < 0 ? 0 : (hx > 17 ? 17 : hx);
-    pl_lds[pos] = (hy * 18 + hx) * 64 + (x3_slot(scg, hx) << 4);
-    pl_pos[pos] = (((hy + 1) & 1) << 1) | ((hx + 1) & 1);
+    for (int s = 0; s < NSLOT; ++s) {
+      int pu = tid + NTHR * s;
+      if (pu >= 400) pu -= NSLOT * NTHR - 400;
+      const int spp = pu >> 2;
+      scg[s] = pu & 3;
+      sprow[s] = (spp * 205) >> 11;
+      spcol[s] = spp - sprow[s] * 10;
+#pragma unroll
+      for (int pos = 0; pos < 4; ++pos) {
+        int hy = 2 * sprow[s] - 1 + (pos >> 1), hx = 2 * spcol[s] - 1 + (pos & 1);
+        hy = hy < 0 ? 0 : (hy > 17 ? 17 : hy);
+        hx = hx < 0 ? 0 : (hx > 17 ? 17 : hx);
+        pl_lds[s][pos] = (hy * 18 + hx) * 64 + (x3_slot(scg[s], hx) << 4);
+        pl_pos[s][pos] = (((hy + 1) & 1) << 1) | ((hx + 1) & 1);
+      }
+      pidx[s] = make_uint2(0u, 0u);
+    }
   }
-  uint2 pidx = make_uint2(0u, 0u);
-  auto pool_load = [&](const X3Job& J, int lit_, int chunk) {
+  auto pool_load = [&](const X3Job& J, int lit_, int chunk, int sa, int sb) {
     constexpr int HP = HW / 2;
     const int img = lit_ / RPI, rrem = lit_ % RPI;
-    const int pr = ((rrem / RPX) * 16) / 2 - 1 + sprow, pc = ((rrem % RPX) * 16) / 2 - 1 + spcol;
-    const bool ok = (unsigned)pr < (unsigned)HP && (unsigned)pc < (unsigned)HP;
-    sv[0][0] = make_float4(0.f, 0.f, 0.f, 0.f);      // (outside the image the gradient is zero: the scatter still overwrites the stale halo)
-    sv[0][1] = sv[0][0];
-    pidx = make_uint2(0u, 0u);
-    if (ok) {
-      const size_t o = (size_t)img * HP * HP + (size_t)(pr * HP + pc);
-      const float* v = J.in + o * KC + chunk * 32 + scg * 8;
-      sv[0][0] = *reinterpret_cast<const float4*>(v);
-      sv[0][1] = *reinterpret_cast<const float4*>(v + 4);
-      pidx = *reinterpret_cast<const uint2*>(J.in_idx + o * KC + chunk * 32 + scg * 8);
+#pragma unroll
+    for (int s = 0; s < NSLOT; ++s) {
+      if (s < sa || s >= sb) continue;
+      const int pr = ((rrem / RPX) * 16) / 2 - 1 + sprow[IN_POOLED ? s : 0], pc = ((rrem % RPX) * 16) / 2 - 1 + spcol[IN_POOLED ? s : 0];
+      const bool ok = (unsigned)pr < (unsigned)HP && (unsigned)pc < (unsigned)HP;
+      sv[s][0] = make_float4(0.f, 0.f, 0.f, 0.f);      // (outside the image the gradient is zero: the scatter still overwrites the stale halo)
+      sv[s][1] = sv[s][0];
+      pidx[IN_POOLED ? s : 0] = make_uint2(0u, 0u);
+      if (ok) {
+        const size_t o = (size_t)img * HP * HP + (size_t)(pr * HP + pc);
+        const float* v = J.in + o * KC + chunk * 32 + scg[IN_POOLED ? s : 0] * 8;
+        sv[s][0] = *reinterpret_cast<const float4*>(v);
+        sv[s][1] = *reinterpret_cast<const float4*>(v + 4);
+        pidx[IN_POOLED ? s : 0] = *reinterpret_cast<const uint2*>(J.in_idx + o * KC + chunk * 32 + scg[IN_POOLED ? s : 0] * 8);
+      }
     }
   };
-  auto pool_store = [&](int buf) {
+  auto pool_store = [&](int buf, int s) {
     uint4 q0, q1, q2;
-    split8(sv[0][0], sv[0][1], q0, q1, q2);
+    split8(sv[s][0], sv[s][1], q0, q1, q2);
     const unsigned a0[4] = {q0.x, q0.y, q0.z, q0.w}, a1[4] = {q1.x, q1.y, q1.z, q1.w}, a2[4] = {q2.x, q2.y, q2.z, q2.w};
+    const uint2 pix = pidx[IN_POOLED ? s : 0];
 #pragma unroll
     for (int pos = 0; pos < 4; ++pos) {
-      const unsigned ps = (unsigned)pl_pos[pos];
+      const unsigned ps = (unsigned)pl_pos[IN_POOLED ? s : 0][pos];
       unsigned m[4];
 #pragma unroll
       for (int d = 0; d < 4; ++d) {
-        const unsigned w = d < 2 ? pidx.x : pidx.y;
+        const unsigned w = d < 2 ? pix.x : pix.y;
         const unsigned b0 = (w >> (16 * (d & 1))) & 0xffu, b1 = (w >> (16 * (d & 1) + 8)) & 0xffu;
         m[d] = (b0 == ps ? 0x0000ffffu : 0u) | (b1 == ps ? 0xffff0000u : 0u);
       }
-      char* rec = smem + buf * X3_BUF + pl_lds[pos];
+      char* rec = smem + buf * X3_BUF + pl_lds[IN_POOLED ? s : 0][pos];
       *reinterpret_cast<uint4*>(rec) = make_uint4(a0[0] & m[0], a0[1] & m[1], a0[2] & m[2], a0[3] & m[3]);
       *reinterpret_cast<uint4*>(rec + X3_PLANE) = make_uint4(a1[0] & m[0], a1[1] & m[1], a1[2] & m[2], a1[3] & m[3]);
       *reinterpret_cast<uint4*>(rec + 2 * X3_PLANE) = make_uint4(a2[0] & m[0], a2[1] & m[1], a2[2] & m[2], a2[3] & m[3]);
     }
   };
-  // ---- the tile sequence of this workgroup: (item, chunk), chunk fastest.  Tile t + 1 is split and written into the other halo
-  // buffer while tile t is multiplied; the fp32 values of tile t + 2 are fetched right behind that (two tiles of latency cover).
+  // ---- the tile sequence of this workgroup: (item, chunk), chunk fastest.  Tile t + 1 is split and written while (8 waves) or after
+  // (4 waves) tile t is multiplied; the fp32 values of tile t + 2 are fetched right behind that (two tiles of latency cover).
   struct Tl { int item, chunk; };
   auto tl_next = [&](Tl t) {
     Tl r;
@@ -242,18 +268,31 @@ __global__ __launch_bounds__(512, 2) void conv_x3_kernel(const X3Jobs jt) {
     r.chunk = t.chunk + 1 < NCHUNK ? t.chunk + 1 : 0;
     return r;
   };
-  auto tile_load = [&](Tl t) {
+  auto tile_load = [&](Tl t, int sa = 0, int sb = 64) {
     if (t.item >= ir.end) return;
     const int j = job_of(jt, t.item);
-    if constexpr (IN_POOLED) pool_load(jt.job[j], t.item - jt.start[j], t.chunk);
-    else stage_load(jt.job[j], t.item - jt.start[j], t.chunk);
+    if constexpr (IN_POOLED) pool_load(jt.job[j], t.item - jt.start[j], t.chunk, sa, sb);
+    else stage_load(jt.job[j], t.item - jt.start[j], t.chunk, sa, sb);
   };
-  constexpr int NUNIT = IN_POOLED ? 1 : 3;
   auto tile_store_unit = [&](int buf, int u) {
-    if constexpr (IN_POOLED) pool_store(buf);
+    if constexpr (IN_POOLED) pool_store(buf, u);
     else stage_store_unit(buf, u);
   };
 
+  // 4 waves: a tile is fetched, split and written in rounds of SROUND slots (the staging registers of a round are reused by the next)
+  constexpr int SROUND = (!DB && !IN_POOLED && NC >= 64) ? 3 : NSLOT;
+  auto tile_fetch_write = [&](Tl t) {
+#pragma unroll
+    for (int r0 = 0; r0 < NSLOT; r0 += SROUND) {
+      tile_load(t, r0, r0 + SROUND);
+      __builtin_amdgcn_sched_barrier(0);
+#if !(UGN_X3_ABL & 2)
+#pragma unroll
+      for (int u = r0; u < r0 + SROUND && u < NSLOT; ++u) tile_store_unit(0, u);
+#endif
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
   // ---- the wave's filter fragments: [dy][plane] of one tap column (streamed), or [dx][dy][plane] of the whole chunk (RES)
   uint4 wr[RES ? 3 : 1][3][3];
   uint4 nb[RES ? 1 : 3][3];
@@ -279,8 +318,8 @@ __global__ __launch_bounds__(512, 2) void conv_x3_kernel(const X3Jobs jt) {
   Tl t_cur = {item, 0};
   tile_load(t_cur);
 #pragma unroll
-  for (int u = 0; u < NUNIT; ++u) tile_store_unit(0, u);
-  tile_load(tl_next(t_cur));
+  for (int u = 0; u < NSLOT; ++u) tile_store_unit(0, u);
+  if constexpr (DB) tile_load(tl_next(t_cur));
   int hbuf = 0;
 
   for (; item < ir.end; item += ir.stride) {
@@ -301,7 +340,7 @@ __global__ __launch_bounds__(512, 2) void conv_x3_kernel(const X3Jobs jt) {
     const int ry0 = (rrem / RPX) * 16, rx0 = (rrem % RPX) * 16;
     const int py0 = ry0 + mh * ROWS, ch0 = 16 * ng + 4 * kg;
     // LeakyReLU' operands of the first rows, fetched behind the last MFMAs (the rest in the epilogue)
-    constexpr int APF = EPI == EPI_DGRAD_ACT && ROWS <= 8 ? (IN_POOLED ? 2 : ROWS) : 0;      // (16 rows, pooled staging: no registers left)
+    constexpr int APF = EPI == EPI_DGRAD_ACT && ROWS <= 8 && DB ? (IN_POOLED ? 2 : ROWS) : 0;      // (where registers are left)
     float4 actv[APF > 0 ? APF : 1];
 
 #pragma unroll 1
@@ -312,7 +351,7 @@ __global__ __launch_bounds__(512, 2) void conv_x3_kernel(const X3Jobs jt) {
       const Tl t1 = tl_next(Tl{item, chunk});
       const bool have_t1 = t1.item < ir.end;
 #if !(UGN_X3_ABL & 16)
-      __syncthreads();                                      // the chunk's tile is complete; nobody reads the other buffer any more
+      __syncthreads();                                      // the chunk's tile is complete (8 waves: nobody reads the other buffer any more)
 #endif
 #pragma unroll
       for (int dx = 0; dx < 3; ++dx) {
@@ -326,7 +365,9 @@ __global__ __launch_bounds__(512, 2) void conv_x3_kernel(const X3Jobs jt) {
           if (dx < 2) load_col(jt.job[jb].wpk, chunk, dx + 1, nb);
           else load_col(jt.job[nx_job].wpk, n_chunk, 0, nb);
         }
-        if (dx == 1 && have_t1 && !(UGN_X3_ABL & 8)) tile_load(tl_next(t1));     // the fp32 values of the tile after next (its registers are free again)
+        if constexpr (DB) {
+          if (dx == 1 && have_t1 && !(UGN_X3_ABL & 8)) tile_load(tl_next(t1));     // the fp32 values of the tile after next (registers free again)
+        }
         if constexpr (APF > 0) {
           if (dx == 2 && last_chunk) {
             const float* act = jt.job[jb].act + (size_t)img * HW * HW * NC + ch0;
@@ -348,20 +389,6 @@ __global__ __launch_bounds__(512, 2) void conv_x3_kernel(const X3Jobs jt) {
           }
           __builtin_amdgcn_sched_barrier(0);
           int nmf = 0;
-#if UGN_X3_ORDER == 1
-          // product-major: consecutive MFMAs go to DIFFERENT accumulators (the row's three taps), an accumulator recurs every third MFMA
-#pragma unroll
-          for (int i = 0; i < kProducts; ++i)
-#pragma unroll
-            for (int dy = 0; dy < 3; ++dy) {
-              const int m = j - dy;
-              if (m >= 0 && m < ROWS) {
-                nmf += 1;
-                if constexpr (RES) acc[m] = mfma_bf(wr[dx][dy][prod_w(i)], fa[j & 1][prod_x(i)], acc[m]);
-                else acc[m] = mfma_bf(cb[dy][prod_w(i)], fa[j & 1][prod_x(i)], acc[m]);
-              }
-            }
-#else
 #pragma unroll
           for (int dy = 0; dy < 3; ++dy) {
             const int m = j - dy;
@@ -379,28 +406,39 @@ __global__ __launch_bounds__(512, 2) void conv_x3_kernel(const X3Jobs jt) {
               }
             }
           }
-#endif
-          // the next tile's units are split and written behind the MFMAs of rows 1, 1 + ROWS / 4, ... of the FIRST column, their
-          // vector instructions interleaved with the matrix ones (one MFMA, three VALU, ...)
-          constexpr int USTEP = ROWS / 4;
-          if (dx == 0 && j >= 1 && (j - 1) % USTEP == 0 && (j - 1) / USTEP < NUNIT) {
+          // 8 waves: the next tile's units are split and written behind the MFMAs of rows 1, 1 + ROWS / 4, ... of the FIRST column,
+          // their vector instructions interleaved with the matrix ones (one MFMA, four VALU, ...)
+          if constexpr (DB) {
+            constexpr int USTEP = ROWS / 4;
+            if (dx == 0 && j >= 1 && (j - 1) % USTEP == 0 && (j - 1) / USTEP < NSLOT) {
 #if !(UGN_X3_ABL & 2)
-            tile_store_unit(hbuf ^ 1, (j - 1) / USTEP);      // (no tile after this one: stale values into the idle buffer)
+              tile_store_unit(hbuf ^ 1, (j - 1) / USTEP);      // (no tile after this one: stale values into the idle buffer)
 #endif
-#if UGN_X3_SGB > 0
 #pragma unroll
-            for (int k = 0; k < 18; ++k) {
-              if (k < nmf) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-              __builtin_amdgcn_sched_group_barrier(0x002, UGN_X3_SGB, 0);
+              for (int k = 0; k < 18; ++k) {
+                if (k < nmf) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+              }
             }
-#endif
           }
           __builtin_amdgcn_sched_barrier(0);
         }
       }
-      hbuf ^= 1;
+      if constexpr (DB) {
+        hbuf ^= 1;
 #pragma unroll
-      for (int dx = 0; dx < 3; ++dx) ab[dx] += hbuf ? X3_BUF : -X3_BUF;
+        for (int dx = 0; dx < 3; ++dx) ab[dx] += hbuf ? X3_BUF : -X3_BUF;
+      } else {
+        // 4 waves: everybody has finished reading the tile -> fetch, split and write the next one into the same buffer (the other
+        // workgroup of the CU multiplies meanwhile; no staging register lives through the MFMA loop).  Behind the LAST chunk the
+        // fetch is issued before the epilogue and the split follows it.
+        __syncthreads();
+        if (!last_chunk) tile_fetch_write(t1);
+      }
+    }
+    if constexpr (!DB && SROUND == NSLOT) {
+      if (more) tile_load(Tl{next_item, 0});
+      __builtin_amdgcn_sched_barrier(0);
     }
 
 #if UGN_X3_ABL & 4
@@ -469,6 +507,15 @@ __global__ __launch_bounds__(512, 2) void conv_x3_kernel(const X3Jobs jt) {
       }
     }
     }
+    if constexpr (!DB && SROUND == NSLOT) {
+#if !(UGN_X3_ABL & 2)
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < NSLOT; ++u) tile_store_unit(0, u);      // (no next item: stale values into a buffer nobody reads)
+#endif
+    } else if constexpr (!DB) {
+      if (more) tile_fetch_write(Tl{next_item, 0});
+    }
     jb = jn;
     lit = nlit;
   }
@@ -487,14 +534,30 @@ inline int make_table(X3Jobs& jt, const X3Job* jobs, const int* n, int njobs, in
   return total;
 }
 
+// 4-wave form (two workgroups per CU) for the launches with <= 64 output columns, 8-wave form for 128 (a wave would own two column
+// tiles: 128 accumulator registers beside 144 of filter fragments)
+#ifndef UGN_X3_W4
+#define UGN_X3_W4 1
+#endif
+template <int KC, int NC, int EPI, int IN_POOLED>
+constexpr int x3_waves() {
+  if (!UGN_X3_W4 || NC > 64) return 8;
+  // (64 columns: 16 rows per wave = 64 accumulator registers; with the pooling epilogue, or four K chunks of streamed filters, the
+  //  4-wave form spills 40-50 registers)
+  if (NC == 64 && !IN_POOLED && (EPI == EPI_LRELU_POOL || KC > 64)) return 8;
+  return 4;
+}
+
 template <int KC, int NC, int HW, int EPI, int IN_POOLED>
 int launch_x3(const X3Job* jobs, const int* n, int njobs, hipStream_t stream) {
+  constexpr int WAVES = x3_waves<KC, NC, EPI, IN_POOLED>();
+  constexpr int LDS = WAVES == 8 ? X3_LDS : X3_BUF;
   static bool attr = false;
-  auto* kern = conv_x3_kernel<KC, NC, HW, EPI, IN_POOLED>;
+  auto* kern = conv_x3_kernel<KC, NC, HW, EPI, IN_POOLED, WAVES>;
   if (!attr) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     if (e != hipSuccess) {
-      ugn_set_error("conv_x3_kernel: cannot reserve %d bytes of LDS: %s", X3_LDS, hipGetErrorString(e));
+      ugn_set_error("conv_x3_kernel: cannot reserve %d bytes of LDS: %s", LDS, hipGetErrorString(e));
       return (int)e;
     }
     attr = true;
@@ -502,7 +565,7 @@ int launch_x3(const X3Job* jobs, const int* n, int njobs, hipStream_t stream) {
   X3Jobs jt;
   const int total = make_table(jt, jobs, n, njobs, (HW / 16) * (HW / 16));
   if (total == 0) return 0;
-  hipLaunchKernelGGL(kern, dim3(g_grid), dim3(512), X3_LDS, stream, jt);
+  hipLaunchKernelGGL(kern, dim3(g_grid * (8 / WAVES)), dim3(64 * WAVES), LDS, stream, jt);
   UGN_CHECK_LAUNCH("conv_x3_kernel");
   return 0;
 }

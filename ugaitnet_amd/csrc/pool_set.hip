@@ -147,6 +147,102 @@ __global__ __launch_bounds__(128) void setmax_bwd_kernel(const SetmaxJobs jt, in
     }
 }
 
+// ---- set pooling with ROUTING WORDS (round 5; the fp32 twin of h2_elem.hip's routed kernels) -------------------------------
+// reduce_max's gradient needs, per (clip, pixel, channel), WHICH of the l frames hold the maximum (TF splits the gradient evenly among
+// them) and, for the LeakyReLU' that follows, which are positive: 2 x l bits, for which setmax_bwd_kernel reads all l frames again
+// (4 l bytes per set element).  The forward pass writes them as two u32 words per element -- route[b][s4][2] as uint4: word k of
+// channel c = bit t set iff frame t holds the maximum (k = 0) / is positive (k = 1) -- while it streams the frames anyway (one
+// pass: a frame above the running maximum restarts the mask, an equal one joins it), and the gradient reads those 8 bytes INSTEAD of
+// the frames.  Bit-identical to setmax_fwd_kernel / setmax_bwd_kernel (tests/test_kernels_gpu.py::test_setmax_routed).
+struct RouteJobs {
+  const float4* p[kPoolJobs];        // fwd: frames
+  const float4* addend[kPoolJobs];   // fwd: optional [b,s]; bwd: optional second gradient path [b,l,s]
+  const float4* dm[kPoolJobs];       // bwd
+  float4* m[kPoolJobs];              // fwd: maxima; bwd: out
+  float4* sum_out[kPoolJobs];
+  uint4* route[kPoolJobs];
+  int b[kPoolJobs];
+};
+__device__ __forceinline__ void route_step(float v, float& mx, unsigned& mask, unsigned& pos, unsigned bit) {
+  mask = v > mx ? bit : (v == mx ? mask | bit : mask);
+  mx = fmaxf(mx, v);
+  pos |= v > 0.f ? bit : 0u;
+}
+__global__ __launch_bounds__(128) void setmax_fwd_routed_kernel(const RouteJobs jt, int l, size_t s4) {
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = blockIdx.z, b = blockIdx.y;
+  if (e >= s4 || b >= jt.b[j]) return;
+  const float4* src = jt.p[j] + (size_t)b * l * s4 + e;
+  float4 mx = src[0];
+  uint4 mask = make_uint4(1u, 1u, 1u, 1u);
+  uint4 pos = make_uint4(mx.x > 0.f ? 1u : 0u, mx.y > 0.f ? 1u : 0u, mx.z > 0.f ? 1u : 0u, mx.w > 0.f ? 1u : 0u);
+  int t = 1;
+  for (; t + 6 <= l; t += 6) {    // six independent 16-byte loads in flight per lane (L = 25: 1 + 4 x 6)
+    float4 v[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) v[k] = src[(size_t)(t + k) * s4];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      const unsigned bit = 1u << (t + k);
+      route_step(v[k].x, mx.x, mask.x, pos.x, bit);
+      route_step(v[k].y, mx.y, mask.y, pos.y, bit);
+      route_step(v[k].z, mx.z, mask.z, pos.z, bit);
+      route_step(v[k].w, mx.w, mask.w, pos.w, bit);
+    }
+  }
+  for (; t < l; ++t) {
+    const float4 v = src[(size_t)t * s4];
+    const unsigned bit = 1u << t;
+    route_step(v.x, mx.x, mask.x, pos.x, bit);
+    route_step(v.y, mx.y, mask.y, pos.y, bit);
+    route_step(v.z, mx.z, mask.z, pos.z, bit);
+    route_step(v.w, mx.w, mask.w, pos.w, bit);
+  }
+  jt.m[j][(size_t)b * s4 + e] = mx;
+  uint4* r = jt.route[j] + ((size_t)b * s4 + e) * 2;
+  r[0] = mask;
+  r[1] = pos;
+  if (jt.addend[j]) {
+    const float4 a = jt.addend[j][(size_t)b * s4 + e];
+    jt.sum_out[j][(size_t)b * s4 + e] = make_float4(mx.x + a.x, mx.y + a.y, mx.z + a.z, mx.w + a.w);
+  }
+}
+__device__ __forceinline__ float route_out(unsigned mask, unsigned pos, unsigned bit, float g, float add, int lrelu) {
+  float o = ((mask & bit) ? g : 0.f) + add;
+  if (lrelu) o *= (pos & bit) ? 1.f : UGN_LRELU_ALPHA;
+  return o;
+}
+__global__ __launch_bounds__(128) void setmax_bwd_routed_kernel(const RouteJobs jt, int l, size_t s4, int lrelu) {
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = blockIdx.z, b = blockIdx.y;
+  if (e >= s4 || b >= jt.b[j]) return;
+  const uint4* r = jt.route[j] + ((size_t)b * s4 + e) * 2;
+  const uint4 mask = r[0], pos = r[1];
+  const float4 g = jt.dm[j][(size_t)b * s4 + e];
+  // (the division setmax_bwd_kernel does: gradient / number of maxima, counted as a float there -- same quotient)
+  const float4 gs = make_float4(g.x / (float)__popc(mask.x), g.y / (float)__popc(mask.y), g.z / (float)__popc(mask.z), g.w / (float)__popc(mask.w));
+  const float4* asrc = jt.addend[j] ? jt.addend[j] + (size_t)b * l * s4 + e : nullptr;
+  float4* dst = jt.m[j] + (size_t)b * l * s4 + e;
+  int t = 0;
+  for (; t + 4 <= l; t += 4) {
+    float4 a[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) a[k] = asrc ? asrc[(size_t)(t + k) * s4] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const unsigned bit = 1u << (t + k);
+      dst[(size_t)(t + k) * s4] = make_float4(route_out(mask.x, pos.x, bit, gs.x, a[k].x, lrelu), route_out(mask.y, pos.y, bit, gs.y, a[k].y, lrelu),
+                                              route_out(mask.z, pos.z, bit, gs.z, a[k].z, lrelu), route_out(mask.w, pos.w, bit, gs.w, a[k].w, lrelu));
+    }
+  }
+  for (; t < l; ++t) {
+    const float4 a = asrc ? asrc[(size_t)t * s4] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const unsigned bit = 1u << t;
+    dst[(size_t)t * s4] = make_float4(route_out(mask.x, pos.x, bit, gs.x, a.x, lrelu), route_out(mask.y, pos.y, bit, gs.y, a.y, lrelu),
+                                      route_out(mask.z, pos.z, bit, gs.z, a.z, lrelu), route_out(mask.w, pos.w, bit, gs.w, a.w, lrelu));
+  }
+}
+
 // ---- HPP ------------------------------------------------------------------------------------------------
 // feature rows: for bins in {1,2,4,8,16}: a's strips then s3's strips.  Row offsets of the a-part per level:
 __device__ __constant__ int kHppOff[5] = {0, 2, 6, 14, 30};
@@ -374,6 +470,45 @@ extern "C" int ugn_setmax_bwd_multi(const float* const* p, const float* const* d
   hipLaunchKernelGGL(setmax_bwd_kernel, dim3((unsigned)((s4 + 127) / 128), bmax, njobs), dim3(128), 0, (hipStream_t)stream, jt, l,
                      s4, apply_lrelu);
   UGN_CHECK_LAUNCH("setmax_bwd");
+  return 0;
+}
+
+extern "C" int ugn_setmax_fwd_routed_multi(const float* const* p, const float* const* addend, float* const* m, float* const* sum_out,
+                                           uint32_t* const* route, const int* b, int njobs, int l, size_t s, void* stream) {
+  UGN_REQUIRE(p && m && route && b && njobs >= 1 && njobs <= kPoolJobs, "ugn_setmax_fwd_routed_multi: bad arguments (1..%d jobs)", kPoolJobs);
+  UGN_REQUIRE(l > 0 && l <= 32 && s > 0 && s % 4 == 0, "ugn_setmax_fwd_routed_multi: s must be a multiple of 4, l in 1..32 (one bit per frame)");
+  RouteJobs jt = {};
+  int bmax = 0;
+  for (int j = 0; j < njobs; ++j) {
+    UGN_REQUIRE(p[j] && m[j] && route[j] && b[j] > 0, "ugn_setmax_fwd_routed_multi: null pointer or b <= 0 in job %d", j);
+    const float* ad = addend ? addend[j] : nullptr;
+    UGN_REQUIRE(!ad || (sum_out && sum_out[j]), "ugn_setmax_fwd_routed_multi: addend needs sum_out");
+    jt.p[j] = (const float4*)p[j]; jt.addend[j] = (const float4*)ad; jt.m[j] = (float4*)m[j];
+    jt.sum_out[j] = ad ? (float4*)sum_out[j] : nullptr; jt.route[j] = (uint4*)route[j]; jt.b[j] = b[j];
+    if (b[j] > bmax) bmax = b[j];
+  }
+  const size_t s4 = s / 4;
+  hipLaunchKernelGGL(setmax_fwd_routed_kernel, dim3((unsigned)((s4 + 127) / 128), bmax, njobs), dim3(128), 0, (hipStream_t)stream, jt, l, s4);
+  UGN_CHECK_LAUNCH("setmax_fwd_routed");
+  return 0;
+}
+
+extern "C" int ugn_setmax_bwd_routed_multi(const uint32_t* const* route, const float* const* dm, const float* const* addend,
+                                           float* const* out, const int* b, int njobs, int l, size_t s, int apply_lrelu, void* stream) {
+  UGN_REQUIRE(route && dm && out && b && njobs >= 1 && njobs <= kPoolJobs, "ugn_setmax_bwd_routed_multi: bad arguments (1..%d jobs)", kPoolJobs);
+  UGN_REQUIRE(l > 0 && l <= 32 && s > 0 && s % 4 == 0, "ugn_setmax_bwd_routed_multi: s must be a multiple of 4, l in 1..32");
+  RouteJobs jt = {};
+  int bmax = 0;
+  for (int j = 0; j < njobs; ++j) {
+    UGN_REQUIRE(route[j] && dm[j] && out[j] && b[j] > 0, "ugn_setmax_bwd_routed_multi: null pointer or b <= 0 in job %d", j);
+    jt.route[j] = (uint4*)route[j]; jt.dm[j] = (const float4*)dm[j]; jt.addend[j] = (const float4*)(addend ? addend[j] : nullptr);
+    jt.m[j] = (float4*)out[j]; jt.b[j] = b[j];
+    if (b[j] > bmax) bmax = b[j];
+  }
+  const size_t s4 = s / 4;
+  hipLaunchKernelGGL(setmax_bwd_routed_kernel, dim3((unsigned)((s4 + 127) / 128), bmax, njobs), dim3(128), 0, (hipStream_t)stream, jt, l,
+                     s4, apply_lrelu);
+  UGN_CHECK_LAUNCH("setmax_bwd_routed");
   return 0;
 }
 

@@ -36,16 +36,17 @@ CONV_SPECS = (
 NBINS, FEAT, HIDDEN = 62, 128, 256
 
 # Arithmetic of the 3x3 layers when a model does not name one (GaitCore(conv_precision=...), UGN_CONV_PRECISION):
-#   "h2"  (default) activations / gradients between the 3x3 layers as split-fp16 halves + block exponent (22 significant bits),
-#         3x3 layers as direct convolutions on the f16 matrix pipe: holds every fp32 parity bar of tests/ and is 1.4x faster
-#   "f32x3" IEEE fp32 tensors everywhere; the 3x3 layers multiply them on the bf16 matrix pipe through the exact three-way bf16
+#   "h2"  activations / gradients between the 3x3 layers as split-fp16 halves + ONE block exponent per tensor (22 significant bits),
+#         3x3 layers as direct convolutions on the f16 matrix pipe: holds the fp32 parity bars of tests/ and is the fastest set, but
+#         it is narrower than the reference's fp32 and a clip's result depends on its batch-mates -- opt-in since round 5
+#   "f32x3" (default) IEEE fp32 tensors everywhere; the 3x3 layers multiply them on the bf16 matrix pipe through the exact three-way bf16
 #         split of both operands (six partial products per fp32 product, fp32 accumulate: csrc/x3_common.h) -- fp32-grade results
 #         with no storage format, block exponent or dependence on the other clips of a batch
 #   "f32" IEEE fp32 tensors, Winograd F(2x2,3x3) on the fp32 MFMA
 #   "bf16" BASELINE configs[4]: bf16 activations / gradients / saved tensors in HBM, direct convolutions on the bf16 matrix pipe,
 #         fp32 accumulate, fp32 master weights and Adam (engine_bf.py)
 #   "bf16w" (round 1-2) fp32 tensors, Winograd with bf16-rounded MFMA operands
-DEFAULT_PRECISION = os.environ.get("UGN_CONV_PRECISION", "h2")
+DEFAULT_PRECISION = os.environ.get("UGN_CONV_PRECISION", "f32x3")
 # Arithmetic of forward-only queries behind the Keras surface (model.predict, get_layer(...).output taps, UWYHSemiNet.encode):
 # UGN_GATE_NORM_FUSED=0: the gate / fMerge and the batch normalisation as two launches each way (rounds 1-3; same results)
 GATE_NORM_FUSED = os.environ.get("UGN_GATE_NORM_FUSED", "1") != "0"
@@ -147,6 +148,9 @@ HEAD_SIDE = os.environ.get("UGN_HEAD_SIDE", "1") == "1"
 # UGN_ROUTED=1: form the set-max gradient inside the a3 / a5 data-gradient epilogues instead of materialising it with
 # setmax_bwd (bit-identical; measured 2.5 % SLOWER on MI355X: three operand loads per element make those epilogues spill).
 ROUTED = USE_WINOGRAD and os.environ.get("UGN_ROUTED", "0") == "1"
+# UGN_SET_ROUTED=0: the set-pooling gradients of the fp32-tensor paths find the maximum frames by reading the frames again (rounds 1-4;
+# same results); default: the forward pass writes routing words and the gradients read those (csrc/pool_set.hip, merged path, l <= 32)
+SET_ROUTED_F32 = os.environ.get("UGN_SET_ROUTED", "1") != "0"
 
 
 def glorot_uniform(gen, shape):
@@ -491,7 +495,16 @@ def forward_merged(encs, xs):
                       [B(e, e.act, "i2", (g[2], 32, 32, 32), U8) for e, g in zip(encs, geo)])
     bs, l0 = [g[0] for g in geo], geo[0][1]
     assert all(g[1] == l0 for g in geo), "the modalities of a batch share the set length"
-    m1s = ops.setmax_fwd_multi(p2s, bs, l0, [B(e, e.act, "m1", (g[0], 32, 32, 32)) for e, g in zip(encs, geo)])
+    routed = SET_ROUTED_F32 and l0 <= 32
+    RW = lambda key, hw, c: [B(e, e.act, key, (g[0], hw * hw * c // 4, 2, 4), torch.int32) for e, g in zip(encs, geo)]
+
+    def setmax(key, ps, ms, hw, c, addends=None, sum_outs=None):
+        if routed:
+            return ops.setmax_fwd_routed_multi(ps, bs, l0, ms, RW(key, hw, c), addends=addends, sum_outs=sum_outs)
+        for e in encs:
+            e.act.pop(key, None)
+        return ops.setmax_fwd_multi(ps, bs, l0, ms, addends=addends, sum_outs=sum_outs)
+    m1s = setmax("r1", p2s, [B(e, e.act, "m1", (g[0], 32, 32, 32)) for e, g in zip(encs, geo)], 32, 32)
 
     def pair_layer(na, nb, xa, xb, cout, hw, pool, ka, kb, ia=None, ib=None):
         """frame-level layer `na` on xa and set-level twin `nb` on xb, all modalities: jobs = [frame..., set...]"""
@@ -508,12 +521,12 @@ def forward_merged(encs, xs):
 
     a3s, b1s = pair_layer("a3", "b1", p2s, m1s, 64, 32, False, "a3", "b1")
     p4s, q2s = pair_layer("a4", "b2", a3s, b1s, 64, 32, True, "p4", "q2", "i4", "j2")
-    _, s2s = ops.setmax_fwd_multi(p4s, bs, l0, [B(e, e.act, "m2", (g[0], 16, 16, 64)) for e, g in zip(encs, geo)], addends=q2s,
-                                  sum_outs=[B(e, e.act, "s2", (g[0], 16, 16, 64)) for e, g in zip(encs, geo)])
+    _, s2s = setmax("r2", p4s, [B(e, e.act, "m2", (g[0], 16, 16, 64)) for e, g in zip(encs, geo)], 16, 64, addends=q2s,
+                    sum_outs=[B(e, e.act, "s2", (g[0], 16, 16, 64)) for e, g in zip(encs, geo)])
     a5s, b3s = pair_layer("a5", "b3", p4s, s2s, 128, 16, False, "a5", "b3")
     a6s, b4s = pair_layer("a6", "b4", a5s, b3s, 128, 16, False, "a6", "b4")
-    m3s, s3s = ops.setmax_fwd_multi(a6s, bs, l0, [B(e, e.act, "m3", (g[0], 16, 16, 128)) for e, g in zip(encs, geo)], addends=b4s,
-                                    sum_outs=[B(e, e.act, "s3", (g[0], 16, 16, 128)) for e, g in zip(encs, geo)])
+    m3s, s3s = setmax("r3", a6s, [B(e, e.act, "m3", (g[0], 16, 16, 128)) for e, g in zip(encs, geo)], 16, 128, addends=b4s,
+                      sum_outs=[B(e, e.act, "s3", (g[0], 16, 16, 128)) for e, g in zip(encs, geo)])
     feats = ops.hpp_fwd_multi(m3s, s3s, [B(e, e.act, "feat", (NBINS, g[0], FEAT)) for e, g in zip(encs, geo)])
     return ops.binfc_fwd_multi(feats, [e.W("fc") for e in encs], [B(e, e.act, "out", (NBINS, g[0], HIDDEN)) for e, g in zip(encs, geo)])
 
@@ -532,7 +545,12 @@ def backward_merged(encs, douts, scratches):
                                     [buf(i, "dfeat", (NBINS, geo[i][0], FEAT)) for i in R])
     dm3, dzb4 = ops.hpp_bwd_multi([a["m3"] for a in A], [a["s3"] for a in A], [a["b4"] for a in A], dfeats,
                                   [buf(i, "dm3", (geo[i][0], 16, 16, 128)) for i in R], [buf(i, "dzb4", (geo[i][0], 16, 16, 128)) for i in R])
-    dz6 = ops.setmax_bwd_multi([a["a6"] for a in A], dm3, bs, l0, True, [buf(i, "dz6", (geo[i][2], 16, 16, 128)) for i in R])
+    def setmax_bwd(rkey, pkey, dms, outs, addends=None):
+        """reduce_max's gradient (+ addend) * LeakyReLU'(p): from the forward pass's routing words where it wrote them"""
+        if all(rkey in a for a in A):
+            return ops.setmax_bwd_routed_multi([a[rkey] for a in A], dms, bs, l0, True, outs, addends=addends)
+        return ops.setmax_bwd_multi([a[pkey] for a in A], dms, bs, l0, True, outs, addends=addends)
+    dz6 = setmax_bwd("r3", "a6", dm3, [buf(i, "dz6", (geo[i][2], 16, 16, 128)) for i in R])
 
     def wgrad(na, nb, xa, xb, dza, dzb, cout, ia=None, ib=None):
         with _side(dev):
@@ -554,7 +572,7 @@ def backward_merged(encs, douts, scratches):
     raw4, ds2 = dgrad("a5", "b3", dz5, dzb3, 16, 64, 128, [buf(i, "g4", (geo[i][2], 16, 16, 64)) for i in R],
                       [buf(i, "ds2", (geo[i][0], 16, 16, 64)) for i in R])
     dq2 = ops.lrelu_bwd_multi(ds2, [a["q2"] for a in A], [buf(i, "dq2", (geo[i][0], 16, 16, 64)) for i in R])
-    dp4 = ops.setmax_bwd_multi([a["p4"] for a in A], ds2, bs, l0, True, raw4, addends=raw4)
+    dp4 = setmax_bwd("r2", "p4", ds2, raw4, addends=raw4)
     # block 2 (a3, a4) with block 1 of the global branch (b1, b2); a4 / b2 are pooled
     i4, j2 = [a["i4"] for a in A], [a["j2"] for a in A]
     wgrad("a4", "b2", [a["a3"] for a in A], [a["b1"] for a in A], dp4, dq2, 64, i4, j2)
@@ -563,7 +581,7 @@ def backward_merged(encs, douts, scratches):
     wgrad("a3", "b1", [a["p2"] for a in A], [a["m1"] for a in A], dz3, dzb1, 64)
     raw2, dm1 = dgrad("a3", "b1", dz3, dzb1, 32, 32, 64, [buf(i, "g2", (geo[i][2], 32, 32, 32)) for i in R],
                       [buf(i, "dm1", (geo[i][0], 32, 32, 32)) for i in R])
-    dp2 = ops.setmax_bwd_multi([a["p2"] for a in A], dm1, bs, l0, True, raw2, addends=raw2)
+    dp2 = setmax_bwd("r1", "p2", dm1, raw2, addends=raw2)
     # block 1 (a1, a2)
     i2 = [a["i2"] for a in A]
     with _side(dev):

@@ -183,7 +183,7 @@ class GaitSetModel:
                              # encoder work is skipped -- same outputs and gradients, 1.5x the clips/s on the 7-pattern masks
                              # (bench.py's headline computes those pairs; `value_skip_masked` is this mode).  UGN_SKIP_MASKED=0: dense
                              skip_masked=os.environ.get("UGN_SKIP_MASKED", "1") != "0",
-                             conv_precision=None)      # engine.DEFAULT_PRECISION (UGN_CONV_PRECISION; "h2")
+                             conv_precision=None)      # engine.DEFAULT_PRECISION (UGN_CONV_PRECISION; "f32x3")
         if world > 1:  # replicas start from identical weights (MirroredStrategy semantics)
             self.core.join_pack()
             torch.distributed.broadcast(self.core.store.flat, src=0)

@@ -413,6 +413,33 @@ def setmax_bwd_multi(ps, dms, bs, l, apply_lrelu, outs, addends=None):
     return outs
 
 
+def setmax_fwd_routed_multi(ps, bs, l, ms, routes, addends=None, sum_outs=None):
+    """setmax_fwd_multi that also writes the routing words (int32 [b, s/4, 2, 4]) the routed gradient reads instead of the frames."""
+    for t in list(ps) + list(ms):
+        _chk(t)
+    for r in routes:
+        _chk(r, torch.int32)
+    s = ps[0].numel() // (bs[0] * l)
+    nb = sum(4.0 * s * b * (l + 3 + (2 if addends is not None else 0)) for b in bs)
+    call("ugn_setmax_fwd_routed_multi", ptr_array(ps), _opt_ptr_array(addends), ptr_array(ms), _opt_ptr_array(sum_outs), ptr_array(routes),
+         _int_array(bs), len(ps), l, s, _stream(), label="setmax_fwd_routed[%s x %d x %d]" % ("+".join(str(b) for b in bs), l, s),
+         work=_hbm_work("setmax_fwd_routed_kernel", nb))
+    return (ms, sum_outs) if addends is not None else ms
+
+
+def setmax_bwd_routed_multi(routes, dms, bs, l, apply_lrelu, outs, addends=None):
+    """setmax_bwd_multi from the routing words: 4 l (+ 4 l with an addend) + 12 bytes per set element instead of 8 l (+ 4 l) + 4."""
+    for t in list(dms) + list(outs):
+        _chk(t)
+    s = outs[0].numel() // (bs[0] * l)
+    nb = sum(4.0 * s * b * (l + 3 + (l if addends is not None else 0)) for b in bs)
+    call("ugn_setmax_bwd_routed_multi", ptr_array(routes), ptr_array(dms), _opt_ptr_array(addends), ptr_array(outs), _int_array(bs), len(outs),
+         l, s, int(bool(apply_lrelu)), _stream(),
+         label="setmax_bwd_routed[%s x %d x %d%s]" % ("+".join(str(b) for b in bs), l, s, " +addend" if addends is not None else ""),
+         work=_hbm_work("setmax_bwd_routed_kernel", nb))
+    return outs
+
+
 def lrelu_bwd_multi(gs, acts, outs):
     for t in list(gs) + list(acts) + list(outs):
         _chk(t)
