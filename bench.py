@@ -191,7 +191,7 @@ def roofline_pass(core, batch, steps, dtype, table_path=""):
     taken AFTER the timed region; returns the roofline object of the kernel with the largest total duration."""
     import torch
     from ugaitnet_amd import _lib, engine
-    with engine.serial_launches():
+    with core.serial_launches():
         core.train_step(*batch)            # un-timed: first step on the one-stream schedule
         torch.cuda.synchronize()
         _lib.PROFILE, _lib.WORK = {}, {}
@@ -381,7 +381,7 @@ def run(args):
             dt = float(t.item())
         return dt
 
-    ctx = engine.serial_launches() if args.serial else None
+    ctx = core.serial_launches() if args.serial else None
     if ctx:
         ctx.__enter__()
     if use_dist:      # per-collective event pairs during the timed steps (warm-up included: divided by all steps run)
@@ -436,7 +436,7 @@ def run(args):
             except Exception:
                 rccl = None
             dist_info = dict(backend=dist.get_backend(), world_size=dist.get_world_size(), rccl_version=rccl,
-                             allreduce="bucketed, overlapped with backward" if engine.AR_OVERLAP else "one call after backward",
+                             allreduce="bucketed, overlapped with backward" if engine.DEFAULTS.ar_overlap else "one call after backward",
                              gradient_bytes=grad_bytes, collectives_ms_per_step=coll_ms)
         fpc = flop_per_clip(kinds)
         exec_factor = EXEC_FACTOR[args.dtype]

@@ -93,8 +93,8 @@ int ugn_conv3x3_dgrad_wino_pair(const float* const* dz, const uint8_t* const* dz
 /* The same for up to 6 convolutions of one shape in a single launch (arrays of length njobs): the three modality encoders
  * of nets/mj_uwyhNets_ba.py:1102-1140 are the same ten layer shapes, so a 3-modality step issues ONE launch per layer for the
  * frame-level convolutions of all modalities and their set-level twins.  Items of all jobs form one list that the
- * persistent workgroups stride over; a job's filter slices stay resident in LDS across its items where they fit.  bf16 != 0
- * selects the bf16-operand kernels (see below).  Rules for act / addend / raw_out / dz_idx as in the pair form. */
+ * persistent workgroups stride over; a job's filter slices stay resident in LDS across its items where they fit.  bf16 must be 0
+ * (the bf16-operand Winograd kernels of rounds 1-4 are retired: UGN_EINVAL).  Rules for act / addend / raw_out / dz_idx as in the pair form. */
 int ugn_conv3x3_fwd_wino_multi(const float* const* in, const float* const* u_packed, float* const* out,
                                uint8_t* const* out_idx, const int* n, int njobs, int hw, int cin, int cout, int pool, int bf16,
                                void* stream);
@@ -102,20 +102,6 @@ int ugn_conv3x3_dgrad_wino_multi(const float* const* dz, const uint8_t* const* d
                                  const float* const* act, const float* const* addend, float* const* out,
                                  float* const* raw_out, const int* n, int njobs, int hw, int cin, int cout, int bf16,
                                  void* stream);
-/* bf16-operand variants (BASELINE.json configs[4] / SURVEY 8(d) "C5": bf16 operands in the MFMA, fp32 accumulate): same
- * arguments, tensors stay fp32 in HBM; the Winograd-domain operands are rounded to bf16 (round to nearest even) and multiplied
- * on v_mfma_f32_16x16x16_bf16.  u_packed must come from ugn_wino_pack with 4 added to `dgrad` (bf16 elements, first half of
- * the buffer).  The data gradient supports the plain epilogue and `act` (no addend / raw_out). */
-int ugn_conv3x3_fwd_wino_bf16(const float* in, const float* u_packed, float* out, uint8_t* out_idx, int n, int hw, int cin,
-                              int cout, int pool, void* stream);
-int ugn_conv3x3_dgrad_wino_bf16(const float* dz, const uint8_t* dz_idx, const float* u_packed, const float* act,
-                                const float* addend, float* out, float* raw_out, int n, int hw, int cin, int cout,
-                                void* stream);
-int ugn_conv3x3_fwd_wino_pair_bf16(const float* const* in, const float* const* u_packed, float* const* out,
-                                   uint8_t* const* out_idx, const int* n, int hw, int cin, int cout, int pool, void* stream);
-int ugn_conv3x3_dgrad_wino_pair_bf16(const float* const* dz, const uint8_t* const* dz_idx, const float* const* u_packed,
-                                     const float* const* act, const float* const* addend, float* const* out,
-                                     float* const* raw_out, const int* n, int hw, int cin, int cout, void* stream);
 /* Data gradient whose addend is the set-max gradient of the layer's output (the Add of the two gradient paths into p2 / p4,
  * nets/mj_uwyhNets_ba.py:435,451): out = (dgrad + ((act == smax_m[clip]) ? smax_g[clip] : 0)) * LeakyReLU'(act), clip =
  * image / frames; smax_m [n/frames,hw,hw,cin] = the set maxima (ugn_setmax_fwd_cnt), smax_g = dL/dm / #maxima (ugn_div of
@@ -138,15 +124,6 @@ int ugn_conv3x3_wgrad_wino_pair(const float* const* in, const float* const* dz, 
 int ugn_conv3x3_wgrad_wino_multi(const float* const* in, const float* const* dz, const uint8_t* const* dz_idx,
                                  float* const* dw, const int* n, int njobs, int hw, int cin, int cout, void* ws,
                                  size_t ws_bytes, int bf16, void* stream);
-
-/* bf16-operand weight gradient (see ugn_conv3x3_fwd_wino_bf16): the transformed inputs and output gradients of 16 tiles are
- * rounded to bf16 and contracted by one v_mfma_f32_16x16x16_bf16 per Winograd point; fp32 accumulate, fp32 tensors, same
- * workspace (the 32 -> 32 layer at 64x64 has 8 tiles per wave and region: half of the MFMA's k-slots stay empty). */
-int ugn_conv3x3_wgrad_wino_bf16(const float* in, const float* dz, const uint8_t* dz_idx, float* dw, int n, int hw, int cin,
-                                int cout, void* ws, size_t ws_bytes, void* stream);
-int ugn_conv3x3_wgrad_wino_pair_bf16(const float* const* in, const float* const* dz, const uint8_t* const* dz_idx,
-                                     float* const* dw, const int* n, int hw, int cin, int cout, void* ws, size_t ws_bytes,
-                                     void* stream);
 
 /* ---- set pooling over the L frames: tf.math.reduce_max(x, axis=1), nets/mj_uwyhNets_ba.py:435,451,463 ----
  * p [b,l,s] -> m [b,s]; if addend != NULL also sum_out = m + addend (the Add layers :452,:465). */

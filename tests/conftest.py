@@ -54,6 +54,7 @@ def _oracle_ahead(request):
             if M.WORKLOAD[n] not in wanted:
                 wanted.append(M.WORKLOAD[n])
             M.LAST_SELECTED[M.WORKLOAD[n]] = n
+        M.DEFER_FORCED = any("forced_to_the_hip_routing" in item.nodeid for item in request.session.items)
         M.PREFETCH.start(wanted)
     yield
     if cases and torch.cuda.is_available():

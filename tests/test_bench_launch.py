@@ -82,38 +82,41 @@ def test_rccl_path_with_one_rank(dev):
 
 @pytest.mark.gpu
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("dtype", ["h2", "f32"])
+@pytest.mark.parametrize("dtype", ["f32x3", "h2", "f32"])
 def test_roofline_object_of_the_default_command(dev, tmp_path, dtype):
     """The bench line's roofline: dominant kernel by total duration of the serialised pass, fraction of peak on EXECUTED matrix
     FLOPs (<= 1) against the peak of the instruction that executes them, the algorithmic rate beside it, HBM-bound rows priced in
-    bytes; --kernel-table writes every row.  h2 is what the bare command runs (dtype f16x2); f32 is the Winograd line."""
+    bytes; --kernel-table writes every row.  f32x3 is what the bare command runs (fp32 tensors, three-way bf16 split: `dtype` starts
+    with f32); h2 is the f16x2 line, f32 the Winograd fp32-MFMA line."""
     table = str(tmp_path / "ktable.csv")
     r = subprocess.run([sys.executable, BENCH, "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--dense-only", "--clips-per-gpu",
-                        "8", "--kernel-table", table] + ([] if dtype == "h2" else ["--dtype", dtype]),
+                        "8", "--kernel-table", table] + ([] if dtype == "f32x3" else ["--dtype", dtype]),
                        env=_env(), capture_output=True, text=True, timeout=800)
     assert r.returncode == 0, r.stderr[-3000:]
     d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
     roof = d["roofline"]
     assert d["dtype"].startswith("f16x2" if dtype == "h2" else "f32")
-    if dtype == "h2":
+    if dtype in ("h2", "f32x3"):
         # both roofs are priced; `bound` names the one whose floor (executed FLOPs / 2516.8 TFLOP/s, algorithmic bytes / 8 TB/s) is higher
         assert roof["bound"] in ("mfma", "hbm") and 0 < roof["mfma_frac"] <= 1.0 and 0 < roof["hbm_frac"] <= 1.0
         assert (roof["bound"] == "mfma") == (roof["mfma_floor_us"] >= roof["hbm_floor_us"])
         assert roof["frac"] == (roof["mfma_frac"] if roof["bound"] == "mfma" else roof["hbm_frac"])
         assert (roof["unit"], roof["peak"]) == (("TFLOP/s", 2516.8) if roof["bound"] == "mfma" else ("GB/s", 8000.0))
-        # three f16 MFMAs per product; the pooled weight gradients on the sparse pipe execute half of them
-        assert min(abs(roof["mfma_tflops"] / roof["algorithmic_tflops"] - r) for r in (3.0, 1.5)) < 0.01
+        # h2: three f16 MFMAs per product (the pooled weight gradients on the sparse pipe execute half of them); x3: six bf16 MFMAs
+        ratios = (3.0, 1.5) if dtype == "h2" else (6.0,)
+        assert min(abs(roof["mfma_tflops"] / roof["algorithmic_tflops"] - r) for r in ratios) < 0.01
     else:
         assert roof["bound"] == "mfma" and roof["unit"] == "TFLOP/s" and roof["peak"] == 157.3
         assert abs(roof["achieved"] / roof["algorithmic_tflops"] - 16.0 / 36.0) < 0.01     # Winograd: 16/36 of the direct count
     assert 0.05 < roof["frac"] <= 1.0 and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3
-    names = ("_mm_kernel", "conv_mm16_kernel", "conv_nr_kernel", "conv_d2_kernel", "conv32_d2p_kernel") if dtype == "h2" else ("wino",)
-    assert roof["kernel"].startswith("conv3x3_") and any(n in roof["rocprof_kernel"] for n in names)
+    names = {"h2": ("_mm_kernel", "conv_mm16_kernel", "conv_nr_kernel", "conv_d2_kernel", "conv32_d2p_kernel"), "f32": ("wino",),
+             "f32x3": ("conv_x3_kernel", "wgrad_x3_kernel")}[dtype]
+    assert "conv3x3_" in roof["kernel"] and any(n in roof["rocprof_kernel"] for n in names)
     assert roof["launches_per_step"] >= 1
     assert roof["avg_us"] > 0 and 0 < roof["share_of_step"] < 0.5 and roof["serial_step_us"] > 0
     kinds = {k.get("bound") for k in roof["other_kernels"]}
     assert "mfma" in kinds and all(k.get("frac", 0) <= 1.0 for k in roof["other_kernels"] if k.get("bound") in ("mfma", "hbm"))
-    assert "value_f32" not in d       # (--dense-only: the named arithmetic only)
+    assert "value_f32_mfma" not in d and "value_h2" not in d       # (--dense-only: the named arithmetic only)
     rows = open(table).read().splitlines()
     assert rows[0].startswith("label,launches_per_step") and len(rows) > 25
     assert any("setmax_fwd" in ln and ",hbm," in ln for ln in rows)
@@ -122,16 +125,20 @@ def test_roofline_object_of_the_default_command(dev, tmp_path, dtype):
 
 @pytest.mark.gpu
 @pytest.mark.timeout(900)
-def test_fp32_line_beside_the_default_line(dev):
-    """the bare command times the IEEE-fp32 path (BASELINE configs[1..3] say fp32; the reference computes in fp32,
-    nets/mj_uwyhNets_ba.py:428-462) for the same steps / warm-up after the default f16x2 run and reports it BESIDE `value`."""
+def test_other_fp32_class_lines_beside_the_headline(dev):
+    """The bare command's `value` is the fp32-tensor arithmetic the product trains in (BASELINE configs[1..3] say fp32; the reference
+    computes in fp32, nets/mj_uwyhNets_ba.py:428-462); the same job -- batch, weights, steps, warm-up -- is then timed on the Winograd
+    fp32-MFMA kernels and in the f16x2 arithmetic and reported BESIDE it, never as `value`."""
     r = subprocess.run([sys.executable, BENCH, "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--clips-per-gpu", "8"],
                        env=_env(), capture_output=True, text=True, timeout=800)
     assert r.returncode == 0, r.stderr[-3000:]
     d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
-    assert d["dtype"].startswith("f16x2") and d["dtype_f32"].startswith("f32")
-    assert d["value_f32"] > 0 and d["ms_per_step_f32"] > 0 and abs(d["value_f32"] * d["ms_per_step_f32"] / 1e3 - 8) < 0.05
-    rf = d["roofline_f32"]
+    assert d["dtype"].startswith("f32") and "three-way bf16 split" in d["dtype"]
+    assert d["dtype_f32_mfma"].startswith("f32") and "v_mfma_f32_16x16x4_f32" in d["dtype_f32_mfma"] and d["dtype_h2"].startswith("f16x2")
+    for tag in ("f32_mfma", "h2"):
+        assert d["value_" + tag] > 0 and abs(d["value_" + tag] * d["ms_per_step_" + tag] / 1e3 - 8) < 0.05
+        assert abs(d["loss_" + tag] - d["loss"]) < 1e-3      # the same job: same batch, same initial weights, same number of steps
+    rf = d["roofline_f32_mfma"]
     assert rf["bound"] == "mfma" and rf["peak"] == 157.3 and 0.05 < rf["frac"] <= 1.0 and "wino" in rf["rocprof_kernel"]
-    assert abs(d["loss_f32"] - d["loss"]) < 1e-3      # the same job: same batch, same initial weights, same number of steps
+    assert d["roofline_h2"]["peak"] in (2516.8, 8000.0)
     assert d["value"] > 0 and "value_skip_masked" in d

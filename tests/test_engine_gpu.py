@@ -34,20 +34,34 @@ def oracle_params(kinds, nclasses, seed=5):
     return p
 
 
-# "f32": the Winograd fp32-MFMA kernels; "h2": activations / gradients as split-fp16 halves, 3x3 layers on the f16 matrix pipe
-# (ugaitnet_amd/engine_h2.py).  Both are held to the SAME bars: the H2 path claims fp32-class arithmetic.
+# "f32x3" (the default): fp32 tensors, 3x3 products through the exact three-way bf16 split on the bf16 matrix pipe; "f32": fp32 tensors,
+# Winograd on the fp32 MFMA; "h2": activations / gradients as split-fp16 halves, 3x3 layers on the f16 matrix pipe
+# (ugaitnet_amd/engine_h2.py).  All three are held to the SAME bars.
 PRECISIONS = ["f32x3", "f32", "h2"]
 
+# the fp64 oracle of a test case is evaluated once per session and shared by the precisions (it depends on the inputs only)
+_ORACLE = {}
 
-@pytest.mark.parametrize("prec", PRECISIONS)
-@pytest.mark.parametrize("mode", ["sign_max", "max", "avg"])
+
+def oracle_step(key, *args, **kw):
+    if key not in _ORACLE:
+        _ORACLE[key] = O.model_loss_and_grads(*args, **kw)
+    return _ORACLE[key]
+
+
+SMALL3 = {"sign_max": (8, 4, 4), "max": (6, 3, 3), "avg": (6, 3, 3)}      # (clips, frames, identities) of the three-modality cases
+
+
+# every fusion mode in the default arithmetic; the reference's own fusion (sign_max) in all three
+@pytest.mark.parametrize("mode,prec", [("sign_max", "f32x3"), ("max", "f32x3"), ("avg", "f32x3"), ("sign_max", "f32"), ("sign_max", "h2")])
 def test_three_modalities_forward_backward(dev, mode, prec):
-    kinds, b, l, ncls = ('of', 'gray', 'depth'), 8, 4, 10
-    xs, uses, labels, onehot = make_batch(kinds, b, l, ncls, ids=4, seed=1)
+    # (8 clips x 4 frames for the reference's fusion; the two other fusion modes share the encoders: 6 x 3, a third of the oracle's time)
+    kinds, (b, l, ids), ncls = ('of', 'gray', 'depth'), SMALL3[mode], 10
+    xs, uses, labels, onehot = make_batch(kinds, b, l, ncls, ids=ids, seed=1)
     p64 = oracle_params(kinds, ncls)
     core = build(kinds, ncls, mode, p64, conv_precision=prec)
-    r, g = O.model_loss_and_grads([x.astype(np.float64) for x in xs], [u.astype(np.float64) for u in uses], labels,
-                                  onehot.astype(np.float64), p64, margin=0.2, loss_weights=(1.0, 0.1), mode=mode)
+    r, g = oracle_step(("three", mode), [x.astype(np.float64) for x in xs], [u.astype(np.float64) for u in uses], labels,
+                       onehot.astype(np.float64), p64, margin=0.2, loss_weights=(1.0, 0.1), mode=mode)
     core.forward_backward(xs, uses, labels, onehot)
     torch.cuda.synchronize()
     sig = core.sig.cpu().numpy()
@@ -73,12 +87,14 @@ def test_three_modalities_forward_backward(dev, mode, prec):
     #  columns are small and amplify rounding, as for the signature above: 5e-4 instead of 5e-5 with the routing forced)
     # (the census + forced evaluation runs for sign_max, the reference's fusion; max / avg share the encoders and their flips and keep
     #  a flat 1e-2: measured with the routing forced -- avg 2e-6, max 4e-5 / 1.5e-4, its small batch-axis norms amplify rounding)
+    # (the census + forced evaluation also runs in the default arithmetic only: the Winograd and f16x2 sets keep the flat 1e-2 here and
+    #  their forced-routing checks in test_branch_gradients_with_the_hip_paths_routing / tests/test_fullsize_parity_gpu.py)
     R.check_gradients(core, g, xs, uses, labels, onehot, p64, tight=2e-3, mode=mode, label="%s/%s" % (mode, prec),
-                      loose=None if mode == 'sign_max' else 1e-2)
+                      loose=None if (mode == 'sign_max' and prec == 'f32x3') else 1e-2)
 
 
-@pytest.mark.parametrize("prec", PRECISIONS)
-@pytest.mark.parametrize("b,l,ids", [(2, 1, 1), (3, 5, 3), (6, 7, 2)])
+@pytest.mark.parametrize("b,l,ids,prec", [(2, 1, 1, "f32x3"), (3, 5, 3, "f32x3"), (4, 6, 2, "f32x3"), (2, 1, 1, "f32"), (3, 5, 3, "f32"),
+                                          (2, 1, 1, "h2"), (3, 5, 3, "h2")])
 def test_ragged_batches_and_set_lengths(dev, b, l, ids, prec):
     """Edge shapes: a single frame per clip (set-max over one element), odd clip counts and set lengths, a batch that
     fills only a few of the persistent workgroups, identities with a single sample (no positive pair besides itself)."""
@@ -86,8 +102,8 @@ def test_ragged_batches_and_set_lengths(dev, b, l, ids, prec):
     xs, uses, labels, onehot = make_batch(kinds, b, l, ncls, ids=ids, seed=40 + b)
     p64 = oracle_params(kinds, ncls)
     core = build(kinds, ncls, "sign_max", p64, conv_precision=prec)
-    r, g = O.model_loss_and_grads([x.astype(np.float64) for x in xs], [u.astype(np.float64) for u in uses], labels,
-                                  onehot.astype(np.float64), p64, margin=0.2, loss_weights=(1.0, 0.1), mode="sign_max")
+    r, g = oracle_step(("ragged", b, l, ids), [x.astype(np.float64) for x in xs], [u.astype(np.float64) for u in uses], labels,
+                       onehot.astype(np.float64), p64, margin=0.2, loss_weights=(1.0, 0.1), mode="sign_max")
     core.forward_backward(xs, uses, labels, onehot)
     torch.cuda.synchronize()
     for enc, ref in zip(core.encoders, r['outs']):
@@ -133,8 +149,8 @@ def test_single_modality_graph(dev, prec):
     xs, uses, labels, onehot = make_batch(kinds, b, l, ncls, ids=3, seed=2)
     p64 = oracle_params(kinds, ncls)
     core = build(kinds, ncls, 'sign_max', p64, multimodal=False, conv_precision=prec)
-    r, g = O.model_loss_and_grads([xs[0].astype(np.float64)], None, labels, onehot.astype(np.float64), p64, margin=0.2,
-                                  loss_weights=(1.0, 0.1), multimodal=False)
+    r, g = oracle_step(("single",), [xs[0].astype(np.float64)], None, labels, onehot.astype(np.float64), p64, margin=0.2,
+                       loss_weights=(1.0, 0.1), multimodal=False)
     core.forward_backward(xs, None, labels, onehot)
     assert relmax(core.sig.cpu().numpy(), r['signature']) <= 2e-5
     ls = core.losses()
@@ -151,46 +167,52 @@ def test_two_modalities_train_steps_track_oracle(dev, prec):
     and three steps keep the loss on the oracle's trajectory."""
     kinds, b, l, ncls = ('of', 'gray'), 6, 3, 8
     xs, uses, labels, onehot = make_batch(kinds, b, l, ncls, ids=3, seed=3)
-    p64 = oracle_params(kinds, ncls)
     p0 = oracle_params(kinds, ncls)
-    core = build(kinds, ncls, 'sign_max', p64, lr=1e-3, conv_precision=prec)
-    keys = [('branches', mi, k) for mi in range(2) for k in sorted(p64['branches'][mi])] + [('head', None, k) for k in ('bc', 'wc')]
+    core = build(kinds, ncls, 'sign_max', p0, lr=1e-3, conv_precision=prec)
+    keys = [('branches', mi, k) for mi in range(2) for k in sorted(p0['branches'][mi])] + [('head', None, k) for k in ('bc', 'wc')]
     get = lambda p, key: p['head'][key[2]] if key[0] == 'head' else p['branches'][key[1]][key[2]]
-    ms = {key: np.zeros_like(get(p64, key)) for key in keys}
-    vs = {key: np.zeros_like(get(p64, key)) for key in keys}
-    x64 = [x.astype(np.float64) for x in xs]
-    u64 = [u.astype(np.float64) for u in uses]
-    for t in (1, 2, 3):
-        r, g = O.model_loss_and_grads(x64, u64, labels, onehot.astype(np.float64), p64, margin=0.2, loss_weights=(1.0, 0.1))
-        for key in keys:
-            O.adam_step(get(p64, key), get(g, key), ms[key], vs[key], t, lr=1e-3)
+    if "train" not in _ORACLE:      # the oracle's three steps: once per session, shared by the precisions
+        p64 = oracle_params(kinds, ncls)
+        ms = {key: np.zeros_like(get(p64, key)) for key in keys}
+        vs = {key: np.zeros_like(get(p64, key)) for key in keys}
+        x64 = [x.astype(np.float64) for x in xs]
+        u64 = [u.astype(np.float64) for u in uses]
+        traj = []
+        for t in (1, 2, 3):
+            r, g = O.model_loss_and_grads(x64, u64, labels, onehot.astype(np.float64), p64, margin=0.2, loss_weights=(1.0, 0.1))
+            for key in keys:
+                O.adam_step(get(p64, key), get(g, key), ms[key], vs[key], t, lr=1e-3)
+            traj.append(dict(loss=float(r['loss']), g=g if t == 1 else None,
+                             p_after={key: get(p64, key).copy() for key in keys} if t == 1 else None))
+        _ORACLE["train"] = traj
+    for t, step in zip((1, 2, 3), _ORACLE["train"]):
         core.train_step(xs, uses, labels, onehot)
-        assert abs(core.losses()['loss'] - float(r['loss'])) <= 2e-2 * max(1.0, abs(float(r['loss'])))
+        assert abs(core.losses()['loss'] - step['loss']) <= 2e-2 * max(1.0, abs(step['loss']))
         if t == 1:
             got = core.get_params_numpy()
             for key in keys:
-                gk = get(g, key)
+                gk = get(step['g'], key)
                 solid = np.abs(gk) > 1e-2 * np.abs(gk).max()   # update saturated at lr*sign(g): immune to routing flips
-                d_ref = (get(p64, key) - get(p0, key))[solid]
+                d_ref = (step['p_after'][key] - get(p0, key))[solid]
                 d_got = (get(got, key).astype(np.float64) - get(p0, key))[solid]
                 assert np.abs(d_got - d_ref).max() <= 5e-5, (key, np.abs(d_got - d_ref).max())   # |update| ~ 1e-3
 
 
-@pytest.mark.parametrize("bfmode", ["bf16", "bf16w"])
+@pytest.mark.parametrize("bfmode", ["bf16"])
 def test_bf16_operand_mode_against_the_oracle(dev, bfmode):
-    """BASELINE configs[4] arithmetic -- "bf16": bf16 tensors in HBM + bf16 MFMA + fp32 accumulate (engine_bf.py); "bf16w": the
-    round 1-2 form (fp32 tensors, Winograd with bf16-rounded operands): same graph, same oracle, tolerances of an 8-bit significand -- encoder outputs and signatures 2e-2 of their
+    """BASELINE configs[4] arithmetic -- "bf16": bf16 tensors in HBM + bf16 MFMA + fp32 accumulate (engine_bf.py) (the round 1-2 form
+    "bf16w", fp32 tensors with bf16-rounded Winograd operands, is retired): same graph, same oracle, tolerances of an 8-bit significand -- encoder outputs and signatures 2e-2 of their
     scale, losses 5e-2 relative, gradients 2e-1 relative L2 (argmax flips of the pooling layers move whole routing decisions
     at this precision) -- and demonstrably NOT the fp32 path.  The element-wise comparison uses the smooth 'avg' fusion;
     under sign_max a near-tie between two modalities flips the selected one (and possibly the sign), so there only the
     fraction of such elements is bounded."""
-    kinds, b, l, ncls = ('of', 'gray', 'depth'), 8, 4, 10
-    xs, uses, labels, onehot = make_batch(kinds, b, l, ncls, ids=4, seed=1)
+    kinds, (b, l, ids), ncls = ('of', 'gray', 'depth'), SMALL3['avg'], 10        # (the 'avg' case of the test above: one oracle evaluation)
+    xs, uses, labels, onehot = make_batch(kinds, b, l, ncls, ids=ids, seed=1)
     p64 = oracle_params(kinds, ncls)
     x64, u64 = [x.astype(np.float64) for x in xs], [u.astype(np.float64) for u in uses]
     core = build(kinds, ncls, 'avg', p64, conv_precision=bfmode)
     ref32 = build(kinds, ncls, 'avg', p64, conv_precision='f32')
-    r, g = O.model_loss_and_grads(x64, u64, labels, onehot.astype(np.float64), p64, margin=0.2, loss_weights=(1.0, 0.1), mode='avg')
+    r, g = oracle_step(("three", "avg"), x64, u64, labels, onehot.astype(np.float64), p64, margin=0.2, loss_weights=(1.0, 0.1), mode='avg')
     core.forward_backward(xs, uses, labels, onehot)
     ref32.forward_backward(xs, uses, labels, onehot)
     torch.cuda.synchronize()
@@ -221,8 +243,9 @@ def test_bf16_operand_mode_against_the_oracle(dev, bfmode):
     assert np.isfinite(core.losses()['loss'])
     if r is not None:
         assert (np.abs(core.sig.cpu().numpy() - r['signature']) > 5e-2).mean() < 0.05
-    with pytest.raises(ValueError):
-        build(kinds, ncls, 'sign_max', p64, conv_precision='fp8')
+    for retired in ('fp8', 'bf16w'):
+        with pytest.raises(ValueError):
+            build(kinds, ncls, 'sign_max', p64, conv_precision=retired)
 
 
 @pytest.mark.parametrize("prec,bar_out,bar_grad,bar_med", [("bf16", 1e-2, 3e-1, 1e-1), ("h2", 2e-6, 1e-1, 1e-3)])
@@ -256,10 +279,10 @@ def test_branch_gradients_with_a_fixed_cotangent(dev, prec, bar_out, bar_grad, b
     if prec == "h2":
         core.meta_pool.reset()
         outs = engine_h2.forward_h2(core.encoders, xg)
-        engine_h2.backward_h2(core.encoders, [torch.from_numpy(d.astype(np.float32)).to(core.device) for d in douts], engine._side)
+        engine_h2.backward_h2(core.encoders, [torch.from_numpy(d.astype(np.float32)).to(core.device) for d in douts], core.launch.side)
     else:
         outs = engine_bf.forward_bf(core.encoders, xg)
-        engine_bf.backward_bf(core.encoders, [torch.from_numpy(d.astype(np.float32)).to(core.device) for d in douts], engine._side)
+        engine_bf.backward_bf(core.encoders, [torch.from_numpy(d.astype(np.float32)).to(core.device) for d in douts], core.launch.side)
     torch.cuda.synchronize()
     got = core.get_grads_numpy()
     worst, eo = {}, []
@@ -364,12 +387,12 @@ def test_branch_gradients_with_the_hip_paths_routing(dev, prec, bar, bar_med):
     if prec == "h2":
         core.meta_pool.reset()
         engine_h2.forward_h2(core.encoders, xg)
-        engine_h2.backward_h2(core.encoders, dg, engine._side)
+        engine_h2.backward_h2(core.encoders, dg, core.launch.side)
         state = lambda e: e.h2
         vals = lambda t: t.numpy()
     else:
         engine_bf.forward_bf(core.encoders, xg)
-        engine_bf.backward_bf(core.encoders, dg, engine._side)
+        engine_bf.backward_bf(core.encoders, dg, core.launch.side)
         state = lambda e: e.bf
         vals = lambda t: BF.to_numpy(t)
     torch.cuda.synchronize()
@@ -396,17 +419,16 @@ def test_branch_gradients_with_the_hip_paths_routing(dev, prec, bar, bar_med):
     assert max(worst.values()) <= bar and med <= bar_med, worst
 
 
-def test_fused_first_layer_weight_gradient(dev, monkeypatch):
-    """UGN_FUSE_W5=1 (engine_h2.FUSE_W5): the data gradient of the pooled 32 -> 32 layer fused with the 5x5 layer's weight gradient
+def test_fused_first_layer_weight_gradient(dev):
+    """UGN_FUSE_W5=1 (Settings.fuse_w5): the data gradient of the pooled 32 -> 32 layer fused with the 5x5 layer's weight gradient
     (ugn_mm_dgrad32_wgrad5_multi) gives the first layer the gradient the two separate launches give it."""
-    from ugaitnet_amd import engine_h2
+    from ugaitnet_amd import engine
     kinds, b, l, ncls = ('of', 'gray', 'depth'), 6, 4, 10
     xs, uses, labels, onehot = make_batch(kinds, b, l, ncls, ids=3, seed=4)
     p64 = oracle_params(kinds, ncls)
     grads = []
     for fuse in (False, True):
-        monkeypatch.setattr(engine_h2, "FUSE_W5", fuse)
-        core = build(kinds, ncls, 'sign_max', p64, conv_precision='h2')
+        core = build(kinds, ncls, 'sign_max', p64, conv_precision='h2', config=engine.DEFAULTS.replace(fuse_w5=fuse))
         core.forward_backward(xs, uses, labels, onehot)
         torch.cuda.synchronize()
         grads.append(core.get_grads_numpy())
@@ -415,6 +437,46 @@ def test_fused_first_layer_weight_gradient(dev, monkeypatch):
         assert rell2(got, ref) <= 2e-6, (mi, rell2(got, ref))
         for k in ('a2', 'a3', 'fc'):     # everything else is computed by the same launches: bit-identical
             assert np.array_equal(grads[0]['branches'][mi][k], grads[1]['branches'][mi][k]), (mi, k)
+
+
+def test_two_cores_with_different_settings_in_one_process(dev):
+    """Settings are per core (ugaitnet_amd/config.py), not import-time globals: a core on the direct fp32 kernels with every launch on
+    one stream, a core on the Winograd kernels with side streams, and a default (f32x3) core serialised through `serial_launches()`,
+    alive and stepping alternately in ONE process, each give bit for bit what a process of its own gives (the same cores run alone,
+    one after the other, in a fresh interpreter each would: here, freshly built cores stepped without interleaving)."""
+    from ugaitnet_amd import engine
+    kinds, b, l, ncls = ('of', 'gray', 'depth'), 4, 3, 6
+    xs, uses, labels, onehot = make_batch(kinds, b, l, ncls, ids=2, seed=9)
+    p64 = oracle_params(kinds, ncls)
+    specs = [dict(conv_precision='f32', config=engine.DEFAULTS.replace(use_winograd=False, wgrad_stream=False, fwd_streams=0, merge_modalities=False)),
+             dict(conv_precision='f32', config=engine.DEFAULTS.replace(wgrad_stream=True, set_routed=False)),
+             dict(conv_precision='f32x3', config=engine.DEFAULTS.replace(head_side=False))]
+
+    def run_alone(spec, serial):
+        core = build(kinds, ncls, 'sign_max', p64, lr=1e-3, **spec)
+        for _ in range(3):
+            if serial:
+                with core.serial_launches():
+                    core.train_step(xs, uses, labels, onehot)
+            else:
+                core.train_step(xs, uses, labels, onehot)
+        torch.cuda.synchronize()
+        return core.store.flat.cpu().numpy().copy()
+    alone = [run_alone(s, i == 2) for i, s in enumerate(specs)]
+    cores = [build(kinds, ncls, 'sign_max', p64, lr=1e-3, **s) for s in specs]
+    assert cores[0].cfg is not cores[1].cfg and not cores[0].cfg.use_winograd and cores[1].cfg.use_winograd and cores[2].x3
+    for _ in range(3):            # interleaved: every core sees the others' launches between its own steps
+        cores[0].train_step(xs, uses, labels, onehot)
+        cores[1].train_step(xs, uses, labels, onehot)
+        with cores[2].serial_launches():
+            assert cores[1].cfg.wgrad_stream and not cores[2].cfg.wgrad_stream          # serialising one core leaves the others alone
+            cores[2].train_step(xs, uses, labels, onehot)
+        assert cores[2].cfg.wgrad_stream
+    torch.cuda.synchronize()
+    for i, core in enumerate(cores):
+        assert np.array_equal(core.store.flat.cpu().numpy(), alone[i]), "core %d differs from the same core run alone" % i
+    # the three arithmetics / launch shapes agree to rounding, and are not the same computation
+    assert 0 < np.abs(alone[0] - alone[1]).max() < 1e-2 and 0 < np.abs(alone[1] - alone[2]).max() < 1e-2
 
 
 def test_h2_path_properties(dev):

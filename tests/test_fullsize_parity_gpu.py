@@ -7,10 +7,12 @@ these sizes).
 C5 (configs[4]: C4's modalities, 16 clips per GPU, bf16 MFMA operands) runs the same comparison with the bf16 mode's bars.
 Bars: loss <= 1e-4, signature <= 1e-3 (north_star's tolerance; observed ~1e-5), active-triplet counts equal up to hinges that
 sit within fp32 rounding of zero (C3: exact; C4 has 744k hinges per step: at most 1 per bin, 3 in all), every parameter
-gradient <= 5e-3 relative L2 WITH the routing census beside it (round 4): every MaxPool / set-max / HPP / sign_max decision of the
-step is compared with the fp64 oracle's, the flips are counted per family and each one is proven a near-tie (tests/routing.py); with
-no flip the bar is 1e-4, and on the headline workload (C3, f16x2) the oracle is also forced to the HIP path's routing: 5e-5.
-The fp64 oracle is evaluated ONCE per workload (the f32 and the f16x2 case share it)."""
+gradient WITH the routing census beside it (round 4): every MaxPool / set-max / HPP / LeakyReLU / sign_max decision of the step is
+compared with the fp64 oracle's, the flips are counted per family and each one is proven a near-tie (tests/routing.py); with no flip
+the gradient bar is 1e-4 relative L2, with flips (20-50 of 6e8 decisions at these sizes; a single re-routed decision moves a tensor
+by up to 6e-3) 1e-2, and on the headline workload and arithmetic (C3, f32x3) the oracle is also FORCED to the HIP path's routing: 5e-5.
+Cases: C2 / C3 / C4 in the default arithmetic (f32x3: fp32 tensors, three-way bf16 split), C3w = C3 on the Winograd fp32-MFMA
+kernels, C3h2 = the f16x2 tensors (its CASIA-shaped case C4h2 can be named on the command line: not in the default list), C5 = bf16.  The fp64 oracle is evaluated ONCE per workload (its cases share it)."""
 import atexit
 import os
 import pickle
@@ -40,8 +42,9 @@ CASES = {
     # BASELINE.json configs[1] / SURVEY "C2": BL-single gray, 24 clips = 12 ids x 2, 150 classes -- the single-modality graph
     # (no gate, no normalisation: nets/mj_uwyhNets_ba.py:893-903) at its full size
     "C2": dict(kinds=("gray",), b=24, ids=12, ncls=150, multimodal=False),
-    # the same steps with the 3x3 layers on the f16 matrix pipe (H2 tensors, ugaitnet_amd/engine_h2.py) at the fp32 bars
-    "C2h2": dict(kinds=("gray",), b=24, ids=12, ncls=150, multimodal=False, precision="h2"),
+    # C3 on the Winograd fp32-MFMA kernels (conv_precision="f32"), and the steps with the 3x3 layers on the f16 matrix pipe (H2
+    # tensors, ugaitnet_amd/engine_h2.py) at the fp32 bars
+    "C3w": dict(kinds=("of", "gray", "depth"), b=24, ids=12, ncls=150, precision="f32"),
     "C3h2": dict(kinds=("of", "gray", "depth"), b=24, ids=12, ncls=150, precision="h2"),
     "C4h2": dict(kinds=("of", "gray", "sil"), b=40, ids=4, ncls=74, precision="h2"),
 }
@@ -57,7 +60,7 @@ def _rell2(a, b):
 # the tests in a child process (tests/conftest.py starts it at session start and moves this module's tests to the end of the
 # session): while the other GPU tests run, the first workloads are evaluated; at most MAX_AHEAD finished entries are held (an entry is
 # up to ~11 GB: inputs, gradients and every routing decision of the step with its gap).
-WORKLOAD = {"C2": "C2", "C2h2": "C2", "C3": "C3", "C3h2": "C3", "C4": "C4", "C4h2": "C4", "C5": "C5"}
+WORKLOAD = {"C2": "C2", "C3": "C3", "C3w": "C3", "C3h2": "C3", "C4": "C4", "C4h2": "C4", "C5": "C5"}
 MAX_AHEAD = 3
 
 
@@ -153,7 +156,7 @@ def _worker(outdir, wanted):
 
 
 PREFETCH = _Prefetch()
-LAST_CASE = {"C2": "C2h2", "C3": "C3h2", "C4": "C4h2", "C5": "C5"}      # the case after which a workload's entry is dropped
+LAST_CASE = {"C2": "C2", "C3": "C3h2", "C4": "C4", "C5": "C5"}      # the case after which a workload's entry is dropped
 
 
 # the decisions of a step may differ from the fp64 oracle's only at near-ties: the oracle's value at the HIP path's choice within
@@ -164,7 +167,8 @@ NEAR_TIE = 8
 
 # cases of one workload are adjacent: the oracle is evaluated once per workload
 @pytest.mark.timeout(1500)
-@pytest.mark.parametrize("name", ["C2", "C2h2", "C3", "C3h2", "C4", "C4h2", "C5"])
+# (C3 first: its forced-routing evaluation -- 66 s of fp64 on the host cores -- runs on a thread beside the cases that follow)
+@pytest.mark.parametrize("name", ["C3", "C3w", "C3h2", "C2", "C4", "C5"])
 def test_whole_step_matches_the_fp64_oracle(dev, name):
     w = WORKLOAD[name]
     try:
@@ -175,6 +179,8 @@ def test_whole_step_matches_the_fp64_oracle(dev, name):
 
 
 LAST_SELECTED = {}      # (filled by tests/conftest.py from the session's selection: workload -> its last selected case)
+DEFER_FORCED = False    # (set by tests/conftest.py when test_headline_step_with_the_oracle_forced_... is part of the session)
+FORCED = {}             # the deferred forced-routing evaluation of the headline case: thread, its result, what to compare with
 
 
 def _whole_step(dev, name, c, E):
@@ -184,7 +190,7 @@ def _whole_step(dev, name, c, E):
     multimodal = c.get("multimodal", True)
     xs, uses, labels, onehot, p64 = E["xs"], E["uses"], E["labels"], E["onehot"], E["p64"]
     core = GaitCore([2 if k == "of" else 1 for k in kinds], nclasses=ncls, multimodal=multimodal, fuse_mode="sign_max", margin=0.2,
-                    loss_weights=(1.0, 0.1), device=dev, conv_precision=c.get("precision", "f32"))
+                    loss_weights=(1.0, 0.1), device=dev, conv_precision=c.get("precision", "f32x3"))
     core.set_params_numpy(O.cast_params(p64, np.float32))
     core.forward_backward(xs, uses if multimodal else None, labels, onehot)
     torch.cuda.synchronize()
@@ -259,14 +265,42 @@ def _whole_step(dev, name, c, E):
         bar = 1e-2 if flips else 1e-4
         bad = {k: v for k, v in worst.items() if v > bar}
         assert not bad, (flips, bad, worst)
-        if name == "C3h2" and flips:
-            gf = R.forced_step_grads(E["x64"], E["u64"], labels, onehot, p64, routes, sel, multimodal=multimodal)
-            wf = R.grad_errors(got, gf)
-            print("%s with the oracle forced to the HIP path's routing: worst gradient rel-L2 %.2e (%s), median %.2e; unforced worst %.2e"
-                  % (name, max(wf.values()), max(wf, key=wf.get), float(np.median(list(wf.values()))), max(worst.values())))
-            assert max(wf.values()) <= 5e-5, wf
+        if name == "C3" and flips:
+            def forced():
+                try:
+                    FORCED["gf"] = R.forced_step_grads(E["x64"], E["u64"], labels, onehot, p64, routes, sel, multimodal=multimodal)
+                except BaseException as exc:      # (re-raised by the test that joins the thread)
+                    FORCED["error"] = exc
+            FORCED.update(got=got, worst=worst, name=name)
+            if DEFER_FORCED:      # beside the remaining cases; test_headline_step_with_the_oracle_forced_to_the_hip_routing joins it
+                import threading
+                FORCED["thread"] = threading.Thread(target=forced, daemon=True)
+                FORCED["thread"].start()
+            else:
+                forced()
+                _check_forced()
     print("%s: loss %.6f (oracle %.6f), max |sig - oracle| %.2e, worst gradient rel-L2 %.2e (%s)"
           % (name, ls["loss"], E["loss"], np.abs(sig - E["signature"]).max(), max(worst.values()), max(worst, key=worst.get)))
+
+
+def _check_forced():
+    if "error" in FORCED:
+        raise FORCED["error"]
+    wf = R.grad_errors(FORCED["got"], FORCED["gf"])
+    print("%s with the oracle forced to the HIP path's routing: worst gradient rel-L2 %.2e (%s), median %.2e; unforced worst %.2e"
+          % (FORCED["name"], max(wf.values()), max(wf, key=wf.get), float(np.median(list(wf.values()))), max(FORCED["worst"].values())))
+    assert max(wf.values()) <= 5e-5, wf
+
+
+@pytest.mark.timeout(900)
+def test_headline_step_with_the_oracle_forced_to_the_hip_routing(dev):
+    """The second half of the C3 case above: the fp64 oracle, FORCED to every routing decision the HIP path took (MaxPool argmax, set-max
+    frames, HPP positions, LeakyReLU signs, sign_max selections -- each difference from the oracle's own decision proven a near-tie
+    there), must reproduce the HIP gradients to 5e-5 relative L2 per tensor.  Evaluated on a thread since the C3 case."""
+    if "thread" not in FORCED:
+        pytest.skip("nothing deferred: C3 not selected in this session, or no routing decision differed (its 1e-4 bar held)")
+    FORCED["thread"].join()
+    _check_forced()
 
 
 if __name__ == "__main__":      # the oracle child process: python -m tests.test_fullsize_parity_gpu <dir> <workload> ...

@@ -118,58 +118,6 @@ def test_conv3x3_winograd_fwd_and_dgrad(dev, hw, cin, cout, pool):
     close(got, np.where(act_prev > 0, t, 0.3 * t), 5e-6, "wino dgrad fused")
 
 
-@pytest.mark.parametrize("hw,cin,cout,pool", CONV_CFGS)
-def test_conv3x3_bf16_operand_variant(dev, hw, cin, cout, pool):
-    """bf16 operands in the MFMA, fp32 accumulate.  Against the fp64 oracle the error is that of rounding both
-    Winograd-domain operands to 8 significant bits (2^-9 relative each): rel-L2 a few 1e-3, bounded here by 1e-2; and the
-    result equals the fp32 kernel run on operands rounded the same way only statistically, so no tighter check exists."""
-    from ugaitnet_amd import ops
-    rng = np.random.default_rng(9100 + hw + cin + cout)
-    n = 9 if hw <= 32 else 5
-    x = rng.uniform(-1, 1, (n, hw, hw, cin)).astype(np.float32)
-    w = rng.uniform(-0.2, 0.2, (3, 3, cin, cout)).astype(np.float32)
-    act = O.leaky(O.conv2d_same(x.astype(np.float64), w.astype(np.float64)))
-    uf = ops.wino_pack(T(w, dev), False, bf16=True)
-    if pool:
-        out, idx = ops.conv3x3_fwd_wino(T(x, dev), uf, cout, True, bf16=True)
-        pref, _ = O.maxpool2x2(act)
-        assert idx.max().item() <= 3
-    else:
-        out, pref = ops.conv3x3_fwd_wino(T(x, dev), uf, cout, False, bf16=True), act
-    e_f = rel_l2(out, pref)
-    assert 1e-4 < e_f < 1e-2, e_f                  # not fp32-exact (the bf16 path really ran), within the bf16 budget
-    if pool:
-        dp = rng.normal(size=(n, hw // 2, hw // 2, cout)).astype(np.float32)
-        pidx = rng.integers(0, 4, size=dp.shape).astype(np.uint8)
-        dz = O.maxpool2x2_bwd(pidx, dp)
-        dz_t, idx_t = T(dp, dev), T(pidx, dev)
-    else:
-        dz = rng.normal(size=(n, hw, hw, cout)).astype(np.float32)
-        dz_t, idx_t = T(dz, dev), None
-    _, dx_ref = O.conv2d_same_bwd(x.astype(np.float64), w.astype(np.float64), dz.astype(np.float64))
-    ud = ops.wino_pack(T(w, dev), True, pooled_dz=bool(pool), bf16=True)
-    e_d = rel_l2(ops.conv3x3_dgrad_wino(dz_t, ud, hw, cin, cout, dz_idx=idx_t, bf16=True), dx_ref)
-    assert 1e-4 < e_d < 1e-2, e_d
-    act_prev = rng.normal(size=(n, hw, hw, cin)).astype(np.float32)
-    got = ops.conv3x3_dgrad_wino(dz_t, ud, hw, cin, cout, dz_idx=idx_t, act=T(act_prev, dev), bf16=True)
-    assert rel_l2(got, np.where(act_prev > 0, dx_ref, 0.3 * dx_ref)) < 1e-2
-    with pytest.raises(ValueError):                 # epilogues outside the training step's are not built for bf16
-        ops.conv3x3_dgrad_wino(dz_t, ud, hw, cin, cout, dz_idx=idx_t, act=T(act_prev, dev), addend=T(act_prev, dev), bf16=True)
-    # weight gradient: 16 (8 for the 32 -> 32 layer) tiles per bf16 MFMA
-    dw_ref, _ = O.conv2d_same_bwd(x.astype(np.float64), w.astype(np.float64), dz.astype(np.float64), need_dx=False)
-    e_w = rel_l2(ops.conv3x3_wgrad_wino(T(x, dev), dz_t, cout, dz_idx=idx_t, bf16=True), dw_ref)
-    assert 1e-5 < e_w < 1e-2, e_w
-    # pair launch: two jobs, same results as the single launches (bitwise: same kernel, same per-item arithmetic)
-    if (hw, cin, cout) != (64, 32, 32):
-        x2 = rng.uniform(-1, 1, (2, hw, hw, cin)).astype(np.float32)
-        ho = hw // 2 if pool else hw
-        outs = [torch.empty((n, ho, ho, cout), device=dev), torch.empty((2, ho, ho, cout), device=dev)]
-        idxs = [torch.empty((n, ho, ho, cout), device=dev, dtype=torch.uint8), torch.empty((2, ho, ho, cout), device=dev, dtype=torch.uint8)]
-        ops.conv3x3_fwd_wino_pair([T(x, dev), T(x2, dev)], [uf, uf], cout, pool, outs, idxs if pool else None, bf16=True)
-        single = ops.conv3x3_fwd_wino(T(x2, dev), uf, cout, pool, bf16=True)
-        assert torch.equal(outs[0], out) and torch.equal(outs[1], single[0] if pool else single)
-
-
 def rel_l2(got, ref):
     g = got.detach().cpu().numpy().astype(np.float64) if hasattr(got, "detach") else np.asarray(got, np.float64)
     return float(np.linalg.norm(g - ref) / np.linalg.norm(ref))

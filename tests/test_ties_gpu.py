@@ -17,7 +17,7 @@ the last bit, the tie of the reference is then no tie here and the larger roundi
 DIAGONAL (a 45-degree silhouette edge) ties outputs (0,0) and (1,1) in exact arithmetic only.  Both move the gradient between
 positions whose input patches are IDENTICAL: forward values and weight gradients of that layer do not change, only the
 placement of the data gradient.  The tests below count how often it happens on tie-heavy batches and bound the effect on
-every parameter gradient; the direct kernels (UGN_WINO=0, `engine.USE_WINOGRAD = False`) reproduce first-max everywhere and
+every parameter gradient; the direct kernels (UGN_WINO=0, `Settings.use_winograd = False`) reproduce first-max everywhere and
 are checked bit-exactly on the same batches."""
 import numpy as np
 import pytest
@@ -80,23 +80,18 @@ def _diag_batch(b=6, l=3, seed=4):
 def _run(dev, batch, direct=False, precision="f32"):
     from ugaitnet_amd import engine
     from ugaitnet_amd.engine import GaitCore
-    assert engine.USE_WINOGRAD, "conv_precision='f32' means the Winograd kernels unless UGN_WINO=0"
+    assert engine.DEFAULTS.use_winograd, "conv_precision='f32' means the Winograd kernels unless UGN_WINO=0"
     xs, uses, labels, onehot = batch
     rng = np.random.default_rng(21)
     p64 = dict(branches=[O.init_branch_params(rng, c, np.float64) for c in (2, 1, 1)], head=O.init_head_params(rng, 4, np.float64))
-    saved = (engine.USE_WINOGRAD, engine._wgrad3x3)
-    if direct:      # the direct implicit-GEMM kernels (what UGN_WINO=0 selects at import time)
-        from ugaitnet_amd import ops
-        engine.USE_WINOGRAD, engine._wgrad3x3 = False, ops.conv3x3_wgrad
-    try:
-        core = GaitCore([2, 1, 1], nclasses=4, fuse_mode="sign_max", margin=0.2, loss_weights=(1.0, 0.1), device=dev,
-                        conv_precision=precision)
-        core.set_params_numpy(O.cast_params(p64, np.float32))
-        core.forward_backward(xs, uses, labels, onehot)
-        torch.cuda.synchronize()
-        core._test_ctx = (xs, uses, labels, onehot, p64)
-    finally:
-        engine.USE_WINOGRAD, engine._wgrad3x3 = saved
+    # direct: the direct implicit-GEMM fp32 kernels (what UGN_WINO=0 selects) -- a setting of THIS core (ugaitnet_amd/config.py)
+    cfg = engine.DEFAULTS.replace(use_winograd=False) if direct else None
+    core = GaitCore([2, 1, 1], nclasses=4, fuse_mode="sign_max", margin=0.2, loss_weights=(1.0, 0.1), device=dev,
+                    conv_precision=precision, config=cfg)
+    core.set_params_numpy(O.cast_params(p64, np.float32))
+    core.forward_backward(xs, uses, labels, onehot)
+    torch.cuda.synchronize()
+    core._test_ctx = (xs, uses, labels, onehot, p64)
     r, g = O.model_loss_and_grads([x.astype(np.float64) for x in xs], [u.astype(np.float64) for u in uses], labels,
                                   onehot.astype(np.float64), p64, margin=0.2, loss_weights=(1.0, 0.1))
     return core, r, g

@@ -134,7 +134,7 @@ def in_step():
         rec.append(("%d->%d @%d" % (xs_[0].shape[3], cout, xs_[0].shape[1]), ev))
         return (outs, idxs) if pool else outs
     h2.conv3x3_fwd_mm_multi = timed
-    with engine.serial_launches():
+    with core.serial_launches():
         for _ in range(4):
             rec.clear()
             rec2.clear()

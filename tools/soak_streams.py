@@ -26,8 +26,10 @@ if __name__ == "__main__":
     # Two launch shapes -- one launch per layer for all modalities (default) and one per layer and modality (UGN_MERGE=0) -- sum
     # the weight gradients in different orders, so each is compared with itself under its stream modes.
     groups = (({"UGN_WSTREAM": "0"}, {"UGN_WSTREAM": "1"}),
-              ({"UGN_MERGE": "0", "UGN_WSTREAM": "0", "UGN_FSTREAMS": "0"}, {"UGN_MERGE": "0", "UGN_WSTREAM": "1", "UGN_FSTREAMS": "2"},
-               {"UGN_MERGE": "0", "UGN_WSTREAM": "1", "UGN_FSTREAMS": "2", "UGN_BSTREAMS": "1"}))
+              # (one launch per layer and modality exists on the Winograd fp32-MFMA set only: the default x3 set runs merged launches)
+              ({"UGN_CONV_PRECISION": "f32", "UGN_MERGE": "0", "UGN_WSTREAM": "0", "UGN_FSTREAMS": "0"},
+               {"UGN_CONV_PRECISION": "f32", "UGN_MERGE": "0", "UGN_WSTREAM": "1", "UGN_FSTREAMS": "2"},
+               {"UGN_CONV_PRECISION": "f32", "UGN_MERGE": "0", "UGN_WSTREAM": "1", "UGN_FSTREAMS": "2", "UGN_BSTREAMS": "1"}))
     for envs in groups:
         outs = []
         for env in envs:

@@ -51,13 +51,7 @@ PROTOTYPES = {
     "ugn_binfc_bwd_parts_multi": (_i, [C.POINTER(_p)] * 5 + [C.POINTER(_i), _i, _i, _p]),
     "ugn_conv3x3_dgrad_wino_routed": (_i, [_p, _p, _p, _p, _p, _i, _p, _i, _i, _i, _i, _p]),
     "ugn_conv3x3_dgrad_wino_pair": (_i, [C.POINTER(_p)] * 7 + [C.POINTER(_i), _i, _i, _i, _p]),
-    "ugn_conv3x3_fwd_wino_bf16": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
-    "ugn_conv3x3_dgrad_wino_bf16": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
-    "ugn_conv3x3_fwd_wino_pair_bf16": (_i, [C.POINTER(_p)] * 4 + [C.POINTER(_i), _i, _i, _i, _i, _p]),
-    "ugn_conv3x3_dgrad_wino_pair_bf16": (_i, [C.POINTER(_p)] * 7 + [C.POINTER(_i), _i, _i, _i, _p]),
     "ugn_conv3x3_wgrad_wino_pair": (_i, [C.POINTER(_p)] * 4 + [C.POINTER(_i), _i, _i, _i, _p, _sz, _p]),
-    "ugn_conv3x3_wgrad_wino_pair_bf16": (_i, [C.POINTER(_p)] * 4 + [C.POINTER(_i), _i, _i, _i, _p, _sz, _p]),
-    "ugn_conv3x3_wgrad_wino_bf16": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p, _sz, _p]),
     "ugn_conv3x3_wgrad_wino_ws": (_sz, [_i, _i, _i, _i]),
     "ugn_conv3x3_wgrad_wino": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p, _sz, _p]),
     "ugn_setmax_fwd": (_i, [_p, _p, _p, _p, _i, _i, _sz, _p]),

@@ -102,8 +102,8 @@ constexpr int lds_bytes() {
 #define UGN_T16_MIN 32
 #endif
 #ifndef UGN_D2P16
-#define UGN_D2P16 1       /* the pooled 32 -> 32 data gradient on conv_d2_kernel<..., IN_POOLED> (16x16x32 tiles) instead of conv32_d2p_kernel
-                             (32x32x16): 400 -> 362 us in the step.  (The fused dgrad32_w5 kernel reads that filter in the 32-column block
+#define UGN_D2P16 1       /* the pooled 32 -> 32 data gradient on conv_d2_kernel<..., IN_POOLED> (16x16x32 tiles); its first form, conv32_d2p_kernel
+                             on 32x32x16 (400 against 362 us in the step), was removed in round 5: 0 now selects conv_mm_kernel.  (The fused dgrad32_w5 kernel reads that filter in the 32-column block
                              layout: its caller packs a copy with flag bit 1 of ugn_mm_pack_multi.) */
 #endif
 #ifndef UGN_NR_POOLED
@@ -1495,177 +1495,6 @@ __global__ __launch_bounds__(512, 4) void conv_d2_kernel(const MmJobs jt, const 
   h2_publish_amax_block(jt.job[meta_jb].out_meta, mx, reinterpret_cast<float*>(smem), tid, 8);
 }
 
-// The same for the POOLED data gradient of the layer (a2: dL/dp2 + argmax bytes -> dL/da1, the largest tensor of the backward pass).
-// 32x32x16 shape (the data-gradient filters of this layer are packed for it; the fused first-layer kernel below reads them too),
-// one accumulator block per wave, the one-block epilogue of conv_mm_kernel.  MaxPool backward: the pooled values + argmax bytes
-// of the tile AFTER the next one travel through registers (plain global loads, an item ahead) and are scattered into the single halo
-// buffer behind barrier B, in the swizzled order the fragment reads expect.
-template <int HW>
-__global__ __launch_bounds__(512, 4) void conv32_d2p_kernel(const MmJobs jt) {
-  constexpr int KC = 32, NC = 32, HP = HW / 2;
-  constexpr int RPX = HW / 16, RPI = RPX * RPX;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const unsigned sbase = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem);
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  // A-side role (conv_mm_kernel): row r of the wave's 32-pixel block = window win, position q; k half h
-  const int r = lane & 31, h = lane >> 5, win = r >> 2, q = r & 3;
-  const int row0 = 2 * wave + (q >> 1), col0 = 2 * win + (q & 1);
-  int abase[3][2];                      // [dx][parity of dy]: slot (k-step 0, H plane); k-step 1: ^ 32, L plane: ^ 64
-#pragma unroll
-  for (int dx = 0; dx < 3; ++dx)
-#pragma unroll
-    for (int dp = 0; dp < 2; ++dp) {
-      const int g = ((((col0 + dx) >> 1) & 3) << 1) | ((row0 + dp) & 1);
-      abase[dx][dp] = (row0 * 18 + col0) * 128 + ((g ^ h) << 4);
-    }
-  const int b_lane = D2_W_OFF + lane * 16;
-  const int c = lane & 31;
-
-  int item = xcd_first_item();
-  const int nitems = jt.start[kMaxJobs];
-  if (item >= nitems) return;
-  int jb = mm_job_of(jt, item), lit = item - jt.start[jb];
-
-  // this thread's unit of the 10 x 10 pooled pixels under a region's halo: pooled pixel spp, channel group scg (8 channels)
-  const int spp = tid >> 2, scg = tid & 3;
-  const int sprow = (spp * 205) >> 11, spcol = spp - sprow * 10;
-  uint4 shi = make_uint4(0u, 0u, 0u, 0u), slo = shi;
-  uint2 six = make_uint2(0u, 0u);
-  auto stg_load = [&](const MmJob& J, int lit_) {
-    const int img = lit_ / RPI, rrem = lit_ % RPI;
-    const int pr = ((rrem / RPX) * 16) / 2 - 1 + sprow, pc = ((rrem % RPX) * 16) / 2 - 1 + spcol;
-    const bool ok = tid < 400 && (unsigned)pr < (unsigned)HP && (unsigned)pc < (unsigned)HP;
-    shi = make_uint4(0u, 0u, 0u, 0u);
-    slo = shi;
-    six = make_uint2(0u, 0u);
-    if (ok) {
-      const unsigned o = (unsigned)(pr * HP + pc);
-      const char* v = reinterpret_cast<const char*>(J.in) + ((size_t)img * HP * HP + o) * (KC * 4) + (unsigned)(scg * 16);
-      shi = *reinterpret_cast<const uint4*>(v);
-      slo = *reinterpret_cast<const uint4*>(v + KC * 2);
-      six = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(J.in_idx) + ((size_t)img * HP * HP + o) * KC + (unsigned)(scg * 8));
-    }
-  };
-  auto scatter = [&]() {              // registers -> the halo tile: quarter jj of pixel (hy, hx) into slot jj ^ g(hy, hx)
-    if (tid >= 400) return;
-    const unsigned hv[4] = {shi.x, shi.y, shi.z, shi.w}, lv[4] = {slo.x, slo.y, slo.z, slo.w};
-#pragma unroll
-    for (int pos = 0; pos < 4; ++pos) {
-      const int hy = 2 * sprow - 1 + (pos >> 1), hx = 2 * spcol - 1 + (pos & 1);
-      if ((unsigned)hy >= 18u || (unsigned)hx >= 18u) continue;
-      unsigned m[4];
-#pragma unroll
-      for (int d = 0; d < 4; ++d) {
-        const unsigned w = d < 2 ? six.x : six.y;
-        const unsigned b0 = (w >> (16 * (d & 1))) & 0xffu, b1 = (w >> (16 * (d & 1) + 8)) & 0xffu;
-        m[d] = (b0 == (unsigned)pos ? 0x0000ffffu : 0u) | (b1 == (unsigned)pos ? 0xffff0000u : 0u);
-      }
-      const int g = (((hx >> 1) & 3) << 1) | (hy & 1);
-      char* rec = smem + (hy * 18 + hx) * 128;
-      *reinterpret_cast<uint4*>(rec + ((scg ^ g) << 4)) = make_uint4(hv[0] & m[0], hv[1] & m[1], hv[2] & m[2], hv[3] & m[3]);
-      *reinterpret_cast<uint4*>(rec + (((4 + scg) ^ g) << 4)) = make_uint4(lv[0] & m[0], lv[1] & m[1], lv[2] & m[2], lv[3] & m[3]);
-    }
-  };
-  auto issue_filter = [&](const uint16_t* wpk) {
-#pragma unroll
-    for (int j = 0; j < 5; ++j) {
-      const int p = wave + 8 * j;
-      if (p < D2_WBYTES / 1024) dma16(reinterpret_cast<const char*>(wpk) + p * 1024 + lane * 16, sbase + D2_W_OFF + (unsigned)p * 1024u);
-    }
-  };
-  // ---- prologue: tile of the first item -> halo, the second item's pooled pixels -> registers, the job's filter -> LDS
-  stg_load(jt.job[jb], lit);
-  issue_filter(jt.job[jb].wpk);
-  scatter();
-  {
-    const int ni = item + gridDim.x;
-    if (ni < nitems) { const int j2 = mm_job_of(jt, ni); stg_load(jt.job[j2], ni - jt.start[j2]); }
-  }
-  int res_job = jb;
-  bool first_item = true;
-  int meta_jb = -1, e_out = 0;
-  float factor = 1.f, mx = 0.f;
-
-  for (; item < nitems; item += gridDim.x) {
-    const int next_item = item + gridDim.x, next2 = item + 2 * (int)gridDim.x;
-    const bool more = next_item < nitems;
-    const int jn = more ? mm_job_of(jt, next_item) : jb, nlit = more ? next_item - jt.start[jn] : lit;
-    if (jb != meta_jb) {
-      if (meta_jb >= 0) h2_publish_amax(jt.job[meta_jb].out_meta, wave_max(mx), lane);
-      mx = 0.f;
-      const MmJob& Jm = jt.job[jb];
-      const int e_in = Jm.in_meta->e;
-      const float amax_in = h2_true_amax(e_in, Jm.in_meta->amax);
-      e_out = h2_exp_for_bound(amax_in * Jm.wmeta->l1);
-      factor = ldexpf(1.f, e_out - e_in - Jm.wmeta->e);
-      meta_jb = jb;
-    }
-    if (jb != res_job) {              // the previous job's taps ended behind barrier B
-      issue_filter(jt.job[jb].wpk);
-      res_job = jb;
-      first_item = true;
-    }
-    if (first_item) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the filter DMA; the scatter awaited its loads itself)
-    __syncthreads();                  // A: the scattered tile (and the filter) visible
-    first_item = false;
-
-    f32x16 acc;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-#pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-      const int dy = tap / 3, dx = tap % 3;
-      const int aoff = (dy * 18 + dx) * 128;
-      const int ab = abase[dx][dy & 1];
-#pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        const uint4 ah = *reinterpret_cast<const uint4*>(smem + (ab ^ (s << 5)) + aoff);
-        const uint4 al = *reinterpret_cast<const uint4*>(smem + (ab ^ (s << 5) ^ 64) + aoff);
-        const uint4 bh = *reinterpret_cast<const uint4*>(smem + b_lane + ((tap * 2 + s) * 2 + 0) * 1024);
-        const uint4 bl = *reinterpret_cast<const uint4*>(smem + b_lane + ((tap * 2 + s) * 2 + 1) * 1024);
-        acc = mfma_h(ah, bh, acc);
-        acc = mfma_h(ah, bl, acc);
-        acc = mfma_h(al, bh, acc);
-      }
-    }
-    __syncthreads();                  // B: the halo buffer is free
-    if (more) {
-      scatter();                      // the next item's tile (its loads were issued an item ago)
-      if (next2 < nitems) { const int j2 = mm_job_of(jt, next2); stg_load(jt.job[j2], next2 - jt.start[j2]); }
-    }
-
-    // ---- epilogue (conv_mm_kernel, one block): lane c owns channel c; lanes (c, c ^ 1) exchange halves: the even lane stores the H
-    // pair, the odd lane the L pair.  acc[4g + i]: window 2g + h of the wave's 8, position i
-    const int img = lit / RPI, rrem = lit % RPI;
-    const int ry0 = (rrem / RPX) * 16, rx0 = (rrem % RPX) * 16;
-    const MmJob& J = jt.job[jb];
-    if (lit == 0 && tid == 0) J.out_meta->e = e_out;
-    char* out = reinterpret_cast<char*>(J.out) + (size_t)img * HW * HW * NC * 4;
-    const unsigned sel = (c & 1) ? 0x03020706u : 0x05040100u;
-    const unsigned chb = (c & 1) ? (unsigned)(NC * 2 + (c - 1) * 2) : (unsigned)(c * 2);
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int wx = 2 * g + h;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const unsigned pix = (unsigned)((ry0 + 2 * wave + (i >> 1)) * HW + rx0 + 2 * wx + (i & 1));
-        const float v = acc[4 * g + i] * factor;
-        mx = fmaxf(mx, fabsf(v));
-        _Float16 hi, lo;
-        h2_split(v, hi, lo);
-        const unsigned own = h2_pack(hi, lo);
-        const unsigned oth = (unsigned)__builtin_amdgcn_update_dpp(0, (int)own, 0xB1, 0xf, 0xf, false);   // quad_perm [1,0,3,2]
-        UGN_ST(unsigned, out + pix * (unsigned)(NC * 4) + chb, __builtin_amdgcn_perm(oth, own, sel));
-      }
-    }
-    jb = jn;
-    lit = nlit;
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  h2_publish_amax_block(jt.job[meta_jb].out_meta, mx, reinterpret_cast<float*>(smem), tid, 8);
-}
-
 // ---------------------------------------------------------------------------------------------------------------------
 // "NR": the N channels split over the waves, the filter fragments in REGISTERS (64 / 128 output columns, un-pooled input)
 // ---------------------------------------------------------------------------------------------------------------------
@@ -2378,23 +2207,6 @@ int launch_nr(const MmJob* jobs, const int* n, int njobs, hipStream_t st) {
   return 0;
 }
 
-template <int HW>
-int launch_d2p(const MmJob* jobs, const int* n, int njobs, hipStream_t st) {
-  auto kern = conv32_d2p_kernel<HW>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, D2_LDS);
-    if (e != hipSuccess) { ugn_set_error("conv32_d2p: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
-    attr_done = true;
-  }
-  MmJobs jt;
-  const int nitems = make_mm_table(jt, jobs, n, njobs, (HW / 16) * (HW / 16));
-  const int wgs = 2 * g_persistent_wgs;
-  const int grid = nitems < wgs ? nitems : wgs;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), D2_LDS, st, jt);
-  UGN_CHECK_LAUNCH("conv32_d2p");
-  return 0;
-}
 
 int dispatch_fwd(const MmJob* jobs, const int* n, int njobs, int hw, int cin, int cout, int pool, hipStream_t st) {
   if constexpr ((UGN_MM_D2 & 1) != 0) {
@@ -2424,7 +2236,7 @@ int dispatch_fwd(const MmJob* jobs, const int* n, int njobs, int hw, int cin, in
 int dispatch_dgrad(const MmJob* jobs, const int* n, int njobs, int hw, int cin, int cout, int unpool, bool act, hipStream_t st) {
   if constexpr ((UGN_MM_D2 & 2) != 0) {
     if (cin == 32 && cout == 32 && hw == 64 && unpool && !act)
-      return UGN_D2P16 ? launch_d2<32, 32, 64, EPI_DGRAD, 1>(jobs, n, njobs, st) : launch_d2p<64>(jobs, n, njobs, st);
+      return launch_d2<32, 32, 64, EPI_DGRAD, 1>(jobs, n, njobs, st);
     if (UGN_D2P16 && cin == 32 && cout == 32 && hw == 64 && unpool && act) return launch_d2<32, 32, 64, EPI_DGRAD_ACT, 1>(jobs, n, njobs, st);
   }
   if constexpr ((UGN_MM_D2 & 4) != 0) {        // (GEMM K = cout, N = cin)

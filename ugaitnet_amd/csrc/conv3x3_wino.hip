@@ -715,11 +715,8 @@ int launch_wino(const WinoJob* jobs, const int* n, int njobs, hipStream_t st) {
 template <int KC, int NCF, int HW, int IN_UNPOOL>
 int launch_wino_dgrad(const WinoJob* jobs, const int* n, int njobs, bool bf, hipStream_t st) {
   const int flags = (jobs[0].act ? 1 : 0) | (jobs[0].addend ? 2 : 0) | (jobs[0].raw_out ? 4 : 0) | (jobs[0].smax_m ? 8 : 0);
-  if (bf) {   // bf16 operands: the two epilogues the training step uses (plain, and LeakyReLU' of the layer's input)
-    if (flags == 0) return launch_wino<KC, NCF, HW, IN_UNPOOL, EPI_DGRAD, 0, true>(jobs, n, njobs, st);
-    if (flags == 1) return launch_wino<KC, NCF, HW, IN_UNPOOL, EPI_DGRAD, 1, true>(jobs, n, njobs, st);
-    ugn_set_error("ugn_conv3x3_dgrad_wino_bf16: epilogue combination %d is not built for bf16 operands (plain or act only)", flags);
-    return UGN_EINVAL;
+  if (bf) {   // (the BF = true instantiations -- bf16-rounded Winograd-domain operands on fp32 tensors, rounds 1-4 -- are no longer built)
+    ugn_set_error("the bf16-operand Winograd kernels (fp32 tensors, 'bf16w') were retired in round 5: conv_precision='bf16' is the configs[4] path"); return UGN_EINVAL;
   }
   if constexpr (KC == 128 && NCF == 64 && HW == 16 && !IN_UNPOOL)   // a5: act + routed set-max gradient
     if (flags == 9) return launch_wino<KC, NCF, HW, IN_UNPOOL, EPI_DGRAD, 9>(jobs, n, njobs, st);
@@ -736,11 +733,11 @@ int launch_wino_dgrad(const WinoJob* jobs, const int* n, int njobs, bool bf, hip
 }
 
 int dispatch_fwd(const WinoJob* jobs, const int* n, int njobs, int hw, int cin, int cout, int pool, bool bf, hipStream_t st) {
+  if (bf) { ugn_set_error("the bf16-operand Winograd kernels (fp32 tensors, 'bf16w') were retired in round 5: conv_precision='bf16' is the configs[4] path"); return UGN_EINVAL; }
   if (wino_tall(cin, cout)) return launch_tall(0, jobs, n, njobs, hw, cin, pool != 0, bf, st);   // (the filter layout differs)
 #define WF(KC_, NC_, HW_, P_)                                                                                     \
   if (cin == KC_ && cout == NC_ && hw == HW_ && (pool != 0) == (P_ != 0))                                         \
-    return bf ? launch_wino<KC_, NC_, HW_, 0, P_ ? EPI_LRELU_POOL : EPI_LRELU, 0, true>(jobs, n, njobs, st)       \
-              : launch_wino<KC_, NC_, HW_, 0, P_ ? EPI_LRELU_POOL : EPI_LRELU, 0>(jobs, n, njobs, st);
+    return launch_wino<KC_, NC_, HW_, 0, P_ ? EPI_LRELU_POOL : EPI_LRELU, 0>(jobs, n, njobs, st);
   WF(32, 32, 64, 1) WF(32, 64, 32, 0) WF(64, 64, 32, 1) WF(64, 128, 16, 0) WF(128, 128, 16, 0)
 #undef WF
   ugn_set_error("ugn_conv3x3_fwd_wino: unsupported shape cin=%d cout=%d hw=%d pool=%d", cin, cout, hw, pool);
@@ -824,10 +821,6 @@ extern "C" int ugn_conv3x3_fwd_wino(const float* in, const float* u_packed, floa
                                     int cin, int cout, int pool, void* stream) {
   return fwd_one(in, u_packed, out, out_idx, n, hw, cin, cout, pool, false, stream);
 }
-extern "C" int ugn_conv3x3_fwd_wino_bf16(const float* in, const float* u_packed, float* out, uint8_t* out_idx, int n, int hw,
-                                         int cin, int cout, int pool, void* stream) {
-  return fwd_one(in, u_packed, out, out_idx, n, hw, cin, cout, pool, true, stream);
-}
 
 static int fwd_multi(const float* const* in, const float* const* u_packed, float* const* out, uint8_t* const* out_idx,
                      const int* n, int njobs, int hw, int cin, int cout, int pool, bool bf, void* stream) {
@@ -855,11 +848,6 @@ extern "C" int ugn_conv3x3_fwd_wino_pair(const float* const* in, const float* co
                                          void* stream) {
   return fwd_pair(in, u_packed, out, out_idx, n, hw, cin, cout, pool, false, stream);
 }
-extern "C" int ugn_conv3x3_fwd_wino_pair_bf16(const float* const* in, const float* const* u_packed, float* const* out,
-                                              uint8_t* const* out_idx, const int* n, int hw, int cin, int cout, int pool,
-                                              void* stream) {
-  return fwd_pair(in, u_packed, out, out_idx, n, hw, cin, cout, pool, true, stream);
-}
 
 static int dgrad_one(const float* dz, const uint8_t* dz_idx, const float* u_packed, const float* act, const float* addend,
                      float* out, float* raw_out, int n, int hw, int cin, int cout, bool bf, void* stream) {
@@ -871,11 +859,6 @@ extern "C" int ugn_conv3x3_dgrad_wino(const float* dz, const uint8_t* dz_idx, co
                                       const float* addend, float* out, float* raw_out, int n, int hw, int cin, int cout,
                                       void* stream) {
   return dgrad_one(dz, dz_idx, u_packed, act, addend, out, raw_out, n, hw, cin, cout, false, stream);
-}
-extern "C" int ugn_conv3x3_dgrad_wino_bf16(const float* dz, const uint8_t* dz_idx, const float* u_packed, const float* act,
-                                           const float* addend, float* out, float* raw_out, int n, int hw, int cin, int cout,
-                                           void* stream) {
-  return dgrad_one(dz, dz_idx, u_packed, act, addend, out, raw_out, n, hw, cin, cout, true, stream);
 }
 
 extern "C" int ugn_conv3x3_dgrad_wino_routed(const float* dz, const float* u_packed, const float* act, const float* smax_m,
@@ -919,10 +902,4 @@ extern "C" int ugn_conv3x3_dgrad_wino_pair(const float* const* dz, const uint8_t
                                            const float* const* act, const float* const* addend, float* const* out,
                                            float* const* raw_out, const int* n, int hw, int cin, int cout, void* stream) {
   return dgrad_pair(dz, dz_idx, u_packed, act, addend, out, raw_out, n, hw, cin, cout, false, stream);
-}
-extern "C" int ugn_conv3x3_dgrad_wino_pair_bf16(const float* const* dz, const uint8_t* const* dz_idx,
-                                                const float* const* u_packed, const float* const* act,
-                                                const float* const* addend, float* const* out, float* const* raw_out,
-                                                const int* n, int hw, int cin, int cout, void* stream) {
-  return dgrad_pair(dz, dz_idx, u_packed, act, addend, out, raw_out, n, hw, cin, cout, true, stream);
 }

@@ -414,12 +414,7 @@ int launch_tall_t(const WinoJob* jobs, const int* n, int njobs, hipStream_t st) 
 template <int KC, int HW, int IN_UNPOOL>
 int launch_tall_dgrad(const WinoJob* jobs, const int* n, int njobs, bool bf, hipStream_t st) {
   const int flags = (jobs[0].act ? 1 : 0) | (jobs[0].addend ? 2 : 0) | (jobs[0].raw_out ? 4 : 0) | (jobs[0].smax_m ? 8 : 0);
-  if (bf) {
-    if (flags == 0) return launch_tall_t<KC, HW, IN_UNPOOL, EPI_DGRAD, 0, true>(jobs, n, njobs, st);
-    if (flags == 1) return launch_tall_t<KC, HW, IN_UNPOOL, EPI_DGRAD, 1, true>(jobs, n, njobs, st);
-    ugn_set_error("ugn_conv3x3_dgrad_wino_bf16: epilogue combination %d is not built for bf16 operands (plain or act only)", flags);
-    return UGN_EINVAL;
-  }
+  if (bf) { ugn_set_error("the bf16-operand Winograd kernels (fp32 tensors, 'bf16w') were retired in round 5: conv_precision='bf16' is the configs[4] path"); return UGN_EINVAL; }
   if constexpr (KC == 64 && HW == 32 && !IN_UNPOOL)   // a3: act + routed set-max gradient
     if (flags == 9) return launch_tall_t<KC, HW, IN_UNPOOL, EPI_DGRAD, 9>(jobs, n, njobs, st);
 #define UGN_TDG(F_) \
@@ -443,9 +438,9 @@ bool tall_supported(int kind, int hw, int kc, int flag) {
 }
 
 int launch_tall(int kind, const WinoJob* jobs, const int* n, int njobs, int hw, int kc, int flag, bool bf, hipStream_t st) {
+  if (bf) { ugn_set_error("the bf16-operand Winograd kernels (fp32 tensors, 'bf16w') were retired in round 5: conv_precision='bf16' is the configs[4] path"); return UGN_EINVAL; }
   if (kind == 0 && hw == 64 && kc == 32 && flag)
-    return bf ? launch_tall_t<32, 64, 0, EPI_LRELU_POOL, 0, true>(jobs, n, njobs, st)
-              : launch_tall_t<32, 64, 0, EPI_LRELU_POOL, 0>(jobs, n, njobs, st);
+    return launch_tall_t<32, 64, 0, EPI_LRELU_POOL, 0>(jobs, n, njobs, st);
   if (kind == 1 && hw == 64 && kc == 32 && flag) return launch_tall_dgrad<32, 64, 1>(jobs, n, njobs, bf, st);
   if (kind == 1 && hw == 32 && kc == 64 && !flag) return launch_tall_dgrad<64, 32, 0>(jobs, n, njobs, bf, st);
   ugn_set_error("wino tall: unsupported shape kind=%d hw=%d kc=%d flag=%d", kind, hw, kc, flag);

@@ -670,13 +670,7 @@ bool wg_cfg(int hw, int cin, int cout, int* coc) {
 
 int dispatch_wgrad(const WgHostJob* hj, int njobs, int hw, int cin, int cout, void* ws, size_t ws_bytes, bool bf, hipStream_t st) {
   const int unpool = hj[0].dz_idx != nullptr;
-  if (bf) {
-#define WGB(CI_, CO_, HW_, COC_, U_)                          \
-  if (cin == CI_ && cout == CO_ && hw == HW_ && unpool == U_) \
-    return launch_wgrad_wino<CI_, CO_, HW_, COC_, U_, true>(hj, njobs, (float*)ws, ws_bytes / sizeof(float), st);
-    WGB(32, 32, 64, 32, 1) WGB(32, 64, 32, 64, 0) WGB(64, 64, 32, 64, 1) WGB(64, 128, 16, 64, 0) WGB(128, 128, 16, 64, 0)
-#undef WGB
-  }
+  if (bf) { ugn_set_error("the bf16-operand Winograd kernels (fp32 tensors, 'bf16w') were retired in round 5: conv_precision='bf16' is the configs[4] path"); return UGN_EINVAL; }
 #define WGW(CI_, CO_, HW_, COC_, U_)                          \
   if (cin == CI_ && cout == CO_ && hw == HW_ && unpool == U_) \
     return launch_wgrad_wino<CI_, CO_, HW_, COC_, U_>(hj, njobs, (float*)ws, ws_bytes / sizeof(float), st);
@@ -710,10 +704,6 @@ extern "C" int ugn_conv3x3_wgrad_wino(const float* in, const float* dz, const ui
                                       int cin, int cout, void* ws, size_t ws_bytes, void* stream) {
   return wgrad_one(in, dz, dz_idx, dw, n, hw, cin, cout, ws, ws_bytes, false, stream);
 }
-extern "C" int ugn_conv3x3_wgrad_wino_bf16(const float* in, const float* dz, const uint8_t* dz_idx, float* dw, int n, int hw,
-                                           int cin, int cout, void* ws, size_t ws_bytes, void* stream) {
-  return wgrad_one(in, dz, dz_idx, dw, n, hw, cin, cout, ws, ws_bytes, true, stream);
-}
 
 static int wgrad_multi(const float* const* in, const float* const* dz, const uint8_t* const* dz_idx, float* const* dw,
                        const int* n, int njobs, int hw, int cin, int cout, void* ws, size_t ws_bytes, bool bf, void* stream) {
@@ -740,9 +730,4 @@ extern "C" int ugn_conv3x3_wgrad_wino_pair(const float* const* in, const float* 
                                            float* const* dw, const int* n, int hw, int cin, int cout, void* ws,
                                            size_t ws_bytes, void* stream) {
   return wgrad_pair(in, dz, dz_idx, dw, n, hw, cin, cout, ws, ws_bytes, false, stream);
-}
-extern "C" int ugn_conv3x3_wgrad_wino_pair_bf16(const float* const* in, const float* const* dz, const uint8_t* const* dz_idx,
-                                                float* const* dw, const int* n, int hw, int cin, int cout, void* ws,
-                                                size_t ws_bytes, void* stream) {
-  return wgrad_pair(in, dz, dz_idx, dw, n, hw, cin, cout, ws, ws_bytes, true, stream);
 }

@@ -35,122 +35,64 @@ CONV_SPECS = (
 )
 NBINS, FEAT, HIDDEN = 62, 128, 256
 
-# Arithmetic of the 3x3 layers when a model does not name one (GaitCore(conv_precision=...), UGN_CONV_PRECISION):
-#   "h2"  activations / gradients between the 3x3 layers as split-fp16 halves + ONE block exponent per tensor (22 significant bits),
-#         3x3 layers as direct convolutions on the f16 matrix pipe: holds the fp32 parity bars of tests/ and is the fastest set, but
-#         it is narrower than the reference's fp32 and a clip's result depends on its batch-mates -- opt-in since round 5
-#   "f32x3" (default) IEEE fp32 tensors everywhere; the 3x3 layers multiply them on the bf16 matrix pipe through the exact three-way bf16
-#         split of both operands (six partial products per fp32 product, fp32 accumulate: csrc/x3_common.h) -- fp32-grade results
-#         with no storage format, block exponent or dependence on the other clips of a batch
-#   "f32" IEEE fp32 tensors, Winograd F(2x2,3x3) on the fp32 MFMA
-#   "bf16" BASELINE configs[4]: bf16 activations / gradients / saved tensors in HBM, direct convolutions on the bf16 matrix pipe,
-#         fp32 accumulate, fp32 master weights and Adam (engine_bf.py)
-#   "bf16w" (round 1-2) fp32 tensors, Winograd with bf16-rounded MFMA operands
-DEFAULT_PRECISION = os.environ.get("UGN_CONV_PRECISION", "f32x3")
-# Arithmetic of forward-only queries behind the Keras surface (model.predict, get_layer(...).output taps, UWYHSemiNet.encode):
-# UGN_GATE_NORM_FUSED=0: the gate / fMerge and the batch normalisation as two launches each way (rounds 1-3; same results)
-GATE_NORM_FUSED = os.environ.get("UGN_GATE_NORM_FUSED", "1") != "0"
-# "f32" by default -- see GaitCore.arithmetic; "same" keeps the training arithmetic (UGN_INFER_PRECISION).
-INFER_PRECISION = os.environ.get("UGN_INFER_PRECISION", "f32")
+# Every launch / arithmetic switch of a model lives in ONE Settings object per GaitCore (ugaitnet_amd/config.py); DEFAULTS is what
+# the UGN_* environment says at import.  `GaitCore(config=..., conv_precision=...)` takes its own copy: two cores with different
+# settings in one process behave like two processes (tests/test_engine_gpu.py::test_two_cores_with_different_settings_in_one_process).
+from .config import Settings
 
-# Winograd F(2x2,3x3) kernels for the 3x3 forward convolutions and data gradients (UGN_WINO=0 selects the direct
-# implicit-GEMM kernels, whose MaxPool tie-breaking on exactly equal activations follows the reference's first-max rule).
-USE_WINOGRAD = os.environ.get("UGN_WINO", "1") != "0"
+DEFAULTS = Settings.from_env()
+DEFAULT_PRECISION = DEFAULTS.conv_precision     # (read-only conveniences for callers that only want to know the defaults)
+INFER_PRECISION = DEFAULTS.infer_precision
 WINO_DGRAD = ("a2", "a3", "a4", "a5", "a6", "b1", "b2", "b3", "b4")
-_wgrad3x3 = ops.conv3x3_wgrad_wino if USE_WINOGRAD else ops.conv3x3_wgrad
-PAIR_LAUNCHES = os.environ.get("UGN_PAIR", "1") != "0"   # frame-level layer + set-level twin in one launch
-A1_SIGN_BITS = os.environ.get("UGN_A1_BITS", "1") != "0"   # LeakyReLU' of the first layer from 1 bit per element
-# Weight gradients on a side stream: a layer's weight gradient and data gradient only share their inputs, so the two
-# persistent launches may overlap -- the tail of one (last, partly filled round of work items) and the prologue of the other
-# fill each other's idle CUs.  Results are unchanged (no kernel's inputs depend on the order).
-WGRAD_STREAM = os.environ.get("UGN_WSTREAM", "1") != "0"
-# UGN_BSTREAMS=1 additionally puts the backward chains of the modalities, which are independent of each other after the
-# fusion gradient, on streams of their own (each with its weight-gradient stream).  Measured slower (9.51 vs 9.40 ms): six
-# LDS-filling kernels contending for the CUs thrash more than they fill.  The forward stays on one stream: bench.py times it.
-BRANCH_STREAMS = WGRAD_STREAM and os.environ.get("UGN_BSTREAMS", "0") == "1"
-# UGN_FSTREAMS=1|2: the forward chains of modalities 1.. run on that many side streams (default 2; 0 = one stream).  Worth
-# 1.6 % / 2.7 % of the step (9.29 / 9.19 ms against 9.44).  Per-kernel durations are then no longer clean -- bench.py takes
-# its roofline figures from a separate, fully serialised pass after the timed region (`serial_launches()`).
-FWD_STREAMS = int(os.environ.get("UGN_FSTREAMS", "2"))
-_WSTREAM = {}
-_BSTREAM = {}
 
 
-def _wgrad_stream(device):
-    # one weight-gradient stream per stream that issues backward chains
-    key = (device, torch.cuda.current_stream(device).cuda_stream)
-    st = _WSTREAM.get(key)
-    if st is None:
-        st = _WSTREAM[key] = torch.cuda.Stream(device=device)
-    return st
+class _Launch:
+    """Streams of ONE core and the settings its launches follow: weight gradients on a second stream beside the data gradients (a
+    layer's weight gradient and data gradient only share their inputs, so the two persistent launches may overlap -- the tail of one
+    and the prologue of the other fill each other's idle CUs; results are unchanged), optional per-branch / forward side streams."""
 
+    def __init__(self, cfg, device):
+        self.cfg, self.device = cfg, device
+        self.wstream, self.bstream = {}, {}
 
-def _branch_stream(device, mi):
-    st = _BSTREAM.get((device, mi))
-    if st is None:
-        st = _BSTREAM[(device, mi)] = torch.cuda.Stream(device=device)
-    return st
+    def wgrad_stream(self):
+        # one weight-gradient stream per stream that issues backward chains
+        key = torch.cuda.current_stream(self.device).cuda_stream
+        st = self.wstream.get(key)
+        if st is None:
+            st = self.wstream[key] = torch.cuda.Stream(device=self.device)
+        return st
 
+    def branch_stream(self, mi):
+        st = self.bstream.get(mi)
+        if st is None:
+            st = self.bstream[mi] = torch.cuda.Stream(device=self.device)
+        return st
 
-PACK_ON_SIDE_STREAM = os.environ.get("UGN_PACK_SIDE", "1") != "0"      # (experiments: 0 = repack on the main stream, after Adam)
+    @contextlib.contextmanager
+    def side(self, device=None):
+        """`with launch.side():` -- run the enclosed launches on the weight-gradient stream, after everything issued so far."""
+        if not self.cfg.wgrad_stream:
+            yield
+            return
+        st = self.wgrad_stream()
+        st.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(st):
+            yield
 
-
-@contextlib.contextmanager
-def serial_launches():
-    """Every launch on ONE stream (no weight-gradient / branch / forward side streams) while the context is active: the
-    per-kernel durations bench.py's roofline pass and the rocprofv3 kernel-trace summaries quote.  Results are unchanged."""
-    global WGRAD_STREAM, BRANCH_STREAMS, FWD_STREAMS
-    saved = (WGRAD_STREAM, BRANCH_STREAMS, FWD_STREAMS)
-    WGRAD_STREAM, BRANCH_STREAMS, FWD_STREAMS = False, False, 0
-    try:
-        yield
-    finally:
-        WGRAD_STREAM, BRANCH_STREAMS, FWD_STREAMS = saved
-
-
-class _side:
-    """`with _side(device):` -- run the enclosed launches on the weight-gradient stream, after everything issued so far."""
-
-    def __init__(self, device):
-        self.device = device
-
-    def __enter__(self):
-        if WGRAD_STREAM:
-            st = _wgrad_stream(self.device)
-            st.wait_stream(torch.cuda.current_stream(self.device))
-            self.ctx = torch.cuda.stream(st)
-            self.ctx.__enter__()
-
-    def __exit__(self, *exc):
-        if WGRAD_STREAM:
-            self.ctx.__exit__(*exc)
-
-
-def join_backward_streams(device):
-    """The current stream waits for every backward chain and weight gradient issued so far."""
-    cur = torch.cuda.current_stream(device)
-    for (dev, _), st in list(_BSTREAM.items()) + list(_WSTREAM.items()):
-        if dev == device:
+    def join_backward_streams(self):
+        """The current stream waits for every backward chain and weight gradient issued so far."""
+        cur = torch.cuda.current_stream(self.device)
+        for st in list(self.bstream.values()) + list(self.wstream.values()):
             cur.wait_stream(st)
 
 
-# UGN_AR_OVERLAP=1: data parallelism reduces the gradient in buckets -- the head's as soon as the head's backward is queued,
-# each branch's as soon as that branch's backward is -- so that RCCL moves them over xGMI while the remaining branches still
-# compute.  Default 0 (one all-reduce over the whole flat buffer after the backward pass): the convolution kernels are
-# persistent launches of exactly one workgroup per CU that own the CU's whole LDS, so every CU an RCCL channel holds sends one
-# of their workgroups into a second round, and whether the hidden 0.3-0.5 ms outweigh that could not be measured on the
-# single-GPU boxes this round ran on.
-AR_OVERLAP = os.environ.get("UGN_AR_OVERLAP", "0") == "1"
-
-# UGN_HEAD_SIDE=0: the classification head's forward on the main stream, behind the triplet kernel, instead of beside it.
-HEAD_SIDE = os.environ.get("UGN_HEAD_SIDE", "1") == "1"
-
-# UGN_ROUTED=1: form the set-max gradient inside the a3 / a5 data-gradient epilogues instead of materialising it with
-# setmax_bwd (bit-identical; measured 2.5 % SLOWER on MI355X: three operand loads per element make those epilogues spill).
-ROUTED = USE_WINOGRAD and os.environ.get("UGN_ROUTED", "0") == "1"
-# UGN_SET_ROUTED=0: the set-pooling gradients of the fp32-tensor paths find the maximum frames by reading the frames again (rounds 1-4;
-# same results); default: the forward pass writes routing words and the gradients read those (csrc/pool_set.hip, merged path, l <= 32)
-SET_ROUTED_F32 = os.environ.get("UGN_SET_ROUTED", "1") != "0"
+@contextlib.contextmanager
+def serial_launches(core):
+    """Every launch of `core` on ONE stream (no weight-gradient / branch / forward side streams) while the context is active: the
+    per-kernel durations bench.py's roofline pass and the rocprofv3 kernel-trace summaries quote.  Results are unchanged."""
+    with core.serial_launches():
+        yield
 
 
 def glorot_uniform(gen, shape):
@@ -204,13 +146,15 @@ class ParamStore:
 class Encoder:
     """One modality branch: build_gaitset_branch (nets/mj_uwyhNets_ba.py:419-484), forward and backward."""
 
-    def __init__(self, store, prefix, cin, bf16=False):
+    def __init__(self, store, prefix, cin, bf16=False, cfg=None, launch=None):
         self.store, self.prefix, self.cin = store, prefix, cin
+        self.cfg = DEFAULTS if cfg is None else cfg              # the owning core's settings (a stand-alone encoder: the defaults)
+        self.launch = _Launch(self.cfg, store.device) if launch is None else launch
         # bf16: the 3x3 convolutions, data gradients and weight gradients multiply bf16-rounded Winograd-domain
         # operands (fp32 accumulate, fp32 tensors); the 5x5 layer and everything else stay fp32 (DESIGN section 4)
         self.bf16 = bool(bf16)
-        if self.bf16 and not (USE_WINOGRAD and PAIR_LAUNCHES and not ROUTED):
-            raise ValueError("conv_precision='bf16' needs the default Winograd pair-launch path")
+        if self.bf16:
+            raise ValueError("the bf16-operand Winograd kernels on fp32 tensors were retired in round 5 (conv_precision='bf16' is configs[4])")
         self.x3 = False    # 3x3 layers on the x3 kernels (GaitCore(conv_precision="f32x3")): fp32 tensors, three-way bf16 split
         self.xf = {}       # x3: packed filter planes, forward
         self.xd = {}       # x3: packed filter planes, data gradient
@@ -220,6 +164,9 @@ class Encoder:
         self.act = None    # saved activations of the last forward
         self.shape = None
         self.scratch = {}
+
+    def _wgrad3x3(self, *a, **kw):
+        return (ops.conv3x3_wgrad_wino if self.cfg.use_winograd else ops.conv3x3_wgrad)(*a, **kw)
 
     def W(self, name):
         return self.store.p[self.prefix + name]
@@ -257,7 +204,7 @@ class Encoder:
         """Refresh the kernel-ready copies of the 3x3 weights (after every optimizer step)."""
         if self.x3:
             x3.pack_multi(self.x3_pack_jobs())
-        elif USE_WINOGRAD:
+        elif self.cfg.use_winograd:
             ops.wino_pack_multi(self.pack_jobs(), bf16=self.bf16)
         else:
             for name, k, _, _, _, _ in CONV_SPECS:
@@ -266,13 +213,13 @@ class Encoder:
 
     def conv(self, name, x, pool, out, idx=None):
         """3x3 conv + LeakyReLU (+ MaxPool) of layer `name`."""
-        if USE_WINOGRAD:
+        if self.cfg.use_winograd:
             return ops.conv3x3_fwd_wino(x, self.uf[name], self.W(name).shape[3], pool, out, idx, bf16=self.bf16)
         return ops.conv3x3_fwd(x, self.wp[name], pool, out, idx)
 
     def dgrad(self, name, dz, hw, **kw):
         """Data gradient of layer `name` (fused epilogue options as in ops.conv3x3_dgrad)."""
-        if USE_WINOGRAD and name in WINO_DGRAD:
+        if self.cfg.use_winograd and name in WINO_DGRAD:
             w = self.W(name)
             return ops.conv3x3_dgrad_wino(dz, self.ud[name], hw, w.shape[2], w.shape[3], bf16=self.bf16, **kw)
         return ops.conv3x3_dgrad(dz, self.W(name), hw, **kw)
@@ -281,14 +228,14 @@ class Encoder:
     # Alone such a launch fills a fraction of the CUs, so the Winograd kernels take the frame-level layer and its set-level
     # twin (a3|b1, a4|b2, a5|b3, a6|b4) as two jobs of ONE launch wherever the data dependencies allow it.
     def conv_pair(self, names, xs, pool, outs, idxs=None):
-        if USE_WINOGRAD and PAIR_LAUNCHES:
+        if self.cfg.use_winograd and self.cfg.pair_launches:
             return ops.conv3x3_fwd_wino_pair(list(xs), [self.uf[n] for n in names], self.W(names[0]).shape[3], pool, list(outs),
                                              list(idxs) if pool else None, bf16=self.bf16)
         res = [self.conv(n, x, pool, o, i) for n, x, o, i in zip(names, xs, outs, idxs or (None, None))]
         return ([r[0] for r in res], [r[1] for r in res]) if pool else res
 
     def dgrad_pair(self, names, dzs, hw, outs, dz_idxs=None, acts=None):
-        if USE_WINOGRAD and PAIR_LAUNCHES:
+        if self.cfg.use_winograd and self.cfg.pair_launches:
             w = self.W(names[0])
             return ops.conv3x3_dgrad_wino_pair(list(dzs), [self.ud[n] for n in names], hw, w.shape[2], w.shape[3], list(outs),
                                                dz_idxs=dz_idxs, acts=acts, bf16=self.bf16)
@@ -296,10 +243,10 @@ class Encoder:
                            out=outs[k]) for k, (n, dz) in enumerate(zip(names, dzs))]
 
     def wgrad_pair(self, names, xs, dzs, cout, dz_idxs=None):
-        if USE_WINOGRAD and PAIR_LAUNCHES:
+        if self.cfg.use_winograd and self.cfg.pair_launches:
             return ops.conv3x3_wgrad_wino_pair(list(xs), list(dzs), cout, [self.G(n) for n in names], dz_idxs=dz_idxs,
                                                bf16=self.bf16)
-        return [_wgrad3x3(x, dz, cout, dz_idx=None if dz_idxs is None else dz_idxs[k], dw=self.G(n))
+        return [self._wgrad3x3(x, dz, cout, dz_idx=None if dz_idxs is None else dz_idxs[k], dw=self.G(n))
                 for k, (n, x, dz) in enumerate(zip(names, xs, dzs))]
 
     def _buf(self, pool, key, shape, dtype=F32):
@@ -317,17 +264,17 @@ class Encoder:
             self.act, self.shape = {}, (b, l)
         A = self.act
         U8 = torch.uint8
-        if not (self.uf if USE_WINOGRAD else self.wp):
+        if not (self.uf if self.cfg.use_winograd else self.wp):
             self.repack()
         xf = x.reshape(n, 60, 60, self.cin)
         A["x"] = xf
         # a1's LeakyReLU' factor travels as one bit per element: the a2 data gradient then skips re-reading a1 (315 MB per
         # modality) and the 5x5 weight gradient applies the factor while it multiplies
         a1 = ops.conv5x5_in_fwd(xf, self.W("a1"), self._buf(A, "a1", (n, 64, 64, 32)),
-                                sign=self._buf(A, "a1s", (n, 64, 64), torch.int32) if A1_SIGN_BITS else None)
+                                sign=self._buf(A, "a1s", (n, 64, 64), torch.int32) if self.cfg.a1_sign_bits else None)
         p2, i2 = self.conv("a2", a1, True, self._buf(A, "p2", (n, 32, 32, 32)),
                                  self._buf(A, "i2", (n, 32, 32, 32), U8))
-        if ROUTED:   # also count the maxima: the set-max gradient is then formed inside the a3 / a5 data-gradient epilogues
+        if self.cfg.routed:   # also count the maxima: the set-max gradient is then formed inside the a3 / a5 data-gradient epilogues
             m1, _ = ops.setmax_fwd_cnt(p2, b, l, m=self._buf(A, "m1", (b, 32, 32, 32)), cnt=self._buf(A, "c1", (b, 32, 32, 32)))
         else:
             m1 = ops.setmax_fwd(p2, b, l, m=self._buf(A, "m1", (b, 32, 32, 32)))
@@ -336,7 +283,7 @@ class Encoder:
         (p4, q2), (i4, j2) = self.conv_pair(("a4", "b2"), (a3, b1), True,
                                             (self._buf(A, "p4", (n, 16, 16, 64)), self._buf(A, "q2", (b, 16, 16, 64))),
                                             (self._buf(A, "i4", (n, 16, 16, 64), U8), self._buf(A, "j2", (b, 16, 16, 64), U8)))
-        if ROUTED:
+        if self.cfg.routed:
             _, s2, _ = ops.setmax_fwd_cnt(p4, b, l, addend=q2, m=self._buf(A, "m2", (b, 16, 16, 64)),
                                           sum_out=self._buf(A, "s2", (b, 16, 16, 64)), cnt=self._buf(A, "c2", (b, 16, 16, 64)))
         else:
@@ -365,14 +312,14 @@ class Encoder:
         # block 3 of the frame stack (a5, a6) with block 2 of the global branch (b3, b4)
         dz6 = ops.setmax_bwd(A["a6"], dm3, b, l, True, buf("dz6", (n, 16, 16, 128)))
         dev = self.store.device
-        with _side(dev):
+        with self.launch.side():
             self.wgrad_pair(("a6", "b4"), (A["a5"], A["b3"]), (dz6, dzb4), 128)
         dz5, dzb3 = self.dgrad_pair(("a6", "b4"), (dz6, dzb4), 16,
                                     (buf("dz5", (n, 16, 16, 128)), buf("dzb3", (b, 16, 16, 128))), acts=(A["a5"], A["b3"]))
-        with _side(dev):
+        with self.launch.side():
             self.wgrad_pair(("a5", "b3"), (A["p4"], A["s2"]), (dz5, dzb3), 128)
         ds2 = buf("ds2", (b, 16, 16, 64))
-        if USE_WINOGRAD and PAIR_LAUNCHES and not ROUTED:
+        if self.cfg.use_winograd and self.cfg.pair_launches and not self.cfg.routed:
             # Both data gradients of the pair run with a PLAIN epilogue in one launch; what the frame-level one still needs
             # (+ set-max gradient of p4, * LeakyReLU'(p4)) is applied by the set-max backward pass, what the set-level one
             # needs (* LeakyReLU'(q2), the raw copy for the set-max path) by a tiny elementwise kernel.
@@ -381,11 +328,11 @@ class Encoder:
             dp4 = ops.setmax_bwd(A["p4"], ds2, b, l, True, out=raw4, addend=raw4)
         else:
             dq2 = self.dgrad("b3", dzb3, 16, act=A["q2"], out=buf("dq2", (b, 16, 16, 64)), raw_out=ds2)
-            if ROUTED:
+            if self.cfg.routed:
                 dms2 = ops.div(ds2, A["c2"], buf("dms2", (b, 16, 16, 64)))   # dL/dm2 / #maxima (TF reduce_max gradient)
                 dp4 = ops.conv3x3_dgrad_wino_routed(dz5, self.ud["a5"], 16, 64, 128, A["p4"], A["m2"], dms2, l,
                                                     out=buf("g4", (n, 16, 16, 64)))
-            elif USE_WINOGRAD:
+            elif self.cfg.use_winograd:
                 raw4 = self.dgrad("a5", dz5, 16, out=buf("g4", (n, 16, 16, 64)))
                 dp4 = ops.setmax_bwd(A["p4"], ds2, b, l, True, out=raw4, addend=raw4)
             else:
@@ -393,38 +340,38 @@ class Encoder:
                 dp4 = self.dgrad("a5", dz5, 16, act=A["p4"], addend=g4, out=g4)  # in place over the addend
         # block 2 (a3, a4) with block 1 of the global branch (b1, b2); a4 / b2 are pooled: dp4 / dq2 are their gradients at
         # pooled resolution, routed through the argmax maps i4 / j2
-        with _side(dev):
+        with self.launch.side():
             self.wgrad_pair(("a4", "b2"), (A["a3"], A["b1"]), (dp4, dq2), 64, dz_idxs=(A["i4"], A["j2"]))
         dz3, dzb1 = self.dgrad_pair(("a4", "b2"), (dp4, dq2), 32,
                                     (buf("dz3", (n, 32, 32, 64)), buf("dzb1", (b, 32, 32, 64))),
                                     dz_idxs=(A["i4"], A["j2"]), acts=(A["a3"], A["b1"]))
-        with _side(dev):
+        with self.launch.side():
             self.wgrad_pair(("a3", "b1"), (A["p2"], A["m1"]), (dz3, dzb1), 64)
-        if USE_WINOGRAD and PAIR_LAUNCHES and not ROUTED:
+        if self.cfg.use_winograd and self.cfg.pair_launches and not self.cfg.routed:
             raw2, dm1 = self.dgrad_pair(("a3", "b1"), (dz3, dzb1), 32, (buf("g2", (n, 32, 32, 32)), buf("dm1", (b, 32, 32, 32))))
             dp2 = ops.setmax_bwd(A["p2"], dm1, b, l, True, out=raw2, addend=raw2)
         else:
             dm1 = self.dgrad("b1", dzb1, 32, out=buf("dm1", (b, 32, 32, 32)))
-            if ROUTED:
+            if self.cfg.routed:
                 dms1 = ops.div(dm1, A["c1"], buf("dms1", (b, 32, 32, 32)))
                 dp2 = ops.conv3x3_dgrad_wino_routed(dz3, self.ud["a3"], 32, 32, 64, A["p2"], A["m1"], dms1, l,
                                                     out=buf("g2", (n, 32, 32, 32)))
-            elif USE_WINOGRAD:
+            elif self.cfg.use_winograd:
                 raw2 = self.dgrad("a3", dz3, 32, out=buf("g2", (n, 32, 32, 32)))
                 dp2 = ops.setmax_bwd(A["p2"], dm1, b, l, True, out=raw2, addend=raw2)
             else:
                 g2 = ops.setmax_bwd(A["p2"], dm1, b, l, False, buf("g2", (n, 32, 32, 32)))
                 dp2 = self.dgrad("a3", dz3, 32, act=A["p2"], addend=g2, out=g2)
         # block 1 (a1, a2)
-        with _side(dev):
-            _wgrad3x3(A["a1"], dp2, 32, dz_idx=A["i2"], dw=self.G("a2"), **({"bf16": True} if self.bf16 else {}))
-        if A1_SIGN_BITS:
+        with self.launch.side():
+            self._wgrad3x3(A["a1"], dp2, 32, dz_idx=A["i2"], dw=self.G("a2"), **({"bf16": True} if self.bf16 else {}))
+        if self.cfg.a1_sign_bits:
             dz1 = self.dgrad("a2", dp2, 64, dz_idx=A["i2"], out=buf("dz1", (n, 64, 64, 32)))   # dL/da1
-            with _side(dev):
+            with self.launch.side():
                 ops.conv5x5_in_wgrad(A["x"], dz1, self.G("a1"), sign=A["a1s"])
         else:
             dz1 = self.dgrad("a2", dp2, 64, dz_idx=A["i2"], act=A["a1"], out=buf("dz1", (n, 64, 64, 32)))
-            with _side(dev):
+            with self.launch.side():
                 ops.conv5x5_in_wgrad(A["x"], dz1, self.G("a1"))
 
 
@@ -433,12 +380,6 @@ class Encoder:
 # set-level twin of every modality as up to six jobs of one launch: a third of the convolution launches of a step (what a
 # 5-clip-per-GPU step of the 8-GPU C4 split mostly consists of), items of all modalities in one work list (no per-modality
 # tail), and no need for side streams in the forward pass.
-MERGE_MODALITIES = os.environ.get("UGN_MERGE", "1") != "0"
-
-
-def _merged_ok():
-    return MERGE_MODALITIES and USE_WINOGRAD and PAIR_LAUNCHES and not ROUTED
-
 
 class _Conv3:
     """The 3x3 kernel set the merged forward / backward passes run on: Winograd on the fp32 MFMA (ops.*_wino_multi, transformed
@@ -470,7 +411,7 @@ class _Conv3:
 def forward_merged(encs, xs):
     """Encoder.forward of several modality branches in lockstep: [x_m [B_m,L,60,60,C_m]] -> [[62,B_m,256]]."""
     U8 = torch.uint8
-    C3 = _Conv3(encs[0])
+    C3, cfg = _Conv3(encs[0]), encs[0].cfg
     geo = []
     for e, x in zip(encs, xs):
         b, l = x.shape[0], x.shape[1]
@@ -487,7 +428,7 @@ def forward_merged(encs, xs):
         xf = x.reshape(n, 60, 60, e.cin)
         e.act["x"] = xf
         a1s.append(ops.conv5x5_in_fwd(xf, e.W("a1"), B(e, e.act, "a1", (n, 64, 64, 32)),
-                                      sign=B(e, e.act, "a1s", (n, 64, 64), torch.int32) if A1_SIGN_BITS else None))
+                                      sign=B(e, e.act, "a1s", (n, 64, 64), torch.int32) if cfg.a1_sign_bits else None))
     hook = getattr(encs[0], "before_conv3", None)     # (a filter repack queued on the second stream: GaitCore.apply_gradients)
     if hook is not None:
         hook()
@@ -495,7 +436,7 @@ def forward_merged(encs, xs):
                       [B(e, e.act, "i2", (g[2], 32, 32, 32), U8) for e, g in zip(encs, geo)])
     bs, l0 = [g[0] for g in geo], geo[0][1]
     assert all(g[1] == l0 for g in geo), "the modalities of a batch share the set length"
-    routed = SET_ROUTED_F32 and l0 <= 32
+    routed = cfg.set_routed and l0 <= 32
     RW = lambda key, hw, c: [B(e, e.act, key, (g[0], hw * hw * c // 4, 2, 4), torch.int32) for e, g in zip(encs, geo)]
 
     def setmax(key, ps, ms, hw, c, addends=None, sum_outs=None):
@@ -533,7 +474,7 @@ def forward_merged(encs, xs):
 
 def backward_merged(encs, douts, scratches):
     """Encoder.backward of several modality branches in lockstep (same arithmetic, one launch per layer for all of them)."""
-    C3 = _Conv3(encs[0])
+    C3, cfg, side = _Conv3(encs[0]), encs[0].cfg, encs[0].launch.side
     dev = encs[0].store.device
     geo = [(e.shape[0], e.shape[1], e.shape[0] * e.shape[1]) for e in encs]
     A = [e.act for e in encs]
@@ -553,7 +494,7 @@ def backward_merged(encs, douts, scratches):
     dz6 = setmax_bwd("r3", "a6", dm3, [buf(i, "dz6", (geo[i][2], 16, 16, 128)) for i in R])
 
     def wgrad(na, nb, xa, xb, dza, dzb, cout, ia=None, ib=None):
-        with _side(dev):
+        with side():
             C3.wgrad(list(xa) + list(xb), list(dza) + list(dzb), cout, [e.G(na) for e in encs] + [e.G(nb) for e in encs],
                      dz_idxs=None if ia is None else list(ia) + list(ib))
 
@@ -584,13 +525,13 @@ def backward_merged(encs, douts, scratches):
     dp2 = setmax_bwd("r1", "p2", dm1, raw2, addends=raw2)
     # block 1 (a1, a2)
     i2 = [a["i2"] for a in A]
-    with _side(dev):
+    with side():
         C3.wgrad([a["a1"] for a in A], dp2, 32, [e.G("a2") for e in encs], dz_idxs=i2)
     dz1 = C3.dgrad(encs, ("a2",), dp2, 64, 32, 32, [buf(i, "dz1", (geo[i][2], 64, 64, 32)) for i in R],
-                   dz_idxs=i2, acts=None if A1_SIGN_BITS else [a["a1"] for a in A])
-    with _side(dev):
+                   dz_idxs=i2, acts=None if cfg.a1_sign_bits else [a["a1"] for a in A])
+    with side():
         for i, e in enumerate(encs):
-            ops.conv5x5_in_wgrad(A[i]["x"], dz1[i], e.G("a1"), sign=A[i]["a1s"] if A1_SIGN_BITS else None)
+            ops.conv5x5_in_wgrad(A[i]["x"], dz1[i], e.G("a1"), sign=A[i]["a1s"] if cfg.a1_sign_bits else None)
 
 
 class GaitCore:
@@ -599,7 +540,7 @@ class GaitCore:
     def __init__(self, in_channels, nclasses=0, multimodal=None, fuse_mode="sign_max", margin=0.2,
                  loss_weights=(1.0, 1.0), device=None, seed=None, lr=1e-4, beta_1=0.9, beta_2=0.999, epsilon=1e-7,
                  process_group=None, world_size=1, skip_masked=False, dp_mode="replica", conv_precision=None,
-                 force_collectives=False, triplet_mode="all"):
+                 force_collectives=False, triplet_mode="all", config=None):
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         self.in_channels = tuple(int(c) for c in in_channels)
         self.nmod = len(self.in_channels)
@@ -648,14 +589,18 @@ class GaitCore:
         # "f32": Winograd fp32 MFMA kernels; "bf16": the same with bf16-rounded MFMA operands; "h2": activations / gradients
         # between the 3x3 layers held as split-fp16 halves + block exponent, 3x3 layers on the f16 matrix pipe at fp32-class
         # accuracy (engine_h2.py, csrc/mm_common.h)
-        conv_precision = DEFAULT_PRECISION if conv_precision is None else conv_precision
-        if conv_precision not in ("f32x3", "f32", "bf16", "bf16w", "h2"):
-            raise ValueError("conv_precision must be 'f32x3', 'f32', 'h2', 'bf16' or 'bf16w', got %r" % (conv_precision,))
+        base = DEFAULTS if config is None else config
+        conv_precision = base.conv_precision if conv_precision is None else conv_precision
+        # this core's OWN copy of the settings (ugaitnet_amd/config.py) and its own streams: nothing process-wide
+        self.cfg = base.replace(conv_precision=conv_precision)
+        self.launch = _Launch(self.cfg, self.device)
+        if conv_precision not in ("f32x3", "f32", "bf16", "h2"):     # ('bf16w', Winograd with bf16-rounded operands on fp32 tensors: retired)
+            raise ValueError("conv_precision must be 'f32x3', 'f32', 'h2' or 'bf16', got %r" % (conv_precision,))
         self.conv_precision = conv_precision
         self.h2 = conv_precision == "h2"
         self.bf = conv_precision == "bf16"
         self.x3 = conv_precision == "f32x3"
-        if self.x3 and not (USE_WINOGRAD and PAIR_LAUNCHES and not ROUTED and MERGE_MODALITIES and A1_SIGN_BITS):
+        if self.x3 and not (self.cfg.merged_ok() and self.cfg.a1_sign_bits):
             raise ValueError("conv_precision='f32x3' runs on the merged one-launch-per-layer path (UGN_WINO / UGN_PAIR / UGN_MERGE / "
                              "UGN_A1_BITS at their defaults, UGN_ROUTED off)")
         if (self.h2 or self.bf or self.x3) and self.nmod > 3:
@@ -664,8 +609,7 @@ class GaitCore:
             # modalities (nets/mj_uwyhNets_ba.py:1031-1299)
             raise ValueError("conv_precision=%r takes at most 3 modalities (6 jobs per launch), got %d; use conv_precision='f32' with "
                              "UGN_MERGE=0" % (conv_precision, self.nmod))
-        self.encoders = [Encoder(self.store, "m%d." % mi, cin, bf16=conv_precision == "bf16w")
-                         for mi, cin in enumerate(self.in_channels)]
+        self.encoders = [Encoder(self.store, "m%d." % mi, cin, cfg=self.cfg, launch=self.launch) for mi, cin in enumerate(self.in_channels)]
         for enc in self.encoders:
             enc.x3 = self.x3
         if self.bf:
@@ -674,9 +618,9 @@ class GaitCore:
         if self.h2:
             # UGN_PERSISTENT_WGS=n (< 256): the persistent launches leave 256 - n CUs free -- room for RCCL's channels when the
             # bucketed all-reduce (UGN_AR_OVERLAP=1) overlaps the backward pass.  Results do not depend on it (tests/test_mm_gpu.py).
-            if os.environ.get("UGN_PERSISTENT_WGS"):
-                h2.set_persistent_wgs(int(os.environ["UGN_PERSISTENT_WGS"]))
-            elif self.world > 1 and AR_OVERLAP:
+            if self.cfg.persistent_wgs:
+                h2.set_persistent_wgs(int(self.cfg.persistent_wgs))
+            elif self.world > 1 and self.cfg.ar_overlap:
                 # the bucketed all-reduce runs BESIDE the rest of the backward pass: leave RCCL's channels 32 of the 256 CUs
                 # (every persistent launch of the library -- forward / data gradient, weight gradients, the 5x5 layer -- then
                 # starts 224 workgroups or the matching number of groups; unmeasured on multi-GPU hardware: UGN_PERSISTENT_WGS overrides)
@@ -702,6 +646,17 @@ class GaitCore:
         self._buckets = list(zip(starts, ends))
         self._ar_pending = None     # work handles of the bucket all-reduces of the current step
         self.init_weights(seed)
+
+    @contextlib.contextmanager
+    def serial_launches(self):
+        """Every launch of THIS core on one stream (no weight-gradient / branch / forward side streams) while the context is active: the
+        per-kernel durations bench.py's roofline pass and the rocprofv3 kernel-trace summaries quote.  Results are unchanged."""
+        saved = (self.cfg.wgrad_stream, self.cfg.branch_streams, self.cfg.fwd_streams)
+        self.cfg.wgrad_stream, self.cfg.branch_streams, self.cfg.fwd_streams = False, False, 0
+        try:
+            yield
+        finally:
+            self.cfg.wgrad_stream, self.cfg.branch_streams, self.cfg.fwd_streams = saved
 
     # ---- parameters -------------------------------------------------------------------------------------
     def init_weights(self, seed=None):
@@ -734,7 +689,7 @@ class GaitCore:
         if self.x3:          # the three bf16 planes of every 3x3 filter, both directions: one launch for all branches
             x3.pack_multi([j for e in self.encoders for j in e.x3_pack_jobs()])
             return
-        if USE_WINOGRAD:     # one launch for the filters of all branches
+        if self.cfg.use_winograd:     # one launch for the filters of all branches
             jobs = [j for e in self.encoders for j in e.pack_jobs()]
             ops.wino_pack_multi(jobs, bf16=self.encoders[0].bf16)
             return
@@ -749,7 +704,7 @@ class GaitCore:
         in IEEE fp32, where an embedding does not depend on the other clips of the batch beyond what the reference's own
         batch-axis normalisation does.  Parameters must not change inside the block (the f16x2 / bf16 filter packs stay valid)."""
         if precision is None or precision == self.conv_precision or self.conv_precision not in ("h2", "bf16"):   # (f32x3: IEEE fp32 tensors already)
-            yield                   # (fp32 models, and the fp32-tensor 'bf16w' mode, answer in their own arithmetic)
+            yield                   # (fp32-tensor models answer in their own arithmetic)
             return
         if precision != "f32":
             raise ValueError("arithmetic(%r): only 'f32' inside an 'h2' / 'bf16' model" % (precision,))
@@ -833,7 +788,7 @@ class GaitCore:
         xs = [self._dev(x) for x in xs]
         b = xs[0].shape[0]
         self._active = None
-        merged = (_merged_ok() and len(self.encoders) > 1) or self.h2 or self.bf or self.x3
+        merged = (self.cfg.merged_ok() and len(self.encoders) > 1) or self.h2 or self.bf or self.x3
         if self.h2:
             self.meta_pool.reset()      # every H2 meta of the step gathers its maximum from zero: one memset
         fwd_many = forward_h2 if self.h2 else (forward_bf if self.bf else forward_merged)
@@ -865,17 +820,17 @@ class GaitCore:
                     outs[mi].index_copy_(1, idx, o)
         elif merged:
             outs = fwd_many(self.encoders, xs)
-        elif FWD_STREAMS and len(self.encoders) > 1:
+        elif self.cfg.fwd_streams and len(self.encoders) > 1:
             main = torch.cuda.current_stream(self.device)
             outs = [None] * len(self.encoders)
             for mi in range(1, len(self.encoders)):
-                st = _branch_stream(self.device, 100 + (mi % FWD_STREAMS))
+                st = self.launch.branch_stream(100 + (mi % self.cfg.fwd_streams))
                 st.wait_stream(main)
                 with torch.cuda.stream(st):
                     outs[mi] = self.encoders[mi].forward(xs[mi])
             outs[0] = self.encoders[0].forward(xs[0])
             for mi in range(1, len(self.encoders)):
-                main.wait_stream(_branch_stream(self.device, 100 + (mi % FWD_STREAMS)))
+                main.wait_stream(self.launch.branch_stream(100 + (mi % self.cfg.fwd_streams)))
         else:
             outs = [enc.forward(x) for enc, x in zip(self.encoders, xs)]
         self.last_b = b
@@ -885,7 +840,7 @@ class GaitCore:
             self.sig = dp.gather_batch_axis(outs[0], 1, self.pg, check=False, force=self.force) if gather else outs[0]
             return self.sig
         self.uses = [self._dev(u, (b,)) for u in uses]
-        if not gather and GATE_NORM_FUSED and b <= ops.GATE_NORM_MAXB:
+        if not gather and self.cfg.gate_norm_fused and b <= ops.GATE_NORM_MAXB:
             # gate / fMerge and the normalisation over the (local) batch in one launch: same results, one launch and one round trip less
             self.fused, self.sel, self.sig = ops.gate_norm_fwd(outs, self.uses, self.fuse_mode, self._buf("fused", (NBINS, b, HIDDEN)),
                                                                self._buf("sel", (NBINS, b, HIDDEN), torch.uint8),
@@ -932,19 +887,19 @@ class GaitCore:
             labels, onehot = self._gather_targets(labels, onehot)
         sig = self.forward(xs, uses, gather=self.global_batch)
         b = sig.shape[1]
-        self._ar_pending = [] if (self.dp_active and AR_OVERLAP and not BRANCH_STREAMS) else None
+        self._ar_pending = [] if (self.dp_active and self.cfg.ar_overlap and not self.cfg.branch_streams) else None
         w_tri, w_id = self.loss_weights
         if self.nclasses > 0:
             # the classification head's forward (two small kernels) runs on the side stream, beside the triplet kernel: both
             # only read the signature; the head's backward ADDS to the triplet's signature gradient, so it waits for both
             oh = self._dev(onehot, (b, self.nclasses))
-            with (_side(self.device) if HEAD_SIDE else contextlib.nullcontext()):
+            with (self.launch.side() if self.cfg.head_side else contextlib.nullcontext()):
                 self.head = ops.head_fwd(sig, self.store.p["head.wc"], self.store.p["head.bc"], oh, w_id / b,
                                          self._head_bufs(b))
         self.bin_loss, self.bin_num, dsig = self._triplet(sig, labels, w_tri)
         if self.nclasses > 0:
-            if WGRAD_STREAM and HEAD_SIDE:
-                torch.cuda.current_stream(self.device).wait_stream(_wgrad_stream(self.device))
+            if self.cfg.wgrad_stream and self.cfg.head_side:
+                torch.cuda.current_stream(self.device).wait_stream(self.launch.wgrad_stream())
             ops.head_bwd(sig, self.store.p["head.wc"], self.head["dlogits"], dsig, True, self.store.g["head.wc"],
                          self.store.g["head.bc"])
             if self.global_batch:   # every replica holds the head gradient of the whole batch; the all-reduce sums them
@@ -958,7 +913,7 @@ class GaitCore:
             return
         bl, lo = self.last_b, self.row0
         own = (lambda t: t[:, lo:lo + bl].contiguous()) if self.global_batch else (lambda t: t)
-        if self.multimodal and not self.global_batch and GATE_NORM_FUSED and b <= ops.GATE_NORM_MAXB:
+        if self.multimodal and not self.global_batch and self.cfg.gate_norm_fused and b <= ops.GATE_NORM_MAXB:
             douts = ops.gate_norm_bwd(self.fused, sig, dsig, self.sel, self.uses, self.fuse_mode,
                                       [self._buf("dout%d" % m, (NBINS, bl, HIDDEN)) for m in range(self.nmod)])
         elif self.multimodal:
@@ -967,7 +922,7 @@ class GaitCore:
                                       [self._buf("dout%d" % m, (NBINS, bl, HIDDEN)) for m in range(self.nmod)])
         else:
             douts = [own(dsig)]
-        if self.h2 or self.bf or self.x3 or (_merged_ok() and self.nmod > 1 and not BRANCH_STREAMS):
+        if self.h2 or self.bf or self.x3 or (self.cfg.merged_ok() and self.nmod > 1 and not self.cfg.branch_streams):
             encs, ds = [], []
             for mi, (enc, d) in enumerate(zip(self.encoders, douts)):
                 idx = self._active[mi] if self._active is not None else None
@@ -982,22 +937,22 @@ class GaitCore:
                     ds.append(d.index_select(1, idx).contiguous())
             if self.h2 or self.bf:
                 if encs:
-                    (backward_h2 if self.h2 else backward_bf)(encs, ds, _side)
+                    (backward_h2 if self.h2 else backward_bf)(encs, ds, self.launch.side)
             elif len(encs) > 1 or (self.x3 and encs):
                 backward_merged(encs, ds, [self.scratch.setdefault(self.encoders.index(e), {}) for e in encs])
             elif encs:
                 encs[0].backward(ds[0], self.scratch.setdefault(self.encoders.index(encs[0]), {}))
             for mi in range(self.nmod):
                 self._reduce_bucket(mi)
-            join_backward_streams(self.device)
+            self.launch.join_backward_streams()
             return
         main = torch.cuda.current_stream(self.device)
         for mi, (enc, d) in enumerate(zip(self.encoders, douts)):
             idx = self._active[mi] if self._active is not None else None
             # (frame-sized gradient scratch per branch: the branches' backward chains overlap)
             scratch = self.scratch.setdefault(mi, {})
-            if BRANCH_STREAMS and mi > 0:
-                st = _branch_stream(self.device, mi)
+            if self.cfg.branch_streams and mi > 0:
+                st = self.launch.branch_stream(mi)
                 st.wait_stream(main)           # the fusion gradient is ready
                 ctx = torch.cuda.stream(st)
             else:
@@ -1011,7 +966,7 @@ class GaitCore:
                 else:
                     enc.backward(d.index_select(1, idx).contiguous(), scratch)
             self._reduce_bucket(mi)
-        join_backward_streams(self.device)
+        self.launch.join_backward_streams()
 
     def forward_loss_only(self, xs, uses, labels, onehot):
         """Validation step: forward + both losses/metrics, no parameter gradients."""
@@ -1029,7 +984,7 @@ class GaitCore:
         if self._ar_pending is None:
             return
         lo, hi = self._buckets[k]
-        with _side(self.device):    # the weight-gradient stream, ordered after the main stream's work up to here
+        with self.launch.side():    # the weight-gradient stream, ordered after the main stream's work up to here
             w = dp.allreduce_sum_async(self.store.grad[lo:hi], self.pg, force=self.force)
         if w is not None:
             self._ar_pending.append(w)
@@ -1065,10 +1020,10 @@ class GaitCore:
             ops.adam_step(st.flat[lo:hi], st.grad[lo:hi], st.m[lo:hi], st.v[lo:hi], lr_t, self.beta_1, self.beta_2, self.epsilon, scale)
             return                      # (the convolution filters did not change: no repack)
         ops.adam_step(st.flat, st.grad, st.m, st.v, lr_t, self.beta_1, self.beta_2, self.epsilon, scale)
-        if (self.h2 or self.bf or self.x3) and WGRAD_STREAM and PACK_ON_SIDE_STREAM and not torch.cuda.is_current_stream_capturing():
+        if (self.h2 or self.bf or self.x3) and self.cfg.wgrad_stream and self.cfg.pack_on_side_stream and not torch.cuda.is_current_stream_capturing():
             # the repack of the 3x3 filters (3 launches, ~50 us whatever the batch) runs on the second stream, beside the next
             # step's input copies and 5x5 layer; the first 3x3 layer waits for it (`_before_conv3`)
-            with _side(self.device):
+            with self.launch.side():
                 self.weights_changed()
                 ev = torch.cuda.Event()
                 ev.record(torch.cuda.current_stream(self.device))
@@ -1106,9 +1061,9 @@ class GraphedTrainStep:
     `step()` copies the new batch into the captured buffers and replays; a batch of another geometry raises ValueError."""
 
     def __init__(self, core, xs, uses, labels, onehot):
-        if core.skip_masked or core.global_batch or BRANCH_STREAMS:
+        if core.skip_masked or core.global_batch or core.cfg.branch_streams:
             raise ValueError("graph capture needs the dense step with per-replica losses")
-        if AR_OVERLAP and core.world > 1:
+        if core.cfg.ar_overlap and core.world > 1:
             # the bucket all-reduces would be issued inside the capture and a second reduction would follow in step()
             raise ValueError("graph capture and UGN_AR_OVERLAP=1 exclude each other under data parallelism")
         if _lib.PROFILE is not None:
@@ -1124,8 +1079,7 @@ class GraphedTrainStep:
         cur = torch.cuda.current_stream(dev)
         warm = torch.cuda.Stream(device=dev)
         warm.wait_stream(cur)
-        global FWD_STREAMS
-        fwd_streams, FWD_STREAMS = FWD_STREAMS, 0     # the captured forward pass is one chain (the backward keeps its two streams)
+        fwd_streams, core.cfg.fwd_streams = core.cfg.fwd_streams, 0     # the captured forward pass is one chain (the backward keeps its two streams)
         try:
             with torch.cuda.stream(warm):   # allocations, function attributes, triplet lists: all outside the capture
                 for _ in range(2):
@@ -1137,7 +1091,7 @@ class GraphedTrainStep:
             with torch.cuda.graph(self.g_fb):
                 core.forward_backward(self.xs, self.uses, self.labels, self.onehot)
         finally:
-            FWD_STREAMS = fwd_streams
+            core.cfg.fwd_streams = fwd_streams
         core._ar_pending = None     # (bucket all-reduces are not captured: the reduction runs between the two graphs)
         scale = (1.0 / core.world) if core.world > 1 else 1.0
         self.g_up = torch.cuda.CUDAGraph()

@@ -10,7 +10,6 @@ from __future__ import annotations
 import torch
 
 from . import bf16, ops
-from .engine_h2 import SET_ROUTED
 
 F32 = torch.float32
 U8 = torch.uint8
@@ -72,7 +71,7 @@ def forward_bf(encs, xs):
     bf16.conv3x3_fwd_multi(a1s, [s.wf("a2") for s in S], 32, True, p2s, i2s)
     m1s = [S[i].t("m1", (geo[i][0], 32, 32, 32)) for i in R]
     # routing words of the three set poolings (engine_h2.forward_h2): their gradients read these instead of the l frames
-    routes = lambda key, hw, c: [S[i].t(key, (geo[i][0], hw, hw, 2, c), I32) for i in R] if SET_ROUTED and l0 <= 32 else None
+    routes = lambda key, hw, c: [S[i].t(key, (geo[i][0], hw, hw, 2, c), I32) for i in R] if encs[0].cfg.set_routed and l0 <= 32 else None
     bf16.setmax_fwd_multi(p2s, bs, l0, ms=m1s, routes=routes("r1", 32, 32))
 
     def pair_layer(na, nb, xa, xb, cout, hw, pool, ka, kb, ia=None, ib=None):
@@ -108,7 +107,7 @@ def backward_bf(encs, douts, side):
     R = range(k)
     bs, l0 = [g[0] for g in geo], geo[0][1]
     T = lambda key: [s.bufs[key] for s in S]
-    RT = lambda key: T(key) if SET_ROUTED and l0 <= 32 else None       # routing words of a set pooling (forward_bf)
+    RT = lambda key: T(key) if encs[0].cfg.set_routed and l0 <= 32 else None       # routing words of a set pooling (forward_bf)
     fc_args = (T("feat"), [e.W("fc") for e in encs], douts, [e.G("fc") for e in encs],
                                     [S[i].t("dfeat", (NBINS, geo[i][0], FEAT), F32) for i in R])
     ops.binfc_bwd_multi(*fc_args, parts=2)            # dfeat: the rest of the backward pass waits for it

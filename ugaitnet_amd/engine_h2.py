@@ -19,13 +19,12 @@ U8 = torch.uint8
 I16 = torch.int16
 I32 = torch.int32
 NBINS, FEAT, HIDDEN = 62, 128, 256
-# UGN_FUSE_W5=1: the a2 data gradient multiplies its registers with the input patch in place and dL/da1 is never written
+# Settings.fuse_w5 (UGN_FUSE_W5=1): the a2 data gradient multiplies its registers with the input patch in place and dL/da1 is never written
 # (dgrad32_w5_kernel).  Correct (tests/test_engine_gpu.py) but not the default: the fused launch takes 704 us against 469 + 278 for
 # the two it replaces, and those 278 ran on the second stream -- the step got 0.12 ms LONGER (the patch gather and the on-the-fly
 # split of both operands cost more vector instructions than the stores they replace).
-FUSE_W5 = os.environ.get("UGN_FUSE_W5", "0") != "0"
-# UGN_SET_ROUTED=0: the set-pooling gradients find the maximum frames by reading the frames again (the round-3 kernels; same results)
-SET_ROUTED = os.environ.get("UGN_SET_ROUTED", "1") != "0"
+# Settings.set_routed (UGN_SET_ROUTED=0): the set-pooling gradients find the maximum frames by reading the frames again (the round-3
+# kernels; same results).  Both switches are read from the owning core's settings (enc.cfg, ugaitnet_amd/config.py).
 # 3x3 layers: name, cin, cout, spatial size, pooled
 LAYERS3 = (("a2", 32, 32, 64, True), ("b1", 32, 64, 32, False), ("b2", 64, 64, 32, True), ("a3", 32, 64, 32, False),
            ("a4", 64, 64, 32, True), ("b3", 64, 128, 16, False), ("b4", 128, 128, 16, False), ("a5", 64, 128, 16, False),
@@ -47,7 +46,7 @@ class H2State:
 
     def pack_jobs(self):
         jobs = [(self.enc.W(name), self.pk[name][d][0], self.pk[name][d][1], d) for name, *_ in LAYERS3 for d in (0, 1)]
-        if FUSE_W5:     # the fused kernel reads the a2 data-gradient filter in the 32-column block layout: a copy of its own
+        if self.enc.cfg.fuse_w5:     # the fused kernel reads the a2 data-gradient filter in the 32-column block layout: a copy of its own
             if "a2w5" not in self.pk:
                 dev = self.enc.store.device
                 self.pk["a2w5"] = (torch.empty((18 * 32 * 32,), dtype=I16, device=dev), torch.zeros(4, dtype=I32, device=dev))
@@ -109,7 +108,7 @@ def forward_h2(encs, xs):
     m1s = [S[i].t("m1", (geo[i][0], 32, 32, 32)) for i in R]
     # routing words of the three set poolings (which frames hold the maximum / are positive): their gradients read these 8 bytes
     # per set element instead of the l frames again
-    routes = lambda key, hw, c: [S[i].f32(key, (geo[i][0], hw, hw, 2, c), I32) for i in R] if SET_ROUTED and l0 <= 32 else None
+    routes = lambda key, hw, c: [S[i].f32(key, (geo[i][0], hw, hw, 2, c), I32) for i in R] if encs[0].cfg.set_routed and l0 <= 32 else None
     h2.setmax_fwd_h2_multi(p2s, bs, l0, ms=m1s, routes=routes("r1", 32, 32))
 
     def pair_layer(na, nb, xa, xb, cout, hw, pool, ka, kb, ia=None, ib=None):
@@ -150,7 +149,7 @@ def backward_h2(encs, douts, side):
     R = range(k)
     bs, l0 = [g[0] for g in geo], geo[0][1]
     T = lambda key: [s.bufs[key] for s in S]
-    RT = lambda key: T(key) if SET_ROUTED and l0 <= 32 else None       # routing words of a set pooling (forward_h2)
+    RT = lambda key: T(key) if encs[0].cfg.set_routed and l0 <= 32 else None       # routing words of a set pooling (forward_h2)
     fc_args = (T("feat"), [e.W("fc") for e in encs], douts, [e.G("fc") for e in encs],
                                     [S[i].f32("dfeat", (NBINS, geo[i][0], FEAT)) for i in R])
     ops.binfc_bwd_multi(*fc_args, parts=2)            # dfeat: the rest of the backward pass waits for it
@@ -202,7 +201,7 @@ def backward_h2(encs, douts, side):
     i2 = T("i2")
     with side(dev):
         h2.conv3x3_wgrad_mm_multi(T("a1"), dp2, 32, [e.G("a2") for e in encs], dz_idxs=i2)
-    if FUSE_W5:
+    if encs[0].cfg.fuse_w5:
         # dL/da1 has one consumer, the 5x5 layer's weight gradient: the a2 data gradient multiplies its registers with the input
         # patch in place (dgrad32_w5_kernel) -- 0.94 GB per step neither written nor read back, three launches fewer
         h2.dgrad32_wgrad5_multi(dp2, i2, [s.pk["a2w5"][0] for s in S], [s.pk["a2w5"][1] for s in S], [s.x for s in S],

@@ -459,9 +459,9 @@ def _call(callbacks, method, *args):
 
 
 def _infer_precision():
-    """engine.INFER_PRECISION ('f32': inference in IEEE fp32 whatever the training arithmetic; 'same': the model's own)"""
+    """engine.DEFAULTS.infer_precision ('f32': inference in IEEE fp32 whatever the training arithmetic; 'same': the model's own)"""
     from . import engine
-    return None if engine.INFER_PRECISION == "same" else engine.INFER_PRECISION
+    return None if engine.DEFAULTS.infer_precision == "same" else engine.DEFAULTS.infer_precision
 
 
 class SubModel:

@@ -68,6 +68,13 @@ def _conv_work(kind, hw, cin, cout, pooled, ns, bf16=False, wino=True, flags=0):
                        images=n, dtype="bf16" if bf16 else "f32")
 
 
+def _no_bf16w(bf16):
+    """The bf16-operand Winograd kernels on fp32 tensors ('bf16w', rounds 1-4) are retired: conv_precision='bf16' is the configs[4] path."""
+    if bf16:
+        raise ValueError("the bf16-operand Winograd kernels were retired in round 5; use conv_precision='bf16' (ugaitnet_amd.bf16)")
+    return ""
+
+
 def _hbm_work(kernel, nbytes):
     return dict(flops=None, mfma_flops=None, bytes=float(nbytes), kernel=kernel, bound="hbm")
 
@@ -177,7 +184,7 @@ def conv3x3_fwd_wino(x, upk, cout, pool, out=None, idx=None, bf16=False):
     if pool and idx is None:
         idx = torch.empty((n, ho, ho, cout), dtype=U8, device=x.device)
     label, work = _conv_work("fwd", hw, cin, cout, pool, [n], bf16)
-    call("ugn_conv3x3_fwd_wino" + ("_bf16" if bf16 else ""), ptr(x), ptr(upk), ptr(out), ptr(idx) if pool else None, n, hw, cin, cout,
+    call("ugn_conv3x3_fwd_wino" + _no_bf16w(bf16), ptr(x), ptr(upk), ptr(out), ptr(idx) if pool else None, n, hw, cin, cout,
          int(bool(pool)), _stream(), label=label, work=work)
     return (out, idx) if pool else out
 
@@ -187,7 +194,7 @@ def conv3x3_dgrad_wino(dz, upk, hw, cin, cout, dz_idx=None, act=None, addend=Non
     n = dz.shape[0]
     out = torch.empty((n, hw, hw, cin), dtype=F32, device=dz.device) if out is None else out
     label, work = _conv_work("dgrad", hw, cin, cout, dz_idx is not None, [n], bf16, flags=_epi_flags(act, addend, raw_out))
-    call("ugn_conv3x3_dgrad_wino" + ("_bf16" if bf16 else ""), ptr(dz), ptr(dz_idx), ptr(upk), ptr(act), ptr(addend), ptr(out), ptr(raw_out), n, hw,
+    call("ugn_conv3x3_dgrad_wino" + _no_bf16w(bf16), ptr(dz), ptr(dz_idx), ptr(upk), ptr(act), ptr(addend), ptr(out), ptr(raw_out), n, hw,
          cin, cout, _stream(), label=label, work=work)
     return out
 
@@ -218,7 +225,7 @@ def conv3x3_fwd_wino_pair(xs, upks, cout, pool, outs, idxs=None, bf16=False):
     assert xs[1].shape[1:] == xs[0].shape[1:] and (not pool or idxs is not None)
     ns = (C.c_int * 2)(xs[0].shape[0], xs[1].shape[0])
     label, work = _conv_work("fwd", hw, cin, cout, pool, list(ns), bf16)
-    call("ugn_conv3x3_fwd_wino_pair" + ("_bf16" if bf16 else ""), ptr_array(xs), ptr_array(upks), ptr_array(outs), _opt_ptr_array(idxs if pool else None),
+    call("ugn_conv3x3_fwd_wino_pair" + _no_bf16w(bf16), ptr_array(xs), ptr_array(upks), ptr_array(outs), _opt_ptr_array(idxs if pool else None),
          ns, hw, cin, cout, int(bool(pool)), _stream(), label=label, work=work)
     return (outs, idxs) if pool else outs
 
@@ -230,7 +237,7 @@ def conv3x3_dgrad_wino_pair(dzs, upks, hw, cin, cout, outs, dz_idxs=None, acts=N
     ns = (C.c_int * 2)(dzs[0].shape[0], dzs[1].shape[0])
     flags = _epi_flags(acts and acts[0], addends and addends[0], raw_outs and raw_outs[0])
     label, work = _conv_work("dgrad", hw, cin, cout, bool(dz_idxs) and dz_idxs[0] is not None, list(ns), bf16, flags=flags)
-    call("ugn_conv3x3_dgrad_wino_pair" + ("_bf16" if bf16 else ""), ptr_array(dzs), _opt_ptr_array(dz_idxs), ptr_array(upks), _opt_ptr_array(acts),
+    call("ugn_conv3x3_dgrad_wino_pair" + _no_bf16w(bf16), ptr_array(dzs), _opt_ptr_array(dz_idxs), ptr_array(upks), _opt_ptr_array(acts),
          _opt_ptr_array(addends), ptr_array(outs), _opt_ptr_array(raw_outs), ns, hw, cin, cout, _stream(), label=label, work=work)
     return outs
 
@@ -246,7 +253,7 @@ def conv3x3_wgrad_wino_pair(xs, dzs, cout, dws, dz_idxs=None, bf16=False):
         raise ValueError("conv3x3_wgrad_wino_pair: unsupported shape hw=%d cin=%d cout=%d" % (hw, cin, cout))
     ws = _WS.get(nbytes, xs[0].device)
     label, work = _conv_work("wgrad", hw, cin, cout, bool(dz_idxs) and dz_idxs[0] is not None, list(ns), bf16)
-    call("ugn_conv3x3_wgrad_wino_pair" + ("_bf16" if bf16 else ""), ptr_array(xs), ptr_array(dzs), _opt_ptr_array(dz_idxs), ptr_array(dws), ns, hw, cin, cout,
+    call("ugn_conv3x3_wgrad_wino_pair" + _no_bf16w(bf16), ptr_array(xs), ptr_array(dzs), _opt_ptr_array(dz_idxs), ptr_array(dws), ns, hw, cin, cout,
          ptr(ws), ws.numel(), _stream(), label=label, work=work)
     return dws
 
@@ -320,7 +327,7 @@ def conv3x3_wgrad_wino(x, dz, cout, dz_idx=None, dw=None, bf16=False):
         raise ValueError("conv3x3_wgrad_wino: unsupported shape hw=%d cin=%d cout=%d" % (hw, cin, cout))
     ws = _WS.get(nbytes, x.device)
     label, work = _conv_work("wgrad", hw, cin, cout, dz_idx is not None, [n], bf16)
-    call("ugn_conv3x3_wgrad_wino" + ("_bf16" if bf16 else ""), ptr(x), ptr(dz), ptr(dz_idx), ptr(dw), n, hw, cin, cout, ptr(ws), ws.numel(), _stream(),
+    call("ugn_conv3x3_wgrad_wino" + _no_bf16w(bf16), ptr(x), ptr(dz), ptr(dz_idx), ptr(dw), n, hw, cin, cout, ptr(ws), ws.numel(), _stream(),
          label=label, work=work)
     return dw
 
