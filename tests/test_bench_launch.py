@@ -102,15 +102,15 @@ def test_roofline_object_of_the_default_command(dev, tmp_path, dtype):
         assert (roof["bound"] == "mfma") == (roof["mfma_floor_us"] >= roof["hbm_floor_us"])
         assert roof["frac"] == (roof["mfma_frac"] if roof["bound"] == "mfma" else roof["hbm_frac"])
         assert (roof["unit"], roof["peak"]) == (("TFLOP/s", 2516.8) if roof["bound"] == "mfma" else ("GB/s", 8000.0))
-        # h2: three f16 MFMAs per product (the pooled weight gradients on the sparse pipe execute half of them); x3: six bf16 MFMAs
-        ratios = (3.0, 1.5) if dtype == "h2" else (6.0,)
+        # three f16 (h2) / six bf16 (x3) MFMAs per product; the pooled weight gradients on the sparse pipe execute half of them
+        ratios = (3.0, 1.5) if dtype == "h2" else (6.0, 3.0)
         assert min(abs(roof["mfma_tflops"] / roof["algorithmic_tflops"] - r) for r in ratios) < 0.01
     else:
         assert roof["bound"] == "mfma" and roof["unit"] == "TFLOP/s" and roof["peak"] == 157.3
         assert abs(roof["achieved"] / roof["algorithmic_tflops"] - 16.0 / 36.0) < 0.01     # Winograd: 16/36 of the direct count
     assert 0.05 < roof["frac"] <= 1.0 and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3
     names = {"h2": ("_mm_kernel", "conv_mm16_kernel", "conv_nr_kernel", "conv_d2_kernel", "conv32_d2p_kernel"), "f32": ("wino",),
-             "f32x3": ("conv_x3_kernel", "wgrad_x3_kernel")}[dtype]
+             "f32x3": ("conv_x3_kernel", "wgrad_x3_kernel", "wgrad_x3s_kernel")}[dtype]
     assert "conv3x3_" in roof["kernel"] and any(n in roof["rocprof_kernel"] for n in names)
     assert roof["launches_per_step"] >= 1
     assert roof["avg_us"] > 0 and 0 < roof["share_of_step"] < 0.5 and roof["serial_step_us"] > 0

@@ -12,7 +12,7 @@ compared with the fp64 oracle's, the flips are counted per family and each one i
 the gradient bar is 1e-4 relative L2, with flips (20-50 of 6e8 decisions at these sizes; a single re-routed decision moves a tensor
 by up to 6e-3) 1e-2, and on the headline workload and arithmetic (C3, f32x3) the oracle is also FORCED to the HIP path's routing: 5e-5.
 Cases: C2 / C3 / C4 in the default arithmetic (f32x3: fp32 tensors, three-way bf16 split), C3w = C3 on the Winograd fp32-MFMA
-kernels, C3h2 = the f16x2 tensors (its CASIA-shaped case C4h2 can be named on the command line: not in the default list), C5 = bf16.  The fp64 oracle is evaluated ONCE per workload (its cases share it)."""
+kernels, C3h2 = the f16x2 tensors, C5 = bf16.  The fp64 oracle is evaluated ONCE per workload (its cases share it)."""
 import atexit
 import os
 import pickle
@@ -46,7 +46,6 @@ CASES = {
     # tensors, ugaitnet_amd/engine_h2.py) at the fp32 bars
     "C3w": dict(kinds=("of", "gray", "depth"), b=24, ids=12, ncls=150, precision="f32"),
     "C3h2": dict(kinds=("of", "gray", "depth"), b=24, ids=12, ncls=150, precision="h2"),
-    "C4h2": dict(kinds=("of", "gray", "sil"), b=40, ids=4, ncls=74, precision="h2"),
 }
 
 
@@ -60,7 +59,7 @@ def _rell2(a, b):
 # the tests in a child process (tests/conftest.py starts it at session start and moves this module's tests to the end of the
 # session): while the other GPU tests run, the first workloads are evaluated; at most MAX_AHEAD finished entries are held (an entry is
 # up to ~11 GB: inputs, gradients and every routing decision of the step with its gap).
-WORKLOAD = {"C2": "C2", "C3": "C3", "C3w": "C3", "C3h2": "C3", "C4": "C4", "C4h2": "C4", "C5": "C5"}
+WORKLOAD = {"C2": "C2", "C3": "C3", "C3w": "C3", "C3h2": "C3", "C4": "C4", "C5": "C5"}
 MAX_AHEAD = 3
 
 

@@ -47,13 +47,14 @@ class _WS:
         return buf
 
 
-def _work(kind, hw, cin, cout, pooled, ns, kernel, nbytes):
+def _work(kind, hw, cin, cout, pooled, ns, kernel, nbytes, products=PRODUCTS):
     """bench.py's roofline bookkeeping: algorithmic FLOPs (direct-convolution count), the FLOPs the bf16 pipe executes for them
-    (six partial products per fp32 product) and the algorithmic bytes (every tensor read or written once)."""
+    (six partial products per fp32 product; three dense-equivalent ones on the sparse pipe, which skips the structural zeros of a
+    MaxPool gradient) and the algorithmic bytes (every tensor read or written once)."""
     n = int(sum(ns))
     flops = 2.0 * 9 * cin * cout * hw * hw * n
     label = "x3_conv3x3_%s[%d->%d @%dx%d%s] %s" % (kind, cin, cout, hw, hw, " pooled" if pooled else "", kernel)
-    return label, dict(flops=flops, mfma_flops=flops * PRODUCTS, bytes=float(nbytes), kernel=kernel, bound="roof", images=n, dtype="bf16x3")
+    return label, dict(flops=flops, mfma_flops=flops * products, bytes=float(nbytes), kernel=kernel, bound="roof", images=n, dtype="bf16x3")
 
 
 def split(x):
@@ -133,8 +134,9 @@ def conv3x3_wgrad_multi(xs, dzs, cout, dws, dz_idxs=None):
         raise ValueError("x3.conv3x3_wgrad_multi: unsupported shape hw=%d cin=%d cout=%d" % (hw, cin, cout))
     ws = _WS.get(nbytes_ws, xs[0].device)
     nbytes = n * (hw * hw * cin * 4 + hz * hz * cout * (5 if pooled else 4)) + len(xs) * 36 * cin * cout
-    kern = "wgrad_x3_kernel<%d, %d, %d, %d>" % (cin, cout, hw, int(pooled))
-    label, work = _work("wgrad", hw, cin, cout, pooled, ns, kern, nbytes)
+    # pooled layers: the sparse matrix pipe (v_smfmac_f32_16x16x64_bf16) issues HALF the matrix instructions
+    kern = "wgrad_x3s_kernel<%d, %d, %d>" % (cin, cout, hw) if pooled else "wgrad_x3_kernel<%d, %d, %d, 0>" % (cin, cout, hw)
+    label, work = _work("wgrad", hw, cin, cout, pooled, ns, kern, nbytes, products=PRODUCTS // 2 if pooled else PRODUCTS)
     call("ugn_x3_conv3x3_wgrad_multi", ptr_array(xs), ptr_array(dzs), _opt(dz_idxs) if pooled else None, ptr_array(dws), _ints(ns),
          len(xs), hw, cin, cout, ptr(ws), ws.numel(), _stream(), label=label, work=work)
     return dws
