@@ -49,13 +49,13 @@ def oracle_step(key, *args, **kw):
     return _ORACLE[key]
 
 
-SMALL3 = {"sign_max": (8, 4, 4), "max": (6, 3, 3), "avg": (6, 3, 3)}      # (clips, frames, identities) of the three-modality cases
+SMALL3 = {"sign_max": (8, 4, 4), "max": (8, 4, 4), "avg": (6, 3, 3)}      # (clips, frames, identities) of the three-modality cases
 
 
 # every fusion mode in the default arithmetic; the reference's own fusion (sign_max) in all three
 @pytest.mark.parametrize("mode,prec", [("sign_max", "f32x3"), ("max", "f32x3"), ("avg", "f32x3"), ("sign_max", "f32"), ("sign_max", "h2")])
 def test_three_modalities_forward_backward(dev, mode, prec):
-    # (8 clips x 4 frames for the reference's fusion; the two other fusion modes share the encoders: 6 x 3, a third of the oracle's time)
+    # (8 clips x 4 frames for the reference's fusion; 'avg' shares the encoders: 6 x 3, a third of the oracle's time; 'max' keeps 8 clips -- its batch-axis norms amplify rounding)
     kinds, (b, l, ids), ncls = ('of', 'gray', 'depth'), SMALL3[mode], 10
     xs, uses, labels, onehot = make_batch(kinds, b, l, ncls, ids=ids, seed=1)
     p64 = oracle_params(kinds, ncls)

@@ -45,16 +45,21 @@ def build(force=False, verbose=True, variant=None, extra=()):
     objdir = OBJ if variant is None else OBJ + "_" + variant
     LIB = globals()["LIB"] if variant is None else os.path.join(HERE, "libugaitnet_hip_%s.so" % variant)
     os.makedirs(objdir, exist_ok=True)
+    os.makedirs(OBJ, exist_ok=True)      # (a variant links the default build's objects for sources its macros do not touch)
     if force:
         for f in os.listdir(objdir):
             os.remove(os.path.join(objdir, f))
     # a variant recompiles only the sources (or headers) that mention one of its -D macros; the rest links the default build's objects
+    import glob
+    import re
     macros = [f[2:].split("=")[0] for f in extra if f.startswith("-D")]
-    hdr_hit = any(m in open(h).read() for h in HEADERS for m in macros)
+    word = lambda m, text: re.search(r"\b%s\b" % re.escape(m), text) is not None
+    all_headers = sorted(set(HEADERS + glob.glob(os.path.join(CSRC, "*.h"))))
+    hdr_hit = any(word(m, open(h).read()) for h in all_headers for m in macros)
 
     def one(src):
         if variant is not None and macros and len(macros) == len(list(extra)) and not hdr_hit:
-            if not any(m in open(os.path.join(CSRC, src)).read() for m in macros):
+            if not any(word(m, open(os.path.join(CSRC, src)).read()) for m in macros):
                 return _compile(src, OBJ, ())
         return _compile(src, objdir, extra)
     with ThreadPoolExecutor(max_workers=4) as ex:

@@ -615,16 +615,20 @@ class GaitCore:
         if self.bf:
             for enc in self.encoders:
                 enc.bf = BFState(enc)
-        if self.h2:
-            # UGN_PERSISTENT_WGS=n (< 256): the persistent launches leave 256 - n CUs free -- room for RCCL's channels when the
-            # bucketed all-reduce (UGN_AR_OVERLAP=1) overlaps the backward pass.  Results do not depend on it (tests/test_mm_gpu.py).
+        if self.h2 or self.bf:
+            # Settings.persistent_wgs = n (< 256): the persistent launches of the f16x2 and bf16 sets leave 256 - n CUs free -- room for
+            # RCCL's channels when the bucketed all-reduce (ar_overlap) overlaps the backward pass.  Results do not depend on it
+            # (tests/test_mm_gpu.py).  It is the library's ONE process-wide setting (ugn_set_persistent_wgs): a core that does not ask
+            # for a reduced grid sets it back to all CUs, so a later core never inherits an earlier one's grid.
             if self.cfg.persistent_wgs:
                 h2.set_persistent_wgs(int(self.cfg.persistent_wgs))
             elif self.world > 1 and self.cfg.ar_overlap:
                 # the bucketed all-reduce runs BESIDE the rest of the backward pass: leave RCCL's channels 32 of the 256 CUs
-                # (every persistent launch of the library -- forward / data gradient, weight gradients, the 5x5 layer -- then
-                # starts 224 workgroups or the matching number of groups; unmeasured on multi-GPU hardware: UGN_PERSISTENT_WGS overrides)
+                # (unmeasured on multi-GPU hardware: Settings.persistent_wgs overrides)
                 h2.set_persistent_wgs(224)
+            else:
+                h2.set_persistent_wgs(0)
+        if self.h2:
             self.meta_pool = h2.MetaPool(self.device, 64 * self.nmod)
             for enc in self.encoders:
                 enc.h2 = H2State(enc, self.meta_pool)
@@ -633,7 +637,8 @@ class GaitCore:
         # from waits for THIS EVENT on its own current stream -- not for a flag plus a stream looked up by the current stream, which
         # missed a pack queued from another stream and let two packs interleave on the same buffers.
         self._pack_event = None
-        self.store.before_write = self.join_pack
+        self._param_writes = 0              # bumped by every ParamStore.set (a cached inference-arithmetic filter pack goes stale)
+        self.store.before_write = self._before_param_write
         for enc in self.encoders:
             enc.before_conv3 = self._before_conv3
         self.scratch = {}
@@ -666,19 +671,32 @@ class GaitCore:
             self.store.set(name, np.zeros(shape, np.float32) if name.endswith(".bc") else glorot_uniform(gen, shape))
         self.weights_changed()
 
+    def _before_param_write(self):
+        self._param_writes += 1
+        self.join_pack()
+
     def join_pack(self):
         """The current stream waits for the filter repack queued by the last apply_gradients, if one is outstanding."""
         ev = self._pack_event
-        if ev is not None:
+        if ev is not None:      # (kept until the NEXT pack replaces it: a consumer on another stream must wait for it too -- ADVICE r04)
             torch.cuda.current_stream(self.device).wait_event(ev)
-            self._pack_event = None
 
     def _before_conv3(self):
         """Called by forward_h2 / forward_bf between the 5x5 layer and the first 3x3 layer."""
         self.join_pack()
 
     def weights_changed(self):
+        """Refresh the kernel-ready copies of the 3x3 filters on the current stream and leave the event every consumer waits for."""
         self.join_pack()     # (a repack still running on the second stream: never two packs at once on the pk / wmeta buffers)
+        self._repack()
+        if torch.cuda.is_current_stream_capturing():
+            self._pack_event = None       # (inside a captured graph the pack is ordered by the graph's own edges)
+        else:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.device))
+            self._pack_event = ev
+
+    def _repack(self):
         if self.h2:          # f16 halves + block exponent + L1 bound of every 3x3 filter, both directions: two launches
             h2.mm_pack_multi([j for e in self.encoders for j in e.h2.pack_jobs()])
             return
@@ -708,12 +726,21 @@ class GaitCore:
             return
         if precision != "f32":
             raise ValueError("arithmetic(%r): only 'f32' inside an 'h2' / 'bf16' model" % (precision,))
+        if getattr(self, "_arith_active", False):
+            raise RuntimeError("GaitCore.arithmetic() does not nest")
         saved = (self.conv_precision, self.h2, self.bf)
         self.conv_precision, self.h2, self.bf = "f32", False, False
+        self._arith_active = True           # forward_backward / apply_gradients raise while the block is active
         try:
-            self.weights_changed()          # the Winograd-transformed filters of the current parameters (one launch)
+            # the Winograd-transformed filters of the current parameters: one launch, skipped while the parameters have not changed
+            # since the last block (keyed on the optimizer's step counter and the parameter writes)
+            stamp = (self.iterations, self._param_writes)
+            if getattr(self, "_arith_pack_stamp", None) != stamp:
+                self.weights_changed()
+                self._arith_pack_stamp = stamp
             yield
         finally:
+            self._arith_active = False
             self.conv_precision, self.h2, self.bf = saved
 
     def set_params_numpy(self, params):
@@ -883,6 +910,8 @@ class GaitCore:
     # ---- training step ----------------------------------------------------------------------------------
     def forward_backward(self, xs, uses, labels, onehot):
         """Forward + loss + full backward; gradients land in store.grad.  Returns device scalars (no sync)."""
+        if getattr(self, "_arith_active", False):
+            raise RuntimeError("a training step inside GaitCore.arithmetic(): that block runs forward passes in another arithmetic only")
         if self.global_batch:   # (before the forward pass is queued: the label exchange synchronises with the host)
             labels, onehot = self._gather_targets(labels, onehot)
         sig = self.forward(xs, uses, gather=self.global_batch)
@@ -1010,6 +1039,8 @@ class GaitCore:
 
     def apply_gradients(self):
         """Gradient all-reduce over RCCL (data parallel) + keras Adam, one launch over the flat buffer."""
+        if getattr(self, "_arith_active", False):
+            raise RuntimeError("an optimizer step inside GaitCore.arithmetic(): that block runs forward passes in another arithmetic only")
         scale = self.finish_gradient_allreduce()
         self.iterations += 1
         t = self.iterations
@@ -1024,10 +1055,7 @@ class GaitCore:
             # the repack of the 3x3 filters (3 launches, ~50 us whatever the batch) runs on the second stream, beside the next
             # step's input copies and 5x5 layer; the first 3x3 layer waits for it (`_before_conv3`)
             with self.launch.side():
-                self.weights_changed()
-                ev = torch.cuda.Event()
-                ev.record(torch.cuda.current_stream(self.device))
-            self._pack_event = ev
+                self.weights_changed()        # (records the event the first 3x3 layer of the next step waits for)
         else:
             self.weights_changed()
 
