@@ -295,8 +295,8 @@ int ugn_mm_conv3x3_dgrad_multi(const uint16_t* const* dz, const uint8_t* const* 
 /* Persistent workgroups per launch: 8..256, 0 = default (256 = one per CU).  A process-wide setting (the one piece of mutable state
  * besides the error message): under data parallelism a value below 256 leaves 256 - n CUs to RCCL's channels while the backward pass
  * runs (mains/mj_trainUWYHGaitNet_DataGen_CasiaB.py:342-349: the gradient all-reduce of MirroredStrategy).  It sizes EVERY persistent
- * launch that owns its CUs' whole LDS: the f16x2 and bf16 3x3 forward / data-gradient kernels (items stride over n, or 2n,
- * workgroups), their weight gradients (the grid holds the largest multiple of 8 groups per block combination that fits n; a
+ * launch that owns its CUs' whole LDS: the x3, f16x2 and bf16 3x3 forward / data-gradient kernels (items stride over n, or 2n,
+ * workgroups; the x3 weight gradients keep their 256 fixed shares), their weight gradients (the grid holds the largest multiple of 8 groups per block combination that fits n; a
  * workgroup then walks several of the launch's FIXED shares in turn) and the 5x5 forward (4n workgroups).  Every result is
  * bit-identical for every n.  Call it between launches, not concurrently with them. */
 int ugn_set_persistent_wgs(int n);

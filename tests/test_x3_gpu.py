@@ -167,6 +167,33 @@ def test_x3_multi_job(dev):
         close(dws[j], dw_ref, 3e-6, "wgrad job %d" % j)
 
 
+def test_x3_results_do_not_depend_on_the_persistent_grid(dev):
+    """ugn_set_persistent_wgs(n < 256) leaves CUs free for RCCL's channels under data parallelism: the x3 forward / data-gradient
+    launches then run n (or 2 n) persistent workgroups over the same items -- bit-identical results for every n."""
+    from ugaitnet_amd import h2, x3
+    rng = np.random.default_rng(5)
+    hw, cin, cout, n = 32, 64, 64, 13
+    x = T(rng.uniform(-1, 1, (n, hw, hw, cin)).astype(np.float32), dev)
+    w = T(rng.uniform(-0.1, 0.1, (3, 3, cin, cout)).astype(np.float32), dev)
+    dp = T((rng.normal(size=(n, hw // 2, hw // 2, cout)) * 1e-3).astype(np.float32), dev)
+    pidx = T(rng.integers(0, 4, size=(n, hw // 2, hw // 2, cout)).astype(np.uint8), dev)
+    wf, wd = x3.pack(w, False), x3.pack(w, True)
+    res = []
+    try:
+        for wgs in (0, 224, 64, 8):
+            h2.set_persistent_wgs(wgs)
+            out = torch.empty((n, hw // 2, hw // 2, cout), device=dev)
+            idx = torch.empty((n, hw // 2, hw // 2, cout), dtype=torch.uint8, device=dev)
+            x3.conv3x3_fwd_multi([x], [wf], cout, True, [out], [idx])
+            dx = torch.empty((n, hw, hw, cin), device=dev)
+            x3.conv3x3_dgrad_multi([dp], [wd], hw, cin, cout, [dx], dz_idxs=[pidx], acts=[x])
+            res.append((out, idx, dx))
+    finally:
+        h2.set_persistent_wgs(0)
+    for r in res[1:]:
+        assert all(torch.equal(a, b) for a, b in zip(res[0], r))
+
+
 def test_x3_split_is_exact_and_full_range(dev):
     """The three-way split loses nothing (x0 + x1 + x2 == x bit for bit) over fp32's whole normal range -- no block exponent, no
     dependence on the other elements of a tensor: a convolution of one image is the same inside any batch and at any scale."""

@@ -521,7 +521,12 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv_x3_kernel(const X3Jobs jt)
   }
 }
 
-int g_grid = kGrid;
+// persistent workgroups per CU-filling launch: ugn_set_persistent_wgs (conv3x3_mm.hip; the library's one process-wide setting), rounded
+// down to a multiple of 8 (items are handed out per XCD).  Results do not depend on it (the items are the same, only who runs them).
+int x3_grid() {
+  const int g = ugn_mm::persistent_wgs() / 8 * 8;
+  return g < 8 ? 8 : (g > kGrid ? kGrid : g);
+}
 
 inline int make_table(X3Jobs& jt, const X3Job* jobs, const int* n, int njobs, int per_img) {
   int total = 0;
@@ -565,17 +570,13 @@ int launch_x3(const X3Job* jobs, const int* n, int njobs, hipStream_t stream) {
   X3Jobs jt;
   const int total = make_table(jt, jobs, n, njobs, (HW / 16) * (HW / 16));
   if (total == 0) return 0;
-  hipLaunchKernelGGL(kern, dim3(g_grid * (8 / WAVES)), dim3(64 * WAVES), LDS, stream, jt);
+  hipLaunchKernelGGL(kern, dim3(x3_grid() * (8 / WAVES)), dim3(64 * WAVES), LDS, stream, jt);
   UGN_CHECK_LAUNCH("conv_x3_kernel");
   return 0;
 }
 
 }  // namespace
 
-namespace ugn_x3 {
-int persistent_grid() { return g_grid; }
-void set_persistent_grid(int n) { g_grid = n; }
-}  // namespace ugn_x3
 
 extern "C" int ugn_x3_pack_multi(const float* const* w_hwio_host, uint16_t* const* wpk_host, const int* cin_host, const int* cout_host,
                                  const int* dgrad_host, int njobs, void* stream) {

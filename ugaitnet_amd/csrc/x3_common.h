@@ -16,6 +16,10 @@
 #pragma once
 #include "common.h"
 
+namespace ugn_mm {
+int persistent_wgs();      // conv3x3_mm.hip: ugn_set_persistent_wgs (default 256 = one persistent workgroup per CU)
+}
+
 namespace ugn_x3 {
 
 typedef __bf16 b8 __attribute__((ext_vector_type(8)));
