@@ -1,5 +1,5 @@
-"""Loss trajectory of the same job (C3 batch, fixed) under the fp32 (Winograd), f16x2 (default) and bf16 paths: do they train alike?
-usage: train_curve.py <steps> <out.json> [f32,h2,bf16]"""
+"""Loss trajectory of the same job (C3 batch, fixed) in the default fp32-tensor arithmetic (x3), on the Winograd fp32-MFMA kernels, in f16x2 and in bf16: do they train alike?
+usage: train_curve.py <steps> <out.json> [f32x3,f32,h2,bf16]"""
 import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -12,7 +12,7 @@ dxs = [torch.from_numpy(x).cuda() for x in xs]
 dus = [torch.from_numpy(u).cuda() for u in uses]
 doh = torch.from_numpy(onehot).cuda()
 res = {}
-for prec in (sys.argv[3].split(",") if len(sys.argv) > 3 else ("f32", "h2", "bf16")):
+for prec in (sys.argv[3].split(",") if len(sys.argv) > 3 else ("f32x3", "f32", "h2", "bf16")):
     core = GaitCore([2, 1, 1], nclasses=150, fuse_mode="sign_max", margin=0.2, loss_weights=(1.0, 0.1), seed=232323, lr=1e-4,
                     conv_precision=prec)
     curve = []

@@ -57,6 +57,13 @@ def _work(kind, hw, cin, cout, pooled, ns, kernel, nbytes, products=PRODUCTS):
     return label, dict(flops=flops, mfma_flops=flops * products, bytes=float(nbytes), kernel=kernel, bound="roof", images=n, dtype="bf16x3")
 
 
+def _waves(kc, nc, pool_epilogue, in_pooled):
+    """conv_x3_kernel's last template argument (csrc/conv3x3_x3.hip x3_waves): 4 = two workgroups per CU, 8 = one"""
+    if nc > 64 or (nc == 64 and not in_pooled and (pool_epilogue or kc > 64)):
+        return 8
+    return 4
+
+
 def split(x):
     """fp32 tensor -> int16 tensor [3, numel] of bf16 bit patterns: the three planes the kernels multiply (tests)."""
     _chk(x)
@@ -94,7 +101,7 @@ def conv3x3_fwd_multi(xs, wpks, cout, pool, outs, idxs=None):
     n = sum(ns)
     ho = hw // 2 if pool else hw
     nbytes = n * (hw * hw * cin * 4 + ho * ho * cout * (5 if pool else 4)) + len(xs) * 54 * cin * cout
-    kern = "conv_x3_kernel<%d, %d, %d, %d, 0>" % (cin, cout, hw, 1 if pool else 0)
+    kern = "conv_x3_kernel<%d, %d, %d, %d, 0, %d>" % (cin, cout, hw, 1 if pool else 0, _waves(cin, cout, bool(pool), False))
     label, work = _work("fwd", hw, cin, cout, pool, ns, kern, nbytes)
     call("ugn_x3_conv3x3_fwd_multi", ptr_array(xs), ptr_array(wpks), ptr_array(outs), ptr_array(idxs) if pool else None, _ints(ns),
          len(xs), hw, cin, cout, int(bool(pool)), _stream(), label=label, work=work)
@@ -112,7 +119,7 @@ def conv3x3_dgrad_multi(dzs, wpks, hw, cin, cout, outs, dz_idxs=None, acts=None)
     pooled = bool(dz_idxs) and dz_idxs[0] is not None
     hz = hw // 2 if pooled else hw
     nbytes = n * (hz * hz * cout * (5 if pooled else 4) + hw * hw * cin * (8 if acts else 4)) + len(dzs) * 54 * cin * cout
-    kern = "conv_x3_kernel<%d, %d, %d, %d, %d>" % (cout, cin, hw, 3 if acts else 2, int(pooled))
+    kern = "conv_x3_kernel<%d, %d, %d, %d, %d, %d>" % (cout, cin, hw, 3 if acts else 2, int(pooled), _waves(cout, cin, False, pooled))
     label, work = _work("dgrad", hw, cin, cout, pooled, ns, kern, nbytes)
     call("ugn_x3_conv3x3_dgrad_multi", ptr_array(dzs), _opt(dz_idxs) if pooled else None, ptr_array(wpks), _opt(acts), ptr_array(outs),
          _ints(ns), len(dzs), hw, cin, cout, _stream(), label=label, work=work)
