@@ -127,10 +127,13 @@ __global__ __launch_bounds__(256) void x3_split_kernel(const float* __restrict__
 // second barrier -- splits and writes the next one and runs its epilogue while the OTHER workgroup multiplies.  Inside one workgroup the
 // matrix work and everything else add up (the waves move in lock-step from barrier to barrier; re-ordering the same work changes
 // nothing: tools/bench_x3.py ablations in profiles/r05_x3_experiments.txt); two workgroups drift into anti-phase.
-template <int KC, int NC, int HW, int EPI, int IN_POOLED, int WAVES>
-__global__ __launch_bounds__(64 * WAVES, 2) void conv_x3_kernel(const X3Jobs jt) {
+// FORM: 0 = 8 waves, one workgroup per CU, double-buffered halo; 1 = 4 waves, two workgroups per CU, one halo buffer each;
+//       2 = 8 waves, TWO workgroups per CU (four waves per SIMD, <= 128 registers each), one halo buffer each
+template <int KC, int NC, int HW, int EPI, int IN_POOLED, int FORM>
+__global__ __launch_bounds__(FORM == 1 ? 256 : 512, FORM == 2 ? 4 : 2) void conv_x3_kernel(const X3Jobs jt) {
+  constexpr int WAVES = FORM == 1 ? 4 : 8;
   constexpr int NTHR = 64 * WAVES;
-  constexpr bool DB = WAVES == 8;              // double-buffered halo, staging interleaved with the MFMAs
+  constexpr bool DB = FORM == 0;               // double-buffered halo, staging interleaved with the MFMAs
   constexpr int NT = NC / 16, MPARTS = WAVES / NT, ROWS = 16 / MPARTS, NCHUNK = KC / 32;
   constexpr bool RES = NCHUNK == 1 && DB;      // the job's whole filter tile stays in registers
   constexpr int RPX = HW / 16, RPI = RPX * RPX;
@@ -294,8 +297,10 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv_x3_kernel(const X3Jobs jt)
     }
   };
   // ---- the wave's filter fragments: [dy][plane] of one tap column (streamed), or [dx][dy][plane] of the whole chunk (RES)
+  // (form 2 -- four waves per SIMD, 128 registers -- does not prefetch the next column's fragments: the other waves hide the latency)
+  constexpr bool WPF = !RES && FORM != 2;
   uint4 wr[RES ? 3 : 1][3][3];
-  uint4 nb[RES ? 1 : 3][3];
+  uint4 nb[WPF ? 3 : 1][3];
   auto w_ptr = [&](const uint16_t* wpk, int chunk, int dx) {
     return reinterpret_cast<const char*>(wpk) + ((size_t)((chunk * 3 + dx) * 3) * NT + ng) * 3072 + lane * 16;
   };
@@ -311,7 +316,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv_x3_kernel(const X3Jobs jt)
 #pragma unroll
     for (int dx = 0; dx < 3; ++dx) load_col(jt.job[jb].wpk, 0, dx, wr[dx]);
     w_jb = jb;
-  } else {
+  } else if constexpr (WPF) {
     load_col(jt.job[jb].wpk, 0, 0, nb);
   }
 
@@ -356,7 +361,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv_x3_kernel(const X3Jobs jt)
 #pragma unroll
       for (int dx = 0; dx < 3; ++dx) {
         uint4 cb[RES ? 1 : 3][3];
-        if constexpr (!RES) {
+        if constexpr (WPF) {
 #pragma unroll
           for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
@@ -364,6 +369,8 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv_x3_kernel(const X3Jobs jt)
           // (unconditional -- behind the last chunk of the last item it re-reads chunk 0: a conditional load is its own basic block)
           if (dx < 2) load_col(jt.job[jb].wpk, chunk, dx + 1, nb);
           else load_col(jt.job[nx_job].wpk, n_chunk, 0, nb);
+        } else if constexpr (!RES) {
+          load_col(jt.job[jb].wpk, chunk, dx, cb);
         }
         if constexpr (DB) {
           if (dx == 1 && have_t1 && !(UGN_X3_ABL & 8)) tile_load(tl_next(t1));     // the fp32 values of the tile after next (registers free again)
@@ -436,7 +443,10 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv_x3_kernel(const X3Jobs jt)
         if (!last_chunk) tile_fetch_write(t1);
       }
     }
-    if constexpr (!DB && SROUND == NSLOT) {
+    // (forms 1: the next item's first tile is fetched before the epilogue and split behind it; form 2 -- 128 registers -- fetches it
+    //  behind the epilogue, whose latency the CU's other waves cover)
+    constexpr bool PRE = !DB && SROUND == NSLOT && FORM != 2;
+    if constexpr (PRE) {
       if (more) tile_load(Tl{next_item, 0});
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -507,7 +517,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv_x3_kernel(const X3Jobs jt)
       }
     }
     }
-    if constexpr (!DB && SROUND == NSLOT) {
+    if constexpr (PRE) {
 #if !(UGN_X3_ABL & 2)
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -544,21 +554,30 @@ inline int make_table(X3Jobs& jt, const X3Job* jobs, const int* n, int njobs, in
 #ifndef UGN_X3_W4
 #define UGN_X3_W4 1
 #endif
+#ifndef UGN_X3_FORM32
+#define UGN_X3_FORM32 1      /* launches with 32 output columns (form 2, four waves per SIMD at <= 128 registers, measured 7 % slower) */
+#endif
+#ifndef UGN_X3_FORM64
+#define UGN_X3_FORM64 -1     /* launches with 64 output columns: -1 = form 1 where it fits its registers, else form 0 */
+#endif
 template <int KC, int NC, int EPI, int IN_POOLED>
-constexpr int x3_waves() {
-  if (!UGN_X3_W4 || NC > 64) return 8;
+constexpr int x3_form() {
+  if (!UGN_X3_W4 || NC > 64) return 0;
+  if (NC == 32) return UGN_X3_FORM32;
+  if (UGN_X3_FORM64 >= 0) return UGN_X3_FORM64;
   // (64 columns: 16 rows per wave = 64 accumulator registers; with the pooling epilogue, or four K chunks of streamed filters, the
   //  4-wave form spills 40-50 registers)
-  if (NC == 64 && !IN_POOLED && (EPI == EPI_LRELU_POOL || KC > 64)) return 8;
-  return 4;
+  if (!IN_POOLED && (EPI == EPI_LRELU_POOL || KC > 64)) return 0;
+  return 1;
 }
 
 template <int KC, int NC, int HW, int EPI, int IN_POOLED>
 int launch_x3(const X3Job* jobs, const int* n, int njobs, hipStream_t stream) {
-  constexpr int WAVES = x3_waves<KC, NC, EPI, IN_POOLED>();
-  constexpr int LDS = WAVES == 8 ? X3_LDS : X3_BUF;
+  constexpr int FORM = x3_form<KC, NC, EPI, IN_POOLED>();
+  constexpr int WAVES = FORM == 1 ? 4 : 8, WGS_PER_CU = FORM == 0 ? 1 : 2;
+  constexpr int LDS = FORM == 0 ? X3_LDS : X3_BUF;
   static bool attr = false;
-  auto* kern = conv_x3_kernel<KC, NC, HW, EPI, IN_POOLED, WAVES>;
+  auto* kern = conv_x3_kernel<KC, NC, HW, EPI, IN_POOLED, FORM>;
   if (!attr) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     if (e != hipSuccess) {
@@ -570,7 +589,7 @@ int launch_x3(const X3Job* jobs, const int* n, int njobs, hipStream_t stream) {
   X3Jobs jt;
   const int total = make_table(jt, jobs, n, njobs, (HW / 16) * (HW / 16));
   if (total == 0) return 0;
-  hipLaunchKernelGGL(kern, dim3(x3_grid() * (8 / WAVES)), dim3(64 * WAVES), LDS, stream, jt);
+  hipLaunchKernelGGL(kern, dim3(x3_grid() * WGS_PER_CU), dim3(64 * WAVES), LDS, stream, jt);
   UGN_CHECK_LAUNCH("conv_x3_kernel");
   return 0;
 }

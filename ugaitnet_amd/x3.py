@@ -58,10 +58,11 @@ def _work(kind, hw, cin, cout, pooled, ns, kernel, nbytes, products=PRODUCTS):
 
 
 def _waves(kc, nc, pool_epilogue, in_pooled):
-    """conv_x3_kernel's last template argument (csrc/conv3x3_x3.hip x3_waves): 4 = two workgroups per CU, 8 = one"""
+    """conv_x3_kernel's last template argument (csrc/conv3x3_x3.hip x3_form): 0 = 8 waves, one workgroup per CU; 1 = 4 waves, two
+    workgroups per CU (form 2 -- 8 waves at <= 128 registers, two workgroups per CU -- is built by -DUGN_X3_FORM32=2 only)"""
     if nc > 64 or (nc == 64 and not in_pooled and (pool_epilogue or kc > 64)):
-        return 8
-    return 4
+        return 0
+    return 1
 
 
 def split(x):
