@@ -160,7 +160,7 @@ def test_single_modality_graph(dev, prec):
     assert max(bad.values()) <= 5e-3, bad
 
 
-@pytest.mark.parametrize("prec", PRECISIONS)
+@pytest.mark.parametrize("prec", ["f32x3", "h2"])
 def test_two_modalities_train_steps_track_oracle(dev, prec):
     """keras Adam (eps 1e-7) on the flat parameter buffer: the first update equals the oracle's wherever the gradient is
     not at rounding level (Adam's first step is lr*sign(g), so a sign flip of a ~0 gradient moves a weight by 2*lr),

@@ -11,7 +11,7 @@ pytestmark = pytest.mark.gpu
 
 def test_stream_modes_give_identical_training_trajectories(dev):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, os.path.join(root, "tools", "soak_streams.py"), "6"], capture_output=True, text=True,
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "soak_streams.py"), "4"], capture_output=True, text=True,
                        timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "identical trajectories" in r.stdout

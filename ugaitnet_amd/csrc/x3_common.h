@@ -7,12 +7,14 @@
 // bf16 has fp32's exponent range, so there is no block exponent and nothing to overflow), and a product is the sum of the nine
 // partial products xi * wj, each of them exact in the MFMA's fp32 accumulator.  The kernels here keep the six largest,
 //        x*w ~ x0 w0 + x0 w1 + x1 w0 + x1 w1 + x0 w2 + x2 w0,
-// and drop x1 w2 + x2 w1 + x2 w2 <= 2^-23 |x w|: below the rounding of the fp32 accumulation they are added into.  Measured against
-// fp64 (tests/test_x3_gpu.py, tools/x3_accuracy.py): error 0.7e-7 of sum|x w| for K = 288 ... 4608 -- the same to three digits
-// with all nine products, 0.8-1.0e-7 for an fp32 MFMA chain, 1.9-2.5e-7 for a sequential fp32 FMA chain.  Six bf16 MFMAs cost
-// 6/16 of one fp32 MFMA of the same shape: 2.7x the fp32 matrix rate for fp32-grade results, with fp32 tensors in HBM (nothing
-// about the data layout, the HBM-bound kernels or the saved tensors changes; the split happens in registers while a tile is
-// staged into LDS).
+// and drop x1 w2 + x2 w1 + x2 w2 <= 2^-23 |x w|: below the rounding of the fp32 accumulation they are added into.  Emulated in numpy
+// (tests/test_x3_arithmetic.py, K = 288 ... 4608, error against fp64 relative to sum|x w|): six products 0.7e-7 max -- the same to
+// three digits with all NINE (exact products) -- against 1.8-2.5e-7 for a sequential fp32 FMA chain.  Measured on the GPU against the
+// fp64 oracle, side by side with the library's fp32-MFMA kernels on the same inputs (tools/x3_accuracy.py, profiles/r05_x3_accuracy.txt,
+// asserted in tests/test_x3_gpu.py): forward 0.8-0.9x, data gradients 0.6-1.3x, weight gradients 1.0-2.2x their error, every kernel
+// inside the bars of the fp32 kernels it stands in for.  Six bf16 MFMAs cost 6/16 of one fp32 MFMA of the same shape: 2.7x the fp32
+// matrix rate for fp32-grade results, with fp32 tensors in HBM (nothing about the data layout, the HBM-bound kernels or the saved
+// tensors changes; the split happens in registers while a tile is staged into LDS).
 #pragma once
 #include "common.h"
 
