@@ -426,20 +426,22 @@ int ugn_x3_pack_multi(const float* const* w_hwio_host, uint16_t* const* wpk_host
                       const int* dgrad_host, int njobs, void* stream);
 /* out = LeakyReLU(conv(in)) (+ MaxPooling2D(2,2) and first-maximum argmax bytes when pool != 0) for up to 6 jobs of one shape
  * (the frame-level layer and the set-level twin of every modality): Conv2D + LeakyReLU + MaxPooling2D, :431-462. */
+/* products: 6 = the default arithmetic; 9 = every partial product of the split operands, i.e. the EXACT product (1.5x the matrix time):
+ * for verification -- the two agree to the rounding of the fp32 accumulation (tests/test_x3_gpu.py). */
 int ugn_x3_conv3x3_fwd_multi(const float* const* in, const uint16_t* const* wpk, float* const* out, uint8_t* const* out_idx,
-                             const int* n, int njobs, int hw, int cin, int cout, int pool, void* stream);
+                             const int* n, int njobs, int hw, int cin, int cout, int pool, int products, void* stream);
 /* Data gradient of the layer cin -> cout at hw x hw (Conv2DBackpropInput; with dz_idx: dz is the POOLED gradient [n,hw/2,hw/2,cout]
  * and is scattered through the argmax bytes while it is staged = MaxPoolGrad; with act [n,hw,hw,cin]: out *= LeakyReLU'(act) =
  * LeakyReluGrad).  All jobs or none take dz_idx / act.  wpk from ugn_x3_pack_multi(dgrad = 1). */
 int ugn_x3_conv3x3_dgrad_multi(const float* const* dz, const uint8_t* const* dz_idx, const uint16_t* const* wpk,
                                const float* const* act, float* const* out, const int* n, int njobs, int hw, int cin, int cout,
-                               void* stream);
+                               int products, void* stream);
 /* Weight gradient dw HWIO [3,3,cin,cout] = sum over images and pixels of in (x) dz (Conv2DBackpropFilter (+ MaxPoolGrad when dz_idx
  * is given)), both operands split in registers while they are staged.  ws: >= ugn_x3_conv3x3_wgrad_ws(hw, cin, cout) bytes for the
  * partial-sum slabs (fixed-order reduction, no atomics: bitwise reproducible). */
 size_t ugn_x3_conv3x3_wgrad_ws(int hw, int cin, int cout);
 int ugn_x3_conv3x3_wgrad_multi(const float* const* in, const float* const* dz, const uint8_t* const* dz_idx, float* const* dw,
-                               const int* n, int njobs, int hw, int cin, int cout, void* ws, size_t ws_bytes, void* stream);
+                               const int* n, int njobs, int hw, int cin, int cout, void* ws, size_t ws_bytes, int products, void* stream);
 
 #ifdef __cplusplus
 }

@@ -167,6 +167,46 @@ def test_x3_multi_job(dev):
         close(dws[j], dw_ref, 3e-6, "wgrad job %d" % j)
 
 
+@pytest.mark.parametrize("hw,cin,cout,pool", CONV_CFGS)
+def test_six_products_against_all_nine(dev, hw, cin, cout, pool):
+    """The default arithmetic keeps six of the nine partial products of the split operands; `products=9` keeps all of them -- the
+    EXACT product of every pair of fp32 operands, accumulated in fp32.  On the hardware, same inputs, every kernel: the two differ by
+    no more than the fp32 accumulation's own rounding and have the SAME error against fp64 (measured: equal to three digits in every
+    forward and data-gradient kernel, within 1 % in the weight gradients), i.e. the three dropped products are not what limits the result."""
+    from ugaitnet_amd import x3
+    rng = np.random.default_rng(600 + hw + cin + cout)
+    n = 6 if hw <= 32 else 3
+    x = rng.uniform(-1, 1, (n, hw, hw, cin)).astype(np.float32)
+    w = (rng.standard_normal((3, 3, cin, cout)) * 0.05).astype(np.float32)
+    hz = hw // 2 if pool else hw
+    dzf = (rng.standard_normal((n, hz, hz, cout)) * 1e-3).astype(np.float32)
+    pidx = rng.integers(0, 4, size=dzf.shape).astype(np.uint8) if pool else None
+    xt, wt, dzt = T(x, dev), T(w, dev), T(dzf, dev)
+    it = [T(pidx, dev)] if pool else None
+    x64, w64 = x.astype(np.float64), w.astype(np.float64)
+    act = O.leaky(O.conv2d_same(x64, w64))
+    fref = O.maxpool2x2(act)[0] if pool else act
+    dz64 = O.maxpool2x2_bwd(pidx, dzf.astype(np.float64)) if pool else dzf.astype(np.float64)
+    dw_ref, dx_ref = O.conv2d_same_bwd(x64, w64, dz64)
+    wf, wd = x3.pack(wt, False), x3.pack(wt, True)
+    res = {}
+    for np_ in (6, 9):
+        out = torch.empty((n, hz, hz, cout), device=dev)
+        idx = torch.empty((n, hz, hz, cout), dtype=torch.uint8, device=dev) if pool else None
+        x3.conv3x3_fwd_multi([xt], [wf], cout, pool, [out], [idx] if pool else None, products=np_)
+        dx = torch.empty((n, hw, hw, cin), device=dev)
+        x3.conv3x3_dgrad_multi([dzt], [wd], hw, cin, cout, [dx], dz_idxs=it, products=np_)
+        dw = torch.empty((3, 3, cin, cout), device=dev)
+        x3.conv3x3_wgrad_multi([xt], [dzt], cout, [dw], dz_idxs=it, products=np_)
+        res[np_] = (out, dx, dw)
+    for k, (name, ref) in enumerate((("forward", fref), ("data gradient", dx_ref), ("weight gradient", dw_ref))):
+        e6, e9 = err_of(res[6][k], ref), err_of(res[9][k], ref)
+        d69 = err_of(res[6][k], res[9][k].cpu().numpy().astype(np.float64))
+        print("%s %d->%d @%d: error against fp64 with six products %.2e, with nine %.2e; six against nine %.2e" % (name, cin, cout, hw, e6, e9, d69))
+        assert e6 <= 1.15 * e9 + 2e-8, (name, e6, e9)          # dropping the three smallest products costs nothing measurable ...
+        assert d69 <= max(e6, e9) + 2e-8, (name, d69, e6, e9)           # ... and the two results are no further apart than either is from fp64
+
+
 def test_x3_results_do_not_depend_on_the_persistent_grid(dev):
     """ugn_set_persistent_wgs(n < 256) leaves CUs free for RCCL's channels under data parallelism: the x3 forward / data-gradient
     launches then run n (or 2 n) persistent workgroups over the same items -- bit-identical results for every n."""

@@ -55,6 +55,8 @@ def main():
         oi = torch.empty((nn, ho, ho, cout), dtype=torch.uint8, device=dev) if pool else None
         x3.conv3x3_fwd_multi([xt], [x3.pack(wt, False)], cout, pool, [o], [oi] if pool else None)
         rows["fwd x3"] = errs(o, fref)
+        x3.conv3x3_fwd_multi([xt], [x3.pack(wt, False)], cout, pool, [o], [oi] if pool else None, products=9)
+        rows["fwd x3 (9 products)"] = errs(o, fref)
         r = ops.conv3x3_fwd(xt, ops.pack3x3(wt), pool)
         rows["fwd direct"] = errs(r[0] if pool else r, fref)
         r = ops.conv3x3_fwd_wino(xt, ops.wino_pack(wt, False), cout, pool)
@@ -63,16 +65,20 @@ def main():
         d = torch.empty((nn, hw, hw, cin), device=dev)
         x3.conv3x3_dgrad_multi([dzt], [x3.pack(wt, True)], hw, cin, cout, [d], dz_idxs=[it] if pool else None)
         rows["dgrad x3"] = errs(d, dx_ref)
+        x3.conv3x3_dgrad_multi([dzt], [x3.pack(wt, True)], hw, cin, cout, [d], dz_idxs=[it] if pool else None, products=9)
+        rows["dgrad x3 (9 products)"] = errs(d, dx_ref)
         rows["dgrad direct"] = errs(ops.conv3x3_dgrad(dzt, wt, hw, dz_idx=it), dx_ref)
         rows["dgrad wino"] = errs(ops.conv3x3_dgrad_wino(dzt, ops.wino_pack(wt, True, pooled_dz=pool), hw, cin, cout, dz_idx=it), dx_ref)
         # weight gradient
         g = torch.empty((3, 3, cin, cout), device=dev)
         x3.conv3x3_wgrad_multi([xt], [dzt], cout, [g], dz_idxs=[it] if pool else None)
         rows["wgrad x3"] = errs(g, dw_ref)
+        x3.conv3x3_wgrad_multi([xt], [dzt], cout, [g], dz_idxs=[it] if pool else None, products=9)
+        rows["wgrad x3 (9 products)"] = errs(g, dw_ref)
         rows["wgrad direct"] = errs(ops.conv3x3_wgrad(xt, dzt, cout, dz_idx=it), dw_ref)
         rows["wgrad wino"] = errs(ops.conv3x3_wgrad_wino(xt, dzt, cout, dz_idx=it), dw_ref)
         for k, (mx, rms) in rows.items():
-            print("%s %-13s max %.3e  rms %.3e" % (layer, k, mx, rms), flush=True)
+            print("%s %-22s max %.3e  rms %.3e" % (layer, k, mx, rms), flush=True)
             res["%s %s" % (layer, k)] = dict(max=mx, rms=rms)
     print(json.dumps(res))
 

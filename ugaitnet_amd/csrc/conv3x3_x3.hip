@@ -129,7 +129,7 @@ __global__ __launch_bounds__(256) void x3_split_kernel(const float* __restrict__
 // nothing: tools/bench_x3.py ablations in profiles/r05_x3_experiments.txt); two workgroups drift into anti-phase.
 // FORM: 0 = 8 waves, one workgroup per CU, double-buffered halo; 1 = 4 waves, two workgroups per CU, one halo buffer each;
 //       2 = 8 waves, TWO workgroups per CU (four waves per SIMD, <= 128 registers each), one halo buffer each
-template <int KC, int NC, int HW, int EPI, int IN_POOLED, int FORM>
+template <int KC, int NC, int HW, int EPI, int IN_POOLED, int FORM, int NP>
 __global__ __launch_bounds__(FORM == 1 ? 256 : 512, FORM == 2 ? 4 : 2) void conv_x3_kernel(const X3Jobs jt) {
   constexpr int WAVES = FORM == 1 ? 4 : 8;
   constexpr int NTHR = 64 * WAVES;
@@ -400,15 +400,15 @@ __global__ __launch_bounds__(FORM == 1 ? 256 : 512, FORM == 2 ? 4 : 2) void conv
           for (int dy = 0; dy < 3; ++dy) {
             const int m = j - dy;
             if (m >= 0 && m < ROWS) {
-              nmf += kProducts;
+              nmf += NP;
 #pragma unroll
-              for (int i = 0; i < kProducts; ++i) {
+              for (int i = 0; i < NP; ++i) {
 #if UGN_X3_ABL & 1
-                if constexpr (RES) acc[m][i & 3] += __uint_as_float(wr[dx][dy][prod_w(i)].x ^ fa[j & 1][prod_x(i)].x);
-                else acc[m][i & 3] += __uint_as_float(cb[dy][prod_w(i)].x ^ fa[j & 1][prod_x(i)].x);
+                if constexpr (RES) acc[m][i & 3] += __uint_as_float(wr[dx][dy][prod_w<NP>(i)].x ^ fa[j & 1][prod_x<NP>(i)].x);
+                else acc[m][i & 3] += __uint_as_float(cb[dy][prod_w<NP>(i)].x ^ fa[j & 1][prod_x<NP>(i)].x);
 #else
-                if constexpr (RES) acc[m] = mfma_bf(wr[dx][dy][prod_w(i)], fa[j & 1][prod_x(i)], acc[m]);
-                else acc[m] = mfma_bf(cb[dy][prod_w(i)], fa[j & 1][prod_x(i)], acc[m]);
+                if constexpr (RES) acc[m] = mfma_bf(wr[dx][dy][prod_w<NP>(i)], fa[j & 1][prod_x<NP>(i)], acc[m]);
+                else acc[m] = mfma_bf(cb[dy][prod_w<NP>(i)], fa[j & 1][prod_x<NP>(i)], acc[m]);
 #endif
               }
             }
@@ -571,13 +571,13 @@ constexpr int x3_form() {
   return 1;
 }
 
-template <int KC, int NC, int HW, int EPI, int IN_POOLED>
-int launch_x3(const X3Job* jobs, const int* n, int njobs, hipStream_t stream) {
+template <int KC, int NC, int HW, int EPI, int IN_POOLED, int NP>
+int launch_x3_np(const X3Job* jobs, const int* n, int njobs, hipStream_t stream) {
   constexpr int FORM = x3_form<KC, NC, EPI, IN_POOLED>();
   constexpr int WAVES = FORM == 1 ? 4 : 8, WGS_PER_CU = FORM == 0 ? 1 : 2;
   constexpr int LDS = FORM == 0 ? X3_LDS : X3_BUF;
   static bool attr = false;
-  auto* kern = conv_x3_kernel<KC, NC, HW, EPI, IN_POOLED, FORM>;
+  auto* kern = conv_x3_kernel<KC, NC, HW, EPI, IN_POOLED, FORM, NP>;
   if (!attr) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     if (e != hipSuccess) {
@@ -592,6 +592,12 @@ int launch_x3(const X3Job* jobs, const int* n, int njobs, hipStream_t stream) {
   hipLaunchKernelGGL(kern, dim3(x3_grid() * WGS_PER_CU), dim3(64 * WAVES), LDS, stream, jt);
   UGN_CHECK_LAUNCH("conv_x3_kernel");
   return 0;
+}
+
+template <int KC, int NC, int HW, int EPI, int IN_POOLED>
+int launch_x3(const X3Job* jobs, const int* n, int njobs, int products, hipStream_t stream) {
+  if (products == 9) return launch_x3_np<KC, NC, HW, EPI, IN_POOLED, 9>(jobs, n, njobs, stream);
+  return launch_x3_np<KC, NC, HW, EPI, IN_POOLED, kProducts>(jobs, n, njobs, stream);
 }
 
 }  // namespace
@@ -631,10 +637,11 @@ extern "C" int ugn_x3_split(const float* x, uint16_t* planes, size_t n, void* st
 
 #define X3F(KC_, NC_, HW_, P_)                                                                                          \
   if (cin == KC_ && cout == NC_ && hw == HW_ && (pool != 0) == (P_ != 0))                                               \
-    return launch_x3<KC_, NC_, HW_, P_ ? EPI_LRELU_POOL : EPI_LRELU, 0>(jobs, n, njobs, (hipStream_t)stream);
+    return launch_x3<KC_, NC_, HW_, P_ ? EPI_LRELU_POOL : EPI_LRELU, 0>(jobs, n, njobs, products, (hipStream_t)stream);
 
 extern "C" int ugn_x3_conv3x3_fwd_multi(const float* const* in, const uint16_t* const* wpk, float* const* out, uint8_t* const* out_idx,
-                                        const int* n, int njobs, int hw, int cin, int cout, int pool, void* stream) {
+                                        const int* n, int njobs, int hw, int cin, int cout, int pool, int products, void* stream) {
+  UGN_REQUIRE(products == 6 || products == 9, "ugn_x3_conv3x3_fwd_multi: products must be 6 (default) or 9 (all partial products), got %d", products);
   UGN_REQUIRE(njobs >= 1 && njobs <= kMaxJobs, "ugn_x3_conv3x3_fwd_multi: 1..%d jobs, got %d", kMaxJobs, njobs);
   X3Job jobs[kMaxJobs];
   for (int j = 0; j < njobs; ++j) {
@@ -654,13 +661,14 @@ extern "C" int ugn_x3_conv3x3_fwd_multi(const float* const* in, const uint16_t* 
 // data gradient of the layer cin -> cout at hw x hw: reduction over cout, result [n][hw][hw][cin]
 #define X3D(CI_, CO_, HW_, P_)                                                                                          \
   if (cin == CI_ && cout == CO_ && hw == HW_ && pooled == (P_ != 0)) {                                                  \
-    if (with_act) return launch_x3<CO_, CI_, HW_, EPI_DGRAD_ACT, P_>(jobs, n, njobs, (hipStream_t)stream);              \
-    return launch_x3<CO_, CI_, HW_, EPI_DGRAD, P_>(jobs, n, njobs, (hipStream_t)stream);                                \
+    if (with_act) return launch_x3<CO_, CI_, HW_, EPI_DGRAD_ACT, P_>(jobs, n, njobs, products, (hipStream_t)stream);              \
+    return launch_x3<CO_, CI_, HW_, EPI_DGRAD, P_>(jobs, n, njobs, products, (hipStream_t)stream);                                \
   }
 
 extern "C" int ugn_x3_conv3x3_dgrad_multi(const float* const* dz, const uint8_t* const* dz_idx, const uint16_t* const* wpk,
                                           const float* const* act, float* const* out, const int* n, int njobs, int hw, int cin,
-                                          int cout, void* stream) {
+                                          int cout, int products, void* stream) {
+  UGN_REQUIRE(products == 6 || products == 9, "ugn_x3_conv3x3_dgrad_multi: products must be 6 (default) or 9 (all partial products), got %d", products);
   UGN_REQUIRE(njobs >= 1 && njobs <= kMaxJobs, "ugn_x3_conv3x3_dgrad_multi: 1..%d jobs, got %d", kMaxJobs, njobs);
   const bool pooled = dz_idx != nullptr && dz_idx[0] != nullptr;
   const bool with_act = act != nullptr && act[0] != nullptr;

@@ -66,7 +66,7 @@ __device__ __forceinline__ uint4 tr_pair(const LDS_PTR(char) base, int off0, int
   return make_uint4(ua.x, ua.y, ub.x, ub.y);
 }
 
-template <int CI, int CO, int HW, int POOLED>
+template <int CI, int CO, int HW, int POOLED, int NP>
 __global__ __launch_bounds__(512, 2) void wgrad_x3_kernel(const WgJobs jt) {
   using G = WGeo<CO>;
   constexpr int COW = G::COW, SR = G::SR, KS = G::KS, KGZ = G::KGZ, SET = G::SET;
@@ -230,7 +230,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_x3_kernel(const WgJobs jt) {
       for (int c = 0; c < 2; ++c) {
         f32x4 acc = a4[t][c];
 #pragma unroll
-        for (int i = 0; i < kProducts; ++i) acc = mfma_bf(xa[t & 1][prod_w(i)], zb[c][prod_x(i)], acc);
+        for (int i = 0; i < NP; ++i) acc = mfma_bf(xa[t & 1][prod_w<NP>(i)], zb[c][prod_x<NP>(i)], acc);
         a4[t][c] = acc;
       }
       // the next strip's units are split and written behind the MFMAs of taps 1 .. NSU, one unit per tap, their vector instructions
@@ -238,7 +238,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_x3_kernel(const WgJobs jt) {
       if (t >= 1 && t <= NSU) {
         stage_store_unit(b ^ 1, t - 1);
 #pragma unroll
-        for (int k = 0; k < 2 * kProducts; ++k) {
+        for (int k = 0; k < 2 * NP; ++k) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
           __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
         }
@@ -312,7 +312,7 @@ __device__ __forceinline__ f32x4 smfmac_bf(uint4 a, const u8x& b, f32x4 c, int i
   return __builtin_amdgcn_smfmac_f32_16x16x64_bf16(__builtin_bit_cast(sb8, a), __builtin_bit_cast(sb16, b), c, idx, 0, 0);
 }
 
-template <int CI, int CO, int HW>
+template <int CI, int CO, int HW, int NP>
 __global__ __launch_bounds__(512, 2) void wgrad_x3s_kernel(const WgJobs jt) {
   using G = SGeo;
   constexpr int COW = G::COW, SR = G::SR, SET = G::SET, IN_PLANE = G::IN_PLANE, IN_BYTES = G::IN_BYTES, PZ_PLANE = G::PZ_PLANE;
@@ -473,13 +473,13 @@ __global__ __launch_bounds__(512, 2) void wgrad_x3s_kernel(const WgJobs jt) {
       for (int c = 0; c < 2; ++c) {
         f32x4 acc = a4[t][c];
 #pragma unroll
-        for (int i = 0; i < kProducts; ++i) acc = smfmac_bf(sa[c][prod_w(i)], xb[t & 1][prod_x(i)], acc, sidx[c]);
+        for (int i = 0; i < NP; ++i) acc = smfmac_bf(sa[c][prod_w<NP>(i)], xb[t & 1][prod_x<NP>(i)], acc, sidx[c]);
         a4[t][c] = acc;
       }
       if (t >= 1 && t <= NSU) {
         stage_store_unit(b ^ 1, t - 1);
 #pragma unroll
-        for (int k = 0; k < 2 * kProducts; ++k) {
+        for (int k = 0; k < 2 * NP; ++k) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
           __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
         }
@@ -560,17 +560,17 @@ size_t ws_floats_for(int njobs) {
   return (size_t)NCOMBO * (NG + njobs) * 9 * 32 * G::COW;
 }
 
-template <int CI, int CO, int HW, int POOLED>
-int launch_wgrad(const float* const* in, const float* const* dz, const uint8_t* const* dz_idx, float* const* dw, const int* n, int njobs,
-                 float* ws, size_t ws_floats, hipStream_t st) {
+template <int CI, int CO, int HW, int POOLED, int NP>
+int launch_wgrad_np(const float* const* in, const float* const* dz, const uint8_t* const* dz_idx, float* const* dw, const int* n, int njobs,
+                    float* ws, size_t ws_floats, hipStream_t st) {
   constexpr bool SPARSE = (POOLED != 0) & (UGN_X3_SPARSE != 0);
   using G = LGeo<CO, SPARSE>;
   constexpr int NCOMBO = (CI / 32) * (CO / G::COW), NG = wg_ngroups<CI, CO, SPARSE>();
   constexpr int SPI = (HW / G::SR) * (HW / 16);
   static_assert(G::LDS <= 163840 && NG % 8 == 0 && HW % G::SR == 0, "geometry");
   void (*kern)(const WgJobs);
-  if constexpr (SPARSE) kern = wgrad_x3s_kernel<CI, CO, HW>;
-  else kern = wgrad_x3_kernel<CI, CO, HW, POOLED>;
+  if constexpr (SPARSE) kern = wgrad_x3s_kernel<CI, CO, HW, NP>;
+  else kern = wgrad_x3_kernel<CI, CO, HW, POOLED, NP>;
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
@@ -618,6 +618,13 @@ int launch_wgrad(const float* const* in, const float* const* dz, const uint8_t* 
   return 0;
 }
 
+template <int CI, int CO, int HW, int POOLED>
+int launch_wgrad(const float* const* in, const float* const* dz, const uint8_t* const* dz_idx, float* const* dw, const int* n, int njobs,
+                 float* ws, size_t ws_floats, int products, hipStream_t st) {
+  if (products == 9) return launch_wgrad_np<CI, CO, HW, POOLED, 9>(in, dz, dz_idx, dw, n, njobs, ws, ws_floats, st);
+  return launch_wgrad_np<CI, CO, HW, POOLED, kProducts>(in, dz, dz_idx, dw, n, njobs, ws, ws_floats, st);
+}
+
 }  // namespace
 
 extern "C" size_t ugn_x3_conv3x3_wgrad_ws(int hw, int cin, int cout) {
@@ -633,8 +640,9 @@ extern "C" size_t ugn_x3_conv3x3_wgrad_ws(int hw, int cin, int cout) {
 }
 
 extern "C" int ugn_x3_conv3x3_wgrad_multi(const float* const* in, const float* const* dz, const uint8_t* const* dz_idx, float* const* dw,
-                                          const int* n, int njobs, int hw, int cin, int cout, void* ws, size_t ws_bytes, void* stream) {
+                                          const int* n, int njobs, int hw, int cin, int cout, void* ws, size_t ws_bytes, int products, void* stream) {
   UGN_REQUIRE(in && dz && dw && n && ws, "ugn_x3_conv3x3_wgrad_multi: null array");
+  UGN_REQUIRE(products == 6 || products == 9, "ugn_x3_conv3x3_wgrad_multi: products must be 6 (default) or 9 (all partial products), got %d", products);
   UGN_REQUIRE(njobs >= 1 && njobs <= kMaxJobs, "ugn_x3_conv3x3_wgrad_multi: njobs must be 1..%d (got %d)", kMaxJobs, njobs);
   const bool pooled = dz_idx != nullptr && dz_idx[0] != nullptr;
   for (int j = 0; j < njobs; ++j) {
@@ -646,7 +654,7 @@ extern "C" int ugn_x3_conv3x3_wgrad_multi(const float* const* in, const float* c
   const size_t wfl = ws_bytes / sizeof(float);
 #define WG(CI_, CO_, HW_, P_)                                        \
   if (cin == CI_ && cout == CO_ && hw == HW_ && pooled == (P_ != 0)) \
-    return launch_wgrad<CI_, CO_, HW_, P_>(in, dz, dz_idx, dw, n, njobs, wsf, wfl, st);
+    return launch_wgrad<CI_, CO_, HW_, P_>(in, dz, dz_idx, dw, n, njobs, wsf, wfl, products, st);
   WG(32, 32, 64, 1) WG(32, 64, 32, 0) WG(64, 64, 32, 1) WG(64, 128, 16, 0) WG(128, 128, 16, 0)
 #undef WG
   ugn_set_error("ugn_x3_conv3x3_wgrad_multi: unsupported shape cin=%d cout=%d hw=%d pooled=%d", cin, cout, hw, (int)pooled);

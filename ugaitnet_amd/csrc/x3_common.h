@@ -63,10 +63,16 @@ __device__ __forceinline__ void split8(const float4& u, const float4& v, uint4& 
   split2(v.z, v.w, p0.w, p1.w, p2.w);
 }
 
-// the six partial products kept, smallest first: (filter plane, pixel plane)
+// the partial products, smallest first: (filter plane, pixel plane).  NP = 6 (the default arithmetic) drops the first three of the
+// nine -- x1 w2, x2 w1, x2 w2 <= 2^-23 |x w| together; NP = 9 keeps them: the EXACT product of the operands, 1.5x the matrix time,
+// selectable per call (`products` argument of the ugn_x3_* entry points) so that the claim "the dropped ones are below the rounding
+// of the accumulation" is checked on the hardware itself (tests/test_x3_gpu.py::test_six_products_against_all_nine).
 constexpr int kProducts = 6;
-__host__ __device__ constexpr int prod_w(int i) { return i == 0 ? 0 : i == 1 ? 2 : i == 2 ? 1 : i == 3 ? 0 : i == 4 ? 1 : 0; }
-__host__ __device__ constexpr int prod_x(int i) { return i == 0 ? 2 : i == 1 ? 0 : i == 2 ? 1 : i == 3 ? 1 : i == 4 ? 0 : 0; }
+__host__ __device__ constexpr int prod9_w(int i) { return i == 0 ? 2 : i == 1 ? 1 : i == 2 ? 2 : i == 3 ? 0 : i == 4 ? 2 : i == 5 ? 1 : i == 6 ? 0 : i == 7 ? 1 : 0; }
+__host__ __device__ constexpr int prod9_x(int i) { return i == 0 ? 2 : i == 1 ? 2 : i == 2 ? 1 : i == 3 ? 2 : i == 4 ? 0 : i == 5 ? 1 : i == 6 ? 1 : i == 7 ? 0 : 0; }
+template <int NP> __host__ __device__ constexpr int prod_w(int i) { return prod9_w(i + 9 - NP); }
+template <int NP> __host__ __device__ constexpr int prod_x(int i) { return prod9_x(i + 9 - NP); }
+static_assert(prod_w<6>(0) == 0 && prod_x<6>(0) == 2 && prod_w<6>(5) == 0 && prod_x<6>(5) == 0 && prod_w<9>(0) == 2 && prod_x<9>(0) == 2, "product order");
 
 constexpr int kMaxJobs = 6;      // jobs per launch: the frame-level layer and the set-level twin of up to three modalities
 constexpr int kGrid = 256;       // persistent workgroups (one per CU)

@@ -15,7 +15,7 @@ I16 = torch.int16
 U8 = torch.uint8
 F32 = torch.float32
 MAX_JOBS = 6
-PRODUCTS = 6           # bf16 MFMAs per fp32 product (csrc/x3_common.h kProducts)
+PRODUCTS = 6           # bf16 MFMAs per fp32 product (csrc/x3_common.h kProducts); 9 = all partial products (verification)
 
 
 def _stream():
@@ -92,7 +92,7 @@ def pack(w, dgrad):
     return pk
 
 
-def conv3x3_fwd_multi(xs, wpks, cout, pool, outs, idxs=None):
+def conv3x3_fwd_multi(xs, wpks, cout, pool, outs, idxs=None, products=PRODUCTS):
     """Up to 6 forward convolutions of one shape in a single launch: outs[j] = LeakyReLU(conv(xs[j])) (+ MaxPool, argmax bytes)."""
     assert 1 <= len(xs) <= MAX_JOBS and len(wpks) == len(outs) == len(xs) and (not pool or idxs is not None)
     for t in list(xs) + list(outs):
@@ -105,11 +105,11 @@ def conv3x3_fwd_multi(xs, wpks, cout, pool, outs, idxs=None):
     kern = "conv_x3_kernel<%d, %d, %d, %d, 0, %d>" % (cin, cout, hw, 1 if pool else 0, _waves(cin, cout, bool(pool), False))
     label, work = _work("fwd", hw, cin, cout, pool, ns, kern, nbytes)
     call("ugn_x3_conv3x3_fwd_multi", ptr_array(xs), ptr_array(wpks), ptr_array(outs), ptr_array(idxs) if pool else None, _ints(ns),
-         len(xs), hw, cin, cout, int(bool(pool)), _stream(), label=label, work=work)
+         len(xs), hw, cin, cout, int(bool(pool)), int(products), _stream(), label=label, work=work)
     return (outs, idxs) if pool else outs
 
 
-def conv3x3_dgrad_multi(dzs, wpks, hw, cin, cout, outs, dz_idxs=None, acts=None):
+def conv3x3_dgrad_multi(dzs, wpks, hw, cin, cout, outs, dz_idxs=None, acts=None, products=PRODUCTS):
     """Up to 6 data gradients of the layer cin -> cout at hw x hw in a single launch; dz_idxs: the gradients are POOLED + argmax
     bytes; acts: outs *= LeakyReLU'(acts)."""
     assert 1 <= len(dzs) <= MAX_JOBS and len(wpks) == len(outs) == len(dzs)
@@ -123,11 +123,11 @@ def conv3x3_dgrad_multi(dzs, wpks, hw, cin, cout, outs, dz_idxs=None, acts=None)
     kern = "conv_x3_kernel<%d, %d, %d, %d, %d, %d>" % (cout, cin, hw, 3 if acts else 2, int(pooled), _waves(cout, cin, False, pooled))
     label, work = _work("dgrad", hw, cin, cout, pooled, ns, kern, nbytes)
     call("ugn_x3_conv3x3_dgrad_multi", ptr_array(dzs), _opt(dz_idxs) if pooled else None, ptr_array(wpks), _opt(acts), ptr_array(outs),
-         _ints(ns), len(dzs), hw, cin, cout, _stream(), label=label, work=work)
+         _ints(ns), len(dzs), hw, cin, cout, int(products), _stream(), label=label, work=work)
     return outs
 
 
-def conv3x3_wgrad_multi(xs, dzs, cout, dws, dz_idxs=None):
+def conv3x3_wgrad_multi(xs, dzs, cout, dws, dz_idxs=None, products=PRODUCTS):
     """Up to 6 weight gradients of one shape in a single launch: dws[j] HWIO [3,3,cin,cout] = sum xs[j] (x) dzs[j]."""
     assert 1 <= len(xs) <= MAX_JOBS and len(dzs) == len(dws) == len(xs)
     for t in list(xs) + list(dzs) + list(dws):
@@ -146,5 +146,5 @@ def conv3x3_wgrad_multi(xs, dzs, cout, dws, dz_idxs=None):
     kern = "wgrad_x3s_kernel<%d, %d, %d>" % (cin, cout, hw) if pooled else "wgrad_x3_kernel<%d, %d, %d, 0>" % (cin, cout, hw)
     label, work = _work("wgrad", hw, cin, cout, pooled, ns, kern, nbytes, products=PRODUCTS // 2 if pooled else PRODUCTS)
     call("ugn_x3_conv3x3_wgrad_multi", ptr_array(xs), ptr_array(dzs), _opt(dz_idxs) if pooled else None, ptr_array(dws), _ints(ns),
-         len(xs), hw, cin, cout, ptr(ws), ws.numel(), _stream(), label=label, work=work)
+         len(xs), hw, cin, cout, ptr(ws), ws.numel(), int(products), _stream(), label=label, work=work)
     return dws
