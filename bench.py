@@ -63,9 +63,10 @@ def flop_per_clip(kinds):
 DTYPE_TEXT = {
     "f32x3": "f32: IEEE fp32 tensors in HBM end to end (no storage format, no block exponent); the 3x3 layers multiply them on "
              "v_mfma_f32_16x16x32_bf16 through the EXACT three-way bf16 split of both operands (x = x0 + x1 + x2, 24 = 8 + 8 + 8 bits, "
-             "fp32's exponent range), six of the nine partial products per fp32 product (the dropped ones < 2^-23 of the product), fp32 "
-             "accumulate: error against fp64 at the level of the fp32-MFMA kernels of the same library on the same inputs "
-             "(tests/test_x3_gpu.py, tools/x3_accuracy.py); 5x5 layer, pooling, head, losses, Adam in fp32",
+             "fp32's exponent range), six of the nine partial products per fp32 product (the dropped ones < 2^-23 of the product: on the "
+             "hardware all nine give the same error against fp64 to three digits), fp32 accumulate: error against fp64 at the level of "
+             "the fp32-MFMA kernels of the same library on the same inputs (tests/test_x3_gpu.py, tools/x3_accuracy.py); 5x5 layer, "
+             "pooling, head, losses, Adam in fp32",
     "f32": "f32: IEEE fp32 tensors and arithmetic end to end, 3x3 layers as Winograd F(2x2,3x3) on v_mfma_f32_16x16x4_f32",
     "bf16": "bf16: activations, gradients and saved tensors bf16 in HBM, 3x3 layers on v_mfma_f32_32x32x16_bf16 with f32 accumulate, "
             "f32 weight gradients / master weights / Adam (BASELINE configs[4])",
