@@ -43,6 +43,22 @@ __host__ __device__ constexpr int x3_slot(int kg, int col) { return kg ^ (((col 
 #define UGN_X3_SGB 4        /* vector instructions of the split scheduled behind each MFMA of a staging row (0: hipcc's order) */
 #endif
 
+// diagnostic build only (-DUGN_X3_STAMP=1, tools/stamp_x3.py): s_memtime of wave 0 at the phases of its first items, workgroups 0..31
+#ifndef UGN_X3_STAMP
+#define UGN_X3_STAMP 0
+#endif
+#if UGN_X3_STAMP
+constexpr int kStampWgs = 32, kStampItems = 48;
+__device__ unsigned long long ugn_x3_stamp_buf[kStampWgs * kStampItems * 8];
+#define X3_STAMP(k_)                                                                                                      \
+  do {                                                                                                                    \
+    if (tid == 0 && blockIdx.x < kStampWgs && nstamp < kStampItems)                                                       \
+      ugn_x3_stamp_buf[(blockIdx.x * kStampItems + nstamp) * 8 + (k_)] = (k_) == 6 ? __builtin_amdgcn_s_memrealtime() : __builtin_amdgcn_s_memtime(); \
+  } while (0)
+#else
+#define X3_STAMP(k_) do { } while (0)
+#endif
+
 enum { EPI_LRELU = 0, EPI_LRELU_POOL = 1, EPI_DGRAD = 2, EPI_DGRAD_ACT = 3 };
 
 struct X3Job {
@@ -327,7 +343,12 @@ __global__ __launch_bounds__(FORM == 1 ? 256 : 512, FORM == 2 ? 4 : 2) void conv
   if constexpr (DB) tile_load(tl_next(t_cur));
   int hbuf = 0;
 
+#if UGN_X3_STAMP
+  int nstamp = 0;
+#endif
   for (; item < ir.end; item += ir.stride) {
+    X3_STAMP(0);
+    X3_STAMP(6);
     const int next_item = item + ir.stride;
     const bool more = next_item < ir.end;
     const int jn = more ? job_of(jt, next_item) : jb, nlit = more ? next_item - jt.start[jn] : lit;
@@ -358,6 +379,7 @@ __global__ __launch_bounds__(FORM == 1 ? 256 : 512, FORM == 2 ? 4 : 2) void conv
 #if !(UGN_X3_ABL & 16)
       __syncthreads();                                      // the chunk's tile is complete (8 waves: nobody reads the other buffer any more)
 #endif
+      if (chunk == 0) X3_STAMP(1);
 #pragma unroll
       for (int dx = 0; dx < 3; ++dx) {
         uint4 cb[RES ? 1 : 3][3];
@@ -445,11 +467,13 @@ __global__ __launch_bounds__(FORM == 1 ? 256 : 512, FORM == 2 ? 4 : 2) void conv
     }
     // (forms 1: the next item's first tile is fetched before the epilogue and split behind it; form 2 -- 128 registers -- fetches it
     //  behind the epilogue, whose latency the CU's other waves cover)
+    X3_STAMP(2);
     constexpr bool PRE = !DB && SROUND == NSLOT && FORM != 2;
     if constexpr (PRE) {
       if (more) tile_load(Tl{next_item, 0});
       __builtin_amdgcn_sched_barrier(0);
     }
+    X3_STAMP(3);
 
 #if UGN_X3_ABL & 4
     if (ry0 < 0) {
@@ -517,6 +541,7 @@ __global__ __launch_bounds__(FORM == 1 ? 256 : 512, FORM == 2 ? 4 : 2) void conv
       }
     }
     }
+    X3_STAMP(4);
     if constexpr (PRE) {
 #if !(UGN_X3_ABL & 2)
       __builtin_amdgcn_sched_barrier(0);
@@ -528,6 +553,10 @@ __global__ __launch_bounds__(FORM == 1 ? 256 : 512, FORM == 2 ? 4 : 2) void conv
     }
     jb = jn;
     lit = nlit;
+    X3_STAMP(5);
+#if UGN_X3_STAMP
+    ++nstamp;
+#endif
   }
 }
 
@@ -602,6 +631,16 @@ int launch_x3(const X3Job* jobs, const int* n, int njobs, int products, hipStrea
 
 }  // namespace
 
+
+#if UGN_X3_STAMP
+extern "C" int ugn_x3_debug_stamps(unsigned long long* host_dst, int n) {
+  hipError_t e = hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(ugn_x3_stamp_buf), (size_t)n * sizeof(unsigned long long));
+  void* p = nullptr;
+  if (e == hipSuccess) e = hipGetSymbolAddress(&p, HIP_SYMBOL(ugn_x3_stamp_buf));
+  if (e == hipSuccess) e = hipMemset(p, 0, sizeof(unsigned long long) * kStampWgs * kStampItems * 8);      // (the next launch starts from zeros)
+  return (int)e;
+}
+#endif
 
 extern "C" int ugn_x3_pack_multi(const float* const* w_hwio_host, uint16_t* const* wpk_host, const int* cin_host, const int* cout_host,
                                  const int* dgrad_host, int njobs, void* stream) {
