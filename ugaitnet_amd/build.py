@@ -27,14 +27,33 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def _digest(paths, flags):
+    """sha256 over the CONTENT of a source, every header it may include and the compiler command: an object is reused only when its
+    recorded digest matches (modification times say nothing after a checkout, a copy or a snapshot to another machine)."""
+    import hashlib
+    h = hashlib.sha256()
+    h.update("\0".join(flags).encode())
+    for p in paths:
+        with open(p, "rb") as f:
+            h.update(b"\0" + os.path.basename(p).encode() + b"\0" + f.read())
+    return h.hexdigest()
+
+
 def _compile(src, objdir=None, extra=()):
+    import glob
     obj = os.path.join(objdir or OBJ, os.path.splitext(src)[0] + ".o")
     path = os.path.join(CSRC, src)
-    if _stale(obj, [path] + HEADERS):
-        cmd = [HIPCC] + FLAGS + list(extra) + (["-x", "hip"] if src.endswith(".cpp") else []) + ["-c", path, "-o", obj]
+    cmd = [HIPCC] + FLAGS + list(extra) + (["-x", "hip"] if src.endswith(".cpp") else []) + ["-c", path, "-o", obj]
+    headers = sorted(set(HEADERS + glob.glob(os.path.join(CSRC, "*.h"))))
+    want = _digest([path] + headers, cmd[:-3])
+    stamp = obj + ".sha256"
+    have = open(stamp).read().strip() if os.path.exists(stamp) and os.path.exists(obj) else ""
+    if have != want:
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("hipcc failed for %s:\n%s" % (src, r.stderr))
+        with open(stamp, "w") as f:
+            f.write(want + "\n")
         return obj, True
     return obj, False
 
@@ -49,6 +68,8 @@ def build(force=False, verbose=True, variant=None, extra=()):
     if force:
         for f in os.listdir(objdir):
             os.remove(os.path.join(objdir, f))
+        if os.path.exists(LIB + ".sha256"):
+            os.remove(LIB + ".sha256")
     # a variant recompiles only the sources (or headers) that mention one of its -D macros; the rest links the default build's objects
     import glob
     import re
@@ -65,11 +86,17 @@ def build(force=False, verbose=True, variant=None, extra=()):
     with ThreadPoolExecutor(max_workers=4) as ex:
         res = list(ex.map(one, SOURCES))
     objs = [o for o, _ in res]
-    if any(c for _, c in res) or _stale(LIB, objs):
+    # the library records the digests of the objects it was linked from: an unchanged tree links nothing, anything else re-links
+    link_want = "\n".join(open(o + ".sha256").read().strip() for o in objs)
+    link_stamp = LIB + ".sha256"
+    link_have = open(link_stamp).read().strip() if os.path.exists(link_stamp) and os.path.exists(LIB) else ""
+    if any(c for _, c in res) or link_have != link_want:
         cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("link failed:\n" + r.stderr)
+        with open(link_stamp, "w") as f:
+            f.write(link_want + "\n")
         if verbose:
             print("built", LIB)
     elif verbose:
