@@ -69,3 +69,24 @@ def test_six_partial_products_are_as_good_as_all_nine(k):
     # ... and three products (what two planes would give) are NOT enough: an order of magnitude worse
     e3 = np.abs(_accumulate(A, B, [(0, 1), (1, 0), (0, 0)]) - ref) / scale
     assert e3.mean() > 5 * e6.mean()
+
+
+def test_kernel_labels_name_every_template_argument():
+    """bench.py finds a launch's PMC traffic record (profiles/roofline_traffic_f32x3.json) and the judge finds its rocprofv3 row by
+    the kernel name ugaitnet_amd/x3.py puts in the label: the label must carry as many template arguments as the kernel has, and the
+    committed traffic record must use the same spelling."""
+    import json
+    import os
+    import re
+    root = os.path.join(os.path.dirname(__file__), "..")
+    host = open(os.path.join(root, "ugaitnet_amd", "x3.py")).read()
+    for src, kernel in (("conv3x3_x3.hip", "conv_x3_kernel"), ("wgrad3x3_x3.hip", "wgrad_x3_kernel"), ("wgrad3x3_x3.hip", "wgrad_x3s_kernel")):
+        text = open(os.path.join(root, "ugaitnet_amd", "csrc", src)).read()
+        m = re.search(r"template <([^>]*)>\s*__global__[^\n]*\bvoid %s\(" % kernel, text)
+        assert m, kernel
+        nargs = m.group(1).count(",") + 1
+        labels = re.findall(r'"%s<([^>]*)>"' % kernel, host)
+        assert labels and all(lab.count(",") + 1 == nargs for lab in labels), (kernel, nargs, labels)
+        rec = json.load(open(os.path.join(root, "profiles", "roofline_traffic_f32x3.json")))["kernels"]
+        mine = [r["rocprof_kernel"] for r in rec if r["rocprof_kernel"].startswith(kernel + "<")]
+        assert mine and all(n.count(",") + 1 == nargs for n in mine), (kernel, nargs, mine)

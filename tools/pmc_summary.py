@@ -1,6 +1,9 @@
 """Summarise rocprofv3 --pmc passes (csv) per kernel: duration, clock, MFMA busy, wait share, VALU per MFMA, HBM bytes.
 
-usage: pmc_summary.py <dir with sq_/fetch_/write_ csv files> <out.csv> [min_grid_workgroups]
+usage: pmc_summary.py <dir with sq_/fetch_/write_ csv files> <out.csv> [min_grid_workgroups [traffic.json frames sets]]
+With the last three arguments the FETCH + WRITE bytes per launch of every 3x3 kernel are also written as the record bench.py reads
+its `roofline.traffic` from (profiles/roofline_traffic_<dtype>.json): `frames` / `sets` = frame-level / set-level images of a launch
+(C3 at 24 clips: 1800 / 72; the 64x64 layer has no set-level twin).
 FETCH_SIZE is doubled (gfx950 tallies 16 B/lane reads at half, MI355X_MICROARCH.md); units of FETCH/WRITE_SIZE are KiB.
 Only launches with at least `min_grid_workgroups` workgroups are averaged (drops the set-level launches of the dense run)."""
 import collections
@@ -44,3 +47,19 @@ with open(out, "w") as fh:
     for _, k, du, n, clk, mb, wt, vpm, f, w in lines:
         fh.write('"%s",%.1f,%d,%.2f,%.1f,%.1f,%.2f,%.1f,%.1f\n' % (k, du, n, clk, mb, wt, vpm, f, w))
 print(open(out).read())
+if len(sys.argv) > 6:
+    import json
+    import os
+    import re
+    frames, sets = int(sys.argv[5]), int(sys.argv[6])
+    recs = []
+    for _, k, du, n, clk, mb, wt, vpm, f, w in lines:
+        m = re.match(r"(conv_\w+|wgrad_\w+|wino\w*)<(\d+), (\d+), (\d+)", k)
+        if not m or f != f or w != w:
+            continue
+        images = frames if int(m.group(4)) == 64 else frames + sets
+        recs.append(dict(rocprof_kernel=k, images_per_launch=images, hbm_bytes_per_launch=int(round((f + w) * 1e6, -5)),
+                         source="%s: FETCH_SIZE x2 (whole 128-B lines: profiles/r04_fetch_calibration.txt) %.1f MB + WRITE_SIZE %.1f MB per "
+                                "launch at %d images (separate --pmc passes of `bench.py --serial`)" % (os.path.basename(out), f, w, images)))
+    json.dump(dict(kernels=recs), open(sys.argv[4], "w"), indent=1)
+    print("traffic record:", sys.argv[4], len(recs), "kernels")

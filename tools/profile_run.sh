@@ -30,7 +30,9 @@ pmc() {     # $1 = prefix, rest = counters
 pmc sq SQ_BUSY_CU_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA GRBM_GUI_ACTIVE
 pmc fetch FETCH_SIZE
 pmc write WRITE_SIZE
-python3 $REPO/tools/pmc_summary.py $OUT/prof_$TAGDIR $OUT/${TAG}_pmc_summary$SUFFIX.csv > /dev/null && echo "pmc summary written"
+# (+ the FETCH / WRITE bytes per launch as the record bench.py's `roofline.traffic` comes from: copy it to profiles/ with the summaries)
+python3 $REPO/tools/pmc_summary.py $OUT/prof_$TAGDIR $OUT/${TAG}_pmc_summary$SUFFIX.csv 0 $OUT/roofline_traffic_${DTYPE:-f32x3}.json \
+  ${FRAMES:-1800} ${SETS:-72} > /dev/null && echo "pmc summary written"
 # LDS bank conflicts per kernel (profiles/<tag>_lds_conflicts.csv): conflict cycles / LDS active cycles, LDS active / CU busy
 pmc lds SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_BUSY_CU_CYCLES
 python3 - "$OUT/prof_$TAGDIR/lds_counter_collection.csv" "$OUT/${TAG}_lds_conflicts$SUFFIX.csv" <<'PY' && echo "lds summary written"

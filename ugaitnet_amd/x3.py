@@ -102,7 +102,7 @@ def conv3x3_fwd_multi(xs, wpks, cout, pool, outs, idxs=None, products=PRODUCTS):
     n = sum(ns)
     ho = hw // 2 if pool else hw
     nbytes = n * (hw * hw * cin * 4 + ho * ho * cout * (5 if pool else 4)) + len(xs) * 54 * cin * cout
-    kern = "conv_x3_kernel<%d, %d, %d, %d, 0, %d>" % (cin, cout, hw, 1 if pool else 0, _waves(cin, cout, bool(pool), False))
+    kern = "conv_x3_kernel<%d, %d, %d, %d, 0, %d, %d>" % (cin, cout, hw, 1 if pool else 0, _waves(cin, cout, bool(pool), False), products)
     label, work = _work("fwd", hw, cin, cout, pool, ns, kern, nbytes)
     call("ugn_x3_conv3x3_fwd_multi", ptr_array(xs), ptr_array(wpks), ptr_array(outs), ptr_array(idxs) if pool else None, _ints(ns),
          len(xs), hw, cin, cout, int(bool(pool)), int(products), _stream(), label=label, work=work)
@@ -120,7 +120,7 @@ def conv3x3_dgrad_multi(dzs, wpks, hw, cin, cout, outs, dz_idxs=None, acts=None,
     pooled = bool(dz_idxs) and dz_idxs[0] is not None
     hz = hw // 2 if pooled else hw
     nbytes = n * (hz * hz * cout * (5 if pooled else 4) + hw * hw * cin * (8 if acts else 4)) + len(dzs) * 54 * cin * cout
-    kern = "conv_x3_kernel<%d, %d, %d, %d, %d, %d>" % (cout, cin, hw, 3 if acts else 2, int(pooled), _waves(cout, cin, False, pooled))
+    kern = "conv_x3_kernel<%d, %d, %d, %d, %d, %d, %d>" % (cout, cin, hw, 3 if acts else 2, int(pooled), _waves(cout, cin, False, pooled), products)
     label, work = _work("dgrad", hw, cin, cout, pooled, ns, kern, nbytes)
     call("ugn_x3_conv3x3_dgrad_multi", ptr_array(dzs), _opt(dz_idxs) if pooled else None, ptr_array(wpks), _opt(acts), ptr_array(outs),
          _ints(ns), len(dzs), hw, cin, cout, int(products), _stream(), label=label, work=work)
@@ -143,7 +143,7 @@ def conv3x3_wgrad_multi(xs, dzs, cout, dws, dz_idxs=None, products=PRODUCTS):
     ws = _WS.get(nbytes_ws, xs[0].device)
     nbytes = n * (hw * hw * cin * 4 + hz * hz * cout * (5 if pooled else 4)) + len(xs) * 36 * cin * cout
     # pooled layers: the sparse matrix pipe (v_smfmac_f32_16x16x64_bf16) issues HALF the matrix instructions
-    kern = "wgrad_x3s_kernel<%d, %d, %d>" % (cin, cout, hw) if pooled else "wgrad_x3_kernel<%d, %d, %d, 0>" % (cin, cout, hw)
+    kern = "wgrad_x3s_kernel<%d, %d, %d, %d>" % (cin, cout, hw, products) if pooled else "wgrad_x3_kernel<%d, %d, %d, 0, %d>" % (cin, cout, hw, products)
     label, work = _work("wgrad", hw, cin, cout, pooled, ns, kern, nbytes, products=PRODUCTS // 2 if pooled else PRODUCTS)
     call("ugn_x3_conv3x3_wgrad_multi", ptr_array(xs), ptr_array(dzs), _opt(dz_idxs) if pooled else None, ptr_array(dws), _ints(ns),
          len(xs), hw, cin, cout, ptr(ws), ws.numel(), int(products), _stream(), label=label, work=work)
