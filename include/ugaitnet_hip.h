@@ -424,6 +424,12 @@ int ugn_hpp_bwd_b4bf_multi(const float* const* a, const float* const* s3, const 
 int ugn_x3_split(const float* x, uint16_t* planes, size_t n, void* stream);
 int ugn_x3_pack_multi(const float* const* w_hwio_host, uint16_t* const* wpk_host, const int* cin_host, const int* cout_host,
                       const int* dgrad_host, int njobs, void* stream);
+/* The first layer (ZeroPadding2D(2) + Conv2D(32, 5x5) + LeakyReLU, nets/mj_uwyhNets_ba.py:428-430) and its weight gradient in the same
+ * arithmetic: arguments, tensors and the optional sign words exactly as ugn_conv5x5_in_fwd / ugn_conv5x5_in_wgrad (workspace:
+ * ugn_conv5x5_in_wgrad_ws), six bf16 products per fp32 product on v_mfma_f32_32x32x16_bf16 instead of the fp32 MFMA. */
+int ugn_x3_conv5x5_in_fwd(const float* x, const float* w, float* a1, uint32_t* a1_sign, int n, int cin, void* stream);
+int ugn_x3_conv5x5_in_wgrad(const float* x, const float* dz1, const uint32_t* a1_sign, float* dw, int n, int cin, void* ws,
+                            size_t ws_bytes, void* stream);
 /* out = LeakyReLU(conv(in)) (+ MaxPooling2D(2,2) and first-maximum argmax bytes when pool != 0) for up to 6 jobs of one shape
  * (the frame-level layer and the set-level twin of every modality): Conv2D + LeakyReLU + MaxPooling2D, :431-462. */
 /* products: 6 = the default arithmetic; 9 = every partial product of the split operands, i.e. the EXACT product (1.5x the matrix time):

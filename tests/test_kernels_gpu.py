@@ -22,11 +22,17 @@ def close(got, ref, rtol, name=""):
     assert err <= rtol * scale, "%s: max abs err %.3e vs scale %.3e (rtol %.1e)" % (name, err, scale, rtol)
 
 
+@pytest.mark.parametrize("x3", [False, True], ids=["f32mfma", "x3"])
 @pytest.mark.parametrize("cin", [1, 2])
-def test_conv5x5_in_fwd_and_wgrad(dev, cin):
-    from ugaitnet_amd import ops
+def test_conv5x5_in_fwd_and_wgrad(dev, cin, x3):
+    """x3: the form the default fp32-tensor set runs (three-way bf16 split, six products: csrc/x3_common.h) -- the same bars as the
+    fp32-MFMA form, on more tiles than the persistent grids have workgroups (1,120 against 1,024 / 512: the tile loops run)."""
+    import functools
+    from ugaitnet_amd import ops as ops_
+    ops = type("O5", (), dict(conv5x5_in_fwd=staticmethod(functools.partial(ops_.conv5x5_in_fwd, x3=x3)),
+                              conv5x5_in_wgrad=staticmethod(functools.partial(ops_.conv5x5_in_wgrad, x3=x3))))
     rng = np.random.default_rng(10 + cin)
-    n = 5
+    n = 70 if x3 else 5
     x = rng.uniform(-0.5, 0.5, (n, 60, 60, cin)).astype(np.float32)
     w = rng.uniform(-0.3, 0.3, (5, 5, cin, 32)).astype(np.float32)
     xf = np.pad(x, ((0, 0), (2, 2), (2, 2), (0, 0)))

@@ -5,7 +5,7 @@
 
 Each (library, round) runs in its own process (UGN_LIB selects the build), rounds interleaved A B A B so that clock and thermal
 drift hit both alike; per op the median of the per-launch HIP-event times of every round is printed.
-Ops: conv5x5_fwd1 conv5x5_fwd2 conv5x5_wgrad1 conv5x5_wgrad2 a2_fwd a2_dgrad a2_wgrad a3_fwd a3_dgrad a3_wgrad a4_fwd a4_dgrad
+Ops: conv5x5_fwd1 conv5x5_fwd2 conv5x5_wgrad1 conv5x5_wgrad2 (conv5x5x_*: the same in the x3 arithmetic) a2_fwd a2_dgrad a2_wgrad a3_fwd a3_dgrad a3_wgrad a4_fwd a4_dgrad
 a4_wgrad a5_* a6_* setmax_fwd setmax_bwd step (whole C3 training step, 24 clips)."""
 import json
 import os
@@ -41,17 +41,18 @@ def child(ops_list, frames, reps):
     for op in ops_list:
         if op.startswith("conv5x5"):
             cin = int(op[-1])
+            x3 = op.startswith("conv5x5x")       # conv5x5x_fwd1 ...: the x3 arithmetic form (ugn_x3_conv5x5_in_*)
             x = torch.rand(frames, 60, 60, cin, device=dev) - 0.5
             w = torch.randn(5, 5, cin, 32, device=dev) * 0.1
             a1 = torch.empty(frames, 64, 64, 32, device=dev)
             sg = torch.empty(frames, 64, 64, dtype=torch.int32, device=dev)
             if "fwd" in op:
-                out[op] = timeit(lambda: ops.conv5x5_in_fwd(x, w, a1, sign=sg))
+                out[op] = timeit(lambda: ops.conv5x5_in_fwd(x, w, a1, sign=sg, x3=x3))
             else:
                 ops.conv5x5_in_fwd(x, w, a1, sign=sg)
                 dz = torch.randn(frames, 64, 64, 32, device=dev)
                 dw = torch.empty(5, 5, cin, 32, device=dev)
-                out[op] = timeit(lambda: ops.conv5x5_in_wgrad(x, dz, dw, sign=sg))
+                out[op] = timeit(lambda: ops.conv5x5_in_wgrad(x, dz, dw, sign=sg, x3=x3))
         elif op == "step":
             from tests.synth import make_batch
             from ugaitnet_amd.engine import GaitCore

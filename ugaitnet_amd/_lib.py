@@ -122,6 +122,8 @@ PROTOTYPES = {
     # "x3": fp32 tensors, 3x3 products through the exact three-way bf16 split on the bf16 matrix pipe
     "ugn_x3_split": (_i, [_p, _p, _sz, _p]),
     "ugn_x3_pack_multi": (_i, [C.POINTER(_p)] * 2 + [C.POINTER(_i)] * 3 + [_i, _p]),
+    "ugn_x3_conv5x5_in_fwd": (_i, [_p, _p, _p, _p, _i, _i, _p]),
+    "ugn_x3_conv5x5_in_wgrad": (_i, [_p, _p, _p, _p, _i, _i, _p, _sz, _p]),
     "ugn_x3_conv3x3_fwd_multi": (_i, [C.POINTER(_p)] * 4 + [C.POINTER(_i), _i, _i, _i, _i, _i, _i, _p]),
     "ugn_x3_conv3x3_dgrad_multi": (_i, [C.POINTER(_p)] * 5 + [C.POINTER(_i), _i, _i, _i, _i, _i, _p]),
     "ugn_x3_conv3x3_wgrad_ws": (_sz, [_i, _i, _i]),

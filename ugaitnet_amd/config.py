@@ -37,6 +37,7 @@ class Settings:
     gate_norm_fused: bool = True     # UGN_GATE_NORM_FUSED: gate / fMerge + batch-axis normalisation in one launch each way
     set_routed: bool = True          # UGN_SET_ROUTED: set-pooling gradients from the forward pass's routing words
     fuse_w5: bool = False            # UGN_FUSE_W5=1 (h2): a2 data gradient fused with the 5x5 weight gradient (measured slower)
+    c5_x3: bool = True               # UGN_C5_X3=0: the first layer of the x3 set on the fp32 MFMA instead of the x3 arithmetic (A/B)
     persistent_wgs: int = 0          # UGN_PERSISTENT_WGS: CUs the persistent launches occupy (0 = all; the library's one global)
 
     @classmethod
@@ -48,7 +49,7 @@ class Settings:
                 branch_streams=e.get("UGN_BSTREAMS", "0") == "1", fwd_streams=int(e.get("UGN_FSTREAMS", "2")),
                 pack_on_side_stream=on("UGN_PACK_SIDE"), merge_modalities=on("UGN_MERGE"), ar_overlap=e.get("UGN_AR_OVERLAP", "0") == "1",
                 head_side=e.get("UGN_HEAD_SIDE", "1") == "1", routed=e.get("UGN_ROUTED", "0") == "1", gate_norm_fused=on("UGN_GATE_NORM_FUSED"),
-                set_routed=on("UGN_SET_ROUTED"), fuse_w5=on("UGN_FUSE_W5", "0"), persistent_wgs=int(e.get("UGN_PERSISTENT_WGS", "0") or 0))
+                set_routed=on("UGN_SET_ROUTED"), fuse_w5=on("UGN_FUSE_W5", "0"), c5_x3=on("UGN_C5_X3"), persistent_wgs=int(e.get("UGN_PERSISTENT_WGS", "0") or 0))
         return s.normalised()
 
     def normalised(self):

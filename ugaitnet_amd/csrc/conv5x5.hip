@@ -7,6 +7,7 @@
 // Domain: the explicit 2-pixel zero ring makes the conv domain 64x64; input pixel (u,v) of that domain is raw pixel
 // (u-2,v-2) or 0.  The 5x5 SAME conv then reads (y+dy-2, x+dx-2), dy,dx in 0..4.
 #include "mm_common.h"
+#include "x3_common.h"
 
 namespace {
 
@@ -63,7 +64,11 @@ __device__ __forceinline__ void stage_patch(float* sP, const float* __restrict__
 // H2OUT: a1 leaves as an H2 tensor (mm_common.h: f16 halves [pixel][2][32] + block exponent) for the f16-matrix-pipe 3x3
 // kernels.  x_meta = {0, bits(max|x|)} (ugn_absmax_multi); the exponent comes from the bound max|x| * max_co sum_k |w[k][co]|,
 // which every workgroup forms from the filter it has just staged; the stored maximum is gathered per workgroup.
-// OFMT: 0 fp32 a1, 1 H2 (above), 2 bf16 (configs[4]: [pixel][32] bf16, no exponent)
+// OFMT: 0 fp32 a1, 1 H2 (above), 2 bf16 (configs[4]: [pixel][32] bf16, no exponent), 3 fp32 a1 multiplied in the x3 arithmetic
+// (x3_common.h: the default fp32-tensor set since round 5) -- the gathered patch fragment and the filter split into three bf16
+// planes, six v_mfma_f32_32x32x16_bf16 per k-step of 16 taps: 12 / 24 matrix instructions of 8 issue cycles per 32-pixel block
+// instead of 13 / 25 fp32 ones of 64 cycles that hold the vector pipe (the fp32 form measured 45-63 % MFMA busy: the layer was
+// bound by its fp32 MFMAs, not by writing a1)
 template <int CIN, bool SIGN, int OFMT = 0>
 __global__ __launch_bounds__(256, (OFMT == 1 && UGN_C5_H2MM) ? 3 : UGN_C5_WAVES) void conv5x5_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                                         float* __restrict__ a1, uint32_t* __restrict__ sign_out,
@@ -146,23 +151,28 @@ __global__ __launch_bounds__(256, (OFMT == 1 && UGN_C5_H2MM) ? 3 : UGN_C5_WAVES)
   // 32-pixel block instead of 13 / 25 fp32 MFMAs of 64 cycles that block the vector pipe.
   typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
   constexpr bool BFMM = OFMT == 2;
+  constexpr bool X3MM = OFMT == 3;
   constexpr int KS = (K + 15) / 16;
-  int goff[BFMM || H2MM ? KS : 1][8];
+  int goff[BFMM || H2MM || X3MM ? KS : 1][8];
   bf8 wfrag[BFMM ? KS : 1];
   // filter fragments as f16 halves of w * 2^ew: [k-step][plane][lane-linear 1 KB] in LDS (identical for the four waves; in registers
   // they are 8 KS VGPRs that push the two-channel kernel into scratch)
   __shared__ __attribute__((aligned(16))) uint4 sWf[(OFMT == 1 && UGN_C5_H2MM) ? KS * 2 * 64 : 1];
+  // x3: the filter fragments as three bf16 planes, [k-step][plane][lane-linear 1 KB] (the same for the four waves)
+  __shared__ __attribute__((aligned(16))) uint4 sWx[X3MM ? KS * 3 * 64 : 1];
   int pbb[2];
-  if constexpr (BFMM || H2MM) {
+  if constexpr (BFMM || H2MM || X3MM) {
     __syncthreads();            // sW is complete
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks)
+    for (int ks = 0; ks < KS; ++ks) {
+      float wq[8];
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const int k = 16 * ks + 8 * lh + i;
         const int tap = k / CIN, ch = k % CIN;
         goff[ks][i] = k < K ? (tap / 5) * FP + (tap % 5) * CIN + ch : 0;
         const float wv = k < K ? sW[k * 32 + li] : 0.f;
+        wq[i] = wv;
         if constexpr (BFMM) wfrag[ks][i] = (__bf16)wv;
         if constexpr (H2MM) {
           if (wave == 0) {
@@ -173,6 +183,16 @@ __global__ __launch_bounds__(256, (OFMT == 1 && UGN_C5_H2MM) ? 3 : UGN_C5_WAVES)
           }
         }
       }
+      if constexpr (X3MM) {
+        if (wave == 0) {
+          uint4 q0, q1, q2;
+          ugn_x3::split8(make_float4(wq[0], wq[1], wq[2], wq[3]), make_float4(wq[4], wq[5], wq[6], wq[7]), q0, q1, q2);
+          sWx[(ks * 3 + 0) * 64 + lane] = q0;
+          sWx[(ks * 3 + 1) * 64 + lane] = q1;
+          sWx[(ks * 3 + 2) * 64 + lane] = q2;
+        }
+      }
+    }
 #pragma unroll
     for (int m = 0; m < 2; ++m) pbb[m] = (2 * (wave * 2 + m) + py) * FP + px * CIN;
   }
@@ -215,6 +235,23 @@ __global__ __launch_bounds__(256, (OFMT == 1 && UGN_C5_H2MM) ? 3 : UGN_C5_WAVES)
           for (int i = 0; i < 8; ++i) a[i] = (__bf16)sP[pbb[m] + goff[ks][i]];
           acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, wfrag[ks], acc[m], 0, 0, 0);
         }
+    } else if constexpr (X3MM) {
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const uint4 wp[3] = {sWx[(ks * 3 + 0) * 64 + lane], sWx[(ks * 3 + 1) * 64 + lane], sWx[(ks * 3 + 2) * 64 + lane]};
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+          float v[8];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) v[i] = sP[pbb[m] + goff[ks][i]];
+          uint4 ap[3];
+          ugn_x3::split8(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]), ap[0], ap[1], ap[2]);
+#pragma unroll
+          for (int i = 0; i < ugn_x3::kProducts; ++i)      // the six largest partial products, smallest first (x3_common.h)
+            acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, ap[ugn_x3::prod_x<ugn_x3::kProducts>(i)]),
+                                                             __builtin_bit_cast(bf8, wp[ugn_x3::prod_w<ugn_x3::kProducts>(i)]), acc[m], 0, 0, 0);
+        }
+      }
     } else if constexpr (H2MM) {
       const unsigned* sPu = reinterpret_cast<const unsigned*>(sP);
 #pragma unroll
@@ -328,6 +365,11 @@ __device__ __forceinline__ void dma4_c5(const void* gsrc, unsigned lds_dst_unifo
 // per tile); LeakyReLU'(a1) WITHOUT re-splitting a scaled gradient: slope = 0.3 + 0.7 [a1 > 0], so the kernel keeps two sums,
 // acc_all += x * g and acc_pos += x * (g AND mask) -- masking the halves is exact -- and leaves 0.3 acc_all + 0.7 acc_pos.
 // 6 f16 MFMAs of 32 cycles per 16 pixels and row block instead of 8 fp32 MFMAs of 64 that block the vector pipe.
+// DZFMT 4 (round 5): fp32 dz1 multiplied in the x3 arithmetic (x3_common.h) -- K = 16 pixels per v_mfma_f32_32x32x16_bf16 step; a lane
+// gathers the patch values under its (tap, channel) row and the gradient of its channel at 8 consecutive pixels (fp32, the gradient
+// times LeakyReLU' from the sign words), splits both into three bf16 planes in registers and issues the six products: 6 matrix
+// instructions of 8 issue cycles per 16 pixels and row block instead of 8 fp32 ones of 64 cycles that hold the vector pipe (the fp32
+// form measured 52-64 % MFMA busy on a kernel that should run at the rate dz1 can be read).
 template <int CIN, bool SIGN, int DZFMT = 0>
 __global__ __launch_bounds__(256) void conv5x5_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dz1,
                                                             float* __restrict__ slab, const float* __restrict__ zeros,
@@ -339,7 +381,7 @@ __global__ __launch_bounds__(256) void conv5x5_wgrad_kernel(const float* __restr
   // patch rows of WP pixels (UGN_C5_PITCH)
   constexpr int WP = c5_pitch(CIN);
   constexpr int PE = P5 * WP * CIN, PPIECES = (PE + 63) / 64, SPF = PPIECES * 64;   // patch dwords, 256-B pieces
-  constexpr bool H2X = DZFMT == 3, H2DZ = DZFMT == 1 || H2X, BFDZ = DZFMT == 2;
+  constexpr bool H2X = DZFMT == 3, H2DZ = DZFMT == 1 || H2X, BFDZ = DZFMT == 2, X3W = DZFMT == 4;
   constexpr int DPW = BFDZ ? 4 : DS / 4, PPW = (PPIECES + 3) / 4;    // pieces per wave
   extern __shared__ __attribute__((aligned(16))) float smem5[];
   float* sD0 = smem5;                 // [2][SDF]
@@ -480,6 +522,35 @@ __global__ __launch_bounds__(256) void conv5x5_wgrad_kernel(const float* __restr
           }
         }
       }
+    } else if constexpr (X3W) {
+      typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+      unsigned lane_bit = 1u << li;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {      // tile row 4 wave + ks: 16 pixels, this lane half's 8
+        float g[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          g[i] = sD[(wave * 64 + ks * 16 + 8 * lh + i) * DS + li];
+          if constexpr (SIGN) {
+            const uint32_t wbits = sS0[buf * 256 + wave * 64 + ks * 16 + 8 * lh + i];
+            g[i] *= (wbits & lane_bit) ? 1.f : UGN_LRELU_ALPHA;
+          }
+        }
+        uint4 gp[3];
+        ugn_x3::split8(make_float4(g[0], g[1], g[2], g[3]), make_float4(g[4], g[5], g[6], g[7]), gp[0], gp[1], gp[2]);
+#pragma unroll
+        for (int mb = 0; mb < MBK; ++mb) {
+          float v[8];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) v[i] = sP[abase[mb] + (ks * WP + 8 * lh + i - lh) * CIN];
+          uint4 xp[3];
+          ugn_x3::split8(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]), xp[0], xp[1], xp[2]);
+#pragma unroll
+          for (int i = 0; i < ugn_x3::kProducts; ++i)      // (x plane, gradient plane): the six largest partial products, smallest first
+            acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, xp[ugn_x3::prod_x<ugn_x3::kProducts>(i)]),
+                                                              __builtin_bit_cast(bf8, gp[ugn_x3::prod_w<ugn_x3::kProducts>(i)]), acc[mb], 0, 0, 0);
+        }
+      }
     } else if constexpr (BFDZ) {
       // bf16 gradient (configs[4]): v_mfma_f32_32x32x16_bf16 with K = 16 pixels (one tile row) per step -- the wave's 64 pixels are
       // 4 MFMAs per row block instead of 32 fp32 ones.  A = the patch values under the lane's (tap, channel) at 8 consecutive
@@ -601,6 +672,26 @@ extern "C" int ugn_conv5x5_in_fwd(const float* x, const float* w, float* a1, uin
   return 0;
 }
 
+/* the same layer, fp32 in and out, multiplied in the x3 arithmetic (three-way bf16 split of the patch and the filter, six products
+ * per fp32 product on v_mfma_f32_32x32x16_bf16: csrc/x3_common.h) -- the first layer of the default fp32-tensor set */
+extern "C" int ugn_x3_conv5x5_in_fwd(const float* x, const float* w, float* a1, uint32_t* a1_sign, int n, int cin, void* stream) {
+  UGN_REQUIRE(x && w && a1 && n > 0, "ugn_x3_conv5x5_in_fwd: null pointer or n <= 0");
+  UGN_REQUIRE(cin == 1 || cin == 2, "ugn_x3_conv5x5_in_fwd: cin must be 1 or 2 (got %d)", cin);
+  hipStream_t st = (hipStream_t)stream;
+  const int ntiles = n * 16;
+  const int c5grid = UGN_C5_GRID / ugn_mm::kGrid * ugn_mm::persistent_wgs();     // (4 workgroups per CU of those left to this library)
+  const int grid = ntiles < c5grid ? ntiles : c5grid;
+#define UGN_C5F(C_, S_) hipLaunchKernelGGL((conv5x5_fwd_kernel<C_, S_, 3>), dim3(grid), dim3(256), 0, st, x, w, a1, a1_sign, ntiles)
+  if (cin == 1) {
+    if (a1_sign) UGN_C5F(1, true); else UGN_C5F(1, false);
+  } else {
+    if (a1_sign) UGN_C5F(2, true); else UGN_C5F(2, false);
+  }
+#undef UGN_C5F
+  UGN_CHECK_LAUNCH("conv5x5_fwd_x3");
+  return 0;
+}
+
 /* the same layer with a1 as an H2 tensor [n][64][64][2][32] (+ its ugn_h2meta, zero on entry); x_meta = {0, bits(max|x|)} */
 extern "C" int ugn_conv5x5_in_fwd_h2(const float* x, const void* x_meta, const float* w, uint16_t* a1, void* a1_meta,
                                      uint32_t* a1_sign, int n, int cin, void* stream) {
@@ -631,7 +722,13 @@ extern "C" size_t ugn_conv5x5_in_wgrad_ws(int n, int cin) {
 }
 
 static int conv5x5_wgrad_any(const float* x, const float* dz1, const H2Meta* dz_meta, const uint32_t* a1_sign, float* dw, int n,
-                             int cin, void* ws, size_t ws_bytes, void* stream, bool bf = false, const H2Meta* x_meta = nullptr);
+                             int cin, void* ws, size_t ws_bytes, void* stream, bool bf = false, const H2Meta* x_meta = nullptr,
+                             bool x3 = false);
+/* fp32 dz1, multiplied in the x3 arithmetic (csrc/x3_common.h): the weight gradient of the first layer in the default fp32-tensor set */
+extern "C" int ugn_x3_conv5x5_in_wgrad(const float* x, const float* dz1, const uint32_t* a1_sign, float* dw, int n, int cin,
+                                       void* ws, size_t ws_bytes, void* stream) {
+  return conv5x5_wgrad_any(x, dz1, nullptr, a1_sign, dw, n, cin, ws, ws_bytes, stream, false, nullptr, true);
+}
 extern "C" int ugn_conv5x5_in_wgrad(const float* x, const float* dz1, const uint32_t* a1_sign, float* dw, int n, int cin,
                                     void* ws, size_t ws_bytes, void* stream) {
   return conv5x5_wgrad_any(x, dz1, nullptr, a1_sign, dw, n, cin, ws, ws_bytes, stream);
@@ -673,7 +770,7 @@ extern "C" int ugn_conv5x5_in_fwd_bf(const float* x, const float* w, uint16_t* a
   return 0;
 }
 static int conv5x5_wgrad_any(const float* x, const float* dz1, const H2Meta* dz_meta, const uint32_t* a1_sign, float* dw, int n,
-                             int cin, void* ws, size_t ws_bytes, void* stream, bool bf, const H2Meta* x_meta) {
+                             int cin, void* ws, size_t ws_bytes, void* stream, bool bf, const H2Meta* x_meta, bool x3) {
   UGN_REQUIRE(x && dz1 && dw && ws && n > 0, "ugn_conv5x5_in_wgrad: null pointer or n <= 0");
   UGN_REQUIRE(cin == 1 || cin == 2, "ugn_conv5x5_in_wgrad: cin must be 1 or 2 (got %d)", cin);
   UGN_REQUIRE(ws_bytes >= ugn_conv5x5_in_wgrad_ws(n, cin), "ugn_conv5x5_in_wgrad: workspace too small");
@@ -692,23 +789,28 @@ static int conv5x5_wgrad_any(const float* x, const float* dz1, const H2Meta* dz_
   const int lds = (2 * 256 * UGN_C5_DS + 2 * ((20 * c5_pitch(cin) * cin + 63) / 64) * 64 + 2 * 256) * 4;
   static bool attr_done[3] = {false, false, false};
   if (!attr_done[cin]) {
-    const void* fns[16] = {(const void*)conv5x5_wgrad_kernel<1, false>, (const void*)conv5x5_wgrad_kernel<1, true>,
+    const void* fns[20] = {(const void*)conv5x5_wgrad_kernel<1, false>, (const void*)conv5x5_wgrad_kernel<1, true>,
                            (const void*)conv5x5_wgrad_kernel<1, false, 1>, (const void*)conv5x5_wgrad_kernel<1, true, 1>,
                            (const void*)conv5x5_wgrad_kernel<1, false, 2>, (const void*)conv5x5_wgrad_kernel<1, true, 2>,
                            (const void*)conv5x5_wgrad_kernel<1, false, 3>, (const void*)conv5x5_wgrad_kernel<1, true, 3>,
+                           (const void*)conv5x5_wgrad_kernel<1, false, 4>, (const void*)conv5x5_wgrad_kernel<1, true, 4>,
                            (const void*)conv5x5_wgrad_kernel<2, false>, (const void*)conv5x5_wgrad_kernel<2, true>,
                            (const void*)conv5x5_wgrad_kernel<2, false, 1>, (const void*)conv5x5_wgrad_kernel<2, true, 1>,
                            (const void*)conv5x5_wgrad_kernel<2, false, 2>, (const void*)conv5x5_wgrad_kernel<2, true, 2>,
-                           (const void*)conv5x5_wgrad_kernel<2, false, 3>, (const void*)conv5x5_wgrad_kernel<2, true, 3>};
-    for (int v = 0; v < 8; ++v) {
-      hipError_t e = hipFuncSetAttribute(fns[(cin - 1) * 8 + v], hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+                           (const void*)conv5x5_wgrad_kernel<2, false, 3>, (const void*)conv5x5_wgrad_kernel<2, true, 3>,
+                           (const void*)conv5x5_wgrad_kernel<2, false, 4>, (const void*)conv5x5_wgrad_kernel<2, true, 4>};
+    for (int v = 0; v < 10; ++v) {
+      hipError_t e = hipFuncSetAttribute(fns[(cin - 1) * 10 + v], hipFuncAttributeMaxDynamicSharedMemorySize, lds);
       UGN_REQUIRE(e == hipSuccess, "ugn_conv5x5_in_wgrad: hipFuncSetAttribute: %s", hipGetErrorString(e));
     }
     attr_done[cin] = true;
   }
 #define UGN_C5W(C_, S_)                                                                                                      \
   do {                                                                                                                        \
-    if (bf)                                                                                                                   \
+    if (x3)                                                                                                                   \
+      hipLaunchKernelGGL((conv5x5_wgrad_kernel<C_, S_, 4>), dim3(groups), dim3(256), lds, st, x, dz1, (float*)ws,             \
+                         (const float*)zeros, a1_sign, tiles);                                                                \
+    else if (bf)                                                                                                              \
       hipLaunchKernelGGL((conv5x5_wgrad_kernel<C_, S_, 2>), dim3(groups), dim3(256), lds, st, x, dz1, (float*)ws,             \
                          (const float*)zeros, a1_sign, tiles);                                                                \
     else if (dz_meta && x_meta)                                                                                               \

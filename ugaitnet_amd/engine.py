@@ -428,7 +428,7 @@ def forward_merged(encs, xs):
         xf = x.reshape(n, 60, 60, e.cin)
         e.act["x"] = xf
         a1s.append(ops.conv5x5_in_fwd(xf, e.W("a1"), B(e, e.act, "a1", (n, 64, 64, 32)),
-                                      sign=B(e, e.act, "a1s", (n, 64, 64), torch.int32) if cfg.a1_sign_bits else None))
+                                      sign=B(e, e.act, "a1s", (n, 64, 64), torch.int32) if cfg.a1_sign_bits else None, x3=C3.x3 and cfg.c5_x3))
     hook = getattr(encs[0], "before_conv3", None)     # (a filter repack queued on the second stream: GaitCore.apply_gradients)
     if hook is not None:
         hook()
@@ -531,7 +531,7 @@ def backward_merged(encs, douts, scratches):
                    dz_idxs=i2, acts=None if cfg.a1_sign_bits else [a["a1"] for a in A])
     with side():
         for i, e in enumerate(encs):
-            ops.conv5x5_in_wgrad(A[i]["x"], dz1[i], e.G("a1"), sign=A[i]["a1s"] if cfg.a1_sign_bits else None)
+            ops.conv5x5_in_wgrad(A[i]["x"], dz1[i], e.G("a1"), sign=A[i]["a1s"] if cfg.a1_sign_bits else None, x3=C3.x3 and cfg.c5_x3)
 
 
 class GaitCore:

@@ -79,21 +79,25 @@ def _hbm_work(kernel, nbytes):
     return dict(flops=None, mfma_flops=None, bytes=float(nbytes), kernel=kernel, bound="hbm")
 
 
-def conv5x5_in_fwd(x, w, out=None, sign=None):
-    """sign (optional int32 [n,64,64]): receives one bit per output element, (a1 > 0), for conv5x5_in_wgrad."""
+def conv5x5_in_fwd(x, w, out=None, sign=None, x3=False):
+    """sign (optional int32 [n,64,64]): receives one bit per output element, (a1 > 0), for conv5x5_in_wgrad.
+    x3: multiply in the x3 arithmetic (three-way bf16 split, six products on the bf16 matrix pipe: csrc/x3_common.h) -- the form the
+    default fp32-tensor set runs; False: v_mfma_f32_32x32x2_f32."""
     n, cin = x.shape[0], x.shape[3]
     _chk(x), _chk(w)
     out = torch.empty((n, 64, 64, 32), dtype=F32, device=x.device) if out is None else out
     if sign is not None:
         _chk(sign, torch.int32)
-    call("ugn_conv5x5_in_fwd", ptr(x), ptr(w), ptr(out), ptr(sign), n, cin, _stream(), label="conv5x5_fwd[cin=%d]" % cin,
-         work=_hbm_work("conv5x5_fwd_kernel<%d, %s>" % (cin, "true" if sign is not None else "false"),
+    call("ugn_x3_conv5x5_in_fwd" if x3 else "ugn_conv5x5_in_fwd", ptr(x), ptr(w), ptr(out), ptr(sign), n, cin, _stream(),
+         label="conv5x5_fwd[cin=%d%s]" % (cin, " x3" if x3 else ""),
+         work=_hbm_work("conv5x5_fwd_kernel<%d, %s, %d>" % (cin, "true" if sign is not None else "false", 3 if x3 else 0),
                         n * (3600.0 * cin * 4 + 4096 * 32 * 4 + (4096 * 4 if sign is not None else 0))))
     return out
 
 
-def conv5x5_in_wgrad(x, dz1, dw=None, sign=None):
-    """sign given: dz1 is dL/da1 and the LeakyReLU' factor of a1 is applied inside, from the bits of conv5x5_in_fwd."""
+def conv5x5_in_wgrad(x, dz1, dw=None, sign=None, x3=False):
+    """sign given: dz1 is dL/da1 and the LeakyReLU' factor of a1 is applied inside, from the bits of conv5x5_in_fwd.
+    x3: as conv5x5_in_fwd."""
     n, cin = x.shape[0], x.shape[3]
     _chk(x), _chk(dz1)
     dw = torch.empty((5, 5, cin, 32), dtype=F32, device=x.device) if dw is None else dw
@@ -101,9 +105,9 @@ def conv5x5_in_wgrad(x, dz1, dw=None, sign=None):
     ws = _WS.get(nbytes, x.device)
     if sign is not None:
         _chk(sign, torch.int32)
-    call("ugn_conv5x5_in_wgrad", ptr(x), ptr(dz1), ptr(sign), ptr(dw), n, cin, ptr(ws), ws.numel(), _stream(),
-         label="conv5x5_wgrad[cin=%d]" % cin,
-         work=_hbm_work("conv5x5_wgrad_kernel<%d, %s>" % (cin, "true" if sign is not None else "false"),
+    call("ugn_x3_conv5x5_in_wgrad" if x3 else "ugn_conv5x5_in_wgrad", ptr(x), ptr(dz1), ptr(sign), ptr(dw), n, cin, ptr(ws), ws.numel(),
+         _stream(), label="conv5x5_wgrad[cin=%d%s]" % (cin, " x3" if x3 else ""),
+         work=_hbm_work("conv5x5_wgrad_kernel<%d, %s, %d>" % (cin, "true" if sign is not None else "false", 4 if x3 else 0),
                         n * (3600.0 * cin * 4 + 4096 * 32 * 4 + (4096 * 4 if sign is not None else 0))))
     return dw
 
