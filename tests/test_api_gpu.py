@@ -240,3 +240,72 @@ def test_model_config_file_drives_loadnet_and_surgery(dev, tmp_path):
     assert c.get_layer("classprob").units == 9 and c.margin == 0.3 and c.loss_weights == [1.0, 0.5]
     assert [tuple(s) for s in c.input_shapes] == shapes       # from the stored configuration, not from the (wrong) argument
     assert np.array_equal(c.predict(X)[0], sig)
+
+
+def test_fit_pipeline_matches_the_synchronous_loop(dev):
+    """`fit` as tf.keras runs it for a Sequence (nets/mj_uwyhNets_ba.py:963: workers=1, max_queue_size=10 by default): batches fetched
+    and staged in HBM by a background thread, step k's losses read after step k + 1 is queued.  Against the plain loop (workers=0,
+    pipeline=False) from the same seed: the same History to the last bit, the same parameters, `on_epoch_end` of the generator
+    between the epochs' fetches, a callback that listens to batch events switches the pipelining off by itself, and an exception
+    inside the generator surfaces in `fit`."""
+    import torch
+    from ugaitnet_amd.nets.mj_uwyhNets_ba import UWYHSemiNet3Mods, optimizers, sign_max
+    shapes = [(3, 60, 60, 2), (3, 60, 60, 1), (3, 60, 60, 1)]
+
+    def build():
+        return UWYHSemiNet3Mods.build_or_load(shapes, 4, [7, 5, 3, 2], [96, 192, 512, 4096], ndense_units=0,
+                                              optimizer=optimizers.Adam(lr=1e-3), margin=0.2, nclasses=6,
+                                              loss_weights=[1.0, 0.1], fMerge=sign_max, gaitset=True, seed=3)
+
+    class Gen(ToyGenerator):
+        def __init__(self, *a, **k):
+            super().__init__(*a, **k)
+            self.fetched = []
+
+        def __getitem__(self, i):
+            self.fetched.append((self.epochs_ended, i))
+            return super().__getitem__(i)
+
+    runs = {}
+    for name, kw in (("plain", dict(workers=0, pipeline=False)), ("piped", dict()), ("pool", dict(workers=3, max_queue_size=2))):
+        model, gen = build(), Gen(("of", "gray", "depth"), 4, 3, 6, n_batches=4)
+        hist = model.fit(gen, epochs=3, steps_per_epoch=4, verbose=0, **kw)
+        torch.cuda.synchronize()
+        runs[name] = (hist.history, {n: model.core.store.get(n).copy() for n in model.core.store.names}, gen)
+    assert runs["plain"][0] == runs["piped"][0] == runs["pool"][0] and len(runs["piped"][0]["loss"]) == 3
+    for n, w in runs["plain"][1].items():
+        assert np.array_equal(w, runs["piped"][1][n]) and np.array_equal(w, runs["pool"][1][n]), n
+    gen = runs["piped"][2]
+    assert gen.fetched == [(e, i) for e in range(3) for i in range(4)] and gen.epochs_ended == 3      # epoch e's batches after e reshuffles
+    # three fetching threads: any order inside an epoch, never across its end
+    assert sorted(runs["pool"][2].fetched) == gen.fetched and [e for e, _ in runs["pool"][2].fetched] == sorted(e for e, _ in gen.fetched)
+
+    seen = []
+
+    class BatchCB:
+        def on_batch_end(self, step, logs):
+            seen.append((step, logs["loss"]))
+
+    class Callback:                       # (what a tf.keras callback inherits: no-op hooks that must not switch the pipelining off)
+        def on_batch_end(self, step, logs):
+            pass
+
+    class EpochOnly(Callback):
+        def on_epoch_end(self, epoch, logs):
+            seen.append(("epoch", epoch))
+
+    from ugaitnet_amd import keras_compat
+    assert keras_compat._listens(BatchCB(), "on_batch_end") and not keras_compat._listens(EpochOnly(), "on_batch_end")
+    model = build()
+    h2 = model.fit(Gen(("of", "gray", "depth"), 4, 3, 6, n_batches=4), epochs=1, steps_per_epoch=4, verbose=0, callbacks=[BatchCB(), EpochOnly()])
+    assert [s[0] for s in seen] == [0, 1, 2, 3, "epoch"]         # batch events in order, each BEFORE the next step (no pipelining)
+    assert h2.history["loss"][0] == runs["plain"][0]["loss"][0]
+
+    class Broken(ToyGenerator):
+        def __getitem__(self, i):
+            if i == 2:
+                raise KeyError("sample file of batch 2 is missing")
+            return super().__getitem__(i)
+
+    with pytest.raises(KeyError, match="batch 2"):
+        build().fit(Broken(("of", "gray", "depth"), 4, 3, 6, n_batches=4), epochs=1, steps_per_epoch=4, verbose=0)

@@ -1065,14 +1065,38 @@ class GaitCore:
 
     def losses(self):
         """Host copies of the last step's losses/metrics (synchronises)."""
-        w_tri, w_id = self.loss_weights
-        tri = float(self.bin_loss.cpu().numpy().mean())
-        out = dict(triplet=tri, loss=w_tri * tri)
-        if self.nclasses > 0:
-            xent = float(self.head["row_loss"].cpu().numpy().mean())
-            acc = float(self.head["hit"].cpu().numpy().mean())
-            out.update(xent=xent, acc=acc, loss=w_tri * tri + w_id * xent)
-        return out
+        return self.losses_async().result()
+
+    def losses_async(self):
+        """The same without synchronising: the copies to (pinned) host memory are queued on the current stream right behind the
+        step -- ahead of anything a later step writes into the same device tensors -- and `.result()` waits for THOSE copies only.
+        keras_compat's pipelined `fit` reads step k's losses after step k + 1 has been queued, so the GPU never idles on the host."""
+        return _PendingLosses(self)
+
+
+class _PendingLosses:
+    def __init__(self, core):
+        self.weights, self.has_head = core.loss_weights, core.nclasses > 0
+        src = [core.bin_loss] + ([core.head["row_loss"], core.head["hit"]] if self.has_head else [])
+        self.host = [torch.empty(t.shape, dtype=t.dtype, pin_memory=True) for t in src]
+        for h, t in zip(self.host, src):
+            h.copy_(t, non_blocking=True)
+        self.event = torch.cuda.Event()
+        self.event.record(torch.cuda.current_stream(core.device))
+        self.value = None
+
+    def result(self):
+        if self.value is None:
+            self.event.synchronize()
+            w_tri, w_id = self.weights
+            tri = float(self.host[0].numpy().mean())
+            out = dict(triplet=tri, loss=w_tri * tri)
+            if self.has_head:
+                xent = float(self.host[1].numpy().mean())
+                acc = float(self.host[2].numpy().mean())
+                out.update(xent=xent, acc=acc, loss=w_tri * tri + w_id * xent)
+            self.value, self.host = out, None
+        return self.value
 
 
 class GraphedTrainStep:

@@ -98,6 +98,127 @@ def fusion_mode(fmerge):
 # ---------------------------------------------------------------------------------------------------------
 # model object
 # ---------------------------------------------------------------------------------------------------------
+class _BatchPipeline:
+    """What tf.keras's `fit` does with a `keras.utils.Sequence` (OrderedEnqueuer: `workers=1`, `max_queue_size=10` are its defaults
+    and the reference's call, nets/mj_uwyhNets_ba.py:963, leaves them alone): a background thread pulls the epoch's batches IN ORDER
+    while the device trains, here additionally staging them in HBM -- pinned host copy, asynchronous transfer on a copy stream of its
+    own, an event the training stream waits on -- so that neither the generator's host work nor the 35 MB of a 24-clip batch crossing
+    PCIe sits between two steps.  One pipeline per epoch: the generator's `on_epoch_end` (the reference reshuffles there,
+    data/mj_dataGeneratorMMUWYHsingle_repetitions.py) runs between two of them, never beside a fetch."""
+
+    _END = object()
+
+    STAGED_DEPTH = 4       # batches staged ahead in HBM at most (each holds pinned host memory too); max_queue_size beyond it buys nothing
+
+    def __init__(self, gen, steps, device, depth, stage=True, ring=None, workers=1):
+        import queue
+        import threading
+        self.gen, self.steps, self.device, self.stage = gen, int(steps), device, stage
+        self.workers = max(1, int(workers)) if hasattr(gen, "__len__") else 1     # (an iterator has one consumer)
+        self.q = queue.Queue(maxsize=max(1, min(int(depth), self.STAGED_DEPTH) if stage else int(depth)))
+        # pinned staging buffers: queue + the batch in the step + the one being filled; the caller keeps the list across epochs
+        self.ring = ring if ring is not None else []
+        while len(self.ring) < self.q.maxsize + 2:
+            self.ring.append(dict())
+        self.stop = threading.Event()
+        self.thread = threading.Thread(target=self._run, name="ugaitnet-batches", daemon=True)
+        self.thread.start()
+
+    def _stage(self, arrays, stream, slot):
+        """host arrays -> device tensors through the pinned buffers of ring slot `slot` (allocated once per shape: a fresh pinned
+        allocation per batch costs more than the step itself), asynchronously on the copy stream"""
+        import torch
+        ring = self.ring[slot]
+        if ring.get("event") is not None:
+            ring["event"].synchronize()         # the transfer that last used these pinned buffers has finished
+        outs = []
+        with torch.cuda.stream(stream):
+            for k, a in enumerate(arrays):
+                if isinstance(a, torch.Tensor) and a.is_cuda:
+                    outs.append(a)
+                    continue
+                src = a.numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+                pin = ring.get(k)
+                if pin is None or tuple(pin.shape) != tuple(src.shape):
+                    pin = ring[k] = torch.empty(tuple(src.shape), dtype=torch.float32, pin_memory=True)
+                # one plain memcpy on this thread (numpy releases the GIL for it; converts to fp32 on the way, as GaitCore._dev would).
+                # NOT torch's copy_: its OpenMP team beside the training thread's launches cost 20 ms per batch on a 16-core share
+                np.copyto(pin.numpy(), src, casting="same_kind")
+                outs.append(pin.to(self.device, non_blocking=True))
+            ev = torch.cuda.Event()
+            ev.record(stream)
+        ring["event"] = ev
+        return outs, ev
+
+    def _run(self):
+        import torch
+        try:
+            stream = None
+            if self.stage:
+                torch.cuda.set_device(self.device)
+                stream = torch.cuda.Stream(self.device)
+            sized = hasattr(self.gen, "__len__")
+            pool, ahead = None, []
+            if self.workers > 1:       # tf.keras's OrderedEnqueuer with workers > 1: `__getitem__` calls in parallel, handed on IN ORDER
+                import concurrent.futures
+                pool = concurrent.futures.ThreadPoolExecutor(self.workers, thread_name_prefix="ugaitnet-fetch")
+                self.pool = pool
+            nxt = 0
+            for step in range(self.steps):
+                if self.stop.is_set():
+                    return
+                if pool is not None:
+                    while nxt < self.steps and len(ahead) < self.workers + self.q.maxsize:
+                        ahead.append(pool.submit(self.gen.__getitem__, nxt % len(self.gen)))
+                        nxt += 1
+                    X, Y = ahead.pop(0).result()
+                else:
+                    X, Y = self.gen[step % len(self.gen)] if sized else next(self.gen)
+                item = (X, Y, None)
+                if self.stage:
+                    staged, ev = self._stage(list(X) if isinstance(X, (list, tuple)) else [X], stream, step % len(self.ring))
+                    item = (staged if isinstance(X, (list, tuple)) else staged[0], Y, ev)
+                self._put(item)
+            self._put(self._END)
+        except BaseException as e:      # (surfaces in the training thread, at the step that would have used the batch)
+            self._put(e)
+
+    def _put(self, item):
+        import queue
+        while not self.stop.is_set():
+            try:
+                self.q.put(item, timeout=0.1)
+                return
+            except queue.Full:
+                continue
+
+    def get(self):
+        import torch
+        item = self.q.get()
+        if isinstance(item, BaseException):
+            raise item
+        if item is self._END:
+            raise StopIteration
+        X, Y, ev = item
+        if ev is not None:
+            cur = torch.cuda.current_stream(self.device)
+            cur.wait_event(ev)
+            for t in (X if isinstance(X, (list, tuple)) else [X]):
+                t.record_stream(cur)       # (allocated under the copy stream: the allocator must not hand it out again before the step has read it)
+        return X, Y
+
+    def close(self):
+        self.stop.set()
+        try:
+            while True:
+                self.q.get_nowait()
+        except Exception:
+            pass
+        self.thread.join(timeout=10)
+        if getattr(self, "pool", None) is not None:
+            self.pool.shutdown(wait=False, cancel_futures=True)
+
+
 class History:
     def __init__(self):
         self.epoch = []
@@ -319,12 +440,25 @@ class GaitSetModel:
         return acc
 
     def fit(self, x=None, y=None, validation_data=None, epochs=1, steps_per_epoch=None, callbacks=None,
-            validation_steps=None, initial_epoch=0, verbose=2, **kwargs):
+            validation_steps=None, initial_epoch=0, verbose=2, workers=1, max_queue_size=10, use_multiprocessing=False,
+            pipeline=None, **kwargs):
         """The loop `model.fit(training_generator, ...)` runs in nets/mj_uwyhNets_ba.py:963: per epoch
-        steps_per_epoch batches from the keras.utils.Sequence-like generator, Keras callbacks, History."""
+        steps_per_epoch batches from the keras.utils.Sequence-like generator, Keras callbacks, History.
+
+        workers / max_queue_size: as in tf.keras (defaults 1 / 10): a background thread fetches the epoch's batches in order and
+        stages them in HBM while the device trains (`_BatchPipeline`); workers > 1 call the Sequence's `__getitem__` in parallel and
+        hand the batches on in order; workers=0 fetches on the training thread, as Keras does.
+        pipeline (default: on, unless a callback listens to batch events): step k's losses are read after step k + 1 has been
+        queued, so the device never waits for the host between two steps; the History, the epoch logs and every parameter are
+        bit-identical to the synchronous loop (tests/test_api_gpu.py::test_fit_pipeline_matches_the_synchronous_loop) -- only
+        `on_batch_end` would see the model one step ahead, hence the default.  use_multiprocessing is accepted and ignored (the
+        reference passes its default)."""
         gen = x
         hist = History()
         callbacks = list(callbacks or [])
+        batch_hooks = ("on_batch_begin", "on_batch_end", "on_train_batch_begin", "on_train_batch_end")
+        if pipeline is None:
+            pipeline = not any(_listens(cb, h) for cb in callbacks for h in batch_hooks)
         for cb in callbacks:
             if hasattr(cb, "set_model"):
                 cb.set_model(self)
@@ -334,12 +468,37 @@ class GaitSetModel:
             _call(callbacks, "on_epoch_begin", epoch, {})
             n = steps_per_epoch if steps_per_epoch else len(gen)
             sums = {}
-            for step in range(n):
-                X, Y = gen[step % len(gen)] if hasattr(gen, "__len__") else next(gen)
-                logs = self.train_on_batch(X, Y)
+
+            def account(step, logs):
                 for k, v in logs.items():
                     sums[k] = sums.get(k, 0.0) + v
                 _call(callbacks, "on_batch_end", step, logs)
+            if not hasattr(self, "_pinned_ring"):
+                self._pinned_ring = []
+            feed = _BatchPipeline(gen, n, self.core.device, max_queue_size, ring=self._pinned_ring, workers=workers) if workers and workers > 0 else None
+            try:
+                pending = None
+                for step in range(n):
+                    if feed is not None:
+                        X, Y = feed.get()
+                    else:
+                        X, Y = gen[step % len(gen)] if hasattr(gen, "__len__") else next(gen)
+                    if not pipeline:
+                        account(step, self.train_on_batch(X, Y))
+                        continue
+                    xs, uses = self._split_x(X)
+                    labels, onehot = self._split_y(Y)
+                    self._sync_lr()
+                    self.core.train_step(xs, uses, labels, onehot)
+                    queued = self.core.losses_async()
+                    if pending is not None:
+                        account(step - 1, self._logs(pending.result()))
+                    pending = queued
+                if pending is not None:
+                    account(n - 1, self._logs(pending.result()))
+            finally:
+                if feed is not None:
+                    feed.close()
             logs = {k: v / n for k, v in sums.items()}
             if validation_data is not None:
                 vn = validation_steps if validation_steps else len(validation_data)
@@ -449,6 +608,16 @@ def _savez(path, arrays):
     """npz container written to EXACTLY `path` (the mains name their files *.hdf5; np.load does not mind)."""
     with open(os.fspath(path), "wb") as f:
         np.savez(f, **arrays)
+
+
+def _listens(cb, hook):
+    """does this callback define `hook` itself (a no-op inherited from a base class called Callback does not count)"""
+    if not callable(getattr(cb, hook, None)):
+        return False
+    for klass in type(cb).__mro__:
+        if hook in vars(klass):
+            return klass.__name__ != "Callback"
+    return True
 
 
 def _call(callbacks, method, *args):
