@@ -51,19 +51,24 @@ def test_hip_path_matches_fixture(dev, path):
                     margin=0.2, loss_weights=(1.0, 0.1))
     core.set_params_numpy(O.cast_params(p, np.float32))
     core.forward_backward(xs, uses if mm else None, z['labels'], z['onehot'])
-    # north_star: signatures / logits within 1e-3 in fp32, triplet indices bit-exact
-    assert np.abs(core.sig.cpu().numpy() - z['signature']).max() <= 1e-3
-    assert np.abs(core.head['probs'].cpu().numpy() - z['probs']).max() <= 1e-3
+    # north_star: signatures / logits within 1e-3 in fp32, triplet indices bit-exact.  The bars below are ~5x what the default
+    # fp32-tensor path measures on these fixtures (tools/golden_measure.py, round 5: signatures <= 3.6e-5, probabilities <= 4e-7,
+    # losses <= 2e-7, fc gradient norms <= 1.4e-5, first-layer gradients 2e-6 ... 3e-5, no fusion selection differs)
+    assert np.abs(core.sig.cpu().numpy() - z['signature']).max() <= 2e-4
+    assert np.abs(core.head['probs'].cpu().numpy() - z['probs']).max() <= 2e-6
     hp, hn, kp, kn = ops.triplet_indices(z['labels'])
     assert np.array_equal(hp, z['hp']) and np.array_equal(hn, z['hn']) and (kp, kn) == (int(z['kp']), int(z['kn']))
     assert np.array_equal(core.bin_num.cpu().numpy(), z['active_triplets'])
     ls = core.losses()
-    assert abs(ls['loss'] - float(z['loss'])) <= 1e-4 and abs(ls['triplet'] - float(z['triplet'])) <= 1e-4
+    assert abs(ls['loss'] - float(z['loss'])) <= 2e-6 and abs(ls['triplet'] - float(z['triplet'])) <= 2e-6
     got = core.get_grads_numpy()
+    rel = []
     for i in range(len(kinds)):
         ref = z['grad_m%d_a1' % i]
-        # a flipped near-tie in a max (pooling / set-max / HPP) moves one routing decision: a few 1e-3 of a whole tensor
-        assert np.linalg.norm(got['branches'][i]['a1'] - ref) <= 5e-3 * np.linalg.norm(ref) + 1e-12
-        assert abs(np.linalg.norm(got['branches'][i]['fc']) - float(z['grad_m%d_fc_l2' % i])) <= 1e-3 * float(z['grad_m%d_fc_l2' % i]) + 1e-12
+        rel.append(np.linalg.norm(got['branches'][i]['a1'] - ref) / (np.linalg.norm(ref) + 1e-30))
+        assert abs(np.linalg.norm(got['branches'][i]['fc']) - float(z['grad_m%d_fc_l2' % i])) <= 1e-4 * float(z['grad_m%d_fc_l2' % i]) + 1e-12
+    # ONE flipped near-tie in a max (pooling / set-max / HPP) moves a whole first-layer tensor by ~1e-3 (c4's optical-flow branch
+    # measures 9.3e-4; tests/routing.py counts and proves such flips at full size): at most one tensor per fixture beyond 2e-4, none beyond 5e-3
+    assert max(rel) <= 5e-3 and sum(r > 2e-4 for r in rel) <= 1, rel
     if 'sel' in z.files:
-        assert (core.sel.cpu().numpy() != z['sel']).mean() < 1e-3
+        assert np.array_equal(core.sel.cpu().numpy(), z['sel'])
