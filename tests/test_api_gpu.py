@@ -269,10 +269,11 @@ def test_fit_pipeline_matches_the_synchronous_loop(dev):
     runs = {}
     for name, kw in (("plain", dict(workers=0, pipeline=False)), ("piped", dict()), ("pool", dict(workers=3, max_queue_size=2))):
         model, gen = build(), Gen(("of", "gray", "depth"), 4, 3, 6, n_batches=4)
-        hist = model.fit(gen, epochs=3, steps_per_epoch=4, verbose=0, **kw)
+        val = ToyGenerator(("of", "gray", "depth"), 4, 3, 6, n_batches=2)
+        hist = model.fit(gen, validation_data=val, validation_steps=2, epochs=3, steps_per_epoch=4, verbose=0, **kw)
         torch.cuda.synchronize()
         runs[name] = (hist.history, {n: model.core.store.get(n).copy() for n in model.core.store.names}, gen)
-    assert runs["plain"][0] == runs["piped"][0] == runs["pool"][0] and len(runs["piped"][0]["loss"]) == 3
+    assert runs["plain"][0] == runs["piped"][0] == runs["pool"][0] and len(runs["piped"][0]["loss"]) == 3 and "val_loss" in runs["piped"][0]
     for n, w in runs["plain"][1].items():
         assert np.array_equal(w, runs["piped"][1][n]) and np.array_equal(w, runs["pool"][1][n]), n
     gen = runs["piped"][2]

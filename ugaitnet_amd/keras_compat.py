@@ -430,13 +430,22 @@ class GaitSetModel:
             return self.core.fused.cpu().numpy()
         raise ValueError("no output tap for layer %r" % name)
 
-    def evaluate(self, generator, steps=None, verbose=0):
+    def evaluate(self, generator, steps=None, verbose=0, workers=1, max_queue_size=10):
+        """Mean of the per-batch losses / metrics over `steps` batches; the batches are fetched and staged by the same background
+        pipeline as in `fit` (workers=0: on this thread)."""
         n = len(generator) if steps is None else steps
         acc = {}
-        for i in range(n):
-            X, y = generator[i]
-            for k, v in self.test_on_batch(X, y).items():
-                acc[k] = acc.get(k, 0.0) + v / n
+        if not hasattr(self, "_pinned_ring"):
+            self._pinned_ring = []
+        feed = _BatchPipeline(generator, n, self.core.device, max_queue_size, ring=self._pinned_ring, workers=workers) if workers and workers > 0 else None
+        try:
+            for i in range(n):
+                X, y = feed.get() if feed is not None else generator[i % len(generator)]
+                for k, v in self.test_on_batch(X, y).items():
+                    acc[k] = acc.get(k, 0.0) + v / n
+        finally:
+            if feed is not None:
+                feed.close()
         return acc
 
     def fit(self, x=None, y=None, validation_data=None, epochs=1, steps_per_epoch=None, callbacks=None,
@@ -502,7 +511,7 @@ class GaitSetModel:
             logs = {k: v / n for k, v in sums.items()}
             if validation_data is not None:
                 vn = validation_steps if validation_steps else len(validation_data)
-                for k, v in self.evaluate(validation_data, vn).items():
+                for k, v in self.evaluate(validation_data, vn, workers=workers, max_queue_size=max_queue_size).items():
                     logs["val_" + k] = v
             logs["lr"] = float(self.optimizer.lr)
             hist._append(epoch, logs)
