@@ -229,6 +229,11 @@ def roofline_pass(core, batch, steps, dtype, table_path=""):
                      hbm_floor_us=round(hbm_floor * 1e6, 1), mfma_tflops=round(w["mfma_flops"] / avg / 1e6, 2),
                      algorithmic_tflops=round(w["flops"] / avg / 1e6, 2), algorithmic_gbytes_per_s=round(w["bytes"] / avg / 1e3, 1),
                      rocprof_kernel=w["kernel"], images_per_launch=w["images"])
+            if w.get("dtype") == "bf16x3":
+                # the contract's literal reading for an fp32 path -- ALGORITHMIC FLOPs against the dense MFMA peak of the dtype the path
+                # computes in (fp32: 157.3 TFLOP/s) -- beside `frac`: above 1 means the launch outruns what ANY kernel issuing fp32
+                # matrix instructions could reach, which is what the three-way bf16 split is for
+                d["algorithmic_frac_of_f32_mfma_peak"] = round(w["flops"] / t / PEAK_F32_MFMA, 4)
         elif w and w["bound"] == "mfma":
             peak = PEAK_BF16_MFMA if w["dtype"] in ("bf16", "f16x2") else PEAK_F32_MFMA   # (f16 MFMAs run at the bf16 rate)
             d.update(bound="mfma", unit="TFLOP/s", peak=round(peak / 1e12, 1), achieved=round(w["mfma_flops"] / avg / 1e6, 2),
@@ -459,10 +464,14 @@ def run(args):
                    whole_step_tflops=round(value * fpc / 1e12, 2),
                    whole_step_frac_of_matrix_peak=round(value * fpc * exec_factor / world / exec_peak, 4),
                    loss=round(losses["loss"], 5), roofline=roof)
+        if args.dtype in ("f32x3", "f32"):     # the fp32-tensor arithmetics: algorithmic FLOPs of the whole step against the fp32-MFMA peak
+            out["whole_step_frac_of_f32_mfma_peak"] = round(value * fpc / world / PEAK_F32_MFMA, 4)
         out["whole_step_note"] = ("whole_step_tflops prices the step with SURVEY 8(d)'s algorithmic FLOPs per clip (71.3 G for 3 "
                                   "modalities); the fraction beside it counts the FLOPs the matrix pipe executes for them (f32x3: 6x "
                                   "against the dense bf16 peak of 2.5 PFLOP/s; Winograd f32: 16/36 against the fp32-MFMA peak; f16x2: 3x "
-                                  "against the dense f16 peak)")
+                                  "against the dense f16 peak); whole_step_frac_of_f32_mfma_peak = the ALGORITHMIC FLOPs of the whole step, "
+                                  "head, losses, pooling and Adam included in the time, against 157.3 TFLOP/s: above 1 = faster than any kernel "
+                                  "issuing fp32 matrix instructions could run the convolutions alone")
         if skip_rate is not None:
             out["value_skip_masked"] = round(skip_rate, 2)   # 29 of the 72 (clip, modality) pairs of the C3 batch are masked
         for o in others:
@@ -475,7 +484,7 @@ def run(args):
                                                                  (PEAK_F32_MFMA if prec == "f32" else PEAK_BF16_MFMA), 4)
             if o["roof"] is not None:
                 keep = ("kernel", "bound", "achieved", "peak", "unit", "frac", "avg_us", "launches_per_step", "share_of_step",
-                        "algorithmic_tflops", "mfma_frac", "hbm_frac", "rocprof_kernel", "images_per_launch", "serial_step_us")
+                        "algorithmic_tflops", "mfma_frac", "hbm_frac", "rocprof_kernel", "images_per_launch", "serial_step_us", "algorithmic_frac_of_f32_mfma_peak")
                 out["roofline_" + tag] = {k: o["roof"].get(k) for k in keep if o["roof"].get(k) is not None}
         if not args.no_cpu_baseline and world == 1:
             big = b_gpu > 40      # (the generator-expanded batches: time the workload's own batch on the CPU)

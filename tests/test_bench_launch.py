@@ -105,6 +105,9 @@ def test_roofline_object_of_the_default_command(dev, tmp_path, dtype):
         # three f16 (h2) / six bf16 (x3) MFMAs per product; the pooled weight gradients on the sparse pipe execute half of them
         ratios = (3.0, 1.5) if dtype == "h2" else (6.0, 3.0)
         assert min(abs(roof["mfma_tflops"] / roof["algorithmic_tflops"] - r) for r in ratios) < 0.01
+        if dtype == "f32x3":     # the contract's literal figure beside it: algorithmic FLOPs against the fp32-MFMA peak (may exceed 1)
+            assert abs(roof["algorithmic_frac_of_f32_mfma_peak"] - roof["algorithmic_tflops"] / 157.3) < 2e-3
+            assert abs(d["whole_step_frac_of_f32_mfma_peak"] - d["whole_step_tflops"] / 157.3) < 2e-3
     else:
         assert roof["bound"] == "mfma" and roof["unit"] == "TFLOP/s" and roof["peak"] == 157.3
         assert abs(roof["achieved"] / roof["algorithmic_tflops"] - 16.0 / 36.0) < 0.01     # Winograd: 16/36 of the direct count
