@@ -134,7 +134,9 @@ class _BatchPipeline:
         outs = []
         with torch.cuda.stream(stream):
             for k, a in enumerate(arrays):
-                if isinstance(a, torch.Tensor) and a.is_cuda:
+                if (isinstance(a, torch.Tensor) and a.is_cuda) or np.ndim(a) <= 2:
+                    # (already in HBM; or a [B, 1] modality-flag column: it stays on the host, where GaitCore decides which masked
+                    #  (clip, modality) pairs to skip -- from a device tensor that decision would synchronise with the previous step)
                     outs.append(a)
                     continue
                 src = a.numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
@@ -204,7 +206,8 @@ class _BatchPipeline:
             cur = torch.cuda.current_stream(self.device)
             cur.wait_event(ev)
             for t in (X if isinstance(X, (list, tuple)) else [X]):
-                t.record_stream(cur)       # (allocated under the copy stream: the allocator must not hand it out again before the step has read it)
+                if isinstance(t, torch.Tensor) and t.is_cuda:
+                    t.record_stream(cur)       # (allocated under the copy stream: the allocator must not hand it out again before the step has read it)
         return X, Y
 
     def close(self):
