@@ -38,11 +38,18 @@ def conv2d_same(x, w):
     n, h, ww, cin = x.shape
     cout = w.shape[3]
     xp = np.pad(x, ((0, 0), (p, p), (p, p), (0, 0)))
+    if k * k * cin <= 64:      # the first layer (K = 25 or 50): one product with the patch matrix instead of 25 rank-1 / rank-2 updates
+        return (_patches(xp, k, h, ww) @ w.reshape(k * k * cin, cout)).reshape(n, h, ww, cout)
     out = np.zeros((n * h * ww, cout), dtype=x.dtype)
     for dy in range(k):
         for dx in range(k):
             out += xp[:, dy:dy + h, dx:dx + ww, :].reshape(-1, cin) @ w[dy, dx]
     return out.reshape(n, h, ww, cout)
+
+
+def _patches(xp, k, h, ww):
+    """[n*h*w, k*k*cin] patch matrix of a padded NHWC tensor, taps in HWIO order (small cin only: 25 or 50 columns)."""
+    return np.concatenate([xp[:, dy:dy + h, dx:dx + ww, :].reshape(-1, xp.shape[3]) for dy in range(k) for dx in range(k)], axis=1)
 
 
 def conv2d_same_bwd(x, w, dz, need_dx=True):
@@ -53,6 +60,8 @@ def conv2d_same_bwd(x, w, dz, need_dx=True):
     cout = w.shape[3]
     xp = np.pad(x, ((0, 0), (p, p), (p, p), (0, 0)))
     dz2 = dz.reshape(-1, cout)
+    if not need_dx and k * k * cin <= 64:      # the first layer's filter gradient: one product with the patch matrix
+        return (_patches(xp, k, h, ww).T @ dz2).reshape(w.shape), None
     dw = np.zeros_like(w)
     dxp = np.zeros_like(xp) if need_dx else None
     for dy in range(k):
