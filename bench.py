@@ -203,10 +203,15 @@ def roofline_pass(core, batch, steps, dtype, table_path=""):
             prof, work = _lib.PROFILE, _lib.WORK
         finally:
             _lib.PROFILE = None
-    rows = []
+    rows, stalled = [], 0
     for label, evs in prof.items():
         us = [a.elapsed_time(b) * 1e3 for a, b in evs]
-        rows.append((float(np.sum(us)), float(np.mean(us)), len(us), label))
+        # a launch that took more than five times its label's median is a stall of the box (seen once: one launch 60x its usual time
+        # in a 3-step pass, which made that label "dominant"), not the kernel: averaged over the others, counted in `stalled_launches`
+        med = float(np.median(us))
+        keep = [u for u in us if u <= 5.0 * med] or us
+        stalled += len(us) - len(keep)
+        rows.append((float(np.mean(keep)) * len(us), float(np.mean(keep)), len(us), label))
     rows.sort(reverse=True)
     total = sum(r[0] for r in rows)
 
@@ -281,6 +286,8 @@ def roofline_pass(core, batch, steps, dtype, table_path=""):
             roof["traffic_source"] = "profiles/" + tname + " (rocprofv3 --pmc passes of this kernel at this launch size; not this run)"
             break
     roof["serial_step_us"] = round(total / steps, 1)
+    if stalled:
+        roof["stalled_launches"] = stalled
     roof["other_kernels"] = [describe(r) for r in rows[1:10]]
     return roof
 
