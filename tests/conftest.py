@@ -19,8 +19,17 @@ def pytest_collection_modifyitems(config, items):
     """Without a GPU every test that carries the `gpu` marker is skipped, whether or not it takes the `dev` fixture.
     With one: the full-size parity tests go to the END of the session -- their fp64 oracle evaluations (host cores only) run on a
     child process from the session's start, beside the other GPU tests (`_oracle_ahead` below)."""
+    import re
     import torch
     if torch.cuda.is_available():
+        # the f16x2 ("h2") kernel set is an opt-in build since round 6 (python -m ugaitnet_amd.build --h2): its tests -- the two h2
+        # modules and every case whose id names h2 -- run only against a library that carries it
+        from ugaitnet_amd import _lib
+        if not _lib.has_h2():
+            no_h2 = pytest.mark.skip(reason="libugaitnet_hip.so was built without the opt-in f16x2 set (build --h2)")
+            for item in items:
+                if re.search(r"test_mm_gpu\.py|test_h2_elem_gpu\.py|h2|f16x2", item.nodeid):
+                    item.add_marker(no_h2)
         items[:] = [i for i in items if FULLSIZE not in i.nodeid] + [i for i in items if FULLSIZE in i.nodeid]
         return
     skip = pytest.mark.skip(reason="no GPU visible (gpu-marked test)")

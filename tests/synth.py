@@ -8,8 +8,10 @@ import numpy as np
 MASK_PATTERNS = ((1, 1, 1), (1, 1, 0), (1, 0, 1), (0, 1, 1), (1, 0, 0), (0, 1, 0), (0, 0, 1))
 
 
-def make_batch(kinds, b, l=25, nclasses=150, ids=None, per_id=2, seed=232323, masks=True, dtype=np.float32):
-    """kinds: tuple of 'of' | 'gray' | 'depth' | 'sil'.  Returns (xs, uses, labels, onehot)."""
+def make_batch(kinds, b, l=25, nclasses=150, ids=None, per_id=2, seed=232323, masks=True, dtype=np.float32, all_present=False):
+    """kinds: tuple of 'of' | 'gray' | 'depth' | 'sil'.  Returns (xs, uses, labels, onehot).
+    all_present: no modality dropping (every `use` flag 1, no 1e-9 placeholder tensors): bench.py's value_all_present."""
+    masks = masks and not all_present
     rng = np.random.default_rng(seed)
     xs = []
     for k in kinds:

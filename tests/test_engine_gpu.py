@@ -556,7 +556,8 @@ def test_parameters_set_right_after_a_training_step(dev):
     kinds, b, l, ncls = ('of', 'gray', 'depth'), 4, 3, 6
     xs, uses, labels, onehot = make_batch(kinds, b, l, ncls, ids=2, seed=12)
     pa, pb = oracle_params(kinds, ncls, seed=5), oracle_params(kinds, ncls, seed=6)
-    for prec in ("h2", "bf16"):
+    from ugaitnet_amd import _lib
+    for prec in ("f32x3", "bf16") + (("h2",) if _lib.has_h2() else ()):
         core = build(kinds, ncls, 'sign_max', pa, conv_precision=prec)
         for _ in range(3):
             core.train_step(xs, uses, labels, onehot)

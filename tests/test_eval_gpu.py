@@ -5,6 +5,7 @@ import itertools
 import numpy as np
 import pytest
 
+from oracle import ugaitnet_oracle as O
 from tests.synth import make_batch
 
 pytestmark = pytest.mark.gpu
@@ -22,13 +23,32 @@ def test_signatures_for_all_seven_modality_combinations_and_knn(dev):
     xs, _, labels, _ = make_batch(("of", "gray", "depth"), b, 5, 6, ids=4, seed=11)
     combos = [c for c in itertools.product((0, 1), repeat=3) if any(c)]        # the 7 test-time combinations (:599-601)
     assert len(combos) == 7
-    codes = {}
+    # the model's own parameters, handed to the CPU restatement: what `predict` returns must be O.model_forward's `flat` -- the gated,
+    # fused, batch-normalised signature transposed [1,0,2] and flattened (nets/mj_uwyhNets_ba.py:815-818,847) -- under EVERY combination
+    p32 = model.core.get_params_numpy()
+    p64 = O.cast_params(p32, np.float64)
+    codes, worst = {}, 0.0
     for c in combos:
-        X = []
+        X, us = [], []
         for m in range(3):
-            X += [xs[m], np.full((b, 1), float(c[m]), np.float32)]
+            u = np.full((b, 1), float(c[m]), np.float32)
+            X += [xs[m], u]
+            us.append(u.astype(np.float64))
         codes[c] = model_code.predict(X)
         assert codes[c].shape == (b, 62 * 256) and np.isfinite(codes[c]).all()
+        r = O.model_forward([x.astype(np.float64) for x in xs], us, p64, mode="sign_max")
+        err = float(np.abs(codes[c] - r["flat"]).max())
+        worst = max(worst, err)
+        assert err <= 2e-5, (c, err)              # (unit-norm columns over the batch: the tensor's scale is <= 1)
+        # the selected modality of every element is the oracle's, except where two candidates tie to fp32 rounding
+        sel = model.core.sel.cpu().numpy()
+        diff = sel != r["sel"]
+        if diff.any():
+            g = np.stack([np.abs(o * u.reshape(1, -1, 1)) for o, u in zip(r["outs"], us)])       # [3, 62, b, 256]
+            top = np.sort(g, axis=0)
+            assert ((top[-1] - top[-2])[diff] <= 8 * 1.2e-7 * top[-1].max()).all(), (c, int(diff.sum()))
+        assert diff.mean() < 1e-4
+    print("flatten codes vs the oracle under the 7 modality combinations: max |error| %.2e" % worst)
     # a disabled modality's pixels never matter; an enabled one does
     X = []
     for m, flag in enumerate((1, 0, 1)):

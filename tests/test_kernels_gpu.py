@@ -603,3 +603,24 @@ def test_adam(dev):
     pr, mr, vr = p.copy(), m.copy(), v.copy()
     O.adam_step(pr, g, mr, vr, t)       # fp32 oracle: hyper-parameters rounded to fp32 as TF does
     close(pt, pr, 1e-6, "adam p"); close(mt, mr, 1e-6, "adam m"); close(vt, vr, 1e-6, "adam v")
+
+
+def test_gather_and_scatter_rows(dev):
+    """ugn_gather_rows / ugn_scatter_rows (the dense sub-batches of the mask-skipping step): pure row copies, bit for bit numpy's
+    take / put along the clip axis of [B, L, 60, 60, C] inputs (axis 0) and of [62, B, 256] features (axis 1)."""
+    from ugaitnet_amd import ops
+    rng = np.random.default_rng(31)
+    x = rng.normal(size=(7, 3, 60, 60, 1)).astype(np.float32)
+    f = rng.normal(size=(62, 7, 256)).astype(np.float32)
+    idx = np.array([5, 0, 3, 6], np.int64)
+    it = T(idx, dev)
+    assert np.array_equal(ops.gather_rows(T(x, dev), it, 0).cpu().numpy(), x[idx])
+    assert np.array_equal(ops.gather_rows(T(f, dev), it, 1).cpu().numpy(), f[:, idx])
+    dst = T(np.full_like(f, 7.0), dev)
+    src = rng.normal(size=(62, 4, 256)).astype(np.float32)
+    ops.scatter_rows(T(src, dev), it, 1, dst)
+    want = np.full_like(f, 7.0)
+    want[:, idx] = src
+    assert np.array_equal(dst.cpu().numpy(), want)
+    with pytest.raises(ValueError):         # rows that are not whole float4s
+        ops.gather_rows(T(rng.normal(size=(4, 6)).astype(np.float32), dev), T(np.array([1], np.int64), dev), 0)

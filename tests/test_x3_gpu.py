@@ -210,7 +210,7 @@ def test_six_products_against_all_nine(dev, hw, cin, cout, pool):
 def test_x3_results_do_not_depend_on_the_persistent_grid(dev):
     """ugn_set_persistent_wgs(n < 256) leaves CUs free for RCCL's channels under data parallelism: the x3 forward / data-gradient
     launches then run n (or 2 n) persistent workgroups over the same items -- bit-identical results for every n."""
-    from ugaitnet_amd import h2, x3
+    from ugaitnet_amd import ops, x3
     rng = np.random.default_rng(5)
     hw, cin, cout, n = 32, 64, 64, 13
     x = T(rng.uniform(-1, 1, (n, hw, hw, cin)).astype(np.float32), dev)
@@ -221,7 +221,7 @@ def test_x3_results_do_not_depend_on_the_persistent_grid(dev):
     res = []
     try:
         for wgs in (0, 224, 64, 8):
-            h2.set_persistent_wgs(wgs)
+            ops.set_persistent_wgs(wgs)
             out = torch.empty((n, hw // 2, hw // 2, cout), device=dev)
             idx = torch.empty((n, hw // 2, hw // 2, cout), dtype=torch.uint8, device=dev)
             x3.conv3x3_fwd_multi([x], [wf], cout, True, [out], [idx])
@@ -229,7 +229,7 @@ def test_x3_results_do_not_depend_on_the_persistent_grid(dev):
             x3.conv3x3_dgrad_multi([dp], [wd], hw, cin, cout, [dx], dz_idxs=[pidx], acts=[x])
             res.append((out, idx, dx))
     finally:
-        h2.set_persistent_wgs(0)
+        ops.set_persistent_wgs(0)
     for r in res[1:]:
         assert all(torch.equal(a, b) for a, b in zip(res[0], r))
 
@@ -255,3 +255,24 @@ def test_x3_split_is_exact_and_full_range(dev):
         got = out[0:1].cpu().numpy().astype(np.float64) / float(s)
         assert np.array_equal(got, alone.cpu().numpy().astype(np.float64)), "2^%d: scaling by a power of two must commute bit for bit" % k
         close(got, ref, 2e-6, "scale 2^%d" % k)
+
+
+def test_a_later_core_never_inherits_an_earlier_cores_grid(dev):
+    """the persistent grid is the library's one process-wide setting; every core of a persistent kernel set (x3 included,
+    the default arithmetic) sets it from ITS settings at construction -- a reduced grid (Settings.persistent_wgs, or 224 by itself when
+    the bucketed all-reduce overlaps the backward pass of several ranks) does not outlive the core that asked for it."""
+    from ugaitnet_amd import engine, ops
+    try:
+        small = engine.GaitCore([1], nclasses=4, multimodal=False, conv_precision="bf16", config=engine.DEFAULTS.replace(persistent_wgs=64))
+        assert small.persistent_wgs == 64 and ops.get_persistent_wgs() == 64
+        x3core = engine.GaitCore([1], nclasses=4, multimodal=False, conv_precision="f32x3")
+        assert x3core.persistent_wgs == 0 and ops.get_persistent_wgs() == 256
+        named = engine.GaitCore([1], nclasses=4, multimodal=False, conv_precision="f32x3", config=engine.DEFAULTS.replace(persistent_wgs=128))
+        assert ops.get_persistent_wgs() == 128
+        # what a rank of a data-parallel job with the overlapped all-reduce gets by itself
+        assert engine.GaitCore.grid_for(engine.DEFAULTS.replace(ar_overlap=True), 8) == 224
+        assert engine.GaitCore.grid_for(engine.DEFAULTS.replace(ar_overlap=True), 1) == 0
+        assert engine.GaitCore.grid_for(engine.DEFAULTS.replace(ar_overlap=False), 8) == 0
+        del small, named
+    finally:
+        ops.set_persistent_wgs(0)

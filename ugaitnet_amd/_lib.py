@@ -75,33 +75,14 @@ PROTOTYPES = {
     "ugn_triplet_fwd_bwd": (_i, [_p, _p, _p, _i, _i, _f, _p, _p, _p, _f, _i, _p]),
     "ugn_triplet_hard_fwd_bwd": (_i, [_p, _p, _f, _p, _p, _p, _f, _i, _p]),
     "ugn_assemble_modality": (_i, [_p, _i, _p, _i, _i, _f, _f, _f, _f, _f, _f, _p, _p, _p]),
+    "ugn_gather_rows": (_i, [_p, _p, _p, _i, _i, _i, _sz, _p]),
+    "ugn_scatter_rows": (_i, [_p, _p, _p, _i, _i, _i, _sz, _p]),
     "ugn_knn_ws": (_sz, [_i, _i]),
     "ugn_knn_predict": (_i, [_p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _sz, _p]),
     "ugn_adam_step": (_i, [_p, _p, _p, _p, _sz, _f, _f, _f, _f, _f, _p]),
     "ugn_adam_step_dev": (_i, [_p, _p, _p, _p, _sz, _p, _f, _f, _f, _f, _p]),
-    # H2 tensors (split-fp16 halves + block exponent) and the f16-matrix-pipe 3x3 kernels
-    "ugn_absmax": (_i, [_p, _sz, _p, _p]),
-    "ugn_h2_encode": (_i, [_p, _p, _p, _sz, _i, _p]),
-    "ugn_h2_decode": (_i, [_p, _p, _p, _sz, _i, _p]),
-    "ugn_mm_pack_multi": (_i, [C.POINTER(_p)] * 3 + [C.POINTER(_i)] * 3 + [_i, _p]),
-    "ugn_mm_conv3x3_fwd_multi": (_i, [C.POINTER(_p)] * 7 + [C.POINTER(_i), _i, _i, _i, _i, _i, _p]),
-    "ugn_mm_conv3x3_dgrad_multi": (_i, [C.POINTER(_p)] * 8 + [C.POINTER(_i), _i, _i, _i, _i, _p]),
-    "ugn_mm_dgrad32_wgrad5_ws": (_sz, [_i]),
-    "ugn_mm_dgrad32_wgrad5_multi": (_i, [C.POINTER(_p)] * 10 + [C.POINTER(_i), C.POINTER(_i), _i, _p, _sz, _p]),
-    "ugn_conv5x5_in_fwd_h2": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _p]),
-    "ugn_conv5x5_in_wgrad_h2": (_i, [_p, _p, _p, _p, _p, _i, _i, _p, _sz, _p]),
-    "ugn_conv5x5_in_wgrad_h2x": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _p, _sz, _p]),
-    "ugn_absmax_multi": (_i, [C.POINTER(_p), C.POINTER(_sz), C.POINTER(_p), _i, _p]),
-    "ugn_h2_encode_multi": (_i, [C.POINTER(_p)] * 4 + [C.POINTER(_sz), _i, _i, _p]),
-    "ugn_h2_setmax_fwd_multi": (_i, [C.POINTER(_p)] * 8 + [C.POINTER(_i), _i, _i, _i, _i, _p]),
-    "ugn_h2_setmax_fwd_f32_multi": (_i, [C.POINTER(_p)] * 6 + [C.POINTER(_i), _i, _i, _i, _i, _p]),
-    "ugn_h2_setmax_bwd_multi": (_i, [C.POINTER(_p)] * 4 + [_i] + [C.POINTER(_p)] * 4 + [C.POINTER(_i), _i, _i, _i, _i, _i, _p]),
-    "ugn_h2_setmax_fwd_routed_multi": (_i, [C.POINTER(_p)] * 9 + [C.POINTER(_i), _i, _i, _i, _i, _p]),
-    "ugn_h2_setmax_fwd_f32_routed_multi": (_i, [C.POINTER(_p)] * 7 + [C.POINTER(_i), _i, _i, _i, _i, _p]),
-    "ugn_h2_setmax_bwd_routed_multi": (_i, [C.POINTER(_p)] * 3 + [_i] + [C.POINTER(_p)] * 4 + [C.POINTER(_i), _i, _i, _i, _i, _i, _p]),
-    "ugn_h2_lrelu_bwd_multi": (_i, [C.POINTER(_p)] * 5 + [C.POINTER(_sz), _i, _i, _p]),
-    "ugn_hpp_bwd_b4h2_multi": (_i, [C.POINTER(_p)] * 6 + [C.POINTER(_i), _i, _p]),
     "ugn_set_persistent_wgs": (_i, [_i]),
+    "ugn_get_persistent_wgs": (_i, []),
     # bf16 tensors in HBM (configs[4])
     "ugn_bf_pack_multi": (_i, [C.POINTER(_p)] * 2 + [C.POINTER(_i)] * 4 + [_i, _p]),
     "ugn_bf_conv3x3_fwd_multi": (_i, [C.POINTER(_p)] * 4 + [C.POINTER(_i), _i, _i, _i, _i, _i, _p]),
@@ -128,6 +109,30 @@ PROTOTYPES = {
     "ugn_x3_conv3x3_dgrad_multi": (_i, [C.POINTER(_p)] * 5 + [C.POINTER(_i), _i, _i, _i, _i, _i, _p]),
     "ugn_x3_conv3x3_wgrad_ws": (_sz, [_i, _i, _i]),
     "ugn_x3_conv3x3_wgrad_multi": (_i, [C.POINTER(_p)] * 4 + [C.POINTER(_i), _i, _i, _i, _i, _p, _sz, _i, _p]),
+}
+# the opt-in f16x2 ("H2") set: include/ugaitnet_hip_h2.h, exported only by a library built with `python -m ugaitnet_amd.build --h2`
+PROTOTYPES_H2 = {
+    "ugn_absmax": (_i, [_p, _sz, _p, _p]),
+    "ugn_h2_encode": (_i, [_p, _p, _p, _sz, _i, _p]),
+    "ugn_h2_decode": (_i, [_p, _p, _p, _sz, _i, _p]),
+    "ugn_mm_pack_multi": (_i, [C.POINTER(_p)] * 3 + [C.POINTER(_i)] * 3 + [_i, _p]),
+    "ugn_mm_conv3x3_fwd_multi": (_i, [C.POINTER(_p)] * 7 + [C.POINTER(_i), _i, _i, _i, _i, _i, _p]),
+    "ugn_mm_conv3x3_dgrad_multi": (_i, [C.POINTER(_p)] * 8 + [C.POINTER(_i), _i, _i, _i, _i, _p]),
+    "ugn_mm_dgrad32_wgrad5_ws": (_sz, [_i]),
+    "ugn_mm_dgrad32_wgrad5_multi": (_i, [C.POINTER(_p)] * 10 + [C.POINTER(_i), C.POINTER(_i), _i, _p, _sz, _p]),
+    "ugn_conv5x5_in_fwd_h2": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _p]),
+    "ugn_conv5x5_in_wgrad_h2": (_i, [_p, _p, _p, _p, _p, _i, _i, _p, _sz, _p]),
+    "ugn_conv5x5_in_wgrad_h2x": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _p, _sz, _p]),
+    "ugn_absmax_multi": (_i, [C.POINTER(_p), C.POINTER(_sz), C.POINTER(_p), _i, _p]),
+    "ugn_h2_encode_multi": (_i, [C.POINTER(_p)] * 4 + [C.POINTER(_sz), _i, _i, _p]),
+    "ugn_h2_setmax_fwd_multi": (_i, [C.POINTER(_p)] * 8 + [C.POINTER(_i), _i, _i, _i, _i, _p]),
+    "ugn_h2_setmax_fwd_f32_multi": (_i, [C.POINTER(_p)] * 6 + [C.POINTER(_i), _i, _i, _i, _i, _p]),
+    "ugn_h2_setmax_bwd_multi": (_i, [C.POINTER(_p)] * 4 + [_i] + [C.POINTER(_p)] * 4 + [C.POINTER(_i), _i, _i, _i, _i, _i, _p]),
+    "ugn_h2_setmax_fwd_routed_multi": (_i, [C.POINTER(_p)] * 9 + [C.POINTER(_i), _i, _i, _i, _i, _p]),
+    "ugn_h2_setmax_fwd_f32_routed_multi": (_i, [C.POINTER(_p)] * 7 + [C.POINTER(_i), _i, _i, _i, _i, _p]),
+    "ugn_h2_setmax_bwd_routed_multi": (_i, [C.POINTER(_p)] * 3 + [_i] + [C.POINTER(_p)] * 4 + [C.POINTER(_i), _i, _i, _i, _i, _i, _p]),
+    "ugn_h2_lrelu_bwd_multi": (_i, [C.POINTER(_p)] * 5 + [C.POINTER(_sz), _i, _i, _p]),
+    "ugn_hpp_bwd_b4h2_multi": (_i, [C.POINTER(_p)] * 6 + [C.POINTER(_i), _i, _p]),
     "ugn_mm_conv3x3_wgrad_ws": (_sz, [_i, _i, _i]),
     "ugn_mm_conv3x3_wgrad_multi": (_i, [C.POINTER(_p)] * 6 + [C.POINTER(_i), _i, _i, _i, _i, _p, _sz, _p]),
 }
@@ -158,8 +163,29 @@ def load():
         fn.argtypes = args
     if lib.ugn_abi_version() != 1:
         raise UgnError("libugaitnet_hip.so ABI version mismatch")
+    global HAS_H2
+    HAS_H2 = hasattr(lib, "ugn_mm_conv3x3_fwd_multi")
+    if HAS_H2:
+        for name, (res, args) in PROTOTYPES_H2.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
     _lib = lib
     return lib
+
+
+HAS_H2 = None     # set by load(): the library carries the opt-in f16x2 set
+
+
+def has_h2():
+    load()
+    return bool(HAS_H2)
+
+
+def require_h2(what="conv_precision='h2'"):
+    if not has_h2():
+        raise UgnError("%s needs the opt-in f16x2 kernel set, which this libugaitnet_hip.so was built without: "
+                       "`python -m ugaitnet_amd.build --h2` (or UGN_BUILD_H2=1) adds it" % what)
 
 
 def check(rc, what):
@@ -176,6 +202,7 @@ def check(rc, what):
 # bytes=algorithmic HBM bytes, kernel=the device kernel rocprofv3 shows for it).  None (the default) = no events at all.
 PROFILE = None
 WORK = {}
+ORDER = None       # a list while the order of the profiled launches is wanted too (bench.py records what it drops with it)
 
 
 def call(name, *args, label=None, work=None):
@@ -190,6 +217,8 @@ def call(name, *args, label=None, work=None):
     e1.record()
     key = label or name
     PROFILE.setdefault(key, []).append((e0, e1))
+    if ORDER is not None:
+        ORDER.append(key)
     if work is not None:
         WORK[key] = work
     check(rc, name)

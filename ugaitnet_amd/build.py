@@ -1,6 +1,10 @@
 """Builds libugaitnet_hip.so (gfx950) in-tree with hipcc.  No GPU is needed: hipcc cross-compiles.
 
-    python -m ugaitnet_amd.build [--force]
+    python -m ugaitnet_amd.build [--force] [--h2]
+
+--h2 (or UGN_BUILD_H2=1): also build the opt-in f16x2 ("H2") kernel set of rounds 3-4 (conv3x3_mm.hip, wgrad3x3_mm.hip,
+h2_elem.hip + the h2 entry points of conv5x5.hip / pool_set.hip; include/ugaitnet_hip_h2.h).  The default library does not carry it:
+it is narrower than the reference's fp32, batch-dependent and credited nowhere, and it was the longest part of the build.
 """
 from __future__ import annotations
 
@@ -13,8 +17,15 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "csrc", "_obj")
 LIB = os.path.join(HERE, "libugaitnet_hip.so")
-SOURCES = ["conv3x3.hip", "conv3x3_wino.hip", "conv3x3_wino_tall.hip", "wgrad3x3_wino.hip", "conv3x3_mm.hip", "wgrad3x3_mm.hip", "h2_elem.hip", "conv3x3_bf.hip", "wgrad3x3_bf.hip", "bf_elem.hip", "conv3x3_x3.hip", "wgrad3x3_x3.hip", "conv5x5.hip", "pool_set.hip", "head.hip", "knn.hip", "assemble.hip", "error.cpp"]
-HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "wino_common.h"), os.path.join(CSRC, "mm_common.h"), os.path.join(CSRC, "x3_common.h"), os.path.join(HERE, "..", "include", "ugaitnet_hip.h")]
+# (longest compiles first: four run at a time)
+# conv3x3.hip (the direct fp32-MFMA set: 48 data-gradient instantiations, 150 s as one object) is compiled as five objects:
+# "file@k" = that file with -DUGN_C3_PART=k into <file>_p<k>.o
+SOURCES = ["conv3x3.hip@1", "conv3x3.hip@2", "conv3x3.hip@3", "conv3x3.hip@4", "conv3x3_x3.hip", "conv3x3.hip@0", "conv3x3_wino.hip", "wgrad3x3_x3.hip",
+           "conv5x5.hip", "conv3x3_bf.hip", "wgrad3x3_bf.hip", "wgrad3x3_wino.hip", "conv3x3_wino_tall.hip", "head.hip", "pool_set.hip",
+           "bf_elem.hip", "knn.hip", "assemble.hip", "error.cpp", "runtime.cpp"]
+H2_SOURCES = ["conv3x3_mm.hip", "wgrad3x3_mm.hip", "h2_elem.hip"]       # the opt-in f16x2 set (--h2 / UGN_BUILD_H2=1)
+H2_FLAGGED = ("conv5x5.hip", "pool_set.hip")                           # sources that carry `#if UGN_WITH_H2` entry points
+HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "wino_common.h"), os.path.join(CSRC, "mm_common.h"), os.path.join(CSRC, "x3_common.h"), os.path.join(HERE, "..", "include", "ugaitnet_hip.h"), os.path.join(HERE, "..", "include", "ugaitnet_hip_h2.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-fno-slp-vectorize"]
 FLAGS += os.environ.get("UGN_EXTRA_HIPCC_FLAGS", "").split()   # experiments only (e.g. -DUGN_...); the default build sets none
@@ -39,9 +50,9 @@ def _digest(paths, flags):
     return h.hexdigest()
 
 
-def _compile(src, objdir=None, extra=()):
+def _compile(src, objdir=None, extra=(), suffix=""):
     import glob
-    obj = os.path.join(objdir or OBJ, os.path.splitext(src)[0] + ".o")
+    obj = os.path.join(objdir or OBJ, os.path.splitext(src)[0] + suffix + ".o")
     path = os.path.join(CSRC, src)
     cmd = [HIPCC] + FLAGS + list(extra) + (["-x", "hip"] if src.endswith(".cpp") else []) + ["-c", path, "-o", obj]
     headers = sorted(set(HEADERS + glob.glob(os.path.join(CSRC, "*.h"))))
@@ -49,17 +60,26 @@ def _compile(src, objdir=None, extra=()):
     stamp = obj + ".sha256"
     have = open(stamp).read().strip() if os.path.exists(stamp) and os.path.exists(obj) else ""
     if have != want:
+        import time
+        t0 = time.perf_counter()
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("hipcc failed for %s:\n%s" % (src, r.stderr))
+        if os.environ.get("UGN_BUILD_TIMES"):
+            print("  %-24s %.1f s" % (src, time.perf_counter() - t0), flush=True)
         with open(stamp, "w") as f:
             f.write(want + "\n")
         return obj, True
     return obj, False
 
 
-def build(force=False, verbose=True, variant=None, extra=()):
-    """variant (experiments only): build libugaitnet_hip_<variant>.so with `extra` compiler flags into its own object directory;
+def with_h2():
+    return os.environ.get("UGN_BUILD_H2", "0") not in ("", "0")
+
+
+def build(force=False, verbose=True, variant=None, extra=(), h2=None):
+    """h2: also build the opt-in f16x2 set (None: what UGN_BUILD_H2 says; default off).
+    variant (experiments only): build libugaitnet_hip_<variant>.so with `extra` compiler flags into its own object directory;
     ugaitnet_amd._lib loads it when UGN_LIB names it (tools/ab_ops.py times two builds side by side on one GPU box)."""
     objdir = OBJ if variant is None else OBJ + "_" + variant
     LIB = globals()["LIB"] if variant is None else os.path.join(HERE, "libugaitnet_hip_%s.so" % variant)
@@ -78,13 +98,21 @@ def build(force=False, verbose=True, variant=None, extra=()):
     all_headers = sorted(set(HEADERS + glob.glob(os.path.join(CSRC, "*.h"))))
     hdr_hit = any(word(m, open(h).read()) for h in all_headers for m in macros)
 
+    h2 = with_h2() if h2 is None else bool(h2)
+    sources = (H2_SOURCES + SOURCES) if h2 else SOURCES
+
     def one(src):
+        if "@" in src:                        # one part of a source compiled in several objects
+            name, part = src.split("@")
+            return _compile(name, objdir if variant is not None else OBJ, tuple(extra) + ("-DUGN_C3_PART=" + part,), suffix="_p" + part)
+        if h2 and src in H2_FLAGGED:         # (an object of its own name: toggling the option recompiles nothing)
+            return _compile(src, objdir, tuple(extra) + ("-DUGN_WITH_H2=1",), suffix="_h2")
         if variant is not None and macros and len(macros) == len(list(extra)) and not hdr_hit:
             if not any(word(m, open(os.path.join(CSRC, src)).read()) for m in macros):
                 return _compile(src, OBJ, ())
         return _compile(src, objdir, extra)
-    with ThreadPoolExecutor(max_workers=4) as ex:
-        res = list(ex.map(one, SOURCES))
+    with ThreadPoolExecutor(max_workers=int(os.environ.get("UGN_BUILD_JOBS", "6"))) as ex:
+        res = list(ex.map(one, sources))
     objs = [o for o, _ in res]
     # the library records the digests of the objects it was linked from: an unchanged tree links nothing, anything else re-links
     link_want = "\n".join(open(o + ".sha256").read().strip() for o in objs)
@@ -105,8 +133,9 @@ def build(force=False, verbose=True, variant=None, extra=()):
 
 
 if __name__ == "__main__":
-    args = [a for a in sys.argv[1:] if a != "--force"]
+    args = [a for a in sys.argv[1:] if a not in ("--force", "--h2")]
+    h2 = True if "--h2" in sys.argv else None
     if args and args[0] == "--variant":      # python -m ugaitnet_amd.build --variant NAME -DFLAG ...
-        build(force="--force" in sys.argv, variant=args[1], extra=args[2:])
+        build(force="--force" in sys.argv, variant=args[1], extra=args[2:], h2=h2)
     else:
-        build(force="--force" in sys.argv)
+        build(force="--force" in sys.argv, h2=h2)

@@ -39,6 +39,7 @@ class Settings:
     fuse_w5: bool = False            # UGN_FUSE_W5=1 (h2): a2 data gradient fused with the 5x5 weight gradient (measured slower)
     c5_x3: bool = True               # UGN_C5_X3=0: the first layer of the x3 set on the fp32 MFMA instead of the x3 arithmetic (A/B)
     persistent_wgs: int = 0          # UGN_PERSISTENT_WGS: CUs the persistent launches occupy (0 = all; the library's one global)
+    precision_named: bool = False    # the arithmetic was NAMED (UGN_CONV_PRECISION set, or GaitCore(conv_precision=...)): never replaced
 
     @classmethod
     def from_env(cls, env=None):
@@ -49,7 +50,8 @@ class Settings:
                 branch_streams=e.get("UGN_BSTREAMS", "0") == "1", fwd_streams=int(e.get("UGN_FSTREAMS", "2")),
                 pack_on_side_stream=on("UGN_PACK_SIDE"), merge_modalities=on("UGN_MERGE"), ar_overlap=e.get("UGN_AR_OVERLAP", "0") == "1",
                 head_side=e.get("UGN_HEAD_SIDE", "1") == "1", routed=e.get("UGN_ROUTED", "0") == "1", gate_norm_fused=on("UGN_GATE_NORM_FUSED"),
-                set_routed=on("UGN_SET_ROUTED"), fuse_w5=on("UGN_FUSE_W5", "0"), c5_x3=on("UGN_C5_X3"), persistent_wgs=int(e.get("UGN_PERSISTENT_WGS", "0") or 0))
+                set_routed=on("UGN_SET_ROUTED"), fuse_w5=on("UGN_FUSE_W5", "0"), c5_x3=on("UGN_C5_X3"), persistent_wgs=int(e.get("UGN_PERSISTENT_WGS", "0") or 0),
+                precision_named="UGN_CONV_PRECISION" in e)
         return s.normalised()
 
     def normalised(self):
@@ -59,6 +61,21 @@ class Settings:
 
     def replace(self, **kw):
         return dataclasses.replace(self, **kw).normalised()
+
+    def x3_ok(self):
+        """the default arithmetic ("f32x3") runs on the merged one-launch-per-layer path with the first layer's sign bits"""
+        return self.merged_ok() and self.a1_sign_bits
+
+    def resolve_precision(self, named=None):
+        """The arithmetic a core gets: `named` (GaitCore(conv_precision=...)) or this object's.  The x3 set needs the merged path; when the
+        launch switches exclude it (UGN_WINO=0, UGN_PAIR=0, UGN_MERGE=0, UGN_A1_BITS=0, UGN_ROUTED=1 -- the A/B switches of the fp32
+        kernel sets) and NOBODY named an arithmetic, the core falls back to "f32", the set those switches belong to, with a warning; a
+        NAMED "f32x3" with such switches is an error (`UGN_WINO=0 python mains/...` used to die at construction)."""
+        if named is not None:
+            return named, False
+        if self.conv_precision == "f32x3" and not self.precision_named and not self.x3_ok():
+            return "f32", True
+        return self.conv_precision, False
 
     def merged_ok(self):
         """one launch per layer for all modalities is available on the default Winograd pair-launch path"""

@@ -47,7 +47,47 @@ __global__ __launch_bounds__(256) void assemble_kernel(const T* __restrict__ raw
   }
 }
 
+// Row gather / scatter of the mask-skipping step (GaitCore(skip_masked=True)): a modality's encoder runs on the clips whose flag is 1
+// only, so their rows are gathered into a dense batch on the way in and the branch outputs / gradients scattered back on the way out.
+// t is [outer][rows][row_floats] fp32 (outer = 1 for the clip tensors, 62 for the [62,B,256] features); pure byte-moving, 16 bytes per
+// lane, one workgroup per (outer, gathered row) striding over the row.
+template <bool SCATTER>
+__global__ __launch_bounds__(256) void move_rows_kernel(const float4* __restrict__ src, float4* __restrict__ dst,
+                                                        const int64_t* __restrict__ idx, int nidx, int src_rows, int dst_rows, size_t row_f4) {
+  const int o = blockIdx.y, i = blockIdx.x;
+  const int64_t r = idx[i];
+  const float4* s = src + ((size_t)o * src_rows + (SCATTER ? (size_t)i : (size_t)r)) * row_f4;
+  float4* d = dst + ((size_t)o * dst_rows + (SCATTER ? (size_t)r : (size_t)i)) * row_f4;
+  for (size_t e = threadIdx.x; e < row_f4; e += 256) d[e] = s[e];
+}
+
 }  // namespace
+
+static int move_rows(const float* src, const int64_t* idx, float* dst, int outer, int src_rows, int dst_rows, int nidx, size_t row_floats,
+                     bool scatter, void* stream, const char* what) {
+  UGN_REQUIRE(src && idx && dst && outer > 0 && nidx > 0 && src_rows > 0 && dst_rows > 0, "%s: null pointer or empty shape", what);
+  UGN_REQUIRE(row_floats % 4 == 0 && (((uintptr_t)src | (uintptr_t)dst) & 15) == 0, "%s: rows must be whole, 16-byte aligned float4s", what);
+  UGN_REQUIRE(outer <= 65535, "%s: outer extent %d too large", what, outer);
+  const dim3 grid(nidx, outer), block(256);
+  if (scatter)
+    hipLaunchKernelGGL(move_rows_kernel<true>, grid, block, 0, (hipStream_t)stream, (const float4*)src, (float4*)dst, idx, nidx, src_rows,
+                       dst_rows, row_floats / 4);
+  else
+    hipLaunchKernelGGL(move_rows_kernel<false>, grid, block, 0, (hipStream_t)stream, (const float4*)src, (float4*)dst, idx, nidx, src_rows,
+                       dst_rows, row_floats / 4);
+  UGN_CHECK_LAUNCH(what);
+  return 0;
+}
+
+extern "C" int ugn_gather_rows(const float* src, const int64_t* idx, float* dst, int outer, int src_rows, int nidx, size_t row_floats,
+                               void* stream) {
+  return move_rows(src, idx, dst, outer, src_rows, nidx, nidx, row_floats, false, stream, "ugn_gather_rows");
+}
+
+extern "C" int ugn_scatter_rows(const float* src, const int64_t* idx, float* dst, int outer, int dst_rows, int nidx, size_t row_floats,
+                                void* stream) {
+  return move_rows(src, idx, dst, outer, nidx, dst_rows, nidx, row_floats, true, stream, "ugn_scatter_rows");
+}
 
 extern "C" int ugn_assemble_modality(const void* raw, int is_int16, const int32_t* src_row, int nrows, int channels,
                                      float divisor, float offset, float post_mul, float clip_max, float clip_min, float noise,

@@ -22,6 +22,9 @@
 //   partial slabs are summed by `reduce_slabs_kernel` (deterministic, no atomics).
 #include <stdlib.h>
 #include "common.h"
+#ifndef UGN_C3_PART
+#define UGN_C3_PART 0     // build.py compiles this file five times: 0 = everything but the data gradients, 1-4 = data-gradient groups
+#endif
 
 namespace {
 
@@ -770,6 +773,7 @@ int launch_wgrad(const float* in, const float* dz, const uint8_t* dz_idx, float*
 
 }  // namespace
 
+#if UGN_C3_PART == 0
 extern "C" int ugn_pack3x3(const float* w_hwio, float* w_packed, int cin, int cout, void* stream) {
   UGN_REQUIRE(w_hwio && w_packed && cin > 0 && cout > 0, "ugn_pack3x3: bad arguments");
   const int total = 9 * cin * cout;
@@ -803,27 +807,73 @@ extern "C" int ugn_conv3x3_fwd(const float* in, const float* wp, float* out, uin
   UGN_REQUIRE(false, "ugn_conv3x3_fwd: unsupported shape cin=%d cout=%d hw=%d pool=%d", cin, cout, hw, pool);
 }
 
+#endif  // UGN_C3_PART == 0 (pack, forward)
+
+// The data gradient is 48 kernel instantiations (five shapes + the resident form, eight epilogue variants each): most of this file's
+// compile time.  The file is therefore compiled as FIVE objects (build.py: -DUGN_C3_PART=0..4): part 0 holds everything but the data
+// gradients, parts 1-4 one group of data-gradient shapes each behind ugn_c3::dgrad_part<k>.
+namespace ugn_c3 {
+int dgrad_part1(const float* dz, const uint8_t* dz_idx, const float* w, const float* act, const float* addend, float* out, float* raw_out,
+                int n, int hw, int cin, int cout, hipStream_t st);
+int dgrad_part2(const float* dz, const uint8_t* dz_idx, const float* w, const float* act, const float* addend, float* out, float* raw_out,
+                int n, int hw, int cin, int cout, hipStream_t st);
+int dgrad_part3(const float* dz, const uint8_t* dz_idx, const float* w, const float* act, const float* addend, float* out, float* raw_out,
+                int n, int hw, int cin, int cout, hipStream_t st);
+int dgrad_part4(const float* dz, const uint8_t* dz_idx, const float* w, const float* act, const float* addend, float* out, float* raw_out,
+                int n, int hw, int cin, int cout, hipStream_t st);
+}  // namespace ugn_c3
+
+// kernel K channels = forward cout, kernel N channels = forward cin
+#define DGR(CI_, NCW_, CO_, HW_, TH_, U_)                                                                 \
+  if (cin == CI_ && cout == CO_ && hw == HW_ && unpool == U_)                                                \
+    return launch_dgrad<CO_, CI_, NCW_, HW_, TH_, U_>(dz, dz_idx, w, out, act, addend, raw_out, n, st);
+#if UGN_C3_PART == 1
+int ugn_c3::dgrad_part1(const float* dz, const uint8_t* dz_idx, const float* w, const float* act, const float* addend, float* out,
+                        float* raw_out, int n, int hw, int cin, int cout, hipStream_t st) {
+  if (ugn_resident_enabled()) return launch_resident_dgrad<32, 64, 16, 1>(dz, dz_idx, w, out, act, addend, raw_out, n, st);
+  return dgrad_part4(dz, dz_idx, w, act, addend, out, raw_out, n, hw, cin, cout, st);
+}
+#elif UGN_C3_PART == 4
+int ugn_c3::dgrad_part4(const float* dz, const uint8_t* dz_idx, const float* w, const float* act, const float* addend, float* out,
+                        float* raw_out, int n, int hw, int cin, int cout, hipStream_t st) {
+  const int unpool = dz_idx != nullptr;
+  DGR(32, 32, 32, 64, 16, 1)    // a2, the non-resident form (UGN_RESIDENT=0)
+  return UGN_EINVAL;
+}
+#elif UGN_C3_PART == 2
+int ugn_c3::dgrad_part2(const float* dz, const uint8_t* dz_idx, const float* w, const float* act, const float* addend, float* out,
+                        float* raw_out, int n, int hw, int cin, int cout, hipStream_t st) {
+  const int unpool = dz_idx != nullptr;
+  DGR(32, 32, 64, 32, 16, 0)    // a3, b1
+  DGR(64, 64, 64, 32, 16, 1)    // a4, b2
+  return UGN_EINVAL;
+}
+#elif UGN_C3_PART == 3
+int ugn_c3::dgrad_part3(const float* dz, const uint8_t* dz_idx, const float* w, const float* act, const float* addend, float* out,
+                        float* raw_out, int n, int hw, int cin, int cout, hipStream_t st) {
+  const int unpool = dz_idx != nullptr;
+  DGR(64, 32, 128, 16, 8, 0)    // a5, b3 : 8x16 tiles x 2 channel halves -> 2400 items / 600 frames
+  DGR(128, 64, 128, 16, 8, 0)   // a6, b4
+  return UGN_EINVAL;
+}
+#else
 extern "C" int ugn_conv3x3_dgrad(const float* dz, const uint8_t* dz_idx, const float* w, const float* act,
                                  const float* addend, float* out, float* raw_out, int n, int hw, int cin, int cout,
                                  void* stream) {
   UGN_REQUIRE(dz && w && out && n > 0, "ugn_conv3x3_dgrad: null pointer or n <= 0");
   hipStream_t st = (hipStream_t)stream;
   const int unpool = dz_idx != nullptr;
-  if (ugn_resident_enabled() && cin == 32 && cout == 32 && hw == 64 && unpool)
-    return launch_resident_dgrad<32, 64, 16, 1>(dz, dz_idx, w, out, act, addend, raw_out, n, st);
-  // kernel K channels = forward cout, kernel N channels = forward cin
-#define DGR(CI_, NCW_, CO_, HW_, TH_, U_)                                                                 \
-  if (cin == CI_ && cout == CO_ && hw == HW_ && unpool == U_)                                                \
-    return launch_dgrad<CO_, CI_, NCW_, HW_, TH_, U_>(dz, dz_idx, w, out, act, addend, raw_out, n, st);
-  DGR(32, 32, 32, 64, 16, 1)    // a2
-  DGR(32, 32, 64, 32, 16, 0)    // a3, b1
-  DGR(64, 64, 64, 32, 16, 1)    // a4, b2
-  DGR(64, 32, 128, 16, 8, 0)    // a5, b3 : 8x16 tiles x 2 channel halves -> 2400 items / 600 frames
-  DGR(128, 64, 128, 16, 8, 0)   // a6, b4
-#undef DGR
+  if (cin == 32 && cout == 32 && hw == 64 && unpool) return ugn_c3::dgrad_part1(dz, dz_idx, w, act, addend, out, raw_out, n, hw, cin, cout, st);
+  if (hw == 32 && ((cin == 32 && cout == 64 && !unpool) || (cin == 64 && cout == 64 && unpool)))
+    return ugn_c3::dgrad_part2(dz, dz_idx, w, act, addend, out, raw_out, n, hw, cin, cout, st);
+  if (hw == 16 && cout == 128 && (cin == 64 || cin == 128) && !unpool)
+    return ugn_c3::dgrad_part3(dz, dz_idx, w, act, addend, out, raw_out, n, hw, cin, cout, st);
   UGN_REQUIRE(false, "ugn_conv3x3_dgrad: unsupported shape cin=%d cout=%d hw=%d unpool=%d", cin, cout, hw, unpool);
 }
+#endif
+#undef DGR
 
+#if UGN_C3_PART == 0
 static bool wgrad_cfg(int hw, int cin, int cout, int* coc) {
   if ((hw == 64 && cin == 32 && cout == 32) || (hw == 32 && cin == 32 && cout == 64) ||
       (hw == 32 && cin == 64 && cout == 64) || (hw == 16 && cin == 64 && cout == 128) ||
@@ -860,3 +910,4 @@ extern "C" int ugn_conv3x3_wgrad(const float* in, const float* dz, const uint8_t
 #undef WGR
   UGN_REQUIRE(false, "ugn_conv3x3_wgrad: unsupported shape cin=%d cout=%d hw=%d unpool=%d", cin, cout, hw, unpool);
 }
+#endif  // UGN_C3_PART == 0

@@ -22,6 +22,7 @@
 // -- axis-aligned flats and diagonal edges alike -- routes to the first maximum like TF's MaxPoolGrad.
 #include <stdlib.h>
 #include "mm_common.h"
+#include "../../include/ugaitnet_hip_h2.h"
 
 using namespace ugn_mm;
 
@@ -2120,10 +2121,8 @@ __global__ __launch_bounds__(256) void w5_reduce_kernel(const W5Reduce rt, int n
   rt.dw[j][e] = ldexpf(sum, -rt.scale[j]->e);
 }
 
-// Persistent workgroups of the forward / data-gradient launches (one per CU by default).  Under data parallelism RCCL's channels
-// need CUs of their own while the backward pass still runs: ugn_set_persistent_wgs(n < 256) leaves 256 - n of them free.  Results
-// do not depend on it (an item's arithmetic is the same whichever workgroup runs it).
-int g_persistent_wgs = kGrid;
+// (the persistent grid: ugn_set_persistent_wgs, runtime.cpp)
+#define g_persistent_wgs (ugn_mm::persistent_wgs())
 
 template <int KC, int NC, int HW, int IN_POOLED, int EPI>
 int launch_mm(const MmJob* jobs, const int* n, int njobs, hipStream_t st) {
@@ -2306,17 +2305,7 @@ __global__ void h2_decode_kernel(const uint16_t* __restrict__ y, const H2Meta* m
 
 }  // namespace
 
-int ugn_mm::persistent_wgs() { return g_persistent_wgs; }
-
-const void* ugn_mm::zero_block() {
-  static void* z = nullptr;
-  if (!z) {
-    void* p = nullptr;
-    if (hipMalloc(&p, 256) != hipSuccess || hipMemset(p, 0, 256) != hipSuccess) return nullptr;
-    z = p;
-  }
-  return z;
-}
+// (ugn_mm::persistent_wgs, ugn_mm::zero_block and ugn_set_persistent_wgs: runtime.cpp -- every kernel set uses them)
 
 #ifdef UGN_MM_STAMP
 extern "C" int ugn_mm_debug_stamps(void* buf) {
@@ -2373,12 +2362,6 @@ extern "C" int ugn_mm_dgrad32_wgrad5_multi(const uint16_t* const* dz, const void
   UGN_CHECK_LAUNCH("dgrad32_w5");
   hipLaunchKernelGGL(w5_reduce_kernel, dim3((50 * 32 + 255) / 256, njobs), dim3(256), 0, st, rt, kGrid);
   UGN_CHECK_LAUNCH("w5_reduce");
-  return 0;
-}
-
-extern "C" int ugn_set_persistent_wgs(int n) {
-  UGN_REQUIRE(n == 0 || (n >= 8 && n <= kGrid), "ugn_set_persistent_wgs: 8..%d workgroups, or 0 for the default (got %d)", kGrid, n);
-  g_persistent_wgs = n == 0 ? kGrid : n;
   return 0;
 }
 

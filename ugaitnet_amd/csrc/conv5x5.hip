@@ -16,6 +16,12 @@ using ugn_mm::H2Meta;
 #ifndef UGN_C5_WAVES
 #define UGN_C5_WAVES 4     // waves per SIMD the forward kernel is compiled for (measured: 4 and 6 equal, 8 spills)
 #endif
+#ifndef UGN_WITH_H2
+#define UGN_WITH_H2 0     // 1: also build the entry points of the opt-in f16x2 set (build.py --h2)
+#endif
+#if UGN_WITH_H2
+#include "../../include/ugaitnet_hip_h2.h"
+#endif
 #ifndef UGN_C5_H2MM
 #define UGN_C5_H2MM 1     // H2 output: multiply on the f16 matrix pipe (x and w split into f16 halves on the fly) instead of the fp32 MFMA
 #endif
@@ -692,6 +698,7 @@ extern "C" int ugn_x3_conv5x5_in_fwd(const float* x, const float* w, float* a1, 
   return 0;
 }
 
+#if UGN_WITH_H2      /* the opt-in f16x2 set (python -m ugaitnet_amd.build --h2): not part of the default library */
 /* the same layer with a1 as an H2 tensor [n][64][64][2][32] (+ its ugn_h2meta, zero on entry); x_meta = {0, bits(max|x|)} */
 extern "C" int ugn_conv5x5_in_fwd_h2(const float* x, const void* x_meta, const float* w, uint16_t* a1, void* a1_meta,
                                      uint32_t* a1_sign, int n, int cin, void* stream) {
@@ -713,6 +720,7 @@ extern "C" int ugn_conv5x5_in_fwd_h2(const float* x, const void* x_meta, const f
   UGN_CHECK_LAUNCH("conv5x5_fwd_h2");
   return 0;
 }
+#endif
 
 extern "C" size_t ugn_conv5x5_in_wgrad_ws(int n, int cin) {
   if (n <= 0 || (cin != 1 && cin != 2)) return 0;
@@ -733,6 +741,7 @@ extern "C" int ugn_conv5x5_in_wgrad(const float* x, const float* dz1, const uint
                                     void* ws, size_t ws_bytes, void* stream) {
   return conv5x5_wgrad_any(x, dz1, nullptr, a1_sign, dw, n, cin, ws, ws_bytes, stream);
 }
+#if UGN_WITH_H2
 /* dz1 as an H2 tensor [n][64][64][2][32] with its ugn_h2meta */
 extern "C" int ugn_conv5x5_in_wgrad_h2(const float* x, const uint16_t* dz1, const void* dz1_meta, const uint32_t* a1_sign, float* dw,
                                        int n, int cin, void* ws, size_t ws_bytes, void* stream) {
@@ -746,6 +755,7 @@ extern "C" int ugn_conv5x5_in_wgrad_h2x(const float* x, const void* x_meta, cons
   return conv5x5_wgrad_any(x, reinterpret_cast<const float*>(dz1), (const H2Meta*)dz1_meta, a1_sign, dw, n, cin, ws, ws_bytes, stream,
                            false, (const H2Meta*)x_meta);
 }
+#endif
 /* dz1 as a bf16 tensor [n][64][64][32] (configs[4]) */
 extern "C" int ugn_conv5x5_in_wgrad_bf(const float* x, const uint16_t* dz1, const uint32_t* a1_sign, float* dw, int n, int cin, void* ws,
                                        size_t ws_bytes, void* stream) {
@@ -789,22 +799,40 @@ static int conv5x5_wgrad_any(const float* x, const float* dz1, const H2Meta* dz_
   const int lds = (2 * 256 * UGN_C5_DS + 2 * ((20 * c5_pitch(cin) * cin + 63) / 64) * 64 + 2 * 256) * 4;
   static bool attr_done[3] = {false, false, false};
   if (!attr_done[cin]) {
-    const void* fns[20] = {(const void*)conv5x5_wgrad_kernel<1, false>, (const void*)conv5x5_wgrad_kernel<1, true>,
-                           (const void*)conv5x5_wgrad_kernel<1, false, 1>, (const void*)conv5x5_wgrad_kernel<1, true, 1>,
-                           (const void*)conv5x5_wgrad_kernel<1, false, 2>, (const void*)conv5x5_wgrad_kernel<1, true, 2>,
-                           (const void*)conv5x5_wgrad_kernel<1, false, 3>, (const void*)conv5x5_wgrad_kernel<1, true, 3>,
-                           (const void*)conv5x5_wgrad_kernel<1, false, 4>, (const void*)conv5x5_wgrad_kernel<1, true, 4>,
-                           (const void*)conv5x5_wgrad_kernel<2, false>, (const void*)conv5x5_wgrad_kernel<2, true>,
-                           (const void*)conv5x5_wgrad_kernel<2, false, 1>, (const void*)conv5x5_wgrad_kernel<2, true, 1>,
-                           (const void*)conv5x5_wgrad_kernel<2, false, 2>, (const void*)conv5x5_wgrad_kernel<2, true, 2>,
-                           (const void*)conv5x5_wgrad_kernel<2, false, 3>, (const void*)conv5x5_wgrad_kernel<2, true, 3>,
-                           (const void*)conv5x5_wgrad_kernel<2, false, 4>, (const void*)conv5x5_wgrad_kernel<2, true, 4>};
-    for (int v = 0; v < 10; ++v) {
-      hipError_t e = hipFuncSetAttribute(fns[(cin - 1) * 10 + v], hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    // (DZFMT 1 and 3, the f16x2 forms, exist only in a build with the opt-in set)
+    const void* fns[] = {(const void*)conv5x5_wgrad_kernel<1, false>, (const void*)conv5x5_wgrad_kernel<1, true>,
+                         (const void*)conv5x5_wgrad_kernel<1, false, 2>, (const void*)conv5x5_wgrad_kernel<1, true, 2>,
+                         (const void*)conv5x5_wgrad_kernel<1, false, 4>, (const void*)conv5x5_wgrad_kernel<1, true, 4>,
+#if UGN_WITH_H2
+                         (const void*)conv5x5_wgrad_kernel<1, false, 1>, (const void*)conv5x5_wgrad_kernel<1, true, 1>,
+                         (const void*)conv5x5_wgrad_kernel<1, false, 3>, (const void*)conv5x5_wgrad_kernel<1, true, 3>,
+#endif
+                         (const void*)conv5x5_wgrad_kernel<2, false>, (const void*)conv5x5_wgrad_kernel<2, true>,
+                         (const void*)conv5x5_wgrad_kernel<2, false, 2>, (const void*)conv5x5_wgrad_kernel<2, true, 2>,
+                         (const void*)conv5x5_wgrad_kernel<2, false, 4>, (const void*)conv5x5_wgrad_kernel<2, true, 4>,
+#if UGN_WITH_H2
+                         (const void*)conv5x5_wgrad_kernel<2, false, 1>, (const void*)conv5x5_wgrad_kernel<2, true, 1>,
+                         (const void*)conv5x5_wgrad_kernel<2, false, 3>, (const void*)conv5x5_wgrad_kernel<2, true, 3>,
+#endif
+    };
+    constexpr int NV = (int)(sizeof(fns) / sizeof(fns[0])) / 2;
+    for (int v = 0; v < NV; ++v) {
+      hipError_t e = hipFuncSetAttribute(fns[(cin - 1) * NV + v], hipFuncAttributeMaxDynamicSharedMemorySize, lds);
       UGN_REQUIRE(e == hipSuccess, "ugn_conv5x5_in_wgrad: hipFuncSetAttribute: %s", hipGetErrorString(e));
     }
     attr_done[cin] = true;
   }
+#if UGN_WITH_H2
+#define UGN_C5W_H2(C_, S_)                                                                                                   \
+    else if (dz_meta && x_meta)                                                                                               \
+      hipLaunchKernelGGL((conv5x5_wgrad_kernel<C_, S_, 3>), dim3(groups), dim3(256), lds, st, x, dz1, (float*)ws,             \
+                         (const float*)zeros, a1_sign, tiles, x_meta);                                                        \
+    else if (dz_meta)                                                                                                         \
+      hipLaunchKernelGGL((conv5x5_wgrad_kernel<C_, S_, 1>), dim3(groups), dim3(256), lds, st, x, dz1, (float*)ws,             \
+                         (const float*)zeros, a1_sign, tiles);
+#else
+#define UGN_C5W_H2(C_, S_)
+#endif
 #define UGN_C5W(C_, S_)                                                                                                      \
   do {                                                                                                                        \
     if (x3)                                                                                                                   \
@@ -813,16 +841,12 @@ static int conv5x5_wgrad_any(const float* x, const float* dz1, const H2Meta* dz_
     else if (bf)                                                                                                              \
       hipLaunchKernelGGL((conv5x5_wgrad_kernel<C_, S_, 2>), dim3(groups), dim3(256), lds, st, x, dz1, (float*)ws,             \
                          (const float*)zeros, a1_sign, tiles);                                                                \
-    else if (dz_meta && x_meta)                                                                                               \
-      hipLaunchKernelGGL((conv5x5_wgrad_kernel<C_, S_, 3>), dim3(groups), dim3(256), lds, st, x, dz1, (float*)ws,             \
-                         (const float*)zeros, a1_sign, tiles, x_meta);                                                        \
-    else if (dz_meta)                                                                                                         \
-      hipLaunchKernelGGL((conv5x5_wgrad_kernel<C_, S_, 1>), dim3(groups), dim3(256), lds, st, x, dz1, (float*)ws,             \
-                         (const float*)zeros, a1_sign, tiles);                                                                \
+    UGN_C5W_H2(C_, S_)                                                                                                        \
     else                                                                                                                      \
       hipLaunchKernelGGL((conv5x5_wgrad_kernel<C_, S_>), dim3(groups), dim3(256), lds, st, x, dz1, (float*)ws,                \
                          (const float*)zeros, a1_sign, tiles);                                                                \
   } while (0)
+  UGN_REQUIRE(!dz_meta || UGN_WITH_H2, "ugn_conv5x5_in_wgrad: this library was built without the f16x2 set");
   UGN_REQUIRE(!dz_meta || UGN_C5_DS == 32, "ugn_conv5x5_in_wgrad_h2: built with a padded gradient tile");
   if (cin == 1) {
     if (a1_sign) UGN_C5W(1, true); else UGN_C5W(1, false);
@@ -830,6 +854,7 @@ static int conv5x5_wgrad_any(const float* x, const float* dz1, const H2Meta* dz_
     if (a1_sign) UGN_C5W(2, true); else UGN_C5W(2, false);
   }
 #undef UGN_C5W
+#undef UGN_C5W_H2
   UGN_CHECK_LAUNCH("conv5x5_wgrad");
   const int nelem = 25 * cin * 32;
   hipLaunchKernelGGL(reduce5_kernel, dim3((nelem + 7) / 8), dim3(256), 0, st, (const float*)ws, dw, nelem, groups, dz_meta);

@@ -7,6 +7,7 @@
 // A stored value v = H + L is an fp32 number with 22 significant bits, and splitting v again returns halves with the same
 // sum (|L| <= ulp(H) / 2), so the kernels work on v in fp32 and re-split what they write.
 #include "mm_common.h"
+#include "../../include/ugaitnet_hip_h2.h"
 
 using namespace ugn_mm;
 

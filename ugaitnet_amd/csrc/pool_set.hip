@@ -556,11 +556,17 @@ extern "C" int ugn_hpp_bwd_multi(const float* const* a, const float* const* s3, 
 /* the same with b4 held as an H2 tensor [b][16][16][2][128] (only its sign is used); dm3 / dzb4 stay fp32 */
 static int hpp_bwd_b4fmt(const float* const* a, const float* const* s3, const uint16_t* const* b4, const float* const* dfeat,
                          float* const* dm3, float* const* dzb4, const int* b, int njobs, void* stream, bool bf);
+#ifndef UGN_WITH_H2
+#define UGN_WITH_H2 0
+#endif
+#if UGN_WITH_H2      /* entry point of the opt-in f16x2 set (build.py --h2) */
+#include "../../include/ugaitnet_hip_h2.h"
 extern "C" int ugn_hpp_bwd_b4h2_multi(const float* const* a, const float* const* s3, const uint16_t* const* b4,
                                       const float* const* dfeat, float* const* dm3, float* const* dzb4, const int* b, int njobs,
                                       void* stream) {
   return hpp_bwd_b4fmt(a, s3, b4, dfeat, dm3, dzb4, b, njobs, stream, false);
 }
+#endif
 /* the same with b4 as a bf16 tensor [b][16][16][128] */
 extern "C" int ugn_hpp_bwd_b4bf_multi(const float* const* a, const float* const* s3, const uint16_t* const* b4,
                                       const float* const* dfeat, float* const* dm3, float* const* dzb4, const int* b, int njobs,

@@ -20,6 +20,7 @@
 //     matrix pipe, v_smfmac_f32_16x16x64_f16 (SP = 1; 16-row strips): MaxPool backward is 2:4 sparse along a pixel row and the
 //     compressed operand is the pooled gradient as stored -- see the SP branch of the strip loop.
 #include "mm_common.h"
+#include "../../include/ugaitnet_hip_h2.h"
 
 using namespace ugn_mm;
 

@@ -18,9 +18,10 @@ import torch
 import contextlib
 import os
 
-from . import _lib, dp, h2, ops, x3
+from . import _lib, dp, ops, x3
 from .engine_bf import BFState, backward_bf, forward_bf
-from .engine_h2 import H2State, backward_h2, forward_h2
+# (the opt-in f16x2 set -- ugaitnet_amd/h2.py, engine_h2.py -- is imported where conv_precision="h2" asks for it: the default library
+#  is built without its kernels, python -m ugaitnet_amd.build --h2 adds them)
 
 F32 = torch.float32
 
@@ -590,7 +591,12 @@ class GaitCore:
         # between the 3x3 layers held as split-fp16 halves + block exponent, 3x3 layers on the f16 matrix pipe at fp32-class
         # accuracy (engine_h2.py, csrc/mm_common.h)
         base = DEFAULTS if config is None else config
-        conv_precision = base.conv_precision if conv_precision is None else conv_precision
+        conv_precision, fell_back = base.resolve_precision(conv_precision)
+        if fell_back:
+            import warnings
+            warnings.warn("ugaitnet_amd: UGN_WINO / UGN_PAIR / UGN_MERGE / UGN_A1_BITS / UGN_ROUTED exclude the merged launch path the default "
+                          "arithmetic 'f32x3' runs on; no arithmetic was named, so this model uses conv_precision='f32' (the fp32-MFMA sets "
+                          "those switches select between).  Name one (UGN_CONV_PRECISION / conv_precision=) to silence this.")
         # this core's OWN copy of the settings (ugaitnet_amd/config.py) and its own streams: nothing process-wide
         self.cfg = base.replace(conv_precision=conv_precision)
         self.launch = _Launch(self.cfg, self.device)
@@ -600,9 +606,10 @@ class GaitCore:
         self.h2 = conv_precision == "h2"
         self.bf = conv_precision == "bf16"
         self.x3 = conv_precision == "f32x3"
-        if self.x3 and not (self.cfg.merged_ok() and self.cfg.a1_sign_bits):
+        if self.x3 and not self.cfg.x3_ok():
             raise ValueError("conv_precision='f32x3' runs on the merged one-launch-per-layer path (UGN_WINO / UGN_PAIR / UGN_MERGE / "
-                             "UGN_A1_BITS at their defaults, UGN_ROUTED off)")
+                             "UGN_A1_BITS at their defaults, UGN_ROUTED off); those switches select between the fp32-MFMA kernel sets: "
+                             "use them with conv_precision='f32' (UGN_CONV_PRECISION=f32)")
         if (self.h2 or self.bf or self.x3) and self.nmod > 3:
             # one launch per layer carries the frame-level layer and the set-level twin of EVERY modality as jobs, and the kernels'
             # job tables hold 6 (csrc/mm_common.h kMaxJobs; h2_elem.hip / bf_elem.hip kJobs); the reference's graphs stop at 3
@@ -615,20 +622,22 @@ class GaitCore:
         if self.bf:
             for enc in self.encoders:
                 enc.bf = BFState(enc)
-        if self.h2 or self.bf:
-            # Settings.persistent_wgs = n (< 256): the persistent launches of the f16x2 and bf16 sets leave 256 - n CUs free -- room for
-            # RCCL's channels when the bucketed all-reduce (ar_overlap) overlaps the backward pass.  Results do not depend on it
-            # (tests/test_mm_gpu.py).  It is the library's ONE process-wide setting (ugn_set_persistent_wgs): a core that does not ask
-            # for a reduced grid sets it back to all CUs, so a later core never inherits an earlier one's grid.
-            if self.cfg.persistent_wgs:
-                h2.set_persistent_wgs(int(self.cfg.persistent_wgs))
-            elif self.world > 1 and self.cfg.ar_overlap:
-                # the bucketed all-reduce runs BESIDE the rest of the backward pass: leave RCCL's channels 32 of the 256 CUs
-                # (unmeasured on multi-GPU hardware: Settings.persistent_wgs overrides)
-                h2.set_persistent_wgs(224)
-            else:
-                h2.set_persistent_wgs(0)
         if self.h2:
+            _lib.require_h2("GaitCore(conv_precision='h2')")
+        # Settings.persistent_wgs = n (< 256): the persistent launches of EVERY 3x3 set (x3, bf16, f16x2: forward, data gradient, the
+        # 5x5 forward; the bf16 / f16x2 weight gradients; the x3 weight gradients keep their 256 fixed shares -- include/ugaitnet_hip.h)
+        # leave 256 - n CUs free: room for RCCL's channels when the bucketed all-reduce (ar_overlap) overlaps the backward pass.
+        # Results do not depend on it (tests/test_x3_gpu.py).  It is the library's ONE process-wide setting (ugn_set_persistent_wgs):
+        # a core that does not ask for a reduced grid sets it back to all CUs, so a later core never inherits an earlier one's grid
+        # (round 6: the default x3 arithmetic is covered too -- ADVICE r05).
+        if self.h2 or self.bf or self.x3:
+            self.persistent_wgs = self.grid_for(self.cfg, self.world)
+            ops.set_persistent_wgs(self.persistent_wgs)
+        else:
+            self.persistent_wgs = 0      # (Winograd fp32-MFMA set: its launches are not persistent)
+        if self.h2:
+            from . import h2
+            from .engine_h2 import H2State
             self.meta_pool = h2.MetaPool(self.device, 64 * self.nmod)
             for enc in self.encoders:
                 enc.h2 = H2State(enc, self.meta_pool)
@@ -651,6 +660,15 @@ class GaitCore:
         self._buckets = list(zip(starts, ends))
         self._ar_pending = None     # work handles of the bucket all-reduces of the current step
         self.init_weights(seed)
+
+    @staticmethod
+    def grid_for(cfg, world):
+        """Persistent workgroups per launch for these settings: Settings.persistent_wgs if set; 224 when the bucketed all-reduce runs
+        BESIDE the backward pass of more than one rank (RCCL's channels get 32 of the 256 CUs; unmeasured on multi-GPU hardware);
+        otherwise 0 = all 256."""
+        if cfg.persistent_wgs:
+            return int(cfg.persistent_wgs)
+        return 224 if (world > 1 and cfg.ar_overlap) else 0
 
     @contextlib.contextmanager
     def serial_launches(self):
@@ -698,6 +716,7 @@ class GaitCore:
 
     def _repack(self):
         if self.h2:          # f16 halves + block exponent + L1 bound of every 3x3 filter, both directions: two launches
+            from . import h2
             h2.mm_pack_multi([j for e in self.encoders for j in e.h2.pack_jobs()])
             return
         if self.bf:          # bf16 copies of the fp32 master filters in the order the kernels stream them: one launch
@@ -818,7 +837,10 @@ class GaitCore:
         merged = (self.cfg.merged_ok() and len(self.encoders) > 1) or self.h2 or self.bf or self.x3
         if self.h2:
             self.meta_pool.reset()      # every H2 meta of the step gathers its maximum from zero: one memset
-        fwd_many = forward_h2 if self.h2 else (forward_bf if self.bf else forward_merged)
+        if self.h2:
+            from .engine_h2 import forward_h2 as fwd_many
+        else:
+            fwd_many = forward_bf if self.bf else forward_merged
         if self.multimodal and self.skip_masked:
             outs, self._active = [None] * self.nmod, []
             sub = []      # (modality, rows tensor or None, input of the active clips)
@@ -835,7 +857,7 @@ class GaitCore:
                 outs[mi] = self._buf("out_full%d" % mi, (NBINS, b, HIDDEN))
                 outs[mi].zero_()
                 if len(rows):
-                    sub.append((mi, idx, x.index_select(0, idx).contiguous()))
+                    sub.append((mi, idx, ops.gather_rows(x.contiguous(), idx, 0)))
             if merged and (len(sub) > 1 or ((self.h2 or self.bf or self.x3) and sub)):
                 res = fwd_many([self.encoders[mi] for mi, _, _ in sub], [x for _, _, x in sub])
             else:
@@ -844,7 +866,7 @@ class GaitCore:
                 if idx is None:
                     outs[mi] = o
                 else:
-                    outs[mi].index_copy_(1, idx, o)
+                    ops.scatter_rows(o, idx, 1, outs[mi])
         elif merged:
             outs = fwd_many(self.encoders, xs)
         elif self.cfg.fwd_streams and len(self.encoders) > 1:
@@ -963,10 +985,14 @@ class GaitCore:
                         enc.G(name).zero_()
                 else:
                     encs.append(enc)
-                    ds.append(d.index_select(1, idx).contiguous())
+                    ds.append(ops.gather_rows(d, idx, 1))
             if self.h2 or self.bf:
                 if encs:
-                    (backward_h2 if self.h2 else backward_bf)(encs, ds, self.launch.side)
+                    if self.h2:
+                        from .engine_h2 import backward_h2 as bwd_many
+                    else:
+                        bwd_many = backward_bf
+                    bwd_many(encs, ds, self.launch.side)
             elif len(encs) > 1 or (self.x3 and encs):
                 backward_merged(encs, ds, [self.scratch.setdefault(self.encoders.index(e), {}) for e in encs])
             elif encs:
@@ -993,7 +1019,7 @@ class GaitCore:
                     for name, _ in branch_param_shapes(enc.cin):   # no active clip: this branch's gradient is exactly zero
                         enc.G(name).zero_()
                 else:
-                    enc.backward(d.index_select(1, idx).contiguous(), scratch)
+                    enc.backward(ops.gather_rows(d, idx, 1), scratch)
             self._reduce_bucket(mi)
         self.launch.join_backward_streams()
 

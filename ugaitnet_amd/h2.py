@@ -110,8 +110,9 @@ def decode(t, out=None):
 
 
 def set_persistent_wgs(n):
-    """Workgroups of the persistent forward / data-gradient launches (0 = default, one per CU): see include/ugaitnet_hip.h."""
-    _lib.check(_lib.load().ugn_set_persistent_wgs(int(n)), "ugn_set_persistent_wgs")
+    """Workgroups of the persistent forward / data-gradient launches (0 = default, one per CU): ops.set_persistent_wgs."""
+    from . import ops
+    ops.set_persistent_wgs(n)
 
 
 def absmax(x, meta):

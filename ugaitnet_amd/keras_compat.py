@@ -110,10 +110,13 @@ class _BatchPipeline:
 
     STAGED_DEPTH = 4       # batches staged ahead in HBM at most (each holds pinned host memory too); max_queue_size beyond it buys nothing
 
-    def __init__(self, gen, steps, device, depth, stage=True, ring=None, workers=1):
+    def __init__(self, gen, steps, device, depth, stage=True, ring=None, workers=1, flag_inputs=()):
         import queue
         import threading
         self.gen, self.steps, self.device, self.stage = gen, int(steps), device, stage
+        # positions of the modality-flag inputs in X (GaitSetModel: the odd ones of a multimodal model): they stay on the host, where
+        # GaitCore decides which masked (clip, modality) pairs to skip -- the model's own input split, not a guess from the shape
+        self.flag_inputs = frozenset(int(i) for i in flag_inputs)
         self.workers = max(1, int(workers)) if hasattr(gen, "__len__") else 1     # (an iterator has one consumer)
         self.q = queue.Queue(maxsize=max(1, min(int(depth), self.STAGED_DEPTH) if stage else int(depth)))
         # pinned staging buffers: queue + the batch in the step + the one being filled; the caller keeps the list across epochs
@@ -134,15 +137,18 @@ class _BatchPipeline:
         outs = []
         with torch.cuda.stream(stream):
             for k, a in enumerate(arrays):
-                if (isinstance(a, torch.Tensor) and a.is_cuda) or np.ndim(a) <= 2:
-                    # (already in HBM; or a [B, 1] modality-flag column: it stays on the host, where GaitCore decides which masked
-                    #  (clip, modality) pairs to skip -- from a device tensor that decision would synchronise with the previous step)
+                if (isinstance(a, torch.Tensor) and a.is_cuda) or k in self.flag_inputs:
+                    # (already in HBM; or a modality-flag column: it stays on the host -- from a device tensor the decision which
+                    #  masked pairs to skip would synchronise with the previous step)
                     outs.append(a)
                     continue
                 src = a.numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
-                pin = ring.get(k)
-                if pin is None or tuple(pin.shape) != tuple(src.shape):
-                    pin = ring[k] = torch.empty(tuple(src.shape), dtype=torch.float32, pin_memory=True)
+                # pinned buffers are keyed by (input, shape): pipelines that alternate batch shapes on one ring (a last, smaller batch
+                # of an epoch) never re-pin -- a fresh pinned allocation costs more than a step
+                key = (k, tuple(src.shape))
+                pin = ring.get(key)
+                if pin is None:
+                    pin = ring[key] = torch.empty(tuple(src.shape), dtype=torch.float32, pin_memory=True)
                 # one plain memcpy on this thread (numpy releases the GIL for it; converts to fp32 on the way, as GaitCore._dev would).
                 # NOT torch's copy_: its OpenMP team beside the training thread's launches cost 20 ms per batch on a 16-core share
                 np.copyto(pin.numpy(), src, casting="same_kind")
@@ -217,9 +223,12 @@ class _BatchPipeline:
                 self.q.get_nowait()
         except Exception:
             pass
-        self.thread.join(timeout=10)
+        # No timeout: the thread looks at `stop` every 0.1 s in _put and between two steps, so it ends after at most ONE fetch -- and
+        # the caller's next moves (the generator's on_epoch_end reshuffle, the next epoch's pipeline on the same pinned ring) must never
+        # run beside a fetch that is still in flight.  Fetches of the worker pool that already run are waited for as well.
+        self.thread.join()
         if getattr(self, "pool", None) is not None:
-            self.pool.shutdown(wait=False, cancel_futures=True)
+            self.pool.shutdown(wait=True, cancel_futures=True)
 
 
 class History:
@@ -379,6 +388,10 @@ class GaitSetModel:
             raise ValueError("expected %d inputs %s, got %d" % (2 * nm, self.input_names, len(X)))
         return [X[2 * i] for i in range(nm)], [X[2 * i + 1] for i in range(nm)]
 
+    def _flag_inputs(self):
+        """positions of the modality-flag inputs in X (the `use` columns: odd positions of a multimodal model, none otherwise)"""
+        return tuple(range(1, 2 * len(self.input_shapes), 2)) if self.multimodal else ()
+
     def _split_y(self, y):
         if self.nclasses:
             labels, onehot = y
@@ -438,9 +451,10 @@ class GaitSetModel:
         pipeline as in `fit` (workers=0: on this thread)."""
         n = len(generator) if steps is None else steps
         acc = {}
-        if not hasattr(self, "_pinned_ring"):
-            self._pinned_ring = []
-        feed = _BatchPipeline(generator, n, self.core.device, max_queue_size, ring=self._pinned_ring, workers=workers) if workers and workers > 0 else None
+        if not hasattr(self, "_pinned_ring_eval"):       # (a ring of its own: validation inside `fit` alternates with the training pipeline)
+            self._pinned_ring_eval = []
+        feed = _BatchPipeline(generator, n, self.core.device, max_queue_size, ring=self._pinned_ring_eval, workers=workers,
+                              flag_inputs=self._flag_inputs()) if workers and workers > 0 else None
         try:
             for i in range(n):
                 X, y = feed.get() if feed is not None else generator[i % len(generator)]
@@ -487,7 +501,8 @@ class GaitSetModel:
                 _call(callbacks, "on_batch_end", step, logs)
             if not hasattr(self, "_pinned_ring"):
                 self._pinned_ring = []
-            feed = _BatchPipeline(gen, n, self.core.device, max_queue_size, ring=self._pinned_ring, workers=workers) if workers and workers > 0 else None
+            feed = _BatchPipeline(gen, n, self.core.device, max_queue_size, ring=self._pinned_ring, workers=workers,
+                                  flag_inputs=self._flag_inputs()) if workers and workers > 0 else None
             try:
                 pending = None
                 for step in range(n):

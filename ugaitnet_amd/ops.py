@@ -633,3 +633,38 @@ def adam_step_dev(p, g, m, v, lr_t_dev, b1=0.9, b2=0.999, eps=1e-7, grad_scale=1
     """adam_step with lr_t in device memory (a 1-element fp32 tensor): capturable in a hipGraph."""
     call("ugn_adam_step_dev", ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), ptr(_chk(lr_t_dev)), float(b1), float(b2), float(eps),
          float(grad_scale), _stream())
+
+
+def gather_rows(src, idx, axis, out=None):
+    """out = src.index_select(axis, idx) for axis 0 ([B, ...] clip tensors) or 1 ([62, B, 256] features), as a HIP row copy
+    (ugn_gather_rows): the mask-skipping step's dense sub-batches.  idx: int64 device tensor."""
+    _chk(src)
+    outer = 1 if axis == 0 else src.shape[0]
+    rows = src.shape[axis]
+    row = int(np.prod(src.shape[axis + 1:]))
+    shape = list(src.shape)
+    shape[axis] = idx.numel()
+    out = torch.empty(shape, dtype=F32, device=src.device) if out is None else out
+    call("ugn_gather_rows", ptr(src), ptr(idx), ptr(out), outer, rows, idx.numel(), row, _stream())
+    return out
+
+
+def scatter_rows(src, idx, axis, dst):
+    """dst.index_copy_(axis, idx, src) as a HIP row copy (ugn_scatter_rows); rows of dst that idx does not name are left alone."""
+    _chk(src), _chk(dst)
+    outer = 1 if axis == 0 else dst.shape[0]
+    row = int(np.prod(dst.shape[axis + 1:]))
+    call("ugn_scatter_rows", ptr(src), ptr(idx), ptr(dst), outer, dst.shape[axis], idx.numel(), row, _stream())
+    return dst
+
+
+def set_persistent_wgs(n):
+    """Workgroups of the library's persistent launches (0 = default, one per CU; 8..256): the ONE process-wide launch setting,
+    see include/ugaitnet_hip.h ugn_set_persistent_wgs.  Results do not depend on it."""
+    _lib.check(_lib.load().ugn_set_persistent_wgs(int(n)), "ugn_set_persistent_wgs")
+
+
+def get_persistent_wgs():
+    """The persistent grid in force (8..256)."""
+    return int(_lib.load().ugn_get_persistent_wgs())
+
