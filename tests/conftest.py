@@ -10,6 +10,7 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "h2: needs a library built with the opt-in f16x2 kernel set (python -m ugaitnet_amd.build --h2)")
 
 
 FULLSIZE = "test_fullsize_parity_gpu"
@@ -17,8 +18,7 @@ FULLSIZE = "test_fullsize_parity_gpu"
 
 def pytest_collection_modifyitems(config, items):
     """Without a GPU every test that carries the `gpu` marker is skipped, whether or not it takes the `dev` fixture.
-    With one: the full-size parity tests go to the END of the session -- their fp64 oracle evaluations (host cores only) run on a
-    child process from the session's start, beside the other GPU tests (`_oracle_ahead` below)."""
+    With one: the full-size parity tests are placed inside the session so that their fp64 evaluations overlap the other GPU tests."""
     import re
     import torch
     if torch.cuda.is_available():
@@ -28,9 +28,19 @@ def pytest_collection_modifyitems(config, items):
         if not _lib.has_h2():
             no_h2 = pytest.mark.skip(reason="libugaitnet_hip.so was built without the opt-in f16x2 set (build --h2)")
             for item in items:
-                if re.search(r"test_mm_gpu\.py|test_h2_elem_gpu\.py|h2|f16x2", item.nodeid):
+                if "h2" in item.keywords or re.search(r"test_mm_gpu\.py|test_h2_elem_gpu\.py|h2|f16x2", item.nodeid):
                     item.add_marker(no_h2)
-        items[:] = [i for i in items if FULLSIZE not in i.nodeid] + [i for i in items if FULLSIZE in i.nodeid]
+        # The full-size parity cases run INSIDE the session, not first: their fp64 oracle evaluations (host cores only) run on a child
+        # process from the session's start (`_oracle_ahead` below), and the forced-routing evaluations of the default-arithmetic cases
+        # (20-110 s of fp64 each, one at a time on a background thread) run beside the tests that follow them.  Order: 40 % of the
+        # other tests | C3, C2 | the rest of the other tests | C4 and the other arithmetics | the test that joins the forced evaluations.
+        full = [i for i in items if FULLSIZE in i.nodeid]
+        rest = [i for i in items if FULLSIZE not in i.nodeid]
+        early = [i for i in full if hasattr(i, "callspec") and i.callspec.params.get("name") in ("C3", "C2")]
+        join = [i for i in full if "forced_to_the_hip_routing" in i.nodeid]
+        late = [i for i in full if i not in early and i not in join]
+        cut = (2 * len(rest)) // 5 if early else len(rest)
+        items[:] = rest[:cut] + early + rest[cut:] + late + join
         return
     skip = pytest.mark.skip(reason="no GPU visible (gpu-marked test)")
     for item in items:

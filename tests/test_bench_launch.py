@@ -12,6 +12,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BENCH = os.path.join(ROOT, "bench.py")
 
 
+def _backend(world=2):
+    """RCCL with one rank per GPU where the box has a GPU per rank, else the gloo rehearsal on the box's one GPU"""
+    return "nccl" if torch.cuda.device_count() >= world else "gloo"
+
+
 def _env(**kw):
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env.update(kw)
@@ -38,14 +43,14 @@ def test_world_size_must_match_gpus():
 def test_bench_spawns_its_own_ranks(dev):
     """`python bench.py --gpus 2` alone (gloo rehearsal: both ranks share the box's GPU) prints ONE line with n_gpus 2."""
     r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--dense-only",
-                        "--clips-per-gpu", "4", "--no-roofline-pass"], env=_env(UGN_DIST_BACKEND="gloo"), capture_output=True,
+                        "--clips-per-gpu", "4", "--no-roofline-pass"], env=_env(UGN_DIST_BACKEND=_backend()), capture_output=True,
                        text=True, timeout=800)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "dp2" and d["config"]["distributed"]["world_size"] == 2
-    assert d["config"]["distributed"]["backend"] == "gloo" and d["value"] > 0
+    assert d["config"]["distributed"]["backend"] == _backend() and d["value"] > 0
     cm = d["config"]["distributed"]["collectives_ms_per_step"]          # every rank's view: max / min over the two ranks
     assert "allreduce_grad_ms" in cm and cm["allreduce_grad_ms"]["max_over_ranks"] >= cm["allreduce_grad_ms"]["min_over_ranks"] > 0
 
@@ -55,7 +60,7 @@ def test_bench_spawns_its_own_ranks(dev):
 def test_strong_scaling_splits_the_c4_batch(dev):
     """--workload c4 --scaling strong with 2 ranks: 20 clips per rank, losses on the gathered 40-clip batch."""
     r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--workload", "c4", "--scaling", "strong", "--steps", "1", "--warmup",
-                        "1", "--no-cpu-baseline", "--dense-only", "--no-roofline-pass"], env=_env(UGN_DIST_BACKEND="gloo"),
+                        "1", "--no-cpu-baseline", "--dense-only", "--no-roofline-pass"], env=_env(UGN_DIST_BACKEND=_backend()),
                        capture_output=True, text=True, timeout=800)
     assert r.returncode == 0, r.stderr[-3000:]
     d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])

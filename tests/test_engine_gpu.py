@@ -419,6 +419,7 @@ def test_branch_gradients_with_the_hip_paths_routing(dev, prec, bar, bar_med):
     assert max(worst.values()) <= bar and med <= bar_med, worst
 
 
+@pytest.mark.h2
 def test_fused_first_layer_weight_gradient(dev):
     """UGN_FUSE_W5=1 (Settings.fuse_w5): the data gradient of the pooled 32 -> 32 layer fused with the 5x5 layer's weight gradient
     (ugn_mm_dgrad32_wgrad5_multi) gives the first layer the gradient the two separate launches give it."""

@@ -39,7 +39,9 @@ def test_signatures_for_all_seven_modality_combinations_and_knn(dev):
         r = O.model_forward([x.astype(np.float64) for x in xs], us, p64, mode="sign_max")
         err = float(np.abs(codes[c] - r["flat"]).max())
         worst = max(worst, err)
-        assert err <= 2e-5, (c, err)              # (unit-norm columns over the batch: the tensor's scale is <= 1)
+        # north_star: signatures within 1e-3.  Measured over the seven combinations on the default fp32-tensor path: 1e-5 ... 3.3e-5 (the
+        # batch-axis normalisation over eight clips amplifies a small column's rounding; the golden fixtures measure 3.6e-5): bar 1e-4
+        assert err <= 1e-4, (c, err)
         # the selected modality of every element is the oracle's, except where two candidates tie to fp32 rounding
         sel = model.core.sel.cpu().numpy()
         diff = sel != r["sel"]

@@ -204,7 +204,10 @@ def test_six_products_against_all_nine(dev, hw, cin, cout, pool):
         d69 = err_of(res[6][k], res[9][k].cpu().numpy().astype(np.float64))
         print("%s %d->%d @%d: error against fp64 with six products %.2e, with nine %.2e; six against nine %.2e" % (name, cin, cout, hw, e6, e9, d69))
         assert e6 <= 1.15 * e9 + 2e-8, (name, e6, e9)          # dropping the three smallest products costs nothing measurable ...
-        assert d69 <= max(e6, e9) + 2e-8, (name, d69, e6, e9)           # ... and the two results are no further apart than either is from fp64
+        # ... and the two results are about as far apart as either is from fp64 (two results with INDEPENDENT rounding, each e from the
+        # truth, lie up to 2 e apart; since round 6 the weight gradients' slabs are added segment-wise -- a third of the error of the
+        # former one-chain sum, 1.4e-7 instead of 3.5e-7 at 32->64 -- and what is left is exactly such independent rounding)
+        assert d69 <= 1.5 * max(e6, e9) + 2e-8, (name, d69, e6, e9)
 
 
 def test_x3_results_do_not_depend_on_the_persistent_grid(dev):
@@ -235,7 +238,8 @@ def test_x3_results_do_not_depend_on_the_persistent_grid(dev):
 
 
 def test_x3_split_is_exact_and_full_range(dev):
-    """The three-way split loses nothing (x0 + x1 + x2 == x bit for bit) over fp32's whole normal range -- no block exponent, no
+    """The three-way split loses nothing (x0 + x1 + x2 == x bit for bit) for 2^-110 <= |x| < 3.396e38 (test_x3_edge_semantics pins what
+    happens outside) -- no block exponent, no
     dependence on the other elements of a tensor: a convolution of one image is the same inside any batch and at any scale."""
     from ugaitnet_amd import x3
     rng = np.random.default_rng(3)
@@ -276,3 +280,40 @@ def test_a_later_core_never_inherits_an_earlier_cores_grid(dev):
         del small, named
     finally:
         ops.set_persistent_wgs(0)
+
+
+def test_x3_edge_semantics(dev):
+    """What the x3 arithmetic does OUTSIDE the range where its split is exact, pinned beside the library's direct fp32-MFMA kernel on
+    the same tensors (measured by tools/x3_edges.py, stated in INTEGRATION.md "Known differences"):
+      * exact split, results bit-identical to the fp32 kernel: 2^-110 <= |x| < 3.3961775e38 (0x7f7f8000, where bf16(x) rounds to inf);
+      * |x| >= 3.3961775e38, +-inf: the first plane is inf, the residual inf - inf = NaN -- the output is NaN where an fp32
+        convolution gives a finite value or +-inf (and, like an fp32 convolution's inf * 0, NaN reaches the neighbouring outputs);
+        NaN stays NaN;
+      * |x| < 2^-110 (operands whose planes would be bf16-subnormal below 2^-133): the bits of x below 2^-133 are dropped -- an
+        ABSOLUTE error of at most 2^-133 per operand (relative 2^-23 at 2^-112, 2^-8 at 2^-126; fp32 subnormals below 2^-133 become 0).
+        bf16-subnormal PLANES themselves are multiplied exactly (the matrix pipe does not flush them)."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import x3_edges
+    rows = {r["name"]: r for r in x3_edges.run(dev)}
+    for name in ("+inf", "-inf", "nan", "flt_max", "-flt_max", "tie_to_inf", "w = inf", "w = flt_max"):
+        r = rows[name]
+        assert np.isnan(r["x3"]), (name, r["x3"])
+        want = r["want"]
+        assert (np.isnan(want) and np.isnan(r["direct"])) or r["direct"] == np.float32(want), (name, r["direct"], want)
+    for name in ("bf16_max", "below_tie_to_inf", "3.0e38", "1.0", "2^-100*(1+2^-23+2^-9)", "2^-105*(1+2^-23+2^-9)", "2^-110*(1+2^-23+2^-9)",
+                 "tiny product 2^-70*2^-70"):
+        r = rows[name]
+        assert r["split_exact_x"] and r["split_exact_w"], name
+        assert r["x3"] == r["direct"] == float(np.float32(r["want"])), (name, r["x3"], r["direct"], r["want"])
+        assert r["x3_elsewhere_clean"] and r["direct_elsewhere_clean"], name
+    tiny = 2.0 ** -133
+    for name in ("2^-112*(1+2^-23+2^-9)", "2^-116*(1+2^-23+2^-9)", "2^-120*(1+2^-23+2^-9)", "2^-124*(1+2^-23+2^-9)", "2^-126*(1+2^-23+2^-9)",
+                 "subnormal 2^-130", "subnormal 2^-149"):
+        r = rows[name]
+        assert r["direct"] == float(np.float32(r["want"])), name                  # the fp32 kernel keeps every bit, subnormals included
+        assert abs(r["x3"] - r["want"]) <= tiny, (name, r["x3"], r["want"])       # x3: what lies below 2^-133 is dropped, nothing more
+        assert r["x3_elsewhere_clean"], name
+    assert rows["subnormal 2^-130"]["x3"] == rows["subnormal 2^-130"]["want"]      # a bf16-subnormal plane is multiplied exactly
+    assert rows["2^-112*(1+2^-23+2^-9)"]["x3"] != rows["2^-112*(1+2^-23+2^-9)"]["want"]     # (the loss is real: pinned, not hidden)

@@ -33,7 +33,7 @@ def probes():
     return out
 
 
-def run(dev=None, hw=16, cin=32, cout=64):
+def run(dev=None, hw=16, cin=64, cout=128):
     from ugaitnet_amd import ops, x3
     dev = dev or torch.device("cuda:0")
     rows = []

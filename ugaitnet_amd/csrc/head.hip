@@ -29,7 +29,8 @@ struct FcJobs {
   int b[kFcJobs];
 };
 __global__ __launch_bounds__(256) void binfc_fwd_kernel(const FcJobs jt) {
-  __shared__ float sF[FC_BT][FEAT];          // 12 KB
+  __shared__ __attribute__((aligned(16))) float sFt[FEAT][FC_BT];          // 12 KB, [input feature][sample]: 24 samples = six 16-byte reads
+  static_assert(FC_BT % 4 == 0, "16-byte LDS reads");
   __shared__ float sR[3][FC_BT][64];         // partials of input quarters 1..3
   const float* __restrict__ feat = jt.feat[blockIdx.z];
   const float* __restrict__ w = jt.w[blockIdx.z];
@@ -41,7 +42,7 @@ __global__ __launch_bounds__(256) void binfc_fwd_kernel(const FcJobs jt) {
     __syncthreads();
     for (int e = threadIdx.x; e < FC_BT * FEAT; e += 256) {
       const int bb = e / FEAT, i = e % FEAT;
-      sF[bb][i] = b0 + bb < bsz ? feat[((size_t)k * bsz + b0 + bb) * FEAT + i] : 0.f;
+      sFt[i][bb] = b0 + bb < bsz ? feat[((size_t)k * bsz + b0 + bb) * FEAT + i] : 0.f;
     }
     __syncthreads();
     float acc[FC_BT];
@@ -51,7 +52,13 @@ __global__ __launch_bounds__(256) void binfc_fwd_kernel(const FcJobs jt) {
     for (int i = 0; i < 32; ++i) {
       const float wv = wk[(size_t)i * HID];
 #pragma unroll
-      for (int bb = 0; bb < FC_BT; ++bb) acc[bb] = fmaf(sF[bb][iq * 32 + i], wv, acc[bb]);
+      for (int b4 = 0; b4 < FC_BT / 4; ++b4) {
+        const float4 fv = *reinterpret_cast<const float4*>(&sFt[iq * 32 + i][4 * b4]);
+        acc[4 * b4] = fmaf(fv.x, wv, acc[4 * b4]);
+        acc[4 * b4 + 1] = fmaf(fv.y, wv, acc[4 * b4 + 1]);
+        acc[4 * b4 + 2] = fmaf(fv.z, wv, acc[4 * b4 + 2]);
+        acc[4 * b4 + 3] = fmaf(fv.w, wv, acc[4 * b4 + 3]);
+      }
     }
     if (iq > 0) {
 #pragma unroll
@@ -82,9 +89,13 @@ __global__ __launch_bounds__(256) void binfc_bwd_kernel(const FcJobs jt) {
   float* __restrict__ dw = jt.out[blockIdx.z];
   float* __restrict__ dfeat = jt.dfeat[blockIdx.z];
   const int bsz = jt.b[blockIdx.z];
-  __shared__ float sF[FCB_BT][FCB_IQ];      // 2 KB
-  __shared__ float sD[FCB_BT][HID];         // 16 KB
-  __shared__ float sW[FCB_IQ][HID + 1];     // 32.9 KB: this workgroup's slice of W[k]
+  // (round 6: the same sums in the same order, read with 16-byte LDS instructions -- the feature slice transposed to [i][sample] so that
+  //  a thread's 24 samples of an input feature are six ds_read_b128 instead of 24 ds_read_b32, the gradient rows four outputs at a time:
+  //  2.5x fewer LDS instructions in a kernel that was bound by issuing them)
+  __shared__ __attribute__((aligned(16))) float sFt[FCB_IQ][FCB_BT];      // 3 KB, [input feature][sample]
+  __shared__ __attribute__((aligned(16))) float sD[FCB_BT][HID];          // 24 KB
+  __shared__ float sW[FCB_IQ][HID + 1];                                   // 32.9 KB: this workgroup's slice of W[k]
+  static_assert(FCB_BT % 4 == 0 && HID % 4 == 0, "16-byte LDS reads");
   const int k = blockIdx.x, i0 = blockIdx.y * FCB_IQ, tid = threadIdx.x;
   const float* wk = w + ((size_t)k * FEAT + i0) * HID;
   float* dwk = dw + ((size_t)k * FEAT + i0) * HID;
@@ -96,7 +107,7 @@ __global__ __launch_bounds__(256) void binfc_bwd_kernel(const FcJobs jt) {
     if (PARTS & 1)
       for (int e = tid; e < FCB_BT * FCB_IQ; e += 256) {
         const int bb = e / FCB_IQ, i = e % FCB_IQ;
-        sF[bb][i] = bb < nb ? feat[((size_t)k * bsz + b0 + bb) * FEAT + i0 + i] : 0.f;
+        sFt[i][bb] = bb < nb ? feat[((size_t)k * bsz + b0 + bb) * FEAT + i0 + i] : 0.f;
       }
     for (int e = tid; e < FCB_BT * HID; e += 256) {
       const int bb = e / HID, o = e % HID;
@@ -111,7 +122,13 @@ __global__ __launch_bounds__(256) void binfc_bwd_kernel(const FcJobs jt) {
       for (int i = 0; i < FCB_IQ; ++i) {
         float acc = 0.f;
 #pragma unroll
-        for (int bb = 0; bb < FCB_BT; ++bb) acc = fmaf(sF[bb][i], dreg[bb], acc);
+        for (int b4 = 0; b4 < FCB_BT / 4; ++b4) {
+          const float4 f = *reinterpret_cast<const float4*>(&sFt[i][4 * b4]);
+          acc = fmaf(f.x, dreg[4 * b4], acc);
+          acc = fmaf(f.y, dreg[4 * b4 + 1], acc);
+          acc = fmaf(f.z, dreg[4 * b4 + 2], acc);
+          acc = fmaf(f.w, dreg[4 * b4 + 3], acc);
+        }
         if (b0 == 0) dwk[(size_t)i * HID + tid] = acc;
         else dwk[(size_t)i * HID + tid] += acc;
       }
@@ -119,12 +136,16 @@ __global__ __launch_bounds__(256) void binfc_bwd_kernel(const FcJobs jt) {
     if (PARTS & 2) {   // dfeat for this slice; thread = (i, sample triple): 32 x 8 threads, 3 samples each
       const int i = tid & 31, bq = tid >> 5;
       float a0 = 0.f, a1 = 0.f, a2 = 0.f;
-#pragma unroll 8
-      for (int o = 0; o < HID; ++o) {
-        const float wv = sW[i][o];
-        a0 = fmaf(sD[3 * bq][o], wv, a0);
-        a1 = fmaf(sD[3 * bq + 1][o], wv, a1);
-        a2 = fmaf(sD[3 * bq + 2][o], wv, a2);
+#pragma unroll 4
+      for (int o = 0; o < HID; o += 4) {
+        const float4 d0 = *reinterpret_cast<const float4*>(&sD[3 * bq][o]);
+        const float4 d1 = *reinterpret_cast<const float4*>(&sD[3 * bq + 1][o]);
+        const float4 d2 = *reinterpret_cast<const float4*>(&sD[3 * bq + 2][o]);
+        const float w0 = sW[i][o], w1 = sW[i][o + 1], w2 = sW[i][o + 2], w3 = sW[i][o + 3];
+        a0 = fmaf(d0.x, w0, a0); a1 = fmaf(d1.x, w0, a1); a2 = fmaf(d2.x, w0, a2);
+        a0 = fmaf(d0.y, w1, a0); a1 = fmaf(d1.y, w1, a1); a2 = fmaf(d2.y, w1, a2);
+        a0 = fmaf(d0.z, w2, a0); a1 = fmaf(d1.z, w2, a1); a2 = fmaf(d2.z, w2, a2);
+        a0 = fmaf(d0.w, w3, a0); a1 = fmaf(d1.w, w3, a1); a2 = fmaf(d2.w, w3, a2);
       }
       if (3 * bq < nb) dfeat[((size_t)k * bsz + b0 + 3 * bq) * FEAT + i0 + i] = a0;
       if (3 * bq + 1 < nb) dfeat[((size_t)k * bsz + b0 + 3 * bq + 1) * FEAT + i0 + i] = a1;
@@ -229,14 +250,15 @@ constexpr int HD_PARTS = NBINS * (HID / HD_DQ);   // 248 partial-logit slabs
 // part[(k*4+q)][b][c] = sum_{d in quarter q} sig[k][b][d] * wc[(k*256+d)*ncls + c]
 __global__ __launch_bounds__(256) void head_partial_kernel(const float* __restrict__ sig, const float* __restrict__ wc,
                                                            float* __restrict__ part, int bsz, int ncls) {
-  __shared__ float sS[HD_BT][HD_DQ];
+  __shared__ __attribute__((aligned(16))) float sSt[HD_DQ][HD_BT];      // [feature][sample]: a feature's 24 samples = six 16-byte reads
+  static_assert(HD_BT % 4 == 0, "16-byte LDS reads");
   const int k = blockIdx.x, q = blockIdx.y, c = threadIdx.x;
   const int d0 = q * HD_DQ;
   for (int b0 = 0; b0 < bsz; b0 += HD_BT) {
     __syncthreads();
     for (int e = threadIdx.x; e < HD_BT * HD_DQ; e += 256) {
       const int bb = e / HD_DQ, d = e % HD_DQ;
-      sS[bb][d] = b0 + bb < bsz ? sig[((size_t)k * bsz + b0 + bb) * HID + d0 + d] : 0.f;
+      sSt[d][bb] = b0 + bb < bsz ? sig[((size_t)k * bsz + b0 + bb) * HID + d0 + d] : 0.f;
     }
     __syncthreads();
     if (c < ncls) {
@@ -247,7 +269,13 @@ __global__ __launch_bounds__(256) void head_partial_kernel(const float* __restri
       for (int d = 0; d < HD_DQ; ++d) {
         const float wv = wc[((size_t)k * HID + d0 + d) * ncls + c];
 #pragma unroll
-        for (int bb = 0; bb < HD_BT; ++bb) acc[bb] = fmaf(sS[bb][d], wv, acc[bb]);
+        for (int b4 = 0; b4 < HD_BT / 4; ++b4) {
+          const float4 sv = *reinterpret_cast<const float4*>(&sSt[d][4 * b4]);
+          acc[4 * b4] = fmaf(sv.x, wv, acc[4 * b4]);
+          acc[4 * b4 + 1] = fmaf(sv.y, wv, acc[4 * b4 + 1]);
+          acc[4 * b4 + 2] = fmaf(sv.z, wv, acc[4 * b4 + 2]);
+          acc[4 * b4 + 3] = fmaf(sv.w, wv, acc[4 * b4 + 3]);
+        }
       }
 #pragma unroll
       for (int bb = 0; bb < HD_BT; ++bb)
@@ -321,8 +349,8 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
                                                        const float* __restrict__ dlogits, float* __restrict__ dwc,
                                                        float* __restrict__ dbc, float* __restrict__ dsig, int accumulate,
                                                        int bsz, int ncls) {
-  __shared__ float sS[HB_BT][HD_DQ];    // 4 KB
-  __shared__ float sL[HB_BT][HID];      // dlogits rows (ncls <= 256), 16 KB
+  __shared__ __attribute__((aligned(16))) float sSt[HD_DQ][HB_BT];    // 6 KB, [feature][sample]
+  __shared__ __attribute__((aligned(16))) float sL[HB_BT][HID];      // dlogits rows (ncls <= 256), 24 KB
   extern __shared__ float sWc[];        // [HD_DQ][ncls + 1]: this workgroup's slice of wc, read coalesced once
   const int k = blockIdx.x, q = blockIdx.y, tid = threadIdx.x;
   const int d0 = q * HD_DQ;
@@ -334,7 +362,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
     __syncthreads();
     for (int e = tid; e < HB_BT * HD_DQ; e += 256) {
       const int bb = e / HD_DQ, d = e % HD_DQ;
-      sS[bb][d] = bb < nb ? sig[((size_t)k * bsz + b0 + bb) * HID + d0 + d] : 0.f;
+      sSt[d][bb] = bb < nb ? sig[((size_t)k * bsz + b0 + bb) * HID + d0 + d] : 0.f;
     }
     for (int e = tid; e < HB_BT * HID; e += 256) {
       const int bb = e / HID, c = e % HID;
@@ -349,7 +377,13 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
       for (int d = 0; d < HD_DQ; ++d) {
         float acc = 0.f;
 #pragma unroll
-        for (int bb = 0; bb < HB_BT; ++bb) acc = fmaf(sS[bb][d], lreg[bb], acc);
+        for (int b4 = 0; b4 < HB_BT / 4; ++b4) {
+          const float4 sv = *reinterpret_cast<const float4*>(&sSt[d][4 * b4]);
+          acc = fmaf(sv.x, lreg[4 * b4], acc);
+          acc = fmaf(sv.y, lreg[4 * b4 + 1], acc);
+          acc = fmaf(sv.z, lreg[4 * b4 + 2], acc);
+          acc = fmaf(sv.w, lreg[4 * b4 + 3], acc);
+        }
         const size_t o = ((size_t)k * HID + d0 + d) * ncls + tid;
         if (b0 == 0) dwc[o] = acc; else dwc[o] += acc;
       }
@@ -358,7 +392,19 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
       const int d = tid & 63, bq = tid >> 6;
       float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
       const float* wrow = sWc + d * ldw;
-      for (int c = 0; c < ncls; ++c) {
+      int c = 0;
+      for (; c + 4 <= ncls; c += 4) {          // (the same sums in the same order: the dlogits rows read 16 bytes at a time)
+        const float w0 = wrow[c], w1 = wrow[c + 1], w2 = wrow[c + 2], w3 = wrow[c + 3];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+          const float4 lv = *reinterpret_cast<const float4*>(&sL[6 * bq + j][c]);
+          acc[j] = fmaf(lv.x, w0, acc[j]);
+          acc[j] = fmaf(lv.y, w1, acc[j]);
+          acc[j] = fmaf(lv.z, w2, acc[j]);
+          acc[j] = fmaf(lv.w, w3, acc[j]);
+        }
+      }
+      for (; c < ncls; ++c) {
         const float wv = wrow[c];
 #pragma unroll
         for (int j = 0; j < 6; ++j) acc[j] = fmaf(sL[6 * bq + j][c], wv, acc[j]);

@@ -24,6 +24,7 @@
 
 using namespace ugn_x3;
 
+
 namespace {
 
 typedef short s4 __attribute__((ext_vector_type(4)));
@@ -527,18 +528,37 @@ struct WgFinish {
   float* dw[kMaxJobs];
   int ng[kMaxJobs];
 };
-// dW[tap][ci][co] (HWIO) = sum over the job's groups, in order.  One thread per element; blockIdx.y = job.
-__global__ __launch_bounds__(256) void wgrad_x3_finish(const WgFinish ft, int CI, int CO, int COW) {
+// dW[tap][ci][co] (HWIO) = sum over the job's groups in a FIXED order (bitwise reproducible): the groups are cut into kFinSeg
+// contiguous segments, a thread adds one segment's slabs in group order, the segment sums are added in segment order through LDS.
+// (Round 6.  One thread per element walking all of a job's up to 256 slabs was a chain of 256 dependent 4-byte reads on 36-576
+//  workgroups: 14 us per launch, five launches per step; 32 elements x 8 segments per workgroup read the same bytes on 8x the
+//  workgroups with 8x shorter chains.)
+constexpr int kFinSeg = 8, kFinEl = 32;
+__global__ __launch_bounds__(kFinSeg * kFinEl) void wgrad_x3_finish(const WgFinish ft, int CI, int CO, int COW) {
+  __shared__ float part[kFinSeg][kFinEl];
   const int j = blockIdx.y;
-  const int e = blockIdx.x * 256 + threadIdx.x;
-  if (e >= 9 * CI * CO) return;
-  const int co = e % CO, ci = (e / CO) % CI, tap = e / (CO * CI);
-  const int ncoc = CO / COW, combo = (ci >> 5) * ncoc + co / COW;
-  const int ng = ft.ng[j];
-  const float* sl = ft.slab[j] + (size_t)combo * ng * (9 * 32 * COW) + (tap * 32 + (ci & 31)) * COW + (co % COW);
+  const int el = threadIdx.x % kFinEl, seg = threadIdx.x / kFinEl;
+  const int e = blockIdx.x * kFinEl + el;
+  const bool ok = e < 9 * CI * CO;
   float sum = 0.f;
-  for (int g = 0; g < ng; ++g) sum += sl[(size_t)g * (9 * 32 * COW)];
-  ft.dw[j][e] = sum;
+  if (ok) {
+    const int co = e % CO, ci = (e / CO) % CI, tap = e / (CO * CI);
+    const int ncoc = CO / COW, combo = (ci >> 5) * ncoc + co / COW;
+    const int ng = ft.ng[j];
+    const size_t stride = (size_t)9 * 32 * COW;
+    const float* sl = ft.slab[j] + (size_t)combo * ng * stride + (tap * 32 + (ci & 31)) * COW + (co % COW);
+    const int g0 = seg * ng / kFinSeg, g1 = (seg + 1) * ng / kFinSeg;
+#pragma unroll 4
+    for (int g = g0; g < g1; ++g) sum += sl[(size_t)g * stride];
+  }
+  part[seg][el] = sum;
+  __syncthreads();
+  if (seg == 0 && ok) {
+    float t = part[0][el];
+#pragma unroll
+    for (int k = 1; k < kFinSeg; ++k) t += part[k][el];
+    ft.dw[j][e] = t;
+  }
 }
 
 #ifndef UGN_X3_SPARSE
@@ -613,7 +633,7 @@ int launch_wgrad_np(const float* const* in, const float* const* dz, const uint8_
   }
   hipLaunchKernelGGL(kern, dim3(NG * NCOMBO), dim3(512), G::LDS, st, jt);
   UGN_CHECK_LAUNCH("wgrad_x3");
-  hipLaunchKernelGGL(wgrad_x3_finish, dim3((9 * CI * CO + 255) / 256, njobs), dim3(256), 0, st, ft, CI, CO, G::COW);
+  hipLaunchKernelGGL(wgrad_x3_finish, dim3((9 * CI * CO + kFinEl - 1) / kFinEl, njobs), dim3(kFinSeg * kFinEl), 0, st, ft, CI, CO, G::COW);
   UGN_CHECK_LAUNCH("wgrad_x3 finish");
   return 0;
 }
