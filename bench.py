@@ -93,7 +93,12 @@ def cpu_baseline(kinds, ncls, clips, n_ids, seconds_budget=30.0, multimodal=True
     import torch
     from oracle import torch_ref as T
     from oracle import ugaitnet_oracle as O
+    from tests.cpu_share import usable_cores
     from tests.synth import make_batch
+    # the cores this process may REALLY use (scheduler affinity and the container's CPU quota, not the machine's logical CPUs: a GPU
+    # box reports 128 and grants 16): the thread pool is sized to them and `cores` reports them
+    cores = usable_cores()
+    torch.set_num_threads(cores)
     rng = np.random.default_rng(0)
     params = dict(branches=[O.init_branch_params(rng, 2 if k == "of" else 1) for k in kinds],
                   head=O.init_head_params(rng, ncls))
@@ -112,7 +117,7 @@ def cpu_baseline(kinds, ncls, clips, n_ids, seconds_budget=30.0, multimodal=True
         tr.step(*batch)
         times.append(time.perf_counter() - t0)
     med = float(np.median(times))
-    return dict(value=clips / med, unit="clips/s", cores=int(torch.get_num_threads()), kind="port",
+    return dict(value=clips / med, unit="clips/s", cores=int(cores), logical_cpus_of_the_machine=int(os.cpu_count() or 0), kind="port",
                 sample="%d whole step(s) of the same %d-clip batch (%d modalit%s, L=25) after a 4-clip warm-up, median; "
                        "torch-CPU (oneDNN) restatement oracle/torch_ref.py, fwd+bwd+Adam; the TF-2.3 reference cannot run here"
                        % (len(times), clips, len(kinds), "ies, masks" if multimodal else "y"))
@@ -225,9 +230,17 @@ def roofline_pass(core, batch, steps, dtype, table_path="", step_ms=None):
         torch.cuda.synchronize()
         step_ms = max(e0.elapsed_time(e1), 0.05) if step_ms is None else step_ms
         # the gate of one profiled step: a spin kernel that covers the host's queueing of everything behind it, then `warm` plain steps
-        # (>= 15 ms of the real workload: behind 5-10 ms of a near-idle spin the chip's clocks are not those of the timed region -- the
-        # first gated build of this pass measured every convolution 15-25 % slower than the step's own kernels), then the profiled step
-        warm = max(2, int(np.ceil(15.0 / step_ms)))
+        # (>= 50 ms of the real workload: behind 5-10 ms of a near-idle spin the chip's clocks are not those of the timed region -- the
+        # first gated build of this pass measured every convolution 15-25 % slower than the step's own kernels, with 16 ms of plain steps
+        # in between still 3-6 % slower than rocprofv3's back-to-back run of the same kernels), then the profiled step
+        warm = max(2, int(np.ceil(50.0 / step_ms)))
+        import torch.distributed as _dist
+        if _dist.is_available() and _dist.is_initialized() and _dist.get_world_size() > 1:
+            # every step carries the gradient all-reduce: all ranks must run the SAME number of steps in this pass (a rank's own
+            # timing must not decide it)
+            wt = torch.tensor([warm], device=dev, dtype=torch.int32)
+            _dist.all_reduce(wt, op=_dist.ReduceOp.MAX)
+            warm = int(wt.item())
         spin_ms = min(1.5 * (warm * host_plain_ms + host_ms) + 2.0, 400.0)
         gate_cycles = int(spin_ms * 1e-3 * 2.4e9)      # (spin cycles at <= 2.4 GHz)
         _lib.WORK, _lib.ORDER = {}, []
@@ -345,7 +358,7 @@ def roofline_pass(core, batch, steps, dtype, table_path="", step_ms=None):
         roof["stalled_launch_records"] = dropped[:16]
     roof["gate"] = dict(host_ms_per_profiled_step=round(host_ms, 2), host_ms_per_plain_step=round(host_plain_ms, 2),
                         spin_ms=round(gate_cycles / 2.4e6, 2), warm_steps_behind_the_spin=warm,
-                        why="every profiled step is queued behind a spin kernel (covers the host's queueing) and >= 15 ms of plain steps "
+                        why="every profiled step is queued behind a spin kernel (covers the host's queueing) and >= 50 ms of plain steps "
                             "(the chip's clocks are those of the timed region), so no event pair contains host time")
     roof["other_kernels"] = [describe(r) for r in rows[1:10]]
     return roof

@@ -48,6 +48,17 @@ def pytest_collection_modifyitems(config, items):
             item.add_marker(skip)
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _host_threads():
+    """torch's CPU thread pool sized to the cores this process may really use (tests/cpu_share.py), minus what the full-size oracle
+    child takes while it runs: the numpy / torch-CPU oracles of the tests otherwise start one thread per LOGICAL CPU of the machine."""
+    import torch
+    from tests.cpu_share import usable_cores
+    n = usable_cores()
+    torch.set_num_threads(max(2, n if n <= 8 else n // 2))
+    yield
+
+
 @pytest.fixture(scope="session")
 def dev():
     import torch

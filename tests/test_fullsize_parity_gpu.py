@@ -111,8 +111,11 @@ class _Prefetch:
             self.dir = tempfile.mkdtemp(prefix="ugn_oracle_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
         except OSError:         # (/dev/shm not writable: the default temporary directory)
             self.dir = tempfile.mkdtemp(prefix="ugn_oracle_")
+        from tests.cpu_share import usable_cores
+        # (half of the cores this session may really use -- a container's share, not the machine's logical CPUs; the other half stays
+        #  with the foreground tests' own CPU oracles and the forced-routing thread)
         env = dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="",
-                   OMP_NUM_THREADS=str(max(8, (os.cpu_count() or 16) // 4)))
+                   OMP_NUM_THREADS=str(max(2, usable_cores() // 2)), MKL_NUM_THREADS=str(max(2, usable_cores() // 2)))
         self.proc = subprocess.Popen([sys.executable, "-m", "tests.test_fullsize_parity_gpu", self.dir] + self.wanted,
                                      cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), env=env)
         atexit.register(self.close)

@@ -29,8 +29,7 @@ struct FcJobs {
   int b[kFcJobs];
 };
 __global__ __launch_bounds__(256) void binfc_fwd_kernel(const FcJobs jt) {
-  __shared__ __attribute__((aligned(16))) float sFt[FEAT][FC_BT];          // 12 KB, [input feature][sample]: 24 samples = six 16-byte reads
-  static_assert(FC_BT % 4 == 0, "16-byte LDS reads");
+  __shared__ float sF[FC_BT][FEAT];          // 12 KB
   __shared__ float sR[3][FC_BT][64];         // partials of input quarters 1..3
   const float* __restrict__ feat = jt.feat[blockIdx.z];
   const float* __restrict__ w = jt.w[blockIdx.z];
@@ -42,7 +41,7 @@ __global__ __launch_bounds__(256) void binfc_fwd_kernel(const FcJobs jt) {
     __syncthreads();
     for (int e = threadIdx.x; e < FC_BT * FEAT; e += 256) {
       const int bb = e / FEAT, i = e % FEAT;
-      sFt[i][bb] = b0 + bb < bsz ? feat[((size_t)k * bsz + b0 + bb) * FEAT + i] : 0.f;
+      sF[bb][i] = b0 + bb < bsz ? feat[((size_t)k * bsz + b0 + bb) * FEAT + i] : 0.f;
     }
     __syncthreads();
     float acc[FC_BT];
@@ -52,13 +51,7 @@ __global__ __launch_bounds__(256) void binfc_fwd_kernel(const FcJobs jt) {
     for (int i = 0; i < 32; ++i) {
       const float wv = wk[(size_t)i * HID];
 #pragma unroll
-      for (int b4 = 0; b4 < FC_BT / 4; ++b4) {
-        const float4 fv = *reinterpret_cast<const float4*>(&sFt[iq * 32 + i][4 * b4]);
-        acc[4 * b4] = fmaf(fv.x, wv, acc[4 * b4]);
-        acc[4 * b4 + 1] = fmaf(fv.y, wv, acc[4 * b4 + 1]);
-        acc[4 * b4 + 2] = fmaf(fv.z, wv, acc[4 * b4 + 2]);
-        acc[4 * b4 + 3] = fmaf(fv.w, wv, acc[4 * b4 + 3]);
-      }
+      for (int bb = 0; bb < FC_BT; ++bb) acc[bb] = fmaf(sF[bb][iq * 32 + i], wv, acc[bb]);
     }
     if (iq > 0) {
 #pragma unroll
@@ -250,18 +243,19 @@ constexpr int HD_PARTS = NBINS * (HID / HD_DQ);   // 248 partial-logit slabs
 // part[(k*4+q)][b][c] = sum_{d in quarter q} sig[k][b][d] * wc[(k*256+d)*ncls + c]
 __global__ __launch_bounds__(256) void head_partial_kernel(const float* __restrict__ sig, const float* __restrict__ wc,
                                                            float* __restrict__ part, int bsz, int ncls) {
-  __shared__ __attribute__((aligned(16))) float sSt[HD_DQ][HD_BT];      // [feature][sample]: a feature's 24 samples = six 16-byte reads
-  static_assert(HD_BT % 4 == 0, "16-byte LDS reads");
+  __shared__ float sS[HD_BT][HD_DQ];
   const int k = blockIdx.x, q = blockIdx.y, c = threadIdx.x;
   const int d0 = q * HD_DQ;
   for (int b0 = 0; b0 < bsz; b0 += HD_BT) {
     __syncthreads();
     for (int e = threadIdx.x; e < HD_BT * HD_DQ; e += 256) {
       const int bb = e / HD_DQ, d = e % HD_DQ;
-      sSt[d][bb] = b0 + bb < bsz ? sig[((size_t)k * bsz + b0 + bb) * HID + d0 + d] : 0.f;
+      sS[bb][d] = b0 + bb < bsz ? sig[((size_t)k * bsz + b0 + bb) * HID + d0 + d] : 0.f;
     }
     __syncthreads();
     if (c < ncls) {
+      // (round 6 tried the 16-byte-read form that helps the backward kernels here and in binfc_fwd: 16 -> 40 us and 17 -> 30 us --
+      //  these two stream their weights from HBM inside the loop, and the wider LDS reads cost them the overlap of those loads)
       float acc[HD_BT];
 #pragma unroll
       for (int bb = 0; bb < HD_BT; ++bb) acc[bb] = 0.f;
@@ -269,13 +263,7 @@ __global__ __launch_bounds__(256) void head_partial_kernel(const float* __restri
       for (int d = 0; d < HD_DQ; ++d) {
         const float wv = wc[((size_t)k * HID + d0 + d) * ncls + c];
 #pragma unroll
-        for (int b4 = 0; b4 < HD_BT / 4; ++b4) {
-          const float4 sv = *reinterpret_cast<const float4*>(&sSt[d][4 * b4]);
-          acc[4 * b4] = fmaf(sv.x, wv, acc[4 * b4]);
-          acc[4 * b4 + 1] = fmaf(sv.y, wv, acc[4 * b4 + 1]);
-          acc[4 * b4 + 2] = fmaf(sv.z, wv, acc[4 * b4 + 2]);
-          acc[4 * b4 + 3] = fmaf(sv.w, wv, acc[4 * b4 + 3]);
-        }
+        for (int bb = 0; bb < HD_BT; ++bb) acc[bb] = fmaf(sS[bb][d], wv, acc[bb]);
       }
 #pragma unroll
       for (int bb = 0; bb < HD_BT; ++bb)
