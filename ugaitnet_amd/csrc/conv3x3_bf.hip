@@ -16,6 +16,9 @@ using namespace ugn_mm;
 #ifndef UGN_BF_XCD
 #define UGN_BF_XCD 1
 #endif
+#ifndef UGN_BF_RESW
+#define UGN_BF_RESW 1      /* 0: the staged filter ring of rounds 1-5 everywhere (A/B) */
+#endif
 
 namespace {
 
@@ -42,7 +45,14 @@ struct BGeo {
   static constexpr int STG_PIECES = (100 * SPP + 63) / 64;
   static constexpr int STG_BYTES = STG_PIECES * 1024;
   static constexpr int HPW = (HPIECES + 3) / 4;                        // halo pieces per fetching wave
-  static constexpr int LDS = W_OFF + 2 * WSTAGE + (IN_POOLED ? STG_BYTES : 0);
+  // RESW (round 6): the job's WHOLE packed filter (all chunks, all taps: 9 * KC * NC * 2 bytes) stays in LDS for as long as the
+  // workgroup works on that job, where it fits beside the two halo buffers.  The layers this covers (32 -> 32, 32 <-> 64 and the
+  // pooled 64 -> 64 data gradient: 18-72 KB of filter) multiply only 6-24 MFMAs per stage and wave, so the per-stage filter DMA with
+  // its wait + barrier was an exposed memory latency three times per tile: the matrix pipe was busy 7 % of a 32 -> 32 item.
+  static constexpr int WALL = NCHUNK * NSTG * WSTAGE;                  // the whole filter
+  static constexpr bool RESW = UGN_BF_RESW && (W_OFF + WALL + (IN_POOLED ? STG_BYTES : 0)) <= 147456;
+  static constexpr int WBYTES = RESW ? WALL : 2 * WSTAGE;
+  static constexpr int LDS = W_OFF + WBYTES + (IN_POOLED ? STG_BYTES : 0);
 };
 
 constexpr int kPackJobs = 64;
@@ -137,6 +147,8 @@ __global__ __launch_bounds__(512, 2) void conv_bf_kernel(const MmJobs jt, const 
   using G = BGeo<KC, NC, IN_POOLED>;
   constexpr int NB = G::NB, TPS = G::TPS, NSTG = G::NSTG, WSTAGE = G::WSTAGE, WPIECES = G::WPIECES, NCHUNK = G::NCHUNK;
   constexpr int KSTEPS = G::KSTEPS, W_OFF = G::W_OFF, HALO_BYTES = G::HALO_BYTES;
+  constexpr bool RESW = G::RESW;
+  constexpr int STG_OFF = W_OFF + G::WBYTES;                 // the pooled staging tile sits behind the filter area
   constexpr int RPX = HW / 16, RPI = RPX * RPX;
   static_assert(!IN_POOLED || NSTG >= 2, "the pooled scatter runs in the last stage of a chunk");
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -171,7 +183,7 @@ __global__ __launch_bounds__(512, 2) void conv_bf_kernel(const MmJobs jt, const 
 #pragma unroll
       for (int j = 0; j < (G::STG_PIECES + 3) / 4; ++j) {
         const int p = rw + 4 * j;
-        if (p < G::STG_PIECES) dma_pooled_piece<G, KC, HW>(vb, ib, zeros, ry0, rx0, chunk, p, lane, sbase + W_OFF + 2 * WSTAGE);
+        if (p < G::STG_PIECES) dma_pooled_piece<G, KC, HW>(vb, ib, zeros, ry0, rx0, chunk, p, lane, sbase + STG_OFF);
       }
     } else {
       const char* vb = img_in(J, img);
@@ -191,16 +203,27 @@ __global__ __launch_bounds__(512, 2) void conv_bf_kernel(const MmJobs jt, const 
     }
   };
 
+  // RESW: every piece of the job's packed filter, by all eight waves (the packed order IS [chunk][stage]: one linear copy)
+  auto load_filter = [&](const uint16_t* wpk) {
+    constexpr int NP = G::WALL / 1024;
+    const char* src = reinterpret_cast<const char*>(wpk);
+#pragma unroll
+    for (int j = 0; j < (NP + 7) / 8; ++j) {
+      const int p = wave + 8 * j;
+      if (p < NP) dma16(src + p * 1024 + lane * 16, sbase + W_OFF + (unsigned)p * 1024u);
+    }
+  };
+  if constexpr (RESW) load_filter(jt.job[jb].wpk);
   if (is_hw) {
 #pragma unroll
     for (int k = 0; k < HSTG; ++k) stage_in(jt.job[jb], lit, 0, sbase, k * HPER);
-  } else {
+  } else if constexpr (!RESW) {
     stage_w(jt.job[jb].wpk, 0, sbase + W_OFF);
   }
   if constexpr (IN_POOLED) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    scatter_pooled<G>(smem + W_OFF + 2 * WSTAGE, smem, tid);
+    scatter_pooled<G>(smem + STG_OFF, smem, tid);
   }
   int hbuf = 0, wbuf = 0;
   bool first_item = true;
@@ -229,10 +252,19 @@ __global__ __launch_bounds__(512, 2) void conv_bf_kernel(const MmJobs jt, const 
       const int a_addr = a_lane + hbuf * HALO_BYTES;
 #pragma unroll
       for (int sg = 0; sg < NSTG; ++sg) {
-        if (!(sg == 0 && chunk == 0 && !first_item)) {
-          if (!is_hw || sg == 0 || (IN_POOLED && sg == NSTG - 1)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if constexpr (RESW) {
+          // resident filter: ONE barrier per chunk (its halo tile has landed; nobody reads the other buffer any more) + for a pooled
+          // input the one before the scatter of the next tile's staging records
+          if (sg == 0 || (IN_POOLED && sg == NSTG - 1)) {
+            if (!(sg == 0 && chunk == 0 && !first_item)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+          }
+        } else {
+          if (!(sg == 0 && chunk == 0 && !first_item)) {
+            if (!is_hw || sg == 0 || (IN_POOLED && sg == NSTG - 1)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          }
+          __syncthreads();
         }
-        __syncthreads();
         if constexpr (ACTPF) {
           if (sg == NSTG - 1 && last_chunk) {
             const char* act = reinterpret_cast<const char*>(jt.job[jb].act) + (size_t)img * HW * HW * NC * 2;
@@ -246,19 +278,19 @@ __global__ __launch_bounds__(512, 2) void conv_bf_kernel(const MmJobs jt, const 
               }
           }
         }
-        if (!is_hw) {
+        if (!is_hw && !RESW) {
           if (sg + 1 < NSTG) {
             stage_w(jt.job[jb].wpk, chunk * NSTG + sg + 1, sbase + W_OFF + (unsigned)(wbuf ^ 1) * WSTAGE);
           } else if (next_tile) {
             stage_w(jt.job[nx_job].wpk, n_chunk * NSTG, sbase + W_OFF + (unsigned)(wbuf ^ 1) * WSTAGE);
           }
-        } else if (next_tile) {
+        } else if (is_hw && next_tile) {
           if (IN_POOLED ? sg == 0 : sg < HSTG) stage_in(jt.job[nx_job], n_lit, n_chunk, sbase + (unsigned)(hbuf ^ 1) * HALO_BYTES, sg * HPER);
         }
         if constexpr (IN_POOLED) {
-          if (sg == NSTG - 1 && next_tile) scatter_pooled<G>(smem + W_OFF + 2 * WSTAGE, smem + (hbuf ^ 1) * HALO_BYTES, tid);
+          if (sg == NSTG - 1 && next_tile) scatter_pooled<G>(smem + STG_OFF, smem + (hbuf ^ 1) * HALO_BYTES, tid);
         }
-        const int b_addr = b_lane + wbuf * WSTAGE;
+        const int b_addr = b_lane + (RESW ? (chunk * NSTG + sg) * WSTAGE : wbuf * WSTAGE);
 #pragma unroll
         for (int t = 0; t < TPS; ++t) {
           const int tap = sg * TPS + t, dy = tap / 3, dx = tap % 3;
@@ -275,6 +307,12 @@ __global__ __launch_bounds__(512, 2) void conv_bf_kernel(const MmJobs jt, const 
         wbuf ^= 1;
       }
       hbuf ^= 1;
+    }
+    if constexpr (RESW) {
+      if (more && jn != jb) {        // the next item belongs to another job (another modality's filter): everybody has left the matrix loop
+        __syncthreads();
+        load_filter(jt.job[jn].wpk);
+      }
     }
     if (more) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     first_item = false;

@@ -33,9 +33,6 @@ constexpr int X3_UNITS = 18 * 18 * 4;      // staging units: (halo pixel, 8-chan
 __host__ __device__ constexpr int x3_slot(int kg, int col) { return kg ^ (((col >> 2) & 1) << 1); }
 
 // timing-only ablations (WRONG results): 1 no MFMA, 2 no split / LDS writes of the next tile, 4 no epilogue, 8 no tile loads, 16 no barrier
-#ifndef UGN_X3_PRIO
-#define UGN_X3_PRIO 0       /* > 0 (experiment): s_setprio level of a wave's vector-only phases (epilogue, split + LDS writes of the 4-wave form) */
-#endif
 #ifndef UGN_X3_ABL
 #define UGN_X3_ABL 0
 #endif
@@ -382,9 +379,6 @@ __global__ __launch_bounds__(FORM == 1 ? 256 : 512, FORM == 2 ? 4 : 2) void conv
 #if !(UGN_X3_ABL & 16)
       __syncthreads();                                      // the chunk's tile is complete (8 waves: nobody reads the other buffer any more)
 #endif
-#if UGN_X3_PRIO
-      __builtin_amdgcn_s_setprio(0);                        // matrix phase: normal priority (see the epilogue)
-#endif
       if (chunk == 0) X3_STAMP(1);
 #pragma unroll
       for (int dx = 0; dx < 3; ++dx) {
@@ -468,20 +462,12 @@ __global__ __launch_bounds__(FORM == 1 ? 256 : 512, FORM == 2 ? 4 : 2) void conv
         // workgroup of the CU multiplies meanwhile; no staging register lives through the MFMA loop).  Behind the LAST chunk the
         // fetch is issued before the epilogue and the split follows it.
         __syncthreads();
-#if UGN_X3_PRIO
-        // everything up to the next matrix phase is vector / memory work: it takes the issue slots it needs AHEAD of the SIMD's other wave,
-        // which is in ITS matrix phase and loses at most the tail of one 16-cycle MFMA slot per vector instruction issued here
-        __builtin_amdgcn_s_setprio(UGN_X3_PRIO);
-#endif
         if (!last_chunk) tile_fetch_write(t1);
       }
     }
     // (forms 1: the next item's first tile is fetched before the epilogue and split behind it; form 2 -- 128 registers -- fetches it
     //  behind the epilogue, whose latency the CU's other waves cover)
     X3_STAMP(2);
-#if UGN_X3_PRIO
-    if constexpr (DB) __builtin_amdgcn_s_setprio(UGN_X3_PRIO);      // 8 waves: the epilogue beside the partner wave's last MFMAs / next tile
-#endif
     constexpr bool PRE = !DB && SROUND == NSLOT && FORM != 2;
     if constexpr (PRE) {
       if (more) tile_load(Tl{next_item, 0});
