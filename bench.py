@@ -209,9 +209,8 @@ def roofline_pass(core, batch, steps, dtype, table_path="", step_ms=None):
     # "stalled launch" was (test_roofline_object[f32], 8 clips per GPU: frac 0.0091 = one ~50-us Winograd launch measured at ~60x), a
     # measurement bug, not a device stall.  Round 6: every profiled step is queued BEHIND A GATE -- a spin kernel (torch.cuda._sleep)
     # long enough for the host to queue everything behind it, then plain steps of the same workload (the clocks of the timed region) --
-    # so all pairs are device-side back-to-back stamps.  The filter stays as a
-    # second line of defence, and what it drops is recorded (label, position, duration, the label queued before it, whether it was that
-    # label's first launch of the pass) instead of counted.
+    # so all pairs are device-side back-to-back stamps.  The filter stays as a second line of defence, and what it drops is recorded
+    # (label, position, duration, the label queued before it, whether it was that label's first launch of the pass) instead of counted.
     host_ms, host_plain_ms, gate_cycles, warm = 0.0, 0.0, 0, 0
     with core.serial_launches():
         core.train_step(*batch)            # un-timed: first step on the one-stream schedule
@@ -221,31 +220,31 @@ def roofline_pass(core, batch, steps, dtype, table_path="", step_ms=None):
         host_plain_ms = (time.perf_counter() - t0) * 1e3
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         torch.cuda.synchronize()
-        _lib.PROFILE, _lib.WORK = {}, {}
-        e0.record()
-        t0 = time.perf_counter()
-        core.train_step(*batch)            # ... and WITH them (un-timed as well)
-        host_ms = (time.perf_counter() - t0) * 1e3
-        e1.record()
-        torch.cuda.synchronize()
-        step_ms = max(e0.elapsed_time(e1), 0.05) if step_ms is None else step_ms
-        # the gate of one profiled step: a spin kernel that covers the host's queueing of everything behind it, then `warm` plain steps
-        # (>= 50 ms of the real workload: behind 5-10 ms of a near-idle spin the chip's clocks are not those of the timed region -- the
-        # first gated build of this pass measured every convolution 15-25 % slower than the step's own kernels, with 16 ms of plain steps
-        # in between still 3-6 % slower than rocprofv3's back-to-back run of the same kernels), then the profiled step
-        warm = max(2, int(np.ceil(50.0 / step_ms)))
-        import torch.distributed as _dist
-        if _dist.is_available() and _dist.is_initialized() and _dist.get_world_size() > 1:
-            # every step carries the gradient all-reduce: all ranks must run the SAME number of steps in this pass (a rank's own
-            # timing must not decide it)
-            wt = torch.tensor([warm], device=dev, dtype=torch.int32)
-            _dist.all_reduce(wt, op=_dist.ReduceOp.MAX)
-            warm = int(wt.item())
-        spin_ms = min(1.5 * (warm * host_plain_ms + host_ms) + 2.0, 400.0)
-        gate_cycles = int(spin_ms * 1e-3 * 2.4e9)      # (spin cycles at <= 2.4 GHz)
-        _lib.WORK, _lib.ORDER = {}, []
-        prof = {}
+        prof, work, order = {}, {}, []
         try:
+            _lib.PROFILE, _lib.WORK = {}, {}
+            e0.record()
+            t0 = time.perf_counter()
+            core.train_step(*batch)            # ... and WITH them (un-timed as well)
+            host_ms = (time.perf_counter() - t0) * 1e3
+            e1.record()
+            torch.cuda.synchronize()
+            step_ms = max(e0.elapsed_time(e1), 0.05) if step_ms is None else step_ms
+            # the gate of one profiled step: a spin kernel that covers the host's queueing of everything behind it, then `warm` plain
+            # steps (>= 50 ms of the real workload: behind 5-10 ms of a near-idle spin the chip's clocks are not those of the timed region
+            # -- the first gated build of this pass measured every convolution 15-25 % slower than the step's own kernels, with 16 ms of
+            # plain steps in between still 3-6 % slower than rocprofv3's back-to-back run of the same kernels), then the profiled step
+            warm = max(2, int(np.ceil(50.0 / step_ms)))
+            import torch.distributed as _dist
+            if _dist.is_available() and _dist.is_initialized() and _dist.get_world_size() > 1:
+                # every step carries the gradient all-reduce: all ranks must run the SAME number of steps in this pass (a rank's own
+                # timing must not decide it)
+                wt = torch.tensor([warm], device=dev, dtype=torch.int32)
+                _dist.all_reduce(wt, op=_dist.ReduceOp.MAX)
+                warm = int(wt.item())
+            spin_ms = min(1.5 * (warm * host_plain_ms + host_ms) + 2.0, 400.0)
+            gate_cycles = int(spin_ms * 1e-3 * 2.4e9)      # (spin cycles at <= 2.4 GHz)
+            _lib.WORK, _lib.ORDER = work, order
             for _ in range(steps):
                 _lib.PROFILE = None
                 torch.cuda._sleep(gate_cycles)
@@ -255,7 +254,6 @@ def roofline_pass(core, batch, steps, dtype, table_path="", step_ms=None):
                 core.train_step(*batch)
                 _lib.PROFILE = None
                 torch.cuda.synchronize()
-            work, order = _lib.WORK, _lib.ORDER
         finally:
             _lib.PROFILE, _lib.ORDER = None, None
     rows, dropped = [], []
