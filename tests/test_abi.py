@@ -61,6 +61,34 @@ def test_argument_validation_without_gpu():
     assert lib.ugn_conv5x5_in_wgrad_ws(600, 3) == 0
 
 
+def test_persistent_grid_setting_round_trips_without_gpu():
+    """ugn_set_persistent_wgs / ugn_get_persistent_wgs: the library's one process-wide launch setting is plain host state."""
+    from ugaitnet_amd import _lib
+    lib = _lib.load()
+    try:
+        assert lib.ugn_get_persistent_wgs() == 256
+        assert lib.ugn_set_persistent_wgs(224) == 0 and lib.ugn_get_persistent_wgs() == 224
+        assert lib.ugn_set_persistent_wgs(4) == -22 and b"8..256" in lib.ugn_last_error()      # (out of range: refused, unchanged)
+        assert lib.ugn_get_persistent_wgs() == 224
+    finally:
+        assert lib.ugn_set_persistent_wgs(0) == 0 and lib.ugn_get_persistent_wgs() == 256
+
+
+def test_opt_in_f16x2_entry_points_are_declared_apart():
+    """The f16x2 ("H2") set is an opt-in build: its entry points live in include/ugaitnet_hip_h2.h, none of them in the main header,
+    and the default library exports them only when it was built with --h2 (then all of them, bound by ugaitnet_amd._lib)."""
+    from ugaitnet_amd import _lib
+    text = open(os.path.join(ROOT, "include", "ugaitnet_hip_h2.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    h2 = sorted(set(re.findall(r"\b(ugn_[a-z0-9_]+)\s*\(", text)))
+    assert len(h2) >= 20 and sorted(_lib.PROTOTYPES_H2) == h2
+    assert not set(h2) & set(declared_symbols())
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    have = [hasattr(lib, n) for n in h2]
+    assert all(have) or not any(have)
+    assert _lib.has_h2() == all(have)
+
+
 def test_product_package_never_imports_the_oracle():
     pkg = os.path.join(ROOT, "ugaitnet_amd")
     for dp, _, files in os.walk(pkg):
